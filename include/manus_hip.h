@@ -1,0 +1,192 @@
+/* manus_hip.h — C ABI of libmanus_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the one hot path of brown-ivl/manus that this project
+ * accelerates.  Every entry point is `extern "C"`, takes plain device pointers,
+ * sizes and a hipStream_t (passed as void*), and returns 0 or a negative MGR_E*.
+ * No torch types appear here; the Python shims in manus_amd/ bind these with
+ * ctypes, and INTEGRATION.md shows the binding a MANUS maintainer would add.
+ *
+ * Reference interfaces replaced (paths relative to the brown-ivl/manus tree):
+ *   mgr_raster_forward / mgr_raster_backward
+ *       diff_gaussian_rasterization._C.rasterize_gaussians{,_backward}, called by
+ *       GaussianRasterizer at src/utils/gaussian_utils.py:393-416 (installed by
+ *       setup_env.sh:6; colors_precomp + cov3D_precomp variant only — the one
+ *       MANUS uses).
+ *   mgr_knn3_mean_dist2
+ *       simple_knn._C.distCUDA2, src/models/gaussian.py:4,110.
+ *   mgr_skin_weights_fwd/bwd
+ *       skinning_weights_from_voxel_grid, src/utils/gaussian_utils.py:167-196
+ *       (via HandGaussianModel.get_skin_weights, src/models/hand_gaussian.py:65-76).
+ *   mgr_lbs_cov_fwd/bwd
+ *       TrainingModule.forward LBS block, src/modules/hand_dynamic.py:106-127, with
+ *       GaussianModel.get_covariance, src/models/gaussian.py:49-53,84-93 and
+ *       build_rotation/build_scaling_rotation, src/utils/gaussian_utils.py:279-314.
+ *   mgr_sh_color_fwd/bwd
+ *       calculate_colors_from_sh, src/utils/gaussian_utils.py:431-449 with
+ *       eval_sh, src/utils/sh_utils.py:57-104.
+ *   mgr_project_points
+ *       project_points, src/utils/transforms.py:304-311.
+ *
+ * Conventions
+ *   - All pointers are DEVICE pointers unless the name ends in _host.
+ *   - All tensors are dense fp32 / int32, caller-owned; outputs are fully
+ *     written (no zero-initialisation needed) unless stated.
+ *   - "V" = number of camera views batched in one call, "N" = Gaussians.
+ *     Per-Gaussian inputs take a view stride in ELEMENTS (floats); 0 means the
+ *     same array is shared by every view.
+ *   - Cameras: a device array of V records of MGR_CAM_FLOATS floats:
+ *       [0] tanfovx [1] tanfovy [2..17] viewmatrix [18..33] projmatrix
+ *       [34..36] campos [37..39] unused
+ *     with the matrices exactly as MANUS stores them
+ *     (`world_view_transform`, `full_proj_transform`, src/utils/cam_utils.py:58-63:
+ *     row-major storage of the transposed matrix == column-major math matrix,
+ *     element (row r, col c) at [4*c + r]).
+ *   - Launches are asynchronous on `stream`; no hidden streams, no library-owned
+ *     device memory.  The only host synchronisation is in the *_sync helpers.
+ */
+#ifndef MANUS_HIP_H
+#define MANUS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MGR_VERSION 100
+#define MGR_CAM_FLOATS 40
+#define MGR_TILE 16
+#define MGR_MAX_BONES 32
+
+enum {
+    MGR_OK = 0,
+    MGR_EINVAL = -1,   /* bad argument */
+    MGR_ENOMEM = -2,   /* workspace too small (see mgr_raster_workspace_bytes) */
+    MGR_EHIP = -3,     /* a HIP call failed; text in mgr_last_error() */
+    MGR_EOVERFLOW = -4 /* pair capacity exceeded (reported by mgr_raster_status_sync) */
+};
+
+int mgr_version(void);
+/* Thread-local text of the last error returned on this host thread. */
+const char* mgr_last_error(void);
+
+/* ------------------------------------------------------------------------
+ * Rasterizer (tile binning, per-tile depth sort, alpha compositing, backward)
+ * ------------------------------------------------------------------------ */
+
+/* Bytes of workspace needed for V views of N Gaussians at W x H with room for
+ * `pair_capacity` (Gaussian, tile) pairs summed over all views.  The workspace
+ * must be zero-filled once when (re)allocated; afterwards it is opaque state
+ * that links a forward call to its backward call. */
+size_t mgr_raster_workspace_bytes(int V, int N, int W, int H, int64_t pair_capacity);
+
+/* Forward.  out_color: (V,3,H,W).  radii: (V,N) int32.  bg: 3 floats.
+ * means3D (N,3), cov3D (N,6) packed [xx,xy,xz,yy,yz,zz], colors (N,3),
+ * opacity (N) — each with its per-view stride.
+ * If the number of pairs exceeds pair_capacity the image is still written but
+ * is incomplete and the overflow flag is raised: check with
+ * mgr_raster_status_sync and retry with a larger workspace. */
+int mgr_raster_forward(int V, int N, int W, int H, const float* cams, const float* bg,
+                       const float* means3D, int64_t stride_means3D, const float* cov3D,
+                       int64_t stride_cov3D, const float* colors, int64_t stride_colors,
+                       const float* opacity, int64_t stride_opacity, float* out_color,
+                       int32_t* radii, void* workspace, size_t workspace_bytes,
+                       int64_t pair_capacity, int debug, void* stream);
+
+/* Backward of the forward that last used `workspace` (same inputs again).
+ * dL_dcolor: (V,3,H,W).  Outputs, all fully written:
+ * dL_dmeans3D (V,N,3), dL_dmeans2D (V,N,3) (z = 0; x,y in NDC-scaled pixel units
+ * 0.5*W, 0.5*H as the reference's densification statistic expects,
+ * src/models/gaussian.py:335-338), dL_dcolors (V,N,3), dL_dopacity (V,N),
+ * dL_dcov3D (V,N,6) (off-diagonals carry the factor 2 of the symmetric pack). */
+int mgr_raster_backward(int V, int N, int W, int H, const float* cams, const float* bg,
+                        const float* means3D, int64_t stride_means3D, const float* cov3D,
+                        int64_t stride_cov3D, const float* colors, int64_t stride_colors,
+                        const float* opacity, int64_t stride_opacity, const float* dL_dcolor,
+                        float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dcolors,
+                        float* dL_dopacity, float* dL_dcov3D, void* workspace,
+                        size_t workspace_bytes, int64_t pair_capacity, int debug, void* stream);
+
+/* Blocking read-back of the workspace header after a forward: total number of
+ * (Gaussian, tile) pairs (`num_rendered`, summed over views) and the overflow
+ * flag.  Returns MGR_EOVERFLOW when the flag is set. */
+int mgr_raster_status_sync(const void* workspace, int64_t* num_pairs, int32_t* overflow,
+                           void* stream);
+
+/* Debug/test access to the binning state of view v after a forward (blocking):
+ * tile_ranges_host (tiles,2) int32 [start,end) into the global sorted list,
+ * point_list_host up to `max_pairs` Gaussian indices in blend order. */
+int mgr_raster_debug_binning_sync(const void* workspace, int V, int N, int W, int H,
+                                  int64_t pair_capacity, int view, int32_t* tile_ranges_host,
+                                  int32_t* point_list_host, int64_t max_pairs, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Articulation: skin weights, LBS of means + covariances, SH colour
+ * ------------------------------------------------------------------------ */
+
+/* Trilinear sample (align_corners=True, zero padding) of a channel-last grid
+ * (D,H,W,B) at u = (xyz - center)/scale, u=(x,y,z) indexing (W,H,D), then
+ * w /= sum(w) without epsilon (0/0 -> NaN exactly like the reference).
+ * out_w: (N,B).  B <= MGR_MAX_BONES. */
+int mgr_skin_weights_fwd(int N, const float* xyz, const float* grid, int D, int H, int W, int B,
+                         const float* center3, const float* scale3, float* out_w, void* stream);
+/* dL_dxyz (N,3) written (not accumulated). */
+int mgr_skin_weights_bwd(int N, const float* xyz, const float* grid, int D, int H, int W, int B,
+                         const float* center3, const float* scale3, const float* dL_dw,
+                         float* dL_dxyz, void* stream);
+
+/* LBS for P poses.  transforms: (P,B,16) row-major 4x4 bone transforms
+ * T_b = posed_b * inv(rest_b) (+ identity background).  skin_w (N,B) or NULL for
+ * the static-object path (identity transform: posed = xyz, cov = Sigma).
+ * Outputs: posed_xyz (P,N,3), posed_cov (P,N,6), tf (P,N,12) = rows 0..2 of the
+ * blended 4x4 (may be NULL). */
+int mgr_lbs_cov_fwd(int P, int N, int B, const float* xyz, const float* log_scale,
+                    const float* rot, const float* skin_w, const float* transforms,
+                    float* posed_xyz, float* posed_cov, float* tf, void* stream);
+/* Backward.  dL_dtf (P,N,12) may be NULL.  Outputs fully written, summed over
+ * poses: dL_dxyz (N,3) (direct path only — the skin-weight path is dL_dw),
+ * dL_dlog_scale (N,3), dL_drot (N,4), dL_dw (N,B) (NULL when skin_w is NULL). */
+int mgr_lbs_cov_bwd(int P, int N, int B, const float* xyz, const float* log_scale,
+                    const float* rot, const float* skin_w, const float* transforms,
+                    const float* dL_dposed_xyz, const float* dL_dposed_cov, const float* dL_dtf,
+                    float* dL_dxyz, float* dL_dlog_scale, float* dL_drot, float* dL_dw,
+                    void* stream);
+
+/* SH degree-3 colour for V views.  sh: (N,16,3).  If tf != NULL (V,N,12 with
+ * stride_tf floats per view, 0 = shared) the camera is pulled back to canonical
+ * space: dir = xyz - inv(tf)*campos; else dir = xyz - campos, where xyz has
+ * stride_xyz floats per view.  colors (V,N,3) = max(sh2rgb + 0.5, 0). */
+int mgr_sh_color_fwd(int V, int N, const float* sh, const float* xyz, int64_t stride_xyz,
+                     const float* tf, int64_t stride_tf, const float* cams, float* colors,
+                     void* stream);
+/* Outputs fully written: dL_dsh (N,16,3) summed over views, dL_dxyz (V,N,3) per
+ * view, dL_dtf (V,N,12) per view (NULL when tf is NULL). */
+int mgr_sh_color_bwd(int V, int N, const float* sh, const float* xyz, int64_t stride_xyz,
+                     const float* tf, int64_t stride_tf, const float* cams,
+                     const float* dL_dcolors, float* dL_dsh, float* dL_dxyz, float* dL_dtf,
+                     void* stream);
+
+/* uv = (K*E*[x;1])[:2]/z for N points; K (3,3), E (3,4) row-major. */
+int mgr_project_points(int N, const float* xyz, const float* K9, const float* E12, float* uv,
+                       void* stream);
+
+/* ------------------------------------------------------------------------
+ * simple-knn: mean squared distance to the 3 nearest other points
+ * ------------------------------------------------------------------------ */
+size_t mgr_knn3_workspace_bytes(int N);
+int mgr_knn3_mean_dist2(int N, const float* xyz, float* out, void* workspace,
+                        size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Image loss used by the benchmark step: L = mean|a-b| over (V,3,H,W);
+ * writes dL/da = sign(a-b) * scale and accumulates sum|a-b| into loss_sum[0].
+ * (src/utils/loss_utils.py:22-27 with src/modules/base.py:329-331.)
+ * ------------------------------------------------------------------------ */
+int mgr_l1_loss_grad(int64_t count, const float* a, const float* b, float scale, float* dL_da,
+                     float* loss_sum, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MANUS_HIP_H */

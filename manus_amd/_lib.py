@@ -1,0 +1,115 @@
+"""ctypes binding of libmanus_hip.so (the C ABI declared in include/manus_hip.h).
+
+The library is mandatory for every compute op of this package: there is NO
+CPU or PyTorch fallback.  `lib()` raises if the .so has not been built
+(`python -m manus_amd.build`) and the ops raise if their tensors are not on a
+GPU.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmanus_hip.so")
+_LIB = None
+
+MGR_CAM_FLOATS = 40
+MGR_MAX_BONES = 32
+
+c_int, c_i64, c_f32, c_vp, c_sz = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
+
+# name -> (restype, argtypes); must list every symbol of include/manus_hip.h
+SIGNATURES = {
+    "mgr_version": (c_int, []),
+    "mgr_last_error": (ctypes.c_char_p, []),
+    "mgr_raster_workspace_bytes": (c_sz, [c_int, c_int, c_int, c_int, c_i64]),
+    "mgr_raster_forward": (c_int, [c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp,
+                                   c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_sz, c_i64, c_int, c_vp]),
+    "mgr_raster_backward": (c_int, [c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp,
+                                    c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz,
+                                    c_i64, c_int, c_vp]),
+    "mgr_raster_status_sync": (c_int, [c_vp, ctypes.POINTER(c_i64), ctypes.POINTER(ctypes.c_int32), c_vp]),
+    "mgr_raster_debug_binning_sync": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_i64, c_int, c_vp, c_vp,
+                                              c_i64, c_vp]),
+    "mgr_skin_weights_fwd": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
+    "mgr_skin_weights_bwd": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp,
+                                     c_vp]),
+    "mgr_lbs_cov_fwd": (c_int, [c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "mgr_lbs_cov_bwd": (c_int, [c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                c_vp, c_vp, c_vp, c_vp]),
+    "mgr_sh_color_fwd": (c_int, [c_int, c_int, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp]),
+    "mgr_sh_color_bwd": (c_int, [c_int, c_int, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                 c_vp]),
+    "mgr_project_points": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "mgr_knn3_workspace_bytes": (c_sz, [c_int]),
+    "mgr_knn3_mean_dist2": (c_int, [c_int, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "mgr_l1_loss_grad": (c_int, [c_i64, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp]),
+}
+
+
+class ManusHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libmanus_hip.so; raise loudly if it is missing (no fallback)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ManusHipError(
+                "libmanus_hip.so is not built (%s). Run `python -m manus_amd.build`; "
+                "this package has no CPU/PyTorch fallback." % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def check(code, what=""):
+    if code != 0:
+        msg = lib().mgr_last_error()
+        raise ManusHipError("%s failed (%d): %s" % (what, code, msg.decode() if msg else ""))
+
+
+def ptr(t):
+    """Device pointer of a contiguous fp32/int32 CUDA(HIP) tensor, or None."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise ManusHipError("manus_amd ops need GPU tensors (got %s); there is no CPU fallback" % t.device)
+    if not t.is_contiguous():
+        raise ManusHipError("tensor must be contiguous")
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def f32c(t):
+    """contiguous fp32 view/copy (the reference passes fp32 everywhere)."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def pack_cameras(tanfovx, tanfovy, viewmatrix, projmatrix, campos, device):
+    """Build the (V, MGR_CAM_FLOATS) device camera table from reference-style
+    camera tensors (each may carry a leading batch dim of 1).
+    Lists give V > 1.  No host synchronisation."""
+    if not isinstance(viewmatrix, (list, tuple)):
+        tanfovx, tanfovy, viewmatrix, projmatrix, campos = [tanfovx], [tanfovy], [viewmatrix], [projmatrix], [campos]
+    rows = []
+    for tx, ty, vm, pm, cp in zip(tanfovx, tanfovy, viewmatrix, projmatrix, campos):
+        head = torch.tensor([float(tx), float(ty)], dtype=torch.float32, device=device)
+        rows.append(torch.cat([
+            head,
+            torch.as_tensor(vm, dtype=torch.float32, device=device).reshape(-1)[:16],
+            torch.as_tensor(pm, dtype=torch.float32, device=device).reshape(-1)[:16],
+            torch.as_tensor(cp, dtype=torch.float32, device=device).reshape(-1)[:3],
+            torch.zeros(3, dtype=torch.float32, device=device)]))
+    return torch.stack(rows).contiguous()

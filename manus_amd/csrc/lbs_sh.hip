@@ -1,0 +1,640 @@
+// Articulation kernels for gfx950: skin-weight sampling from the voxel grid,
+// linear-blend skinning of means and covariances, SH colour — forward and
+// analytic backward.  One thread per Gaussian, bone transforms and cameras are
+// wave-uniform (scalar loads), per-pose / per-view sums are taken inside the
+// thread in a fixed order (no atomics, deterministic).
+//
+// Reference semantics (paths relative to /root/reference):
+//   skin weights   src/utils/gaussian_utils.py:167-196
+//   LBS            src/modules/hand_dynamic.py:106-127
+//   covariance     src/models/gaussian.py:49-53,84-93; src/utils/gaussian_utils.py:279-314
+//   SH colour      src/utils/gaussian_utils.py:431-449; src/utils/sh_utils.py:57-104
+//   projection     src/utils/transforms.py:304-311
+//   L1 loss        src/utils/loss_utils.py:22-27
+#include "mgr_common.h"
+
+// ---------------------------------------------------------------------------
+// skin weights: trilinear, align_corners=True, zero padding, then w / sum(w)
+// ---------------------------------------------------------------------------
+struct TriSetup {
+    int x0, y0, z0;
+    float fx, fy, fz;  // fractional parts
+};
+
+__device__ __forceinline__ TriSetup tri_setup(const float* __restrict__ xyz, int i,
+                                              const float* __restrict__ center,
+                                              const float* __restrict__ scale, int D, int H, int W) {
+    TriSetup s;
+    const float ux = (xyz[3 * i + 0] - center[0]) / scale[0];
+    const float uy = (xyz[3 * i + 1] - center[1]) / scale[1];
+    const float uz = (xyz[3 * i + 2] - center[2]) / scale[2];
+    const float ix = ((ux + 1.0f) * 0.5f) * (float)(W - 1);
+    const float iy = ((uy + 1.0f) * 0.5f) * (float)(H - 1);
+    const float iz = ((uz + 1.0f) * 0.5f) * (float)(D - 1);
+    const float flx = floorf(ix), fly = floorf(iy), flz = floorf(iz);
+    // clamp far-away points so the int conversion is defined; they are out of
+    // bounds either way and contribute zero
+    s.x0 = (int)fminf(fmaxf(flx, -2.0f), (float)W + 1.0f);
+    s.y0 = (int)fminf(fmaxf(fly, -2.0f), (float)H + 1.0f);
+    s.z0 = (int)fminf(fmaxf(flz, -2.0f), (float)D + 1.0f);
+    s.fx = ix - flx;
+    s.fy = iy - fly;
+    s.fz = iz - flz;
+    return s;
+}
+
+// value of channel b at the 8 corners (0 when out of bounds)
+__device__ __forceinline__ void tri_corners(const float* __restrict__ grid, const TriSetup& s, int D,
+                                            int H, int W, int B, int b, float c[8]) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int x = s.x0 + (k & 1), y = s.y0 + ((k >> 1) & 1), z = s.z0 + (k >> 2);
+        const bool ok = x >= 0 && x < W && y >= 0 && y < H && z >= 0 && z < D;
+        c[k] = ok ? grid[(((size_t)z * H + y) * W + x) * B + b] : 0.0f;
+    }
+}
+
+__device__ __forceinline__ float tri_value(const TriSetup& s, const float c[8]) {
+    const float wx0 = 1.0f - s.fx, wx1 = s.fx, wy0 = 1.0f - s.fy, wy1 = s.fy, wz0 = 1.0f - s.fz,
+                wz1 = s.fz;
+    return c[0] * (wx0 * wy0 * wz0) + c[1] * (wx1 * wy0 * wz0) + c[2] * (wx0 * wy1 * wz0) +
+           c[3] * (wx1 * wy1 * wz0) + c[4] * (wx0 * wy0 * wz1) + c[5] * (wx1 * wy0 * wz1) +
+           c[6] * (wx0 * wy1 * wz1) + c[7] * (wx1 * wy1 * wz1);
+}
+
+__global__ __launch_bounds__(256) void k_skin_fwd(int N, const float* __restrict__ xyz,
+                                                  const float* __restrict__ grid, int D, int H, int W,
+                                                  int B, const float* __restrict__ center,
+                                                  const float* __restrict__ scale,
+                                                  float* __restrict__ out_w) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const TriSetup s = tri_setup(xyz, i, center, scale, D, H, W);
+    float sum = 0.f;
+    for (int b = 0; b < B; ++b) {
+        float c[8];
+        tri_corners(grid, s, D, H, W, B, b, c);
+        const float v = tri_value(s, c);
+        out_w[(size_t)i * B + b] = v;
+        sum += v;
+    }
+    for (int b = 0; b < B; ++b) out_w[(size_t)i * B + b] = out_w[(size_t)i * B + b] / sum;
+}
+
+__global__ __launch_bounds__(256) void k_skin_bwd(int N, const float* __restrict__ xyz,
+                                                  const float* __restrict__ grid, int D, int H, int W,
+                                                  int B, const float* __restrict__ center,
+                                                  const float* __restrict__ scale,
+                                                  const float* __restrict__ dL_dw,
+                                                  float* __restrict__ dL_dxyz) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const TriSetup s = tri_setup(xyz, i, center, scale, D, H, W);
+    // pass 1: S = sum raw, dot = sum_c dLdw_c * raw_c
+    float S = 0.f, dot = 0.f;
+    for (int b = 0; b < B; ++b) {
+        float c[8];
+        tri_corners(grid, s, D, H, W, B, b, c);
+        const float v = tri_value(s, c);
+        S += v;
+        dot += dL_dw[(size_t)i * B + b] * v;
+    }
+    const float invS = 1.0f / S;
+    dot *= invS;  // = sum_c dLdw_c * w_c
+    // pass 2: dL/draw_b = (dLdw_b - dot)/S ; chain through the trilinear weights
+    float gx = 0.f, gy = 0.f, gz = 0.f;
+    const float wx0 = 1.0f - s.fx, wx1 = s.fx, wy0 = 1.0f - s.fy, wy1 = s.fy, wz0 = 1.0f - s.fz,
+                wz1 = s.fz;
+    for (int b = 0; b < B; ++b) {
+        float c[8];
+        tri_corners(grid, s, D, H, W, B, b, c);
+        const float gr = (dL_dw[(size_t)i * B + b] - dot) * invS;
+        const float ddx = (c[1] - c[0]) * (wy0 * wz0) + (c[3] - c[2]) * (wy1 * wz0) +
+                          (c[5] - c[4]) * (wy0 * wz1) + (c[7] - c[6]) * (wy1 * wz1);
+        const float ddy = (c[2] - c[0]) * (wx0 * wz0) + (c[3] - c[1]) * (wx1 * wz0) +
+                          (c[6] - c[4]) * (wx0 * wz1) + (c[7] - c[5]) * (wx1 * wz1);
+        const float ddz = (c[4] - c[0]) * (wx0 * wy0) + (c[5] - c[1]) * (wx1 * wy0) +
+                          (c[6] - c[2]) * (wx0 * wy1) + (c[7] - c[3]) * (wx1 * wy1);
+        gx += gr * ddx;
+        gy += gr * ddy;
+        gz += gr * ddz;
+    }
+    dL_dxyz[3 * i + 0] = gx * (0.5f * (float)(W - 1)) / scale[0];
+    dL_dxyz[3 * i + 1] = gy * (0.5f * (float)(H - 1)) / scale[1];
+    dL_dxyz[3 * i + 2] = gz * (0.5f * (float)(D - 1)) / scale[2];
+}
+
+// ---------------------------------------------------------------------------
+// LBS of means and covariances
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void quat_rot(const float q[4], float R[9]) {
+    const float r = q[0], x = q[1], y = q[2], z = q[3];
+    R[0] = 1.f - 2.f * (y * y + z * z); R[1] = 2.f * (x * y - r * z); R[2] = 2.f * (x * z + r * y);
+    R[3] = 2.f * (x * y + r * z); R[4] = 1.f - 2.f * (x * x + z * z); R[5] = 2.f * (y * z - r * x);
+    R[6] = 2.f * (x * z - r * y); R[7] = 2.f * (y * z + r * x); R[8] = 1.f - 2.f * (x * x + y * y);
+}
+
+// tf rows 0..2 (3x4, row-major) = sum_b w_b * T_b ; identity when w == nullptr
+__device__ __forceinline__ void blend_tf(const float* __restrict__ w_row, const float* __restrict__ Tp,
+                                         int B, float tf[12]) {
+    if (w_row == nullptr) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) tf[k] = (k == 0 || k == 5 || k == 10) ? 1.f : 0.f;
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < 12; ++k) tf[k] = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float w = w_row[b];
+        const float* T = Tp + (size_t)b * 16;  // wave-uniform address
+#pragma unroll
+        for (int k = 0; k < 12; ++k) tf[k] += w * T[k];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_lbs_fwd(int N, int B, const float* __restrict__ xyz,
+                                                 const float* __restrict__ log_scale,
+                                                 const float* __restrict__ rot,
+                                                 const float* __restrict__ skin_w,
+                                                 const float* __restrict__ transforms,
+                                                 float* __restrict__ posed_xyz,
+                                                 float* __restrict__ posed_cov,
+                                                 float* __restrict__ tf_out) {
+    const int i = blockIdx.x * 256 + threadIdx.x, p = blockIdx.y;
+    if (i >= N) return;
+    float tf[12];
+    blend_tf(skin_w ? skin_w + (size_t)i * B : nullptr, transforms ? transforms + (size_t)p * B * 16 : nullptr, B, tf);
+    const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+    const size_t pi = (size_t)p * N + i;
+    posed_xyz[pi * 3 + 0] = tf[0] * x + tf[1] * y + tf[2] * z + tf[3];
+    posed_xyz[pi * 3 + 1] = tf[4] * x + tf[5] * y + tf[6] * z + tf[7];
+    posed_xyz[pi * 3 + 2] = tf[8] * x + tf[9] * y + tf[10] * z + tf[11];
+    const float qr[4] = {rot[4 * i], rot[4 * i + 1], rot[4 * i + 2], rot[4 * i + 3]};
+    const float nrm = sqrtf(qr[0] * qr[0] + qr[1] * qr[1] + qr[2] * qr[2] + qr[3] * qr[3]);
+    const float q[4] = {qr[0] / nrm, qr[1] / nrm, qr[2] / nrm, qr[3] / nrm};
+    float R[9];
+    quat_rot(q, R);
+    const float s[3] = {expf(log_scale[3 * i]), expf(log_scale[3 * i + 1]), expf(log_scale[3 * i + 2])};
+    // M = A * R * diag(s)
+    float M[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            M[3 * r + c] = (tf[4 * r] * R[c] + tf[4 * r + 1] * R[3 + c] + tf[4 * r + 2] * R[6 + c]) * s[c];
+    float* o = posed_cov + pi * 6;
+    o[0] = M[0] * M[0] + M[1] * M[1] + M[2] * M[2];
+    o[1] = M[0] * M[3] + M[1] * M[4] + M[2] * M[5];
+    o[2] = M[0] * M[6] + M[1] * M[7] + M[2] * M[8];
+    o[3] = M[3] * M[3] + M[4] * M[4] + M[5] * M[5];
+    o[4] = M[3] * M[6] + M[4] * M[7] + M[5] * M[8];
+    o[5] = M[6] * M[6] + M[7] * M[7] + M[8] * M[8];
+    if (tf_out) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) tf_out[pi * 12 + k] = tf[k];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_lbs_bwd(int P, int N, int B, const float* __restrict__ xyz,
+                                                 const float* __restrict__ log_scale,
+                                                 const float* __restrict__ rot,
+                                                 const float* __restrict__ skin_w,
+                                                 const float* __restrict__ transforms,
+                                                 const float* __restrict__ g_xyz,
+                                                 const float* __restrict__ g_cov,
+                                                 const float* __restrict__ g_tf,
+                                                 float* __restrict__ dL_dxyz,
+                                                 float* __restrict__ dL_dls,
+                                                 float* __restrict__ dL_drot,
+                                                 float* __restrict__ dL_dw) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+    const float qr[4] = {rot[4 * i], rot[4 * i + 1], rot[4 * i + 2], rot[4 * i + 3]};
+    const float nrm = sqrtf(qr[0] * qr[0] + qr[1] * qr[1] + qr[2] * qr[2] + qr[3] * qr[3]);
+    const float q[4] = {qr[0] / nrm, qr[1] / nrm, qr[2] / nrm, qr[3] / nrm};
+    float R[9];
+    quat_rot(q, R);
+    const float s[3] = {expf(log_scale[3 * i]), expf(log_scale[3 * i + 1]), expf(log_scale[3 * i + 2])};
+    float dxyz[3] = {0.f, 0.f, 0.f}, ds[3] = {0.f, 0.f, 0.f};
+    float dR[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float dw[MGR_MAX_BONES];
+#pragma unroll
+    for (int b = 0; b < MGR_MAX_BONES; ++b) dw[b] = 0.f;
+
+    for (int p = 0; p < P; ++p) {
+        const size_t pi = (size_t)p * N + i;
+        const float* Tp = transforms ? transforms + (size_t)p * B * 16 : nullptr;
+        float tf[12];
+        blend_tf(skin_w ? skin_w + (size_t)i * B : nullptr, Tp, B, tf);
+        // Gs = G + G^T of the upper-triangular cov gradient
+        const float* g6 = g_cov + pi * 6;
+        const float Gs[9] = {2.f * g6[0], g6[1], g6[2], g6[1], 2.f * g6[3], g6[4], g6[2], g6[4], 2.f * g6[5]};
+        // AL = A * L, L = R diag(s)
+        float L[9], AL[9];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) L[3 * r + c] = R[3 * r + c] * s[c];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                AL[3 * r + c] = tf[4 * r] * L[c] + tf[4 * r + 1] * L[3 + c] + tf[4 * r + 2] * L[6 + c];
+        // dM = Gs * AL
+        float dM[9];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                dM[3 * r + c] = Gs[3 * r] * AL[c] + Gs[3 * r + 1] * AL[3 + c] + Gs[3 * r + 2] * AL[6 + c];
+        // dL_L = A^T dM ; dA = dM L^T
+        float dtf[12];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float dLrc = tf[r] * dM[c] + tf[4 + r] * dM[3 + c] + tf[8 + r] * dM[6 + c];
+                ds[c] += dLrc * R[3 * r + c];
+                dR[3 * r + c] += dLrc * s[c];
+                dtf[4 * r + c] = dM[3 * r] * L[3 * c] + dM[3 * r + 1] * L[3 * c + 1] + dM[3 * r + 2] * L[3 * c + 2];
+            }
+        // means: posed = A xyz + t
+        const float gp[3] = {g_xyz[pi * 3], g_xyz[pi * 3 + 1], g_xyz[pi * 3 + 2]};
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            dtf[4 * r + 0] += gp[r] * x;
+            dtf[4 * r + 1] += gp[r] * y;
+            dtf[4 * r + 2] += gp[r] * z;
+            dtf[4 * r + 3] = gp[r];
+        }
+        dxyz[0] += tf[0] * gp[0] + tf[4] * gp[1] + tf[8] * gp[2];
+        dxyz[1] += tf[1] * gp[0] + tf[5] * gp[1] + tf[9] * gp[2];
+        dxyz[2] += tf[2] * gp[0] + tf[6] * gp[1] + tf[10] * gp[2];
+        if (g_tf) {
+#pragma unroll
+            for (int k = 0; k < 12; ++k) dtf[k] += g_tf[pi * 12 + k];
+        }
+        if (skin_w) {
+#pragma unroll
+            for (int b = 0; b < MGR_MAX_BONES; ++b) {
+                if (b < B) {
+                    const float* T = Tp + (size_t)b * 16;
+                    float a = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 12; ++k) a += dtf[k] * T[k];
+                    dw[b] += a;
+                }
+            }
+        }
+    }
+    dL_dxyz[3 * i] = dxyz[0]; dL_dxyz[3 * i + 1] = dxyz[1]; dL_dxyz[3 * i + 2] = dxyz[2];
+    dL_dls[3 * i] = ds[0] * s[0]; dL_dls[3 * i + 1] = ds[1] * s[1]; dL_dls[3 * i + 2] = ds[2] * s[2];
+    // R(q) -> q -> raw quaternion
+    const float r = q[0], qx = q[1], qy = q[2], qz = q[3];
+    float dq[4];
+    dq[0] = 2.f * (-qz * dR[1] + qy * dR[2] + qz * dR[3] - qx * dR[5] - qy * dR[6] + qx * dR[7]);
+    dq[1] = 2.f * (qy * dR[1] + qz * dR[2] + qy * dR[3] - 2.f * qx * dR[4] - r * dR[5] + qz * dR[6] + r * dR[7] - 2.f * qx * dR[8]);
+    dq[2] = 2.f * (-2.f * qy * dR[0] + qx * dR[1] + r * dR[2] + qx * dR[3] + qz * dR[5] - r * dR[6] + qz * dR[7] - 2.f * qy * dR[8]);
+    dq[3] = 2.f * (-2.f * qz * dR[0] - r * dR[1] + qx * dR[2] + r * dR[3] - 2.f * qz * dR[4] + qy * dR[5] + qx * dR[6] + qy * dR[7]);
+    const float qd = q[0] * dq[0] + q[1] * dq[1] + q[2] * dq[2] + q[3] * dq[3];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dL_drot[4 * i + k] = (dq[k] - q[k] * qd) / nrm;
+    if (dL_dw && skin_w) {
+#pragma unroll
+        for (int b = 0; b < MGR_MAX_BONES; ++b)
+            if (b < B) dL_dw[(size_t)i * B + b] = dw[b];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// SH colour (degree 3)
+// ---------------------------------------------------------------------------
+#define SHC0 0.28209479177387814f
+#define SHC1 0.4886025119029199f
+__device__ static const float SHC2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                         -1.0925484305920792f, 0.5462742152960396f};
+__device__ static const float SHC3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                         0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
+                                         -0.5900435899266435f};
+
+__device__ __forceinline__ void sh_basis(float x, float y, float z, float Y[16]) {
+    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+    Y[0] = SHC0;
+    Y[1] = -SHC1 * y; Y[2] = SHC1 * z; Y[3] = -SHC1 * x;
+    Y[4] = SHC2[0] * xy; Y[5] = SHC2[1] * yz; Y[6] = SHC2[2] * (2.f * zz - xx - yy);
+    Y[7] = SHC2[3] * xz; Y[8] = SHC2[4] * (xx - yy);
+    Y[9] = SHC3[0] * y * (3.f * xx - yy); Y[10] = SHC3[1] * xy * z;
+    Y[11] = SHC3[2] * y * (4.f * zz - xx - yy); Y[12] = SHC3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy);
+    Y[13] = SHC3[4] * x * (4.f * zz - xx - yy); Y[14] = SHC3[5] * z * (xx - yy);
+    Y[15] = SHC3[6] * x * (xx - 3.f * yy);
+}
+
+// direction (un-normalised d, and pulled-back camera) for one (view, Gaussian)
+struct ShDir {
+    float d[3], n, ci[3];  // d = xyz - cam', n = |d|, ci = inv(tf)*cam (when tf)
+    float Ainv[9];         // inverse of tf[:3,:3] (when tf)
+};
+
+__device__ __forceinline__ void sh_dir(const float* __restrict__ xyz_v, int i,
+                                       const float* __restrict__ tf_v, const float cam[3], ShDir& o) {
+    const float x = xyz_v[3 * i], y = xyz_v[3 * i + 1], z = xyz_v[3 * i + 2];
+    if (tf_v) {
+        const float* t = tf_v + (size_t)i * 12;
+        const float a = t[0], b = t[1], c = t[2], d = t[4], e = t[5], f = t[6], g = t[8], h = t[9], k = t[10];
+        const float c00 = e * k - f * h, c01 = f * g - d * k, c02 = d * h - e * g;
+        const float det = a * c00 + b * c01 + c * c02;
+        const float id = 1.0f / det;
+        o.Ainv[0] = c00 * id; o.Ainv[1] = (c * h - b * k) * id; o.Ainv[2] = (b * f - c * e) * id;
+        o.Ainv[3] = c01 * id; o.Ainv[4] = (a * k - c * g) * id; o.Ainv[5] = (c * d - a * f) * id;
+        o.Ainv[6] = c02 * id; o.Ainv[7] = (b * g - a * h) * id; o.Ainv[8] = (a * e - b * d) * id;
+        const float bx = cam[0] - t[3], by = cam[1] - t[7], bz = cam[2] - t[11];
+        o.ci[0] = o.Ainv[0] * bx + o.Ainv[1] * by + o.Ainv[2] * bz;
+        o.ci[1] = o.Ainv[3] * bx + o.Ainv[4] * by + o.Ainv[5] * bz;
+        o.ci[2] = o.Ainv[6] * bx + o.Ainv[7] * by + o.Ainv[8] * bz;
+        o.d[0] = x - o.ci[0]; o.d[1] = y - o.ci[1]; o.d[2] = z - o.ci[2];
+    } else {
+        o.d[0] = x - cam[0]; o.d[1] = y - cam[1]; o.d[2] = z - cam[2];
+    }
+    o.n = sqrtf(o.d[0] * o.d[0] + o.d[1] * o.d[1] + o.d[2] * o.d[2]);
+}
+
+__global__ __launch_bounds__(256) void k_sh_fwd(int N, const float* __restrict__ sh,
+                                                const float* __restrict__ xyz, int64_t s_xyz,
+                                                const float* __restrict__ tf, int64_t s_tf,
+                                                const float* __restrict__ cams,
+                                                float* __restrict__ colors) {
+    const int i = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y;
+    if (i >= N) return;
+    const float* cp = cams + (size_t)v * MGR_CAM_FLOATS + 34;
+    const float cam[3] = {cp[0], cp[1], cp[2]};
+    ShDir D;
+    sh_dir(xyz + (size_t)v * s_xyz, i, tf ? tf + (size_t)v * s_tf : nullptr, cam, D);
+    float Y[16];
+    sh_basis(D.d[0] / D.n, D.d[1] / D.n, D.d[2] / D.n, Y);
+    const float* c = sh + (size_t)i * 48;
+    float r = 0.f, g = 0.f, b = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        r += Y[k] * c[3 * k];
+        g += Y[k] * c[3 * k + 1];
+        b += Y[k] * c[3 * k + 2];
+    }
+    float* o = colors + ((size_t)v * N + i) * 3;
+    o[0] = fmaxf(r + 0.5f, 0.f);
+    o[1] = fmaxf(g + 0.5f, 0.f);
+    o[2] = fmaxf(b + 0.5f, 0.f);
+}
+
+__global__ __launch_bounds__(256) void k_sh_bwd(int V, int N, const float* __restrict__ sh,
+                                                const float* __restrict__ xyz, int64_t s_xyz,
+                                                const float* __restrict__ tf, int64_t s_tf,
+                                                const float* __restrict__ cams,
+                                                const float* __restrict__ g_col,
+                                                float* __restrict__ dL_dsh,
+                                                float* __restrict__ dL_dxyz,
+                                                float* __restrict__ dL_dtf) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    float c[48], dsh[48];
+#pragma unroll
+    for (int k = 0; k < 48; ++k) {
+        c[k] = sh[(size_t)i * 48 + k];
+        dsh[k] = 0.f;
+    }
+    for (int v = 0; v < V; ++v) {
+        const float* cp = cams + (size_t)v * MGR_CAM_FLOATS + 34;
+        const float cam[3] = {cp[0], cp[1], cp[2]};
+        ShDir D;
+        sh_dir(xyz + (size_t)v * s_xyz, i, tf ? tf + (size_t)v * s_tf : nullptr, cam, D);
+        const float inv_n = 1.0f / D.n;
+        const float x = D.d[0] * inv_n, y = D.d[1] * inv_n, z = D.d[2] * inv_n;
+        float Y[16];
+        sh_basis(x, y, z, Y);
+        float rgb[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            rgb[0] += Y[k] * c[3 * k];
+            rgb[1] += Y[k] * c[3 * k + 1];
+            rgb[2] += Y[k] * c[3 * k + 2];
+        }
+        const float* gc = g_col + ((size_t)v * N + i) * 3;
+        float dr[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) dr[ch] = (rgb[ch] + 0.5f >= 0.f) ? gc[ch] : 0.f;
+        float t[16];  // dL/dY_k
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            t[k] = c[3 * k] * dr[0] + c[3 * k + 1] * dr[1] + c[3 * k + 2] * dr[2];
+            dsh[3 * k] += Y[k] * dr[0];
+            dsh[3 * k + 1] += Y[k] * dr[1];
+            dsh[3 * k + 2] += Y[k] * dr[2];
+        }
+        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+        float gdx = -SHC1 * t[3] + SHC2[0] * y * t[4] + SHC2[2] * (-2.f * x) * t[6] + SHC2[3] * z * t[7] +
+                    SHC2[4] * 2.f * x * t[8] + SHC3[0] * 6.f * xy * t[9] + SHC3[1] * yz * t[10] +
+                    SHC3[2] * (-2.f * xy) * t[11] + SHC3[3] * (-6.f * xz) * t[12] +
+                    SHC3[4] * (4.f * zz - 3.f * xx - yy) * t[13] + SHC3[5] * 2.f * xz * t[14] +
+                    SHC3[6] * (3.f * xx - 3.f * yy) * t[15];
+        float gdy = -SHC1 * t[1] + SHC2[0] * x * t[4] + SHC2[1] * z * t[5] + SHC2[2] * (-2.f * y) * t[6] +
+                    SHC2[4] * (-2.f * y) * t[8] + SHC3[0] * (3.f * xx - 3.f * yy) * t[9] +
+                    SHC3[1] * xz * t[10] + SHC3[2] * (4.f * zz - xx - 3.f * yy) * t[11] +
+                    SHC3[3] * (-6.f * yz) * t[12] + SHC3[4] * (-2.f * xy) * t[13] +
+                    SHC3[5] * (-2.f * yz) * t[14] + SHC3[6] * (-6.f * xy) * t[15];
+        float gdz = SHC1 * t[2] + SHC2[1] * y * t[5] + SHC2[2] * 4.f * z * t[6] + SHC2[3] * x * t[7] +
+                    SHC3[1] * xy * t[10] + SHC3[2] * 8.f * yz * t[11] +
+                    SHC3[3] * (6.f * zz - 3.f * xx - 3.f * yy) * t[12] + SHC3[4] * 8.f * xz * t[13] +
+                    SHC3[5] * (xx - yy) * t[14];
+        // through the normalisation dir = d/|d|
+        const float dp = x * gdx + y * gdy + z * gdz;
+        const float gd[3] = {(gdx - x * dp) * inv_n, (gdy - y * dp) * inv_n, (gdz - z * dp) * inv_n};
+        float* ox = dL_dxyz + ((size_t)v * N + i) * 3;
+        ox[0] = gd[0]; ox[1] = gd[1]; ox[2] = gd[2];
+        if (tf && dL_dtf) {
+            // cam' = Ainv (cam - t);  g_cam' = -gd;  h = Ainv^T g_cam'
+            const float h0 = -(D.Ainv[0] * gd[0] + D.Ainv[3] * gd[1] + D.Ainv[6] * gd[2]);
+            const float h1 = -(D.Ainv[1] * gd[0] + D.Ainv[4] * gd[1] + D.Ainv[7] * gd[2]);
+            const float h2 = -(D.Ainv[2] * gd[0] + D.Ainv[5] * gd[1] + D.Ainv[8] * gd[2]);
+            float* ot = dL_dtf + ((size_t)v * N + i) * 12;
+            ot[0] = -h0 * D.ci[0]; ot[1] = -h0 * D.ci[1]; ot[2] = -h0 * D.ci[2]; ot[3] = -h0;
+            ot[4] = -h1 * D.ci[0]; ot[5] = -h1 * D.ci[1]; ot[6] = -h1 * D.ci[2]; ot[7] = -h1;
+            ot[8] = -h2 * D.ci[0]; ot[9] = -h2 * D.ci[1]; ot[10] = -h2 * D.ci[2]; ot[11] = -h2;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 48; ++k) dL_dsh[(size_t)i * 48 + k] = dsh[k];
+}
+
+// ---------------------------------------------------------------------------
+// misc
+// ---------------------------------------------------------------------------
+__global__ void k_project(int N, const float* __restrict__ xyz, const float* __restrict__ K,
+                          const float* __restrict__ E, float* __restrict__ uv) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    float Pm[12];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) Pm[4 * r + c] = K[3 * r] * E[c] + K[3 * r + 1] * E[4 + c] + K[3 * r + 2] * E[8 + c];
+    const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+    const float a = Pm[0] * x + Pm[1] * y + Pm[2] * z + Pm[3];
+    const float b = Pm[4] * x + Pm[5] * y + Pm[6] * z + Pm[7];
+    const float c = Pm[8] * x + Pm[9] * y + Pm[10] * z + Pm[11];
+    uv[2 * i] = a / c;
+    uv[2 * i + 1] = b / c;
+}
+
+__global__ __launch_bounds__(256) void k_l1_grad(int64_t count, const float4* __restrict__ a,
+                                                 const float4* __restrict__ b, float scale,
+                                                 float4* __restrict__ g, float* __restrict__ loss_sum,
+                                                 const float* a1, const float* b1, float* g1) {
+    __shared__ float s_part[4];
+    const int64_t n4 = count >> 2;
+    float acc = 0.f;
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n4; k += (int64_t)gridDim.x * 256) {
+        const float4 x = a[k], y = b[k];
+        const float d0 = x.x - y.x, d1 = x.y - y.y, d2 = x.z - y.z, d3 = x.w - y.w;
+        acc += fabsf(d0) + fabsf(d1) + fabsf(d2) + fabsf(d3);
+        float4 o;
+        o.x = d0 > 0.f ? scale : (d0 < 0.f ? -scale : 0.f);
+        o.y = d1 > 0.f ? scale : (d1 < 0.f ? -scale : 0.f);
+        o.z = d2 > 0.f ? scale : (d2 < 0.f ? -scale : 0.f);
+        o.w = d3 > 0.f ? scale : (d3 < 0.f ? -scale : 0.f);
+        g[k] = o;
+    }
+    if (blockIdx.x == 0) {  // tail
+        for (int64_t k = (n4 << 2) + threadIdx.x; k < count; k += 256) {
+            const float d = a1[k] - b1[k];
+            acc += fabsf(d);
+            g1[k] = d > 0.f ? scale : (d < 0.f ? -scale : 0.f);
+        }
+    }
+    acc = mgr_wave_sum63(acc);
+    if ((threadIdx.x & 63) == 63) s_part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0 && loss_sum) atomicAdd(loss_sum, (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]));
+}
+
+// ---------------------------------------------------------------------------
+// host entries
+// ---------------------------------------------------------------------------
+extern "C" int mgr_skin_weights_fwd(int N, const float* xyz, const float* grid, int D, int H, int W,
+                                    int B, const float* center3, const float* scale3, float* out_w,
+                                    void* stream_) {
+    if (N < 0 || B <= 0 || B > MGR_MAX_BONES || D <= 0 || H <= 0 || W <= 0)
+        return mgr_fail(MGR_EINVAL, "mgr_skin_weights_fwd: bad sizes");
+    if (N == 0) return MGR_OK;
+    if (!xyz || !grid || !center3 || !scale3 || !out_w) return mgr_fail(MGR_EINVAL, "mgr_skin_weights_fwd: null pointer");
+    hipStream_t stream = (hipStream_t)stream_;
+    hipLaunchKernelGGL(k_skin_fwd, dim3((N + 255) / 256), dim3(256), 0, stream, N, xyz, grid, D, H, W, B,
+                       center3, scale3, out_w);
+    MGR_LAUNCH_CHECK("k_skin_fwd", stream, 0);
+    return MGR_OK;
+}
+
+extern "C" int mgr_skin_weights_bwd(int N, const float* xyz, const float* grid, int D, int H, int W,
+                                    int B, const float* center3, const float* scale3,
+                                    const float* dL_dw, float* dL_dxyz, void* stream_) {
+    if (N < 0 || B <= 0 || B > MGR_MAX_BONES || D <= 0 || H <= 0 || W <= 0)
+        return mgr_fail(MGR_EINVAL, "mgr_skin_weights_bwd: bad sizes");
+    if (N == 0) return MGR_OK;
+    if (!xyz || !grid || !center3 || !scale3 || !dL_dw || !dL_dxyz)
+        return mgr_fail(MGR_EINVAL, "mgr_skin_weights_bwd: null pointer");
+    hipStream_t stream = (hipStream_t)stream_;
+    hipLaunchKernelGGL(k_skin_bwd, dim3((N + 255) / 256), dim3(256), 0, stream, N, xyz, grid, D, H, W, B,
+                       center3, scale3, dL_dw, dL_dxyz);
+    MGR_LAUNCH_CHECK("k_skin_bwd", stream, 0);
+    return MGR_OK;
+}
+
+extern "C" int mgr_lbs_cov_fwd(int P, int N, int B, const float* xyz, const float* log_scale,
+                               const float* rot, const float* skin_w, const float* transforms,
+                               float* posed_xyz, float* posed_cov, float* tf, void* stream_) {
+    if (P <= 0 || N < 0 || (skin_w && (B <= 0 || B > MGR_MAX_BONES)))
+        return mgr_fail(MGR_EINVAL, "mgr_lbs_cov_fwd: bad sizes");
+    if (N == 0) return MGR_OK;
+    if (!xyz || !log_scale || !rot || !posed_xyz || !posed_cov || (skin_w && !transforms))
+        return mgr_fail(MGR_EINVAL, "mgr_lbs_cov_fwd: null pointer");
+    hipStream_t stream = (hipStream_t)stream_;
+    hipLaunchKernelGGL(k_lbs_fwd, dim3((N + 255) / 256, P), dim3(256), 0, stream, N, B, xyz, log_scale, rot,
+                       skin_w, transforms, posed_xyz, posed_cov, tf);
+    MGR_LAUNCH_CHECK("k_lbs_fwd", stream, 0);
+    return MGR_OK;
+}
+
+extern "C" int mgr_lbs_cov_bwd(int P, int N, int B, const float* xyz, const float* log_scale,
+                               const float* rot, const float* skin_w, const float* transforms,
+                               const float* dL_dposed_xyz, const float* dL_dposed_cov,
+                               const float* dL_dtf, float* dL_dxyz, float* dL_dlog_scale,
+                               float* dL_drot, float* dL_dw, void* stream_) {
+    if (P <= 0 || N < 0 || (skin_w && (B <= 0 || B > MGR_MAX_BONES)))
+        return mgr_fail(MGR_EINVAL, "mgr_lbs_cov_bwd: bad sizes");
+    if (N == 0) return MGR_OK;
+    if (!xyz || !log_scale || !rot || !dL_dposed_xyz || !dL_dposed_cov || !dL_dxyz || !dL_dlog_scale ||
+        !dL_drot || (skin_w && (!transforms || !dL_dw)))
+        return mgr_fail(MGR_EINVAL, "mgr_lbs_cov_bwd: null pointer");
+    hipStream_t stream = (hipStream_t)stream_;
+    hipLaunchKernelGGL(k_lbs_bwd, dim3((N + 255) / 256), dim3(256), 0, stream, P, N, B, xyz, log_scale, rot,
+                       skin_w, transforms, dL_dposed_xyz, dL_dposed_cov, dL_dtf, dL_dxyz, dL_dlog_scale,
+                       dL_drot, dL_dw);
+    MGR_LAUNCH_CHECK("k_lbs_bwd", stream, 0);
+    return MGR_OK;
+}
+
+extern "C" int mgr_sh_color_fwd(int V, int N, const float* sh, const float* xyz, int64_t stride_xyz,
+                                const float* tf, int64_t stride_tf, const float* cams, float* colors,
+                                void* stream_) {
+    if (V <= 0 || N < 0) return mgr_fail(MGR_EINVAL, "mgr_sh_color_fwd: bad sizes");
+    if (N == 0) return MGR_OK;
+    if (!sh || !xyz || !cams || !colors) return mgr_fail(MGR_EINVAL, "mgr_sh_color_fwd: null pointer");
+    hipStream_t stream = (hipStream_t)stream_;
+    hipLaunchKernelGGL(k_sh_fwd, dim3((N + 255) / 256, V), dim3(256), 0, stream, N, sh, xyz, stride_xyz, tf,
+                       stride_tf, cams, colors);
+    MGR_LAUNCH_CHECK("k_sh_fwd", stream, 0);
+    return MGR_OK;
+}
+
+extern "C" int mgr_sh_color_bwd(int V, int N, const float* sh, const float* xyz, int64_t stride_xyz,
+                                const float* tf, int64_t stride_tf, const float* cams,
+                                const float* dL_dcolors, float* dL_dsh, float* dL_dxyz, float* dL_dtf,
+                                void* stream_) {
+    if (V <= 0 || N < 0) return mgr_fail(MGR_EINVAL, "mgr_sh_color_bwd: bad sizes");
+    if (N == 0) return MGR_OK;
+    if (!sh || !xyz || !cams || !dL_dcolors || !dL_dsh || !dL_dxyz || (tf && !dL_dtf))
+        return mgr_fail(MGR_EINVAL, "mgr_sh_color_bwd: null pointer");
+    hipStream_t stream = (hipStream_t)stream_;
+    hipLaunchKernelGGL(k_sh_bwd, dim3((N + 255) / 256), dim3(256), 0, stream, V, N, sh, xyz, stride_xyz, tf,
+                       stride_tf, cams, dL_dcolors, dL_dsh, dL_dxyz, dL_dtf);
+    MGR_LAUNCH_CHECK("k_sh_bwd", stream, 0);
+    return MGR_OK;
+}
+
+extern "C" int mgr_project_points(int N, const float* xyz, const float* K9, const float* E12, float* uv,
+                                  void* stream_) {
+    if (N < 0) return mgr_fail(MGR_EINVAL, "mgr_project_points: bad sizes");
+    if (N == 0) return MGR_OK;
+    if (!xyz || !K9 || !E12 || !uv) return mgr_fail(MGR_EINVAL, "mgr_project_points: null pointer");
+    hipStream_t stream = (hipStream_t)stream_;
+    hipLaunchKernelGGL(k_project, dim3((N + 255) / 256), dim3(256), 0, stream, N, xyz, K9, E12, uv);
+    MGR_LAUNCH_CHECK("k_project", stream, 0);
+    return MGR_OK;
+}
+
+extern "C" int mgr_l1_loss_grad(int64_t count, const float* a, const float* b, float scale, float* dL_da,
+                                float* loss_sum, void* stream_) {
+    if (count < 0) return mgr_fail(MGR_EINVAL, "mgr_l1_loss_grad: bad sizes");
+    if (count == 0) return MGR_OK;
+    if (!a || !b || !dL_da) return mgr_fail(MGR_EINVAL, "mgr_l1_loss_grad: null pointer");
+    if (((uintptr_t)a | (uintptr_t)b | (uintptr_t)dL_da) & 15)
+        return mgr_fail(MGR_EINVAL, "mgr_l1_loss_grad: pointers must be 16-byte aligned");
+    hipStream_t stream = (hipStream_t)stream_;
+    int64_t n4 = count >> 2;
+    int blocks = (int)((n4 + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_l1_grad, dim3(blocks), dim3(256), 0, stream, count, (const float4*)a, (const float4*)b,
+                       scale, (float4*)dL_da, loss_sum, a, b, dL_da);
+    MGR_LAUNCH_CHECK("k_l1_grad", stream, 0);
+    return MGR_OK;
+}

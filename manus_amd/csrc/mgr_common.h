@@ -1,0 +1,177 @@
+// Shared device/host helpers for libmanus_hip.so (gfx950 only, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/manus_hip.h"
+
+#define MGR_WAVE 64
+
+// ---------------------------------------------------------------------------
+// error handling: thread-local text, never abort()
+// ---------------------------------------------------------------------------
+extern thread_local char g_mgr_err[512];
+
+static inline int mgr_fail(int code, const char* fmt, const char* a = "", const char* b = "") {
+    snprintf(g_mgr_err, sizeof(g_mgr_err), fmt, a, b);
+    return code;
+}
+
+#define MGR_HIP(call)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess) return mgr_fail(MGR_EHIP, "%s: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+// after a launch: catch launch errors always; in debug mode also sync + check
+#define MGR_LAUNCH_CHECK(name, stream, debug)                                              \
+    do {                                                                                   \
+        hipError_t e_ = hipGetLastError();                                                 \
+        if (e_ != hipSuccess) return mgr_fail(MGR_EHIP, "launch %s: %s", name, hipGetErrorString(e_)); \
+        if (debug) {                                                                       \
+            e_ = hipStreamSynchronize(stream);                                             \
+            if (e_ != hipSuccess) return mgr_fail(MGR_EHIP, "sync %s: %s", name, hipGetErrorString(e_)); \
+        }                                                                                  \
+    } while (0)
+
+// ---------------------------------------------------------------------------
+// workspace layout of the rasterizer (shared by forward and backward)
+// ---------------------------------------------------------------------------
+struct MgrHeader {            // first 256 bytes of the workspace
+    uint32_t total_pairs;     // sum of tiles_touched over all views (may exceed capacity)
+    uint32_t overflow;        // 1 if total_pairs > capacity
+    uint32_t epoch;           // backward call counter (tags valid pair-gradient records)
+    uint32_t queue_len;       // number of non-empty tiles in tile_queue
+    uint32_t queue_head;      // work-queue cursor (sort)
+    uint32_t queue_head2;     // spare cursor
+    uint32_t pad[58];
+};
+
+// 48-byte per-(view,Gaussian) record gathered by the blend kernels
+struct __attribute__((aligned(16))) MgrGRec {
+    float x, y, ca, cb;       // pixel centre, conic A, B
+    float cc, op, r, g;       // conic C, opacity, colour r, g
+    float b;                  // colour b
+    int32_t slot_base;        // pair slot = slot_base + ty*rect_w + tx
+    int32_t rect_w;
+    int32_t pad;
+};
+
+struct MgrLayout {
+    size_t header, grec, depth, rect, pair_off, tile_count, tile_start, tile_cursor, tile_done,
+        tile_queue, keys, sorted_gid, final_T, n_contrib, pair_tag, pair_grad, total;
+};
+
+static inline size_t mgr_align(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static inline MgrLayout mgr_layout(int V, int N, int W, int H, int64_t cap) {
+    MgrLayout L;
+    size_t VN = (size_t)V * (size_t)(N > 0 ? N : 1);
+    size_t gx = (W + MGR_TILE - 1) / MGR_TILE, gy = (H + MGR_TILE - 1) / MGR_TILE;
+    size_t VT = (size_t)V * gx * gy, VP = (size_t)V * W * H;
+    size_t c = (size_t)(cap > 0 ? cap : 1);
+    size_t o = 0;
+    L.header = o;      o += mgr_align(sizeof(MgrHeader));
+    L.grec = o;        o += mgr_align(VN * sizeof(MgrGRec));
+    L.depth = o;       o += mgr_align(VN * 4);
+    L.rect = o;        o += mgr_align(VN * 8);       // 4 x uint16
+    L.pair_off = o;    o += mgr_align(VN * 4);
+    L.tile_count = o;  o += mgr_align(VT * 4);
+    L.tile_start = o;  o += mgr_align((VT + 1) * 4);
+    L.tile_cursor = o; o += mgr_align(VT * 4);
+    L.tile_done = o;   o += mgr_align(VT * 4);
+    L.tile_queue = o;  o += mgr_align(VT * 4);
+    L.keys = o;        o += mgr_align(c * 8);
+    L.sorted_gid = o;  o += mgr_align(c * 4);
+    L.final_T = o;     o += mgr_align(VP * 4);
+    L.n_contrib = o;   o += mgr_align(VP * 4);
+    L.pair_tag = o;    o += mgr_align(c * 4);
+    L.pair_grad = o;   o += mgr_align(c * 48);
+    L.total = o;
+    return L;
+}
+
+// ---------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------
+#ifdef __HIPCC__
+
+struct MgrCam {
+    float tanfovx, tanfovy;
+    float view[16], proj[16];
+    float campos[3];
+};
+
+// camera record is wave-uniform: these become scalar loads
+__device__ __forceinline__ void mgr_load_cam(const float* __restrict__ cams, int v, MgrCam& c) {
+    const float* p = cams + (size_t)v * MGR_CAM_FLOATS;
+    c.tanfovx = p[0];
+    c.tanfovy = p[1];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        c.view[i] = p[2 + i];
+        c.proj[i] = p[18 + i];
+    }
+    c.campos[0] = p[34];
+    c.campos[1] = p[35];
+    c.campos[2] = p[36];
+}
+
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
+__device__ __forceinline__ float mgr_dpp(float v) {
+    // lanes without a source (or masked rows) receive 0 (old operand)
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, BANK_MASK, false));
+}
+
+// Full wave64 sum; the total is valid in lane 63 only.
+__device__ __forceinline__ float mgr_wave_sum63(float v) {
+    v += mgr_dpp<0xb1>(v);          // quad_perm [1,0,3,2]
+    v += mgr_dpp<0x4e>(v);          // quad_perm [2,3,0,1]
+    v += mgr_dpp<0x114>(v);         // row_shr:4
+    v += mgr_dpp<0x118>(v);         // row_shr:8
+    v += mgr_dpp<0x142, 0xa>(v);    // row_bcast:15 -> rows 1,3
+    v += mgr_dpp<0x143, 0xc>(v);    // row_bcast:31 -> rows 2,3
+    return v;
+}
+
+__device__ __forceinline__ float mgr_readlane63(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+__device__ __forceinline__ int mgr_lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// EWA projection rows M0, M1 of (J * Rwv) with the 1.3*tanfov clamp.
+__device__ __forceinline__ void mgr_ewa_rows(const MgrCam& c, float W, float H, const float p[3],
+                                             float M0[3], float M1[3], float t[3], float& xmul,
+                                             float& ymul, float& fx, float& fy) {
+    const float* v = c.view;
+    fx = W / (2.0f * c.tanfovx);
+    fy = H / (2.0f * c.tanfovy);
+    t[0] = v[0] * p[0] + v[4] * p[1] + v[8] * p[2] + v[12];
+    t[1] = v[1] * p[0] + v[5] * p[1] + v[9] * p[2] + v[13];
+    t[2] = v[2] * p[0] + v[6] * p[1] + v[10] * p[2] + v[14];
+    const float limx = 1.3f * c.tanfovx, limy = 1.3f * c.tanfovy;
+    const float txtz = t[0] / t[2], tytz = t[1] / t[2];
+    xmul = (txtz < -limx || txtz > limx) ? 0.0f : 1.0f;
+    ymul = (tytz < -limy || tytz > limy) ? 0.0f : 1.0f;
+    t[0] = fminf(limx, fmaxf(-limx, txtz)) * t[2];
+    t[1] = fminf(limy, fmaxf(-limy, tytz)) * t[2];
+    const float j00 = fx / t[2], j02 = -(fx * t[0]) / (t[2] * t[2]);
+    const float j11 = fy / t[2], j12 = -(fy * t[1]) / (t[2] * t[2]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        M0[k] = j00 * v[4 * k + 0] + j02 * v[4 * k + 2];
+        M1[k] = j11 * v[4 * k + 1] + j12 * v[4 * k + 2];
+    }
+}
+
+__device__ __forceinline__ void mgr_sym_mul(const float c6[6], const float m[3], float o[3]) {
+    o[0] = c6[0] * m[0] + c6[1] * m[1] + c6[2] * m[2];
+    o[1] = c6[1] * m[0] + c6[3] * m[1] + c6[4] * m[2];
+    o[2] = c6[2] * m[0] + c6[4] * m[1] + c6[5] * m[2];
+}
+
+#endif  // __HIPCC__

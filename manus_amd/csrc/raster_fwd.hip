@@ -1,0 +1,552 @@
+// Rasterizer forward for gfx950: preprocess -> tile scan/queue -> emit -> per-tile
+// LDS sort -> alpha blend.  All V views of a call are batched into every launch.
+//
+// Replaces diff_gaussian_rasterization._C.rasterize_gaussians as called from
+// /root/reference/src/utils/gaussian_utils.py:393-416 (algorithm: SURVEY.md App. A).
+//
+// Design (MI355X-first, not the upstream CUDA layout):
+//  * no global 64-bit radix sort: pairs are bucketed straight into their tile's
+//    segment (block-aggregated LDS histograms -> one global atomic per (block,tile)),
+//    then each tile is sorted on its own in LDS by the unique key
+//    (depth_bits << 32 | gaussian_index), which reproduces the upstream stable
+//    (tile|depth) order exactly and makes the result independent of atomic order;
+//  * per-(view,Gaussian) data the blend kernels gather is one 48-byte record;
+//  * no host synchronisation: the pair count stays on the device, capacity
+//    overflow raises a flag in the workspace header.
+#include "mgr_common.h"
+
+thread_local char g_mgr_err[512] = {0};
+
+extern "C" int mgr_version(void) { return MGR_VERSION; }
+extern "C" const char* mgr_last_error(void) { return g_mgr_err; }
+
+extern "C" size_t mgr_raster_workspace_bytes(int V, int N, int W, int H, int64_t cap) {
+    return mgr_layout(V, N, W, H, cap).total;
+}
+
+// ---------------------------------------------------------------------------
+// block-wide exclusive scan of one uint per thread (blockDim.x = 1024 or 256)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t val, uint32_t* s_wave /*>=17*/,
+                                                    uint32_t& block_total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    uint32_t incl = val;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int w = 0; w < nw; ++w) {
+            uint32_t t = s_wave[w];
+            s_wave[w] = run;
+            run += t;
+        }
+        s_wave[nw] = run;
+    }
+    __syncthreads();
+    block_total = s_wave[nw];
+    uint32_t r = s_wave[wave] + incl - val;
+    __syncthreads();
+    return r;
+}
+
+// ---------------------------------------------------------------------------
+// K1: per-Gaussian projection, EWA conic, radius, tile rectangle; per-tile
+// counts (LDS-aggregated); pair-slot offsets (block scan + one atomic per block)
+// ---------------------------------------------------------------------------
+#define PRE_THREADS 1024
+
+__global__ __launch_bounds__(PRE_THREADS) void k_preprocess(
+    int N, int W, int H, int gx, int gy, const float* __restrict__ cams,
+    const float* __restrict__ means3D, int64_t s_means, const float* __restrict__ cov3D,
+    int64_t s_cov, const float* __restrict__ colors, int64_t s_col,
+    const float* __restrict__ opacity, int64_t s_op, MgrGRec* __restrict__ grec,
+    float* __restrict__ depth, ushort4* __restrict__ rect, uint32_t* __restrict__ pair_off,
+    uint32_t* __restrict__ tile_count, int32_t* __restrict__ radii, MgrHeader* hdr, int lds_hist) {
+    extern __shared__ uint32_t s_mem[];
+    uint32_t* s_scan = s_mem;       // 32 words
+    uint32_t* s_hist = s_mem + 32;  // gx*gy words when lds_hist
+    const int v = blockIdx.y, tid = threadIdx.x;
+    const int i = blockIdx.x * PRE_THREADS + tid;
+    const int T = gx * gy;
+    if (lds_hist) {
+        for (int k = tid; k < T; k += PRE_THREADS) s_hist[k] = 0;
+    }
+    __syncthreads();
+
+    MgrCam cam;
+    mgr_load_cam(cams, v, cam);
+
+    int radius = 0, x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+    float px = 0.f, py = 0.f, ca = 0.f, cb = 0.f, cc = 0.f, zv = 0.f;
+    if (i < N) {
+        const float* mp = means3D + (size_t)v * s_means + (size_t)i * 3;
+        const float p[3] = {mp[0], mp[1], mp[2]};
+        const float* vm = cam.view;
+        const float* pm = cam.proj;
+        zv = vm[2] * p[0] + vm[6] * p[1] + vm[10] * p[2] + vm[14];
+        if (zv > 0.2f) {
+            const float hx = pm[0] * p[0] + pm[4] * p[1] + pm[8] * p[2] + pm[12];
+            const float hy = pm[1] * p[0] + pm[5] * p[1] + pm[9] * p[2] + pm[13];
+            const float hw = pm[3] * p[0] + pm[7] * p[1] + pm[11] * p[2] + pm[15];
+            const float pw = 1.0f / (hw + 0.0000001f);
+            const float ndx = hx * pw, ndy = hy * pw;
+            const float* cp = cov3D + (size_t)v * s_cov + (size_t)i * 6;
+            const float c6[6] = {cp[0], cp[1], cp[2], cp[3], cp[4], cp[5]};
+            float M0[3], M1[3], t[3], xm, ym, fx, fy, S0[3], S1[3];
+            mgr_ewa_rows(cam, (float)W, (float)H, p, M0, M1, t, xm, ym, fx, fy);
+            mgr_sym_mul(c6, M0, S0);
+            mgr_sym_mul(c6, M1, S1);
+            const float a = M0[0] * S0[0] + M0[1] * S0[1] + M0[2] * S0[2] + 0.3f;
+            const float b = M0[0] * S1[0] + M0[1] * S1[1] + M0[2] * S1[2];
+            const float c = M1[0] * S1[0] + M1[1] * S1[1] + M1[2] * S1[2] + 0.3f;
+            const float det = a * c - b * b;
+            if (det != 0.0f) {
+                const float dinv = 1.0f / det;
+                const float mid = 0.5f * (a + c);
+                const float sq = sqrtf(fmaxf(0.1f, mid * mid - det));
+                const int rad = (int)ceilf(3.0f * sqrtf(fmaxf(mid + sq, mid - sq)));
+                px = ((ndx + 1.0f) * (float)W - 1.0f) * 0.5f;
+                py = ((ndy + 1.0f) * (float)H - 1.0f) * 0.5f;
+                const float fr = (float)rad;
+                x0 = min(gx, max(0, (int)((px - fr) / 16.0f)));
+                y0 = min(gy, max(0, (int)((py - fr) / 16.0f)));
+                x1 = min(gx, max(0, (int)((px + fr + 15.0f) / 16.0f)));
+                y1 = min(gy, max(0, (int)((py + fr + 15.0f) / 16.0f)));
+                if ((x1 - x0) * (y1 - y0) > 0) {
+                    radius = rad;
+                    ca = c * dinv;
+                    cb = -b * dinv;
+                    cc = a * dinv;
+                } else {
+                    x0 = y0 = x1 = y1 = 0;
+                }
+            }
+        }
+    }
+    const uint32_t tiles = (uint32_t)((x1 - x0) * (y1 - y0));
+
+    // tile histogram
+    if (radius > 0) {
+        if (lds_hist) {
+            for (int y = y0; y < y1; ++y)
+                for (int x = x0; x < x1; ++x) atomicAdd(&s_hist[y * gx + x], 1u);
+        } else {
+            for (int y = y0; y < y1; ++y)
+                for (int x = x0; x < x1; ++x) atomicAdd(&tile_count[(size_t)v * T + y * gx + x], 1u);
+        }
+    }
+
+    // pair-slot offsets: contiguous per Gaussian; block base from one atomic
+    uint32_t block_total;
+    const uint32_t local = block_excl_scan(tiles, s_scan, block_total);
+    if (tid == 0) s_scan[20] = block_total ? atomicAdd(&hdr->total_pairs, block_total) : 0u;
+    __syncthreads();
+    const uint32_t off = s_scan[20] + local;
+
+    if (i < N) {
+        const size_t vi = (size_t)v * N + i;
+        MgrGRec r;
+        r.x = px; r.y = py; r.ca = ca; r.cb = cb; r.cc = cc;
+        r.op = opacity[(size_t)v * s_op + i];
+        const float* col = colors + (size_t)v * s_col + (size_t)i * 3;
+        r.r = col[0]; r.g = col[1]; r.b = col[2];
+        r.rect_w = x1 - x0;
+        r.slot_base = (int32_t)off - y0 * (x1 - x0) - x0;
+        r.pad = 0;
+        grec[vi] = r;
+        depth[vi] = zv;
+        rect[vi] = make_ushort4((unsigned short)x0, (unsigned short)y0, (unsigned short)x1,
+                                (unsigned short)y1);
+        pair_off[vi] = off;
+        radii[vi] = radius;
+    }
+
+    if (lds_hist) {
+        __syncthreads();
+        for (int k = tid; k < T; k += PRE_THREADS) {
+            const uint32_t c = s_hist[k];
+            if (c) atomicAdd(&tile_count[(size_t)v * T + k], c);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K2: exclusive scan of the V*T tile counts -> tile_start; queue of non-empty
+// tiles ordered by descending size class (largest first = LPT scheduling)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_tile_scan(int VT, const uint32_t* __restrict__ tile_count,
+                                                    uint32_t* __restrict__ tile_start,
+                                                    uint32_t* __restrict__ tile_cursor,
+                                                    uint32_t* __restrict__ tile_queue,
+                                                    MgrHeader* hdr, uint32_t cap) {
+    __shared__ uint32_t s_scan[32];
+    __shared__ uint32_t s_cls[34];
+    const int tid = threadIdx.x;
+    const int per = (VT + 1023) / 1024;
+    const int b = tid * per, e = min(VT, b + per);
+    if (tid < 34) s_cls[tid] = 0;
+    uint32_t sum = 0;
+    for (int k = b; k < e; ++k) sum += tile_count[k];
+    uint32_t total;
+    uint32_t run = block_excl_scan(sum, s_scan, total);
+    for (int k = b; k < e; ++k) {
+        const uint32_t c = tile_count[k];
+        tile_start[k] = run;
+        tile_cursor[k] = 0;
+        run += c;
+        if (c) atomicAdd(&s_cls[32 - __clz(c)], 1u);
+    }
+    if (tid == 0) {
+        tile_start[VT] = total;
+        hdr->overflow = (total > cap || hdr->total_pairs > cap) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (tid == 0) {  // descending class order
+        uint32_t r = 0;
+        for (int c = 33; c >= 0; --c) {
+            const uint32_t t = s_cls[c];
+            s_cls[c] = r;
+            r += t;
+        }
+        hdr->queue_len = r;
+        hdr->queue_head = 0;
+        hdr->queue_head2 = 0;
+    }
+    __syncthreads();
+    for (int k = b; k < e; ++k) {
+        const uint32_t c = tile_count[k];
+        if (c) tile_queue[atomicAdd(&s_cls[32 - __clz(c)], 1u)] = (uint32_t)k;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K3: emit one 64-bit key per (Gaussian, tile) pair directly into the tile's
+// segment.  Slot within the segment: block base (one returning global atomic per
+// (block, non-empty tile)) + LDS rank.  Order inside a segment is arbitrary; the
+// per-tile sort on a unique key makes the final order deterministic.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(PRE_THREADS) void k_emit(int N, int gx, int gy,
+                                                      const float* __restrict__ depth,
+                                                      const ushort4* __restrict__ rect,
+                                                      const uint32_t* __restrict__ tile_start,
+                                                      uint32_t* __restrict__ tile_cursor,
+                                                      unsigned long long* __restrict__ keys,
+                                                      uint32_t cap, int lds_hist) {
+    extern __shared__ uint32_t s_mem[];
+    uint32_t* s_hist = s_mem;
+    const int v = blockIdx.y, tid = threadIdx.x;
+    const int i = blockIdx.x * PRE_THREADS + tid;
+    const int T = gx * gy;
+    ushort4 rc = make_ushort4(0, 0, 0, 0);
+    float z = 0.f;
+    if (i < N) {
+        rc = rect[(size_t)v * N + i];
+        z = depth[(size_t)v * N + i];
+    }
+    const unsigned long long key_hi = ((unsigned long long)__float_as_uint(z)) << 32;
+    if (lds_hist) {
+        for (int k = tid; k < T; k += PRE_THREADS) s_hist[k] = 0;
+        __syncthreads();
+        for (int y = rc.y; y < rc.w; ++y)
+            for (int x = rc.x; x < rc.z; ++x) atomicAdd(&s_hist[y * gx + x], 1u);
+        __syncthreads();
+        for (int k = tid; k < T; k += PRE_THREADS) {
+            const uint32_t c = s_hist[k];
+            if (c) s_hist[k] = tile_start[(size_t)v * T + k] + atomicAdd(&tile_cursor[(size_t)v * T + k], c);
+        }
+        __syncthreads();
+        for (int y = rc.y; y < rc.w; ++y)
+            for (int x = rc.x; x < rc.z; ++x) {
+                const uint32_t pos = atomicAdd(&s_hist[y * gx + x], 1u);
+                if (pos < cap) keys[pos] = key_hi | (unsigned)i;
+            }
+    } else {
+        for (int y = rc.y; y < rc.w; ++y)
+            for (int x = rc.x; x < rc.z; ++x) {
+                const size_t vt = (size_t)v * T + y * gx + x;
+                const uint32_t pos = tile_start[vt] + atomicAdd(&tile_cursor[vt], 1u);
+                if (pos < cap) keys[pos] = key_hi | (unsigned)i;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K4: per-tile sort.  Persistent workgroups pull tiles (largest first) from the
+// queue.  Segments up to SORT_LDS_KEYS keys are sorted in LDS, larger ones in
+// place in global memory (L2-resident) by the same network.  The network is the
+// "mirror" bitonic form whose compare-exchanges all point the same way, so the
+// tail beyond n behaves as +inf without being stored.
+// ---------------------------------------------------------------------------
+#define SORT_THREADS 1024
+#define SORT_LDS_KEYS 16384
+
+template <typename KeyPtr>
+__device__ __forceinline__ void bitonic_mirror(KeyPtr a, uint32_t n, uint32_t npad, int tid,
+                                               int nthreads) {
+    const uint32_t half = npad >> 1;
+    for (uint32_t k = 2; k <= npad; k <<= 1) {
+        {   // mirror step: i vs block_end - offset
+            const uint32_t hk = k >> 1;
+            for (uint32_t t = tid; t < half; t += nthreads) {
+                const uint32_t blk = t / hk, off = t - blk * hk;
+                const uint32_t i = blk * k + off, l = blk * k + (k - 1 - off);
+                if (l < n) {
+                    const unsigned long long x = a[i], y = a[l];
+                    if (x > y) { a[i] = y; a[l] = x; }
+                }
+            }
+            __syncthreads();
+        }
+        for (uint32_t j = k >> 2; j > 0; j >>= 1) {
+            for (uint32_t t = tid; t < half; t += nthreads) {
+                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i + j;
+                if (l < n) {
+                    const unsigned long long x = a[i], y = a[l];
+                    if (x > y) { a[i] = y; a[l] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(SORT_THREADS) void k_tile_sort(
+    const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ tile_queue,
+    unsigned long long* __restrict__ keys, uint32_t* __restrict__ sorted_gid, MgrHeader* hdr,
+    uint32_t cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    unsigned long long* s_keys = (unsigned long long*)s_raw;
+    // all LDS in the one dynamic array (keeps the 8-byte key accesses aligned)
+    uint32_t* s_item = (uint32_t*)(s_raw + (size_t)SORT_LDS_KEYS * 8);
+    const int tid = threadIdx.x;
+    const uint32_t qlen = hdr->queue_len;
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) *s_item = atomicAdd(&hdr->queue_head, 1u);
+        __syncthreads();
+        const uint32_t item = *s_item;
+        if (item >= qlen) break;
+        const uint32_t vt = tile_queue[item];
+        const uint32_t start = min(tile_start[vt], cap), end = min(tile_start[vt + 1], cap);
+        const uint32_t n = end - start;
+        if (n == 0) continue;
+        uint32_t npad = 1;
+        while (npad < n) npad <<= 1;
+        if (n <= SORT_LDS_KEYS) {
+            for (uint32_t t = tid; t < n; t += SORT_THREADS) s_keys[t] = keys[start + t];
+            __syncthreads();
+            if (n > 1) bitonic_mirror(s_keys, n, npad, tid, SORT_THREADS);
+            for (uint32_t t = tid; t < n; t += SORT_THREADS) sorted_gid[start + t] = (uint32_t)s_keys[t];
+        } else {
+            __syncthreads();
+            bitonic_mirror(keys + start, n, npad, tid, SORT_THREADS);
+            __threadfence_block();
+            for (uint32_t t = tid; t < n; t += SORT_THREADS) sorted_gid[start + t] = (uint32_t)keys[start + t];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K5: front-to-back alpha compositing, one 16x16 tile per 256-thread workgroup
+// (wave w = pixel rows 4w..4w+3), tile list staged through LDS 256 entries at a time
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, int gy,
+                                                   const float* __restrict__ bg,
+                                                   const uint32_t* __restrict__ tile_start,
+                                                   const uint32_t* __restrict__ sorted_gid,
+                                                   const MgrGRec* __restrict__ grec,
+                                                   float* __restrict__ out_color,
+                                                   float* __restrict__ final_T,
+                                                   uint32_t* __restrict__ n_contrib,
+                                                   uint32_t* __restrict__ tile_done, uint32_t cap) {
+    __shared__ float2 s_xy[256];
+    __shared__ float4 s_co[256];
+    __shared__ float s_rgb[256 * 3];
+    __shared__ uint32_t s_max;
+    const int v = blockIdx.z, tid = threadIdx.x;
+    const int T = gx * gy;
+    const size_t vt = (size_t)v * T + blockIdx.y * gx + blockIdx.x;
+    const uint32_t start = min(tile_start[vt], cap), end = min(tile_start[vt + 1], cap);
+    const int px = blockIdx.x * 16 + (tid & 15), py = blockIdx.y * 16 + (tid >> 4);
+    const bool inside = px < W && py < H;
+    const float fpx = (float)px, fpy = (float)py;
+    if (tid == 0) s_max = 0;
+    float Tr = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
+    uint32_t contributor = 0, last = 0;
+    bool done = !inside;
+    for (uint32_t base = start; base < end; base += 256) {
+        if (__syncthreads_count(done) == 256) break;
+        const uint32_t idx = base + tid;
+        if (idx < end) {
+            const MgrGRec* r = grec + (size_t)v * N + sorted_gid[idx];
+            const float4 a = *(const float4*)r;
+            const float4 b = *((const float4*)r + 1);
+            const float c = r->b;
+            s_xy[tid] = make_float2(a.x, a.y);
+            s_co[tid] = make_float4(a.z, a.w, b.x, b.y);
+            s_rgb[tid * 3 + 0] = b.z;
+            s_rgb[tid * 3 + 1] = b.w;
+            s_rgb[tid * 3 + 2] = c;
+        }
+        __syncthreads();
+        const int cnt = (int)min(256u, end - base);
+        for (int j = 0; !done && j < cnt; ++j) {
+            ++contributor;
+            const float2 xy = s_xy[j];
+            const float4 co = s_co[j];
+            const float dx = xy.x - fpx, dy = xy.y - fpy;
+            const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+            if (power > 0.0f) continue;
+            const float alpha = fminf(0.99f, co.w * expf(power));
+            if (alpha < 1.0f / 255.0f) continue;
+            const float testT = Tr * (1.0f - alpha);
+            if (testT < 0.0001f) {
+                done = true;
+                continue;
+            }
+            const float w = alpha * Tr;
+            C0 += s_rgb[j * 3 + 0] * w;
+            C1 += s_rgb[j * 3 + 1] * w;
+            C2 += s_rgb[j * 3 + 2] * w;
+            Tr = testT;
+            last = contributor;
+        }
+    }
+    if (inside) {
+        const size_t P = (size_t)W * H, pix = (size_t)py * W + px;
+        final_T[(size_t)v * P + pix] = Tr;
+        n_contrib[(size_t)v * P + pix] = last;
+        float* o = out_color + (size_t)v * 3 * P + pix;
+        o[0] = C0 + Tr * bg[0];
+        o[P] = C1 + Tr * bg[1];
+        o[2 * P] = C2 + Tr * bg[2];
+    }
+    // per-tile depth actually consumed (drives the backward pass)
+    uint32_t m = last;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
+    __syncthreads();
+    if ((tid & 63) == 0) atomicMax(&s_max, m);
+    __syncthreads();
+    if (tid == 0) tile_done[vt] = s_max;
+}
+
+// ---------------------------------------------------------------------------
+// host entry
+// ---------------------------------------------------------------------------
+extern "C" int mgr_raster_forward(int V, int N, int W, int H, const float* cams, const float* bg,
+                                  const float* means3D, int64_t s_means, const float* cov3D,
+                                  int64_t s_cov, const float* colors, int64_t s_col,
+                                  const float* opacity, int64_t s_op, float* out_color,
+                                  int32_t* radii, void* workspace, size_t workspace_bytes,
+                                  int64_t cap, int debug, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (V <= 0 || N < 0 || W <= 0 || H <= 0 || cap < 0 || cap > 0xFFFFFFF0ll)
+        return mgr_fail(MGR_EINVAL, "mgr_raster_forward: bad sizes");
+    if (!cams || !bg || !out_color || !workspace || (N > 0 && (!means3D || !cov3D || !colors || !opacity || !radii)))
+        return mgr_fail(MGR_EINVAL, "mgr_raster_forward: null pointer");
+    const int gx = (W + 15) / 16, gy = (H + 15) / 16, T = gx * gy;
+    if (gx > 65535 || gy > 65535) return mgr_fail(MGR_EINVAL, "mgr_raster_forward: image too large");
+    const MgrLayout L = mgr_layout(V, N, W, H, cap);
+    if (workspace_bytes < L.total) return mgr_fail(MGR_ENOMEM, "mgr_raster_forward: workspace too small");
+    char* ws = (char*)workspace;
+    MgrHeader* hdr = (MgrHeader*)(ws + L.header);
+    uint32_t* tile_count = (uint32_t*)(ws + L.tile_count);
+    uint32_t* tile_start = (uint32_t*)(ws + L.tile_start);
+    const int VT = V * T;
+
+    static bool attr_set = false;
+    if (!attr_set) {
+        MGR_HIP(hipFuncSetAttribute((const void*)k_tile_sort, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    SORT_LDS_KEYS * 8 + 16));
+        MGR_HIP(hipFuncSetAttribute((const void*)k_preprocess, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    152 * 1024));
+        MGR_HIP(hipFuncSetAttribute((const void*)k_emit, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    152 * 1024));
+        attr_set = true;
+    }
+
+    // per-call counters (epoch lives past the first 32 bytes and persists)
+    MGR_HIP(hipMemsetAsync(hdr, 0, 8, stream));
+    MGR_HIP(hipMemsetAsync(tile_count, 0, (size_t)VT * 4, stream));
+
+    const int lds_hist = ((size_t)T * 4 + 128 <= 150 * 1024) ? 1 : 0;
+    const size_t hist_bytes = lds_hist ? (size_t)T * 4 : 0;
+    if (N > 0) {
+        dim3 grid((N + PRE_THREADS - 1) / PRE_THREADS, V);
+        hipLaunchKernelGGL(k_preprocess, grid, dim3(PRE_THREADS), 128 + hist_bytes, stream, N, W, H, gx,
+                           gy, cams, means3D, s_means, cov3D, s_cov, colors, s_col, opacity, s_op,
+                           (MgrGRec*)(ws + L.grec), (float*)(ws + L.depth), (ushort4*)(ws + L.rect),
+                           (uint32_t*)(ws + L.pair_off), tile_count, radii, hdr, lds_hist);
+        MGR_LAUNCH_CHECK("k_preprocess", stream, debug);
+    }
+    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, stream, VT, tile_count, tile_start,
+                       (uint32_t*)(ws + L.tile_cursor), (uint32_t*)(ws + L.tile_queue), hdr,
+                       (uint32_t)cap);
+    MGR_LAUNCH_CHECK("k_tile_scan", stream, debug);
+    if (N > 0) {
+        dim3 grid((N + PRE_THREADS - 1) / PRE_THREADS, V);
+        hipLaunchKernelGGL(k_emit, grid, dim3(PRE_THREADS), hist_bytes + 16, stream, N, gx, gy,
+                           (const float*)(ws + L.depth), (const ushort4*)(ws + L.rect), tile_start,
+                           (uint32_t*)(ws + L.tile_cursor), (unsigned long long*)(ws + L.keys),
+                           (uint32_t)cap, lds_hist);
+        MGR_LAUNCH_CHECK("k_emit", stream, debug);
+        hipLaunchKernelGGL(k_tile_sort, dim3(256), dim3(SORT_THREADS), SORT_LDS_KEYS * 8 + 16, stream,
+                           tile_start, (const uint32_t*)(ws + L.tile_queue),
+                           (unsigned long long*)(ws + L.keys), (uint32_t*)(ws + L.sorted_gid), hdr,
+                           (uint32_t)cap);
+        MGR_LAUNCH_CHECK("k_tile_sort", stream, debug);
+    }
+    hipLaunchKernelGGL(k_blend_fwd, dim3(gx, gy, V), dim3(256), 0, stream, N, W, H, gx, gy, bg, tile_start,
+                       (const uint32_t*)(ws + L.sorted_gid), (const MgrGRec*)(ws + L.grec), out_color,
+                       (float*)(ws + L.final_T), (uint32_t*)(ws + L.n_contrib),
+                       (uint32_t*)(ws + L.tile_done), (uint32_t)cap);
+    MGR_LAUNCH_CHECK("k_blend_fwd", stream, debug);
+    return MGR_OK;
+}
+
+extern "C" int mgr_raster_status_sync(const void* workspace, int64_t* num_pairs, int32_t* overflow,
+                                      void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    uint32_t h[2] = {0, 0};
+    MGR_HIP(hipMemcpyAsync(h, workspace, 8, hipMemcpyDeviceToHost, stream));
+    MGR_HIP(hipStreamSynchronize(stream));
+    if (num_pairs) *num_pairs = h[0];
+    if (overflow) *overflow = (int32_t)h[1];
+    if (h[1]) return mgr_fail(MGR_EOVERFLOW, "pair capacity exceeded");
+    return MGR_OK;
+}
+
+extern "C" int mgr_raster_debug_binning_sync(const void* workspace, int V, int N, int W, int H,
+                                             int64_t cap, int view, int32_t* tile_ranges_host,
+                                             int32_t* point_list_host, int64_t max_pairs,
+                                             void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const int gx = (W + 15) / 16, gy = (H + 15) / 16, T = gx * gy;
+    if (view < 0 || view >= V) return mgr_fail(MGR_EINVAL, "bad view");
+    const MgrLayout L = mgr_layout(V, N, W, H, cap);
+    const char* ws = (const char*)workspace;
+    uint32_t* ts = (uint32_t*)malloc((size_t)(T + 1) * 4);
+    MGR_HIP(hipMemcpyAsync(ts, ws + L.tile_start + (size_t)view * T * 4, (size_t)(T + 1) * 4,
+                           hipMemcpyDeviceToHost, stream));
+    MGR_HIP(hipStreamSynchronize(stream));
+    const uint32_t b = ts[0], e = ts[T];
+    for (int t = 0; t < T; ++t) {
+        tile_ranges_host[2 * t] = (int32_t)(ts[t] - b);
+        tile_ranges_host[2 * t + 1] = (int32_t)(ts[t + 1] - b);
+    }
+    free(ts);
+    int64_t n = (int64_t)e - (int64_t)b;
+    if (n > max_pairs) n = max_pairs;
+    if (n > 0 && point_list_host) {
+        MGR_HIP(hipMemcpyAsync(point_list_host, ws + L.sorted_gid + (size_t)b * 4, (size_t)n * 4,
+                               hipMemcpyDeviceToHost, stream));
+        MGR_HIP(hipStreamSynchronize(stream));
+    }
+    return MGR_OK;
+}

@@ -1,0 +1,128 @@
+"""Multi-view training step: V views batched per GPU, views sharded across GPUs,
+one all-reduce of the per-Gaussian gradients (RCCL over xGMI via torch.distributed).
+
+The reference trains one (frame, view) per step on one GPU (config/trainer/trainer.yaml:5,
+main.py:84-87 DDP commented out).  "V views per iteration" is defined here as
+    grad = (1/V) * sum_v grad(L_v)            (with V=1 it is the reference step)
+and the densification statistics follow the reference's per-view rule
+(src/models/gaussian.py:335-338, src/utils/gaussian_utils.py:469-471):
+    xyz_gradient_accum += sum_v ||d L_v / d means2D[:, :2]||   (visible Gaussians only)
+    denom              += sum_v visible_v
+    max_radii2D         = max_v radii_v
+"""
+import torch
+import torch.distributed as dist
+
+# packed leaf-gradient layout: 59 floats per Gaussian
+GRAD_LAYOUT = (("_xyz", 3), ("_features_dc", 3), ("_features_rest", 45), ("_opacity", 1),
+               ("_scaling", 3), ("_rotation", 4))
+GRAD_WIDTH = sum(w for _, w in GRAD_LAYOUT)
+
+
+def shard_views(n_views, rank, world_size):
+    """Round-robin assignment of view indices to ranks."""
+    return list(range(rank, n_views, world_size))
+
+
+def pack_grads(grads, N, device):
+    buf = torch.empty((N, GRAD_WIDTH), dtype=torch.float32, device=device)
+    o = 0
+    for name, w in GRAD_LAYOUT:
+        buf[:, o:o + w] = grads[name].reshape(N, w)
+        o += w
+    return buf
+
+
+def unpack_grads(buf, shapes):
+    out, o = {}, 0
+    for name, w in GRAD_LAYOUT:
+        out[name] = buf[:, o:o + w].reshape(shapes[name])
+        o += w
+    return out
+
+
+class ViewShardedStep:
+    """Runs `compute_fn(view_ids)` on this rank's views and reduces across ranks.
+
+    compute_fn returns a dict with
+        grads      {leaf name: sum over the given views of dL_v/dleaf}
+        grad2d     (N,) sum over views of the visible 2D-gradient norms
+        vis        (N,) number of views in which the Gaussian was visible
+        radii      (N,) int32 max screen radius over views
+        loss       scalar tensor, sum of L_v
+    """
+
+    def __init__(self, n_gaussians, shapes, compute_fn, n_views, rank=0, world_size=1, group=None):
+        self.N, self.shapes, self.compute_fn = n_gaussians, shapes, compute_fn
+        self.n_views, self.rank, self.world, self.group = n_views, rank, world_size, group
+        self.local_views = shard_views(n_views, rank, world_size)
+
+    def step(self):
+        out = self.compute_fn(self.local_views)
+        dev = out["grad2d"].device
+        N = self.N
+        flat = torch.empty(N * (GRAD_WIDTH + 2) + 1, dtype=torch.float32, device=dev)
+        flat[: N * GRAD_WIDTH] = pack_grads(out["grads"], N, dev).reshape(-1)
+        flat[N * GRAD_WIDTH: N * (GRAD_WIDTH + 1)] = out["grad2d"]
+        flat[N * (GRAD_WIDTH + 1): N * (GRAD_WIDTH + 2)] = out["vis"]
+        flat[-1] = out["loss"]
+        radii = out["radii"].to(torch.int32)
+        if self.world > 1:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_reduce(radii, op=dist.ReduceOp.MAX, group=self.group)
+        inv = 1.0 / float(self.n_views)
+        grads = unpack_grads((flat[: N * GRAD_WIDTH] * inv).reshape(N, GRAD_WIDTH), self.shapes)
+        return dict(grads=grads, grad2d=flat[N * GRAD_WIDTH: N * (GRAD_WIDTH + 1)],
+                    vis=flat[N * (GRAD_WIDTH + 1): N * (GRAD_WIDTH + 2)], radii=radii,
+                    loss=flat[-1] * inv)
+
+
+class HipViewCompute:
+    """compute_fn over the HIP kernels: skin weights once, LBS per pose, SH colour and
+    rasterisation per view, L1 image loss (rgb_loss of src/modules/base.py:329-331),
+    backward to the six leaf tensors.  All local views go through every kernel launch
+    together."""
+
+    def __init__(self, scene, targets, cam_table, loss_weight=1.0):
+        from . import ops, rasterizer
+        self.ops, self.rz = ops, rasterizer
+        self.s = scene
+        self.targets = targets          # (V_all,3,H,W) on the GPU
+        self.cams = cam_table           # (V_all,40)
+        self.loss_weight = loss_weight
+        self.is_hand = scene.get("grid") is not None and scene["kind"] == "hand"
+        self.params = {k: v.detach().clone().requires_grad_(True) for k, v in scene["params"].items()}
+
+    def forward_views(self, view_ids):
+        s, p, ops = self.s, self.params, self.ops
+        cams = self.cams[view_ids].contiguous()
+        V = len(view_ids)
+        feats = torch.cat([p["_features_dc"], p["_features_rest"]], dim=1)
+        opac = torch.sigmoid(p["_opacity"])
+        if self.is_hand:
+            w = ops.skin_weights(p["_xyz"], s["grid"], s["grid_center"], s["grid_scale"])
+            T = s["transforms"][view_ids].contiguous()  # one pose per view (reference: one (frame,view) per step)
+            pxyz, pcov, tf = ops.lbs_cov(p["_xyz"], p["_scaling"], p["_rotation"], w, T)
+            col = ops.sh_colors(feats, p["_xyz"], tf, cams)
+        else:
+            pxyz1, pcov1, _ = ops.lbs_cov(p["_xyz"], p["_scaling"], p["_rotation"], None, None)
+            pxyz, pcov = p["_xyz"], pcov1[0]
+            col = ops.sh_colors(feats, p["_xyz"], None, cams)
+        N = p["_xyz"].shape[0]
+        means2D = torch.zeros((V, N, 3), dtype=torch.float32, device=cams.device, requires_grad=True)
+        img, radii = self.rz.rasterize_views(cams, pxyz, means2D, col, opac, pcov, s["bg"], s["width"], s["height"])
+        return img, radii, means2D
+
+    def __call__(self, view_ids):
+        for v in self.params.values():
+            v.grad = None
+        img, radii, means2D = self.forward_views(view_ids)
+        tgt = self.targets[view_ids]
+        per_view = img[0].numel()
+        loss_sum, g = self.ops.l1_loss_grad(img, tgt, scale=self.loss_weight / per_view)
+        img.backward(g)
+        vis = radii > 0
+        g2 = means2D.grad[..., :2].norm(dim=-1)
+        return dict(grads={k: v.grad for k, v in self.params.items()},
+                    grad2d=(g2 * vis).sum(0), vis=vis.sum(0).float(),
+                    radii=radii.max(dim=0).values, loss=loss_sum[0] * (self.loss_weight / per_view))

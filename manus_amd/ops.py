@@ -1,0 +1,185 @@
+"""Autograd operators over the articulation kernels of libmanus_hip.so.
+
+Each op mirrors one block of MANUS Python code (reference tree brown-ivl/manus):
+
+    skin_weights   skinning_weights_from_voxel_grid      src/utils/gaussian_utils.py:167-196
+    lbs_cov        TrainingModule.forward LBS block      src/modules/hand_dynamic.py:106-127
+                   + GaussianModel.get_covariance        src/models/gaussian.py:49-53,84-93
+    sh_colors      calculate_colors_from_sh / eval_sh    src/utils/gaussian_utils.py:431-449
+    project_points project_points                        src/utils/transforms.py:304-311
+    distCUDA2      simple_knn._C.distCUDA2               src/models/gaussian.py:110
+
+All of them require GPU tensors; there is no CPU or PyTorch fallback.
+"""
+import torch
+
+from ._lib import MGR_MAX_BONES, ManusHipError, check, f32c, lib, ptr, stream
+
+
+class _SkinWeights(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xyz, grid, center, scale):
+        xyz, grid = f32c(xyz), f32c(grid)
+        center, scale = f32c(center).reshape(-1), f32c(scale).reshape(-1)
+        D, H, W, B = grid.shape
+        if B > MGR_MAX_BONES:
+            raise ManusHipError("skin_weights: at most %d transforms" % MGR_MAX_BONES)
+        N = xyz.shape[0]
+        w = torch.empty((N, B), dtype=torch.float32, device=xyz.device)
+        check(lib().mgr_skin_weights_fwd(N, ptr(xyz), ptr(grid), D, H, W, B, ptr(center), ptr(scale), ptr(w),
+                                         stream()), "mgr_skin_weights_fwd")
+        ctx.save_for_backward(xyz, grid, center, scale)
+        return w
+
+    @staticmethod
+    def backward(ctx, g_w):
+        xyz, grid, center, scale = ctx.saved_tensors
+        D, H, W, B = grid.shape
+        N = xyz.shape[0]
+        g_w = f32c(g_w)
+        g_xyz = torch.empty((N, 3), dtype=torch.float32, device=xyz.device)
+        check(lib().mgr_skin_weights_bwd(N, ptr(xyz), ptr(grid), D, H, W, B, ptr(center), ptr(scale), ptr(g_w),
+                                         ptr(g_xyz), stream()), "mgr_skin_weights_bwd")
+        return g_xyz, None, None, None
+
+
+def skin_weights(xyz, grid_weights, grid_center, grid_scale):
+    """xyz (N,3); grid_weights (D,H,W,B) channel-last on the GPU -> (N,B), rows sum to 1."""
+    return _SkinWeights.apply(xyz, grid_weights, grid_center, grid_scale)
+
+
+class _LbsCov(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xyz, log_scale, rot, skin_w, transforms):
+        xyz, log_scale, rot = f32c(xyz), f32c(log_scale), f32c(rot)
+        N = xyz.shape[0]
+        if skin_w is not None:
+            skin_w = f32c(skin_w)
+            transforms = f32c(transforms)
+            if transforms.dim() == 3:
+                transforms = transforms[None]
+            P, B = transforms.shape[0], transforms.shape[1]
+            if skin_w.shape[1] != B:
+                raise ManusHipError("lbs_cov: skin weights have %d columns, %d transforms given"
+                                    % (skin_w.shape[1], B))  # hand_dynamic.py:104
+        else:
+            P, B = 1, 0
+        dev = xyz.device
+        pxyz = torch.empty((P, N, 3), dtype=torch.float32, device=dev)
+        pcov = torch.empty((P, N, 6), dtype=torch.float32, device=dev)
+        tf = torch.empty((P, N, 12), dtype=torch.float32, device=dev)
+        check(lib().mgr_lbs_cov_fwd(P, N, B, ptr(xyz), ptr(log_scale), ptr(rot), ptr(skin_w), ptr(transforms),
+                                    ptr(pxyz), ptr(pcov), ptr(tf), stream()), "mgr_lbs_cov_fwd")
+        ctx.save_for_backward(xyz, log_scale, rot, skin_w, transforms)
+        ctx.meta = (P, N, B)
+        return pxyz, pcov, tf
+
+    @staticmethod
+    def backward(ctx, g_xyz, g_cov, g_tf):
+        xyz, log_scale, rot, skin_w, transforms = ctx.saved_tensors
+        P, N, B = ctx.meta
+        dev = xyz.device
+        g_xyz = f32c(g_xyz) if g_xyz is not None else torch.zeros((P, N, 3), dtype=torch.float32, device=dev)
+        g_cov = f32c(g_cov) if g_cov is not None else torch.zeros((P, N, 6), dtype=torch.float32, device=dev)
+        g_tf = f32c(g_tf) if g_tf is not None else None
+        d_xyz = torch.empty((N, 3), dtype=torch.float32, device=dev)
+        d_ls = torch.empty((N, 3), dtype=torch.float32, device=dev)
+        d_rot = torch.empty((N, 4), dtype=torch.float32, device=dev)
+        d_w = torch.empty((N, B), dtype=torch.float32, device=dev) if skin_w is not None else None
+        check(lib().mgr_lbs_cov_bwd(P, N, B, ptr(xyz), ptr(log_scale), ptr(rot), ptr(skin_w), ptr(transforms),
+                                    ptr(g_xyz), ptr(g_cov), ptr(g_tf), ptr(d_xyz), ptr(d_ls), ptr(d_rot),
+                                    ptr(d_w), stream()), "mgr_lbs_cov_bwd")
+        return d_xyz, d_ls, d_rot, d_w, None
+
+
+def lbs_cov(xyz, log_scale, rot, skin_w, transforms):
+    """Skin means and covariances for P poses.
+
+    xyz (N,3), log_scale (N,3) (`_scaling`), rot (N,4) raw (`_rotation`),
+    skin_w (N,B) or None (static object: identity transform),
+    transforms (P,B,4,4) / (B,4,4) = posed @ inv(rest) (+ identity background).
+    Returns posed_xyz (P,N,3), posed_cov (P,N,6), tf (P,N,12) (rows 0..2 of the
+    blended 4x4)."""
+    return _LbsCov.apply(xyz, log_scale, rot, skin_w, transforms)
+
+
+class _ShColors(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, sh, xyz, tf, cams):
+        sh, xyz = f32c(sh), f32c(xyz)
+        N = sh.shape[0]
+        V = cams.shape[0]
+        if sh.shape[1:] != (16, 3):
+            raise ManusHipError("sh_colors: features must be (N,16,3) (sh_degree 3)")
+        s_xyz = xyz.stride(0) if xyz.dim() == 3 else 0
+        s_tf = 0
+        if tf is not None:
+            tf = f32c(tf)
+            s_tf = tf.stride(0) if tf.dim() == 3 else 0
+        col = torch.empty((V, N, 3), dtype=torch.float32, device=sh.device)
+        check(lib().mgr_sh_color_fwd(V, N, ptr(sh), ptr(xyz), s_xyz, ptr(tf), s_tf, ptr(cams), ptr(col),
+                                     stream()), "mgr_sh_color_fwd")
+        ctx.save_for_backward(sh, xyz, tf, cams)
+        ctx.meta = (V, N, s_xyz, s_tf)
+        return col
+
+    @staticmethod
+    def backward(ctx, g_col):
+        sh, xyz, tf, cams = ctx.saved_tensors
+        V, N, s_xyz, s_tf = ctx.meta
+        dev = sh.device
+        g_col = f32c(g_col)
+        d_sh = torch.empty((N, 16, 3), dtype=torch.float32, device=dev)
+        d_xyz = torch.empty((V, N, 3), dtype=torch.float32, device=dev)
+        d_tf = torch.empty((V, N, 12), dtype=torch.float32, device=dev) if tf is not None else None
+        check(lib().mgr_sh_color_bwd(V, N, ptr(sh), ptr(xyz), s_xyz, ptr(tf), s_tf, ptr(cams), ptr(g_col),
+                                     ptr(d_sh), ptr(d_xyz), ptr(d_tf), stream()), "mgr_sh_color_bwd")
+        g_xyz = d_xyz if xyz.dim() == 3 else (d_xyz.sum(0) if V > 1 else d_xyz[0])
+        g_tf = None
+        if tf is not None:
+            g_tf = d_tf if tf.dim() == 3 else (d_tf.sum(0) if V > 1 else d_tf[0])
+        return d_sh, g_xyz, g_tf, None
+
+
+def sh_colors(features, xyz, tf, cams):
+    """Degree-3 SH colour for V views: features (N,16,3); xyz (N,3) or (V,N,3)
+    (canonical means when tf is given, posed means otherwise); tf (N,12)/(V,N,12)
+    or None; cams (V,40).  Returns (V,N,3) = max(sh2rgb + 0.5, 0)."""
+    return _ShColors.apply(features, xyz, tf, cams)
+
+
+def project_points(points, K, extrin):
+    """points (B,N,3) or (N,3); K (3,3); extrin (3,4) -> (...,N,2)."""
+    p = f32c(points)
+    shape = p.shape
+    flat = p.reshape(-1, 3)
+    K, E = f32c(K).reshape(-1)[:9].contiguous(), f32c(extrin).reshape(-1)[:12].contiguous()
+    uv = torch.empty((flat.shape[0], 2), dtype=torch.float32, device=p.device)
+    check(lib().mgr_project_points(flat.shape[0], ptr(flat), ptr(K), ptr(E), ptr(uv), stream()),
+          "mgr_project_points")
+    return uv.reshape(shape[:-1] + (2,))
+
+
+def distCUDA2(points):
+    """Mean squared distance to the 3 nearest other points, (N,3) -> (N,)."""
+    p = f32c(points)
+    N = p.shape[0]
+    out = torch.empty((N,), dtype=torch.float32, device=p.device)
+    nbytes = int(lib().mgr_knn3_workspace_bytes(N))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=p.device)
+    check(lib().mgr_knn3_mean_dist2(N, ptr(p), ptr(out), ptr(ws), nbytes, stream()), "mgr_knn3_mean_dist2")
+    return out
+
+
+def l1_loss_grad(pred, target, scale=None):
+    """sum|pred-target| (device scalar) and d(mean|pred-target|)/dpred * weight.
+    `scale` defaults to 1/numel (the reference's torch.mean of the L1 map)."""
+    pred, target = f32c(pred), f32c(target)
+    n = pred.numel()
+    if scale is None:
+        scale = 1.0 / n
+    g = torch.empty_like(pred)
+    s = torch.zeros(1, dtype=torch.float32, device=pred.device)
+    check(lib().mgr_l1_loss_grad(n, ptr(pred), ptr(target), float(scale), ptr(g), ptr(s), stream()),
+          "mgr_l1_loss_grad")
+    return s, g

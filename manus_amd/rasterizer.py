@@ -1,0 +1,261 @@
+"""Drop-in operator surface of `diff_gaussian_rasterization` on MI355X.
+
+Mirrors the interface MANUS imports at src/utils/gaussian_utils.py:18-21 and calls
+at :378-416 (reference tree brown-ivl/manus):
+
+    GaussianRasterizationSettings(image_height, image_width, tanfovx, tanfovy, bg,
+        scale_modifier, viewmatrix, projmatrix, sh_degree, campos, prefiltered, debug)
+    GaussianRasterizer(raster_settings)(means3D, means2D, opacities, shs=None,
+        colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None)
+        -> (color (3,H,W), radii (N,) int32)
+
+Everything is computed by hand-written HIP kernels through the C ABI of
+libmanus_hip.so; there is no PyTorch fallback.  `rasterize_views` is the
+multi-view batched form (V cameras in every launch) used by the training engine.
+"""
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import check, f32c, lib, ptr, stream
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+# ---------------------------------------------------------------------------
+# workspace pool: one opaque byte tensor links a forward to its backward
+# ---------------------------------------------------------------------------
+class RasterWorkspace:
+    def __init__(self, device, V, N, W, H, cap):
+        self.key = (V, N, W, H)
+        self.cap = int(cap)
+        self.nbytes = int(lib().mgr_raster_workspace_bytes(V, N, W, H, self.cap))
+        # zero-filled once: pair tags start at 0 = "never written"
+        self.buf = torch.zeros(self.nbytes, dtype=torch.uint8, device=device)
+        self.busy = False
+
+
+class _Pool:
+    def __init__(self):
+        self.items = {}
+
+    def acquire(self, device, V, N, W, H, min_cap):
+        lst = self.items.setdefault((str(device), V, N, W, H), [])
+        for ws in lst:
+            if not ws.busy and ws.cap >= min_cap:
+                ws.busy = True
+                return ws
+        # drop idle smaller workspaces before growing
+        lst[:] = [w for w in lst if w.busy]
+        ws = RasterWorkspace(device, V, N, W, H, min_cap)
+        ws.busy = True
+        lst.append(ws)
+        return ws
+
+    def clear(self):
+        self.items.clear()
+
+
+_POOL = _Pool()
+_CAP_HINT = {}  # (device,V,N,W,H) -> last observed pair count
+_POLICY = {"sync_every_forward": True}
+_LAST_WS = {"ws": None}
+
+
+def set_sync_policy(sync_every_forward):
+    """True (default, drop-in behaviour): every forward reads back the pair count
+    (one host sync, like the upstream extension) and transparently retries with a
+    larger workspace on overflow.  False (training engine): no host sync; the
+    capacity learnt so far is used and `check_overflow()` must be polled."""
+    _POLICY["sync_every_forward"] = bool(sync_every_forward)
+
+
+def check_overflow():
+    """Blocking check of the most recent forward's workspace; returns the pair
+    count, raises ManusHipError on overflow (after enlarging the capacity hint so
+    that a retry succeeds)."""
+    import ctypes
+    ws = _LAST_WS["ws"]
+    if ws is None:
+        return 0
+    npairs, ovf = ctypes.c_int64(0), ctypes.c_int32(0)
+    rc = lib().mgr_raster_status_sync(ptr(ws.buf), ctypes.byref(npairs), ctypes.byref(ovf), stream())
+    key = (str(ws.buf.device),) + ws.key
+    _CAP_HINT[key] = max(_CAP_HINT.get(key, 0), int(npairs.value * 1.25) + 4096)
+    if rc != 0:
+        check(rc, "rasterizer overflow check (retry: capacity hint was enlarged)")
+    return int(npairs.value)
+
+
+class _Lease:
+    """Releases the workspace when the autograd graph that needs it is freed."""
+
+    def __init__(self, ws):
+        self.ws = ws
+
+    def __del__(self):
+        self.ws.busy = False
+
+
+def default_pair_capacity(V, N):
+    return max(4096, 8 * V * max(N, 1))
+
+
+def _run_forward(cams, V, N, W, H, bg, means3D, cov3D, colors, opacity, debug, sync_check=True):
+    dev = means3D.device
+    key = (str(dev), V, N, W, H)
+    out = torch.empty((V, 3, H, W), dtype=torch.float32, device=dev)
+    radii = torch.empty((V, N), dtype=torch.int32, device=dev)
+    s_m = means3D.stride(0) if means3D.dim() == 3 else 0
+    s_c = cov3D.stride(0) if cov3D.dim() == 3 else 0
+    s_col = colors.stride(0) if colors.dim() == 3 else 0
+    s_o = opacity.stride(0) if opacity.dim() == 2 else 0
+    cap = max(_CAP_HINT.get(key, 0), default_pair_capacity(V, N))
+    while True:
+        ws = _POOL.acquire(dev, V, N, W, H, cap)
+        check(lib().mgr_raster_forward(V, N, W, H, ptr(cams), ptr(bg), ptr(means3D), s_m, ptr(cov3D), s_c,
+                                       ptr(colors), s_col, ptr(opacity), s_o, ptr(out), ptr(radii),
+                                       ptr(ws.buf), ws.nbytes, ws.cap, int(bool(debug)), stream()),
+              "mgr_raster_forward")
+        _LAST_WS["ws"] = ws
+        if not (sync_check and _POLICY["sync_every_forward"]):
+            return out, radii, ws, None
+        import ctypes
+        npairs, ovf = ctypes.c_int64(0), ctypes.c_int32(0)
+        rc = lib().mgr_raster_status_sync(ptr(ws.buf), ctypes.byref(npairs), ctypes.byref(ovf), stream())
+        if rc == 0:
+            _CAP_HINT[key] = max(_CAP_HINT.get(key, 0), int(npairs.value * 1.25) + 4096)
+            return out, radii, ws, int(npairs.value)
+        if rc != -4:
+            check(rc, "mgr_raster_status_sync")
+        ws.busy = False  # overflow: retry with room for the observed count
+        cap = int(npairs.value * 1.5) + 4096
+
+
+def _opacity_layout(op, V, N):
+    """(N,1)/(N,) -> shared (N); (V,N,1)/(V,N) -> per view (V,N)."""
+    if op.dim() == 3:
+        return op.reshape(V, N)
+    if op.dim() == 2 and op.shape[1] == 1:
+        return op.reshape(N)
+    if op.dim() == 2:
+        return op.reshape(V, N)
+    return op.reshape(N)
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, colors, opacities, cov3D, cams, bg, W, H, debug):
+        V = cams.shape[0]
+        means3D, colors, cov3D = f32c(means3D), f32c(colors), f32c(cov3D)
+        opac = f32c(opacities)
+        N = means3D.shape[-2]
+        opac = _opacity_layout(opac, V, N)
+        bg = f32c(bg).reshape(-1)
+        out, radii, ws, npairs = _run_forward(cams, V, N, W, H, bg, means3D, cov3D, colors, opac, debug)
+        ctx.lease = _Lease(ws)
+        ctx.meta = (V, N, W, H, bool(debug), means2D.shape, opacities.shape)
+        ctx.num_rendered = npairs
+        ctx.save_for_backward(means3D, colors, opac, cov3D, cams, bg)
+        ctx.mark_non_differentiable(radii)
+        return out, radii
+
+    @staticmethod
+    def backward(ctx, g_color, _g_radii):
+        means3D, colors, opac, cov3D, cams, bg = ctx.saved_tensors
+        V, N, W, H, debug, m2d_shape, op_shape = ctx.meta
+        ws = ctx.lease.ws
+        dev = means3D.device
+        g_color = f32c(g_color)
+        d_m3 = torch.empty((V, N, 3), dtype=torch.float32, device=dev)
+        d_m2 = torch.empty((V, N, 3), dtype=torch.float32, device=dev)
+        d_col = torch.empty((V, N, 3), dtype=torch.float32, device=dev)
+        d_op = torch.empty((V, N), dtype=torch.float32, device=dev)
+        d_cov = torch.empty((V, N, 6), dtype=torch.float32, device=dev)
+        s_m = means3D.stride(0) if means3D.dim() == 3 else 0
+        s_c = cov3D.stride(0) if cov3D.dim() == 3 else 0
+        s_col = colors.stride(0) if colors.dim() == 3 else 0
+        s_o = opac.stride(0) if opac.dim() == 2 else 0
+        check(lib().mgr_raster_backward(V, N, W, H, ptr(cams), ptr(bg), ptr(means3D), s_m, ptr(cov3D), s_c,
+                                        ptr(colors), s_col, ptr(opac), s_o, ptr(g_color), ptr(d_m3), ptr(d_m2),
+                                        ptr(d_col), ptr(d_op), ptr(d_cov), ptr(ws.buf), ws.nbytes, ws.cap,
+                                        int(debug), stream()), "mgr_raster_backward")
+
+        def fold(g, shared, shape=None):
+            # inputs shared by all views receive the sum over views
+            if shared:
+                g = g.sum(0) if V > 1 else g[0]
+            return g.reshape(shape) if shape is not None else g
+
+        g_m3 = fold(d_m3, means3D.dim() == 2)
+        g_m2 = fold(d_m2, len(m2d_shape) == 2, m2d_shape)
+        g_col = fold(d_col, colors.dim() == 2)
+        g_op = fold(d_op, opac.dim() == 1, op_shape)
+        g_cov = fold(d_cov, cov3D.dim() == 2)
+        return g_m3, g_m2, g_col, g_op, g_cov, None, None, None, None, None
+
+
+def rasterize_views(cams, means3D, means2D, colors, opacities, cov3D, bg, W, H, debug=False):
+    """V views in one call.  cams (V,40) from `_lib.pack_cameras`; per-Gaussian
+    inputs are (N,..) shared by all views or (V,N,..).  Returns color (V,3,H,W),
+    radii (V,N)."""
+    return _RasterizeGaussians.apply(means3D, means2D, colors, opacities, cov3D, cams, bg, int(W), int(H), debug)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        """In-frustum mask (view-space z > 0.2), as the upstream helper."""
+        with torch.no_grad():
+            vm = self.raster_settings.viewmatrix.reshape(4, 4).to(positions)
+            z = positions @ vm[:3, 2] + vm[3, 2]
+            return z > 0.2
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None,
+                rotations=None, cov3D_precomp=None):
+        rs = self.raster_settings
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or (
+                (scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        dev = means3D.device
+        if not means3D.is_cuda:
+            raise _lib.ManusHipError("GaussianRasterizer needs GPU tensors; there is no CPU fallback")
+        cams = _lib.pack_cameras(rs.tanfovx, rs.tanfovy, rs.viewmatrix, rs.projmatrix, rs.campos, dev)
+        if cov3D_precomp is None:
+            from .ops import lbs_cov
+            _, cov, _ = lbs_cov(means3D, torch.log(scales * rs.scale_modifier), rotations, None, None)
+            cov3D_precomp = cov[0]
+        if colors_precomp is None:
+            from .ops import sh_colors
+            K = (rs.sh_degree + 1) ** 2
+            sh = shs
+            if sh.shape[1] < 16 or K < 16:
+                full = torch.zeros((sh.shape[0], 16, 3), dtype=sh.dtype, device=dev)
+                k = min(K, sh.shape[1])
+                full[:, :k] = sh[:, :k]
+                sh = full
+            colors_precomp = sh_colors(sh, means3D, None, cams)[0]
+        color, radii = _RasterizeGaussians.apply(means3D, means2D, colors_precomp, opacities, cov3D_precomp,
+                                                 cams, rs.bg, int(rs.image_width), int(rs.image_height),
+                                                 bool(rs.debug))
+        return color[0], radii[0]

@@ -1,0 +1,122 @@
+"""CPU oracle package — TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+anything from here.  The product path (manus_amd/) never does; it fails loudly
+when its HIP extension is missing.
+
+* torch_ref.py      — pure-PyTorch restatement of the reference's LBS / covariance
+                      / SH / camera / FK code (pinned by tests/golden/*.npz which
+                      were produced by importing the reference).
+* raster_oracle.c   — scalar C restatement of the external rasterizer + kNN
+                      (PARITY UNPINNED upstream: no reference tests or vectors
+                      exist for that boundary; see raster_oracle_impl.h).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("raster_oracle.c", "raster_oracle_impl.h")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = ctypes.CDLL(build())
+        for sfx in ("_f32", "_f64"):
+            getattr(_LIB, "orc_forward" + sfx).restype = ctypes.c_void_p
+            getattr(_LIB, "orc_num_rendered" + sfx).restype = ctypes.c_long
+            for fn in ("orc_free", "orc_get_geom", "orc_get_binning", "orc_get_image_state", "orc_backward"):
+                getattr(_LIB, fn + sfx).restype = None
+        _LIB.orc_knn3_mean_dist2.restype = None
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+class RasterOracle:
+    """One forward (+ optional backward) of the scalar rasterizer.
+
+    view/proj are the (4,4) `world_view_transform` / `full_proj_transform`
+    tensors of the reference (row-major storage of the transposed matrices,
+    i.e. column-major math matrices; cam_utils.py:58-63)."""
+
+    def __init__(self, W, H, tanfovx, tanfovy, view, proj, means3D, cov3D, colors, opacity, bg,
+                 dtype=np.float32):
+        self.dt = np.dtype(dtype)
+        self.sfx = "_f32" if self.dt == np.float32 else "_f64"
+        self.c_real = ctypes.c_float if self.dt == np.float32 else ctypes.c_double
+        L = lib()
+        c = lambda a, shape=None: np.ascontiguousarray(np.asarray(a, dtype=self.dt).reshape(shape or np.shape(a)))
+        self.N = int(np.shape(means3D)[0])
+        self.W, self.H = int(W), int(H)
+        self.gx, self.gy = (self.W + 15) // 16, (self.H + 15) // 16
+        view, proj = c(view, (16,)), c(proj, (16,))
+        means3D, cov3D, colors = c(means3D, (self.N, 3)), c(cov3D, (self.N, 6)), c(colors, (self.N, 3))
+        opacity, bg = c(opacity, (self.N,)), c(bg, (3,))
+        self.color = np.zeros((3, self.H, self.W), dtype=self.dt)
+        self.radii = np.zeros((self.N,), dtype=np.int32)
+        self._h = getattr(L, "orc_forward" + self.sfx)(
+            ctypes.c_int(self.W), ctypes.c_int(self.H), self.c_real(tanfovx), self.c_real(tanfovy),
+            _p(view), _p(proj), ctypes.c_int(self.N), _p(means3D), _p(cov3D), _p(colors), _p(opacity),
+            _p(bg), _p(self.color), _p(self.radii))
+        self._h = ctypes.c_void_p(self._h)
+        self.num_rendered = int(getattr(L, "orc_num_rendered" + self.sfx)(self._h))
+
+    def geom(self):
+        xy = np.zeros((self.N, 2), self.dt); depth = np.zeros((self.N,), self.dt)
+        co = np.zeros((self.N, 4), self.dt); tt = np.zeros((self.N,), np.int32)
+        rect = np.zeros((self.N, 4), np.int32)
+        getattr(lib(), "orc_get_geom" + self.sfx)(self._h, _p(xy), _p(depth), _p(co), _p(tt), _p(rect))
+        return dict(xy=xy, depth=depth, conic_opacity=co, tiles_touched=tt, rect=rect)
+
+    def binning(self):
+        pl = np.zeros((max(self.num_rendered, 1),), np.int32)
+        rg = np.zeros((self.gx * self.gy, 2), np.int32)
+        getattr(lib(), "orc_get_binning" + self.sfx)(self._h, _p(pl), _p(rg))
+        return pl[: self.num_rendered], rg
+
+    def image_state(self):
+        ft = np.zeros((self.H, self.W), self.dt); nc = np.zeros((self.H, self.W), np.int32)
+        getattr(lib(), "orc_get_image_state" + self.sfx)(self._h, _p(ft), _p(nc))
+        return ft, nc
+
+    def backward(self, dL_dpix):
+        g = np.ascontiguousarray(np.asarray(dL_dpix, dtype=self.dt).reshape(3, self.H, self.W))
+        out = dict(means3D=np.zeros((self.N, 3), self.dt), means2D=np.zeros((self.N, 3), self.dt),
+                   colors=np.zeros((self.N, 3), self.dt), opacity=np.zeros((self.N,), self.dt),
+                   cov3D=np.zeros((self.N, 6), self.dt), conic=np.zeros((self.N, 3), self.dt))
+        getattr(lib(), "orc_backward" + self.sfx)(
+            self._h, _p(g), _p(out["means3D"]), _p(out["means2D"]), _p(out["colors"]),
+            _p(out["opacity"]), _p(out["cov3D"]), _p(out["conic"]))
+        return out
+
+    def close(self):
+        if self._h:
+            getattr(lib(), "orc_free" + self.sfx)(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def knn3_mean_dist2(xyz):
+    xyz = np.ascontiguousarray(np.asarray(xyz, dtype=np.float32))
+    out = np.zeros((xyz.shape[0],), np.float32)
+    lib().orc_knn3_mean_dist2(ctypes.c_int(xyz.shape[0]), _p(xyz), _p(out))
+    return out

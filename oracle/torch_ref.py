@@ -1,0 +1,249 @@
+"""CPU oracle (test infrastructure, NOT product code) for the torch half of the
+MANUS hot path: skin-weight sampling, linear-blend skinning of means and
+covariances, SH colour, camera matrices, FK and pin-hole projection.
+
+This is a plain-PyTorch restatement of the reference's op sequence; every
+function cites the reference lines it follows (paths relative to
+/root/reference).  It is pinned to the reference by tests/golden/*.npz, which
+were produced by importing the reference itself (tests/golden/make_golden.py).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module.  The product path (manus_amd/) never does.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+# ---------------------------------------------------------------------------
+# SH basis constants (src/utils/sh_utils.py:26-43)
+# ---------------------------------------------------------------------------
+SH_C0 = 0.28209479177387814
+SH_C1 = 0.4886025119029199
+SH_C2 = (1.0925484305920792, -1.0925484305920792, 0.31539156525252005,
+         -1.0925484305920792, 0.5462742152960396)
+SH_C3 = (-0.5900435899266435, 2.890611442640554, -0.4570457994644658,
+         0.3731763325901154, -0.4570457994644658, 1.445305721320277,
+         -0.5900435899266435)
+
+
+def eval_sh(deg, sh, dirs):
+    """Real SH of degree <=3.  sh: (..., C, K), dirs: (..., 3) unit.
+    Follows src/utils/sh_utils.py:57-104 (sign pattern :74-103)."""
+    res = SH_C0 * sh[..., 0]
+    if deg > 0:
+        x, y, z = dirs[..., 0:1], dirs[..., 1:2], dirs[..., 2:3]
+        res = res - SH_C1 * y * sh[..., 1] + SH_C1 * z * sh[..., 2] - SH_C1 * x * sh[..., 3]
+        if deg > 1:
+            xx, yy, zz = x * x, y * y, z * z
+            xy, yz, xz = x * y, y * z, x * z
+            res = (res + SH_C2[0] * xy * sh[..., 4] + SH_C2[1] * yz * sh[..., 5]
+                   + SH_C2[2] * (2.0 * zz - xx - yy) * sh[..., 6]
+                   + SH_C2[3] * xz * sh[..., 7] + SH_C2[4] * (xx - yy) * sh[..., 8])
+            if deg > 2:
+                res = (res + SH_C3[0] * y * (3 * xx - yy) * sh[..., 9]
+                       + SH_C3[1] * xy * z * sh[..., 10]
+                       + SH_C3[2] * y * (4 * zz - xx - yy) * sh[..., 11]
+                       + SH_C3[3] * z * (2 * zz - 3 * xx - 3 * yy) * sh[..., 12]
+                       + SH_C3[4] * x * (4 * zz - xx - yy) * sh[..., 13]
+                       + SH_C3[5] * z * (xx - yy) * sh[..., 14]
+                       + SH_C3[6] * x * (xx - 3 * yy) * sh[..., 15])
+    return res
+
+
+def rgb2sh(rgb):
+    """src/utils/sh_utils.py:123."""
+    return (rgb - 0.5) / SH_C0
+
+
+# ---------------------------------------------------------------------------
+# covariance from scale / rotation (src/models/gaussian.py:49-53,84-93;
+# src/utils/gaussian_utils.py:279-314, 248-276)
+# ---------------------------------------------------------------------------
+def quat_to_rotmat(q_raw):
+    """Normalise (r,x,y,z) and build R.  src/utils/gaussian_utils.py:279-302."""
+    q = q_raw / torch.sqrt((q_raw * q_raw).sum(-1, keepdim=True))
+    r, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    rows = [1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+            2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+            2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)]
+    return torch.stack(rows, -1).reshape(-1, 3, 3)
+
+
+def covariance_3x3(log_scale, q_raw, scale_mod=1.0):
+    """Sigma = (R S)(R S)^T with S = diag(exp(log_scale)*mod).
+    src/models/gaussian.py:49-53 + :62-64 (exp activation)."""
+    s = torch.exp(log_scale) * scale_mod
+    L = quat_to_rotmat(q_raw) * s[:, None, :]
+    return L @ L.transpose(1, 2)
+
+
+def pack_sym6(m):
+    """[xx,xy,xz,yy,yz,zz] upper triangle.  src/utils/gaussian_utils.py:248-261."""
+    return torch.stack([m[:, 0, 0], m[:, 0, 1], m[:, 0, 2], m[:, 1, 1], m[:, 1, 2], m[:, 2, 2]], -1)
+
+
+# ---------------------------------------------------------------------------
+# skin weights from the voxel grid (src/utils/gaussian_utils.py:167-196)
+# ---------------------------------------------------------------------------
+def skin_weights_from_grid(xyz, grid_center, grid_scale, grid_weights):
+    """grid_weights: (D,H,W,B) channel-last, sampled trilinearly at
+    u = (xyz - center)/scale with align_corners=True, zero padding, then
+    renormalised to sum 1 (no epsilon, :183)."""
+    g = grid_weights.permute(3, 0, 1, 2).unsqueeze(0)
+    u = ((xyz - grid_center) / grid_scale).reshape(1, -1, 1, 1, 3)
+    w = F.grid_sample(g, u, mode="bilinear", padding_mode="zeros", align_corners=True)
+    w = w.reshape(g.shape[1], -1).T
+    return w / w.sum(-1, keepdim=True)
+
+
+def bone_transforms(posed, rest, background=True):
+    """T_b = posed_b @ inv(rest_b), plus identity background transform.
+    src/modules/hand_dynamic.py:93-102."""
+    T = torch.einsum("nij,njk->nik", posed, torch.linalg.inv(rest))
+    if background:
+        T = torch.cat([T, torch.eye(4, dtype=T.dtype, device=T.device)[None]], 0)
+    return T
+
+
+def lbs_forward(xyz, log_scale, q_raw, skin_wts, transforms):
+    """Blend transforms, skin means and covariances.
+    src/modules/hand_dynamic.py:106-127.  Returns posed_xyz (N,3),
+    posed_cov (N,6), tf (N,4,4)."""
+    tf = torch.einsum("nb,bij->nij", skin_wts, transforms)
+    xyz_h = F.pad(xyz, (0, 1), value=1.0)
+    posed = torch.einsum("nij,nj->ni", tf, xyz_h)[:, :3]
+    cov = covariance_3x3(log_scale, q_raw)
+    R = tf[:, :3, :3]
+    cov = R @ cov @ R.transpose(1, 2)
+    return posed, pack_sym6(cov), tf
+
+
+def sh_colors(posed_xyz, features, cano_xyz, cam_center, sh_degree=3, tf=None):
+    """View-dependent colour.  features (N,16,3).  With tf the camera is pulled
+    back to canonical space through inv(tf).  src/utils/gaussian_utils.py:431-449."""
+    shs = features.transpose(1, 2).reshape(-1, 3, (sh_degree + 1) ** 2)
+    cam = cam_center.reshape(1, 3).expand(features.shape[0], 3)
+    if tf is not None:
+        cam_h = F.pad(cam, (0, 1), value=1.0)
+        cam_inv = torch.einsum("nij,nj->ni", torch.linalg.inv(tf), cam_h)[:, :3]
+        d = cano_xyz - cam_inv
+    else:
+        d = posed_xyz - cam
+    d = d / d.norm(dim=1, keepdim=True)
+    return torch.clamp_min(eval_sh(sh_degree, shs, d) + 0.5, 0.0)
+
+
+def hand_forward(params, grid, grid_center, grid_scale, posed, rest, cam_center):
+    """Whole a1-a5 chain for the hand.  params: dict with _xyz,_scaling,_rotation,
+    _features_dc,_features_rest,_opacity.  Returns dict of tensors."""
+    w = skin_weights_from_grid(params["_xyz"], grid_center, grid_scale, grid)
+    T = bone_transforms(posed, rest)
+    pxyz, pcov, tf = lbs_forward(params["_xyz"], params["_scaling"], params["_rotation"], w, T)
+    feats = torch.cat([params["_features_dc"], params["_features_rest"]], 1)
+    col = sh_colors(pxyz, feats, params["_xyz"], cam_center, 3, tf)
+    return dict(posed_xyz=pxyz, posed_cov=pcov, tf=tf, skin_wts=w, colors=col,
+                opacity=torch.sigmoid(params["_opacity"]))
+
+
+def object_forward(params, cam_center):
+    """src/modules/object.py:32-41 (no LBS, tf=None)."""
+    pxyz = params["_xyz"]
+    pcov = pack_sym6(covariance_3x3(params["_scaling"], params["_rotation"]))
+    feats = torch.cat([params["_features_dc"], params["_features_rest"]], 1)
+    col = sh_colors(pxyz, feats, pxyz, cam_center, 3, None)
+    return dict(posed_xyz=pxyz, posed_cov=pcov, colors=col,
+                opacity=torch.sigmoid(params["_opacity"]))
+
+
+# ---------------------------------------------------------------------------
+# cameras (src/utils/cam_utils.py:19-78)
+# ---------------------------------------------------------------------------
+def projection_matrix(znear, zfar, fovx, fovy):
+    """src/utils/cam_utils.py:19-39 (principal point dropped: l=-r, b=-t)."""
+    ty, tx = math.tan(fovy / 2), math.tan(fovx / 2)
+    top, right = ty * znear, tx * znear
+    P = np.zeros((4, 4))
+    P[0, 0] = 2.0 * znear / (2 * right)
+    P[1, 1] = 2.0 * znear / (2 * top)
+    P[3, 2] = 1.0
+    P[2, 2] = zfar / (zfar - znear)
+    P[2, 3] = -(zfar * znear) / (zfar - znear)
+    return P
+
+
+def camera_attributes(K, extr, width, height, zfar=100.0, znear=0.01):
+    """src/utils/cam_utils.py:50-78.  extr (3,4).  float64 numpy out."""
+    fovx = 2 * math.atan(width / (2 * K[0, 0]))
+    fovy = 2 * math.atan(height / (2 * K[1, 1]))
+    E = np.concatenate([extr, np.array([[0, 0, 0, 1.0]])], 0)
+    wvt = E.T
+    proj = projection_matrix(znear, zfar, fovx, fovy).T
+    full = wvt @ proj
+    center = np.linalg.inv(wvt)[3, :3]
+    return dict(width=int(width), height=int(height), fovx=fovx, fovy=fovy, K=K, extr=E,
+                world_view_transform=wvt, projection_matrix=proj,
+                full_proj_transform=full, camera_center=center)
+
+
+# ---------------------------------------------------------------------------
+# FK and projection (src/utils/transforms.py)
+# ---------------------------------------------------------------------------
+def _axis_rot(axis, a):
+    """src/utils/transforms.py:533-558."""
+    c, s, o, z = torch.cos(a), torch.sin(a), torch.ones_like(a), torch.zeros_like(a)
+    if axis == "X":
+        flat = (o, z, z, z, c, -s, z, s, c)
+    elif axis == "Y":
+        flat = (c, z, s, z, o, z, -s, z, c)
+    else:
+        flat = (c, -s, z, s, c, z, z, z, o)
+    return torch.stack(flat, -1).reshape(a.shape + (3, 3))
+
+
+def euler_to_matrix(euler, convention="XYZ", intrinsic=False):
+    """src/utils/transforms.py:489-530: intrinsic = reversed convention on flipped angles."""
+    if intrinsic:
+        convention = convention[::-1]
+        euler = euler.flip(-1)
+    m = [_axis_rot(c, e) for c, e in zip(convention, torch.unbind(euler, -1))]
+    return m[0] @ m[1] @ m[2]
+
+
+def fk_pose_wrt_root(rest, pose_rot, global_R, global_t, parents):
+    """Kinematic-tree FK.  rest (20,4,4), pose_rot (B,20,3,3), global_R (B,3,3),
+    global_t (B,3), parents int array (-1 = root).  src/utils/transforms.py:233-261:
+    root: G @ rest_i @ pose_i ; child: M_parent @ inv(rest_parent) @ rest_i @ pose_i."""
+    B = pose_rot.shape[0]
+    pose = torch.zeros(B, pose_rot.shape[1], 4, 4, dtype=rest.dtype)
+    pose[:, :, :3, :3] = pose_rot
+    pose[:, :, 3, 3] = 1.0
+    G = torch.zeros(B, 4, 4, dtype=rest.dtype)
+    G[:, :3, :3] = global_R
+    G[:, :3, 3] = global_t
+    G[:, 3, 3] = 1.0
+    M = [None] * len(parents)
+    for i, p in enumerate(parents):
+        if p == -1:
+            M[i] = G @ rest[i][None] @ pose[:, i]
+    for i, p in enumerate(parents):
+        if p == -1:
+            continue
+        local = torch.linalg.inv(rest[p]) @ rest[i]
+        M[i] = M[p] @ (local[None] @ pose[:, i])
+    return torch.stack(M, 1)
+
+
+def project_points(points, K, extr):
+    """points (B,N,3), K (3,3), extr (3,4) -> (B,N,2).  src/utils/transforms.py:304-311."""
+    P = K @ extr
+    ph = F.pad(points, (0, 1), value=1.0)
+    q = torch.einsum("ij,bnj->bni", P, ph)
+    return (q / q[..., 2:])[..., :2]
+
+
+def psnr(a, b):
+    """src/utils/loss_utils.py:100-108."""
+    mse = torch.mean((a - b) ** 2)
+    return -10.0 * torch.log10(mse)

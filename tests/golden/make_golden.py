@@ -1,0 +1,348 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by IMPORTING the reference.
+
+Run in the authoring container only (needs /root/reference):
+
+    python tests/golden/make_golden.py
+
+The reference's Python is imported from /root/reference with stub modules for
+the packages this image lacks; it never travels to the GPU box.  Only arrays
+(inputs and the reference's outputs / autograd gradients) are written, as
+.npz files next to this script.  Nothing here is product code.
+
+Reference functions exercised (paths relative to /root/reference):
+  * src/modules/hand_dynamic.py:86-137     TrainingModule.forward  (LBS)
+  * src/models/hand_gaussian.py:65-76      get_skin_weights
+  * src/utils/gaussian_utils.py:167-196    skinning_weights_from_voxel_grid
+  * src/models/gaussian.py:49-93           activations / get_covariance
+  * src/utils/gaussian_utils.py:431-449    calculate_colors_from_sh
+  * src/utils/sh_utils.py:57-120           eval_sh
+  * src/utils/cam_utils.py:19-78           getProjectionMatrix / get_opengl_camera_attributes
+  * src/utils/transforms.py:233-261,489-530,304-311  get_pose_wrt_root / euler_angles_to_matrix / project_points
+  * data/meta_data/novel_pose.pkl, data/camera_paths/real.pkl  (known-answer data)
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+# --------------------------------------------------------------------------
+# stubs for packages absent from this image
+# --------------------------------------------------------------------------
+class _Anything(types.ModuleType):
+    __path__ = []  # behave as a package so "import stub.sub" resolves
+
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        sub = _Anything(self.__name__ + "." + name)
+        setattr(self, name, sub)
+        return sub
+
+    def __call__(self, *a, **k):
+        return _Anything(self.__name__ + "()")
+
+
+class _StubFinder:
+    """Resolve any submodule of a stubbed root package to another stub."""
+    roots = set()
+
+    @classmethod
+    def find_spec(cls, name, path=None, target=None):
+        import importlib.machinery
+        if name.split(".")[0] in cls.roots:
+            return importlib.machinery.ModuleSpec(name, cls)
+        return None
+
+    @staticmethod
+    def create_module(spec):
+        return _Anything(spec.name)
+
+    @staticmethod
+    def exec_module(module):
+        pass
+
+
+def _install_stubs():
+    sys.meta_path.append(_StubFinder)
+    for name in [
+        "cv2", "termcolor", "trimesh", "pymeshlab", "taichi", "skimage",
+        "skimage.measure", "diff_gaussian_rasterization", "simple_knn",
+        "simple_knn._C", "lpips", "pysdf", "hydra", "hydra.utils", "omegaconf",
+        "pytorch_lightning", "natsort", "h5py", "plotly", "imageio",
+    ]:
+        _StubFinder.roots.add(name.split(".")[0])
+        if name not in sys.modules:
+            sys.modules[name] = _Anything(name)
+    sys.modules["termcolor"].colored = lambda s, *a, **k: s
+    sys.modules["termcolor"].cprint = lambda *a, **k: None
+    pl = sys.modules["pytorch_lightning"]
+    pl.LightningModule = torch.nn.Module
+    dgr = sys.modules["diff_gaussian_rasterization"]
+    dgr.GaussianRasterizationSettings = object
+    dgr.GaussianRasterizer = object
+    sys.modules["simple_knn._C"].distCUDA2 = lambda x: None
+    sys.modules["omegaconf"].OmegaConf = object
+    ed = types.ModuleType("easydict")
+
+    class EasyDict(dict):
+        def __init__(self, d=None, **kw):
+            super().__init__()
+            d = dict(d or {}, **kw)
+            for k, v in d.items():
+                self[k] = v
+
+        def __getattr__(self, k):
+            try:
+                return self[k]
+            except KeyError:
+                raise AttributeError(k)
+
+        def __setattr__(self, k, v):
+            self[k] = v
+
+    ed.EasyDict = EasyDict
+    sys.modules["easydict"] = ed
+
+    # the reference hard-codes device="cuda" in a few tensor factories
+    for fn in ["zeros", "ones", "empty", "eye", "tensor", "full"]:
+        orig = getattr(torch, fn)
+
+        def wrap(*a, __orig=orig, **k):
+            if str(k.get("device", "")).startswith("cuda"):
+                k["device"] = "cpu"
+            return __orig(*a, **k)
+
+        setattr(torch, fn, wrap)
+
+
+def _import_reference():
+    _install_stubs()
+    sys.path.insert(0, REF)
+    os.chdir(REF)  # cam_utils does sys.path.insert(0, os.getcwd())
+    import src.utils.sh_utils as sh_utils
+    import src.utils.transforms as transforms
+    import src.utils.cam_utils as cam_utils
+    import src.utils.gaussian_utils as gaussian_utils
+    import src.models.gaussian as gaussian
+    import src.models.hand_gaussian as hand_gaussian
+    import src.modules.hand_dynamic as hand_dynamic
+    return dict(sh_utils=sh_utils, transforms=transforms, cam_utils=cam_utils,
+                gaussian_utils=gaussian_utils, gaussian=gaussian,
+                hand_gaussian=hand_gaussian, hand_dynamic=hand_dynamic)
+
+
+# --------------------------------------------------------------------------
+def _rand_rigid(g, n, ang=0.6, trans=0.05):
+    """n random rigid 4x4 transforms (numpy, float32)."""
+    out = np.tile(np.eye(4, dtype=np.float64), (n, 1, 1))
+    for i in range(n):
+        a = g.normal(size=3)
+        a = a / np.linalg.norm(a) * g.uniform(0, ang)
+        th = np.linalg.norm(a)
+        k = a / max(th, 1e-12)
+        K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+        R = np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+        out[i, :3, :3] = R
+        out[i, :3, 3] = g.normal(size=3) * trans
+    return out.astype(np.float32)
+
+
+def make_lbs_sh_case(mods, seed, n, posed):
+    """Inputs + reference outputs + autograd grads for a1-a5."""
+    g = np.random.default_rng(seed)
+    D, H, W, B = 8, 9, 10, 21
+    xyz = (g.uniform(-0.8, 0.8, size=(n, 3)) * np.array([0.05, 0.04, 0.03])).astype(np.float32)
+    scaling = np.log(g.uniform(5e-4, 4e-3, size=(n, 3))).astype(np.float32)
+    rotation = g.normal(size=(n, 4)).astype(np.float32)
+    fdc = g.normal(size=(n, 1, 3)).astype(np.float32)
+    frest = (0.1 * g.normal(size=(n, 15, 3))).astype(np.float32)
+    opacity = (1.5 * g.normal(size=(n, 1))).astype(np.float32)
+    grid = g.uniform(0.0, 1.0, size=(D, H, W, B)).astype(np.float32) ** 4
+    grid_center = np.array([0.002, -0.001, 0.003], dtype=np.float32)
+    grid_scale = np.array([[0.06, 0.05, 0.04]], dtype=np.float32)
+    rest = _rand_rigid(g, 20, ang=1.0, trans=0.05)
+    posed_t = _rand_rigid(g, 20, ang=0.7, trans=0.03) @ rest
+    cam_center = np.array([[0.1, -0.2, 0.9]], dtype=np.float32)
+    r1 = g.normal(size=(n, 3)).astype(np.float32)
+    r2 = g.normal(size=(n, 6)).astype(np.float32)
+    r3 = g.normal(size=(n, 3)).astype(np.float32)
+
+    hd, hg, gm, gu = (mods["hand_dynamic"], mods["hand_gaussian"], mods["gaussian"],
+                      mods["gaussian_utils"])
+    from easydict import EasyDict as edict
+
+    model = hg.HandGaussianModel.__new__(hg.HandGaussianModel)
+    torch.nn.Module.__init__(model)
+    model.opts = edict(sh_degree=3, isotropic_scaling=False,
+                       skin_weights_init_type="mano_init_voxel")
+    model.setup_functions()
+    leaves = {}
+    for name, arr in [("_xyz", xyz), ("_scaling", scaling), ("_rotation", rotation),
+                      ("_features_dc", fdc), ("_features_rest", frest), ("_opacity", opacity)]:
+        t = torch.nn.Parameter(torch.from_numpy(arr.copy()))
+        setattr(model, name, t)
+        leaves[name] = t
+    model.skin_weights_init_type = "mano_init_voxel"
+    model.grid_center = torch.from_numpy(grid_center)
+    model.grid_scale = torch.from_numpy(grid_scale)
+    model.grid_weights = torch.from_numpy(grid)
+
+    out = dict(xyz=xyz, scaling=scaling, rotation=rotation, features_dc=fdc,
+               features_rest=frest, opacity=opacity, grid=grid, grid_center=grid_center,
+               grid_scale=grid_scale, rest=rest, posed=posed_t, cam_center=cam_center,
+               r1=r1, r2=r2, r3=r3)
+
+    class _Cam:
+        camera_center = torch.from_numpy(cam_center)
+
+    if posed:
+        fake = types.SimpleNamespace(
+            model=model,
+            opts=edict(model=edict(opts=edict(skin_weights_init_type="mano_init_voxel"))))
+        batch = dict(bones_posed=types.SimpleNamespace(transforms=torch.from_numpy(posed_t)),
+                     bones_rest=types.SimpleNamespace(transforms=torch.from_numpy(rest)))
+        pred = hd.TrainingModule.forward(fake, batch)
+        colors = gu.calculate_colors_from_sh(pred.posed_xyz, pred.cano_features, pred.cano_xyz,
+                                             _Cam, 3, pred.tf)
+        posed_xyz, posed_cov = pred.posed_xyz, pred.posed_cov
+        out.update(tf=pred.tf.detach().numpy(), skin_wts=pred.skin_wts.detach().numpy())
+    else:
+        # object path: src/modules/object.py:32-41 (identity "LBS", tf=None)
+        posed_xyz = model.get_xyz
+        posed_cov = model.get_covariance(full=False)
+        colors = gu.calculate_colors_from_sh(posed_xyz, model.get_features, model.get_xyz,
+                                             _Cam, 3, None)
+    loss = ((posed_xyz * torch.from_numpy(r1)).sum() + (posed_cov * torch.from_numpy(r2)).sum()
+            + (colors * torch.from_numpy(r3)).sum())
+    loss.backward()
+    out.update(posed_xyz=posed_xyz.detach().numpy(), posed_cov=posed_cov.detach().numpy(),
+               colors=colors.detach().numpy(), opacity_act=model.get_opacity.detach().numpy(),
+               loss=np.float64(loss.item()))
+    for name, t in leaves.items():
+        out["grad" + name] = (t.grad.detach().numpy() if t.grad is not None
+                              else np.zeros_like(t.detach().numpy()))
+    return out
+
+
+def make_camera_golden(mods):
+    import joblib
+    cu = mods["cam_utils"]
+    d = joblib.load(os.path.join(REF, "data/camera_paths/real.pkl"))
+    def kmat(t):  # pkl stores (fx, fy, cx, cy)
+        fx, fy, cx, cy = [float(x) for x in t]
+        return np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1]], dtype=np.float64)
+
+    K = np.stack([kmat(k) for k in d["intrs"]])
+    E = np.stack([np.asarray(e, dtype=np.float64) for e in d["extrs"]])
+    idx = list(range(0, len(K), 10))
+    res = dict(K=K[idx], extr=E[idx][:, :3, :4], width=np.int32(1920), height=np.int32(1080))
+    keys = ["fovx", "fovy", "world_view_transform", "projection_matrix",
+            "full_proj_transform", "camera_center"]
+    acc = {k: [] for k in keys}
+    for i in idx:
+        o = cu.get_opengl_camera_attributes(K[i].copy(), E[i][:3, :4].copy(), 1920, 1080)
+        for k in keys:
+            acc[k].append(np.asarray(o[k], dtype=np.float64))
+    for k in keys:
+        res[k] = np.stack(acc[k])
+    res["proj_0p01_100"] = cu.getProjectionMatrix(0.01, 100.0, 0.7, 0.5)
+    # also the canonical camera (f=8000)
+    c = joblib.load(os.path.join(REF, "data/camera_paths/cano_camera.pkl"))
+    res["cano_K"] = kmat(c["intrs"][0])
+    res["cano_extr"] = np.asarray(c["extrs"][0], dtype=np.float64)[:3, :4]
+    return res
+
+
+def make_fk_golden(mods):
+    import joblib
+    tr = mods["transforms"]
+    d = joblib.load(os.path.join(REF, "data/meta_data/novel_pose.pkl"))
+    frames = [0, 10, 100, 250]
+    kintree = tr.build_kintree(d["bnames"], d["bnames_parent"])
+    parents = np.array([kintree[str(i)] for i in range(20)], dtype=np.int32)
+    rest = torch.tensor(d["rest_matrixs"], dtype=torch.float32)
+    pose = torch.tensor(d["pose_params"][frames], dtype=torch.float32)
+    eye = torch.eye(3)[None].repeat(len(frames), 1, 1)
+    zero = torch.zeros(len(frames), 3)
+    fk = tr.get_pose_wrt_root(rest, pose, eye, zero, kintree).detach().numpy()
+    # with a non-trivial global transform too
+    g = np.random.default_rng(7)
+    gR = _rand_rigid(g, len(frames), ang=1.0)[:, :3, :3]
+    gt = g.normal(size=(len(frames), 3)).astype(np.float32) * 0.1
+    fk_g = tr.get_pose_wrt_root(rest, pose, torch.from_numpy(gR), torch.from_numpy(gt),
+                                kintree).detach().numpy()
+    eul = torch.tensor(d["root_rotation"][frames], dtype=torch.float32)
+    e_in = tr.euler_angles_to_matrix(eul, "XYZ", intrinsic=True).numpy()
+    e_ex = tr.euler_angles_to_matrix(eul, "XYZ", intrinsic=False).numpy()
+    eul_all = torch.tensor(d["eulers"][frames], dtype=torch.float32)  # (F,20,3)
+    e_bones = tr.euler_angles_to_matrix(eul_all, "XYZ", intrinsic=True).numpy()
+    # skeleton fixture for the synthetic scene: world-space rest + posed frames
+    w = tr.convert_armature_space_to_world_space(
+        {k: np.asarray(v) for k, v in d.items() if k not in ("bnames", "bnames_parent")})
+    # project_points golden
+    pts = torch.tensor(g.normal(size=(1, 50, 3)) * 0.1 + np.array([0, 0, 1.0]), dtype=torch.float32)
+    K = torch.tensor([[2666.67, 0, 959.5], [0, 2666.67, 539.5], [0, 0, 1]], dtype=torch.float32)
+    E = torch.tensor(np.concatenate([gR[0], gt[0][:, None] + np.array([[0], [0], [0.5]])], 1),
+                     dtype=torch.float32)
+    p2d = tr.project_points(pts, K, E).numpy()
+    return dict(
+        frames=np.array(frames), parents=parents,
+        rest_matrixs=d["rest_matrixs"].astype(np.float32),
+        pose_params=d["pose_params"][frames].astype(np.float32),
+        pose_matrixs=d["pose_matrixs"][frames].astype(np.float32),
+        fk=fk, global_R=gR, global_t=gt, fk_global=fk_g,
+        root_rotation=d["root_rotation"][frames].astype(np.float32),
+        pose_matrix_world0=d["pose_matrix_world"][frames][:, 0].astype(np.float32),
+        euler_intrinsic=e_in, euler_extrinsic=e_ex,
+        eulers=d["eulers"][frames].astype(np.float32), euler_bones_intrinsic=e_bones,
+        world_rest_matrixs=np.asarray(w["rest_matrixs"], dtype=np.float32),
+        world_rest_heads=np.asarray(w["rest_heads"], dtype=np.float32),
+        world_rest_tails=np.asarray(w["rest_tails"], dtype=np.float32),
+        world_pose_matrixs=np.asarray(w["pose_matrixs"], dtype=np.float32)[frames],
+        world_pose_heads=np.asarray(w["pose_heads"], dtype=np.float32)[frames],
+        world_pose_tails=np.asarray(w["pose_tails"], dtype=np.float32)[frames],
+        pp_points=pts.numpy(), pp_K=K.numpy(), pp_E=E.numpy(), pp_out=p2d,
+    )
+
+
+def make_sh_golden(mods):
+    sh = mods["sh_utils"]
+    g = np.random.default_rng(11)
+    coeffs = g.normal(size=(200, 3, 16)).astype(np.float32)
+    dirs = g.normal(size=(200, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    out = {"coeffs": coeffs, "dirs": dirs}
+    for deg in range(4):
+        out[f"deg{deg}"] = sh.eval_sh(deg, torch.from_numpy(coeffs), torch.from_numpy(dirs)).numpy()
+    out["rgb2sh"] = sh.RGB2SH(torch.from_numpy(coeffs[:, :, 0])).numpy()
+    return out
+
+
+def main():
+    mods = _import_reference()
+    torch.manual_seed(0)
+    for seed in (0, 1, 2):
+        for n in (64, 1000):
+            if n == 1000 and seed > 0:
+                continue
+            c = make_lbs_sh_case(mods, seed, n, posed=True)
+            np.savez_compressed(os.path.join(OUT, f"lbs_sh_hand_s{seed}_n{n}.npz"), **c)
+    c = make_lbs_sh_case(mods, 3, 64, posed=False)
+    np.savez_compressed(os.path.join(OUT, "lbs_sh_object_s3_n64.npz"), **c)
+    np.savez_compressed(os.path.join(OUT, "cameras.npz"), **make_camera_golden(mods))
+    np.savez_compressed(os.path.join(OUT, "fk_novel_pose.npz"), **make_fk_golden(mods))
+    np.savez_compressed(os.path.join(OUT, "sh_eval.npz"), **make_sh_golden(mods))
+    for f in sorted(os.listdir(OUT)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__":
+    main()
