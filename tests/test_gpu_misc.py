@@ -1,0 +1,172 @@
+"""GPU: simple-knn replacement, drop-in package surface, reference-signature render call,
+L1 loss kernel, and the multi-view engine step against the oracle."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import RasterOracle, knn3_mean_dist2
+from oracle import torch_ref as tr
+
+from util import cam_args, make_camera, max_rel_err, psnr, random_gaussians
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("n,kind", [(1, "normal"), (3, "normal"), (2000, "normal"), (3000, "hand"), (500, "dup"), (800, "line")])
+def test_distcuda2_equals_brute_force(n, kind):
+    from simple_knn._C import distCUDA2
+    g = np.random.default_rng(n)
+    if kind == "normal":
+        pts = g.normal(size=(n, 3)).astype(np.float32)
+    elif kind == "hand":
+        from manus_amd.synthetic import make_scene
+        pts = make_scene(n_gaussians=n, kind="hand", seed=0, grid_res=8, n_cameras=1, width=32, height=32)["params"]["_xyz"].numpy()
+    elif kind == "dup":
+        pts = np.repeat(g.normal(size=(n // 5, 3)), 5, 0).astype(np.float32)  # coincident points -> distance 0
+    else:
+        pts = np.zeros((n, 3), np.float32); pts[:, 0] = g.uniform(0, 1, n)  # degenerate extent in y, z
+    got = distCUDA2(torch.tensor(pts, device=DEV)).cpu().numpy()
+    ref = knn3_mean_dist2(pts)
+    if n < 4:
+        assert np.isinf(got).all() and np.isinf(ref).all()
+    else:
+        np.testing.assert_allclose(got, ref, rtol=2e-5, atol=1e-12)
+
+
+def test_distcuda2_full_size_property():
+    """300k points: equals brute force on a random subset (the oracle is O(N^2))."""
+    from simple_knn._C import distCUDA2
+    from manus_amd.synthetic import make_scene
+    pts = make_scene(n_gaussians=300000, kind="hand", seed=0, grid_res=8, n_cameras=1, width=32, height=32)["params"]["_xyz"]
+    got = distCUDA2(pts.to(DEV)).cpu().numpy()
+    assert np.isfinite(got).all() and (got >= 0).all()
+    p = pts.numpy().astype(np.float32)
+    for i in np.random.default_rng(0).integers(0, p.shape[0], 50):
+        d = ((p - p[i]) ** 2).sum(1)
+        d[i] = np.inf
+        ref = np.sort(d)[:3].mean()
+        assert abs(got[i] - ref) <= 2e-5 * ref + 1e-12
+
+
+def test_dropin_packages_and_argument_errors():
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    cam = make_camera(64, 48)
+    a = cam_args(cam)
+    st = GaussianRasterizationSettings(image_height=48, image_width=64, tanfovx=a["tanfovx"], tanfovy=a["tanfovy"],
+                                       bg=torch.ones(3, device=DEV), scale_modifier=1,
+                                       viewmatrix=torch.tensor(a["view"], device=DEV).reshape(1, 4, 4),
+                                       projmatrix=torch.tensor(a["proj"], device=DEV).reshape(1, 4, 4), sh_degree=3,
+                                       campos=torch.tensor(cam["camera_center"], device=DEV).reshape(1, 3),
+                                       prefiltered=False, debug=False)
+    assert len(st) == 12
+    r = GaussianRasterizer(raster_settings=st)
+    m, c, col, op = [torch.tensor(x, device=DEV) for x in random_gaussians(100, seed=0)]
+    m2 = torch.zeros_like(m)
+    with pytest.raises(Exception):
+        r(means3D=m, means2D=m2, opacities=op[:, None], shs=None, colors_precomp=None, cov3D_precomp=c)
+    with pytest.raises(Exception):
+        r(means3D=m, means2D=m2, opacities=op[:, None], colors_precomp=col, scales=None, rotations=None, cov3D_precomp=None)
+    with pytest.raises(Exception):
+        r(means3D=m, means2D=m2, opacities=op[:, None], colors_precomp=col, scales=torch.ones_like(m),
+          rotations=torch.ones((100, 4), device=DEV), cov3D_precomp=c)
+    img, radii = r(means3D=m, means2D=m2, opacities=op[:, None], shs=None, colors_precomp=col, scales=None,
+                   rotations=None, cov3D_precomp=c)
+    assert img.shape == (3, 48, 64) and radii.shape == (100,) and radii.dtype == torch.int32
+    assert r.markVisible(m).dtype == torch.bool
+    with pytest.raises(Exception):  # no CPU fallback
+        r(means3D=m.cpu(), means2D=m2.cpu(), opacities=op[:, None].cpu(), colors_precomp=col.cpu(), cov3D_precomp=c.cpu())
+
+
+def test_render_gaussians_reference_signature(golden_dir):
+    """The reference call sequence (hand module forward -> render_gaussians) end to end vs the oracles."""
+    from types import SimpleNamespace
+    from manus_amd.modules import hand_forward
+    from manus_amd.render import render_gaussians
+    from manus_amd.structures import Bones
+    from manus_amd.synthetic import make_scene
+    sc = make_scene(n_gaussians=3000, kind="hand", seed=5, grid_res=24, n_cameras=1, width=96, height=64,
+                    cam_radius=0.5, sigma_range=(2e-3, 8e-3), device="cpu")
+    P = {k: v.clone().to(DEV).requires_grad_(True) for k, v in sc["params"].items()}
+    model = SimpleNamespace(_xyz=P["_xyz"], _scaling=P["_scaling"], _rotation=P["_rotation"],
+                            get_features=torch.cat([P["_features_dc"], P["_features_rest"]], 1),
+                            get_opacity=torch.sigmoid(P["_opacity"]), grid_center=sc["grid_center"],
+                            grid_scale=sc["grid_scale"], grid_weights=sc["grid"])
+    batch = dict(bones_posed=Bones(None, None, None, sc["posed"][0]), bones_rest=Bones(None, None, None, sc["rest"]))
+    pred = hand_forward(model, batch)
+    assert pred.tf.shape == (3000, 4, 4)
+    c = sc["cameras"][0]
+    camera = SimpleNamespace(fovx=c["fovx"], fovy=c["fovy"], height=c["height"], width=c["width"],
+                             world_view_transform=torch.tensor(c["world_view_transform"], dtype=torch.float32)[None],
+                             full_proj_transform=torch.tensor(c["full_proj_transform"], dtype=torch.float32)[None],
+                             camera_center=torch.tensor(c["camera_center"], dtype=torch.float32)[None])
+    out = render_gaussians(pred.posed_xyz, pred.posed_cov, pred.cano_xyz, pred.cano_features, pred.cano_opacity,
+                           camera, torch.ones(3), sh_degree=3, tf=pred.tf, device=torch.device(DEV))
+    assert out["render"].shape == (64, 96, 3) and out["visibility_filter"].dtype == torch.bool
+    g = torch.randn((64, 96, 3), generator=torch.Generator().manual_seed(0)).to(DEV)
+    (out["render"] * g).sum().backward()
+    assert out["viewspace_points"].grad is not None and out["viewspace_points"].grad.shape == (3000, 3)
+    # oracle: torch chain -> C rasterizer -> torch backward
+    Pc = {k: v.clone().requires_grad_(True) for k, v in sc["params"].items()}
+    o = tr.hand_forward(Pc, sc["grid"], sc["grid_center"], sc["grid_scale"], sc["posed"][0], sc["rest"],
+                        torch.tensor(c["camera_center"], dtype=torch.float32))
+    a = cam_args(c)
+    ro = RasterOracle(a["W"], a["H"], a["tanfovx"], a["tanfovy"], a["view"], a["proj"], o["posed_xyz"].detach().numpy(),
+                      o["posed_cov"].detach().numpy(), o["colors"].detach().numpy(), o["opacity"].detach().numpy()[:, 0],
+                      np.ones(3, np.float32))
+    img_o = np.transpose(ro.color, (1, 2, 0))
+    assert np.abs(out["render"].detach().cpu().numpy() - img_o).max() < 5e-3
+    tgt = np.clip(img_o + 0.05, 0, 1)
+    assert abs(psnr(out["render"].detach().cpu().numpy(), tgt) - psnr(img_o, tgt)) < 0.01
+    b = ro.backward(np.transpose(g.cpu().numpy(), (2, 0, 1)))
+    (o["posed_xyz"] * torch.tensor(b["means3D"])).sum().backward(retain_graph=True)
+    (o["posed_cov"] * torch.tensor(b["cov3D"])).sum().backward(retain_graph=True)
+    (o["colors"] * torch.tensor(b["colors"])).sum().backward(retain_graph=True)
+    (o["opacity"][:, 0] * torch.tensor(b["opacity"])).sum().backward()
+    for k in P:
+        e = max_rel_err(P[k].grad.cpu().numpy(), Pc[k].grad.numpy())
+        assert e < 2e-4, (k, e)
+    vis = ro.radii > 0
+    assert (out["visibility_filter"].cpu().numpy() == vis).all()
+    assert max_rel_err(out["viewspace_points"].grad.cpu().numpy(), b["means2D"]) < 1e-4
+
+
+def test_l1_loss_kernel():
+    from manus_amd.ops import l1_loss_grad
+    a = torch.rand((2, 3, 37, 53), device=DEV)
+    b = torch.rand((2, 3, 37, 53), device=DEV)
+    a[0, 0, 0, :5] = b[0, 0, 0, :5]
+    s, g = l1_loss_grad(a, b)
+    assert abs(float(s) - float((a - b).abs().sum())) < 1e-2
+    assert torch.equal(g, torch.sign(a - b) / a.numel())
+
+
+def test_engine_step_matches_sequential_reference_steps():
+    """V views in one batched step == the mean of V single-view reference-style steps."""
+    from manus_amd.engine import HipViewCompute, ViewShardedStep
+    from manus_amd.synthetic import camera_table, make_scene
+    sc = make_scene(n_gaussians=4000, kind="hand", seed=2, grid_res=24, n_cameras=4, width=96, height=64,
+                    cam_radius=0.5, sigma_range=(2e-3, 8e-3), device=DEV)
+    ct = camera_table(sc["cameras"], DEV)
+    tg = torch.rand((4, 3, 64, 96), device=DEV)
+    hc = HipViewCompute(sc, tg, ct)
+    shapes = {k: v.shape for k, v in hc.params.items()}
+    full = ViewShardedStep(sc["N"], shapes, hc, 4).step()
+    acc = None
+    for v in range(4):
+        o = hc([v])
+        if acc is None:
+            acc = {k: g.clone() for k, g in o["grads"].items()}
+            g2, vis, rad, loss = o["grad2d"].clone(), o["vis"].clone(), o["radii"].clone(), o["loss"].clone()
+        else:
+            for k in acc:
+                acc[k] += o["grads"][k]
+            g2 += o["grad2d"]; vis += o["vis"]; rad = torch.maximum(rad, o["radii"]); loss += o["loss"]
+    for k in acc:
+        assert max_rel_err(full["grads"][k].cpu().numpy(), (acc[k] / 4).cpu().numpy()) < 1e-5, k
+    assert max_rel_err(full["grad2d"].cpu().numpy(), g2.cpu().numpy()) < 1e-5
+    assert torch.equal(full["vis"], vis) and torch.equal(full["radii"], rad.to(torch.int32))
+    assert abs(float(full["loss"]) - float(loss) / 4) < 1e-5
