@@ -186,6 +186,15 @@ int mgr_knn3_mean_dist2(int N, const float* xyz, float* out, void* workspace,
 int mgr_l1_loss_grad(int64_t count, const float* a, const float* b, float scale, float* dL_da,
                      float* loss_sum, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Measurement aid: when enabled, every kernel launched by this library is
+ * bracketed by HIP events recorded on the caller's stream.
+ * mgr_profile_report synchronises the stream, writes one line per kernel
+ * "name count total_ms\n" into buf (NUL terminated) and clears the records.
+ * ------------------------------------------------------------------------ */
+int mgr_profile_enable(int on);
+int mgr_profile_report(char* buf_host, size_t len, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -45,7 +45,24 @@ SIGNATURES = {
     "mgr_knn3_workspace_bytes": (c_sz, [c_int]),
     "mgr_knn3_mean_dist2": (c_int, [c_int, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "mgr_l1_loss_grad": (c_int, [c_i64, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp]),
+    "mgr_profile_enable": (c_int, [c_int]),
+    "mgr_profile_report": (c_int, [ctypes.c_char_p, c_sz, c_vp]),
 }
+
+
+def profile_enable(on):
+    check(lib().mgr_profile_enable(int(bool(on))), "mgr_profile_enable")
+
+
+def profile_report():
+    """{kernel name: (launches, total_ms)} since the last report (synchronises)."""
+    buf = ctypes.create_string_buffer(1 << 16)
+    check(lib().mgr_profile_report(buf, len(buf), stream()), "mgr_profile_report")
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, cnt, ms = line.split()
+        out[name] = (int(cnt), float(ms))
+    return out
 
 
 class ManusHipError(RuntimeError):

@@ -232,14 +232,14 @@ extern "C" int mgr_knn3_mean_dist2(int N, const float* xyz, float* out, void* wo
     uint32_t* cursor = (uint32_t*)(ws + o);  o += mgr_align(mc * 4);
     float4* sorted = (float4*)(ws + o);
     MGR_HIP(hipMemsetAsync(cnt, 0, mc * 4, stream));
-    hipLaunchKernelGGL(k_knn_init, dim3(1), dim3(1), 0, stream, P);
+    { MGR_PROF("k_knn_init", stream); hipLaunchKernelGGL(k_knn_init, dim3(1), dim3(1), 0, stream, P); }
     int blocks = (N + 255) / 256;
-    hipLaunchKernelGGL(k_knn_bbox, dim3(blocks > 1024 ? 1024 : blocks), dim3(256), 0, stream, N, xyz, P);
-    hipLaunchKernelGGL(k_knn_setup, dim3(1), dim3(1), 0, stream, N, (int)mc, P);
-    hipLaunchKernelGGL(k_knn_count, dim3(blocks), dim3(256), 0, stream, N, xyz, P, cnt);
-    hipLaunchKernelGGL(k_knn_scan, dim3(1), dim3(1024), 0, stream, P, cnt, start, cursor);
-    hipLaunchKernelGGL(k_knn_scatter, dim3(blocks), dim3(256), 0, stream, N, xyz, P, start, cursor, sorted);
-    hipLaunchKernelGGL(k_knn_query, dim3(blocks), dim3(256), 0, stream, N, xyz, P, start, sorted, out);
+    { MGR_PROF("k_knn_bbox", stream); hipLaunchKernelGGL(k_knn_bbox, dim3(blocks > 1024 ? 1024 : blocks), dim3(256), 0, stream, N, xyz, P); }
+    { MGR_PROF("k_knn_setup", stream); hipLaunchKernelGGL(k_knn_setup, dim3(1), dim3(1), 0, stream, N, (int)mc, P); }
+    { MGR_PROF("k_knn_count", stream); hipLaunchKernelGGL(k_knn_count, dim3(blocks), dim3(256), 0, stream, N, xyz, P, cnt); }
+    { MGR_PROF("k_knn_scan", stream); hipLaunchKernelGGL(k_knn_scan, dim3(1), dim3(1024), 0, stream, P, cnt, start, cursor); }
+    { MGR_PROF("k_knn_scatter", stream); hipLaunchKernelGGL(k_knn_scatter, dim3(blocks), dim3(256), 0, stream, N, xyz, P, start, cursor, sorted); }
+    { MGR_PROF("k_knn_query", stream); hipLaunchKernelGGL(k_knn_query, dim3(blocks), dim3(256), 0, stream, N, xyz, P, start, sorted, out); }
     MGR_LAUNCH_CHECK("knn3", stream, 0);
     return MGR_OK;
 }

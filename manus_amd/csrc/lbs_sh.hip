@@ -527,8 +527,8 @@ extern "C" int mgr_skin_weights_fwd(int N, const float* xyz, const float* grid, 
     if (N == 0) return MGR_OK;
     if (!xyz || !grid || !center3 || !scale3 || !out_w) return mgr_fail(MGR_EINVAL, "mgr_skin_weights_fwd: null pointer");
     hipStream_t stream = (hipStream_t)stream_;
-    hipLaunchKernelGGL(k_skin_fwd, dim3((N + 255) / 256), dim3(256), 0, stream, N, xyz, grid, D, H, W, B,
-                       center3, scale3, out_w);
+    { MGR_PROF("k_skin_fwd", stream); hipLaunchKernelGGL(k_skin_fwd, dim3((N + 255) / 256), dim3(256), 0, stream, N, xyz, grid, D, H, W, B,
+                       center3, scale3, out_w); }
     MGR_LAUNCH_CHECK("k_skin_fwd", stream, 0);
     return MGR_OK;
 }
@@ -542,8 +542,8 @@ extern "C" int mgr_skin_weights_bwd(int N, const float* xyz, const float* grid, 
     if (!xyz || !grid || !center3 || !scale3 || !dL_dw || !dL_dxyz)
         return mgr_fail(MGR_EINVAL, "mgr_skin_weights_bwd: null pointer");
     hipStream_t stream = (hipStream_t)stream_;
-    hipLaunchKernelGGL(k_skin_bwd, dim3((N + 255) / 256), dim3(256), 0, stream, N, xyz, grid, D, H, W, B,
-                       center3, scale3, dL_dw, dL_dxyz);
+    { MGR_PROF("k_skin_bwd", stream); hipLaunchKernelGGL(k_skin_bwd, dim3((N + 255) / 256), dim3(256), 0, stream, N, xyz, grid, D, H, W, B,
+                       center3, scale3, dL_dw, dL_dxyz); }
     MGR_LAUNCH_CHECK("k_skin_bwd", stream, 0);
     return MGR_OK;
 }
@@ -557,8 +557,8 @@ extern "C" int mgr_lbs_cov_fwd(int P, int N, int B, const float* xyz, const floa
     if (!xyz || !log_scale || !rot || !posed_xyz || !posed_cov || (skin_w && !transforms))
         return mgr_fail(MGR_EINVAL, "mgr_lbs_cov_fwd: null pointer");
     hipStream_t stream = (hipStream_t)stream_;
-    hipLaunchKernelGGL(k_lbs_fwd, dim3((N + 255) / 256, P), dim3(256), 0, stream, N, B, xyz, log_scale, rot,
-                       skin_w, transforms, posed_xyz, posed_cov, tf);
+    { MGR_PROF("k_lbs_fwd", stream); hipLaunchKernelGGL(k_lbs_fwd, dim3((N + 255) / 256, P), dim3(256), 0, stream, N, B, xyz, log_scale, rot,
+                       skin_w, transforms, posed_xyz, posed_cov, tf); }
     MGR_LAUNCH_CHECK("k_lbs_fwd", stream, 0);
     return MGR_OK;
 }
@@ -575,9 +575,9 @@ extern "C" int mgr_lbs_cov_bwd(int P, int N, int B, const float* xyz, const floa
         !dL_drot || (skin_w && (!transforms || !dL_dw)))
         return mgr_fail(MGR_EINVAL, "mgr_lbs_cov_bwd: null pointer");
     hipStream_t stream = (hipStream_t)stream_;
-    hipLaunchKernelGGL(k_lbs_bwd, dim3((N + 255) / 256), dim3(256), 0, stream, P, N, B, xyz, log_scale, rot,
+    { MGR_PROF("k_lbs_bwd", stream); hipLaunchKernelGGL(k_lbs_bwd, dim3((N + 255) / 256), dim3(256), 0, stream, P, N, B, xyz, log_scale, rot,
                        skin_w, transforms, dL_dposed_xyz, dL_dposed_cov, dL_dtf, dL_dxyz, dL_dlog_scale,
-                       dL_drot, dL_dw);
+                       dL_drot, dL_dw); }
     MGR_LAUNCH_CHECK("k_lbs_bwd", stream, 0);
     return MGR_OK;
 }
@@ -589,8 +589,8 @@ extern "C" int mgr_sh_color_fwd(int V, int N, const float* sh, const float* xyz,
     if (N == 0) return MGR_OK;
     if (!sh || !xyz || !cams || !colors) return mgr_fail(MGR_EINVAL, "mgr_sh_color_fwd: null pointer");
     hipStream_t stream = (hipStream_t)stream_;
-    hipLaunchKernelGGL(k_sh_fwd, dim3((N + 255) / 256, V), dim3(256), 0, stream, N, sh, xyz, stride_xyz, tf,
-                       stride_tf, cams, colors);
+    { MGR_PROF("k_sh_fwd", stream); hipLaunchKernelGGL(k_sh_fwd, dim3((N + 255) / 256, V), dim3(256), 0, stream, N, sh, xyz, stride_xyz, tf,
+                       stride_tf, cams, colors); }
     MGR_LAUNCH_CHECK("k_sh_fwd", stream, 0);
     return MGR_OK;
 }
@@ -604,8 +604,8 @@ extern "C" int mgr_sh_color_bwd(int V, int N, const float* sh, const float* xyz,
     if (!sh || !xyz || !cams || !dL_dcolors || !dL_dsh || !dL_dxyz || (tf && !dL_dtf))
         return mgr_fail(MGR_EINVAL, "mgr_sh_color_bwd: null pointer");
     hipStream_t stream = (hipStream_t)stream_;
-    hipLaunchKernelGGL(k_sh_bwd, dim3((N + 255) / 256), dim3(256), 0, stream, V, N, sh, xyz, stride_xyz, tf,
-                       stride_tf, cams, dL_dcolors, dL_dsh, dL_dxyz, dL_dtf);
+    { MGR_PROF("k_sh_bwd", stream); hipLaunchKernelGGL(k_sh_bwd, dim3((N + 255) / 256), dim3(256), 0, stream, V, N, sh, xyz, stride_xyz, tf,
+                       stride_tf, cams, dL_dcolors, dL_dsh, dL_dxyz, dL_dtf); }
     MGR_LAUNCH_CHECK("k_sh_bwd", stream, 0);
     return MGR_OK;
 }
@@ -616,7 +616,7 @@ extern "C" int mgr_project_points(int N, const float* xyz, const float* K9, cons
     if (N == 0) return MGR_OK;
     if (!xyz || !K9 || !E12 || !uv) return mgr_fail(MGR_EINVAL, "mgr_project_points: null pointer");
     hipStream_t stream = (hipStream_t)stream_;
-    hipLaunchKernelGGL(k_project, dim3((N + 255) / 256), dim3(256), 0, stream, N, xyz, K9, E12, uv);
+    { MGR_PROF("k_project", stream); hipLaunchKernelGGL(k_project, dim3((N + 255) / 256), dim3(256), 0, stream, N, xyz, K9, E12, uv); }
     MGR_LAUNCH_CHECK("k_project", stream, 0);
     return MGR_OK;
 }
@@ -633,8 +633,8 @@ extern "C" int mgr_l1_loss_grad(int64_t count, const float* a, const float* b, f
     int blocks = (int)((n4 + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_l1_grad, dim3(blocks), dim3(256), 0, stream, count, (const float4*)a, (const float4*)b,
-                       scale, (float4*)dL_da, loss_sum, a, b, dL_da);
+    { MGR_PROF("k_l1_grad", stream); hipLaunchKernelGGL(k_l1_grad, dim3(blocks), dim3(256), 0, stream, count, (const float4*)a, (const float4*)b,
+                       scale, (float4*)dL_da, loss_sum, a, b, dL_da); }
     MGR_LAUNCH_CHECK("k_l1_grad", stream, 0);
     return MGR_OK;
 }

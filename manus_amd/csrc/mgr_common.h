@@ -37,6 +37,25 @@ static inline int mgr_fail(int code, const char* fmt, const char* a = "", const 
     } while (0)
 
 // ---------------------------------------------------------------------------
+// optional per-kernel timing with HIP events on the caller's stream
+// (mgr_profile_enable / mgr_profile_report); zero cost when disabled
+// ---------------------------------------------------------------------------
+void mgr_prof_begin(const char* name, hipStream_t stream);
+void mgr_prof_end(hipStream_t stream);
+extern int g_mgr_prof_on;
+struct MgrProfScope {
+    hipStream_t s;
+    bool on;
+    MgrProfScope(const char* name, hipStream_t stream) : s(stream), on(g_mgr_prof_on != 0) {
+        if (on) mgr_prof_begin(name, s);
+    }
+    ~MgrProfScope() {
+        if (on) mgr_prof_end(s);
+    }
+};
+#define MGR_PROF(name, stream) MgrProfScope mgr_prof_scope_(name, stream)
+
+// ---------------------------------------------------------------------------
 // workspace layout of the rasterizer (shared by forward and backward)
 // ---------------------------------------------------------------------------
 struct MgrHeader {            // first 256 bytes of the workspace

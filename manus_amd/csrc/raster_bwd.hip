@@ -286,18 +286,18 @@ extern "C" int mgr_raster_backward(int V, int N, int W, int H, const float* cams
     if (epoch == 0) epoch = g_epoch.fetch_add(1) + 1;
     (void)hdr;
 
-    hipLaunchKernelGGL(k_blend_bwd, dim3(gx, gy, V), dim3(256), 0, stream, N, W, H, gx, gy, bg,
+    { MGR_PROF("k_blend_bwd", stream); hipLaunchKernelGGL(k_blend_bwd, dim3(gx, gy, V), dim3(256), 0, stream, N, W, H, gx, gy, bg,
                        (const uint32_t*)(ws + L.tile_start), (const uint32_t*)(ws + L.sorted_gid),
                        (const MgrGRec*)(ws + L.grec), (const float*)(ws + L.final_T),
                        (const uint32_t*)(ws + L.n_contrib), (const uint32_t*)(ws + L.tile_done),
                        dL_dcolor, (uint32_t*)(ws + L.pair_tag), (float4*)(ws + L.pair_grad),
-                       (uint32_t)cap, epoch);
+                       (uint32_t)cap, epoch); }
     MGR_LAUNCH_CHECK("k_blend_bwd", stream, debug);
-    hipLaunchKernelGGL(k_preprocess_bwd, dim3((N + 255) / 256, V), dim3(256), 0, stream, N, W, H, cams,
+    { MGR_PROF("k_preprocess_bwd", stream); hipLaunchKernelGGL(k_preprocess_bwd, dim3((N + 255) / 256, V), dim3(256), 0, stream, N, W, H, cams,
                        means3D, s_means, cov3D, s_cov, (const int32_t*)nullptr,
                        (const ushort4*)(ws + L.rect), (const uint32_t*)(ws + L.pair_off),
                        (const uint32_t*)(ws + L.pair_tag), (const float4*)(ws + L.pair_grad),
-                       dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dcov3D, (uint32_t)cap, epoch);
+                       dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dcov3D, (uint32_t)cap, epoch); }
     MGR_LAUNCH_CHECK("k_preprocess_bwd", stream, debug);
     return MGR_OK;
 }

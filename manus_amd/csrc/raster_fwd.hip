@@ -15,7 +15,71 @@
 //    overflow raises a flag in the workspace header.
 #include "mgr_common.h"
 
+#include <map>
+#include <string>
+#include <vector>
+
 thread_local char g_mgr_err[512] = {0};
+
+// ---------------------------------------------------------------------------
+// event profiler
+// ---------------------------------------------------------------------------
+int g_mgr_prof_on = 0;
+namespace {
+struct ProfRec { const char* name; hipEvent_t a, b; };
+std::vector<ProfRec> g_prof_recs;
+std::vector<hipEvent_t> g_prof_pool;
+hipEvent_t prof_event() {
+    if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+}  // namespace
+
+void mgr_prof_begin(const char* name, hipStream_t stream) {
+    ProfRec r{name, prof_event(), prof_event()};
+    if (r.a) (void)hipEventRecord(r.a, stream);
+    g_prof_recs.push_back(r);
+}
+void mgr_prof_end(hipStream_t stream) {
+    if (!g_prof_recs.empty() && g_prof_recs.back().b) (void)hipEventRecord(g_prof_recs.back().b, stream);
+}
+
+extern "C" int mgr_profile_enable(int on) {
+    g_mgr_prof_on = on ? 1 : 0;
+    return MGR_OK;
+}
+
+extern "C" int mgr_profile_report(char* buf, size_t len, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    MGR_HIP(hipStreamSynchronize(stream));
+    std::map<std::string, std::pair<long, double>> agg;
+    std::vector<std::string> order;
+    for (auto& r : g_prof_recs) {
+        float ms = 0.f;
+        if (r.a && r.b && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            auto it = agg.find(r.name);
+            if (it == agg.end()) { order.push_back(r.name); agg[r.name] = {1, ms}; }
+            else { it->second.first += 1; it->second.second += ms; }
+        }
+        if (r.a) g_prof_pool.push_back(r.a);
+        if (r.b) g_prof_pool.push_back(r.b);
+    }
+    g_prof_recs.clear();
+    std::string out;
+    for (auto& n : order) {
+        char line[256];
+        snprintf(line, sizeof(line), "%s %ld %.6f\n", n.c_str(), agg[n].first, agg[n].second);
+        out += line;
+    }
+    if (buf && len) {
+        size_t k = out.size() < len - 1 ? out.size() : len - 1;
+        memcpy(buf, out.data(), k);
+        buf[k] = 0;
+    }
+    return MGR_OK;
+}
 
 extern "C" int mgr_version(void) { return MGR_VERSION; }
 extern "C" const char* mgr_last_error(void) { return g_mgr_err; }
@@ -479,33 +543,33 @@ extern "C" int mgr_raster_forward(int V, int N, int W, int H, const float* cams,
     const size_t hist_bytes = lds_hist ? (size_t)T * 4 : 0;
     if (N > 0) {
         dim3 grid((N + PRE_THREADS - 1) / PRE_THREADS, V);
-        hipLaunchKernelGGL(k_preprocess, grid, dim3(PRE_THREADS), 128 + hist_bytes, stream, N, W, H, gx,
+        { MGR_PROF("k_preprocess", stream); hipLaunchKernelGGL(k_preprocess, grid, dim3(PRE_THREADS), 128 + hist_bytes, stream, N, W, H, gx,
                            gy, cams, means3D, s_means, cov3D, s_cov, colors, s_col, opacity, s_op,
                            (MgrGRec*)(ws + L.grec), (float*)(ws + L.depth), (ushort4*)(ws + L.rect),
-                           (uint32_t*)(ws + L.pair_off), tile_count, radii, hdr, lds_hist);
+                           (uint32_t*)(ws + L.pair_off), tile_count, radii, hdr, lds_hist); }
         MGR_LAUNCH_CHECK("k_preprocess", stream, debug);
     }
-    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, stream, VT, tile_count, tile_start,
+    { MGR_PROF("k_tile_scan", stream); hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, stream, VT, tile_count, tile_start,
                        (uint32_t*)(ws + L.tile_cursor), (uint32_t*)(ws + L.tile_queue), hdr,
-                       (uint32_t)cap);
+                       (uint32_t)cap); }
     MGR_LAUNCH_CHECK("k_tile_scan", stream, debug);
     if (N > 0) {
         dim3 grid((N + PRE_THREADS - 1) / PRE_THREADS, V);
-        hipLaunchKernelGGL(k_emit, grid, dim3(PRE_THREADS), hist_bytes + 16, stream, N, gx, gy,
+        { MGR_PROF("k_emit", stream); hipLaunchKernelGGL(k_emit, grid, dim3(PRE_THREADS), hist_bytes + 16, stream, N, gx, gy,
                            (const float*)(ws + L.depth), (const ushort4*)(ws + L.rect), tile_start,
                            (uint32_t*)(ws + L.tile_cursor), (unsigned long long*)(ws + L.keys),
-                           (uint32_t)cap, lds_hist);
+                           (uint32_t)cap, lds_hist); }
         MGR_LAUNCH_CHECK("k_emit", stream, debug);
-        hipLaunchKernelGGL(k_tile_sort, dim3(256), dim3(SORT_THREADS), SORT_LDS_KEYS * 8 + 16, stream,
+        { MGR_PROF("k_tile_sort", stream); hipLaunchKernelGGL(k_tile_sort, dim3(256), dim3(SORT_THREADS), SORT_LDS_KEYS * 8 + 16, stream,
                            tile_start, (const uint32_t*)(ws + L.tile_queue),
                            (unsigned long long*)(ws + L.keys), (uint32_t*)(ws + L.sorted_gid), hdr,
-                           (uint32_t)cap);
+                           (uint32_t)cap); }
         MGR_LAUNCH_CHECK("k_tile_sort", stream, debug);
     }
-    hipLaunchKernelGGL(k_blend_fwd, dim3(gx, gy, V), dim3(256), 0, stream, N, W, H, gx, gy, bg, tile_start,
+    { MGR_PROF("k_blend_fwd", stream); hipLaunchKernelGGL(k_blend_fwd, dim3(gx, gy, V), dim3(256), 0, stream, N, W, H, gx, gy, bg, tile_start,
                        (const uint32_t*)(ws + L.sorted_gid), (const MgrGRec*)(ws + L.grec), out_color,
                        (float*)(ws + L.final_T), (uint32_t*)(ws + L.n_contrib),
-                       (uint32_t*)(ws + L.tile_done), (uint32_t)cap);
+                       (uint32_t*)(ws + L.tile_done), (uint32_t)cap); }
     MGR_LAUNCH_CHECK("k_blend_fwd", stream, debug);
     return MGR_OK;
 }

@@ -24,20 +24,21 @@ def shard_views(n_views, rank, world_size):
     return list(range(rank, n_views, world_size))
 
 
-def pack_grads(grads, N, device):
-    buf = torch.empty((N, GRAD_WIDTH), dtype=torch.float32, device=device)
+def pack_grads(grads, N, device, out=None):
+    """Flat SoA buffer: one contiguous segment per leaf, in GRAD_LAYOUT order."""
+    buf = out if out is not None else torch.empty(N * GRAD_WIDTH, dtype=torch.float32, device=device)
     o = 0
     for name, w in GRAD_LAYOUT:
-        buf[:, o:o + w] = grads[name].reshape(N, w)
-        o += w
+        buf[o:o + N * w].copy_(grads[name].reshape(-1))
+        o += N * w
     return buf
 
 
-def unpack_grads(buf, shapes):
+def unpack_grads(buf, shapes, N):
     out, o = {}, 0
     for name, w in GRAD_LAYOUT:
-        out[name] = buf[:, o:o + w].reshape(shapes[name])
-        o += w
+        out[name] = buf[o:o + N * w].reshape(shapes[name])
+        o += N * w
     return out
 
 
@@ -45,36 +46,43 @@ class ViewShardedStep:
     """Runs `compute_fn(view_ids)` on this rank's views and reduces across ranks.
 
     compute_fn returns a dict with
-        grads      {leaf name: sum over the given views of dL_v/dleaf}
-        grad2d     (N,) sum over views of the visible 2D-gradient norms
+        grads      {leaf name: scale * sum over the given views of dL_v/dleaf}
+        grad2d     (N,) sum over views of the visible 2D-gradient norms (unscaled)
         vis        (N,) number of views in which the Gaussian was visible
         radii      (N,) int32 max screen radius over views
-        loss       scalar tensor, sum of L_v
+        loss       scalar tensor, scale * sum of L_v
+    where compute_fn is called as compute_fn(view_ids, scale).
     """
 
     def __init__(self, n_gaussians, shapes, compute_fn, n_views, rank=0, world_size=1, group=None):
         self.N, self.shapes, self.compute_fn = n_gaussians, shapes, compute_fn
         self.n_views, self.rank, self.world, self.group = n_views, rank, world_size, group
         self.local_views = shard_views(n_views, rank, world_size)
+        self._flat = None
 
     def step(self):
-        out = self.compute_fn(self.local_views)
+        # compute_fn folds the 1/V of "grad = (1/V) sum_v grad L_v" into the loss scale
+        out = self.compute_fn(self.local_views, 1.0 / float(self.n_views))
         dev = out["grad2d"].device
         N = self.N
-        flat = torch.empty(N * (GRAD_WIDTH + 2) + 1, dtype=torch.float32, device=dev)
-        flat[: N * GRAD_WIDTH] = pack_grads(out["grads"], N, dev).reshape(-1)
-        flat[N * GRAD_WIDTH: N * (GRAD_WIDTH + 1)] = out["grad2d"]
-        flat[N * (GRAD_WIDTH + 1): N * (GRAD_WIDTH + 2)] = out["vis"]
-        flat[-1] = out["loss"]
+        if self.world == 1:
+            return dict(grads=out["grads"], grad2d=out["grad2d"], vis=out["vis"],
+                        radii=out["radii"].to(torch.int32), loss=out["loss"])
+        # one flat buffer -> one SUM all-reduce (+ one MAX all-reduce for the radii)
+        if self._flat is None or self._flat.device != dev:
+            self._flat = torch.empty(N * (GRAD_WIDTH + 2) + 1, dtype=torch.float32, device=dev)
+        flat = self._flat
+        pack_grads(out["grads"], N, dev, out=flat[: N * GRAD_WIDTH])
+        flat[N * GRAD_WIDTH: N * (GRAD_WIDTH + 1)].copy_(out["grad2d"])
+        flat[N * (GRAD_WIDTH + 1): N * (GRAD_WIDTH + 2)].copy_(out["vis"])
+        flat[-1:].copy_(out["loss"].reshape(1))
         radii = out["radii"].to(torch.int32)
-        if self.world > 1:
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-            dist.all_reduce(radii, op=dist.ReduceOp.MAX, group=self.group)
-        inv = 1.0 / float(self.n_views)
-        grads = unpack_grads((flat[: N * GRAD_WIDTH] * inv).reshape(N, GRAD_WIDTH), self.shapes)
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        dist.all_reduce(radii, op=dist.ReduceOp.MAX, group=self.group)
+        grads = unpack_grads(flat[: N * GRAD_WIDTH], self.shapes, N)
         return dict(grads=grads, grad2d=flat[N * GRAD_WIDTH: N * (GRAD_WIDTH + 1)],
                     vis=flat[N * (GRAD_WIDTH + 1): N * (GRAD_WIDTH + 2)], radii=radii,
-                    loss=flat[-1] * inv)
+                    loss=flat[-1])
 
 
 class HipViewCompute:
@@ -92,20 +100,33 @@ class HipViewCompute:
         self.loss_weight = loss_weight
         self.is_hand = scene.get("grid") is not None and scene["kind"] == "hand"
         self.params = {k: v.detach().clone().requires_grad_(True) for k, v in scene["params"].items()}
+        self._cache = {}
+
+    def _select(self, view_ids):
+        """Per-view constants for a set of views (cached: no per-step gather copies)."""
+        key = tuple(view_ids)
+        c = self._cache.get(key)
+        if c is None:
+            idx = list(view_ids)
+            c = dict(cams=self.cams[idx].contiguous(), targets=self.targets[idx].contiguous(),
+                     T=self.s["transforms"][idx].contiguous() if self.is_hand else None)
+            self._cache = {key: c}
+        return c
 
     def forward_views(self, view_ids):
         s, p, ops = self.s, self.params, self.ops
-        cams = self.cams[view_ids].contiguous()
+        sel = self._select(view_ids)
+        cams = sel["cams"]
         V = len(view_ids)
         feats = torch.cat([p["_features_dc"], p["_features_rest"]], dim=1)
         opac = torch.sigmoid(p["_opacity"])
         if self.is_hand:
             w = ops.skin_weights(p["_xyz"], s["grid"], s["grid_center"], s["grid_scale"])
-            T = s["transforms"][view_ids].contiguous()  # one pose per view (reference: one (frame,view) per step)
-            pxyz, pcov, tf = ops.lbs_cov(p["_xyz"], p["_scaling"], p["_rotation"], w, T)
+            # one pose per view (the reference trains one (frame, view) per step)
+            pxyz, pcov, tf = ops.lbs_cov(p["_xyz"], p["_scaling"], p["_rotation"], w, sel["T"])
             col = ops.sh_colors(feats, p["_xyz"], tf, cams)
         else:
-            pxyz1, pcov1, _ = ops.lbs_cov(p["_xyz"], p["_scaling"], p["_rotation"], None, None)
+            _, pcov1, _ = ops.lbs_cov(p["_xyz"], p["_scaling"], p["_rotation"], None, None)
             pxyz, pcov = p["_xyz"], pcov1[0]
             col = ops.sh_colors(feats, p["_xyz"], None, cams)
         N = p["_xyz"].shape[0]
@@ -113,16 +134,17 @@ class HipViewCompute:
         img, radii = self.rz.rasterize_views(cams, pxyz, means2D, col, opac, pcov, s["bg"], s["width"], s["height"])
         return img, radii, means2D
 
-    def __call__(self, view_ids):
+    def __call__(self, view_ids, scale=1.0):
         for v in self.params.values():
             v.grad = None
         img, radii, means2D = self.forward_views(view_ids)
-        tgt = self.targets[view_ids]
+        tgt = self._select(view_ids)["targets"]
         per_view = img[0].numel()
-        loss_sum, g = self.ops.l1_loss_grad(img, tgt, scale=self.loss_weight / per_view)
+        k = self.loss_weight * scale / per_view
+        loss_sum, g = self.ops.l1_loss_grad(img, tgt, scale=k)
         img.backward(g)
         vis = radii > 0
-        g2 = means2D.grad[..., :2].norm(dim=-1)
-        return dict(grads={k: v.grad for k, v in self.params.items()},
+        g2 = means2D.grad[..., :2].norm(dim=-1) * (1.0 / scale)
+        return dict(grads={n: v.grad for n, v in self.params.items()},
                     grad2d=(g2 * vis).sum(0), vis=vis.sum(0).float(),
-                    radii=radii.max(dim=0).values, loss=loss_sum[0] * (self.loss_weight / per_view))
+                    radii=radii.max(dim=0).values, loss=loss_sum[0] * k)

@@ -166,7 +166,7 @@ def test_engine_step_matches_sequential_reference_steps():
     full = ViewShardedStep(sc["N"], shapes, hc, 4).step()
     acc = None
     for v in range(4):
-        o = hc([v])
+        o = hc([v], 1.0)
         if acc is None:
             acc = {k: g.clone() for k, g in o["grads"].items()}
             g2, vis, rad, loss = o["grad2d"].clone(), o["vis"].clone(), o["radii"].clone(), o["loss"].clone()
