@@ -79,7 +79,7 @@ struct __attribute__((aligned(16))) MgrGRec {
 };
 
 struct MgrLayout {
-    size_t header, grec, depth, rect, pair_off, tile_count, tile_start, tile_cursor, tile_done,
+    size_t header, grec, depth, rect, alive, pair_off, tile_count, tile_start, tile_cursor, tile_done,
         tile_queue, keys, sorted_gid, final_T, n_contrib, pair_tag, pair_grad, total;
 };
 
@@ -96,6 +96,7 @@ static inline MgrLayout mgr_layout(int V, int N, int W, int H, int64_t cap) {
     L.grec = o;        o += mgr_align(VN * sizeof(MgrGRec));
     L.depth = o;       o += mgr_align(VN * 4);
     L.rect = o;        o += mgr_align(VN * 8);       // 4 x uint16
+    L.alive = o;       o += mgr_align(VN * 8);       // bitmask of non-null tiles of the rect
     L.pair_off = o;    o += mgr_align(VN * 4);
     L.tile_count = o;  o += mgr_align(VT * 4);
     L.tile_start = o;  o += mgr_align((VT + 1) * 4);
@@ -192,5 +193,45 @@ __device__ __forceinline__ void mgr_sym_mul(const float c6[6], const float m[3],
     o[1] = c6[1] * m[0] + c6[3] * m[1] + c6[4] * m[2];
     o[2] = c6[2] * m[0] + c6[4] * m[1] + c6[5] * m[2];
 }
+
+// ---------------------------------------------------------------------------
+// exact null-pair culling
+//
+// A (pixel, Gaussian) evaluation contributes only if alpha = o*exp(-q/2) >= 1/255,
+// i.e. q <= qmax = 2 ln(255 o), with q = A dx^2 + 2B dx dy + C dy^2.  If the minimum
+// of q over a box of pixel centres exceeds qmax (plus a margin that covers fp32
+// rounding of both this bound and the per-pixel test), NO pixel of the box can
+// pass the per-pixel test, so dropping the pair changes neither image nor
+// gradients.  Non-positive-definite conics or NaNs are never culled.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float mgr_qmax(float opacity) { return 2.0f * __logf(255.0f * opacity); }
+
+__device__ __forceinline__ bool mgr_box_dead(float cx, float cy, float A, float B, float C, float qmax,
+                                             float x0, float y0, float x1, float y1) {
+    if (!(A > 0.0f && C > 0.0f && A * C - B * B > 0.0f)) return false;
+    const bool in_x = cx >= x0 && cx <= x1, in_y = cy >= y0 && cy <= y1;
+    if (in_x && in_y) return !(qmax >= -0.01f);  // centre inside the box: q_min = 0
+    float best = 3.0e38f, bestM = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {  // vertical edges x = x0 / x1
+        const float dx = (e ? x1 : x0) - cx;
+        const float y = fminf(fmaxf(cy - B * dx / C, y0), y1), dy = y - cy;
+        const float t0 = A * dx * dx, t1 = 2.0f * B * dx * dy, t2 = C * dy * dy;
+        const float q = t0 + t1 + t2;
+        if (q < best) { best = q; bestM = t0 + fabsf(t1) + t2; }
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {  // horizontal edges y = y0 / y1
+        const float dy = (e ? y1 : y0) - cy;
+        const float x = fminf(fmaxf(cx - B * dy / A, x0), x1), dx = x - cx;
+        const float t0 = A * dx * dx, t1 = 2.0f * B * dx * dy, t2 = C * dy * dy;
+        const float q = t0 + t1 + t2;
+        if (q < best) { best = q; bestM = t0 + fabsf(t1) + t2; }
+    }
+    return best > qmax + 0.01f + 1.0e-5f * bestM;
+}
+
+// natural exponential through v_exp_f32 (arguments here lie in [-12, 0])
+__device__ __forceinline__ float mgr_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
 
 #endif  // __HIPCC__

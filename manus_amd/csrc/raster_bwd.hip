@@ -19,8 +19,12 @@
 
 #include "mgr_common.h"
 
-#define BWD_BATCH 64
+#define BWD_BATCH 128
+#define BWD_SW (BWD_BATCH / 64)
 
+// Wave w owns the 8x8 pixel quadrant (w&1, w>>1) of the tile.  Entries are staged back to
+// front, BWD_BATCH at a time; the staging threads test each entry against the four quadrants
+// (mgr_box_dead) so that a wave only walks entries that can reach one of its pixels.
 __global__ __launch_bounds__(256) void k_blend_bwd(
     int N, int W, int H, int gx, int gy, const float* __restrict__ bg,
     const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ sorted_gid,
@@ -33,6 +37,7 @@ __global__ __launch_bounds__(256) void k_blend_bwd(
     __shared__ float s_rgb[BWD_BATCH * 3];
     __shared__ int32_t s_slot[BWD_BATCH];
     __shared__ uint32_t s_touch[BWD_BATCH];
+    __shared__ unsigned long long s_mask[BWD_SW][4];
     __shared__ float s_acc[4][BWD_BATCH][9];
 
     const int v = blockIdx.z, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -41,9 +46,11 @@ __global__ __launch_bounds__(256) void k_blend_bwd(
     const uint32_t nproc = tile_done[vt];
     if (nproc == 0) return;
     const uint32_t start = min(tile_start[vt], cap);
-    const int px = blockIdx.x * 16 + (tid & 15), py = blockIdx.y * 16 + (tid >> 4);
+    const int px = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
+    const int py = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
     const bool inside = px < W && py < H;
     const float fpx = (float)px, fpy = (float)py;
+    const float tx0 = (float)(blockIdx.x * 16), ty0 = (float)(blockIdx.y * 16);
     const size_t P = (size_t)W * H, pix = (size_t)py * W + px;
 
     float Tf = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f;
@@ -56,6 +63,9 @@ __global__ __launch_bounds__(256) void k_blend_bwd(
         g1 = gp[P];
         g2 = gp[2 * P];
     }
+    uint32_t wlast = last;  // deepest contributor of this wave's quadrant
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) wlast = max(wlast, (uint32_t)__shfl_xor((int)wlast, d, 64));
     const float bgdot = bg[0] * g0 + bg[1] * g1 + bg[2] * g2;
     const float ddelx = 0.5f * (float)W, ddely = 0.5f * (float)H;
     float Tr = Tf, a0 = 0.f, a1 = 0.f, a2 = 0.f, l0 = 0.f, l1 = 0.f, l2 = 0.f, last_alpha = 0.f;
@@ -63,89 +73,113 @@ __global__ __launch_bounds__(256) void k_blend_bwd(
     for (uint32_t hi = nproc; hi > 0; hi -= min(hi, (uint32_t)BWD_BATCH)) {
         const int cnt = (int)min(hi, (uint32_t)BWD_BATCH);
         __syncthreads();  // previous batch fully flushed
-        if (tid < cnt) {
-            const uint32_t gid = sorted_gid[start + hi - 1 - tid];
-            const MgrGRec* r = grec + (size_t)v * N + gid;
-            const float4 a = *(const float4*)r;
-            const float4 b = *((const float4*)r + 1);
-            const float4 c = *((const float4*)r + 2);
-            s_xy[tid] = make_float2(a.x, a.y);
-            s_co[tid] = make_float4(a.z, a.w, b.x, b.y);
-            s_rgb[tid * 3 + 0] = b.z;
-            s_rgb[tid * 3 + 1] = b.w;
-            s_rgb[tid * 3 + 2] = c.x;
-            s_slot[tid] = __float_as_int(c.y) + (int)blockIdx.y * __float_as_int(c.z) + (int)blockIdx.x;
+        if (tid < BWD_BATCH) {
+            bool d0 = true, d1 = true, d2 = true, d3 = true;
+            if (tid < cnt) {
+                const uint32_t gid = sorted_gid[start + hi - 1 - tid];
+                const MgrGRec* r = grec + (size_t)v * N + gid;
+                const float4 a = *(const float4*)r;
+                const float4 b = *((const float4*)r + 1);
+                const float4 c = *((const float4*)r + 2);
+                s_xy[tid] = make_float2(a.x, a.y);
+                s_co[tid] = make_float4(a.z, a.w, b.x, b.y);
+                s_rgb[tid * 3 + 0] = b.z;
+                s_rgb[tid * 3 + 1] = b.w;
+                s_rgb[tid * 3 + 2] = c.x;
+                s_slot[tid] = __float_as_int(c.y) + (int)blockIdx.y * __float_as_int(c.z) + (int)blockIdx.x;
+                const float qmax = mgr_qmax(b.y);
+                d0 = mgr_box_dead(a.x, a.y, a.z, a.w, b.x, qmax, tx0, ty0, tx0 + 7.f, ty0 + 7.f);
+                d1 = mgr_box_dead(a.x, a.y, a.z, a.w, b.x, qmax, tx0 + 8.f, ty0, tx0 + 15.f, ty0 + 7.f);
+                d2 = mgr_box_dead(a.x, a.y, a.z, a.w, b.x, qmax, tx0, ty0 + 8.f, tx0 + 7.f, ty0 + 15.f);
+                d3 = mgr_box_dead(a.x, a.y, a.z, a.w, b.x, qmax, tx0 + 8.f, ty0 + 8.f, tx0 + 15.f, ty0 + 15.f);
+            }
             s_touch[tid] = 0;
+            const unsigned long long m0 = __ballot(!d0), m1 = __ballot(!d1), m2 = __ballot(!d2), m3 = __ballot(!d3);
+            if (lane == 0) {
+                s_mask[wave][0] = m0; s_mask[wave][1] = m1; s_mask[wave][2] = m2; s_mask[wave][3] = m3;
+            }
         }
-        for (int k = tid; k < 4 * BWD_BATCH * 9; k += 256) (&s_acc[0][0][0])[k] = 0.f;
         __syncthreads();
 
-        for (int j = 0; j < cnt; ++j) {
-            const uint32_t pos = hi - 1 - (uint32_t)j;  // 0-based position in the tile list
-            float v_mx = 0.f, v_my = 0.f, v_ca = 0.f, v_cb = 0.f, v_cc = 0.f, v_op = 0.f,
-                  v_r = 0.f, v_g = 0.f, v_b = 0.f;
-            bool hit = false;
-            if (pos < last) {
-                const float2 xy = s_xy[j];
-                const float4 co = s_co[j];
-                const float dx = xy.x - fpx, dy = xy.y - fpy;
-                const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-                if (power <= 0.0f) {
-                    const float G = expf(power);
-                    const float alpha = fminf(0.99f, co.w * G);
-                    if (alpha >= 1.0f / 255.0f) {
-                        hit = true;
-                        Tr = Tr / (1.0f - alpha);
-                        const float dch = alpha * Tr;
-                        const float c0 = s_rgb[j * 3 + 0], c1 = s_rgb[j * 3 + 1], c2 = s_rgb[j * 3 + 2];
-                        a0 = last_alpha * l0 + (1.0f - last_alpha) * a0;
-                        a1 = last_alpha * l1 + (1.0f - last_alpha) * a1;
-                        a2 = last_alpha * l2 + (1.0f - last_alpha) * a2;
-                        l0 = c0; l1 = c1; l2 = c2;
-                        float dalpha = (c0 - a0) * g0 + (c1 - a1) * g1 + (c2 - a2) * g2;
-                        v_r = dch * g0; v_g = dch * g1; v_b = dch * g2;
-                        dalpha *= Tr;
-                        last_alpha = alpha;
-                        dalpha += (-Tf / (1.0f - alpha)) * bgdot;
-                        const float dG = co.w * dalpha;
-                        const float gdx = G * dx, gdy = G * dy;
-                        const float dGdx = -gdx * co.x - gdy * co.y;
-                        const float dGdy = -gdy * co.z - gdx * co.y;
-                        v_mx = dG * dGdx * ddelx;
-                        v_my = dG * dGdy * ddely;
-                        v_ca = -0.5f * gdx * dx * dG;
-                        v_cb = -0.5f * gdx * dy * dG;
-                        v_cc = -0.5f * gdy * dy * dG;
-                        v_op = G * dalpha;
+#pragma unroll 1
+        for (int sw = 0; sw < BWD_SW; ++sw) {
+            unsigned long long m = s_mask[sw][wave];
+            while (m) {
+                const int j = sw * 64 + __builtin_ctzll(m);
+                m &= m - 1;
+                const uint32_t pos = hi - 1 - (uint32_t)j;  // 0-based position in the tile list
+                if (pos >= wlast) continue;                  // wave-uniform
+                float v_mx = 0.f, v_my = 0.f, v_ca = 0.f, v_cb = 0.f, v_cc = 0.f, v_op = 0.f,
+                      v_r = 0.f, v_g = 0.f, v_b = 0.f;
+                bool hit = false;
+                if (pos < last) {
+                    const float2 xy = s_xy[j];
+                    const float4 co = s_co[j];
+                    const float dx = xy.x - fpx, dy = xy.y - fpy;
+                    const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+                    if (power <= 0.0f) {
+                        const float G = mgr_exp(power);
+                        const float alpha = fminf(0.99f, co.w * G);
+                        if (alpha >= 1.0f / 255.0f) {
+                            hit = true;
+                            Tr = Tr / (1.0f - alpha);
+                            const float dch = alpha * Tr;
+                            const float c0 = s_rgb[j * 3 + 0], c1 = s_rgb[j * 3 + 1], c2 = s_rgb[j * 3 + 2];
+                            a0 = last_alpha * l0 + (1.0f - last_alpha) * a0;
+                            a1 = last_alpha * l1 + (1.0f - last_alpha) * a1;
+                            a2 = last_alpha * l2 + (1.0f - last_alpha) * a2;
+                            l0 = c0; l1 = c1; l2 = c2;
+                            float dalpha = (c0 - a0) * g0 + (c1 - a1) * g1 + (c2 - a2) * g2;
+                            v_r = dch * g0; v_g = dch * g1; v_b = dch * g2;
+                            dalpha *= Tr;
+                            last_alpha = alpha;
+                            dalpha += (-Tf / (1.0f - alpha)) * bgdot;
+                            const float dG = co.w * dalpha;
+                            const float gdx = G * dx, gdy = G * dy;
+                            const float dGdx = -gdx * co.x - gdy * co.y;
+                            const float dGdy = -gdy * co.z - gdx * co.y;
+                            v_mx = dG * dGdx * ddelx;
+                            v_my = dG * dGdy * ddely;
+                            v_ca = -0.5f * gdx * dx * dG;
+                            v_cb = -0.5f * gdx * dy * dG;
+                            v_cc = -0.5f * gdy * dy * dG;
+                            v_op = G * dalpha;
+                        }
+                    }
+                }
+                if (__ballot(hit) != 0ull) {  // wave-uniform
+                    v_mx = mgr_wave_sum63(v_mx);
+                    v_my = mgr_wave_sum63(v_my);
+                    v_ca = mgr_wave_sum63(v_ca);
+                    v_cb = mgr_wave_sum63(v_cb);
+                    v_cc = mgr_wave_sum63(v_cc);
+                    v_op = mgr_wave_sum63(v_op);
+                    v_r = mgr_wave_sum63(v_r);
+                    v_g = mgr_wave_sum63(v_g);
+                    v_b = mgr_wave_sum63(v_b);
+                    if (lane == 63) {
+                        float* d = s_acc[wave][j];
+                        d[0] = v_mx; d[1] = v_my; d[2] = v_ca; d[3] = v_cb; d[4] = v_cc;
+                        d[5] = v_op; d[6] = v_r; d[7] = v_g; d[8] = v_b;
+                        atomicOr(&s_touch[j], 1u << wave);
                     }
                 }
             }
-            if (__ballot(hit) != 0ull) {  // wave-uniform
-                v_mx = mgr_wave_sum63(v_mx);
-                v_my = mgr_wave_sum63(v_my);
-                v_ca = mgr_wave_sum63(v_ca);
-                v_cb = mgr_wave_sum63(v_cb);
-                v_cc = mgr_wave_sum63(v_cc);
-                v_op = mgr_wave_sum63(v_op);
-                v_r = mgr_wave_sum63(v_r);
-                v_g = mgr_wave_sum63(v_g);
-                v_b = mgr_wave_sum63(v_b);
-                if (lane == 63) {
-                    float* d = s_acc[wave][j];
-                    d[0] = v_mx; d[1] = v_my; d[2] = v_ca; d[3] = v_cb; d[4] = v_cc;
-                    d[5] = v_op; d[6] = v_r; d[7] = v_g; d[8] = v_b;
-                    s_touch[j] = 1;
-                }
-            }
         }
         __syncthreads();
-        if (tid < cnt && s_touch[tid]) {
+        if (tid < cnt) {
+            const uint32_t fl = s_touch[tid];
             const int32_t slot = s_slot[tid];
-            if (slot >= 0 && (uint32_t)slot < cap) {
+            if (fl && slot >= 0 && (uint32_t)slot < cap) {
                 float r[9];
 #pragma unroll
-                for (int c = 0; c < 9; ++c)
-                    r[c] = ((s_acc[0][tid][c] + s_acc[1][tid][c]) + s_acc[2][tid][c]) + s_acc[3][tid][c];
+                for (int c = 0; c < 9; ++c) r[c] = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w)  // fixed wave order: deterministic sum
+                    if (fl & (1u << w)) {
+#pragma unroll
+                        for (int c = 0; c < 9; ++c) r[c] += s_acc[w][tid][c];
+                    }
                 float4* o = pair_grad + (size_t)slot * 3;
                 o[0] = make_float4(r[0], r[1], r[2], r[3]);
                 o[1] = make_float4(r[4], r[5], r[6], r[7]);

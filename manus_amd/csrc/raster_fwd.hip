@@ -129,8 +129,9 @@ __global__ __launch_bounds__(PRE_THREADS) void k_preprocess(
     const float* __restrict__ means3D, int64_t s_means, const float* __restrict__ cov3D,
     int64_t s_cov, const float* __restrict__ colors, int64_t s_col,
     const float* __restrict__ opacity, int64_t s_op, MgrGRec* __restrict__ grec,
-    float* __restrict__ depth, ushort4* __restrict__ rect, uint32_t* __restrict__ pair_off,
-    uint32_t* __restrict__ tile_count, int32_t* __restrict__ radii, MgrHeader* hdr, int lds_hist) {
+    float* __restrict__ depth, ushort4* __restrict__ rect, unsigned long long* __restrict__ alive,
+    uint32_t* __restrict__ pair_off, uint32_t* __restrict__ tile_count, int32_t* __restrict__ radii,
+    MgrHeader* hdr, int lds_hist) {
     extern __shared__ uint32_t s_mem[];
     uint32_t* s_scan = s_mem;       // 32 words
     uint32_t* s_hist = s_mem + 32;  // gx*gy words when lds_hist
@@ -193,16 +194,28 @@ __global__ __launch_bounds__(PRE_THREADS) void k_preprocess(
         }
     }
     const uint32_t tiles = (uint32_t)((x1 - x0) * (y1 - y0));
+    const float op_i = (i < N) ? opacity[(size_t)v * s_op + i] : 0.0f;
 
-    // tile histogram
+    // tile histogram over the NON-NULL tiles of the rectangle (exact culling, see
+    // mgr_box_dead); the mask is stored so that k_emit makes the identical decision.
+    // Rectangles of more than 64 tiles are not culled.
+    unsigned long long amask = ~0ull;
     if (radius > 0) {
-        if (lds_hist) {
-            for (int y = y0; y < y1; ++y)
-                for (int x = x0; x < x1; ++x) atomicAdd(&s_hist[y * gx + x], 1u);
-        } else {
-            for (int y = y0; y < y1; ++y)
-                for (int x = x0; x < x1; ++x) atomicAdd(&tile_count[(size_t)v * T + y * gx + x], 1u);
-        }
+        const bool small = tiles <= 64;
+        const float qmax = mgr_qmax(op_i);
+        if (small) amask = 0ull;
+        int k = 0;
+        for (int y = y0; y < y1; ++y)
+            for (int x = x0; x < x1; ++x, ++k) {
+                if (small) {
+                    if (mgr_box_dead(px, py, ca, cb, cc, qmax, 16.0f * x, 16.0f * y, 16.0f * x + 15.0f,
+                                     16.0f * y + 15.0f))
+                        continue;
+                    amask |= 1ull << k;
+                }
+                if (lds_hist) atomicAdd(&s_hist[y * gx + x], 1u);
+                else atomicAdd(&tile_count[(size_t)v * T + y * gx + x], 1u);
+            }
     }
 
     // pair-slot offsets: contiguous per Gaussian; block base from one atomic
@@ -216,7 +229,7 @@ __global__ __launch_bounds__(PRE_THREADS) void k_preprocess(
         const size_t vi = (size_t)v * N + i;
         MgrGRec r;
         r.x = px; r.y = py; r.ca = ca; r.cb = cb; r.cc = cc;
-        r.op = opacity[(size_t)v * s_op + i];
+        r.op = op_i;
         const float* col = colors + (size_t)v * s_col + (size_t)i * 3;
         r.r = col[0]; r.g = col[1]; r.b = col[2];
         r.rect_w = x1 - x0;
@@ -226,6 +239,7 @@ __global__ __launch_bounds__(PRE_THREADS) void k_preprocess(
         depth[vi] = zv;
         rect[vi] = make_ushort4((unsigned short)x0, (unsigned short)y0, (unsigned short)x1,
                                 (unsigned short)y1);
+        alive[vi] = amask;
         pair_off[vi] = off;
         radii[vi] = radius;
     }
@@ -297,6 +311,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan(int VT, const uint32_t* __re
 __global__ __launch_bounds__(PRE_THREADS) void k_emit(int N, int gx, int gy,
                                                       const float* __restrict__ depth,
                                                       const ushort4* __restrict__ rect,
+                                                      const unsigned long long* __restrict__ alive,
                                                       const uint32_t* __restrict__ tile_start,
                                                       uint32_t* __restrict__ tile_cursor,
                                                       unsigned long long* __restrict__ keys,
@@ -308,30 +323,41 @@ __global__ __launch_bounds__(PRE_THREADS) void k_emit(int N, int gx, int gy,
     const int T = gx * gy;
     ushort4 rc = make_ushort4(0, 0, 0, 0);
     float z = 0.f;
+    unsigned long long am = 0ull;
     if (i < N) {
         rc = rect[(size_t)v * N + i];
         z = depth[(size_t)v * N + i];
+        am = alive[(size_t)v * N + i];
     }
+    const bool small = (uint32_t)((rc.z - rc.x) * (rc.w - rc.y)) <= 64u;
     const unsigned long long key_hi = ((unsigned long long)__float_as_uint(z)) << 32;
     if (lds_hist) {
         for (int k = tid; k < T; k += PRE_THREADS) s_hist[k] = 0;
         __syncthreads();
-        for (int y = rc.y; y < rc.w; ++y)
-            for (int x = rc.x; x < rc.z; ++x) atomicAdd(&s_hist[y * gx + x], 1u);
+        {
+            int k = 0;
+            for (int y = rc.y; y < rc.w; ++y)
+                for (int x = rc.x; x < rc.z; ++x, ++k)
+                    if (!small || ((am >> k) & 1ull)) atomicAdd(&s_hist[y * gx + x], 1u);
+        }
         __syncthreads();
         for (int k = tid; k < T; k += PRE_THREADS) {
             const uint32_t c = s_hist[k];
             if (c) s_hist[k] = tile_start[(size_t)v * T + k] + atomicAdd(&tile_cursor[(size_t)v * T + k], c);
         }
         __syncthreads();
+        int k = 0;
         for (int y = rc.y; y < rc.w; ++y)
-            for (int x = rc.x; x < rc.z; ++x) {
+            for (int x = rc.x; x < rc.z; ++x, ++k) {
+                if (small && !((am >> k) & 1ull)) continue;
                 const uint32_t pos = atomicAdd(&s_hist[y * gx + x], 1u);
                 if (pos < cap) keys[pos] = key_hi | (unsigned)i;
             }
     } else {
+        int k = 0;
         for (int y = rc.y; y < rc.w; ++y)
-            for (int x = rc.x; x < rc.z; ++x) {
+            for (int x = rc.x; x < rc.z; ++x, ++k) {
+                if (small && !((am >> k) & 1ull)) continue;
                 const size_t vt = (size_t)v * T + y * gx + x;
                 const uint32_t pos = tile_start[vt] + atomicAdd(&tile_cursor[vt], 1u);
                 if (pos < cap) keys[pos] = key_hi | (unsigned)i;
@@ -416,8 +442,11 @@ __global__ __launch_bounds__(SORT_THREADS) void k_tile_sort(
 }
 
 // ---------------------------------------------------------------------------
-// K5: front-to-back alpha compositing, one 16x16 tile per 256-thread workgroup
-// (wave w = pixel rows 4w..4w+3), tile list staged through LDS 256 entries at a time
+// K5: front-to-back alpha compositing, one 16x16 tile per 256-thread workgroup.
+// Wave w owns the 8x8 pixel quadrant (w&1, w>>1).  The tile list is staged through
+// LDS 256 entries at a time; while staging, every entry is tested against the four
+// quadrants (mgr_box_dead) and the per-quadrant survivor bitmasks are published in
+// LDS, so a wave only walks entries that can reach at least one of its pixels.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, int gy,
                                                    const float* __restrict__ bg,
@@ -431,21 +460,25 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, 
     __shared__ float2 s_xy[256];
     __shared__ float4 s_co[256];
     __shared__ float s_rgb[256 * 3];
+    __shared__ unsigned long long s_mask[4][4];  // [staging wave][quadrant]
     __shared__ uint32_t s_max;
-    const int v = blockIdx.z, tid = threadIdx.x;
+    const int v = blockIdx.z, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int T = gx * gy;
     const size_t vt = (size_t)v * T + blockIdx.y * gx + blockIdx.x;
     const uint32_t start = min(tile_start[vt], cap), end = min(tile_start[vt + 1], cap);
-    const int px = blockIdx.x * 16 + (tid & 15), py = blockIdx.y * 16 + (tid >> 4);
+    const int px = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
+    const int py = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
     const bool inside = px < W && py < H;
     const float fpx = (float)px, fpy = (float)py;
+    const float tx0 = (float)(blockIdx.x * 16), ty0 = (float)(blockIdx.y * 16);
     if (tid == 0) s_max = 0;
     float Tr = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
-    uint32_t contributor = 0, last = 0;
+    uint32_t last = 0;
     bool done = !inside;
     for (uint32_t base = start; base < end; base += 256) {
         if (__syncthreads_count(done) == 256) break;
         const uint32_t idx = base + tid;
+        bool d0 = true, d1 = true, d2 = true, d3 = true;
         if (idx < end) {
             const MgrGRec* r = grec + (size_t)v * N + sorted_gid[idx];
             const float4 a = *(const float4*)r;
@@ -456,29 +489,46 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, 
             s_rgb[tid * 3 + 0] = b.z;
             s_rgb[tid * 3 + 1] = b.w;
             s_rgb[tid * 3 + 2] = c;
+            const float qmax = mgr_qmax(b.y);
+            d0 = mgr_box_dead(a.x, a.y, a.z, a.w, b.x, qmax, tx0, ty0, tx0 + 7.f, ty0 + 7.f);
+            d1 = mgr_box_dead(a.x, a.y, a.z, a.w, b.x, qmax, tx0 + 8.f, ty0, tx0 + 15.f, ty0 + 7.f);
+            d2 = mgr_box_dead(a.x, a.y, a.z, a.w, b.x, qmax, tx0, ty0 + 8.f, tx0 + 7.f, ty0 + 15.f);
+            d3 = mgr_box_dead(a.x, a.y, a.z, a.w, b.x, qmax, tx0 + 8.f, ty0 + 8.f, tx0 + 15.f, ty0 + 15.f);
+        }
+        const unsigned long long m0 = __ballot(!d0), m1 = __ballot(!d1), m2 = __ballot(!d2), m3 = __ballot(!d3);
+        if (lane == 0) {
+            s_mask[wave][0] = m0; s_mask[wave][1] = m1; s_mask[wave][2] = m2; s_mask[wave][3] = m3;
         }
         __syncthreads();
-        const int cnt = (int)min(256u, end - base);
-        for (int j = 0; !done && j < cnt; ++j) {
-            ++contributor;
-            const float2 xy = s_xy[j];
-            const float4 co = s_co[j];
-            const float dx = xy.x - fpx, dy = xy.y - fpy;
-            const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-            if (power > 0.0f) continue;
-            const float alpha = fminf(0.99f, co.w * expf(power));
-            if (alpha < 1.0f / 255.0f) continue;
-            const float testT = Tr * (1.0f - alpha);
-            if (testT < 0.0001f) {
-                done = true;
-                continue;
+        if (!__all(done)) {
+#pragma unroll 1
+            for (int sw = 0; sw < 4; ++sw) {
+                unsigned long long m = s_mask[sw][wave];
+                while (m) {
+                    const int j = sw * 64 + __builtin_ctzll(m);
+                    m &= m - 1;
+                    if (done) continue;
+                    const float2 xy = s_xy[j];
+                    const float4 co = s_co[j];
+                    const float dx = xy.x - fpx, dy = xy.y - fpy;
+                    const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+                    if (power > 0.0f) continue;
+                    const float alpha = fminf(0.99f, co.w * mgr_exp(power));
+                    if (alpha < 1.0f / 255.0f) continue;
+                    const float testT = Tr * (1.0f - alpha);
+                    if (testT < 0.0001f) {
+                        done = true;
+                        continue;
+                    }
+                    const float w = alpha * Tr;
+                    C0 += s_rgb[j * 3 + 0] * w;
+                    C1 += s_rgb[j * 3 + 1] * w;
+                    C2 += s_rgb[j * 3 + 2] * w;
+                    Tr = testT;
+                    last = (base - start) + (uint32_t)j + 1u;  // 1-based position in the tile list
+                }
+                if (__all(done)) break;
             }
-            const float w = alpha * Tr;
-            C0 += s_rgb[j * 3 + 0] * w;
-            C1 += s_rgb[j * 3 + 1] * w;
-            C2 += s_rgb[j * 3 + 2] * w;
-            Tr = testT;
-            last = contributor;
         }
     }
     if (inside) {
@@ -495,7 +545,7 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, 
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
     __syncthreads();
-    if ((tid & 63) == 0) atomicMax(&s_max, m);
+    if (lane == 0) atomicMax(&s_max, m);
     __syncthreads();
     if (tid == 0) tile_done[vt] = s_max;
 }
@@ -546,7 +596,8 @@ extern "C" int mgr_raster_forward(int V, int N, int W, int H, const float* cams,
         { MGR_PROF("k_preprocess", stream); hipLaunchKernelGGL(k_preprocess, grid, dim3(PRE_THREADS), 128 + hist_bytes, stream, N, W, H, gx,
                            gy, cams, means3D, s_means, cov3D, s_cov, colors, s_col, opacity, s_op,
                            (MgrGRec*)(ws + L.grec), (float*)(ws + L.depth), (ushort4*)(ws + L.rect),
-                           (uint32_t*)(ws + L.pair_off), tile_count, radii, hdr, lds_hist); }
+                           (unsigned long long*)(ws + L.alive), (uint32_t*)(ws + L.pair_off), tile_count, radii,
+                           hdr, lds_hist); }
         MGR_LAUNCH_CHECK("k_preprocess", stream, debug);
     }
     { MGR_PROF("k_tile_scan", stream); hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, stream, VT, tile_count, tile_start,
@@ -556,7 +607,8 @@ extern "C" int mgr_raster_forward(int V, int N, int W, int H, const float* cams,
     if (N > 0) {
         dim3 grid((N + PRE_THREADS - 1) / PRE_THREADS, V);
         { MGR_PROF("k_emit", stream); hipLaunchKernelGGL(k_emit, grid, dim3(PRE_THREADS), hist_bytes + 16, stream, N, gx, gy,
-                           (const float*)(ws + L.depth), (const ushort4*)(ws + L.rect), tile_start,
+                           (const float*)(ws + L.depth), (const ushort4*)(ws + L.rect),
+                           (const unsigned long long*)(ws + L.alive), tile_start,
                            (uint32_t*)(ws + L.tile_cursor), (unsigned long long*)(ws + L.keys),
                            (uint32_t)cap, lds_hist); }
         MGR_LAUNCH_CHECK("k_emit", stream, debug);
