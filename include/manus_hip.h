@@ -94,7 +94,8 @@ int mgr_raster_forward(int V, int N, int W, int H, const float* cams, const floa
                        int32_t* radii, void* workspace, size_t workspace_bytes,
                        int64_t pair_capacity, int debug, void* stream);
 
-/* Backward of the forward that last used `workspace` (same inputs again).
+/* Backward of the forward that last used `workspace` (same inputs again, plus the
+ * image that forward produced: out_color (V,3,H,W)).
  * dL_dcolor: (V,3,H,W).  Outputs, all fully written:
  * dL_dmeans3D (V,N,3), dL_dmeans2D (V,N,3) (z = 0; x,y in NDC-scaled pixel units
  * 0.5*W, 0.5*H as the reference's densification statistic expects,
@@ -103,10 +104,15 @@ int mgr_raster_forward(int V, int N, int W, int H, const float* cams, const floa
 int mgr_raster_backward(int V, int N, int W, int H, const float* cams, const float* bg,
                         const float* means3D, int64_t stride_means3D, const float* cov3D,
                         int64_t stride_cov3D, const float* colors, int64_t stride_colors,
-                        const float* opacity, int64_t stride_opacity, const float* dL_dcolor,
-                        float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dcolors,
+                        const float* opacity, int64_t stride_opacity, const float* out_color,
+                        const float* dL_dcolor, float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dcolors,
                         float* dL_dopacity, float* dL_dcov3D, void* workspace,
                         size_t workspace_bytes, int64_t pair_capacity, int debug, void* stream);
+
+/* Debug/test: byte offsets of the workspace regions, in the order header, grec, depth, rect,
+ * alive, pair_off, tile_count, tile_start, tile_cursor, tile_done, tile_queue, chunk_start, items,
+ * ckpt, keys, sorted_gid, final_T, n_contrib, pair_tag, pair_grad, total.  Returns the count. */
+int mgr_raster_layout(int V, int N, int W, int H, int64_t pair_capacity, size_t* out, int n_out);
 
 /* Blocking read-back of the workspace header after a forward: total number of
  * (Gaussian, tile) pairs (`num_rendered`, summed over views) and the overflow
@@ -128,13 +134,16 @@ int mgr_raster_debug_binning_sync(const void* workspace, int V, int N, int W, in
 /* Trilinear sample (align_corners=True, zero padding) of a channel-last grid
  * (D,H,W,B) at u = (xyz - center)/scale, u=(x,y,z) indexing (W,H,D), then
  * w /= sum(w) without epsilon (0/0 -> NaN exactly like the reference).
- * out_w: (N,B).  B <= MGR_MAX_BONES. */
+ * out_w: (N,B).  B <= MGR_MAX_BONES.  grid_stride = floats per voxel: B (the
+ * reference layout) or 24 (channels zero-padded to 24, 16-byte aligned base: the
+ * fast path with float4 gathers; needs B <= 24). */
 int mgr_skin_weights_fwd(int N, const float* xyz, const float* grid, int D, int H, int W, int B,
-                         const float* center3, const float* scale3, float* out_w, void* stream);
+                         int grid_stride, const float* center3, const float* scale3, float* out_w,
+                         void* stream);
 /* dL_dxyz (N,3) written (not accumulated). */
 int mgr_skin_weights_bwd(int N, const float* xyz, const float* grid, int D, int H, int W, int B,
-                         const float* center3, const float* scale3, const float* dL_dw,
-                         float* dL_dxyz, void* stream);
+                         int grid_stride, const float* center3, const float* scale3,
+                         const float* dL_dw, float* dL_dxyz, void* stream);
 
 /* LBS for P poses.  transforms: (P,B,16) row-major 4x4 bone transforms
  * T_b = posed_b * inv(rest_b) (+ identity background).  skin_w (N,B) or NULL for

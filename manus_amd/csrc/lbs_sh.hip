@@ -125,6 +125,99 @@ __global__ __launch_bounds__(256) void k_skin_bwd(int N, const float* __restrict
 }
 
 // ---------------------------------------------------------------------------
+// fast path: channel stride padded to 24 floats (96 B per voxel, 16-byte aligned), so every
+// corner is six float4 loads; one pass over the 8 corners in both directions.
+// Backward algebra: with per-corner scalars P_k = sum_b a_b c_k[b] and Q_k = sum_b c_k[b]
+// (a = dL/dw) and trilinear weights W_k, S = sum_k W_k Q_k, dot*S = sum_k W_k P_k and
+//   dL/d(ix) = (1/S) [ sum_k dW_k/d(ix) P_k - (dot*S / S) sum_k dW_k/d(ix) Q_k ].
+// ---------------------------------------------------------------------------
+#define SKIN_BP 24
+
+__device__ __forceinline__ void tri_weights(const TriSetup& s, float Wk[8]) {
+    const float wx[2] = {1.0f - s.fx, s.fx}, wy[2] = {1.0f - s.fy, s.fy}, wz[2] = {1.0f - s.fz, s.fz};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) Wk[k] = wx[k & 1] * wy[(k >> 1) & 1] * wz[k >> 2];
+}
+
+__global__ __launch_bounds__(256) void k_skin_fwd24(int N, const float* __restrict__ xyz,
+                                                    const float4* __restrict__ grid, int D, int H, int W,
+                                                    int B, const float* __restrict__ center,
+                                                    const float* __restrict__ scale,
+                                                    float* __restrict__ out_w) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const TriSetup s = tri_setup(xyz, i, center, scale, D, H, W);
+    float Wk[8];
+    tri_weights(s, Wk);
+    float acc[SKIN_BP];
+#pragma unroll
+    for (int b = 0; b < SKIN_BP; ++b) acc[b] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int x = s.x0 + (k & 1), y = s.y0 + ((k >> 1) & 1), z = s.z0 + (k >> 2);
+        if (x >= 0 && x < W && y >= 0 && y < H && z >= 0 && z < D) {
+            const float4* p = grid + (((size_t)z * H + y) * W + x) * (SKIN_BP / 4);
+#pragma unroll
+            for (int q = 0; q < SKIN_BP / 4; ++q) {
+                const float4 c = p[q];
+                acc[4 * q + 0] += Wk[k] * c.x;
+                acc[4 * q + 1] += Wk[k] * c.y;
+                acc[4 * q + 2] += Wk[k] * c.z;
+                acc[4 * q + 3] += Wk[k] * c.w;
+            }
+        }
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int b = 0; b < SKIN_BP; ++b) sum += acc[b];  // pad channels are zero
+#pragma unroll
+    for (int b = 0; b < SKIN_BP; ++b)
+        if (b < B) out_w[(size_t)i * B + b] = acc[b] / sum;
+}
+
+__global__ __launch_bounds__(256) void k_skin_bwd24(int N, const float* __restrict__ xyz,
+                                                    const float4* __restrict__ grid, int D, int H, int W,
+                                                    int B, const float* __restrict__ center,
+                                                    const float* __restrict__ scale,
+                                                    const float* __restrict__ dL_dw,
+                                                    float* __restrict__ dL_dxyz) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const TriSetup s = tri_setup(xyz, i, center, scale, D, H, W);
+    float a[SKIN_BP];
+#pragma unroll
+    for (int b = 0; b < SKIN_BP; ++b) a[b] = (b < B) ? dL_dw[(size_t)i * B + b] : 0.f;
+    const float wx[2] = {1.0f - s.fx, s.fx}, wy[2] = {1.0f - s.fy, s.fy}, wz[2] = {1.0f - s.fz, s.fz};
+    float S = 0.f, dS = 0.f, gxP = 0.f, gyP = 0.f, gzP = 0.f, gxQ = 0.f, gyQ = 0.f, gzQ = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int bx = k & 1, by = (k >> 1) & 1, bz = k >> 2;
+        const int x = s.x0 + bx, y = s.y0 + by, z = s.z0 + bz;
+        if (x >= 0 && x < W && y >= 0 && y < H && z >= 0 && z < D) {
+            const float4* p = grid + (((size_t)z * H + y) * W + x) * (SKIN_BP / 4);
+            float Pk = 0.f, Qk = 0.f;
+#pragma unroll
+            for (int q = 0; q < SKIN_BP / 4; ++q) {
+                const float4 c = p[q];
+                Pk += a[4 * q] * c.x + a[4 * q + 1] * c.y + a[4 * q + 2] * c.z + a[4 * q + 3] * c.w;
+                Qk += (c.x + c.y) + (c.z + c.w);
+            }
+            const float Wk = wx[bx] * wy[by] * wz[bz];
+            const float Dx = (bx ? 1.f : -1.f) * wy[by] * wz[bz];
+            const float Dy = (by ? 1.f : -1.f) * wx[bx] * wz[bz];
+            const float Dz = (bz ? 1.f : -1.f) * wx[bx] * wy[by];
+            S += Wk * Qk; dS += Wk * Pk;
+            gxP += Dx * Pk; gyP += Dy * Pk; gzP += Dz * Pk;
+            gxQ += Dx * Qk; gyQ += Dy * Qk; gzQ += Dz * Qk;
+        }
+    }
+    const float invS = 1.0f / S, dot = dS * invS;
+    dL_dxyz[3 * i + 0] = (gxP - dot * gxQ) * invS * (0.5f * (float)(W - 1)) / scale[0];
+    dL_dxyz[3 * i + 1] = (gyP - dot * gyQ) * invS * (0.5f * (float)(H - 1)) / scale[1];
+    dL_dxyz[3 * i + 2] = (gzP - dot * gzQ) * invS * (0.5f * (float)(D - 1)) / scale[2];
+}
+
+// ---------------------------------------------------------------------------
 // LBS of means and covariances
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void quat_rot(const float q[4], float R[9]) {
@@ -520,13 +613,21 @@ __global__ __launch_bounds__(256) void k_l1_grad(int64_t count, const float4* __
 // host entries
 // ---------------------------------------------------------------------------
 extern "C" int mgr_skin_weights_fwd(int N, const float* xyz, const float* grid, int D, int H, int W,
-                                    int B, const float* center3, const float* scale3, float* out_w,
-                                    void* stream_) {
+                                    int B, int grid_stride, const float* center3, const float* scale3,
+                                    float* out_w, void* stream_) {
     if (N < 0 || B <= 0 || B > MGR_MAX_BONES || D <= 0 || H <= 0 || W <= 0)
         return mgr_fail(MGR_EINVAL, "mgr_skin_weights_fwd: bad sizes");
     if (N == 0) return MGR_OK;
     if (!xyz || !grid || !center3 || !scale3 || !out_w) return mgr_fail(MGR_EINVAL, "mgr_skin_weights_fwd: null pointer");
     hipStream_t stream = (hipStream_t)stream_;
+    if (grid_stride != B && grid_stride != SKIN_BP) return mgr_fail(MGR_EINVAL, "mgr_skin_weights_fwd: grid_stride must be B or 24");
+    if (grid_stride == SKIN_BP && B <= SKIN_BP && ((uintptr_t)grid & 15) == 0) {
+        { MGR_PROF("k_skin_fwd24", stream); hipLaunchKernelGGL(k_skin_fwd24, dim3((N + 255) / 256), dim3(256), 0, stream, N, xyz, (const float4*)grid, D, H, W, B,
+                           center3, scale3, out_w); }
+        MGR_LAUNCH_CHECK("k_skin_fwd24", stream, 0);
+        return MGR_OK;
+    }
+    if (grid_stride != B) return mgr_fail(MGR_EINVAL, "mgr_skin_weights_fwd: padded grid must be 16-byte aligned with B <= 24");
     { MGR_PROF("k_skin_fwd", stream); hipLaunchKernelGGL(k_skin_fwd, dim3((N + 255) / 256), dim3(256), 0, stream, N, xyz, grid, D, H, W, B,
                        center3, scale3, out_w); }
     MGR_LAUNCH_CHECK("k_skin_fwd", stream, 0);
@@ -534,7 +635,7 @@ extern "C" int mgr_skin_weights_fwd(int N, const float* xyz, const float* grid, 
 }
 
 extern "C" int mgr_skin_weights_bwd(int N, const float* xyz, const float* grid, int D, int H, int W,
-                                    int B, const float* center3, const float* scale3,
+                                    int B, int grid_stride, const float* center3, const float* scale3,
                                     const float* dL_dw, float* dL_dxyz, void* stream_) {
     if (N < 0 || B <= 0 || B > MGR_MAX_BONES || D <= 0 || H <= 0 || W <= 0)
         return mgr_fail(MGR_EINVAL, "mgr_skin_weights_bwd: bad sizes");
@@ -542,6 +643,14 @@ extern "C" int mgr_skin_weights_bwd(int N, const float* xyz, const float* grid, 
     if (!xyz || !grid || !center3 || !scale3 || !dL_dw || !dL_dxyz)
         return mgr_fail(MGR_EINVAL, "mgr_skin_weights_bwd: null pointer");
     hipStream_t stream = (hipStream_t)stream_;
+    if (grid_stride != B && grid_stride != SKIN_BP) return mgr_fail(MGR_EINVAL, "mgr_skin_weights_bwd: grid_stride must be B or 24");
+    if (grid_stride == SKIN_BP && B <= SKIN_BP && ((uintptr_t)grid & 15) == 0) {
+        { MGR_PROF("k_skin_bwd24", stream); hipLaunchKernelGGL(k_skin_bwd24, dim3((N + 255) / 256), dim3(256), 0, stream, N, xyz, (const float4*)grid, D, H, W, B,
+                           center3, scale3, dL_dw, dL_dxyz); }
+        MGR_LAUNCH_CHECK("k_skin_bwd24", stream, 0);
+        return MGR_OK;
+    }
+    if (grid_stride != B) return mgr_fail(MGR_EINVAL, "mgr_skin_weights_bwd: padded grid must be 16-byte aligned with B <= 24");
     { MGR_PROF("k_skin_bwd", stream); hipLaunchKernelGGL(k_skin_bwd, dim3((N + 255) / 256), dim3(256), 0, stream, N, xyz, grid, D, H, W, B,
                        center3, scale3, dL_dw, dL_dxyz); }
     MGR_LAUNCH_CHECK("k_skin_bwd", stream, 0);

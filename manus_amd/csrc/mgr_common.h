@@ -65,7 +65,9 @@ struct MgrHeader {            // first 256 bytes of the workspace
     uint32_t queue_len;       // number of non-empty tiles in tile_queue
     uint32_t queue_head;      // work-queue cursor (sort)
     uint32_t queue_head2;     // spare cursor
-    uint32_t pad[58];
+    uint32_t n_items;         // number of (tile, chunk) work items appended by the forward blend
+    uint32_t item_head;       // backward work-queue cursor
+    uint32_t pad[56];
 };
 
 // 48-byte per-(view,Gaussian) record gathered by the blend kernels
@@ -78,9 +80,11 @@ struct __attribute__((aligned(16))) MgrGRec {
     int32_t pad;
 };
 
+#define MGR_CHUNK 128        // list entries per backward work item / forward checkpoint interval
+
 struct MgrLayout {
     size_t header, grec, depth, rect, alive, pair_off, tile_count, tile_start, tile_cursor, tile_done,
-        tile_queue, keys, sorted_gid, final_T, n_contrib, pair_tag, pair_grad, total;
+        tile_queue, chunk_start, items, ckpt, keys, sorted_gid, final_T, n_contrib, pair_tag, pair_grad, total;
 };
 
 static inline size_t mgr_align(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -103,6 +107,9 @@ static inline MgrLayout mgr_layout(int V, int N, int W, int H, int64_t cap) {
     L.tile_cursor = o; o += mgr_align(VT * 4);
     L.tile_done = o;   o += mgr_align(VT * 4);
     L.tile_queue = o;  o += mgr_align(VT * 4);
+    L.chunk_start = o; o += mgr_align((VT + 1) * 4);
+    L.items = o;       o += mgr_align((c / MGR_CHUNK + VT + 1) * 8);
+    L.ckpt = o;        o += mgr_align((c / MGR_CHUNK + 1) * 256 * 16);  // float4 per pixel per checkpoint
     L.keys = o;        o += mgr_align(c * 8);
     L.sorted_gid = o;  o += mgr_align(c * 4);
     L.final_T = o;     o += mgr_align(VP * 4);
@@ -157,6 +164,30 @@ __device__ __forceinline__ float mgr_wave_sum63(float v) {
     return v;
 }
 
+// Nine independent wave64 sums at once, totals valid in lane 63.  Written with fused
+// v_add_f32_dpp (in place: lanes/rows without a DPP source keep their value, i.e. add 0).
+// The nine chains are interleaved so that every DPP read of a VGPR is at least two
+// instructions after the VALU write of it (the hazard hipcc cannot see inside asm).
+#define MGR_DPP9(ctrl)                                                                              \
+    asm volatile("s_nop 1\n"                                                                        \
+                 "v_add_f32_dpp %0, %0, %0 " ctrl "\n v_add_f32_dpp %1, %1, %1 " ctrl "\n"          \
+                 "v_add_f32_dpp %2, %2, %2 " ctrl "\n v_add_f32_dpp %3, %3, %3 " ctrl "\n"          \
+                 "v_add_f32_dpp %4, %4, %4 " ctrl "\n v_add_f32_dpp %5, %5, %5 " ctrl "\n"          \
+                 "v_add_f32_dpp %6, %6, %6 " ctrl "\n v_add_f32_dpp %7, %7, %7 " ctrl "\n"          \
+                 "v_add_f32_dpp %8, %8, %8 " ctrl "\n"                                              \
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(a8))
+
+__device__ __forceinline__ void mgr_wave_sum63_x9(float& a0, float& a1, float& a2, float& a3, float& a4,
+                                                  float& a5, float& a6, float& a7, float& a8) {
+    MGR_DPP9("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
+    MGR_DPP9("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
+    MGR_DPP9("row_shr:4 row_mask:0xf bank_mask:0xf");
+    MGR_DPP9("row_shr:8 row_mask:0xf bank_mask:0xf");
+    MGR_DPP9("row_bcast:15 row_mask:0xa bank_mask:0xf");
+    MGR_DPP9("row_bcast:31 row_mask:0xc bank_mask:0xf");
+    asm volatile("s_nop 1");
+}
+
 __device__ __forceinline__ float mgr_readlane63(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
@@ -209,13 +240,14 @@ __device__ __forceinline__ float mgr_qmax(float opacity) { return 2.0f * __logf(
 __device__ __forceinline__ bool mgr_box_dead(float cx, float cy, float A, float B, float C, float qmax,
                                              float x0, float y0, float x1, float y1) {
     if (!(A > 0.0f && C > 0.0f && A * C - B * B > 0.0f)) return false;
+    const float invA = __builtin_amdgcn_rcpf(A), invC = __builtin_amdgcn_rcpf(C);
     const bool in_x = cx >= x0 && cx <= x1, in_y = cy >= y0 && cy <= y1;
     if (in_x && in_y) return !(qmax >= -0.01f);  // centre inside the box: q_min = 0
     float best = 3.0e38f, bestM = 0.0f;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {  // vertical edges x = x0 / x1
         const float dx = (e ? x1 : x0) - cx;
-        const float y = fminf(fmaxf(cy - B * dx / C, y0), y1), dy = y - cy;
+        const float y = fminf(fmaxf(cy - B * dx * invC, y0), y1), dy = y - cy;
         const float t0 = A * dx * dx, t1 = 2.0f * B * dx * dy, t2 = C * dy * dy;
         const float q = t0 + t1 + t2;
         if (q < best) { best = q; bestM = t0 + fabsf(t1) + t2; }
@@ -223,7 +255,7 @@ __device__ __forceinline__ bool mgr_box_dead(float cx, float cy, float A, float 
 #pragma unroll
     for (int e = 0; e < 2; ++e) {  // horizontal edges y = y0 / y1
         const float dy = (e ? y1 : y0) - cy;
-        const float x = fminf(fmaxf(cx - B * dy / A, x0), x1), dx = x - cx;
+        const float x = fminf(fmaxf(cx - B * dy * invA, x0), x1), dx = x - cx;
         const float t0 = A * dx * dx, t1 = 2.0f * B * dx * dy, t2 = C * dy * dy;
         const float q = t0 + t1 + t2;
         if (q < best) { best = q; bestM = t0 + fabsf(t1) + t2; }

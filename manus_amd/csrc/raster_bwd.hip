@@ -19,19 +19,28 @@
 
 #include "mgr_common.h"
 
-#define BWD_BATCH 128
+#define BWD_BATCH MGR_CHUNK
 #define BWD_SW (BWD_BATCH / 64)
 
-// Wave w owns the 8x8 pixel quadrant (w&1, w>>1) of the tile.  Entries are staged back to
-// front, BWD_BATCH at a time; the staging threads test each entry against the four quadrants
-// (mgr_box_dead) so that a wave only walks entries that can reach one of its pixels.
+// Work item = (tile, chunk of MGR_CHUNK list entries).  The forward pass saved, per pixel, the
+// prefix colour and transmittance in front of every chunk, so chunks are independent:
+//   T_i        transmittance in front of entry i (forward recurrence from the checkpoint)
+//   w_i        = alpha_i * T_i
+//   suffix_i   = (output pixel) - (prefix colour through i) = everything behind i incl. background
+//   dL/dalpha_i = T_i (c_i . g) - (suffix_i . g) / (1 - alpha_i)
+// which is the upstream back-to-front recurrence rearranged.
+// Persistent workgroups pull items from a queue; wave w owns the 8x8 quadrant (w&1, w>>1) and
+// walks only the entries whose footprint can reach it (mgr_box_dead).  The 64 pixels of a wave
+// are reduced with DPP row operations, the 4 waves through LDS in a fixed order, and one 48-byte
+// record per (tile, Gaussian) pair is written, tagged with the call's epoch.
 __global__ __launch_bounds__(256) void k_blend_bwd(
-    int N, int W, int H, int gx, int gy, const float* __restrict__ bg,
-    const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ sorted_gid,
-    const MgrGRec* __restrict__ grec, const float* __restrict__ final_T,
+    int N, int W, int H, int gx, int gy, const uint32_t* __restrict__ tile_start,
+    const uint32_t* __restrict__ sorted_gid, const MgrGRec* __restrict__ grec,
     const uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ tile_done,
-    const float* __restrict__ dL_dpix, uint32_t* __restrict__ pair_tag,
-    float4* __restrict__ pair_grad, uint32_t cap, uint32_t epoch) {
+    const uint32_t* __restrict__ chunk_start, const float4* __restrict__ ckpt,
+    const unsigned long long* __restrict__ items, MgrHeader* hdr, const float* __restrict__ out_color,
+    const float* __restrict__ dL_dpix, uint32_t* __restrict__ pair_tag, float4* __restrict__ pair_grad,
+    uint32_t cap, uint32_t epoch) {
     __shared__ float2 s_xy[BWD_BATCH];
     __shared__ float4 s_co[BWD_BATCH];
     __shared__ float s_rgb[BWD_BATCH * 3];
@@ -39,44 +48,40 @@ __global__ __launch_bounds__(256) void k_blend_bwd(
     __shared__ uint32_t s_touch[BWD_BATCH];
     __shared__ unsigned long long s_mask[BWD_SW][4];
     __shared__ float s_acc[4][BWD_BATCH][9];
+    __shared__ uint32_t s_item;
 
-    const int v = blockIdx.z, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int T = gx * gy;
-    const size_t vt = (size_t)v * T + blockIdx.y * gx + blockIdx.x;
-    const uint32_t nproc = tile_done[vt];
-    if (nproc == 0) return;
-    const uint32_t start = min(tile_start[vt], cap);
-    const int px = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
-    const int py = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
-    const bool inside = px < W && py < H;
-    const float fpx = (float)px, fpy = (float)py;
-    const float tx0 = (float)(blockIdx.x * 16), ty0 = (float)(blockIdx.y * 16);
-    const size_t P = (size_t)W * H, pix = (size_t)py * W + px;
-
-    float Tf = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f;
-    uint32_t last = 0;
-    if (inside) {
-        Tf = final_T[(size_t)v * P + pix];
-        last = n_contrib[(size_t)v * P + pix];
-        const float* gp = dL_dpix + (size_t)v * 3 * P + pix;
-        g0 = gp[0];
-        g1 = gp[P];
-        g2 = gp[2 * P];
-    }
-    uint32_t wlast = last;  // deepest contributor of this wave's quadrant
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) wlast = max(wlast, (uint32_t)__shfl_xor((int)wlast, d, 64));
-    const float bgdot = bg[0] * g0 + bg[1] * g1 + bg[2] * g2;
+    const uint32_t n_items = hdr->n_items;
+    const size_t P = (size_t)W * H;
     const float ddelx = 0.5f * (float)W, ddely = 0.5f * (float)H;
-    float Tr = Tf, a0 = 0.f, a1 = 0.f, a2 = 0.f, l0 = 0.f, l1 = 0.f, l2 = 0.f, last_alpha = 0.f;
 
-    for (uint32_t hi = nproc; hi > 0; hi -= min(hi, (uint32_t)BWD_BATCH)) {
-        const int cnt = (int)min(hi, (uint32_t)BWD_BATCH);
-        __syncthreads();  // previous batch fully flushed
+    for (;;) {
+        __syncthreads();  // previous item fully flushed
+        if (tid == 0) s_item = atomicAdd(&hdr->item_head, 1u);
+        __syncthreads();
+        const uint32_t item = s_item;
+        if (item >= n_items) break;
+        const unsigned long long it = items[item];
+        const uint32_t vt = (uint32_t)(it >> 32), chunk = (uint32_t)it;
+        const int v = (int)(vt / (uint32_t)T), t = (int)(vt % (uint32_t)T);
+        const int bx = t % gx, by = t / gx;
+        const uint32_t nproc = tile_done[vt];
+        const uint32_t start = min(tile_start[vt], cap);
+        const uint32_t first = chunk * BWD_BATCH;             // list position of the chunk's first entry
+        const int cnt = (int)min((uint32_t)BWD_BATCH, nproc - first);
+        const int px = bx * 16 + (wave & 1) * 8 + (lane & 7);
+        const int py = by * 16 + (wave >> 1) * 8 + (lane >> 3);
+        const bool inside = px < W && py < H;
+        const float fpx = (float)px, fpy = (float)py;
+        const float tx0 = (float)(bx * 16), ty0 = (float)(by * 16);
+        const size_t pix = (size_t)py * W + px;
+
+        // stage the chunk (front to back) and the per-quadrant survivor masks
         if (tid < BWD_BATCH) {
             bool d0 = true, d1 = true, d2 = true, d3 = true;
             if (tid < cnt) {
-                const uint32_t gid = sorted_gid[start + hi - 1 - tid];
+                const uint32_t gid = sorted_gid[start + first + tid];
                 const MgrGRec* r = grec + (size_t)v * N + gid;
                 const float4 a = *(const float4*)r;
                 const float4 b = *((const float4*)r + 1);
@@ -86,7 +91,7 @@ __global__ __launch_bounds__(256) void k_blend_bwd(
                 s_rgb[tid * 3 + 0] = b.z;
                 s_rgb[tid * 3 + 1] = b.w;
                 s_rgb[tid * 3 + 2] = c.x;
-                s_slot[tid] = __float_as_int(c.y) + (int)blockIdx.y * __float_as_int(c.z) + (int)blockIdx.x;
+                s_slot[tid] = __float_as_int(c.y) + by * __float_as_int(c.z) + bx;
                 const float qmax = mgr_qmax(b.y);
                 d0 = mgr_box_dead(a.x, a.y, a.z, a.w, b.x, qmax, tx0, ty0, tx0 + 7.f, ty0 + 7.f);
                 d1 = mgr_box_dead(a.x, a.y, a.z, a.w, b.x, qmax, tx0 + 8.f, ty0, tx0 + 15.f, ty0 + 7.f);
@@ -99,69 +104,78 @@ __global__ __launch_bounds__(256) void k_blend_bwd(
                 s_mask[wave][0] = m0; s_mask[wave][1] = m1; s_mask[wave][2] = m2; s_mask[wave][3] = m3;
             }
         }
+        // per-pixel state in front of the chunk
+        float Tr = 1.0f, pg = 0.f, Og = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f;
+        uint32_t last = 0;
+        if (inside) {
+            last = n_contrib[(size_t)v * P + pix];
+            if (last > first) {
+                const float* gp = dL_dpix + (size_t)v * 3 * P + pix;
+                const float* op = out_color + (size_t)v * 3 * P + pix;
+                g0 = gp[0]; g1 = gp[P]; g2 = gp[2 * P];
+                Og = op[0] * g0 + op[P] * g1 + op[2 * P] * g2;
+                if (chunk > 0) {
+                    const float4 s = ckpt[(size_t)(chunk_start[vt] + chunk - 1) * 256 + ((wave << 6) | lane)];
+                    Tr = s.w;
+                    pg = s.x * g0 + s.y * g1 + s.z * g2;
+                }
+            }
+        }
+        uint32_t wlast = last;  // deepest contributor of this wave's quadrant
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) wlast = max(wlast, (uint32_t)__shfl_xor((int)wlast, d, 64));
         __syncthreads();
 
+        if (wlast > first) {
 #pragma unroll 1
-        for (int sw = 0; sw < BWD_SW; ++sw) {
-            unsigned long long m = s_mask[sw][wave];
-            while (m) {
-                const int j = sw * 64 + __builtin_ctzll(m);
-                m &= m - 1;
-                const uint32_t pos = hi - 1 - (uint32_t)j;  // 0-based position in the tile list
-                if (pos >= wlast) continue;                  // wave-uniform
-                float v_mx = 0.f, v_my = 0.f, v_ca = 0.f, v_cb = 0.f, v_cc = 0.f, v_op = 0.f,
-                      v_r = 0.f, v_g = 0.f, v_b = 0.f;
-                bool hit = false;
-                if (pos < last) {
-                    const float2 xy = s_xy[j];
-                    const float4 co = s_co[j];
-                    const float dx = xy.x - fpx, dy = xy.y - fpy;
-                    const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-                    if (power <= 0.0f) {
-                        const float G = mgr_exp(power);
-                        const float alpha = fminf(0.99f, co.w * G);
-                        if (alpha >= 1.0f / 255.0f) {
-                            hit = true;
-                            Tr = Tr / (1.0f - alpha);
-                            const float dch = alpha * Tr;
-                            const float c0 = s_rgb[j * 3 + 0], c1 = s_rgb[j * 3 + 1], c2 = s_rgb[j * 3 + 2];
-                            a0 = last_alpha * l0 + (1.0f - last_alpha) * a0;
-                            a1 = last_alpha * l1 + (1.0f - last_alpha) * a1;
-                            a2 = last_alpha * l2 + (1.0f - last_alpha) * a2;
-                            l0 = c0; l1 = c1; l2 = c2;
-                            float dalpha = (c0 - a0) * g0 + (c1 - a1) * g1 + (c2 - a2) * g2;
-                            v_r = dch * g0; v_g = dch * g1; v_b = dch * g2;
-                            dalpha *= Tr;
-                            last_alpha = alpha;
-                            dalpha += (-Tf / (1.0f - alpha)) * bgdot;
-                            const float dG = co.w * dalpha;
-                            const float gdx = G * dx, gdy = G * dy;
-                            const float dGdx = -gdx * co.x - gdy * co.y;
-                            const float dGdy = -gdy * co.z - gdx * co.y;
-                            v_mx = dG * dGdx * ddelx;
-                            v_my = dG * dGdy * ddely;
-                            v_ca = -0.5f * gdx * dx * dG;
-                            v_cb = -0.5f * gdx * dy * dG;
-                            v_cc = -0.5f * gdy * dy * dG;
-                            v_op = G * dalpha;
+            for (int sw = 0; sw < BWD_SW; ++sw) {
+                unsigned long long m = s_mask[sw][wave];
+                while (m) {
+                    const int j = sw * 64 + __builtin_ctzll(m);
+                    m &= m - 1;
+                    const uint32_t pos = first + (uint32_t)j;  // 0-based position in the tile list
+                    if (pos >= wlast) break;                    // wave-uniform; later entries are deeper still
+                    float v_mx = 0.f, v_my = 0.f, v_ca = 0.f, v_cb = 0.f, v_cc = 0.f, v_op = 0.f,
+                          v_r = 0.f, v_g = 0.f, v_b = 0.f;
+                    bool hit = false;
+                    if (pos < last) {
+                        const float2 xy = s_xy[j];
+                        const float4 co = s_co[j];
+                        const float dx = xy.x - fpx, dy = xy.y - fpy;
+                        const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+                        if (power <= 0.0f) {
+                            const float G = mgr_exp(power);
+                            const float alpha = fminf(0.99f, co.w * G);
+                            if (alpha >= 1.0f / 255.0f) {
+                                hit = true;
+                                const float w = alpha * Tr;
+                                const float cg = s_rgb[j * 3 + 0] * g0 + s_rgb[j * 3 + 1] * g1 + s_rgb[j * 3 + 2] * g2;
+                                pg += w * cg;                                   // prefix . g through this entry
+                                const float oma = 1.0f - alpha;
+                                const float dalpha = Tr * cg - (Og - pg) * __builtin_amdgcn_rcpf(oma);
+                                v_r = w * g0; v_g = w * g1; v_b = w * g2;
+                                Tr *= oma;
+                                const float dG = co.w * dalpha;
+                                const float gdx = G * dx, gdy = G * dy;
+                                const float dGdx = -gdx * co.x - gdy * co.y;
+                                const float dGdy = -gdy * co.z - gdx * co.y;
+                                v_mx = dG * dGdx * ddelx;
+                                v_my = dG * dGdy * ddely;
+                                v_ca = -0.5f * gdx * dx * dG;
+                                v_cb = -0.5f * gdx * dy * dG;
+                                v_cc = -0.5f * gdy * dy * dG;
+                                v_op = G * dalpha;
+                            }
                         }
                     }
-                }
-                if (__ballot(hit) != 0ull) {  // wave-uniform
-                    v_mx = mgr_wave_sum63(v_mx);
-                    v_my = mgr_wave_sum63(v_my);
-                    v_ca = mgr_wave_sum63(v_ca);
-                    v_cb = mgr_wave_sum63(v_cb);
-                    v_cc = mgr_wave_sum63(v_cc);
-                    v_op = mgr_wave_sum63(v_op);
-                    v_r = mgr_wave_sum63(v_r);
-                    v_g = mgr_wave_sum63(v_g);
-                    v_b = mgr_wave_sum63(v_b);
-                    if (lane == 63) {
-                        float* d = s_acc[wave][j];
-                        d[0] = v_mx; d[1] = v_my; d[2] = v_ca; d[3] = v_cb; d[4] = v_cc;
-                        d[5] = v_op; d[6] = v_r; d[7] = v_g; d[8] = v_b;
-                        atomicOr(&s_touch[j], 1u << wave);
+                    if (__ballot(hit) != 0ull) {  // wave-uniform
+                        mgr_wave_sum63_x9(v_mx, v_my, v_ca, v_cb, v_cc, v_op, v_r, v_g, v_b);
+                        if (lane == 63) {
+                            float* d = s_acc[wave][j];
+                            d[0] = v_mx; d[1] = v_my; d[2] = v_ca; d[3] = v_cb; d[4] = v_cc;
+                            d[5] = v_op; d[6] = v_r; d[7] = v_g; d[8] = v_b;
+                            atomicOr(&s_touch[j], 1u << wave);
+                        }
                     }
                 }
             }
@@ -293,15 +307,15 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
 extern "C" int mgr_raster_backward(int V, int N, int W, int H, const float* cams, const float* bg,
                                    const float* means3D, int64_t s_means, const float* cov3D,
                                    int64_t s_cov, const float* colors, int64_t s_col,
-                                   const float* opacity, int64_t s_op, const float* dL_dcolor,
-                                   float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dcolors,
+                                   const float* opacity, int64_t s_op, const float* out_color,
+                                   const float* dL_dcolor, float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dcolors,
                                    float* dL_dopacity, float* dL_dcov3D, void* workspace,
                                    size_t workspace_bytes, int64_t cap, int debug, void* stream_) {
     (void)colors; (void)s_col; (void)opacity; (void)s_op;  // captured in the workspace records
     hipStream_t stream = (hipStream_t)stream_;
     if (V <= 0 || N < 0 || W <= 0 || H <= 0 || cap < 0)
         return mgr_fail(MGR_EINVAL, "mgr_raster_backward: bad sizes");
-    if (!cams || !bg || !dL_dcolor || !workspace)
+    if (!cams || !bg || !dL_dcolor || !out_color || !workspace)
         return mgr_fail(MGR_EINVAL, "mgr_raster_backward: null pointer");
     if (N == 0) return MGR_OK;
     if (!means3D || !cov3D || !dL_dmeans3D || !dL_dmeans2D || !dL_dcolors || !dL_dopacity || !dL_dcov3D)
@@ -318,12 +332,13 @@ extern "C" int mgr_raster_backward(int V, int N, int W, int H, const float* cams
     static std::atomic<uint32_t> g_epoch{0};
     uint32_t epoch = g_epoch.fetch_add(1) + 1;
     if (epoch == 0) epoch = g_epoch.fetch_add(1) + 1;
-    (void)hdr;
 
-    { MGR_PROF("k_blend_bwd", stream); hipLaunchKernelGGL(k_blend_bwd, dim3(gx, gy, V), dim3(256), 0, stream, N, W, H, gx, gy, bg,
+    MGR_HIP(hipMemsetAsync(&hdr->item_head, 0, 4, stream));
+    { MGR_PROF("k_blend_bwd", stream); hipLaunchKernelGGL(k_blend_bwd, dim3(256 * 5), dim3(256), 0, stream, N, W, H, gx, gy,
                        (const uint32_t*)(ws + L.tile_start), (const uint32_t*)(ws + L.sorted_gid),
-                       (const MgrGRec*)(ws + L.grec), (const float*)(ws + L.final_T),
-                       (const uint32_t*)(ws + L.n_contrib), (const uint32_t*)(ws + L.tile_done),
+                       (const MgrGRec*)(ws + L.grec), (const uint32_t*)(ws + L.n_contrib),
+                       (const uint32_t*)(ws + L.tile_done), (const uint32_t*)(ws + L.chunk_start),
+                       (const float4*)(ws + L.ckpt), (const unsigned long long*)(ws + L.items), hdr, out_color,
                        dL_dcolor, (uint32_t*)(ws + L.pair_tag), (float4*)(ws + L.pair_grad),
                        (uint32_t)cap, epoch); }
     MGR_LAUNCH_CHECK("k_blend_bwd", stream, debug);

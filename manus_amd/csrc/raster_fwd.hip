@@ -261,6 +261,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan(int VT, const uint32_t* __re
                                                     uint32_t* __restrict__ tile_start,
                                                     uint32_t* __restrict__ tile_cursor,
                                                     uint32_t* __restrict__ tile_queue,
+                                                    uint32_t* __restrict__ chunk_start,
                                                     MgrHeader* hdr, uint32_t cap) {
     __shared__ uint32_t s_scan[32];
     __shared__ uint32_t s_cls[34];
@@ -268,20 +269,31 @@ __global__ __launch_bounds__(1024) void k_tile_scan(int VT, const uint32_t* __re
     const int per = (VT + 1023) / 1024;
     const int b = tid * per, e = min(VT, b + per);
     if (tid < 34) s_cls[tid] = 0;
-    uint32_t sum = 0;
-    for (int k = b; k < e; ++k) sum += tile_count[k];
-    uint32_t total;
+    // checkpoints are needed for every chunk of a tile list except the first
+    uint32_t sum = 0, csum = 0;
+    for (int k = b; k < e; ++k) {
+        const uint32_t c = tile_count[k];
+        sum += c;
+        csum += c ? (c - 1) / MGR_CHUNK : 0u;
+    }
+    uint32_t total, ctotal;
     uint32_t run = block_excl_scan(sum, s_scan, total);
+    uint32_t crun = block_excl_scan(csum, s_scan, ctotal);
     for (int k = b; k < e; ++k) {
         const uint32_t c = tile_count[k];
         tile_start[k] = run;
+        chunk_start[k] = crun;
         tile_cursor[k] = 0;
         run += c;
-        if (c) atomicAdd(&s_cls[32 - __clz(c)], 1u);
+        crun += c ? (c - 1) / MGR_CHUNK : 0u;
+        atomicAdd(&s_cls[c ? 32 - __clz(c) : 0], 1u);
     }
     if (tid == 0) {
         tile_start[VT] = total;
+        chunk_start[VT] = ctotal;
         hdr->overflow = (total > cap || hdr->total_pairs > cap) ? 1u : 0u;
+        hdr->n_items = 0;
+        hdr->item_head = 0;
     }
     __syncthreads();
     if (tid == 0) {  // descending class order
@@ -291,14 +303,14 @@ __global__ __launch_bounds__(1024) void k_tile_scan(int VT, const uint32_t* __re
             s_cls[c] = r;
             r += t;
         }
-        hdr->queue_len = r;
+        hdr->queue_len = s_cls[0];  // class 0 (empty tiles) starts after all non-empty ones
         hdr->queue_head = 0;
         hdr->queue_head2 = 0;
     }
     __syncthreads();
     for (int k = b; k < e; ++k) {
         const uint32_t c = tile_count[k];
-        if (c) tile_queue[atomicAdd(&s_cls[32 - __clz(c)], 1u)] = (uint32_t)k;
+        tile_queue[atomicAdd(&s_cls[c ? 32 - __clz(c) : 0], 1u)] = (uint32_t)k;
     }
 }
 
@@ -405,6 +417,20 @@ __device__ __forceinline__ void bitonic_mirror(KeyPtr a, uint32_t n, uint32_t np
     }
 }
 
+#define SORT_MAX_GROUPS 64
+#define SORT_SAMPLES 1024
+#define SORT_LDS_EXTRA 2048  // splitters (65 x 8) + counters/offsets (2 x 65 x 4) + cursors
+
+// group index of a key among ascending splitters sp[1..G-1] (sp[g] = first key of group g)
+__device__ __forceinline__ int sort_group(const unsigned long long* sp, int G, unsigned long long key) {
+    int lo = 0, hi = G - 1;  // invariant: key belongs to a group in [lo, hi]
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (key >= sp[mid]) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
 __global__ __launch_bounds__(SORT_THREADS) void k_tile_sort(
     const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ tile_queue,
     unsigned long long* __restrict__ keys, uint32_t* __restrict__ sorted_gid, MgrHeader* hdr,
@@ -412,14 +438,17 @@ __global__ __launch_bounds__(SORT_THREADS) void k_tile_sort(
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     unsigned long long* s_keys = (unsigned long long*)s_raw;
     // all LDS in the one dynamic array (keeps the 8-byte key accesses aligned)
-    uint32_t* s_item = (uint32_t*)(s_raw + (size_t)SORT_LDS_KEYS * 8);
-    const int tid = threadIdx.x;
+    unsigned long long* s_sp = (unsigned long long*)(s_raw + (size_t)SORT_LDS_KEYS * 8);  // 65 splitters
+    uint32_t* s_cnt = (uint32_t*)(s_sp + SORT_MAX_GROUPS + 1);                           // 65 counts
+    uint32_t* s_off = s_cnt + SORT_MAX_GROUPS + 1;                                        // 65 offsets
+    uint32_t* s_item = s_off + SORT_MAX_GROUPS + 1;                                       // [0] item, [1] fill, [2] flag
+    const int tid = threadIdx.x, lane = tid & 63;
     const uint32_t qlen = hdr->queue_len;
     for (;;) {
         __syncthreads();
-        if (tid == 0) *s_item = atomicAdd(&hdr->queue_head, 1u);
+        if (tid == 0) s_item[0] = atomicAdd(&hdr->queue_head, 1u);
         __syncthreads();
-        const uint32_t item = *s_item;
+        const uint32_t item = s_item[0];
         if (item >= qlen) break;
         const uint32_t vt = tile_queue[item];
         const uint32_t start = min(tile_start[vt], cap), end = min(tile_start[vt + 1], cap);
@@ -432,7 +461,74 @@ __global__ __launch_bounds__(SORT_THREADS) void k_tile_sort(
             __syncthreads();
             if (n > 1) bitonic_mirror(s_keys, n, npad, tid, SORT_THREADS);
             for (uint32_t t = tid; t < n; t += SORT_THREADS) sorted_gid[start + t] = (uint32_t)s_keys[t];
+            continue;
+        }
+        // ---- big segment: split by sampled splitters into groups that fit the LDS, sort each
+        const int G = (int)((n + SORT_LDS_KEYS / 2 - 1) / (SORT_LDS_KEYS / 2));
+        bool fallback = G > SORT_MAX_GROUPS;
+        if (!fallback) {
+            for (uint32_t t = tid; t < SORT_SAMPLES; t += SORT_THREADS)
+                s_keys[t] = keys[start + (uint32_t)(((unsigned long long)t * n) / SORT_SAMPLES)];
+            __syncthreads();
+            bitonic_mirror(s_keys, SORT_SAMPLES, SORT_SAMPLES, tid, SORT_THREADS);
+            if (tid <= G) {
+                s_sp[tid] = (tid == 0) ? 0ull : (tid == G ? ~0ull : s_keys[(tid * SORT_SAMPLES) / G]);
+                s_cnt[tid] = 0;
+            }
+            __syncthreads();
+            // count group sizes (wave-aggregated)
+            for (uint32_t t0 = (uint32_t)(tid & ~63); t0 < n; t0 += SORT_THREADS) {
+                const uint32_t t = t0 + lane;
+                const int g = t < n ? sort_group(s_sp, G, keys[start + t]) : -1;
+                for (int gg = 0; gg < G; ++gg) {
+                    const unsigned long long mk = __ballot(g == gg);
+                    if (lane == 0 && mk) atomicAdd(&s_cnt[gg], (uint32_t)__popcll(mk));
+                }
+            }
+            __syncthreads();
+            if (tid == 0) {
+                uint32_t run = 0, big = 0;
+                for (int g = 0; g < G; ++g) {
+                    s_off[g] = run;
+                    run += s_cnt[g];
+                    big |= s_cnt[g] > SORT_LDS_KEYS;
+                }
+                s_item[2] = big;
+            }
+            __syncthreads();
+            fallback = s_item[2] != 0;
+        }
+        if (!fallback) {
+            for (int g = 0; g < G; ++g) {
+                const uint32_t ng = s_cnt[g];
+                if (tid == 0) s_item[1] = 0;
+                __syncthreads();
+                for (uint32_t t0 = (uint32_t)(tid & ~63); t0 < n; t0 += SORT_THREADS) {
+                    const uint32_t t = t0 + lane;
+                    unsigned long long key = 0ull;
+                    bool mine = false;
+                    if (t < n) {
+                        key = keys[start + t];
+                        mine = sort_group(s_sp, G, key) == g;
+                    }
+                    const unsigned long long mk = __ballot(mine);
+                    uint32_t base = 0;
+                    if (lane == 0 && mk) base = atomicAdd(&s_item[1], (uint32_t)__popcll(mk));
+                    base = (uint32_t)__shfl((int)base, 0, 64);
+                    if (mine) s_keys[base + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull))] = key;
+                }
+                __syncthreads();
+                if (ng > 1) {
+                    uint32_t gp = 1;
+                    while (gp < ng) gp <<= 1;
+                    bitonic_mirror(s_keys, ng, gp, tid, SORT_THREADS);
+                }
+                const uint32_t o = start + s_off[g];
+                for (uint32_t t = tid; t < ng; t += SORT_THREADS) sorted_gid[o + t] = (uint32_t)s_keys[t];
+                __syncthreads();
+            }
         } else {
+            // last resort (pathological distributions): in-place network in global memory
             __syncthreads();
             bitonic_mirror(keys + start, n, npad, tid, SORT_THREADS);
             __threadfence_block();
@@ -442,112 +538,208 @@ __global__ __launch_bounds__(SORT_THREADS) void k_tile_sort(
 }
 
 // ---------------------------------------------------------------------------
-// K5: front-to-back alpha compositing, one 16x16 tile per 256-thread workgroup.
-// Wave w owns the 8x8 pixel quadrant (w&1, w>>1).  The tile list is staged through
-// LDS 256 entries at a time; while staging, every entry is tested against the four
-// quadrants (mgr_box_dead) and the per-quadrant survivor bitmasks are published in
-// LDS, so a wave only walks entries that can reach at least one of its pixels.
+// K5: front-to-back alpha compositing, one 16x16 tile at a time per 256-thread workgroup.
+//  * persistent workgroups: non-empty tiles are pulled from the size-ordered queue (largest
+//    first), then the empty tiles are background-filled with a static stride;
+//  * wave w owns the 8x8 pixel quadrant (w&1, w>>1); the list is staged through LDS 256 entries
+//    at a time, each entry tested against the four quadrants (mgr_box_dead) so that a wave only
+//    walks entries that can reach one of its pixels;
+//  * the gather of the next batch (index two batches ahead, record one batch ahead) is in
+//    flight while the current batch is blended;
+//  * every MGR_CHUNK entries the per-pixel prefix state is checkpointed for the backward pass.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, int gy,
+struct FwdRec {
+    float4 a, b;
+    float c;
+};
+
+__global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, int gy, int VT,
                                                    const float* __restrict__ bg,
                                                    const uint32_t* __restrict__ tile_start,
+                                                   const uint32_t* __restrict__ tile_queue,
                                                    const uint32_t* __restrict__ sorted_gid,
                                                    const MgrGRec* __restrict__ grec,
                                                    float* __restrict__ out_color,
                                                    float* __restrict__ final_T,
                                                    uint32_t* __restrict__ n_contrib,
-                                                   uint32_t* __restrict__ tile_done, uint32_t cap) {
+                                                   uint32_t* __restrict__ tile_done,
+                                                   const uint32_t* __restrict__ chunk_start,
+                                                   float4* __restrict__ ckpt,
+                                                   unsigned long long* __restrict__ items, MgrHeader* hdr,
+                                                   uint32_t cap) {
     __shared__ float2 s_xy[256];
     __shared__ float4 s_co[256];
     __shared__ float s_rgb[256 * 3];
     __shared__ unsigned long long s_mask[4][4];  // [staging wave][quadrant]
-    __shared__ uint32_t s_max;
-    const int v = blockIdx.z, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    __shared__ uint32_t s_max, s_next, s_ibase;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int T = gx * gy;
-    const size_t vt = (size_t)v * T + blockIdx.y * gx + blockIdx.x;
-    const uint32_t start = min(tile_start[vt], cap), end = min(tile_start[vt + 1], cap);
-    const int px = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
-    const int py = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
-    const bool inside = px < W && py < H;
-    const float fpx = (float)px, fpy = (float)py;
-    const float tx0 = (float)(blockIdx.x * 16), ty0 = (float)(blockIdx.y * 16);
-    if (tid == 0) s_max = 0;
-    float Tr = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
-    uint32_t last = 0;
-    bool done = !inside;
-    for (uint32_t base = start; base < end; base += 256) {
-        if (__syncthreads_count(done) == 256) break;
-        const uint32_t idx = base + tid;
-        bool d0 = true, d1 = true, d2 = true, d3 = true;
-        if (idx < end) {
-            const MgrGRec* r = grec + (size_t)v * N + sorted_gid[idx];
-            const float4 a = *(const float4*)r;
-            const float4 b = *((const float4*)r + 1);
-            const float c = r->b;
-            s_xy[tid] = make_float2(a.x, a.y);
-            s_co[tid] = make_float4(a.z, a.w, b.x, b.y);
-            s_rgb[tid * 3 + 0] = b.z;
-            s_rgb[tid * 3 + 1] = b.w;
-            s_rgb[tid * 3 + 2] = c;
-            const float qmax = mgr_qmax(b.y);
-            d0 = mgr_box_dead(a.x, a.y, a.z, a.w, b.x, qmax, tx0, ty0, tx0 + 7.f, ty0 + 7.f);
-            d1 = mgr_box_dead(a.x, a.y, a.z, a.w, b.x, qmax, tx0 + 8.f, ty0, tx0 + 15.f, ty0 + 7.f);
-            d2 = mgr_box_dead(a.x, a.y, a.z, a.w, b.x, qmax, tx0, ty0 + 8.f, tx0 + 7.f, ty0 + 15.f);
-            d3 = mgr_box_dead(a.x, a.y, a.z, a.w, b.x, qmax, tx0 + 8.f, ty0 + 8.f, tx0 + 15.f, ty0 + 15.f);
+    const uint32_t n_busy = hdr->queue_len;
+    const size_t P = (size_t)W * H;
+    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+    const int pslot = (wave << 6) | lane;  // pixel slot inside a checkpoint (same mapping in backward)
+
+    if (tid == 0) s_next = atomicAdd(&hdr->queue_head2, 1u);
+    __syncthreads();
+    uint32_t item = s_next;
+    while (item < n_busy) {
+        const uint32_t vt = tile_queue[item];
+        const int v = (int)(vt / (uint32_t)T), t = (int)(vt % (uint32_t)T);
+        const int bx = t % gx, by = t / gx;
+        const uint32_t start = min(tile_start[vt], cap), end = min(tile_start[vt + 1], cap);
+        const uint32_t nlist = end - start;
+        const int px = bx * 16 + (wave & 1) * 8 + (lane & 7);
+        const int py = by * 16 + (wave >> 1) * 8 + (lane >> 3);
+        const bool inside = px < W && py < H;
+        const float fpx = (float)px, fpy = (float)py;
+        const float tx0 = (float)(bx * 16), ty0 = (float)(by * 16);
+        const uint32_t ck0 = chunk_start[vt];  // checkpoint c (c >= 1) of this tile lives at ck0 + c - 1
+        __syncthreads();                       // everyone has read s_next
+        if (tid == 0) {
+            s_max = 0;
+            s_next = atomicAdd(&hdr->queue_head2, 1u);  // next tile's index arrives while this one is blended
         }
-        const unsigned long long m0 = __ballot(!d0), m1 = __ballot(!d1), m2 = __ballot(!d2), m3 = __ballot(!d3);
-        if (lane == 0) {
-            s_mask[wave][0] = m0; s_mask[wave][1] = m1; s_mask[wave][2] = m2; s_mask[wave][3] = m3;
+        float Tr = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
+        uint32_t last = 0;
+        bool done = !inside;
+
+        // software pipeline: rec = record of batch k, gid_n = index of batch k+1
+        FwdRec rec;
+        uint32_t gid_n = 0;
+        {
+            const uint32_t i0 = tid, i1 = 256 + tid;
+            const uint32_t g0 = i0 < nlist ? sorted_gid[start + i0] : 0u;
+            gid_n = i1 < nlist ? sorted_gid[start + i1] : 0u;
+            const MgrGRec* r = grec + (size_t)v * N + g0;
+            rec.a = *(const float4*)r;
+            rec.b = *((const float4*)r + 1);
+            rec.c = r->b;
         }
-        __syncthreads();
-        if (!__all(done)) {
-#pragma unroll 1
-            for (int sw = 0; sw < 4; ++sw) {
-                unsigned long long m = s_mask[sw][wave];
-                while (m) {
-                    const int j = sw * 64 + __builtin_ctzll(m);
-                    m &= m - 1;
-                    if (done) continue;
-                    const float2 xy = s_xy[j];
-                    const float4 co = s_co[j];
-                    const float dx = xy.x - fpx, dy = xy.y - fpy;
-                    const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-                    if (power > 0.0f) continue;
-                    const float alpha = fminf(0.99f, co.w * mgr_exp(power));
-                    if (alpha < 1.0f / 255.0f) continue;
-                    const float testT = Tr * (1.0f - alpha);
-                    if (testT < 0.0001f) {
-                        done = true;
-                        continue;
-                    }
-                    const float w = alpha * Tr;
-                    C0 += s_rgb[j * 3 + 0] * w;
-                    C1 += s_rgb[j * 3 + 1] * w;
-                    C2 += s_rgb[j * 3 + 2] * w;
-                    Tr = testT;
-                    last = (base - start) + (uint32_t)j + 1u;  // 1-based position in the tile list
+        for (uint32_t off = 0; off < nlist; off += 256) {
+            if (__syncthreads_count(done) == 256) break;
+            const uint32_t idx = off + tid;
+            bool d0 = true, d1 = true, d2 = true, d3 = true;
+            if (idx < nlist) {
+                const float4 a = rec.a, b = rec.b;
+                s_xy[tid] = make_float2(a.x, a.y);
+                s_co[tid] = make_float4(a.z, a.w, b.x, b.y);
+                s_rgb[tid * 3 + 0] = b.z;
+                s_rgb[tid * 3 + 1] = b.w;
+                s_rgb[tid * 3 + 2] = rec.c;
+                const float qmax = mgr_qmax(b.y);
+                d0 = mgr_box_dead(a.x, a.y, a.z, a.w, b.x, qmax, tx0, ty0, tx0 + 7.f, ty0 + 7.f);
+                d1 = mgr_box_dead(a.x, a.y, a.z, a.w, b.x, qmax, tx0 + 8.f, ty0, tx0 + 15.f, ty0 + 7.f);
+                d2 = mgr_box_dead(a.x, a.y, a.z, a.w, b.x, qmax, tx0, ty0 + 8.f, tx0 + 7.f, ty0 + 15.f);
+                d3 = mgr_box_dead(a.x, a.y, a.z, a.w, b.x, qmax, tx0 + 8.f, ty0 + 8.f, tx0 + 15.f, ty0 + 15.f);
+            }
+            const unsigned long long m0 = __ballot(!d0), m1 = __ballot(!d1), m2 = __ballot(!d2), m3 = __ballot(!d3);
+            if (lane == 0) {
+                s_mask[wave][0] = m0; s_mask[wave][1] = m1; s_mask[wave][2] = m2; s_mask[wave][3] = m3;
+            }
+            // issue the gathers of the following batches; they complete during the blend below
+            {
+                const uint32_t i1 = off + 256 + tid, i2 = off + 512 + tid;
+                if (i1 < nlist) {
+                    const MgrGRec* r = grec + (size_t)v * N + gid_n;
+                    rec.a = *(const float4*)r;
+                    rec.b = *((const float4*)r + 1);
+                    rec.c = r->b;
                 }
-                if (__all(done)) break;
+                gid_n = i2 < nlist ? sorted_gid[start + i2] : 0u;
+            }
+            __syncthreads();
+            if (!__all(done)) {
+#pragma unroll 1
+                for (int sw = 0; sw < 4; ++sw) {
+                    unsigned long long m = s_mask[sw][wave];
+                    // Four list entries per step: their alphas are independent (ILP hides the LDS
+                    // and exp latency); only the short transmittance update is sequential.
+                    while (m) {
+                        int jj[4];
+                        float al[4], cr[4], cg[4], cb[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const bool have = m != 0ull;
+                            jj[k] = sw * 64 + (have ? __builtin_ctzll(m) : 0);
+                            m = have ? (m & (m - 1)) : 0ull;
+                            const float2 xy = s_xy[jj[k]];
+                            const float4 co = s_co[jj[k]];
+                            cr[k] = s_rgb[jj[k] * 3 + 0];
+                            cg[k] = s_rgb[jj[k] * 3 + 1];
+                            cb[k] = s_rgb[jj[k] * 3 + 2];
+                            const float dx = xy.x - fpx, dy = xy.y - fpy;
+                            const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+                            const float a = fminf(0.99f, co.w * mgr_exp(fminf(power, 0.0f)));
+                            al[k] = (have && power <= 0.0f && a >= 1.0f / 255.0f) ? a : 0.0f;
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const bool val = !done && al[k] > 0.0f;
+                            const float testT = Tr * (1.0f - al[k]);
+                            const bool stop = val && testT < 0.0001f;
+                            const bool app = val && !stop;
+                            const float w = app ? al[k] * Tr : 0.0f;
+                            C0 += cr[k] * w;
+                            C1 += cg[k] * w;
+                            C2 += cb[k] * w;
+                            Tr = app ? testT : Tr;
+                            last = app ? off + (uint32_t)jj[k] + 1u : last;  // 1-based list position
+                            done = done || stop;
+                        }
+                        if (__all(done)) break;
+                    }
+                    // pixel state in front of the next chunk (prefix colour + transmittance): lets the
+                    // backward pass process every MGR_CHUNK-entry chunk of the list independently
+                    if (sw & 1) {
+                        const uint32_t nextpos = off + (uint32_t)(sw + 1) * 64u;
+                        if (nextpos < nlist)
+                            ckpt[(size_t)(ck0 + nextpos / MGR_CHUNK - 1) * 256 + pslot] = make_float4(C0, C1, C2, Tr);
+                    }
+                }
             }
         }
-    }
-    if (inside) {
-        const size_t P = (size_t)W * H, pix = (size_t)py * W + px;
-        final_T[(size_t)v * P + pix] = Tr;
-        n_contrib[(size_t)v * P + pix] = last;
-        float* o = out_color + (size_t)v * 3 * P + pix;
-        o[0] = C0 + Tr * bg[0];
-        o[P] = C1 + Tr * bg[1];
-        o[2 * P] = C2 + Tr * bg[2];
-    }
-    // per-tile depth actually consumed (drives the backward pass)
-    uint32_t m = last;
+        if (inside) {
+            const size_t pix = (size_t)py * W + px;
+            final_T[(size_t)v * P + pix] = Tr;
+            n_contrib[(size_t)v * P + pix] = last;
+            float* o = out_color + (size_t)v * 3 * P + pix;
+            o[0] = C0 + Tr * bg0;
+            o[P] = C1 + Tr * bg1;
+            o[2 * P] = C2 + Tr * bg2;
+        }
+        // per-tile depth actually consumed (drives the backward pass)
+        uint32_t m = last;
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
-    __syncthreads();
-    if (lane == 0) atomicMax(&s_max, m);
-    __syncthreads();
-    if (tid == 0) tile_done[vt] = s_max;
+        for (int d = 32; d > 0; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
+        if (lane == 0) atomicMax(&s_max, m);
+        __syncthreads();
+        const uint32_t tmax = s_max;
+        const uint32_t nchunks = (tmax + MGR_CHUNK - 1) / MGR_CHUNK;
+        if (tid == 0) {
+            tile_done[vt] = tmax;
+            // backward work items: one per MGR_CHUNK entries actually consumed by this tile
+            s_ibase = nchunks ? atomicAdd(&hdr->n_items, nchunks) : 0u;
+        }
+        __syncthreads();
+        for (uint32_t c = tid; c < nchunks; c += 256) items[s_ibase + c] = ((unsigned long long)vt << 32) | c;
+        item = s_next;
+    }
+    // empty tiles: background only
+    for (uint32_t q = n_busy + blockIdx.x; q < (uint32_t)VT; q += gridDim.x) {
+        const uint32_t vt = tile_queue[q];
+        const int v = (int)(vt / (uint32_t)T), t = (int)(vt % (uint32_t)T);
+        const int px = (t % gx) * 16 + (tid & 15), py = (t / gx) * 16 + (tid >> 4);
+        if (px < W && py < H) {
+            const size_t pix = (size_t)py * W + px;
+            final_T[(size_t)v * P + pix] = 1.0f;
+            n_contrib[(size_t)v * P + pix] = 0;
+            float* o = out_color + (size_t)v * 3 * P + pix;
+            o[0] = bg0;
+            o[P] = bg1;
+            o[2 * P] = bg2;
+        }
+        if (tid == 0) tile_done[vt] = 0;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -577,7 +769,7 @@ extern "C" int mgr_raster_forward(int V, int N, int W, int H, const float* cams,
     static bool attr_set = false;
     if (!attr_set) {
         MGR_HIP(hipFuncSetAttribute((const void*)k_tile_sort, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    SORT_LDS_KEYS * 8 + 16));
+                                    SORT_LDS_KEYS * 8 + SORT_LDS_EXTRA));
         MGR_HIP(hipFuncSetAttribute((const void*)k_preprocess, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     152 * 1024));
         MGR_HIP(hipFuncSetAttribute((const void*)k_emit, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -601,8 +793,8 @@ extern "C" int mgr_raster_forward(int V, int N, int W, int H, const float* cams,
         MGR_LAUNCH_CHECK("k_preprocess", stream, debug);
     }
     { MGR_PROF("k_tile_scan", stream); hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, stream, VT, tile_count, tile_start,
-                       (uint32_t*)(ws + L.tile_cursor), (uint32_t*)(ws + L.tile_queue), hdr,
-                       (uint32_t)cap); }
+                       (uint32_t*)(ws + L.tile_cursor), (uint32_t*)(ws + L.tile_queue),
+                       (uint32_t*)(ws + L.chunk_start), hdr, (uint32_t)cap); }
     MGR_LAUNCH_CHECK("k_tile_scan", stream, debug);
     if (N > 0) {
         dim3 grid((N + PRE_THREADS - 1) / PRE_THREADS, V);
@@ -612,18 +804,29 @@ extern "C" int mgr_raster_forward(int V, int N, int W, int H, const float* cams,
                            (uint32_t*)(ws + L.tile_cursor), (unsigned long long*)(ws + L.keys),
                            (uint32_t)cap, lds_hist); }
         MGR_LAUNCH_CHECK("k_emit", stream, debug);
-        { MGR_PROF("k_tile_sort", stream); hipLaunchKernelGGL(k_tile_sort, dim3(256), dim3(SORT_THREADS), SORT_LDS_KEYS * 8 + 16, stream,
+        { MGR_PROF("k_tile_sort", stream); hipLaunchKernelGGL(k_tile_sort, dim3(256), dim3(SORT_THREADS), SORT_LDS_KEYS * 8 + SORT_LDS_EXTRA, stream,
                            tile_start, (const uint32_t*)(ws + L.tile_queue),
                            (unsigned long long*)(ws + L.keys), (uint32_t*)(ws + L.sorted_gid), hdr,
                            (uint32_t)cap); }
         MGR_LAUNCH_CHECK("k_tile_sort", stream, debug);
     }
-    { MGR_PROF("k_blend_fwd", stream); hipLaunchKernelGGL(k_blend_fwd, dim3(gx, gy, V), dim3(256), 0, stream, N, W, H, gx, gy, bg, tile_start,
-                       (const uint32_t*)(ws + L.sorted_gid), (const MgrGRec*)(ws + L.grec), out_color,
+    { MGR_PROF("k_blend_fwd", stream); hipLaunchKernelGGL(k_blend_fwd, dim3(256 * 8), dim3(256), 0, stream, N, W, H, gx, gy, VT, bg, tile_start,
+                       (const uint32_t*)(ws + L.tile_queue), (const uint32_t*)(ws + L.sorted_gid), (const MgrGRec*)(ws + L.grec), out_color,
                        (float*)(ws + L.final_T), (uint32_t*)(ws + L.n_contrib),
-                       (uint32_t*)(ws + L.tile_done), (uint32_t)cap); }
+                       (uint32_t*)(ws + L.tile_done), (const uint32_t*)(ws + L.chunk_start),
+                       (float4*)(ws + L.ckpt), (unsigned long long*)(ws + L.items), hdr, (uint32_t)cap); }
     MGR_LAUNCH_CHECK("k_blend_fwd", stream, debug);
     return MGR_OK;
+}
+
+extern "C" int mgr_raster_layout(int V, int N, int W, int H, int64_t cap, size_t* out, int n_out) {
+    const MgrLayout L = mgr_layout(V, N, W, H, cap);
+    const size_t v[] = {L.header, L.grec, L.depth, L.rect, L.alive, L.pair_off, L.tile_count, L.tile_start,
+                        L.tile_cursor, L.tile_done, L.tile_queue, L.chunk_start, L.items, L.ckpt, L.keys,
+                        L.sorted_gid, L.final_T, L.n_contrib, L.pair_tag, L.pair_grad, L.total};
+    const int n = (int)(sizeof(v) / sizeof(v[0]));
+    for (int i = 0; i < n && i < n_out; ++i) out[i] = v[i];
+    return n;
 }
 
 extern "C" int mgr_raster_status_sync(const void* workspace, int64_t* num_pairs, int32_t* overflow,

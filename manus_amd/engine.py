@@ -101,6 +101,7 @@ class HipViewCompute:
         self.is_hand = scene.get("grid") is not None and scene["kind"] == "hand"
         self.params = {k: v.detach().clone().requires_grad_(True) for k, v in scene["params"].items()}
         self._cache = {}
+        self.grid = ops.SkinGrid(scene["grid"], scene["grid"].device) if self.is_hand else None
 
     def _select(self, view_ids):
         """Per-view constants for a set of views (cached: no per-step gather copies)."""
@@ -121,7 +122,7 @@ class HipViewCompute:
         feats = torch.cat([p["_features_dc"], p["_features_rest"]], dim=1)
         opac = torch.sigmoid(p["_opacity"])
         if self.is_hand:
-            w = ops.skin_weights(p["_xyz"], s["grid"], s["grid_center"], s["grid_scale"])
+            w = ops.skin_weights(p["_xyz"], self.grid, s["grid_center"], s["grid_scale"])
             # one pose per view (the reference trains one (frame, view) per step)
             pxyz, pcov, tf = ops.lbs_cov(p["_xyz"], p["_scaling"], p["_rotation"], w, sel["T"])
             col = ops.sh_colors(feats, p["_xyz"], tf, cams)

@@ -30,10 +30,11 @@ def _tf44(tf12):
 def device_grid(model):
     """The reference re-uploads the (D,H,W,21) grid on every call
     (gaussian_utils.py:169); here it is uploaded once and cached on the model."""
+    from .ops import SkinGrid
     g = getattr(model, "_mgr_grid_dev", None)
     dev = model._xyz.device
-    if g is None or g.device != dev:
-        g = torch.as_tensor(model.grid_weights, dtype=torch.float32).to(dev).contiguous()
+    if g is None or g.data.device != dev:
+        g = SkinGrid(model.grid_weights, dev)
         model._mgr_grid_dev = g
     return g
 

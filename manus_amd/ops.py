@@ -16,35 +16,60 @@ import torch
 from ._lib import MGR_MAX_BONES, ManusHipError, check, f32c, lib, ptr, stream
 
 
+class SkinGrid:
+    """Skin-weight voxel grid prepared for the kernels: the reference's channel-last (D,H,W,B)
+    tensor, uploaded once and zero-padded to 24 channels (96 B per voxel) so that every trilinear
+    corner is six aligned float4 loads."""
+
+    def __init__(self, grid_weights, device=None):
+        g = torch.as_tensor(grid_weights, dtype=torch.float32)
+        if device is not None:
+            g = g.to(device)
+        self.D, self.H, self.W, self.B = g.shape
+        if self.B > MGR_MAX_BONES:
+            raise ManusHipError("skin grid: at most %d transforms" % MGR_MAX_BONES)
+        if self.B <= 24:
+            self.stride = 24
+            p = torch.zeros((self.D, self.H, self.W, 24), dtype=torch.float32, device=g.device)
+            p[..., : self.B] = g
+            self.data = p.contiguous()
+        else:
+            self.stride = self.B
+            self.data = g.contiguous()
+
+
 class _SkinWeights(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, xyz, grid, center, scale):
-        xyz, grid = f32c(xyz), f32c(grid)
+    def forward(ctx, xyz, sg, center, scale):
+        xyz = f32c(xyz)
         center, scale = f32c(center).reshape(-1), f32c(scale).reshape(-1)
-        D, H, W, B = grid.shape
-        if B > MGR_MAX_BONES:
-            raise ManusHipError("skin_weights: at most %d transforms" % MGR_MAX_BONES)
         N = xyz.shape[0]
-        w = torch.empty((N, B), dtype=torch.float32, device=xyz.device)
-        check(lib().mgr_skin_weights_fwd(N, ptr(xyz), ptr(grid), D, H, W, B, ptr(center), ptr(scale), ptr(w),
-                                         stream()), "mgr_skin_weights_fwd")
-        ctx.save_for_backward(xyz, grid, center, scale)
+        w = torch.empty((N, sg.B), dtype=torch.float32, device=xyz.device)
+        check(lib().mgr_skin_weights_fwd(N, ptr(xyz), ptr(sg.data), sg.D, sg.H, sg.W, sg.B, sg.stride, ptr(center),
+                                         ptr(scale), ptr(w), stream()), "mgr_skin_weights_fwd")
+        ctx.save_for_backward(xyz, center, scale)
+        ctx.sg = sg
         return w
 
     @staticmethod
     def backward(ctx, g_w):
-        xyz, grid, center, scale = ctx.saved_tensors
-        D, H, W, B = grid.shape
+        xyz, center, scale = ctx.saved_tensors
+        sg = ctx.sg
         N = xyz.shape[0]
         g_w = f32c(g_w)
         g_xyz = torch.empty((N, 3), dtype=torch.float32, device=xyz.device)
-        check(lib().mgr_skin_weights_bwd(N, ptr(xyz), ptr(grid), D, H, W, B, ptr(center), ptr(scale), ptr(g_w),
-                                         ptr(g_xyz), stream()), "mgr_skin_weights_bwd")
+        check(lib().mgr_skin_weights_bwd(N, ptr(xyz), ptr(sg.data), sg.D, sg.H, sg.W, sg.B, sg.stride, ptr(center),
+                                         ptr(scale), ptr(g_w), ptr(g_xyz), stream()), "mgr_skin_weights_bwd")
         return g_xyz, None, None, None
 
 
 def skin_weights(xyz, grid_weights, grid_center, grid_scale):
-    """xyz (N,3); grid_weights (D,H,W,B) channel-last on the GPU -> (N,B), rows sum to 1."""
+    """xyz (N,3); grid_weights: a `SkinGrid` (prepared once) or the reference's (D,H,W,B)
+    channel-last tensor (prepared on the fly) -> (N,B), rows sum to 1."""
+    if not isinstance(grid_weights, SkinGrid):
+        if not xyz.is_cuda:
+            raise ManusHipError("manus_amd ops need GPU tensors; there is no CPU fallback")
+        grid_weights = SkinGrid(grid_weights, xyz.device)
     return _SkinWeights.apply(xyz, grid_weights, grid_center, grid_scale)
 
 

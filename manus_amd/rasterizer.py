@@ -171,13 +171,13 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.lease = _Lease(ws)
         ctx.meta = (V, N, W, H, bool(debug), means2D.shape, opacities.shape)
         ctx.num_rendered = npairs
-        ctx.save_for_backward(means3D, colors, opac, cov3D, cams, bg)
+        ctx.save_for_backward(means3D, colors, opac, cov3D, cams, bg, out)
         ctx.mark_non_differentiable(radii)
         return out, radii
 
     @staticmethod
     def backward(ctx, g_color, _g_radii):
-        means3D, colors, opac, cov3D, cams, bg = ctx.saved_tensors
+        means3D, colors, opac, cov3D, cams, bg, out = ctx.saved_tensors
         V, N, W, H, debug, m2d_shape, op_shape = ctx.meta
         ws = ctx.lease.ws
         dev = means3D.device
@@ -192,7 +192,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         s_col = colors.stride(0) if colors.dim() == 3 else 0
         s_o = opac.stride(0) if opac.dim() == 2 else 0
         check(lib().mgr_raster_backward(V, N, W, H, ptr(cams), ptr(bg), ptr(means3D), s_m, ptr(cov3D), s_c,
-                                        ptr(colors), s_col, ptr(opac), s_o, ptr(g_color), ptr(d_m3), ptr(d_m2),
+                                        ptr(colors), s_col, ptr(opac), s_o, ptr(out), ptr(g_color), ptr(d_m3), ptr(d_m2),
                                         ptr(d_col), ptr(d_op), ptr(d_cov), ptr(ws.buf), ws.nbytes, ws.cap,
                                         int(debug), stream()), "mgr_raster_backward")
 

@@ -124,7 +124,7 @@ def test_argument_validation_without_gpu():
     assert rc == -1 and b"bad sizes" in L.mgr_last_error()
     rc = L.mgr_raster_forward(1, 10, 64, 64, None, None, None, 0, None, 0, None, 0, None, 0, None, None, None, 0, 100, 0, None)
     assert rc == -1 and b"null" in L.mgr_last_error()
-    assert L.mgr_skin_weights_fwd(5, None, None, 4, 4, 4, 64, None, None, None, None) == -1   # > MGR_MAX_BONES
+    assert L.mgr_skin_weights_fwd(5, None, None, 4, 4, 4, 64, 64, None, None, None, None) == -1   # > MGR_MAX_BONES
     assert L.mgr_lbs_cov_fwd(0, 5, 21, None, None, None, None, None, None, None, None, None) == -1
     assert L.mgr_knn3_mean_dist2(-1, None, None, None, 0, None) == -1
     assert L.mgr_sh_color_fwd(1, 0, None, None, 0, None, 0, None, None, None) == 0          # N = 0 is a no-op
