@@ -67,7 +67,10 @@ struct MgrHeader {            // first 256 bytes of the workspace
     uint32_t queue_head2;     // spare cursor
     uint32_t n_items;         // number of (tile, chunk) work items appended by the forward blend
     uint32_t item_head;       // backward work-queue cursor
-    uint32_t pad[56];
+    uint32_t pad[8];
+    uint32_t cls_count[34];   // tiles per size class (class = bit length of the pair count, 0 = empty)
+    uint32_t cls_cursor[34];  // running cursors of the queue scatter
+    uint32_t pad2[56 - 8 - 68 + 64];
 };
 
 // 48-byte per-(view,Gaussian) record gathered by the blend kernels
@@ -83,7 +86,7 @@ struct __attribute__((aligned(16))) MgrGRec {
 #define MGR_CHUNK 128        // list entries per backward work item / forward checkpoint interval
 
 struct MgrLayout {
-    size_t header, grec, depth, rect, alive, pair_off, tile_count, tile_start, tile_cursor, tile_done,
+    size_t header, scan_part, grec, depth, rect, alive, pair_off, tile_count, tile_start, tile_cursor, tile_done,
         tile_queue, chunk_start, items, ckpt, keys, sorted_gid, final_T, n_contrib, pair_tag, pair_grad, total;
 };
 
@@ -97,6 +100,7 @@ static inline MgrLayout mgr_layout(int V, int N, int W, int H, int64_t cap) {
     size_t c = (size_t)(cap > 0 ? cap : 1);
     size_t o = 0;
     L.header = o;      o += mgr_align(sizeof(MgrHeader));
+    L.scan_part = o;   o += mgr_align(((VT + 1023) / 1024 + 1) * 8);  // per-block (pairs, chunks) sums of the tile scan
     L.grec = o;        o += mgr_align(VN * sizeof(MgrGRec));
     L.depth = o;       o += mgr_align(VN * 4);
     L.rect = o;        o += mgr_align(VN * 8);       // 4 x uint16
@@ -261,6 +265,21 @@ __device__ __forceinline__ bool mgr_box_dead(float cx, float cy, float A, float 
         if (q < best) { best = q; bestM = t0 + fabsf(t1) + t2; }
     }
     return best > qmax + 0.01f + 1.0e-5f * bestM;
+}
+
+// Bounding box (in 8x8-quadrant-local pixel units) of the lanes set in `am`, lane = y*8 + x.
+// Returns false when no lane is set.  All scalar (wave-uniform) arithmetic.
+__device__ __forceinline__ bool mgr_quad_bbox(unsigned long long am, int& x0, int& y0, int& x1, int& y1) {
+    if (am == 0ull) return false;
+    y0 = __builtin_ctzll(am) >> 3;
+    y1 = (63 - __builtin_clzll(am)) >> 3;
+    unsigned int c = (unsigned int)(am | (am >> 32));
+    c |= c >> 16;
+    c |= c >> 8;
+    c &= 0xffu;
+    x0 = __builtin_ctz(c);
+    x1 = 31 - __builtin_clz(c);
+    return true;
 }
 
 // natural exponential through v_exp_f32 (arguments here lie in [-12, 0])

@@ -257,60 +257,81 @@ __global__ __launch_bounds__(PRE_THREADS) void k_preprocess(
 // K2: exclusive scan of the V*T tile counts -> tile_start; queue of non-empty
 // tiles ordered by descending size class (largest first = LPT scheduling)
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_tile_scan(int VT, const uint32_t* __restrict__ tile_count,
-                                                    uint32_t* __restrict__ tile_start,
-                                                    uint32_t* __restrict__ tile_cursor,
-                                                    uint32_t* __restrict__ tile_queue,
-                                                    uint32_t* __restrict__ chunk_start,
-                                                    MgrHeader* hdr, uint32_t cap) {
+// Phase A: per-block sums of (pairs, checkpoint chunks) over 1024 tiles, and the global
+// histogram of size classes.
+__global__ __launch_bounds__(1024) void k_tile_scan_a(int VT, const uint32_t* __restrict__ tile_count,
+                                                      uint2* __restrict__ part, MgrHeader* hdr) {
     __shared__ uint32_t s_scan[32];
     __shared__ uint32_t s_cls[34];
-    const int tid = threadIdx.x;
-    const int per = (VT + 1023) / 1024;
-    const int b = tid * per, e = min(VT, b + per);
+    const int tid = threadIdx.x, k = blockIdx.x * 1024 + tid;
     if (tid < 34) s_cls[tid] = 0;
-    // checkpoints are needed for every chunk of a tile list except the first
-    uint32_t sum = 0, csum = 0;
-    for (int k = b; k < e; ++k) {
-        const uint32_t c = tile_count[k];
-        sum += c;
-        csum += c ? (c - 1) / MGR_CHUNK : 0u;
-    }
+    __syncthreads();
+    const uint32_t c = k < VT ? tile_count[k] : 0u;
+    if (k < VT) atomicAdd(&s_cls[c ? 32 - __clz(c) : 0], 1u);
     uint32_t total, ctotal;
-    uint32_t run = block_excl_scan(sum, s_scan, total);
-    uint32_t crun = block_excl_scan(csum, s_scan, ctotal);
-    for (int k = b; k < e; ++k) {
-        const uint32_t c = tile_count[k];
-        tile_start[k] = run;
-        chunk_start[k] = crun;
-        tile_cursor[k] = 0;
-        run += c;
-        crun += c ? (c - 1) / MGR_CHUNK : 0u;
-        atomicAdd(&s_cls[c ? 32 - __clz(c) : 0], 1u);
-    }
+    (void)block_excl_scan(c, s_scan, total);
+    (void)block_excl_scan(c ? (c - 1) / MGR_CHUNK : 0u, s_scan, ctotal);
+    if (tid == 0) part[blockIdx.x] = make_uint2(total, ctotal);
+    if (tid < 34 && s_cls[tid]) atomicAdd(&hdr->cls_count[tid], s_cls[tid]);
+}
+
+// Phase B: every block re-derives its base from the (few) block sums, writes tile_start /
+// chunk_start, and scatters its tiles into the size-ordered queue (largest class first, empty
+// tiles last; order inside a class is arbitrary).
+__global__ __launch_bounds__(1024) void k_tile_scan_b(int VT, int nblk, const uint32_t* __restrict__ tile_count,
+                                                      const uint2* __restrict__ part,
+                                                      uint32_t* __restrict__ tile_start,
+                                                      uint32_t* __restrict__ tile_cursor,
+                                                      uint32_t* __restrict__ tile_queue,
+                                                      uint32_t* __restrict__ chunk_start, MgrHeader* hdr,
+                                                      uint32_t cap) {
+    __shared__ uint32_t s_scan[32];
+    __shared__ uint32_t s_cbase[34], s_lc[34], s_gb[34];
+    __shared__ uint32_t s_base[2], s_tot[2];
+    const int tid = threadIdx.x, k = blockIdx.x * 1024 + tid;
+    if (tid < 34) s_lc[tid] = 0;
     if (tid == 0) {
-        tile_start[VT] = total;
-        chunk_start[VT] = ctotal;
-        hdr->overflow = (total > cap || hdr->total_pairs > cap) ? 1u : 0u;
+        uint32_t r = 0, rc = 0, b0 = 0, b1 = 0;
+        for (int j = 0; j < nblk; ++j) {
+            if (j == (int)blockIdx.x) { b0 = r; b1 = rc; }
+            r += part[j].x;
+            rc += part[j].y;
+        }
+        s_base[0] = b0; s_base[1] = b1; s_tot[0] = r; s_tot[1] = rc;
+        uint32_t q = 0;  // descending class order
+        for (int c = 33; c >= 0; --c) {
+            s_cbase[c] = q;
+            q += hdr->cls_count[c];
+        }
+    }
+    __syncthreads();
+    const uint32_t c = k < VT ? tile_count[k] : 0u;
+    uint32_t total, ctotal;
+    const uint32_t run = block_excl_scan(c, s_scan, total);
+    const uint32_t crun = block_excl_scan(c ? (c - 1) / MGR_CHUNK : 0u, s_scan, ctotal);
+    // queue slot = class base + this block's base inside the class (ONE global atomic per
+    // (block, class)) + rank inside the block (LDS atomic)
+    const int cls = c ? 32 - __clz(c) : 0;
+    uint32_t rank = 0;
+    if (k < VT) {
+        tile_start[k] = s_base[0] + run;
+        chunk_start[k] = s_base[1] + crun;
+        tile_cursor[k] = 0;
+        rank = atomicAdd(&s_lc[cls], 1u);
+    }
+    __syncthreads();
+    if (tid < 34) s_gb[tid] = s_lc[tid] ? atomicAdd(&hdr->cls_cursor[tid], s_lc[tid]) : 0u;
+    __syncthreads();
+    if (k < VT) tile_queue[s_cbase[cls] + s_gb[cls] + rank] = (uint32_t)k;
+    if (blockIdx.x == 0 && tid == 0) {
+        tile_start[VT] = s_tot[0];
+        chunk_start[VT] = s_tot[1];
+        hdr->overflow = (s_tot[0] > cap || hdr->total_pairs > cap) ? 1u : 0u;
         hdr->n_items = 0;
         hdr->item_head = 0;
-    }
-    __syncthreads();
-    if (tid == 0) {  // descending class order
-        uint32_t r = 0;
-        for (int c = 33; c >= 0; --c) {
-            const uint32_t t = s_cls[c];
-            s_cls[c] = r;
-            r += t;
-        }
-        hdr->queue_len = s_cls[0];  // class 0 (empty tiles) starts after all non-empty ones
+        hdr->queue_len = s_cbase[0];  // class 0 (empty tiles) starts after all non-empty ones
         hdr->queue_head = 0;
         hdr->queue_head2 = 0;
-    }
-    __syncthreads();
-    for (int k = b; k < e; ++k) {
-        const uint32_t c = tile_count[k];
-        tile_queue[atomicAdd(&s_cls[c ? 32 - __clz(c) : 0], 1u)] = (uint32_t)k;
     }
 }
 
@@ -571,6 +592,7 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, 
     __shared__ float4 s_co[256];
     __shared__ float s_rgb[256 * 3];
     __shared__ unsigned long long s_mask[4][4];  // [staging wave][quadrant]
+    __shared__ float4 s_box[4];                  // per quadrant: bounding box of the pixels still active
     __shared__ uint32_t s_max, s_next, s_ibase;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int T = gx * gy;
@@ -615,7 +637,15 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, 
             rec.b = *((const float4*)r + 1);
             rec.c = r->b;
         }
+        const float qx0 = tx0 + (float)((wave & 1) * 8), qy0 = ty0 + (float)((wave >> 1) * 8);
         for (uint32_t off = 0; off < nlist; off += 256) {
+            {   // shrink this quadrant's box to the pixels that are still accumulating
+                int bx0, by0, bx1, by1;
+                const bool any = mgr_quad_bbox(__ballot(!done), bx0, by0, bx1, by1);
+                if (lane == 0)
+                    s_box[wave] = any ? make_float4(qx0 + (float)bx0, qy0 + (float)by0, qx0 + (float)bx1, qy0 + (float)by1)
+                                      : make_float4(1.f, 1.f, 0.f, 0.f);
+            }
             if (__syncthreads_count(done) == 256) break;
             const uint32_t idx = off + tid;
             bool d0 = true, d1 = true, d2 = true, d3 = true;
@@ -627,10 +657,11 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, 
                 s_rgb[tid * 3 + 1] = b.w;
                 s_rgb[tid * 3 + 2] = rec.c;
                 const float qmax = mgr_qmax(b.y);
-                d0 = mgr_box_dead(a.x, a.y, a.z, a.w, b.x, qmax, tx0, ty0, tx0 + 7.f, ty0 + 7.f);
-                d1 = mgr_box_dead(a.x, a.y, a.z, a.w, b.x, qmax, tx0 + 8.f, ty0, tx0 + 15.f, ty0 + 7.f);
-                d2 = mgr_box_dead(a.x, a.y, a.z, a.w, b.x, qmax, tx0, ty0 + 8.f, tx0 + 7.f, ty0 + 15.f);
-                d3 = mgr_box_dead(a.x, a.y, a.z, a.w, b.x, qmax, tx0 + 8.f, ty0 + 8.f, tx0 + 15.f, ty0 + 15.f);
+                const float4 q0 = s_box[0], q1 = s_box[1], q2 = s_box[2], q3 = s_box[3];
+                d0 = q0.x > q0.z || mgr_box_dead(a.x, a.y, a.z, a.w, b.x, qmax, q0.x, q0.y, q0.z, q0.w);
+                d1 = q1.x > q1.z || mgr_box_dead(a.x, a.y, a.z, a.w, b.x, qmax, q1.x, q1.y, q1.z, q1.w);
+                d2 = q2.x > q2.z || mgr_box_dead(a.x, a.y, a.z, a.w, b.x, qmax, q2.x, q2.y, q2.z, q2.w);
+                d3 = q3.x > q3.z || mgr_box_dead(a.x, a.y, a.z, a.w, b.x, qmax, q3.x, q3.y, q3.z, q3.w);
             }
             const unsigned long long m0 = __ballot(!d0), m1 = __ballot(!d1), m2 = __ballot(!d2), m3 = __ballot(!d3);
             if (lane == 0) {
@@ -779,6 +810,7 @@ extern "C" int mgr_raster_forward(int V, int N, int W, int H, const float* cams,
 
     // per-call counters (epoch lives past the first 32 bytes and persists)
     MGR_HIP(hipMemsetAsync(hdr, 0, 8, stream));
+    MGR_HIP(hipMemsetAsync(&hdr->cls_count[0], 0, sizeof(uint32_t) * 68, stream));
     MGR_HIP(hipMemsetAsync(tile_count, 0, (size_t)VT * 4, stream));
 
     const int lds_hist = ((size_t)T * 4 + 128 <= 150 * 1024) ? 1 : 0;
@@ -792,9 +824,14 @@ extern "C" int mgr_raster_forward(int V, int N, int W, int H, const float* cams,
                            hdr, lds_hist); }
         MGR_LAUNCH_CHECK("k_preprocess", stream, debug);
     }
-    { MGR_PROF("k_tile_scan", stream); hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, stream, VT, tile_count, tile_start,
-                       (uint32_t*)(ws + L.tile_cursor), (uint32_t*)(ws + L.tile_queue),
-                       (uint32_t*)(ws + L.chunk_start), hdr, (uint32_t)cap); }
+    {
+        const int nblk = (VT + 1023) / 1024;
+        uint2* part = (uint2*)(ws + L.scan_part);
+        { MGR_PROF("k_tile_scan_a", stream); hipLaunchKernelGGL(k_tile_scan_a, dim3(nblk), dim3(1024), 0, stream, VT, tile_count, part, hdr); }
+        { MGR_PROF("k_tile_scan_b", stream); hipLaunchKernelGGL(k_tile_scan_b, dim3(nblk), dim3(1024), 0, stream, VT, nblk, tile_count, part,
+                           tile_start, (uint32_t*)(ws + L.tile_cursor), (uint32_t*)(ws + L.tile_queue),
+                           (uint32_t*)(ws + L.chunk_start), hdr, (uint32_t)cap); }
+    }
     MGR_LAUNCH_CHECK("k_tile_scan", stream, debug);
     if (N > 0) {
         dim3 grid((N + PRE_THREADS - 1) / PRE_THREADS, V);
