@@ -106,7 +106,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        # "nccl" is RCCL on ROCm; MANUS_BENCH_BACKEND=gloo lets the N>1 path be exercised on a
+        # single-GPU box (all ranks then share device 0)
+        dist.init_process_group(os.environ.get("MANUS_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
+    local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 

@@ -67,7 +67,9 @@ struct MgrHeader {            // first 256 bytes of the workspace
     uint32_t queue_head2;     // spare cursor
     uint32_t n_items;         // number of (tile, chunk) work items appended by the forward blend
     uint32_t item_head;       // backward work-queue cursor
-    uint32_t pad[8];
+    uint32_t queue_small;     // queue index of the first tile with fewer than 2048 pairs
+    uint32_t queue_head3;     // cursor of the small-tile sort
+    uint32_t pad[6];
     uint32_t cls_count[34];   // tiles per size class (class = bit length of the pair count, 0 = empty)
     uint32_t cls_cursor[34];  // running cursors of the queue scatter
     uint32_t pad2[56 - 8 - 68 + 64];

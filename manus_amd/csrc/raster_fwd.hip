@@ -330,8 +330,10 @@ __global__ __launch_bounds__(1024) void k_tile_scan_b(int VT, int nblk, const ui
         hdr->n_items = 0;
         hdr->item_head = 0;
         hdr->queue_len = s_cbase[0];  // class 0 (empty tiles) starts after all non-empty ones
+        hdr->queue_small = s_cbase[11]; // classes <= 11: fewer than 2048 pairs
         hdr->queue_head = 0;
         hdr->queue_head2 = 0;
+        hdr->queue_head3 = s_cbase[11];
     }
 }
 
@@ -464,7 +466,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_tile_sort(
     uint32_t* s_off = s_cnt + SORT_MAX_GROUPS + 1;                                        // 65 offsets
     uint32_t* s_item = s_off + SORT_MAX_GROUPS + 1;                                       // [0] item, [1] fill, [2] flag
     const int tid = threadIdx.x, lane = tid & 63;
-    const uint32_t qlen = hdr->queue_len;
+    const uint32_t qlen = hdr->queue_small;  // smaller segments are sorted by k_tile_sort_small
     for (;;) {
         __syncthreads();
         if (tid == 0) s_item[0] = atomicAdd(&hdr->queue_head, 1u);
@@ -555,6 +557,36 @@ __global__ __launch_bounds__(SORT_THREADS) void k_tile_sort(
             __threadfence_block();
             for (uint32_t t = tid; t < n; t += SORT_THREADS) sorted_gid[start + t] = (uint32_t)keys[start + t];
         }
+    }
+}
+
+// Segments of fewer than 2048 pairs (most tiles): 256-thread workgroups with 16 KB of LDS, so
+// that many of them are resident per CU.
+#define SORT_SMALL_KEYS 2048
+__global__ __launch_bounds__(256) void k_tile_sort_small(
+    const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ tile_queue,
+    const unsigned long long* __restrict__ keys, uint32_t* __restrict__ sorted_gid, MgrHeader* hdr,
+    uint32_t cap) {
+    __shared__ __attribute__((aligned(16))) unsigned long long s_keys[SORT_SMALL_KEYS];
+    __shared__ uint32_t s_item;
+    const int tid = threadIdx.x;
+    const uint32_t qlen = hdr->queue_len;
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) s_item = atomicAdd(&hdr->queue_head3, 1u);
+        __syncthreads();
+        const uint32_t item = s_item;
+        if (item >= qlen) break;
+        const uint32_t vt = tile_queue[item];
+        const uint32_t start = min(tile_start[vt], cap), end = min(tile_start[vt + 1], cap);
+        const uint32_t n = min(end - start, (uint32_t)SORT_SMALL_KEYS);
+        if (n == 0) continue;
+        uint32_t npad = 1;
+        while (npad < n) npad <<= 1;
+        for (uint32_t t = tid; t < n; t += 256) s_keys[t] = keys[start + t];
+        __syncthreads();
+        if (n > 1) bitonic_mirror(s_keys, n, npad, tid, 256);
+        for (uint32_t t = tid; t < n; t += 256) sorted_gid[start + t] = (uint32_t)s_keys[t];
     }
 }
 
@@ -844,6 +876,10 @@ extern "C" int mgr_raster_forward(int V, int N, int W, int H, const float* cams,
         { MGR_PROF("k_tile_sort", stream); hipLaunchKernelGGL(k_tile_sort, dim3(256), dim3(SORT_THREADS), SORT_LDS_KEYS * 8 + SORT_LDS_EXTRA, stream,
                            tile_start, (const uint32_t*)(ws + L.tile_queue),
                            (unsigned long long*)(ws + L.keys), (uint32_t*)(ws + L.sorted_gid), hdr,
+                           (uint32_t)cap); }
+        { MGR_PROF("k_tile_sort_small", stream); hipLaunchKernelGGL(k_tile_sort_small, dim3(256 * 8), dim3(256), 0, stream,
+                           tile_start, (const uint32_t*)(ws + L.tile_queue),
+                           (const unsigned long long*)(ws + L.keys), (uint32_t*)(ws + L.sorted_gid), hdr,
                            (uint32_t)cap); }
         MGR_LAUNCH_CHECK("k_tile_sort", stream, debug);
     }
