@@ -11,7 +11,7 @@
 //   SH colour      src/utils/gaussian_utils.py:431-449; src/utils/sh_utils.py:57-104
 //   projection     src/utils/transforms.py:304-311
 //   L1 loss        src/utils/loss_utils.py:22-27
-#include "mgr_common.h"
+#include "instance_math.h"
 
 // ---------------------------------------------------------------------------
 // skin weights: trilinear, align_corners=True, zero padding, then w / sum(w)
@@ -220,31 +220,6 @@ __global__ __launch_bounds__(256) void k_skin_bwd24(int N, const float* __restri
 // ---------------------------------------------------------------------------
 // LBS of means and covariances
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void quat_rot(const float q[4], float R[9]) {
-    const float r = q[0], x = q[1], y = q[2], z = q[3];
-    R[0] = 1.f - 2.f * (y * y + z * z); R[1] = 2.f * (x * y - r * z); R[2] = 2.f * (x * z + r * y);
-    R[3] = 2.f * (x * y + r * z); R[4] = 1.f - 2.f * (x * x + z * z); R[5] = 2.f * (y * z - r * x);
-    R[6] = 2.f * (x * z - r * y); R[7] = 2.f * (y * z + r * x); R[8] = 1.f - 2.f * (x * x + y * y);
-}
-
-// tf rows 0..2 (3x4, row-major) = sum_b w_b * T_b ; identity when w == nullptr
-__device__ __forceinline__ void blend_tf(const float* __restrict__ w_row, const float* __restrict__ Tp,
-                                         int B, float tf[12]) {
-    if (w_row == nullptr) {
-#pragma unroll
-        for (int k = 0; k < 12; ++k) tf[k] = (k == 0 || k == 5 || k == 10) ? 1.f : 0.f;
-        return;
-    }
-#pragma unroll
-    for (int k = 0; k < 12; ++k) tf[k] = 0.f;
-    for (int b = 0; b < B; ++b) {
-        const float w = w_row[b];
-        const float* T = Tp + (size_t)b * 16;  // wave-uniform address
-#pragma unroll
-        for (int k = 0; k < 12; ++k) tf[k] += w * T[k];
-    }
-}
-
 __global__ __launch_bounds__(256) void k_lbs_fwd(int N, int B, const float* __restrict__ xyz,
                                                  const float* __restrict__ log_scale,
                                                  const float* __restrict__ rot,
@@ -257,31 +232,15 @@ __global__ __launch_bounds__(256) void k_lbs_fwd(int N, int B, const float* __re
     if (i >= N) return;
     float tf[12];
     blend_tf(skin_w ? skin_w + (size_t)i * B : nullptr, transforms ? transforms + (size_t)p * B * 16 : nullptr, B, tf);
-    const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+    GaussCano g;
+    cano_load(xyz, log_scale, rot, i, g);
+    float posed[3], cov6[6];
+    lbs_apply(tf, g, posed, cov6);
     const size_t pi = (size_t)p * N + i;
-    posed_xyz[pi * 3 + 0] = tf[0] * x + tf[1] * y + tf[2] * z + tf[3];
-    posed_xyz[pi * 3 + 1] = tf[4] * x + tf[5] * y + tf[6] * z + tf[7];
-    posed_xyz[pi * 3 + 2] = tf[8] * x + tf[9] * y + tf[10] * z + tf[11];
-    const float qr[4] = {rot[4 * i], rot[4 * i + 1], rot[4 * i + 2], rot[4 * i + 3]};
-    const float nrm = sqrtf(qr[0] * qr[0] + qr[1] * qr[1] + qr[2] * qr[2] + qr[3] * qr[3]);
-    const float q[4] = {qr[0] / nrm, qr[1] / nrm, qr[2] / nrm, qr[3] / nrm};
-    float R[9];
-    quat_rot(q, R);
-    const float s[3] = {expf(log_scale[3 * i]), expf(log_scale[3 * i + 1]), expf(log_scale[3 * i + 2])};
-    // M = A * R * diag(s)
-    float M[9];
 #pragma unroll
-    for (int r = 0; r < 3; ++r)
+    for (int k = 0; k < 3; ++k) posed_xyz[pi * 3 + k] = posed[k];
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
-            M[3 * r + c] = (tf[4 * r] * R[c] + tf[4 * r + 1] * R[3 + c] + tf[4 * r + 2] * R[6 + c]) * s[c];
-    float* o = posed_cov + pi * 6;
-    o[0] = M[0] * M[0] + M[1] * M[1] + M[2] * M[2];
-    o[1] = M[0] * M[3] + M[1] * M[4] + M[2] * M[5];
-    o[2] = M[0] * M[6] + M[1] * M[7] + M[2] * M[8];
-    o[3] = M[3] * M[3] + M[4] * M[4] + M[5] * M[5];
-    o[4] = M[3] * M[6] + M[4] * M[7] + M[5] * M[8];
-    o[5] = M[6] * M[6] + M[7] * M[7] + M[8] * M[8];
+    for (int k = 0; k < 6; ++k) posed_cov[pi * 6 + k] = cov6[k];
     if (tf_out) {
 #pragma unroll
         for (int k = 0; k < 12; ++k) tf_out[pi * 12 + k] = tf[k];
@@ -302,13 +261,8 @@ __global__ __launch_bounds__(256) void k_lbs_bwd(int P, int N, int B, const floa
                                                  float* __restrict__ dL_dw) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
-    const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
-    const float qr[4] = {rot[4 * i], rot[4 * i + 1], rot[4 * i + 2], rot[4 * i + 3]};
-    const float nrm = sqrtf(qr[0] * qr[0] + qr[1] * qr[1] + qr[2] * qr[2] + qr[3] * qr[3]);
-    const float q[4] = {qr[0] / nrm, qr[1] / nrm, qr[2] / nrm, qr[3] / nrm};
-    float R[9];
-    quat_rot(q, R);
-    const float s[3] = {expf(log_scale[3 * i]), expf(log_scale[3 * i + 1]), expf(log_scale[3 * i + 2])};
+    GaussCano g;
+    cano_load(xyz, log_scale, rot, i, g);
     float dxyz[3] = {0.f, 0.f, 0.f}, ds[3] = {0.f, 0.f, 0.f};
     float dR[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float dw[MGR_MAX_BONES];
@@ -318,56 +272,17 @@ __global__ __launch_bounds__(256) void k_lbs_bwd(int P, int N, int B, const floa
     for (int p = 0; p < P; ++p) {
         const size_t pi = (size_t)p * N + i;
         const float* Tp = transforms ? transforms + (size_t)p * B * 16 : nullptr;
-        float tf[12];
+        float tf[12], dtf[12];
         blend_tf(skin_w ? skin_w + (size_t)i * B : nullptr, Tp, B, tf);
-        // Gs = G + G^T of the upper-triangular cov gradient
-        const float* g6 = g_cov + pi * 6;
-        const float Gs[9] = {2.f * g6[0], g6[1], g6[2], g6[1], 2.f * g6[3], g6[4], g6[2], g6[4], 2.f * g6[5]};
-        // AL = A * L, L = R diag(s)
-        float L[9], AL[9];
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) L[3 * r + c] = R[3 * r + c] * s[c];
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-                AL[3 * r + c] = tf[4 * r] * L[c] + tf[4 * r + 1] * L[3 + c] + tf[4 * r + 2] * L[6 + c];
-        // dM = Gs * AL
-        float dM[9];
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-                dM[3 * r + c] = Gs[3 * r] * AL[c] + Gs[3 * r + 1] * AL[3 + c] + Gs[3 * r + 2] * AL[6 + c];
-        // dL_L = A^T dM ; dA = dM L^T
-        float dtf[12];
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float dLrc = tf[r] * dM[c] + tf[4 + r] * dM[3 + c] + tf[8 + r] * dM[6 + c];
-                ds[c] += dLrc * R[3 * r + c];
-                dR[3 * r + c] += dLrc * s[c];
-                dtf[4 * r + c] = dM[3 * r] * L[3 * c] + dM[3 * r + 1] * L[3 * c + 1] + dM[3 * r + 2] * L[3 * c + 2];
-            }
-        // means: posed = A xyz + t
         const float gp[3] = {g_xyz[pi * 3], g_xyz[pi * 3 + 1], g_xyz[pi * 3 + 2]};
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            dtf[4 * r + 0] += gp[r] * x;
-            dtf[4 * r + 1] += gp[r] * y;
-            dtf[4 * r + 2] += gp[r] * z;
-            dtf[4 * r + 3] = gp[r];
-        }
-        dxyz[0] += tf[0] * gp[0] + tf[4] * gp[1] + tf[8] * gp[2];
-        dxyz[1] += tf[1] * gp[0] + tf[5] * gp[1] + tf[9] * gp[2];
-        dxyz[2] += tf[2] * gp[0] + tf[6] * gp[1] + tf[10] * gp[2];
+        const float g6[6] = {g_cov[pi * 6], g_cov[pi * 6 + 1], g_cov[pi * 6 + 2],
+                             g_cov[pi * 6 + 3], g_cov[pi * 6 + 4], g_cov[pi * 6 + 5]};
+        float gt[12];
         if (g_tf) {
 #pragma unroll
-            for (int k = 0; k < 12; ++k) dtf[k] += g_tf[pi * 12 + k];
+            for (int k = 0; k < 12; ++k) gt[k] = g_tf[pi * 12 + k];
         }
+        lbs_backward_view(tf, g, gp, g6, g_tf ? gt : nullptr, dxyz, ds, dR, dtf);
         if (skin_w) {
 #pragma unroll
             for (int b = 0; b < MGR_MAX_BONES; ++b) {
@@ -382,17 +297,11 @@ __global__ __launch_bounds__(256) void k_lbs_bwd(int P, int N, int B, const floa
         }
     }
     dL_dxyz[3 * i] = dxyz[0]; dL_dxyz[3 * i + 1] = dxyz[1]; dL_dxyz[3 * i + 2] = dxyz[2];
-    dL_dls[3 * i] = ds[0] * s[0]; dL_dls[3 * i + 1] = ds[1] * s[1]; dL_dls[3 * i + 2] = ds[2] * s[2];
-    // R(q) -> q -> raw quaternion
-    const float r = q[0], qx = q[1], qy = q[2], qz = q[3];
-    float dq[4];
-    dq[0] = 2.f * (-qz * dR[1] + qy * dR[2] + qz * dR[3] - qx * dR[5] - qy * dR[6] + qx * dR[7]);
-    dq[1] = 2.f * (qy * dR[1] + qz * dR[2] + qy * dR[3] - 2.f * qx * dR[4] - r * dR[5] + qz * dR[6] + r * dR[7] - 2.f * qx * dR[8]);
-    dq[2] = 2.f * (-2.f * qy * dR[0] + qx * dR[1] + r * dR[2] + qx * dR[3] + qz * dR[5] - r * dR[6] + qz * dR[7] - 2.f * qy * dR[8]);
-    dq[3] = 2.f * (-2.f * qz * dR[0] - r * dR[1] + qx * dR[2] + r * dR[3] - 2.f * qz * dR[4] + qy * dR[5] + qx * dR[6] + qy * dR[7]);
-    const float qd = q[0] * dq[0] + q[1] * dq[1] + q[2] * dq[2] + q[3] * dq[3];
+    dL_dls[3 * i] = ds[0] * g.s[0]; dL_dls[3 * i + 1] = ds[1] * g.s[1]; dL_dls[3 * i + 2] = ds[2] * g.s[2];
+    float drot[4];
+    quat_backward(g, dR, drot);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) dL_drot[4 * i + k] = (dq[k] - q[k] * qd) / nrm;
+    for (int k = 0; k < 4; ++k) dL_drot[4 * i + k] = drot[k];
     if (dL_dw && skin_w) {
 #pragma unroll
         for (int b = 0; b < MGR_MAX_BONES; ++b)
@@ -403,55 +312,6 @@ __global__ __launch_bounds__(256) void k_lbs_bwd(int P, int N, int B, const floa
 // ---------------------------------------------------------------------------
 // SH colour (degree 3)
 // ---------------------------------------------------------------------------
-#define SHC0 0.28209479177387814f
-#define SHC1 0.4886025119029199f
-__device__ static const float SHC2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
-                                         -1.0925484305920792f, 0.5462742152960396f};
-__device__ static const float SHC3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
-                                         0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
-                                         -0.5900435899266435f};
-
-__device__ __forceinline__ void sh_basis(float x, float y, float z, float Y[16]) {
-    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-    Y[0] = SHC0;
-    Y[1] = -SHC1 * y; Y[2] = SHC1 * z; Y[3] = -SHC1 * x;
-    Y[4] = SHC2[0] * xy; Y[5] = SHC2[1] * yz; Y[6] = SHC2[2] * (2.f * zz - xx - yy);
-    Y[7] = SHC2[3] * xz; Y[8] = SHC2[4] * (xx - yy);
-    Y[9] = SHC3[0] * y * (3.f * xx - yy); Y[10] = SHC3[1] * xy * z;
-    Y[11] = SHC3[2] * y * (4.f * zz - xx - yy); Y[12] = SHC3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy);
-    Y[13] = SHC3[4] * x * (4.f * zz - xx - yy); Y[14] = SHC3[5] * z * (xx - yy);
-    Y[15] = SHC3[6] * x * (xx - 3.f * yy);
-}
-
-// direction (un-normalised d, and pulled-back camera) for one (view, Gaussian)
-struct ShDir {
-    float d[3], n, ci[3];  // d = xyz - cam', n = |d|, ci = inv(tf)*cam (when tf)
-    float Ainv[9];         // inverse of tf[:3,:3] (when tf)
-};
-
-__device__ __forceinline__ void sh_dir(const float* __restrict__ xyz_v, int i,
-                                       const float* __restrict__ tf_v, const float cam[3], ShDir& o) {
-    const float x = xyz_v[3 * i], y = xyz_v[3 * i + 1], z = xyz_v[3 * i + 2];
-    if (tf_v) {
-        const float* t = tf_v + (size_t)i * 12;
-        const float a = t[0], b = t[1], c = t[2], d = t[4], e = t[5], f = t[6], g = t[8], h = t[9], k = t[10];
-        const float c00 = e * k - f * h, c01 = f * g - d * k, c02 = d * h - e * g;
-        const float det = a * c00 + b * c01 + c * c02;
-        const float id = 1.0f / det;
-        o.Ainv[0] = c00 * id; o.Ainv[1] = (c * h - b * k) * id; o.Ainv[2] = (b * f - c * e) * id;
-        o.Ainv[3] = c01 * id; o.Ainv[4] = (a * k - c * g) * id; o.Ainv[5] = (c * d - a * f) * id;
-        o.Ainv[6] = c02 * id; o.Ainv[7] = (b * g - a * h) * id; o.Ainv[8] = (a * e - b * d) * id;
-        const float bx = cam[0] - t[3], by = cam[1] - t[7], bz = cam[2] - t[11];
-        o.ci[0] = o.Ainv[0] * bx + o.Ainv[1] * by + o.Ainv[2] * bz;
-        o.ci[1] = o.Ainv[3] * bx + o.Ainv[4] * by + o.Ainv[5] * bz;
-        o.ci[2] = o.Ainv[6] * bx + o.Ainv[7] * by + o.Ainv[8] * bz;
-        o.d[0] = x - o.ci[0]; o.d[1] = y - o.ci[1]; o.d[2] = z - o.ci[2];
-    } else {
-        o.d[0] = x - cam[0]; o.d[1] = y - cam[1]; o.d[2] = z - cam[2];
-    }
-    o.n = sqrtf(o.d[0] * o.d[0] + o.d[1] * o.d[1] + o.d[2] * o.d[2]);
-}
-
 __global__ __launch_bounds__(256) void k_sh_fwd(int N, const float* __restrict__ sh,
                                                 const float* __restrict__ xyz, int64_t s_xyz,
                                                 const float* __restrict__ tf, int64_t s_tf,
@@ -461,22 +321,18 @@ __global__ __launch_bounds__(256) void k_sh_fwd(int N, const float* __restrict__
     if (i >= N) return;
     const float* cp = cams + (size_t)v * MGR_CAM_FLOATS + 34;
     const float cam[3] = {cp[0], cp[1], cp[2]};
+    const float* xv = xyz + (size_t)v * s_xyz;
     ShDir D;
-    sh_dir(xyz + (size_t)v * s_xyz, i, tf ? tf + (size_t)v * s_tf : nullptr, cam, D);
-    float Y[16];
+    sh_dir_xyz(xv[3 * i], xv[3 * i + 1], xv[3 * i + 2], tf ? tf + (size_t)v * s_tf + (size_t)i * 12 : nullptr, cam, D);
+    float Y[16], c[48], rgb[3];
     sh_basis(D.d[0] / D.n, D.d[1] / D.n, D.d[2] / D.n, Y);
-    const float* c = sh + (size_t)i * 48;
-    float r = 0.f, g = 0.f, b = 0.f;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        r += Y[k] * c[3 * k];
-        g += Y[k] * c[3 * k + 1];
-        b += Y[k] * c[3 * k + 2];
-    }
+    for (int k = 0; k < 48; ++k) c[k] = sh[(size_t)i * 48 + k];
+    sh_rgb(c, Y, rgb);
     float* o = colors + ((size_t)v * N + i) * 3;
-    o[0] = fmaxf(r + 0.5f, 0.f);
-    o[1] = fmaxf(g + 0.5f, 0.f);
-    o[2] = fmaxf(b + 0.5f, 0.f);
+    o[0] = fmaxf(rgb[0] + 0.5f, 0.f);
+    o[1] = fmaxf(rgb[1] + 0.5f, 0.f);
+    o[2] = fmaxf(rgb[2] + 0.5f, 0.f);
 }
 
 __global__ __launch_bounds__(256) void k_sh_bwd(int V, int N, const float* __restrict__ sh,
@@ -498,60 +354,20 @@ __global__ __launch_bounds__(256) void k_sh_bwd(int V, int N, const float* __res
     for (int v = 0; v < V; ++v) {
         const float* cp = cams + (size_t)v * MGR_CAM_FLOATS + 34;
         const float cam[3] = {cp[0], cp[1], cp[2]};
+        const float* xv = xyz + (size_t)v * s_xyz;
+        const bool has_tf = tf != nullptr;
         ShDir D;
-        sh_dir(xyz + (size_t)v * s_xyz, i, tf ? tf + (size_t)v * s_tf : nullptr, cam, D);
-        const float inv_n = 1.0f / D.n;
-        const float x = D.d[0] * inv_n, y = D.d[1] * inv_n, z = D.d[2] * inv_n;
-        float Y[16];
-        sh_basis(x, y, z, Y);
-        float rgb[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            rgb[0] += Y[k] * c[3 * k];
-            rgb[1] += Y[k] * c[3 * k + 1];
-            rgb[2] += Y[k] * c[3 * k + 2];
-        }
-        const float* gc = g_col + ((size_t)v * N + i) * 3;
-        float dr[3];
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch) dr[ch] = (rgb[ch] + 0.5f >= 0.f) ? gc[ch] : 0.f;
-        float t[16];  // dL/dY_k
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            t[k] = c[3 * k] * dr[0] + c[3 * k + 1] * dr[1] + c[3 * k + 2] * dr[2];
-            dsh[3 * k] += Y[k] * dr[0];
-            dsh[3 * k + 1] += Y[k] * dr[1];
-            dsh[3 * k + 2] += Y[k] * dr[2];
-        }
-        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-        float gdx = -SHC1 * t[3] + SHC2[0] * y * t[4] + SHC2[2] * (-2.f * x) * t[6] + SHC2[3] * z * t[7] +
-                    SHC2[4] * 2.f * x * t[8] + SHC3[0] * 6.f * xy * t[9] + SHC3[1] * yz * t[10] +
-                    SHC3[2] * (-2.f * xy) * t[11] + SHC3[3] * (-6.f * xz) * t[12] +
-                    SHC3[4] * (4.f * zz - 3.f * xx - yy) * t[13] + SHC3[5] * 2.f * xz * t[14] +
-                    SHC3[6] * (3.f * xx - 3.f * yy) * t[15];
-        float gdy = -SHC1 * t[1] + SHC2[0] * x * t[4] + SHC2[1] * z * t[5] + SHC2[2] * (-2.f * y) * t[6] +
-                    SHC2[4] * (-2.f * y) * t[8] + SHC3[0] * (3.f * xx - 3.f * yy) * t[9] +
-                    SHC3[1] * xz * t[10] + SHC3[2] * (4.f * zz - xx - 3.f * yy) * t[11] +
-                    SHC3[3] * (-6.f * yz) * t[12] + SHC3[4] * (-2.f * xy) * t[13] +
-                    SHC3[5] * (-2.f * yz) * t[14] + SHC3[6] * (-6.f * xy) * t[15];
-        float gdz = SHC1 * t[2] + SHC2[1] * y * t[5] + SHC2[2] * 4.f * z * t[6] + SHC2[3] * x * t[7] +
-                    SHC3[1] * xy * t[10] + SHC3[2] * 8.f * yz * t[11] +
-                    SHC3[3] * (6.f * zz - 3.f * xx - 3.f * yy) * t[12] + SHC3[4] * 8.f * xz * t[13] +
-                    SHC3[5] * (xx - yy) * t[14];
-        // through the normalisation dir = d/|d|
-        const float dp = x * gdx + y * gdy + z * gdz;
-        const float gd[3] = {(gdx - x * dp) * inv_n, (gdy - y * dp) * inv_n, (gdz - z * dp) * inv_n};
+        sh_dir_xyz(xv[3 * i], xv[3 * i + 1], xv[3 * i + 2], has_tf ? tf + (size_t)v * s_tf + (size_t)i * 12 : nullptr, cam, D);
+        const float* gcp = g_col + ((size_t)v * N + i) * 3;
+        const float gc[3] = {gcp[0], gcp[1], gcp[2]};
+        float gd[3], dtf[12];
+        sh_backward_view(c, D, has_tf, gc, dsh, gd, dtf);
         float* ox = dL_dxyz + ((size_t)v * N + i) * 3;
         ox[0] = gd[0]; ox[1] = gd[1]; ox[2] = gd[2];
-        if (tf && dL_dtf) {
-            // cam' = Ainv (cam - t);  g_cam' = -gd;  h = Ainv^T g_cam'
-            const float h0 = -(D.Ainv[0] * gd[0] + D.Ainv[3] * gd[1] + D.Ainv[6] * gd[2]);
-            const float h1 = -(D.Ainv[1] * gd[0] + D.Ainv[4] * gd[1] + D.Ainv[7] * gd[2]);
-            const float h2 = -(D.Ainv[2] * gd[0] + D.Ainv[5] * gd[1] + D.Ainv[8] * gd[2]);
+        if (has_tf && dL_dtf) {
             float* ot = dL_dtf + ((size_t)v * N + i) * 12;
-            ot[0] = -h0 * D.ci[0]; ot[1] = -h0 * D.ci[1]; ot[2] = -h0 * D.ci[2]; ot[3] = -h0;
-            ot[4] = -h1 * D.ci[0]; ot[5] = -h1 * D.ci[1]; ot[6] = -h1 * D.ci[2]; ot[7] = -h1;
-            ot[8] = -h2 * D.ci[0]; ot[9] = -h2 * D.ci[1]; ot[10] = -h2 * D.ci[2]; ot[11] = -h2;
+#pragma unroll
+            for (int k = 0; k < 12; ++k) ot[k] = dtf[k];
         }
     }
 #pragma unroll

@@ -17,7 +17,7 @@
 // No float atomics anywhere: images and gradients are bitwise reproducible.
 #include <atomic>
 
-#include "mgr_common.h"
+#include "instance_math.h"
 
 #define BWD_BATCH MGR_CHUNK
 #define BWD_SW (BWD_BATCH / 64)
@@ -224,73 +224,14 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
     float acc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float dm[3] = {0.f, 0.f, 0.f}, dc6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (cnt > 0) {
-        const uint32_t off = pair_off[vi];
-        for (uint32_t k = 0; k < cnt; ++k) {
-            const uint32_t slot = off + k;
-            if (slot < cap && pair_tag[slot] == epoch) {
-                const float4* r = pair_grad + (size_t)slot * 3;
-                const float4 a = r[0], b = r[1], c = r[2];
-                acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
-                acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w;
-                acc[8] += c.x;
-            }
-        }
+        gather_pair_grads(pair_off[vi], cnt, pair_tag, pair_grad, cap, epoch, acc);
         MgrCam cam;
         mgr_load_cam(cams, v, cam);
         const float* mp = means3D + (size_t)v * s_means + (size_t)i * 3;
         const float p[3] = {mp[0], mp[1], mp[2]};
         const float* cp = cov3D + (size_t)v * s_cov + (size_t)i * 6;
         const float c6[6] = {cp[0], cp[1], cp[2], cp[3], cp[4], cp[5]};
-        const float* vm = cam.view;
-        float M0[3], M1[3], t[3], xm, ym, fx, fy, S0[3], S1[3];
-        mgr_ewa_rows(cam, (float)W, (float)H, p, M0, M1, t, xm, ym, fx, fy);
-        mgr_sym_mul(c6, M0, S0);
-        mgr_sym_mul(c6, M1, S1);
-        const float a = M0[0] * S0[0] + M0[1] * S0[1] + M0[2] * S0[2] + 0.3f;
-        const float b = M0[0] * S1[0] + M0[1] * S1[1] + M0[2] * S1[2];
-        const float c = M1[0] * S1[0] + M1[1] * S1[1] + M1[2] * S1[2] + 0.3f;
-        const float dA = acc[2], dB = acc[3], dC = acc[4];
-        const float den = a * c - b * b;
-        const float k2 = 1.0f / (den * den + 0.0000001f);
-        float da = 0.f, db = 0.f, dc = 0.f;
-        if (k2 != 0.0f) {
-            da = k2 * (-c * c * dA + 2.0f * b * c * dB + (den - a * c) * dC);
-            dc = k2 * (-a * a * dC + 2.0f * a * b * dB + (den - a * c) * dA);
-            db = k2 * 2.0f * (b * c * dA - (den + 2.0f * b * b) * dB + a * b * dC);
-            dc6[0] = M0[0] * M0[0] * da + M0[0] * M1[0] * db + M1[0] * M1[0] * dc;
-            dc6[3] = M0[1] * M0[1] * da + M0[1] * M1[1] * db + M1[1] * M1[1] * dc;
-            dc6[5] = M0[2] * M0[2] * da + M0[2] * M1[2] * db + M1[2] * M1[2] * dc;
-            dc6[1] = 2.0f * M0[0] * M0[1] * da + (M0[0] * M1[1] + M0[1] * M1[0]) * db + 2.0f * M1[0] * M1[1] * dc;
-            dc6[2] = 2.0f * M0[0] * M0[2] * da + (M0[0] * M1[2] + M0[2] * M1[0]) * db + 2.0f * M1[0] * M1[2] * dc;
-            dc6[4] = 2.0f * M0[2] * M0[1] * da + (M0[1] * M1[2] + M0[2] * M1[1]) * db + 2.0f * M1[1] * M1[2] * dc;
-        }
-        float dM0[3], dM1[3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            dM0[j] = 2.0f * S0[j] * da + S1[j] * db;
-            dM1[j] = 2.0f * S1[j] * dc + S0[j] * db;
-        }
-        const float dJ00 = vm[0] * dM0[0] + vm[4] * dM0[1] + vm[8] * dM0[2];
-        const float dJ02 = vm[2] * dM0[0] + vm[6] * dM0[1] + vm[10] * dM0[2];
-        const float dJ11 = vm[1] * dM1[0] + vm[5] * dM1[1] + vm[9] * dM1[2];
-        const float dJ12 = vm[2] * dM1[0] + vm[6] * dM1[1] + vm[10] * dM1[2];
-        const float tz = 1.0f / t[2], tz2 = tz * tz, tz3 = tz2 * tz;
-        const float dtx = xm * -fx * tz2 * dJ02;
-        const float dty = ym * -fy * tz2 * dJ12;
-        const float dtz = -fx * tz2 * dJ00 - fy * tz2 * dJ11 + (2.0f * fx * t[0]) * tz3 * dJ02 +
-                          (2.0f * fy * t[1]) * tz3 * dJ12;
-        dm[0] = vm[0] * dtx + vm[1] * dty + vm[2] * dtz;
-        dm[1] = vm[4] * dtx + vm[5] * dty + vm[6] * dtz;
-        dm[2] = vm[8] * dtx + vm[9] * dty + vm[10] * dtz;
-        const float* pm = cam.proj;
-        const float hw = pm[3] * p[0] + pm[7] * p[1] + pm[11] * p[2] + pm[15];
-        const float mw = 1.0f / (hw + 0.0000001f);
-        const float mul1 = (pm[0] * p[0] + pm[4] * p[1] + pm[8] * p[2] + pm[12]) * mw * mw;
-        const float mul2 = (pm[1] * p[0] + pm[5] * p[1] + pm[9] * p[2] + pm[13]) * mw * mw;
-        const float gx2 = acc[0], gy2 = acc[1];
-        dm[0] += (pm[0] * mw - pm[3] * mul1) * gx2 + (pm[1] * mw - pm[3] * mul2) * gy2;
-        dm[1] += (pm[4] * mw - pm[7] * mul1) * gx2 + (pm[5] * mw - pm[7] * mul2) * gy2;
-        dm[2] += (pm[8] * mw - pm[11] * mul1) * gx2 + (pm[9] * mw - pm[11] * mul2) * gy2;
+        project_backward(cam, W, H, p, c6, acc, dm, dc6);
     }
     float* o3 = dL_dmeans3D + vi * 3;
     o3[0] = dm[0]; o3[1] = dm[1]; o3[2] = dm[2];

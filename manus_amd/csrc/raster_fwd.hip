@@ -13,7 +13,7 @@
 //  * per-(view,Gaussian) data the blend kernels gather is one 48-byte record;
 //  * no host synchronisation: the pair count stays on the device, capacity
 //    overflow raises a flag in the workspace header.
-#include "mgr_common.h"
+#include "instance_math.h"
 
 #include <map>
 #include <string>
@@ -146,53 +146,18 @@ __global__ __launch_bounds__(PRE_THREADS) void k_preprocess(
     MgrCam cam;
     mgr_load_cam(cams, v, cam);
 
-    int radius = 0, x0 = 0, y0 = 0, x1 = 0, y1 = 0;
-    float px = 0.f, py = 0.f, ca = 0.f, cb = 0.f, cc = 0.f, zv = 0.f;
+    ProjOut po;
+    po.radius = 0; po.x0 = po.y0 = po.x1 = po.y1 = 0;
+    po.px = po.py = po.ca = po.cb = po.cc = po.zv = 0.f;
     if (i < N) {
         const float* mp = means3D + (size_t)v * s_means + (size_t)i * 3;
         const float p[3] = {mp[0], mp[1], mp[2]};
-        const float* vm = cam.view;
-        const float* pm = cam.proj;
-        zv = vm[2] * p[0] + vm[6] * p[1] + vm[10] * p[2] + vm[14];
-        if (zv > 0.2f) {
-            const float hx = pm[0] * p[0] + pm[4] * p[1] + pm[8] * p[2] + pm[12];
-            const float hy = pm[1] * p[0] + pm[5] * p[1] + pm[9] * p[2] + pm[13];
-            const float hw = pm[3] * p[0] + pm[7] * p[1] + pm[11] * p[2] + pm[15];
-            const float pw = 1.0f / (hw + 0.0000001f);
-            const float ndx = hx * pw, ndy = hy * pw;
-            const float* cp = cov3D + (size_t)v * s_cov + (size_t)i * 6;
-            const float c6[6] = {cp[0], cp[1], cp[2], cp[3], cp[4], cp[5]};
-            float M0[3], M1[3], t[3], xm, ym, fx, fy, S0[3], S1[3];
-            mgr_ewa_rows(cam, (float)W, (float)H, p, M0, M1, t, xm, ym, fx, fy);
-            mgr_sym_mul(c6, M0, S0);
-            mgr_sym_mul(c6, M1, S1);
-            const float a = M0[0] * S0[0] + M0[1] * S0[1] + M0[2] * S0[2] + 0.3f;
-            const float b = M0[0] * S1[0] + M0[1] * S1[1] + M0[2] * S1[2];
-            const float c = M1[0] * S1[0] + M1[1] * S1[1] + M1[2] * S1[2] + 0.3f;
-            const float det = a * c - b * b;
-            if (det != 0.0f) {
-                const float dinv = 1.0f / det;
-                const float mid = 0.5f * (a + c);
-                const float sq = sqrtf(fmaxf(0.1f, mid * mid - det));
-                const int rad = (int)ceilf(3.0f * sqrtf(fmaxf(mid + sq, mid - sq)));
-                px = ((ndx + 1.0f) * (float)W - 1.0f) * 0.5f;
-                py = ((ndy + 1.0f) * (float)H - 1.0f) * 0.5f;
-                const float fr = (float)rad;
-                x0 = min(gx, max(0, (int)((px - fr) / 16.0f)));
-                y0 = min(gy, max(0, (int)((py - fr) / 16.0f)));
-                x1 = min(gx, max(0, (int)((px + fr + 15.0f) / 16.0f)));
-                y1 = min(gy, max(0, (int)((py + fr + 15.0f) / 16.0f)));
-                if ((x1 - x0) * (y1 - y0) > 0) {
-                    radius = rad;
-                    ca = c * dinv;
-                    cb = -b * dinv;
-                    cc = a * dinv;
-                } else {
-                    x0 = y0 = x1 = y1 = 0;
-                }
-            }
-        }
+        const float* cp = cov3D + (size_t)v * s_cov + (size_t)i * 6;
+        const float c6[6] = {cp[0], cp[1], cp[2], cp[3], cp[4], cp[5]};
+        project_gaussian(cam, W, H, gx, gy, p, c6, po);
     }
+    const int radius = po.radius, x0 = po.x0, y0 = po.y0, x1 = po.x1, y1 = po.y1;
+    const float px = po.px, py = po.py, ca = po.ca, cb = po.cb, cc = po.cc, zv = po.zv;
     const uint32_t tiles = (uint32_t)((x1 - x0) * (y1 - y0));
     const float op_i = (i < N) ? opacity[(size_t)v * s_op + i] : 0.0f;
 
