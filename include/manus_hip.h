@@ -109,6 +109,36 @@ int mgr_raster_backward(int V, int N, int W, int H, const float* cams, const flo
                         float* dL_dopacity, float* dL_dcov3D, void* workspace,
                         size_t workspace_bytes, int64_t pair_capacity, int debug, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Fused articulated path (training engine): canonical parameters in, image out.
+ * One launch chain per V views = mgr_lbs_cov_fwd + mgr_sh_color_fwd + sigmoid +
+ * mgr_raster_forward, without writing posed means / covariances / transforms /
+ * colours to HBM; the backward returns the leaf gradients of the six MANUS
+ * parameter tensors (src/models/gaussian.py:34-39) summed over the views, the
+ * skin-weight gradient (feed it to mgr_skin_weights_bwd), and the densification
+ * statistics of src/models/gaussian.py:335-338 / src/utils/gaussian_utils.py:469-471.
+ *   xyz (N,3), log_scale (N,3) = _scaling, rot (N,4) = _rotation (raw),
+ *   opacity_logit (N) = _opacity, f_dc (N,1,3) = _features_dc, f_rest (N,15,3) = _features_rest,
+ *   skin_w (N,B) or NULL (static object), transforms (V,B,16): one pose per view.
+ * stat_grad2d (N): sum over views of ||dL/dmeans2D[:, :2]|| * grad2d_scale,
+ * stat_vis (N): number of views with radius > 0, stat_radii (N): max radius (any may be NULL).
+ * ------------------------------------------------------------------------ */
+int mgr_views_forward(int V, int N, int B, int W, int H, const float* cams, const float* bg,
+                      const float* xyz, const float* log_scale, const float* rot,
+                      const float* opacity_logit, const float* f_dc, const float* f_rest,
+                      const float* skin_w, const float* transforms, float* out_color, int32_t* radii,
+                      void* workspace, size_t workspace_bytes, int64_t pair_capacity, int debug,
+                      void* stream);
+int mgr_views_backward(int V, int N, int B, int W, int H, const float* cams, const float* bg,
+                       const float* xyz, const float* log_scale, const float* rot,
+                       const float* opacity_logit, const float* f_dc, const float* f_rest,
+                       const float* skin_w, const float* transforms, const int32_t* radii,
+                       const float* out_color, const float* dL_dcolor, float grad2d_scale, float* d_xyz,
+                       float* d_log_scale, float* d_rot, float* d_opacity_logit, float* d_f_dc,
+                       float* d_f_rest, float* d_skin_w, float* stat_grad2d, float* stat_vis,
+                       int32_t* stat_radii, void* workspace, size_t workspace_bytes,
+                       int64_t pair_capacity, int debug, void* stream);
+
 /* Debug/test: byte offsets of the workspace regions, in the order header, grec, depth, rect,
  * alive, pair_off, tile_count, tile_start, tile_cursor, tile_done, tile_queue, chunk_start, items,
  * ckpt, keys, sorted_gid, final_T, n_contrib, pair_tag, pair_grad, total.  Returns the count. */

@@ -78,8 +78,9 @@ __device__ __forceinline__ void lbs_apply(const float tf[12], const GaussCano& g
 
 // One pose/view of the LBS backward: accumulates into dxyz, ds (d/ds, not d/dlog s), dR and
 // returns dtf (3x4) = gradient w.r.t. the blended transform (incl. the optional extra g_tf).
+template <bool HAS_GTF>
 __device__ __forceinline__ void lbs_backward_view(const float tf[12], const GaussCano& g, const float gp[3],
-                                                  const float g6[6], const float* g_tf, float dxyz[3],
+                                                  const float g6[6], const float g_tf[12], float dxyz[3],
                                                   float ds[3], float dR[9], float dtf[12]) {
     const float Gs[9] = {2.f * g6[0], g6[1], g6[2], g6[1], 2.f * g6[3], g6[4], g6[2], g6[4], 2.f * g6[5]};
     float L[9], AL[9], dM[9];
@@ -116,7 +117,7 @@ __device__ __forceinline__ void lbs_backward_view(const float tf[12], const Gaus
     dxyz[0] += tf[0] * gp[0] + tf[4] * gp[1] + tf[8] * gp[2];
     dxyz[1] += tf[1] * gp[0] + tf[5] * gp[1] + tf[9] * gp[2];
     dxyz[2] += tf[2] * gp[0] + tf[6] * gp[1] + tf[10] * gp[2];
-    if (g_tf) {
+    if (HAS_GTF) {
 #pragma unroll
         for (int k = 0; k < 12; ++k) dtf[k] += g_tf[k];
     }
@@ -164,9 +165,10 @@ struct ShDir {
     float Ainv[9];         // inverse of tf[:3,:3] (when tf)
 };
 
-// t12: the blended transform (rows 0..2) or nullptr (dir = xyz - cam)
-__device__ __forceinline__ void sh_dir_xyz(float x, float y, float z, const float* t, const float cam[3], ShDir& o) {
-    if (t) {
+// HAS_TF: t = the blended transform (rows 0..2); otherwise dir = xyz - cam and t is ignored
+template <bool HAS_TF>
+__device__ __forceinline__ void sh_dir_xyz(float x, float y, float z, const float t[12], const float cam[3], ShDir& o) {
+    if (HAS_TF) {
         const float a = t[0], b = t[1], c = t[2], d = t[4], e = t[5], f = t[6], g = t[8], h = t[9], k = t[10];
         const float c00 = e * k - f * h, c01 = f * g - d * k, c02 = d * h - e * g;
         const float det = a * c00 + b * c01 + c * c02;
@@ -198,14 +200,27 @@ __device__ __forceinline__ void sh_rgb(const float c[48], const float Y[16], flo
 
 // Backward of one view: gc = dL/dcolour (after clamp).  Accumulates dsh (48); returns the
 // gradient w.r.t. the xyz that formed the direction (gd) and, when has_tf, w.r.t. the 3x4
-// transform (dtf, written).
-__device__ __forceinline__ void sh_backward_view(const float c[48], const ShDir& D, bool has_tf, const float gc[3],
+// transform (dtf, written).  The coefficient source C is indexable (register array or a
+// small loader that reads from memory, which keeps 48 registers free in the fused kernel).
+struct ShCoefMem {  // (16,3) coefficients split as f_dc (3) + f_rest (45), read on demand
+    const float* dc;
+    const float* rest;
+    __device__ __forceinline__ float operator[](int k) const { return k < 3 ? dc[k] : rest[k - 3]; }
+};
+
+template <typename C>
+__device__ __forceinline__ void sh_backward_view(const C& c, const ShDir& D, bool has_tf, const float gc[3],
                                                  float dsh[48], float gd[3], float dtf[12]) {
     const float inv_n = 1.0f / D.n;
     const float x = D.d[0] * inv_n, y = D.d[1] * inv_n, z = D.d[2] * inv_n;
-    float Y[16], rgb[3];
+    float Y[16], rgb[3] = {0.f, 0.f, 0.f};
     sh_basis(x, y, z, Y);
-    sh_rgb(c, Y, rgb);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        rgb[0] += Y[k] * c[3 * k];
+        rgb[1] += Y[k] * c[3 * k + 1];
+        rgb[2] += Y[k] * c[3 * k + 2];
+    }
     float dr[3];
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) dr[ch] = (rgb[ch] + 0.5f >= 0.f) ? gc[ch] : 0.f;

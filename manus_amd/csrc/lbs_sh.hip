@@ -278,11 +278,9 @@ __global__ __launch_bounds__(256) void k_lbs_bwd(int P, int N, int B, const floa
         const float g6[6] = {g_cov[pi * 6], g_cov[pi * 6 + 1], g_cov[pi * 6 + 2],
                              g_cov[pi * 6 + 3], g_cov[pi * 6 + 4], g_cov[pi * 6 + 5]};
         float gt[12];
-        if (g_tf) {
 #pragma unroll
-            for (int k = 0; k < 12; ++k) gt[k] = g_tf[pi * 12 + k];
-        }
-        lbs_backward_view(tf, g, gp, g6, g_tf ? gt : nullptr, dxyz, ds, dR, dtf);
+        for (int k = 0; k < 12; ++k) gt[k] = g_tf ? g_tf[pi * 12 + k] : 0.f;
+        lbs_backward_view<true>(tf, g, gp, g6, gt, dxyz, ds, dR, dtf);
         if (skin_w) {
 #pragma unroll
             for (int b = 0; b < MGR_MAX_BONES; ++b) {
@@ -323,7 +321,14 @@ __global__ __launch_bounds__(256) void k_sh_fwd(int N, const float* __restrict__
     const float cam[3] = {cp[0], cp[1], cp[2]};
     const float* xv = xyz + (size_t)v * s_xyz;
     ShDir D;
-    sh_dir_xyz(xv[3 * i], xv[3 * i + 1], xv[3 * i + 2], tf ? tf + (size_t)v * s_tf + (size_t)i * 12 : nullptr, cam, D);
+    float t12[12];
+    if (tf) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) t12[k] = tf[(size_t)v * s_tf + (size_t)i * 12 + k];
+        sh_dir_xyz<true>(xv[3 * i], xv[3 * i + 1], xv[3 * i + 2], t12, cam, D);
+    } else {
+        sh_dir_xyz<false>(xv[3 * i], xv[3 * i + 1], xv[3 * i + 2], t12, cam, D);
+    }
     float Y[16], c[48], rgb[3];
     sh_basis(D.d[0] / D.n, D.d[1] / D.n, D.d[2] / D.n, Y);
 #pragma unroll
@@ -335,7 +340,7 @@ __global__ __launch_bounds__(256) void k_sh_fwd(int N, const float* __restrict__
     o[2] = fmaxf(rgb[2] + 0.5f, 0.f);
 }
 
-__global__ __launch_bounds__(256) void k_sh_bwd(int V, int N, const float* __restrict__ sh,
+__global__ __launch_bounds__(256, 2) void k_sh_bwd(int V, int N, const float* __restrict__ sh,
                                                 const float* __restrict__ xyz, int64_t s_xyz,
                                                 const float* __restrict__ tf, int64_t s_tf,
                                                 const float* __restrict__ cams,
@@ -357,7 +362,14 @@ __global__ __launch_bounds__(256) void k_sh_bwd(int V, int N, const float* __res
         const float* xv = xyz + (size_t)v * s_xyz;
         const bool has_tf = tf != nullptr;
         ShDir D;
-        sh_dir_xyz(xv[3 * i], xv[3 * i + 1], xv[3 * i + 2], has_tf ? tf + (size_t)v * s_tf + (size_t)i * 12 : nullptr, cam, D);
+        float t12[12];
+        if (has_tf) {
+#pragma unroll
+            for (int k = 0; k < 12; ++k) t12[k] = tf[(size_t)v * s_tf + (size_t)i * 12 + k];
+            sh_dir_xyz<true>(xv[3 * i], xv[3 * i + 1], xv[3 * i + 2], t12, cam, D);
+        } else {
+            sh_dir_xyz<false>(xv[3 * i], xv[3 * i + 1], xv[3 * i + 2], t12, cam, D);
+        }
         const float* gcp = g_col + ((size_t)v * N + i) * 3;
         const float gc[3] = {gcp[0], gcp[1], gcp[2]};
         float gd[3], dtf[12];

@@ -245,12 +245,196 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
     for (int j = 0; j < 6; ++j) ov[j] = dc6[j];
 }
 
-extern "C" int mgr_raster_backward(int V, int N, int W, int H, const float* cams, const float* bg,
+// ---------------------------------------------------------------------------
+// Fused backward of the articulated path, two kernels.  Together: for every view, gather the
+// Gaussian's pair records, run the projection backward, the SH-colour backward and the LBS
+// backward, and sum over the views in a fixed order.  Writes the leaf gradients once:
+// d xyz (direct + view-direction paths; the skin-weight path is returned as d w),
+// d log-scale, d raw quaternion, d opacity logit, d f_dc, d f_rest, d w, and the densification
+// statistics of the reference (src/models/gaussian.py:335-338, gaussian_utils.py:469-471):
+// sum_v ||d L_v / d means2D[:, :2]||, visibility count, max radius.
+// Same math as k_preprocess_bwd + k_sh_bwd + k_lbs_bwd (instance_math.h).
+// ---------------------------------------------------------------------------
+// Phase A, one thread per (view, Gaussian): gather the pair records and run the projection
+// backward on the re-derived posed mean / covariance.  Output record (16 floats):
+// [0..2] dL/dposed_mean, [3..8] dL/dposed_cov, [9..11] dL/dcolour, [12] dL/dopacity,
+// [13] ||dL/dmeans2D.xy||, [14] 1 if the instance received any gradient.
+__global__ __launch_bounds__(256) void k_inst_bwd_a(
+    int N, int B, int W, int H, const float* __restrict__ cams, const float* __restrict__ xyz,
+    const float* __restrict__ log_scale, const float* __restrict__ rot, const float* __restrict__ skin_w,
+    const float* __restrict__ transforms, const int32_t* __restrict__ radii, const ushort4* __restrict__ rect,
+    const uint32_t* __restrict__ pair_off, const uint32_t* __restrict__ pair_tag,
+    const float4* __restrict__ pair_grad, float4* __restrict__ inst_grad, uint32_t cap, uint32_t epoch) {
+    const int v = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const size_t vi = (size_t)v * N + i;
+    float4* o = inst_grad + vi * 8;
+    float acc[9];
+    bool any = false;
+    if (radii[vi] > 0) {
+        const ushort4 rc = rect[vi];
+        gather_pair_grads(pair_off[vi], (uint32_t)((rc.z - rc.x) * (rc.w - rc.y)), pair_tag, pair_grad, cap, epoch, acc);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) any = any || (acc[k] != 0.f);
+    }
+    if (!any) {  // culled, or hidden behind saturated pixels everywhere
+        o[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    MgrCam cam;
+    mgr_load_cam(cams, v, cam);
+    GaussCano g;
+    cano_load(xyz, log_scale, rot, i, g);
+    float tf[12], p[3], c6[6], dm[3], dc6[6];
+    blend_tf(skin_w ? skin_w + (size_t)i * B : nullptr, skin_w ? transforms + (size_t)v * B * 16 : nullptr, B, tf);
+    lbs_apply(tf, g, p, c6);
+    project_backward(cam, W, H, p, c6, acc, dm, dc6);
+    o[0] = make_float4(dm[0], dm[1], dm[2], dc6[0]);
+    o[1] = make_float4(dc6[1], dc6[2], dc6[3], dc6[4]);
+    o[2] = make_float4(dc6[5], acc[6], acc[7], acc[8]);
+    o[3] = make_float4(acc[5], sqrtf(acc[0] * acc[0] + acc[1] * acc[1]), 1.0f, 0.f);
+}
+
+// Phase B, one thread per Gaussian, loop over views: SH-colour backward.  Accumulates the SH
+// coefficient gradient in registers (written once) and leaves, per view, the gradient w.r.t.
+// the canonical position through the view direction (gd) and w.r.t. the blended transform.
+__global__ __launch_bounds__(256, 2) void k_inst_bwd_b(
+    int V, int N, int B, const float* __restrict__ cams, const float* __restrict__ xyz,
+    const float* __restrict__ f_dc, const float* __restrict__ f_rest, const float* __restrict__ skin_w,
+    const float* __restrict__ transforms, float4* __restrict__ inst_grad, float* __restrict__ d_fdc,
+    float* __restrict__ d_frest) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    // coefficients are re-read from memory (L1) inside the view loop: holding them would cost 48
+    // more registers next to the 48 accumulators
+    const ShCoefMem c = {f_dc + (size_t)i * 3, f_rest + (size_t)i * 45};
+    float dsh[48];
+#pragma unroll
+    for (int k = 0; k < 48; ++k) dsh[k] = 0.f;
+    const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+    const bool has_tf = skin_w != nullptr;
+#pragma unroll 1
+    for (int v = 0; v < V; ++v) {
+        float4* rec = inst_grad + ((size_t)v * N + i) * 8;
+        if (rec[3].z == 0.f) continue;
+        const float4 r2 = rec[2];
+        const float gc[3] = {r2.y, r2.z, r2.w};
+        const float* cp = cams + (size_t)v * MGR_CAM_FLOATS + 34;
+        const float campos[3] = {cp[0], cp[1], cp[2]};
+        float tf[12];
+        blend_tf(has_tf ? skin_w + (size_t)i * B : nullptr, has_tf ? transforms + (size_t)v * B * 16 : nullptr, B, tf);
+        ShDir D;
+        if (has_tf) sh_dir_xyz<true>(x, y, z, tf, campos, D);
+        else sh_dir_xyz<false>(x, y, z, tf, campos, D);
+        float gd[3], dtf[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) dtf[k] = 0.f;
+        sh_backward_view(c, D, has_tf, gc, dsh, gd, dtf);
+        rec[4] = make_float4(gd[0], gd[1], gd[2], 0.f);
+        rec[5] = make_float4(dtf[0], dtf[1], dtf[2], dtf[3]);
+        rec[6] = make_float4(dtf[4], dtf[5], dtf[6], dtf[7]);
+        rec[7] = make_float4(dtf[8], dtf[9], dtf[10], dtf[11]);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) d_fdc[(size_t)i * 3 + k] = dsh[k];
+#pragma unroll
+    for (int k = 0; k < 45; ++k) d_frest[(size_t)i * 45 + k] = dsh[3 + k];
+}
+
+// Phase C, one thread per Gaussian, loop over views: LBS backward (posed mean / covariance /
+// transform gradients -> canonical position, log-scale, quaternion, skin weights), opacity logit
+// and the densification statistics; sums over the views in a fixed order, writes once.
+template <int BMAX>
+__global__ __launch_bounds__(256) void k_inst_bwd_c(
+    int V, int N, int B, const float* __restrict__ xyz, const float* __restrict__ log_scale,
+    const float* __restrict__ rot, const float* __restrict__ op_logit, const float* __restrict__ skin_w,
+    const float* __restrict__ transforms, const int32_t* __restrict__ radii,
+    const float4* __restrict__ inst_grad, float grad2d_scale, float* __restrict__ d_xyz, float* __restrict__ d_ls,
+    float* __restrict__ d_rot, float* __restrict__ d_op, float* __restrict__ d_w, float* __restrict__ st_grad2d,
+    float* __restrict__ st_vis, int32_t* __restrict__ st_radii) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    GaussCano g;
+    cano_load(xyz, log_scale, rot, i, g);
+    float dxyz[3] = {0.f, 0.f, 0.f}, ds[3] = {0.f, 0.f, 0.f};
+    float dR[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float dw[BMAX];
+#pragma unroll
+    for (int b = 0; b < BMAX; ++b) dw[b] = 0.f;
+    float dop = 0.f, g2 = 0.f, vis = 0.f;
+    int maxrad = 0;
+    const bool has_tf = skin_w != nullptr;
+    for (int v = 0; v < V; ++v) {
+        const size_t vi = (size_t)v * N + i;
+        const int rad = radii[vi];
+        if (rad <= 0) continue;
+        vis += 1.0f;
+        maxrad = max(maxrad, rad);
+        const float4* rec = inst_grad + vi * 8;
+        const float4 r3 = rec[3];
+        if (r3.z == 0.f) continue;
+        const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r4 = rec[4];
+        const float dm[3] = {r0.x, r0.y, r0.z};
+        const float dc6[6] = {r0.w, r1.x, r1.y, r1.z, r1.w, r2.x};
+        dop += r3.x;
+        g2 += r3.y * grad2d_scale;
+        dxyz[0] += r4.x; dxyz[1] += r4.y; dxyz[2] += r4.z;
+        const float* Tp = has_tf ? transforms + (size_t)v * B * 16 : nullptr;
+        float tf[12], dtf[12], gt[12];
+        blend_tf(has_tf ? skin_w + (size_t)i * B : nullptr, Tp, B, tf);
+        {   // zero for the static-object path (phase B leaves these slots untouched there)
+            const float4 a = rec[5], b = rec[6], c = rec[7];
+            gt[0] = has_tf ? a.x : 0.f; gt[1] = has_tf ? a.y : 0.f; gt[2] = has_tf ? a.z : 0.f; gt[3] = has_tf ? a.w : 0.f;
+            gt[4] = has_tf ? b.x : 0.f; gt[5] = has_tf ? b.y : 0.f; gt[6] = has_tf ? b.z : 0.f; gt[7] = has_tf ? b.w : 0.f;
+            gt[8] = has_tf ? c.x : 0.f; gt[9] = has_tf ? c.y : 0.f; gt[10] = has_tf ? c.z : 0.f; gt[11] = has_tf ? c.w : 0.f;
+        }
+        lbs_backward_view<true>(tf, g, dm, dc6, gt, dxyz, ds, dR, dtf);
+        if (has_tf) {
+#pragma unroll
+            for (int b = 0; b < BMAX; ++b) {
+                if (b < B) {
+                    const float* T = Tp + (size_t)b * 16;
+                    float a = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 12; ++k) a += dtf[k] * T[k];
+                    dw[b] += a;
+                }
+            }
+        }
+    }
+    d_xyz[3 * i] = dxyz[0]; d_xyz[3 * i + 1] = dxyz[1]; d_xyz[3 * i + 2] = dxyz[2];
+    d_ls[3 * i] = ds[0] * g.s[0]; d_ls[3 * i + 1] = ds[1] * g.s[1]; d_ls[3 * i + 2] = ds[2] * g.s[2];
+    float drot[4];
+    quat_backward(g, dR, drot);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) d_rot[4 * i + k] = drot[k];
+    const float sg = 1.0f / (1.0f + expf(-op_logit[i]));
+    d_op[i] = dop * sg * (1.0f - sg);
+    if (has_tf && d_w) {
+#pragma unroll
+        for (int b = 0; b < BMAX; ++b)
+            if (b < B) d_w[(size_t)i * B + b] = dw[b];
+    }
+    if (st_grad2d) st_grad2d[i] = g2;
+    if (st_vis) st_vis[i] = vis;
+    if (st_radii) st_radii[i] = maxrad;
+}
+
+struct CanonGrads {  // fused articulated backward: canonical inputs and leaf-gradient outputs
+    int B;
+    const float *xyz, *log_scale, *rot, *op_logit, *f_dc, *f_rest, *skin_w, *transforms;
+    const int32_t* radii;
+    float grad2d_scale;
+    float *d_xyz, *d_ls, *d_rot, *d_op, *d_fdc, *d_frest, *d_w, *st_grad2d, *st_vis;
+    int32_t* st_radii;
+};
+
+static int raster_backward_impl(int V, int N, int W, int H, const float* cams, const float* bg,
                                    const float* means3D, int64_t s_means, const float* cov3D,
                                    int64_t s_cov, const float* colors, int64_t s_col,
                                    const float* opacity, int64_t s_op, const float* out_color,
                                    const float* dL_dcolor, float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dcolors,
-                                   float* dL_dopacity, float* dL_dcov3D, void* workspace,
+                                   float* dL_dopacity, float* dL_dcov3D, const CanonGrads* canon, void* workspace,
                                    size_t workspace_bytes, int64_t cap, int debug, void* stream_) {
     (void)colors; (void)s_col; (void)opacity; (void)s_op;  // captured in the workspace records
     hipStream_t stream = (hipStream_t)stream_;
@@ -259,7 +443,7 @@ extern "C" int mgr_raster_backward(int V, int N, int W, int H, const float* cams
     if (!cams || !bg || !dL_dcolor || !out_color || !workspace)
         return mgr_fail(MGR_EINVAL, "mgr_raster_backward: null pointer");
     if (N == 0) return MGR_OK;
-    if (!means3D || !cov3D || !dL_dmeans3D || !dL_dmeans2D || !dL_dcolors || !dL_dopacity || !dL_dcov3D)
+    if (!canon && (!means3D || !cov3D || !dL_dmeans3D || !dL_dmeans2D || !dL_dcolors || !dL_dopacity || !dL_dcov3D))
         return mgr_fail(MGR_EINVAL, "mgr_raster_backward: null pointer");
     const int gx = (W + 15) / 16, gy = (H + 15) / 16;
     const MgrLayout L = mgr_layout(V, N, W, H, cap);
@@ -283,6 +467,31 @@ extern "C" int mgr_raster_backward(int V, int N, int W, int H, const float* cams
                        dL_dcolor, (uint32_t*)(ws + L.pair_tag), (float4*)(ws + L.pair_grad),
                        (uint32_t)cap, epoch); }
     MGR_LAUNCH_CHECK("k_blend_bwd", stream, debug);
+    if (canon) {
+        float4* ig = (float4*)(ws + L.inst_grad);
+        { MGR_PROF("k_inst_bwd_a", stream);
+          hipLaunchKernelGGL(k_inst_bwd_a, dim3((N + 255) / 256, V), dim3(256), 0, stream, N, canon->B, W, H, cams,
+                             canon->xyz, canon->log_scale, canon->rot, canon->skin_w, canon->transforms, canon->radii,
+                             (const ushort4*)(ws + L.rect), (const uint32_t*)(ws + L.pair_off),
+                             (const uint32_t*)(ws + L.pair_tag), (const float4*)(ws + L.pair_grad), ig,
+                             (uint32_t)cap, epoch); }
+        { MGR_PROF("k_inst_bwd_b", stream);
+          hipLaunchKernelGGL(k_inst_bwd_b, dim3((N + 255) / 256), dim3(256), 0, stream, V, N, canon->B, cams, canon->xyz,
+                             canon->f_dc, canon->f_rest, canon->skin_w, canon->transforms, ig, canon->d_fdc,
+                             canon->d_frest); }
+        MGR_PROF("k_inst_bwd_c", stream);
+        if (canon->B <= 24)
+            hipLaunchKernelGGL(k_inst_bwd_c<24>, dim3((N + 255) / 256), dim3(256), 0, stream, V, N, canon->B, canon->xyz,
+                               canon->log_scale, canon->rot, canon->op_logit, canon->skin_w, canon->transforms,
+                               canon->radii, (const float4*)ig, canon->grad2d_scale, canon->d_xyz, canon->d_ls,
+                               canon->d_rot, canon->d_op, canon->d_w, canon->st_grad2d, canon->st_vis, canon->st_radii);
+        else
+            hipLaunchKernelGGL(k_inst_bwd_c<MGR_MAX_BONES>, dim3((N + 255) / 256), dim3(256), 0, stream, V, N, canon->B,
+                               canon->xyz, canon->log_scale, canon->rot, canon->op_logit, canon->skin_w,
+                               canon->transforms, canon->radii, (const float4*)ig, canon->grad2d_scale, canon->d_xyz,
+                               canon->d_ls, canon->d_rot, canon->d_op, canon->d_w, canon->st_grad2d, canon->st_vis,
+                               canon->st_radii);
+    } else
     { MGR_PROF("k_preprocess_bwd", stream); hipLaunchKernelGGL(k_preprocess_bwd, dim3((N + 255) / 256, V), dim3(256), 0, stream, N, W, H, cams,
                        means3D, s_means, cov3D, s_cov, (const int32_t*)nullptr,
                        (const ushort4*)(ws + L.rect), (const uint32_t*)(ws + L.pair_off),
@@ -290,4 +499,38 @@ extern "C" int mgr_raster_backward(int V, int N, int W, int H, const float* cams
                        dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dcov3D, (uint32_t)cap, epoch); }
     MGR_LAUNCH_CHECK("k_preprocess_bwd", stream, debug);
     return MGR_OK;
+}
+
+extern "C" int mgr_raster_backward(int V, int N, int W, int H, const float* cams, const float* bg,
+                                   const float* means3D, int64_t s_means, const float* cov3D,
+                                   int64_t s_cov, const float* colors, int64_t s_col,
+                                   const float* opacity, int64_t s_op, const float* out_color,
+                                   const float* dL_dcolor, float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dcolors,
+                                   float* dL_dopacity, float* dL_dcov3D, void* workspace,
+                                   size_t workspace_bytes, int64_t cap, int debug, void* stream_) {
+    return raster_backward_impl(V, N, W, H, cams, bg, means3D, s_means, cov3D, s_cov, colors, s_col, opacity, s_op,
+                                out_color, dL_dcolor, dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dcov3D,
+                                nullptr, workspace, workspace_bytes, cap, debug, stream_);
+}
+
+extern "C" int mgr_views_backward(int V, int N, int B, int W, int H, const float* cams, const float* bg,
+                                  const float* xyz, const float* log_scale, const float* rot,
+                                  const float* opacity_logit, const float* f_dc, const float* f_rest,
+                                  const float* skin_w, const float* transforms, const int32_t* radii,
+                                  const float* out_color, const float* dL_dcolor, float grad2d_scale,
+                                  float* d_xyz, float* d_log_scale, float* d_rot, float* d_opacity_logit,
+                                  float* d_f_dc, float* d_f_rest, float* d_skin_w, float* stat_grad2d,
+                                  float* stat_vis, int32_t* stat_radii, void* workspace, size_t workspace_bytes,
+                                  int64_t cap, int debug, void* stream_) {
+    if (N > 0 && (!xyz || !log_scale || !rot || !opacity_logit || !f_dc || !f_rest || !radii || !d_xyz ||
+                  !d_log_scale || !d_rot || !d_opacity_logit || !d_f_dc || !d_f_rest ||
+                  (skin_w && (!transforms || !d_skin_w))))
+        return mgr_fail(MGR_EINVAL, "mgr_views_backward: null pointer");
+    if (skin_w && (B <= 0 || B > MGR_MAX_BONES)) return mgr_fail(MGR_EINVAL, "mgr_views_backward: bad B");
+    const CanonGrads cg = {B, xyz, log_scale, rot, opacity_logit, f_dc, f_rest, skin_w, transforms, radii,
+                           grad2d_scale, d_xyz, d_log_scale, d_rot, d_opacity_logit, d_f_dc, d_f_rest, d_skin_w,
+                           stat_grad2d, stat_vis, stat_radii};
+    return raster_backward_impl(V, N, W, H, cams, bg, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, out_color,
+                                dL_dcolor, nullptr, nullptr, nullptr, nullptr, nullptr, &cg, workspace, workspace_bytes,
+                                cap, debug, stream_);
 }

@@ -124,6 +124,67 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t val, uint32_t* s_wa
 // ---------------------------------------------------------------------------
 #define PRE_THREADS 1024
 
+// Shared tail of the per-instance forward kernels: per-tile histogram over the NON-NULL tiles of
+// the rectangle (exact culling, mgr_box_dead; the mask is stored so that k_emit makes the
+// identical decision; rectangles of more than 64 tiles are not culled), pair-slot offsets
+// (contiguous per Gaussian, block base from one atomic), and the per-instance state records.
+__device__ __forceinline__ void pre_tail(int N, int gx, int gy, int v, int i, const ProjOut& po, float op_i,
+                                         const float col[3], uint32_t* s_scan, uint32_t* s_hist, int lds_hist,
+                                         MgrGRec* __restrict__ grec, float* __restrict__ depth,
+                                         ushort4* __restrict__ rect, unsigned long long* __restrict__ alive,
+                                         uint32_t* __restrict__ pair_off, uint32_t* __restrict__ tile_count,
+                                         int32_t* __restrict__ radii, MgrHeader* hdr) {
+    const int tid = threadIdx.x, T = gx * gy;
+    const int radius = po.radius, x0 = po.x0, y0 = po.y0, x1 = po.x1, y1 = po.y1;
+    const uint32_t tiles = (uint32_t)((x1 - x0) * (y1 - y0));
+    unsigned long long amask = ~0ull;
+    if (radius > 0) {
+        const bool small = tiles <= 64;
+        const float qmax = mgr_qmax(op_i);
+        if (small) amask = 0ull;
+        int k = 0;
+        for (int y = y0; y < y1; ++y)
+            for (int x = x0; x < x1; ++x, ++k) {
+                if (small) {
+                    if (mgr_box_dead(po.px, po.py, po.ca, po.cb, po.cc, qmax, 16.0f * x, 16.0f * y, 16.0f * x + 15.0f,
+                                     16.0f * y + 15.0f))
+                        continue;
+                    amask |= 1ull << k;
+                }
+                if (lds_hist) atomicAdd(&s_hist[y * gx + x], 1u);
+                else atomicAdd(&tile_count[(size_t)v * T + y * gx + x], 1u);
+            }
+    }
+    uint32_t block_total;
+    const uint32_t local = block_excl_scan(tiles, s_scan, block_total);
+    if (tid == 0) s_scan[20] = block_total ? atomicAdd(&hdr->total_pairs, block_total) : 0u;
+    __syncthreads();
+    const uint32_t off = s_scan[20] + local;
+    if (i < N) {
+        const size_t vi = (size_t)v * N + i;
+        MgrGRec r;
+        r.x = po.px; r.y = po.py; r.ca = po.ca; r.cb = po.cb; r.cc = po.cc;
+        r.op = op_i;
+        r.r = col[0]; r.g = col[1]; r.b = col[2];
+        r.rect_w = x1 - x0;
+        r.slot_base = (int32_t)off - y0 * (x1 - x0) - x0;
+        r.pad = 0;
+        grec[vi] = r;
+        depth[vi] = po.zv;
+        rect[vi] = make_ushort4((unsigned short)x0, (unsigned short)y0, (unsigned short)x1, (unsigned short)y1);
+        alive[vi] = amask;
+        pair_off[vi] = off;
+        radii[vi] = radius;
+    }
+    if (lds_hist) {
+        __syncthreads();
+        for (int k = tid; k < T; k += PRE_THREADS) {
+            const uint32_t c = s_hist[k];
+            if (c) atomicAdd(&tile_count[(size_t)v * T + k], c);
+        }
+    }
+}
+
 __global__ __launch_bounds__(PRE_THREADS) void k_preprocess(
     int N, int W, int H, int gx, int gy, const float* __restrict__ cams,
     const float* __restrict__ means3D, int64_t s_means, const float* __restrict__ cov3D,
@@ -156,66 +217,73 @@ __global__ __launch_bounds__(PRE_THREADS) void k_preprocess(
         const float c6[6] = {cp[0], cp[1], cp[2], cp[3], cp[4], cp[5]};
         project_gaussian(cam, W, H, gx, gy, p, c6, po);
     }
-    const int radius = po.radius, x0 = po.x0, y0 = po.y0, x1 = po.x1, y1 = po.y1;
-    const float px = po.px, py = po.py, ca = po.ca, cb = po.cb, cc = po.cc, zv = po.zv;
-    const uint32_t tiles = (uint32_t)((x1 - x0) * (y1 - y0));
     const float op_i = (i < N) ? opacity[(size_t)v * s_op + i] : 0.0f;
-
-    // tile histogram over the NON-NULL tiles of the rectangle (exact culling, see
-    // mgr_box_dead); the mask is stored so that k_emit makes the identical decision.
-    // Rectangles of more than 64 tiles are not culled.
-    unsigned long long amask = ~0ull;
-    if (radius > 0) {
-        const bool small = tiles <= 64;
-        const float qmax = mgr_qmax(op_i);
-        if (small) amask = 0ull;
-        int k = 0;
-        for (int y = y0; y < y1; ++y)
-            for (int x = x0; x < x1; ++x, ++k) {
-                if (small) {
-                    if (mgr_box_dead(px, py, ca, cb, cc, qmax, 16.0f * x, 16.0f * y, 16.0f * x + 15.0f,
-                                     16.0f * y + 15.0f))
-                        continue;
-                    amask |= 1ull << k;
-                }
-                if (lds_hist) atomicAdd(&s_hist[y * gx + x], 1u);
-                else atomicAdd(&tile_count[(size_t)v * T + y * gx + x], 1u);
-            }
-    }
-
-    // pair-slot offsets: contiguous per Gaussian; block base from one atomic
-    uint32_t block_total;
-    const uint32_t local = block_excl_scan(tiles, s_scan, block_total);
-    if (tid == 0) s_scan[20] = block_total ? atomicAdd(&hdr->total_pairs, block_total) : 0u;
-    __syncthreads();
-    const uint32_t off = s_scan[20] + local;
-
+    float col[3] = {0.f, 0.f, 0.f};
     if (i < N) {
-        const size_t vi = (size_t)v * N + i;
-        MgrGRec r;
-        r.x = px; r.y = py; r.ca = ca; r.cb = cb; r.cc = cc;
-        r.op = op_i;
-        const float* col = colors + (size_t)v * s_col + (size_t)i * 3;
-        r.r = col[0]; r.g = col[1]; r.b = col[2];
-        r.rect_w = x1 - x0;
-        r.slot_base = (int32_t)off - y0 * (x1 - x0) - x0;
-        r.pad = 0;
-        grec[vi] = r;
-        depth[vi] = zv;
-        rect[vi] = make_ushort4((unsigned short)x0, (unsigned short)y0, (unsigned short)x1,
-                                (unsigned short)y1);
-        alive[vi] = amask;
-        pair_off[vi] = off;
-        radii[vi] = radius;
+        const float* cp = colors + (size_t)v * s_col + (size_t)i * 3;
+        col[0] = cp[0]; col[1] = cp[1]; col[2] = cp[2];
     }
+    pre_tail(N, gx, gy, v, i, po, op_i, col, s_scan, s_hist, lds_hist, grec, depth, rect, alive, pair_off, tile_count,
+             radii, hdr);
+}
 
+// ---------------------------------------------------------------------------
+// Fused per-instance forward: canonical parameters -> (LBS of mean and covariance) -> SH colour
+// (view direction pulled back through the blended transform) -> sigmoid opacity -> projection
+// and binning state, without writing posed means / covariances / transforms / colours to HBM.
+// Same math as k_lbs_fwd + k_sh_fwd + k_preprocess (instance_math.h).
+// skin_w == nullptr: static object (identity transform, direction = xyz - camera).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(PRE_THREADS) void k_inst_fwd(
+    int N, int B, int W, int H, int gx, int gy, const float* __restrict__ cams,
+    const float* __restrict__ xyz, const float* __restrict__ log_scale, const float* __restrict__ rot,
+    const float* __restrict__ op_logit, const float* __restrict__ f_dc, const float* __restrict__ f_rest,
+    const float* __restrict__ skin_w, const float* __restrict__ transforms, MgrGRec* __restrict__ grec,
+    float* __restrict__ depth, ushort4* __restrict__ rect, unsigned long long* __restrict__ alive,
+    uint32_t* __restrict__ pair_off, uint32_t* __restrict__ tile_count, int32_t* __restrict__ radii,
+    MgrHeader* hdr, int lds_hist) {
+    extern __shared__ uint32_t s_mem[];
+    uint32_t* s_scan = s_mem;
+    uint32_t* s_hist = s_mem + 32;
+    const int v = blockIdx.y, tid = threadIdx.x;
+    const int i = blockIdx.x * PRE_THREADS + tid;
+    const int T = gx * gy;
     if (lds_hist) {
-        __syncthreads();
-        for (int k = tid; k < T; k += PRE_THREADS) {
-            const uint32_t c = s_hist[k];
-            if (c) atomicAdd(&tile_count[(size_t)v * T + k], c);
+        for (int k = tid; k < T; k += PRE_THREADS) s_hist[k] = 0;
+    }
+    __syncthreads();
+    MgrCam cam;
+    mgr_load_cam(cams, v, cam);
+    ProjOut po;
+    po.radius = 0; po.x0 = po.y0 = po.x1 = po.y1 = 0;
+    po.px = po.py = po.ca = po.cb = po.cc = po.zv = 0.f;
+    float col[3] = {0.f, 0.f, 0.f}, op_i = 0.f;
+    if (i < N) {
+        GaussCano g;
+        cano_load(xyz, log_scale, rot, i, g);
+        float tf[12], p[3], c6[6];
+        blend_tf(skin_w ? skin_w + (size_t)i * B : nullptr, skin_w ? transforms + (size_t)v * B * 16 : nullptr, B, tf);
+        lbs_apply(tf, g, p, c6);
+        project_gaussian(cam, W, H, gx, gy, p, c6, po);
+        op_i = 1.0f / (1.0f + expf(-op_logit[i]));
+        if (po.radius > 0) {  // colour is only consumed by the blend
+            ShDir D;
+            if (skin_w) sh_dir_xyz<true>(g.x, g.y, g.z, tf, cam.campos, D);
+            else sh_dir_xyz<false>(g.x, g.y, g.z, tf, cam.campos, D);
+            float Y[16], c[48], rgb[3];
+            sh_basis(D.d[0] / D.n, D.d[1] / D.n, D.d[2] / D.n, Y);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) c[k] = f_dc[(size_t)i * 3 + k];
+#pragma unroll
+            for (int k = 0; k < 45; ++k) c[3 + k] = f_rest[(size_t)i * 45 + k];
+            sh_rgb(c, Y, rgb);
+            col[0] = fmaxf(rgb[0] + 0.5f, 0.f);
+            col[1] = fmaxf(rgb[1] + 0.5f, 0.f);
+            col[2] = fmaxf(rgb[2] + 0.5f, 0.f);
         }
     }
+    pre_tail(N, gx, gy, v, i, po, op_i, col, s_scan, s_hist, lds_hist, grec, depth, rect, alive, pair_off, tile_count,
+             radii, hdr);
 }
 
 // ---------------------------------------------------------------------------
@@ -773,16 +841,22 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, 
 // ---------------------------------------------------------------------------
 // host entry
 // ---------------------------------------------------------------------------
-extern "C" int mgr_raster_forward(int V, int N, int W, int H, const float* cams, const float* bg,
-                                  const float* means3D, int64_t s_means, const float* cov3D,
-                                  int64_t s_cov, const float* colors, int64_t s_col,
-                                  const float* opacity, int64_t s_op, float* out_color,
-                                  int32_t* radii, void* workspace, size_t workspace_bytes,
-                                  int64_t cap, int debug, void* stream_) {
+struct CanonInputs {  // canonical (un-posed) parameters of the fused articulated path
+    int B;
+    const float *xyz, *log_scale, *rot, *op_logit, *f_dc, *f_rest, *skin_w, *transforms;
+};
+
+static int raster_forward_impl(int V, int N, int W, int H, const float* cams, const float* bg,
+                               const float* means3D, int64_t s_means, const float* cov3D,
+                               int64_t s_cov, const float* colors, int64_t s_col,
+                               const float* opacity, int64_t s_op, const CanonInputs* canon, float* out_color,
+                               int32_t* radii, void* workspace, size_t workspace_bytes,
+                               int64_t cap, int debug, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (V <= 0 || N < 0 || W <= 0 || H <= 0 || cap < 0 || cap > 0xFFFFFFF0ll)
         return mgr_fail(MGR_EINVAL, "mgr_raster_forward: bad sizes");
-    if (!cams || !bg || !out_color || !workspace || (N > 0 && (!means3D || !cov3D || !colors || !opacity || !radii)))
+    if (!cams || !bg || !out_color || !workspace ||
+        (N > 0 && !canon && (!means3D || !cov3D || !colors || !opacity)) || (N > 0 && !radii))
         return mgr_fail(MGR_EINVAL, "mgr_raster_forward: null pointer");
     const int gx = (W + 15) / 16, gy = (H + 15) / 16, T = gx * gy;
     if (gx > 65535 || gy > 65535) return mgr_fail(MGR_EINVAL, "mgr_raster_forward: image too large");
@@ -802,6 +876,8 @@ extern "C" int mgr_raster_forward(int V, int N, int W, int H, const float* cams,
                                     152 * 1024));
         MGR_HIP(hipFuncSetAttribute((const void*)k_emit, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     152 * 1024));
+        MGR_HIP(hipFuncSetAttribute((const void*)k_inst_fwd, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    152 * 1024));
         attr_set = true;
     }
 
@@ -814,6 +890,14 @@ extern "C" int mgr_raster_forward(int V, int N, int W, int H, const float* cams,
     const size_t hist_bytes = lds_hist ? (size_t)T * 4 : 0;
     if (N > 0) {
         dim3 grid((N + PRE_THREADS - 1) / PRE_THREADS, V);
+        if (canon) {
+            MGR_PROF("k_inst_fwd", stream);
+            hipLaunchKernelGGL(k_inst_fwd, grid, dim3(PRE_THREADS), 128 + hist_bytes, stream, N, canon->B, W, H, gx, gy,
+                               cams, canon->xyz, canon->log_scale, canon->rot, canon->op_logit, canon->f_dc,
+                               canon->f_rest, canon->skin_w, canon->transforms, (MgrGRec*)(ws + L.grec),
+                               (float*)(ws + L.depth), (ushort4*)(ws + L.rect), (unsigned long long*)(ws + L.alive),
+                               (uint32_t*)(ws + L.pair_off), tile_count, radii, hdr, lds_hist);
+        } else
         { MGR_PROF("k_preprocess", stream); hipLaunchKernelGGL(k_preprocess, grid, dim3(PRE_THREADS), 128 + hist_bytes, stream, N, W, H, gx,
                            gy, cams, means3D, s_means, cov3D, s_cov, colors, s_col, opacity, s_op,
                            (MgrGRec*)(ws + L.grec), (float*)(ws + L.depth), (ushort4*)(ws + L.rect),
@@ -855,6 +939,30 @@ extern "C" int mgr_raster_forward(int V, int N, int W, int H, const float* cams,
                        (float4*)(ws + L.ckpt), (unsigned long long*)(ws + L.items), hdr, (uint32_t)cap); }
     MGR_LAUNCH_CHECK("k_blend_fwd", stream, debug);
     return MGR_OK;
+}
+
+extern "C" int mgr_raster_forward(int V, int N, int W, int H, const float* cams, const float* bg,
+                                  const float* means3D, int64_t s_means, const float* cov3D,
+                                  int64_t s_cov, const float* colors, int64_t s_col,
+                                  const float* opacity, int64_t s_op, float* out_color,
+                                  int32_t* radii, void* workspace, size_t workspace_bytes,
+                                  int64_t cap, int debug, void* stream_) {
+    return raster_forward_impl(V, N, W, H, cams, bg, means3D, s_means, cov3D, s_cov, colors, s_col, opacity, s_op,
+                               nullptr, out_color, radii, workspace, workspace_bytes, cap, debug, stream_);
+}
+
+extern "C" int mgr_views_forward(int V, int N, int B, int W, int H, const float* cams, const float* bg,
+                                 const float* xyz, const float* log_scale, const float* rot,
+                                 const float* opacity_logit, const float* f_dc, const float* f_rest,
+                                 const float* skin_w, const float* transforms, float* out_color,
+                                 int32_t* radii, void* workspace, size_t workspace_bytes, int64_t cap,
+                                 int debug, void* stream_) {
+    if (N > 0 && (!xyz || !log_scale || !rot || !opacity_logit || !f_dc || !f_rest || (skin_w && !transforms)))
+        return mgr_fail(MGR_EINVAL, "mgr_views_forward: null pointer");
+    if (skin_w && (B <= 0 || B > MGR_MAX_BONES)) return mgr_fail(MGR_EINVAL, "mgr_views_forward: bad B");
+    const CanonInputs ci = {B, xyz, log_scale, rot, opacity_logit, f_dc, f_rest, skin_w, transforms};
+    return raster_forward_impl(V, N, W, H, cams, bg, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, &ci, out_color,
+                               radii, workspace, workspace_bytes, cap, debug, stream_);
 }
 
 extern "C" int mgr_raster_layout(int V, int N, int W, int H, int64_t cap, size_t* out, int n_out) {

@@ -91,9 +91,9 @@ class HipViewCompute:
     backward to the six leaf tensors.  All local views go through every kernel launch
     together."""
 
-    def __init__(self, scene, targets, cam_table, loss_weight=1.0):
-        from . import ops, rasterizer
-        self.ops, self.rz = ops, rasterizer
+    def __init__(self, scene, targets, cam_table, loss_weight=1.0, fused=True):
+        from . import fused as fused_mod, ops, rasterizer
+        self.ops, self.rz, self.fz, self.fused = ops, rasterizer, fused_mod, fused
         self.s = scene
         self.targets = targets          # (V_all,3,H,W) on the GPU
         self.cams = cam_table           # (V_all,40)
@@ -135,7 +135,30 @@ class HipViewCompute:
         img, radii = self.rz.rasterize_views(cams, pxyz, means2D, col, opac, pcov, s["bg"], s["width"], s["height"])
         return img, radii, means2D
 
+    def forward_views_fused(self, view_ids, stats=None, grad2d_scale=1.0):
+        s, p, ops = self.s, self.params, self.ops
+        sel = self._select(view_ids)
+        w = ops.skin_weights(p["_xyz"], self.grid, s["grid_center"], s["grid_scale"]) if self.is_hand else None
+        return self.fz.render_views(p["_xyz"], p["_scaling"], p["_rotation"], p["_opacity"], p["_features_dc"],
+                                    p["_features_rest"], w, sel["T"], sel["cams"], s["bg"], s["width"], s["height"],
+                                    stats=stats, grad2d_scale=grad2d_scale)
+
+    def _call_fused(self, view_ids, scale):
+        for v in self.params.values():
+            v.grad = None
+        stats = self.fz.ViewStats()
+        img, radii = self.forward_views_fused(view_ids, stats, 1.0 / scale)
+        tgt = self._select(view_ids)["targets"]
+        per_view = img[0].numel()
+        k = self.loss_weight * scale / per_view
+        loss_sum, g = self.ops.l1_loss_grad(img, tgt, scale=k)
+        img.backward(g)
+        return dict(grads={n: v.grad for n, v in self.params.items()}, grad2d=stats.grad2d, vis=stats.vis,
+                    radii=stats.radii, loss=loss_sum[0] * k)
+
     def __call__(self, view_ids, scale=1.0):
+        if self.fused:
+            return self._call_fused(view_ids, scale)
         for v in self.params.values():
             v.grad = None
         img, radii, means2D = self.forward_views(view_ids)
