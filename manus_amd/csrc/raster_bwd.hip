@@ -169,11 +169,12 @@ __global__ __launch_bounds__(256) void k_blend_bwd(
                         }
                     }
                     if (__ballot(hit) != 0ull) {  // wave-uniform
-                        mgr_wave_sum63_x9(v_mx, v_my, v_ca, v_cb, v_cc, v_op, v_r, v_g, v_b);
+                        // slots 0..7 by the two-at-a-time exchange reduction, slot 8 by the DPP chain
+                        const float w8 = mgr_wave_reduce8(v_mx, v_my, v_ca, v_cb, v_cc, v_op, v_r, v_g, lane);
+                        v_b = mgr_wave_sum63(v_b);
+                        if ((lane & 7) == 0) s_acc[wave][j][MGR_R8_SLOT(lane >> 3)] = w8;
                         if (lane == 63) {
-                            float* d = s_acc[wave][j];
-                            d[0] = v_mx; d[1] = v_my; d[2] = v_ca; d[3] = v_cb; d[4] = v_cc;
-                            d[5] = v_op; d[6] = v_r; d[7] = v_g; d[8] = v_b;
+                            s_acc[wave][j][8] = v_b;
                             atomicOr(&s_touch[j], 1u << wave);
                         }
                     }
