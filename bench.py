@@ -26,6 +26,18 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
 DOMINANT = "k_blend_bwd"
+PMC_FILE = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+
+
+def measured_traffic(kernel, N, V, W, H):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (same workload only)."""
+    try:
+        d = json.load(open(PMC_FILE))
+        if d.get("workload") != [N, V, W, H]:
+            return None
+        return d["kernels"][kernel]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
 
 
 def algorithmic_bytes(N, V, R, P, n_poses):
@@ -176,7 +188,8 @@ def main():
             kb = kernel_algorithmic_bytes(DOMINANT, N, V_local, R_view, P_px)
             ach = kb / (avg_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": DOMINANT, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+                    "traffic": measured_traffic(DOMINANT, N, V_local, W, H) if world == 1 else None,
                     "avg_kernel_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(kb),
                     "iter_algorithmic_GBps": round(b_iter * args.steps / dt / 1e9, 2)}
         if args.profile_all:
