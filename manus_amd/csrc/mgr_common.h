@@ -72,7 +72,10 @@ struct MgrHeader {            // first 256 bytes of the workspace
     uint32_t pad[6];
     uint32_t cls_count[34];   // tiles per size class (class = bit length of the pair count, 0 = empty)
     uint32_t cls_cursor[34];  // running cursors of the queue scatter
-    uint32_t pad2[56 - 8 - 68 + 64];
+    uint32_t queue_giant;     // queue index of the first tile with fewer than 16384 pairs
+    uint32_t n_groups;        // depth groups produced by k_tile_split for the giant tiles
+    uint32_t split_head, group_head;
+    uint32_t pad2[56 - 8 - 68 + 64 - 4];
 };
 
 // 48-byte per-(view,Gaussian) record gathered by the blend kernels
@@ -89,7 +92,7 @@ struct __attribute__((aligned(16))) MgrGRec {
 
 struct MgrLayout {
     size_t header, scan_part, grec, depth, rect, alive, pair_off, tile_count, tile_start, tile_cursor, tile_done,
-        tile_queue, chunk_start, items, ckpt, keys, sorted_gid, final_T, n_contrib, pair_tag, pair_grad, inst_grad, total;
+        tile_queue, chunk_start, items, ckpt, keys, keys2, groups, sorted_gid, final_T, n_contrib, pair_tag, pair_grad, inst_grad, total;
 };
 
 static inline size_t mgr_align(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -117,6 +120,8 @@ static inline MgrLayout mgr_layout(int V, int N, int W, int H, int64_t cap) {
     L.items = o;       o += mgr_align((c / MGR_CHUNK + VT + 1) * 8);
     L.ckpt = o;        o += mgr_align((c / MGR_CHUNK + 1) * 256 * 16);  // float4 per pixel per checkpoint
     L.keys = o;        o += mgr_align(c * 8);
+    L.keys2 = o;       o += mgr_align(c * 8);       // giant tiles: keys regrouped by depth range
+    L.groups = o;      o += mgr_align((c / 4096 + 64) * 16);  // (src offset, count) of every depth group
     L.sorted_gid = o;  o += mgr_align(c * 4);
     L.final_T = o;     o += mgr_align(VP * 4);
     L.n_contrib = o;   o += mgr_align(VP * 4);

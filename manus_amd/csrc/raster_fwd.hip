@@ -364,6 +364,10 @@ __global__ __launch_bounds__(1024) void k_tile_scan_b(int VT, int nblk, const ui
         hdr->item_head = 0;
         hdr->queue_len = s_cbase[0];  // class 0 (empty tiles) starts after all non-empty ones
         hdr->queue_small = s_cbase[11]; // classes <= 11: fewer than 2048 pairs
+        hdr->queue_giant = s_cbase[14]; // classes >= 15: at least 16384 pairs
+        hdr->n_groups = 0;
+        hdr->split_head = 0;
+        hdr->group_head = 0;
         hdr->queue_head = 0;
         hdr->queue_head2 = 0;
         hdr->queue_head3 = s_cbase[11];
@@ -487,22 +491,24 @@ __device__ __forceinline__ int sort_group(const unsigned long long* sp, int G, u
     return lo;
 }
 
-__global__ __launch_bounds__(SORT_THREADS) void k_tile_sort(
+// Giant segments (>= SORT_LDS_KEYS pairs): regroup the keys by depth range so that every group fits
+// the LDS sort, and hand the groups to k_tile_sort as independent work items — the groups of one
+// tile are then sorted by different workgroups instead of one after another.
+// Per tile: 1024 sampled keys are sorted, G-1 of them become splitters, one pass counts the group
+// sizes and one pass scatters the keys into keys2 (group-contiguous, order inside a group arbitrary).
+__global__ __launch_bounds__(SORT_THREADS) void k_tile_split(
     const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ tile_queue,
-    unsigned long long* __restrict__ keys, uint32_t* __restrict__ sorted_gid, MgrHeader* hdr,
-    uint32_t cap) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-    unsigned long long* s_keys = (unsigned long long*)s_raw;
-    // all LDS in the one dynamic array (keeps the 8-byte key accesses aligned)
-    unsigned long long* s_sp = (unsigned long long*)(s_raw + (size_t)SORT_LDS_KEYS * 8);  // 65 splitters
-    uint32_t* s_cnt = (uint32_t*)(s_sp + SORT_MAX_GROUPS + 1);                           // 65 counts
-    uint32_t* s_off = s_cnt + SORT_MAX_GROUPS + 1;                                        // 65 offsets
-    uint32_t* s_item = s_off + SORT_MAX_GROUPS + 1;                                       // [0] item, [1] fill, [2] flag
+    unsigned long long* __restrict__ keys, unsigned long long* __restrict__ keys2,
+    uint4* __restrict__ groups, uint32_t* __restrict__ sorted_gid, MgrHeader* hdr, uint32_t cap) {
+    __shared__ __attribute__((aligned(16))) unsigned long long s_keys[SORT_SAMPLES];
+    __shared__ unsigned long long s_sp[SORT_MAX_GROUPS + 1];
+    __shared__ uint32_t s_cnt[SORT_MAX_GROUPS + 1], s_off[SORT_MAX_GROUPS + 1], s_cur[SORT_MAX_GROUPS + 1];
+    __shared__ uint32_t s_item[4];
     const int tid = threadIdx.x, lane = tid & 63;
-    const uint32_t qlen = hdr->queue_small;  // smaller segments are sorted by k_tile_sort_small
+    const uint32_t qlen = hdr->queue_giant;
     for (;;) {
         __syncthreads();
-        if (tid == 0) s_item[0] = atomicAdd(&hdr->queue_head, 1u);
+        if (tid == 0) s_item[0] = atomicAdd(&hdr->split_head, 1u);
         __syncthreads();
         const uint32_t item = s_item[0];
         if (item >= qlen) break;
@@ -510,18 +516,8 @@ __global__ __launch_bounds__(SORT_THREADS) void k_tile_sort(
         const uint32_t start = min(tile_start[vt], cap), end = min(tile_start[vt + 1], cap);
         const uint32_t n = end - start;
         if (n == 0) continue;
-        uint32_t npad = 1;
-        while (npad < n) npad <<= 1;
-        if (n <= SORT_LDS_KEYS) {
-            for (uint32_t t = tid; t < n; t += SORT_THREADS) s_keys[t] = keys[start + t];
-            __syncthreads();
-            if (n > 1) bitonic_mirror(s_keys, n, npad, tid, SORT_THREADS);
-            for (uint32_t t = tid; t < n; t += SORT_THREADS) sorted_gid[start + t] = (uint32_t)s_keys[t];
-            continue;
-        }
-        // ---- big segment: split by sampled splitters into groups that fit the LDS, sort each
         const int G = (int)((n + SORT_LDS_KEYS / 2 - 1) / (SORT_LDS_KEYS / 2));
-        bool fallback = G > SORT_MAX_GROUPS;
+        bool fallback = G > SORT_MAX_GROUPS || n <= SORT_SAMPLES;
         if (!fallback) {
             for (uint32_t t = tid; t < SORT_SAMPLES; t += SORT_THREADS)
                 s_keys[t] = keys[start + (uint32_t)(((unsigned long long)t * n) / SORT_SAMPLES)];
@@ -532,8 +528,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_tile_sort(
                 s_cnt[tid] = 0;
             }
             __syncthreads();
-            // count group sizes (wave-aggregated)
-            for (uint32_t t0 = (uint32_t)(tid & ~63); t0 < n; t0 += SORT_THREADS) {
+            for (uint32_t t0 = (uint32_t)(tid & ~63); t0 < n; t0 += SORT_THREADS) {  // group sizes
                 const uint32_t t = t0 + lane;
                 const int g = t < n ? sort_group(s_sp, G, keys[start + t]) : -1;
                 for (int gg = 0; gg < G; ++gg) {
@@ -546,50 +541,82 @@ __global__ __launch_bounds__(SORT_THREADS) void k_tile_sort(
                 uint32_t run = 0, big = 0;
                 for (int g = 0; g < G; ++g) {
                     s_off[g] = run;
+                    s_cur[g] = 0;
                     run += s_cnt[g];
                     big |= s_cnt[g] > SORT_LDS_KEYS;
                 }
                 s_item[2] = big;
+                s_item[3] = big ? 0u : atomicAdd(&hdr->n_groups, (uint32_t)G);
             }
             __syncthreads();
             fallback = s_item[2] != 0;
         }
         if (!fallback) {
-            for (int g = 0; g < G; ++g) {
-                const uint32_t ng = s_cnt[g];
-                if (tid == 0) s_item[1] = 0;
-                __syncthreads();
-                for (uint32_t t0 = (uint32_t)(tid & ~63); t0 < n; t0 += SORT_THREADS) {
-                    const uint32_t t = t0 + lane;
-                    unsigned long long key = 0ull;
-                    bool mine = false;
-                    if (t < n) {
-                        key = keys[start + t];
-                        mine = sort_group(s_sp, G, key) == g;
-                    }
-                    const unsigned long long mk = __ballot(mine);
+            for (uint32_t t0 = (uint32_t)(tid & ~63); t0 < n; t0 += SORT_THREADS) {  // scatter
+                const uint32_t t = t0 + lane;
+                unsigned long long key = 0ull;
+                int g = -1;
+                if (t < n) {
+                    key = keys[start + t];
+                    g = sort_group(s_sp, G, key);
+                }
+                for (int gg = 0; gg < G; ++gg) {
+                    const unsigned long long mk = __ballot(g == gg);
+                    if (!mk) continue;
                     uint32_t base = 0;
-                    if (lane == 0 && mk) base = atomicAdd(&s_item[1], (uint32_t)__popcll(mk));
+                    if (lane == 0) base = atomicAdd(&s_cur[gg], (uint32_t)__popcll(mk));
                     base = (uint32_t)__shfl((int)base, 0, 64);
-                    if (mine) s_keys[base + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull))] = key;
+                    if (g == gg) keys2[start + s_off[gg] + base + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull))] = key;
                 }
-                __syncthreads();
-                if (ng > 1) {
-                    uint32_t gp = 1;
-                    while (gp < ng) gp <<= 1;
-                    bitonic_mirror(s_keys, ng, gp, tid, SORT_THREADS);
-                }
-                const uint32_t o = start + s_off[g];
-                for (uint32_t t = tid; t < ng; t += SORT_THREADS) sorted_gid[o + t] = (uint32_t)s_keys[t];
-                __syncthreads();
             }
+            if (tid < G) groups[s_item[3] + tid] = make_uint4(start + s_off[tid], s_cnt[tid], 0u, 0u);
         } else {
-            // last resort (pathological distributions): in-place network in global memory
+            // last resort (pathological depth distributions): in-place network in global memory
+            uint32_t npad = 1;
+            while (npad < n) npad <<= 1;
             __syncthreads();
             bitonic_mirror(keys + start, n, npad, tid, SORT_THREADS);
             __threadfence_block();
             for (uint32_t t = tid; t < n; t += SORT_THREADS) sorted_gid[start + t] = (uint32_t)keys[start + t];
         }
+    }
+}
+
+// Segments of [2048, 16384) pairs and the depth groups of the giant tiles: one LDS sort each.
+__global__ __launch_bounds__(SORT_THREADS) void k_tile_sort(
+    const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ tile_queue,
+    const unsigned long long* __restrict__ keys, const unsigned long long* __restrict__ keys2,
+    const uint4* __restrict__ groups, uint32_t* __restrict__ sorted_gid, MgrHeader* hdr, uint32_t cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    unsigned long long* s_keys = (unsigned long long*)s_raw;
+    uint32_t* s_item = (uint32_t*)(s_raw + (size_t)SORT_LDS_KEYS * 8);  // all LDS in the one dynamic array
+    const int tid = threadIdx.x;
+    const uint32_t n_groups = hdr->n_groups, q0 = hdr->queue_giant, q1 = hdr->queue_small;
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) s_item[0] = atomicAdd(&hdr->group_head, 1u);
+        __syncthreads();
+        const uint32_t item = s_item[0];
+        const unsigned long long* src;
+        uint32_t start, n;
+        if (item < n_groups) {  // groups first: they belong to the deepest tiles
+            const uint4 gr = groups[item];
+            src = keys2; start = gr.x; n = min(gr.y, (uint32_t)SORT_LDS_KEYS);
+        } else {
+            const uint32_t qi = q0 + (item - n_groups);
+            if (qi >= q1) break;
+            const uint32_t vt = tile_queue[qi];
+            src = keys;
+            start = min(tile_start[vt], cap);
+            n = min(min(tile_start[vt + 1], cap) - start, (uint32_t)SORT_LDS_KEYS);
+        }
+        if (n == 0) continue;
+        uint32_t npad = 1;
+        while (npad < n) npad <<= 1;
+        for (uint32_t t = tid; t < n; t += SORT_THREADS) s_keys[t] = src[start + t];
+        __syncthreads();
+        if (n > 1) bitonic_mirror(s_keys, n, npad, tid, SORT_THREADS);
+        for (uint32_t t = tid; t < n; t += SORT_THREADS) sorted_gid[start + t] = (uint32_t)s_keys[t];
     }
 }
 
@@ -871,7 +898,7 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
     static bool attr_set = false;
     if (!attr_set) {
         MGR_HIP(hipFuncSetAttribute((const void*)k_tile_sort, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    SORT_LDS_KEYS * 8 + SORT_LDS_EXTRA));
+                                    SORT_LDS_KEYS * 8 + 16));
         MGR_HIP(hipFuncSetAttribute((const void*)k_preprocess, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     152 * 1024));
         MGR_HIP(hipFuncSetAttribute((const void*)k_emit, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -922,10 +949,14 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
                            (uint32_t*)(ws + L.tile_cursor), (unsigned long long*)(ws + L.keys),
                            (uint32_t)cap, lds_hist); }
         MGR_LAUNCH_CHECK("k_emit", stream, debug);
-        { MGR_PROF("k_tile_sort", stream); hipLaunchKernelGGL(k_tile_sort, dim3(256), dim3(SORT_THREADS), SORT_LDS_KEYS * 8 + SORT_LDS_EXTRA, stream,
+        { MGR_PROF("k_tile_split", stream); hipLaunchKernelGGL(k_tile_split, dim3(128), dim3(SORT_THREADS), 0, stream,
+                           tile_start, (const uint32_t*)(ws + L.tile_queue), (unsigned long long*)(ws + L.keys),
+                           (unsigned long long*)(ws + L.keys2), (uint4*)(ws + L.groups),
+                           (uint32_t*)(ws + L.sorted_gid), hdr, (uint32_t)cap); }
+        { MGR_PROF("k_tile_sort", stream); hipLaunchKernelGGL(k_tile_sort, dim3(256), dim3(SORT_THREADS), SORT_LDS_KEYS * 8 + 16, stream,
                            tile_start, (const uint32_t*)(ws + L.tile_queue),
-                           (unsigned long long*)(ws + L.keys), (uint32_t*)(ws + L.sorted_gid), hdr,
-                           (uint32_t)cap); }
+                           (const unsigned long long*)(ws + L.keys), (const unsigned long long*)(ws + L.keys2),
+                           (const uint4*)(ws + L.groups), (uint32_t*)(ws + L.sorted_gid), hdr, (uint32_t)cap); }
         { MGR_PROF("k_tile_sort_small", stream); hipLaunchKernelGGL(k_tile_sort_small, dim3(256 * 8), dim3(256), 0, stream,
                            tile_start, (const uint32_t*)(ws + L.tile_queue),
                            (const unsigned long long*)(ws + L.keys), (uint32_t*)(ws + L.sorted_gid), hdr,
