@@ -326,6 +326,66 @@ __device__ __forceinline__ bool mgr_quad_bbox(unsigned long long am, int& x0, in
     return true;
 }
 
+// ---------------------------------------------------------------------------
+// Pair-packed staging for the blend kernels.
+//
+// The blend loops evaluate two list entries per step with packed fp32 instructions
+// (v_pk_mul_f32 / v_pk_fma_f32: two lanes of fp32 per VGPR pair).  The survivors of one wave's
+// 64-entry batch are therefore written to LDS two by two, field-interleaved, so that one
+// ds_read_b128 returns (x_a, x_b, y_a, y_b) etc. already in register-pair order:
+//   [0] x_a x_b y_a y_b   [4] A_a A_b B_a B_b   [8] C_a C_b o_a o_b   [12] r_a r_b g_a g_b
+//   [16] b_a b_b pos_a pos_b
+// A, B, C are the conic pre-scaled so that  log2(G) = A dx^2 + B dx dy + C dy^2
+// (A = -0.5 log2e conic.x, B = -log2e conic.y, C = -0.5 log2e conic.z): the exponent feeds v_exp_f32
+// directly.  Forward and backward evaluate alpha through the same mgr_pair_alpha, so both make
+// identical keep/skip decisions.
+// ---------------------------------------------------------------------------
+typedef float mgr_v2f __attribute__((ext_vector_type(2)));
+#define MGR_PAIR_FLOATS 20
+#define MGR_LOG2E 1.44269504088896341f
+#define MGR_LN2 0.69314718055994531f
+
+__device__ __forceinline__ void mgr_pair_store(float* pb, int half, float x, float y, float ca, float cb, float cc,
+                                               float op, float r, float g, float b, uint32_t pos) {
+    pb[0 + half] = x;
+    pb[2 + half] = y;
+    pb[4 + half] = (-0.5f * MGR_LOG2E) * ca;
+    pb[6 + half] = (-MGR_LOG2E) * cb;
+    pb[8 + half] = (-0.5f * MGR_LOG2E) * cc;
+    pb[10 + half] = op;
+    pb[12 + half] = r;
+    pb[14 + half] = g;
+    pb[16 + half] = b;
+    pb[18 + half] = __uint_as_float(pos);
+}
+
+// the second slot of an odd pair: opacity 0 -> alpha 0 -> never valid
+__device__ __forceinline__ void mgr_pair_pad(float* pb) {
+#pragma unroll
+    for (int f = 0; f < 10; ++f) pb[2 * f + 1] = 0.0f;
+}
+
+// alpha of two entries at one pixel; pw = log2 of the Gaussian falloff (valid entries have pw <= 0)
+__device__ __forceinline__ void mgr_pair_alpha(const float4 R0, const float4 R1, const float4 R2, mgr_v2f fpx2,
+                                               mgr_v2f fpy2, mgr_v2f& dx, mgr_v2f& dy, mgr_v2f& G, mgr_v2f& al,
+                                               bool& va, bool& vb) {
+    const mgr_v2f x2 = {R0.x, R0.y}, y2 = {R0.z, R0.w}, A2 = {R1.x, R1.y}, B2 = {R1.z, R1.w}, C2 = {R2.x, R2.y},
+                  o2 = {R2.z, R2.w};
+    dx = x2 - fpx2;
+    dy = y2 - fpy2;
+    mgr_v2f t = A2 * dx;
+    t = B2 * dy + t;
+    const mgr_v2f u = C2 * dy;
+    const mgr_v2f pw = dx * t + u * dy;
+    G.x = __builtin_amdgcn_exp2f(fminf(pw.x, 0.0f));
+    G.y = __builtin_amdgcn_exp2f(fminf(pw.y, 0.0f));
+    al = o2 * G;
+    al.x = fminf(0.99f, al.x);
+    al.y = fminf(0.99f, al.y);
+    va = pw.x <= 0.0f && al.x >= 1.0f / 255.0f;
+    vb = pw.y <= 0.0f && al.y >= 1.0f / 255.0f;
+}
+
 // natural exponential through v_exp_f32 (arguments here lie in [-12, 0])
 __device__ __forceinline__ float mgr_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
 

@@ -491,6 +491,126 @@ __device__ __forceinline__ int sort_group(const unsigned long long* sp, int G, u
     return lo;
 }
 
+// ---------------------------------------------------------------------------
+// LDS radix sort of up to 1024*E (depth, gaussian) keys by 1024 threads, keys held in registers.
+// Stable LSD passes over the 32 depth bits, 8 bits per pass; a pass whose digit is the same for
+// every key is skipped (depths of one tile share their high bytes).  Key order between passes is
+// (wave, row, lane); ranks inside a wave come from wave match masks (8 ballots per row) plus one
+// LDS atomic per distinct digit, ranks across waves from a block scan of the 16x256 counters.
+// Equal depths keep an arbitrary order through the passes, so a final odd-even sweep orders
+// equal-depth neighbours by Gaussian index (the upstream tie-break); it converges immediately
+// when there are no exact ties.
+// ---------------------------------------------------------------------------
+template <int E>
+__device__ __forceinline__ void lds_radix_sort(unsigned long long (&keys)[E], uint32_t n, unsigned long long* s_keys,
+                                               uint32_t* s_cnt /*16*256*/, uint32_t* s_scan /*32*/, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    // which passes matter: OR and AND of all depth words
+    uint32_t o = 0u, a = ~0u;
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        const uint32_t d = (uint32_t)(keys[r] >> 32);
+        if (d != 0xFFFFFFFFu) { o |= d; a &= d; }
+    }
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) {
+        o |= (uint32_t)__shfl_xor((int)o, sft, 64);
+        a &= (uint32_t)__shfl_xor((int)a, sft, 64);
+    }
+    if (lane == 0) { s_cnt[wave] = o; s_cnt[16 + wave] = a; }
+    __syncthreads();
+    o = 0u; a = ~0u;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { o |= s_cnt[w]; a &= s_cnt[16 + w]; }
+    const uint32_t varying = o ^ a;  // bits that differ between some two real keys
+    __syncthreads();
+#pragma unroll 1
+    for (int pass = 0; pass < 4; ++pass) {
+        if (((varying >> (8 * pass)) & 0xFFu) == 0u) continue;  // uniform across the block
+        const int sh = 32 + 8 * pass;
+        for (int q = tid; q < 16 * 256; q += 1024) s_cnt[q] = 0;
+        __syncthreads();
+        uint32_t rnk[E / 2];  // two 16-bit in-wave ranks per register
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+            const uint32_t d = (uint32_t)(keys[r] >> sh) & 0xFFu;
+            unsigned long long m = ~0ull;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const bool bit = (d >> b) & 1u;
+                const unsigned long long bal = __ballot(bit);
+                m &= bit ? bal : ~bal;
+            }
+            const int leader = __builtin_ctzll(m);
+            uint32_t prev = 0;
+            if (lane == leader) prev = atomicAdd(&s_cnt[d * 16 + wave], (uint32_t)__popcll(m));
+            prev = (uint32_t)__shfl((int)prev, leader, 64);
+            const uint32_t rk = prev + (uint32_t)__popcll(m & lt);
+            if (r & 1) rnk[r >> 1] |= rk << 16;
+            else rnk[r >> 1] = rk;
+        }
+        __syncthreads();
+        {   // exclusive scan in (digit major, wave minor) order: 4 counters per thread
+            const uint32_t c0 = s_cnt[4 * tid], c1 = s_cnt[4 * tid + 1], c2 = s_cnt[4 * tid + 2], c3 = s_cnt[4 * tid + 3];
+            uint32_t tot;
+            const uint32_t base = block_excl_scan(c0 + c1 + c2 + c3, s_scan, tot);
+            s_cnt[4 * tid] = base;
+            s_cnt[4 * tid + 1] = base + c0;
+            s_cnt[4 * tid + 2] = base + c0 + c1;
+            s_cnt[4 * tid + 3] = base + c0 + c1 + c2;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+            const uint32_t d = (uint32_t)(keys[r] >> sh) & 0xFFu;
+            s_keys[s_cnt[d * 16 + wave] + ((rnk[r >> 1] >> (16 * (r & 1))) & 0xFFFFu)] = keys[r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < E; ++r) keys[r] = s_keys[wave * (64 * E) + r * 64 + lane];
+        __syncthreads();
+    }
+    // keys -> LDS in final order, then order equal-depth neighbours by Gaussian index
+#pragma unroll
+    for (int r = 0; r < E; ++r) s_keys[wave * (64 * E) + r * 64 + lane] = keys[r];
+    __syncthreads();
+    for (;;) {
+        int changed = 0;
+        for (int phase = 0; phase < 2; ++phase) {
+            for (uint32_t i = (uint32_t)phase + 2u * (uint32_t)tid; i + 1 < n; i += 2048u) {
+                const unsigned long long x = s_keys[i], y = s_keys[i + 1];
+                if ((x >> 32) == (y >> 32) && x > y) { s_keys[i] = y; s_keys[i + 1] = x; changed = 1; }
+            }
+            __syncthreads();
+        }
+        if (!__syncthreads_or(changed)) break;
+    }
+}
+
+// Sort n <= 16384 keys read from src[0..n) and write the sorted Gaussian ids.
+__device__ __forceinline__ void lds_sort_emit(const unsigned long long* __restrict__ src, uint32_t n,
+                                              unsigned long long* s_keys, uint32_t* s_cnt, uint32_t* s_scan, int tid,
+                                              uint32_t* __restrict__ out) {
+    const int lane = tid & 63, wave = tid >> 6;
+#define MGR_RADIX_CASE(EE)                                                                       \
+    {                                                                                            \
+        unsigned long long k[EE];                                                                \
+        _Pragma("unroll") for (int r = 0; r < EE; ++r) {                                        \
+            const uint32_t p = (uint32_t)(wave * (64 * EE) + r * 64 + lane);                     \
+            k[r] = p < n ? src[p] : ~0ull;                                                       \
+        }                                                                                        \
+        lds_radix_sort<EE>(k, n, s_keys, s_cnt, s_scan, tid);                                    \
+    }
+    if (n <= 2048u) MGR_RADIX_CASE(2)
+    else if (n <= 4096u) MGR_RADIX_CASE(4)
+    else if (n <= 8192u) MGR_RADIX_CASE(8)
+    else MGR_RADIX_CASE(16)
+#undef MGR_RADIX_CASE
+    for (uint32_t t = (uint32_t)tid; t < n; t += 1024u) out[t] = (uint32_t)s_keys[t];
+    __syncthreads();
+}
+
 // Giant segments (>= SORT_LDS_KEYS pairs): regroup the keys by depth range so that every group fits
 // the LDS sort, and hand the groups to k_tile_sort as independent work items — the groups of one
 // tile are then sorted by different workgroups instead of one after another.
@@ -589,7 +709,9 @@ __global__ __launch_bounds__(SORT_THREADS) void k_tile_sort(
     const uint4* __restrict__ groups, uint32_t* __restrict__ sorted_gid, MgrHeader* hdr, uint32_t cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     unsigned long long* s_keys = (unsigned long long*)s_raw;
-    uint32_t* s_item = (uint32_t*)(s_raw + (size_t)SORT_LDS_KEYS * 8);  // all LDS in the one dynamic array
+    uint32_t* s_cnt = (uint32_t*)(s_raw + (size_t)SORT_LDS_KEYS * 8);  // 16 x 256 counters (all LDS in the one array)
+    uint32_t* s_scan = s_cnt + 16 * 256;                                // 32 words
+    uint32_t* s_item = s_scan + 32;
     const int tid = threadIdx.x;
     const uint32_t n_groups = hdr->n_groups, q0 = hdr->queue_giant, q1 = hdr->queue_small;
     for (;;) {
@@ -611,12 +733,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_tile_sort(
             n = min(min(tile_start[vt + 1], cap) - start, (uint32_t)SORT_LDS_KEYS);
         }
         if (n == 0) continue;
-        uint32_t npad = 1;
-        while (npad < n) npad <<= 1;
-        for (uint32_t t = tid; t < n; t += SORT_THREADS) s_keys[t] = src[start + t];
-        __syncthreads();
-        if (n > 1) bitonic_mirror(s_keys, n, npad, tid, SORT_THREADS);
-        for (uint32_t t = tid; t < n; t += SORT_THREADS) sorted_gid[start + t] = (uint32_t)s_keys[t];
+        lds_sort_emit(src + start, n, s_keys, s_cnt, s_scan, tid, sorted_gid + start);
     }
 }
 
@@ -654,11 +771,13 @@ __global__ __launch_bounds__(256) void k_tile_sort_small(
 // K5: front-to-back alpha compositing, one 16x16 tile at a time per 256-thread workgroup.
 //  * persistent workgroups: non-empty tiles are pulled from the size-ordered queue (largest
 //    first), then the empty tiles are background-filled with a static stride;
-//  * wave w owns the 8x8 pixel quadrant (w&1, w>>1); the list is staged through LDS 256 entries
-//    at a time, each entry tested against the four quadrants (mgr_box_dead) so that a wave only
-//    walks entries that can reach one of its pixels;
-//  * the gather of the next batch (index two batches ahead, record one batch ahead) is in
-//    flight while the current batch is blended;
+//  * wave w owns the 8x8 pixel quadrant (w&1, w>>1) and walks the tile's list on its own, 64
+//    entries per batch, with no workgroup barrier inside a tile: each lane fetches one entry
+//    (index two batches ahead, record one batch ahead of the blend), tests it against the
+//    bounding box of the quadrant's still-active pixels (mgr_box_dead) and the survivors are
+//    compacted pairwise into the wave's LDS slab (mgr_pair_store);
+//  * the blend loop then takes two entries per step with packed fp32 math; only the short
+//    transmittance update is sequential;
 //  * every MGR_CHUNK entries the per-pixel prefix state is checkpointed for the backward pass.
 // ---------------------------------------------------------------------------
 struct FwdRec {
@@ -680,11 +799,7 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, 
                                                    float4* __restrict__ ckpt,
                                                    unsigned long long* __restrict__ items, MgrHeader* hdr,
                                                    uint32_t cap) {
-    __shared__ float2 s_xy[256];
-    __shared__ float4 s_co[256];
-    __shared__ float s_rgb[256 * 3];
-    __shared__ unsigned long long s_mask[4][4];  // [staging wave][quadrant]
-    __shared__ float4 s_box[4];                  // per quadrant: bounding box of the pixels still active
+    __shared__ __align__(16) float s_pair[4][32][MGR_PAIR_FLOATS];
     __shared__ uint32_t s_max, s_next, s_ibase;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int T = gx * gy;
@@ -692,6 +807,8 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, 
     const size_t P = (size_t)W * H;
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
     const int pslot = (wave << 6) | lane;  // pixel slot inside a checkpoint (same mapping in backward)
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    float* const slab = &s_pair[wave][0][0];
 
     if (tid == 0) s_next = atomicAdd(&hdr->queue_head2, 1u);
     __syncthreads();
@@ -705,8 +822,8 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, 
         const int px = bx * 16 + (wave & 1) * 8 + (lane & 7);
         const int py = by * 16 + (wave >> 1) * 8 + (lane >> 3);
         const bool inside = px < W && py < H;
-        const float fpx = (float)px, fpy = (float)py;
-        const float tx0 = (float)(bx * 16), ty0 = (float)(by * 16);
+        const mgr_v2f fpx2 = {(float)px, (float)px}, fpy2 = {(float)py, (float)py};
+        const float qx0 = (float)(bx * 16 + (wave & 1) * 8), qy0 = (float)(by * 16 + (wave >> 1) * 8);
         const uint32_t ck0 = chunk_start[vt];  // checkpoint c (c >= 1) of this tile lives at ck0 + c - 1
         __syncthreads();                       // everyone has read s_next
         if (tid == 0) {
@@ -716,110 +833,84 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, 
         float Tr = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
         uint32_t last = 0;
         bool done = !inside;
+        const MgrGRec* const gv = grec + (size_t)v * N;
 
         // software pipeline: rec = record of batch k, gid_n = index of batch k+1
         FwdRec rec;
-        uint32_t gid_n = 0;
+        uint32_t gid_n;
         {
-            const uint32_t i0 = tid, i1 = 256 + tid;
-            const uint32_t g0 = i0 < nlist ? sorted_gid[start + i0] : 0u;
-            gid_n = i1 < nlist ? sorted_gid[start + i1] : 0u;
-            const MgrGRec* r = grec + (size_t)v * N + g0;
+            const uint32_t g0 = (uint32_t)lane < nlist ? sorted_gid[start + lane] : 0u;
+            gid_n = 64u + lane < nlist ? sorted_gid[start + 64u + lane] : 0u;
+            const MgrGRec* r = gv + g0;
             rec.a = *(const float4*)r;
             rec.b = *((const float4*)r + 1);
             rec.c = r->b;
         }
-        const float qx0 = tx0 + (float)((wave & 1) * 8), qy0 = ty0 + (float)((wave >> 1) * 8);
-        for (uint32_t off = 0; off < nlist; off += 256) {
-            {   // shrink this quadrant's box to the pixels that are still accumulating
-                int bx0, by0, bx1, by1;
-                const bool any = mgr_quad_bbox(__ballot(!done), bx0, by0, bx1, by1);
-                if (lane == 0)
-                    s_box[wave] = any ? make_float4(qx0 + (float)bx0, qy0 + (float)by0, qx0 + (float)bx1, qy0 + (float)by1)
-                                      : make_float4(1.f, 1.f, 0.f, 0.f);
-            }
-            if (__syncthreads_count(done) == 256) break;
-            const uint32_t idx = off + tid;
-            bool d0 = true, d1 = true, d2 = true, d3 = true;
-            if (idx < nlist) {
-                const float4 a = rec.a, b = rec.b;
-                s_xy[tid] = make_float2(a.x, a.y);
-                s_co[tid] = make_float4(a.z, a.w, b.x, b.y);
-                s_rgb[tid * 3 + 0] = b.z;
-                s_rgb[tid * 3 + 1] = b.w;
-                s_rgb[tid * 3 + 2] = rec.c;
-                const float qmax = mgr_qmax(b.y);
-                const float4 q0 = s_box[0], q1 = s_box[1], q2 = s_box[2], q3 = s_box[3];
-                d0 = q0.x > q0.z || mgr_box_dead(a.x, a.y, a.z, a.w, b.x, qmax, q0.x, q0.y, q0.z, q0.w);
-                d1 = q1.x > q1.z || mgr_box_dead(a.x, a.y, a.z, a.w, b.x, qmax, q1.x, q1.y, q1.z, q1.w);
-                d2 = q2.x > q2.z || mgr_box_dead(a.x, a.y, a.z, a.w, b.x, qmax, q2.x, q2.y, q2.z, q2.w);
-                d3 = q3.x > q3.z || mgr_box_dead(a.x, a.y, a.z, a.w, b.x, qmax, q3.x, q3.y, q3.z, q3.w);
-            }
-            const unsigned long long m0 = __ballot(!d0), m1 = __ballot(!d1), m2 = __ballot(!d2), m3 = __ballot(!d3);
-            if (lane == 0) {
-                s_mask[wave][0] = m0; s_mask[wave][1] = m1; s_mask[wave][2] = m2; s_mask[wave][3] = m3;
+        for (uint32_t off = 0; off < nlist; off += 64) {
+            // bounding box of this quadrant's pixels that are still accumulating
+            int bx0, by0, bx1, by1;
+            if (!mgr_quad_bbox(__ballot(!done), bx0, by0, bx1, by1)) break;
+            bool alive = false;
+            if (off + lane < nlist)
+                alive = !mgr_box_dead(rec.a.x, rec.a.y, rec.a.z, rec.a.w, rec.b.x, mgr_qmax(rec.b.y), qx0 + (float)bx0,
+                                      qy0 + (float)by0, qx0 + (float)bx1, qy0 + (float)by1);
+            const unsigned long long m = __ballot(alive);
+            const int cnt = __popcll(m);
+            if (alive) {
+                const int rank = __popcll(m & lt);
+                float* pb = slab + (rank >> 1) * MGR_PAIR_FLOATS;
+                mgr_pair_store(pb, rank & 1, rec.a.x, rec.a.y, rec.a.z, rec.a.w, rec.b.x, rec.b.y, rec.b.z, rec.b.w, rec.c,
+                               off + (uint32_t)lane + 1u);  // 1-based list position
+                if ((cnt & 1) && rank == cnt - 1) mgr_pair_pad(pb);
             }
             // issue the gathers of the following batches; they complete during the blend below
             {
-                const uint32_t i1 = off + 256 + tid, i2 = off + 512 + tid;
-                if (i1 < nlist) {
-                    const MgrGRec* r = grec + (size_t)v * N + gid_n;
+                if (off + 64u + lane < nlist) {
+                    const MgrGRec* r = gv + gid_n;
                     rec.a = *(const float4*)r;
                     rec.b = *((const float4*)r + 1);
                     rec.c = r->b;
                 }
-                gid_n = i2 < nlist ? sorted_gid[start + i2] : 0u;
+                gid_n = off + 128u + lane < nlist ? sorted_gid[start + off + 128u + lane] : 0u;
             }
-            __syncthreads();
-            if (!__all(done)) {
-#pragma unroll 1
-                for (int sw = 0; sw < 4; ++sw) {
-                    unsigned long long m = s_mask[sw][wave];
-                    // Four list entries per step: their alphas are independent (ILP hides the LDS
-                    // and exp latency); only the short transmittance update is sequential.
-                    while (m) {
-                        int jj[4];
-                        float al[4], cr[4], cg[4], cb[4];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const bool have = m != 0ull;
-                            jj[k] = sw * 64 + (have ? __builtin_ctzll(m) : 0);
-                            m = have ? (m & (m - 1)) : 0ull;
-                            const float2 xy = s_xy[jj[k]];
-                            const float4 co = s_co[jj[k]];
-                            cr[k] = s_rgb[jj[k] * 3 + 0];
-                            cg[k] = s_rgb[jj[k] * 3 + 1];
-                            cb[k] = s_rgb[jj[k] * 3 + 2];
-                            const float dx = xy.x - fpx, dy = xy.y - fpy;
-                            const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-                            const float a = fminf(0.99f, co.w * mgr_exp(fminf(power, 0.0f)));
-                            al[k] = (have && power <= 0.0f && a >= 1.0f / 255.0f) ? a : 0.0f;
-                        }
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const bool val = !done && al[k] > 0.0f;
-                            const float testT = Tr * (1.0f - al[k]);
-                            const bool stop = val && testT < 0.0001f;
-                            const bool app = val && !stop;
-                            const float w = app ? al[k] * Tr : 0.0f;
-                            C0 += cr[k] * w;
-                            C1 += cg[k] * w;
-                            C2 += cb[k] * w;
-                            Tr = app ? testT : Tr;
-                            last = app ? off + (uint32_t)jj[k] + 1u : last;  // 1-based list position
-                            done = done || stop;
-                        }
-                        if (__all(done)) break;
-                    }
-                    // pixel state in front of the next chunk (prefix colour + transmittance): lets the
-                    // backward pass process every MGR_CHUNK-entry chunk of the list independently
-                    if (sw & 1) {
-                        const uint32_t nextpos = off + (uint32_t)(sw + 1) * 64u;
-                        if (nextpos < nlist)
-                            ckpt[(size_t)(ck0 + nextpos / MGR_CHUNK - 1) * 256 + pslot] = make_float4(C0, C1, C2, Tr);
-                    }
+            const int npair = (cnt + 1) >> 1;
+            for (int p = 0; p < npair; ++p) {
+                const float4* pp = (const float4*)(slab + p * MGR_PAIR_FLOATS);
+                const float4 R0 = pp[0], R1 = pp[1], R2 = pp[2], R3 = pp[3], R4 = pp[4];
+                mgr_v2f dx, dy, G, al;
+                bool va, vb;
+                mgr_pair_alpha(R0, R1, R2, fpx2, fpy2, dx, dy, G, al, va, vb);
+                {   // entry a
+                    const float a = (va && !done) ? al.x : 0.0f;
+                    const float testT = Tr * (1.0f - a);
+                    const bool stop = testT < 0.0001f;  // a == 0 leaves testT = Tr >= 1e-4
+                    const float w = stop ? 0.0f : a * Tr;
+                    C0 += R3.x * w;
+                    C1 += R3.z * w;
+                    C2 += R4.x * w;
+                    Tr = stop ? Tr : testT;
+                    last = w > 0.0f ? __float_as_uint(R4.z) : last;
+                    done = done || stop;
                 }
+                {   // entry b
+                    const float a = (vb && !done) ? al.y : 0.0f;
+                    const float testT = Tr * (1.0f - a);
+                    const bool stop = testT < 0.0001f;
+                    const float w = stop ? 0.0f : a * Tr;
+                    C0 += R3.y * w;
+                    C1 += R3.w * w;
+                    C2 += R4.y * w;
+                    Tr = stop ? Tr : testT;
+                    last = w > 0.0f ? __float_as_uint(R4.w) : last;
+                    done = done || stop;
+                }
+                if (__all(done)) break;
             }
+            // pixel state in front of the next chunk (prefix colour + transmittance): lets the
+            // backward pass process every MGR_CHUNK-entry chunk of the list independently
+            const uint32_t nextpos = off + 64u;
+            if ((nextpos % MGR_CHUNK) == 0 && nextpos < nlist)
+                ckpt[(size_t)(ck0 + nextpos / MGR_CHUNK - 1) * 256 + pslot] = make_float4(C0, C1, C2, Tr);
         }
         if (inside) {
             const size_t pix = (size_t)py * W + px;
@@ -831,10 +922,10 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, 
             o[2 * P] = C2 + Tr * bg2;
         }
         // per-tile depth actually consumed (drives the backward pass)
-        uint32_t m = last;
+        uint32_t mx = last;
 #pragma unroll
-        for (int d = 32; d > 0; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
-        if (lane == 0) atomicMax(&s_max, m);
+        for (int d = 32; d > 0; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
+        if (lane == 0) atomicMax(&s_max, mx);
         __syncthreads();
         const uint32_t tmax = s_max;
         const uint32_t nchunks = (tmax + MGR_CHUNK - 1) / MGR_CHUNK;
@@ -898,7 +989,7 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
     static bool attr_set = false;
     if (!attr_set) {
         MGR_HIP(hipFuncSetAttribute((const void*)k_tile_sort, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    SORT_LDS_KEYS * 8 + 16));
+                                    SORT_LDS_KEYS * 8 + 16 * 256 * 4 + 256));
         MGR_HIP(hipFuncSetAttribute((const void*)k_preprocess, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     152 * 1024));
         MGR_HIP(hipFuncSetAttribute((const void*)k_emit, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -953,7 +1044,7 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
                            tile_start, (const uint32_t*)(ws + L.tile_queue), (unsigned long long*)(ws + L.keys),
                            (unsigned long long*)(ws + L.keys2), (uint4*)(ws + L.groups),
                            (uint32_t*)(ws + L.sorted_gid), hdr, (uint32_t)cap); }
-        { MGR_PROF("k_tile_sort", stream); hipLaunchKernelGGL(k_tile_sort, dim3(256), dim3(SORT_THREADS), SORT_LDS_KEYS * 8 + 16, stream,
+        { MGR_PROF("k_tile_sort", stream); hipLaunchKernelGGL(k_tile_sort, dim3(256), dim3(SORT_THREADS), SORT_LDS_KEYS * 8 + 16 * 256 * 4 + 256, stream,
                            tile_start, (const uint32_t*)(ws + L.tile_queue),
                            (const unsigned long long*)(ws + L.keys), (const unsigned long long*)(ws + L.keys2),
                            (const uint4*)(ws + L.groups), (uint32_t*)(ws + L.sorted_gid), hdr, (uint32_t)cap); }

@@ -1,0 +1,42 @@
+"""Aggregate rocprofv3 counter_collection CSVs: mean counter value per launch for each kernel.
+
+Usage: python tools/pmc_summary.py gpurun_out/pmc_TAG_*  [--json out.json]
+FETCH_SIZE / WRITE_SIZE are reported in KB by rocprofv3; on gfx950 FETCH_SIZE under-reports by 2x
+(MI355X_MICROARCH.md, HBM section), which `hbm_bytes` below corrects."""
+import csv, glob, json, os, sys
+from collections import defaultdict
+
+def main():
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    out_json = sys.argv[sys.argv.index("--json") + 1] if "--json" in sys.argv else None
+    if out_json in args:
+        args.remove(out_json)
+    acc = defaultdict(lambda: defaultdict(list))
+    for d in args:
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            per_dispatch = defaultdict(float)
+            names = {}
+            for r in csv.DictReader(open(f)):
+                key = (r["Dispatch_Id"], r["Counter_Name"])
+                per_dispatch[key] += float(r["Counter_Value"])
+                names[r["Dispatch_Id"]] = r["Kernel_Name"].split("(")[0]
+            for (disp, cname), val in per_dispatch.items():
+                acc[names[disp]][cname].append(val)
+    res = {}
+    for k in sorted(acc):
+        if not k.startswith("k_"):
+            continue
+        res[k] = {c: sum(v) / len(v) for c, v in acc[k].items()}
+        res[k]["launches"] = max(len(v) for v in acc[k].values())
+    cols = sorted({c for k in res for c in res[k] if c != "launches"})
+    print("%-22s %8s " % ("kernel", "launches") + " ".join("%16s" % c[:16] for c in cols))
+    for k, d in res.items():
+        print("%-22s %8d " % (k, d["launches"]) + " ".join("%16.1f" % d.get(c, float("nan")) for c in cols))
+    if out_json:
+        for k, d in res.items():
+            if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+                d["hbm_bytes_per_launch"] = (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0
+        json.dump(res, open(out_json, "w"), indent=1)
+
+if __name__ == "__main__":
+    main()
