@@ -29,10 +29,12 @@
 //   suffix_i   = (output pixel) - (prefix colour through i) = everything behind i incl. background
 //   dL/dalpha_i = T_i (c_i . g) - (suffix_i . g) / (1 - alpha_i)
 // which is the upstream back-to-front recurrence rearranged.
-// Persistent workgroups pull items from a queue; wave w owns the 8x8 quadrant (w&1, w>>1) and
-// walks only the entries whose footprint can reach it (mgr_box_dead).  The 64 pixels of a wave
-// are reduced with DPP row operations, the 4 waves through LDS in a fixed order, and one 48-byte
-// record per (tile, Gaussian) pair is written, tagged with the call's epoch.
+// Persistent workgroups pull items from a queue; wave w owns the 8x8 quadrant (w&1, w>>1).  Like
+// the forward pass each wave walks the chunk on its own: 64 entries per batch, tested against the
+// bounding box of the quadrant's pixels that reach this chunk (mgr_box_dead), survivors compacted
+// pairwise into the wave's LDS slab, two entries per step with packed fp32 math.  The 64 pixels
+// of a wave are reduced with lane-half exchanges + DPP, the 4 waves through LDS in a fixed order,
+// and one 48-byte record per (tile, Gaussian) pair is written, tagged with the call's epoch.
 __global__ __launch_bounds__(256) void k_blend_bwd(
     int N, int W, int H, int gx, int gy, const uint32_t* __restrict__ tile_start,
     const uint32_t* __restrict__ sorted_gid, const MgrGRec* __restrict__ grec,
@@ -41,12 +43,9 @@ __global__ __launch_bounds__(256) void k_blend_bwd(
     const unsigned long long* __restrict__ items, MgrHeader* hdr, const float* __restrict__ out_color,
     const float* __restrict__ dL_dpix, uint32_t* __restrict__ pair_tag, float4* __restrict__ pair_grad,
     uint32_t cap, uint32_t epoch) {
-    __shared__ float2 s_xy[BWD_BATCH];
-    __shared__ float4 s_co[BWD_BATCH];
-    __shared__ float s_rgb[BWD_BATCH * 3];
+    __shared__ __align__(16) float s_pair[4][32][MGR_PAIR_FLOATS];
     __shared__ int32_t s_slot[BWD_BATCH];
     __shared__ uint32_t s_touch[BWD_BATCH];
-    __shared__ unsigned long long s_mask[BWD_SW][4];
     __shared__ float s_acc[4][BWD_BATCH][9];
     __shared__ uint32_t s_item;
 
@@ -54,7 +53,10 @@ __global__ __launch_bounds__(256) void k_blend_bwd(
     const int T = gx * gy;
     const uint32_t n_items = hdr->n_items;
     const size_t P = (size_t)W * H;
-    const float ddelx = 0.5f * (float)W, ddely = 0.5f * (float)H;
+    // screen-space mean gradient: d(pixel)/d(ndc) = W/2, H/2; ln2 from the log2-domain conic
+    const float kx = MGR_LN2 * 0.5f * (float)W, ky = MGR_LN2 * 0.5f * (float)H;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    float* const slab = &s_pair[wave][0][0];
 
     for (;;) {
         __syncthreads();  // previous item fully flushed
@@ -73,36 +75,30 @@ __global__ __launch_bounds__(256) void k_blend_bwd(
         const int px = bx * 16 + (wave & 1) * 8 + (lane & 7);
         const int py = by * 16 + (wave >> 1) * 8 + (lane >> 3);
         const bool inside = px < W && py < H;
-        const float fpx = (float)px, fpy = (float)py;
-        const float tx0 = (float)(bx * 16), ty0 = (float)(by * 16);
+        const mgr_v2f fpx2 = {(float)px, (float)px}, fpy2 = {(float)py, (float)py};
+        const float qx0 = (float)(bx * 16 + (wave & 1) * 8), qy0 = (float)(by * 16 + (wave >> 1) * 8);
         const size_t pix = (size_t)py * W + px;
+        const MgrGRec* const gv = grec + (size_t)v * N;
 
-        // stage the chunk (front to back) and the per-quadrant survivor masks
-        if (tid < BWD_BATCH) {
-            bool d0 = true, d1 = true, d2 = true, d3 = true;
-            if (tid < cnt) {
-                const uint32_t gid = sorted_gid[start + first + tid];
-                const MgrGRec* r = grec + (size_t)v * N + gid;
-                const float4 a = *(const float4*)r;
-                const float4 b = *((const float4*)r + 1);
+        // this wave's two 64-entry batches: index and record of entry j = bi*64 + lane
+        float4 ra[BWD_SW], rb[BWD_SW];
+        float rc[BWD_SW];
+#pragma unroll
+        for (int bi = 0; bi < BWD_SW; ++bi) {
+            const int j = bi * 64 + lane;
+            ra[bi] = rb[bi] = make_float4(0.f, 0.f, 0.f, 0.f);
+            rc[bi] = 0.f;
+            if (j < cnt) {
+                const uint32_t gid = sorted_gid[start + first + j];
+                const MgrGRec* r = gv + gid;
+                ra[bi] = *(const float4*)r;
+                rb[bi] = *((const float4*)r + 1);
                 const float4 c = *((const float4*)r + 2);
-                s_xy[tid] = make_float2(a.x, a.y);
-                s_co[tid] = make_float4(a.z, a.w, b.x, b.y);
-                s_rgb[tid * 3 + 0] = b.z;
-                s_rgb[tid * 3 + 1] = b.w;
-                s_rgb[tid * 3 + 2] = c.x;
-                s_slot[tid] = __float_as_int(c.y) + by * __float_as_int(c.z) + bx;
-                const float qmax = mgr_qmax(b.y);
-                d0 = mgr_box_dead(a.x, a.y, a.z, a.w, b.x, qmax, tx0, ty0, tx0 + 7.f, ty0 + 7.f);
-                d1 = mgr_box_dead(a.x, a.y, a.z, a.w, b.x, qmax, tx0 + 8.f, ty0, tx0 + 15.f, ty0 + 7.f);
-                d2 = mgr_box_dead(a.x, a.y, a.z, a.w, b.x, qmax, tx0, ty0 + 8.f, tx0 + 7.f, ty0 + 15.f);
-                d3 = mgr_box_dead(a.x, a.y, a.z, a.w, b.x, qmax, tx0 + 8.f, ty0 + 8.f, tx0 + 15.f, ty0 + 15.f);
+                rc[bi] = c.x;
+                // wave bi records the pair slot of entry j for the flush
+                if (wave == bi) s_slot[j] = __float_as_int(c.y) + by * __float_as_int(c.z) + bx;
             }
-            s_touch[tid] = 0;
-            const unsigned long long m0 = __ballot(!d0), m1 = __ballot(!d1), m2 = __ballot(!d2), m3 = __ballot(!d3);
-            if (lane == 0) {
-                s_mask[wave][0] = m0; s_mask[wave][1] = m1; s_mask[wave][2] = m2; s_mask[wave][3] = m3;
-            }
+            if (wave == bi) s_touch[j] = 0;
         }
         // per-pixel state in front of the chunk
         float Tr = 1.0f, pg = 0.f, Og = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f;
@@ -124,58 +120,101 @@ __global__ __launch_bounds__(256) void k_blend_bwd(
         uint32_t wlast = last;  // deepest contributor of this wave's quadrant
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) wlast = max(wlast, (uint32_t)__shfl_xor((int)wlast, d, 64));
-        __syncthreads();
+        __syncthreads();  // s_touch cleared
 
-        if (wlast > first) {
+        int bx0, by0, bx1, by1;
+        if (mgr_quad_bbox(__ballot(last > first), bx0, by0, bx1, by1)) {
+            const float X0 = qx0 + (float)bx0, Y0 = qy0 + (float)by0, X1 = qx0 + (float)bx1, Y1 = qy0 + (float)by1;
+            const mgr_v2f g0v = {g0, g0}, g1v = {g1, g1}, g2v = {g2, g2};
 #pragma unroll 1
-            for (int sw = 0; sw < BWD_SW; ++sw) {
-                unsigned long long m = s_mask[sw][wave];
-                while (m) {
-                    const int j = sw * 64 + __builtin_ctzll(m);
-                    m &= m - 1;
-                    const uint32_t pos = first + (uint32_t)j;  // 0-based position in the tile list
-                    if (pos >= wlast) break;                    // wave-uniform; later entries are deeper still
-                    float v_mx = 0.f, v_my = 0.f, v_ca = 0.f, v_cb = 0.f, v_cc = 0.f, v_op = 0.f,
-                          v_r = 0.f, v_g = 0.f, v_b = 0.f;
-                    bool hit = false;
-                    if (pos < last) {
-                        const float2 xy = s_xy[j];
-                        const float4 co = s_co[j];
-                        const float dx = xy.x - fpx, dy = xy.y - fpy;
-                        const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-                        if (power <= 0.0f) {
-                            const float G = mgr_exp(power);
-                            const float alpha = fminf(0.99f, co.w * G);
-                            if (alpha >= 1.0f / 255.0f) {
-                                hit = true;
-                                const float w = alpha * Tr;
-                                const float cg = s_rgb[j * 3 + 0] * g0 + s_rgb[j * 3 + 1] * g1 + s_rgb[j * 3 + 2] * g2;
-                                pg += w * cg;                                   // prefix . g through this entry
-                                const float oma = 1.0f - alpha;
-                                const float dalpha = Tr * cg - (Og - pg) * __builtin_amdgcn_rcpf(oma);
-                                v_r = w * g0; v_g = w * g1; v_b = w * g2;
-                                Tr *= oma;
-                                const float dG = co.w * dalpha;
-                                const float gdx = G * dx, gdy = G * dy;
-                                const float dGdx = -gdx * co.x - gdy * co.y;
-                                const float dGdy = -gdy * co.z - gdx * co.y;
-                                v_mx = dG * dGdx * ddelx;
-                                v_my = dG * dGdy * ddely;
-                                v_ca = -0.5f * gdx * dx * dG;
-                                v_cb = -0.5f * gdx * dy * dG;
-                                v_cc = -0.5f * gdy * dy * dG;
-                                v_op = G * dalpha;
-                            }
+            for (int bi = 0; bi < BWD_SW; ++bi) {
+                const int j = bi * 64 + lane;
+                const float4 a4 = bi ? ra[1] : ra[0], b4 = bi ? rb[1] : rb[0];
+                const float c1 = bi ? rc[1] : rc[0];
+                bool alive = false;
+                if (j < cnt && first + (uint32_t)j < wlast)  // later entries are deeper than every pixel's last
+                    alive = !mgr_box_dead(a4.x, a4.y, a4.z, a4.w, b4.x, mgr_qmax(b4.y), X0, Y0, X1, Y1);
+                const unsigned long long m = __ballot(alive);
+                const int na = __popcll(m);
+                if (alive) {
+                    const int rank = __popcll(m & lt);
+                    float* pb = slab + (rank >> 1) * MGR_PAIR_FLOATS;
+                    mgr_pair_store(pb, rank & 1, a4.x, a4.y, a4.z, a4.w, b4.x, b4.y, b4.z, b4.w, c1,
+                                   first + (uint32_t)j + 1u);  // 1-based list position
+                    if ((na & 1) && rank == na - 1) mgr_pair_pad(pb);
+                }
+                const int npair = (na + 1) >> 1;
+                for (int p = 0; p < npair; ++p) {
+                    const float4* pp = (const float4*)(slab + p * MGR_PAIR_FLOATS);
+                    const float4 R0 = pp[0], R1 = pp[1], R2 = pp[2], R3 = pp[3], R4 = pp[4];
+                    mgr_v2f dx, dy, G, al;
+                    bool va, vb;
+                    mgr_pair_alpha(R0, R1, R2, fpx2, fpy2, dx, dy, G, al, va, vb);
+                    const uint32_t pa = __float_as_uint(R4.z), pbpos = __float_as_uint(R4.w);
+                    va = va && pa <= last;
+                    vb = vb && pbpos <= last;
+                    const bool anya = __ballot(va) != 0ull, anyb = __ballot(vb) != 0ull;  // wave-uniform
+                    if (!anya && !anyb) continue;
+                    const mgr_v2f cr = {R3.x, R3.y}, cgn = {R3.z, R3.w}, cb = {R4.x, R4.y};
+                    const mgr_v2f cg = cr * g0v + cgn * g1v + cb * g2v;
+                    mgr_v2f w2, da2;
+                    {
+                        const float a = va ? al.x : 0.0f;
+                        const float w = a * Tr;
+                        pg += w * cg.x;  // prefix . g through this entry
+                        const float oma = 1.0f - a;
+                        const float d = Tr * cg.x - (Og - pg) * __builtin_amdgcn_rcpf(oma);
+                        Tr *= oma;
+                        w2.x = w;
+                        da2.x = va ? d : 0.0f;
+                    }
+                    {
+                        const float a = vb ? al.y : 0.0f;
+                        const float w = a * Tr;
+                        pg += w * cg.y;
+                        const float oma = 1.0f - a;
+                        const float d = Tr * cg.y - (Og - pg) * __builtin_amdgcn_rcpf(oma);
+                        Tr *= oma;
+                        w2.y = w;
+                        da2.y = vb ? d : 0.0f;
+                    }
+                    const mgr_v2f A2 = {R1.x, R1.y}, B2 = {R1.z, R1.w}, C2 = {R2.x, R2.y}, o2 = {R2.z, R2.w};
+                    const mgr_v2f v_r = w2 * g0v, v_g = w2 * g1v, v_b = w2 * g2v;
+                    const mgr_v2f dG = o2 * da2;
+                    const mgr_v2f gdx = G * dx, gdy = G * dy;
+                    const mgr_v2f Bh = B2 * 0.5f;
+                    // dG/ddx = -gdx conic.x - gdy conic.y = 2 ln2 (A gdx + B/2 gdy)
+                    const mgr_v2f v_mx = dG * (A2 * gdx + Bh * gdy) * (2.0f * kx);
+                    const mgr_v2f v_my = dG * (C2 * gdy + Bh * gdx) * (2.0f * ky);
+                    const mgr_v2f h = dG * -0.5f;
+                    const mgr_v2f hx = h * gdx, hy = h * gdy;
+                    const mgr_v2f v_ca = hx * dx, v_cb = hx * dy, v_cc = hy * dy;
+                    const mgr_v2f v_op = G * da2;
+                    // slots 0..7 by the two-at-a-time exchange reduction, slot 8 (blue) for both
+                    // entries at once: halves exchanged, then summed inside each 32-lane half
+                    const float w8a = mgr_wave_reduce8(v_mx.x, v_my.x, v_ca.x, v_cb.x, v_cc.x, v_op.x, v_r.x, v_g.x, lane);
+                    const float w8b = mgr_wave_reduce8(v_mx.y, v_my.y, v_ca.y, v_cb.y, v_cc.y, v_op.y, v_r.y, v_g.y, lane);
+                    float ba = v_b.x, bb = v_b.y;
+                    mgr_swap32(ba, bb);
+                    float b9 = ba + bb;              // lanes 0-31: entry a, lanes 32-63: entry b
+                    b9 += mgr_dpp<0xb1>(b9);         // quad_perm [1,0,3,2]
+                    b9 += mgr_dpp<0x4e>(b9);         // quad_perm [2,3,0,1]
+                    b9 += mgr_dpp<0x141>(b9);        // row_half_mirror
+                    b9 += mgr_dpp<0x140>(b9);        // row_mirror
+                    b9 += mgr_dpp<0x142, 0xa>(b9);   // row_bcast:15 -> rows 1,3: totals in lanes 31 / 63
+                    const int ja = (int)(pa - 1u - first), jb = (int)(pbpos - 1u - first);
+                    if (anya) {
+                        if ((lane & 7) == 0) s_acc[wave][ja][MGR_R8_SLOT(lane >> 3)] = w8a;
+                        if (lane == 31) {
+                            s_acc[wave][ja][8] = b9;
+                            atomicOr(&s_touch[ja], 1u << wave);
                         }
                     }
-                    if (__ballot(hit) != 0ull) {  // wave-uniform
-                        // slots 0..7 by the two-at-a-time exchange reduction, slot 8 by the DPP chain
-                        const float w8 = mgr_wave_reduce8(v_mx, v_my, v_ca, v_cb, v_cc, v_op, v_r, v_g, lane);
-                        v_b = mgr_wave_sum63(v_b);
-                        if ((lane & 7) == 0) s_acc[wave][j][MGR_R8_SLOT(lane >> 3)] = w8;
+                    if (anyb) {
+                        if ((lane & 7) == 0) s_acc[wave][jb][MGR_R8_SLOT(lane >> 3)] = w8b;
                         if (lane == 63) {
-                            s_acc[wave][j][8] = v_b;
-                            atomicOr(&s_touch[j], 1u << wave);
+                            s_acc[wave][jb][8] = b9;
+                            atomicOr(&s_touch[jb], 1u << wave);
                         }
                     }
                 }
@@ -205,8 +244,6 @@ __global__ __launch_bounds__(256) void k_blend_bwd(
     }
 }
 
-// ---------------------------------------------------------------------------
-// per-Gaussian: gather own pair records, then conic->Sigma3D and mean2D->mean3D
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_preprocess_bwd(
     int N, int W, int H, const float* __restrict__ cams, const float* __restrict__ means3D,
@@ -460,7 +497,7 @@ static int raster_backward_impl(int V, int N, int W, int H, const float* cams, c
     if (epoch == 0) epoch = g_epoch.fetch_add(1) + 1;
 
     MGR_HIP(hipMemsetAsync(&hdr->item_head, 0, 4, stream));
-    { MGR_PROF("k_blend_bwd", stream); hipLaunchKernelGGL(k_blend_bwd, dim3(256 * 5), dim3(256), 0, stream, N, W, H, gx, gy,
+    { MGR_PROF("k_blend_bwd", stream); hipLaunchKernelGGL(k_blend_bwd, dim3(256 * 4), dim3(256), 0, stream, N, W, H, gx, gy,
                        (const uint32_t*)(ws + L.tile_start), (const uint32_t*)(ws + L.sorted_gid),
                        (const MgrGRec*)(ws + L.grec), (const uint32_t*)(ws + L.n_contrib),
                        (const uint32_t*)(ws + L.tile_done), (const uint32_t*)(ws + L.chunk_start),
