@@ -35,7 +35,7 @@
 // pairwise into the wave's LDS slab, two entries per step with packed fp32 math.  The 64 pixels
 // of a wave are reduced with lane-half exchanges + DPP, the 4 waves through LDS in a fixed order,
 // and one 48-byte record per (tile, Gaussian) pair is written, tagged with the call's epoch.
-__global__ __launch_bounds__(256) void k_blend_bwd(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_blend_bwd(
     int N, int W, int H, int gx, int gy, const uint32_t* __restrict__ tile_start,
     const uint32_t* __restrict__ sorted_gid, const MgrGRec* __restrict__ grec,
     const uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ tile_done,
@@ -497,7 +497,7 @@ static int raster_backward_impl(int V, int N, int W, int H, const float* cams, c
     if (epoch == 0) epoch = g_epoch.fetch_add(1) + 1;
 
     MGR_HIP(hipMemsetAsync(&hdr->item_head, 0, 4, stream));
-    { MGR_PROF("k_blend_bwd", stream); hipLaunchKernelGGL(k_blend_bwd, dim3(256 * 4), dim3(256), 0, stream, N, W, H, gx, gy,
+    { MGR_PROF("k_blend_bwd", stream); hipLaunchKernelGGL(k_blend_bwd, dim3(256 * 5), dim3(256), 0, stream, N, W, H, gx, gy,
                        (const uint32_t*)(ws + L.tile_start), (const uint32_t*)(ws + L.sorted_gid),
                        (const MgrGRec*)(ws + L.grec), (const uint32_t*)(ws + L.n_contrib),
                        (const uint32_t*)(ws + L.tile_done), (const uint32_t*)(ws + L.chunk_start),
