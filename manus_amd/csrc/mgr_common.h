@@ -285,30 +285,45 @@ __device__ __forceinline__ void mgr_sym_mul(const float c6[6], const float m[3],
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ float mgr_qmax(float opacity) { return 2.0f * __logf(255.0f * opacity); }
 
+// The minimum of the convex quadratic over the box is found coordinate by coordinate, exactly:
+//   dyk = the row of the box nearest the centre; on that line q is smallest at dxo = -B dyk / A,
+//   and min over the strip as a function of dx is convex with its minimum at dxo, so inside the
+//   box it is smallest at dxe = clamp(dxo); there the best dy is dye = clamp(-B dxe / C).
+struct MgrCull {
+    float cx, cy, A, B, C, nBiA, nBiC, thr;
+    bool pd;
+};
+
+__device__ __forceinline__ MgrCull mgr_cull_init(float cx, float cy, float A, float B, float C, float qmax) {
+    MgrCull c;
+    c.cx = cx; c.cy = cy; c.A = A; c.B = B; c.C = C;
+    c.pd = A > 0.0f && C > 0.0f && A * C - B * B > 0.0f;
+    c.nBiA = -B * __builtin_amdgcn_rcpf(A);
+    c.nBiC = -B * __builtin_amdgcn_rcpf(C);
+    c.thr = qmax + 0.01f;
+    return c;
+}
+
+// row part: dy range of the box and the x of the row-constrained minimum
+__device__ __forceinline__ void mgr_cull_row(const MgrCull& c, float y0, float y1, float& dy_lo, float& dy_hi, float& dxo) {
+    dy_lo = y0 - c.cy;
+    dy_hi = y1 - c.cy;
+    dxo = c.nBiA * __builtin_amdgcn_fmed3f(0.0f, dy_lo, dy_hi);
+}
+
+__device__ __forceinline__ bool mgr_cull_dead(const MgrCull& c, float dy_lo, float dy_hi, float dxo, float x0, float x1) {
+    const float dxe = __builtin_amdgcn_fmed3f(dxo, x0 - c.cx, x1 - c.cx);
+    const float dye = __builtin_amdgcn_fmed3f(c.nBiC * dxe, dy_lo, dy_hi);
+    const float t0 = c.A * dxe * dxe, t1 = 2.0f * c.B * dxe * dye, t2 = c.C * dye * dye;
+    return c.pd && (t0 + t1 + t2 > c.thr + 1.0e-5f * (t0 + fabsf(t1) + t2));
+}
+
 __device__ __forceinline__ bool mgr_box_dead(float cx, float cy, float A, float B, float C, float qmax,
                                              float x0, float y0, float x1, float y1) {
-    if (!(A > 0.0f && C > 0.0f && A * C - B * B > 0.0f)) return false;
-    const float invA = __builtin_amdgcn_rcpf(A), invC = __builtin_amdgcn_rcpf(C);
-    const bool in_x = cx >= x0 && cx <= x1, in_y = cy >= y0 && cy <= y1;
-    if (in_x && in_y) return !(qmax >= -0.01f);  // centre inside the box: q_min = 0
-    float best = 3.0e38f, bestM = 0.0f;
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {  // vertical edges x = x0 / x1
-        const float dx = (e ? x1 : x0) - cx;
-        const float y = fminf(fmaxf(cy - B * dx * invC, y0), y1), dy = y - cy;
-        const float t0 = A * dx * dx, t1 = 2.0f * B * dx * dy, t2 = C * dy * dy;
-        const float q = t0 + t1 + t2;
-        if (q < best) { best = q; bestM = t0 + fabsf(t1) + t2; }
-    }
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {  // horizontal edges y = y0 / y1
-        const float dy = (e ? y1 : y0) - cy;
-        const float x = fminf(fmaxf(cx - B * dy * invA, x0), x1), dx = x - cx;
-        const float t0 = A * dx * dx, t1 = 2.0f * B * dx * dy, t2 = C * dy * dy;
-        const float q = t0 + t1 + t2;
-        if (q < best) { best = q; bestM = t0 + fabsf(t1) + t2; }
-    }
-    return best > qmax + 0.01f + 1.0e-5f * bestM;
+    const MgrCull c = mgr_cull_init(cx, cy, A, B, C, qmax);
+    float dy_lo, dy_hi, dxo;
+    mgr_cull_row(c, y0, y1, dy_lo, dy_hi, dxo);
+    return mgr_cull_dead(c, dy_lo, dy_hi, dxo, x0, x1);
 }
 
 // Bounding box (in 8x8-quadrant-local pixel units) of the lanes set in `am`, lane = y*8 + x.

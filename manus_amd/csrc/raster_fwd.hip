@@ -140,20 +140,21 @@ __device__ __forceinline__ void pre_tail(int N, int gx, int gy, int v, int i, co
     unsigned long long amask = ~0ull;
     if (radius > 0) {
         const bool small = tiles <= 64;
-        const float qmax = mgr_qmax(op_i);
+        const MgrCull cull = mgr_cull_init(po.px, po.py, po.ca, po.cb, po.cc, mgr_qmax(op_i));
         if (small) amask = 0ull;
         int k = 0;
-        for (int y = y0; y < y1; ++y)
+        for (int y = y0; y < y1; ++y) {
+            float dy_lo, dy_hi, dxo;
+            mgr_cull_row(cull, 16.0f * y, 16.0f * y + 15.0f, dy_lo, dy_hi, dxo);
             for (int x = x0; x < x1; ++x, ++k) {
                 if (small) {
-                    if (mgr_box_dead(po.px, po.py, po.ca, po.cb, po.cc, qmax, 16.0f * x, 16.0f * y, 16.0f * x + 15.0f,
-                                     16.0f * y + 15.0f))
-                        continue;
+                    if (mgr_cull_dead(cull, dy_lo, dy_hi, dxo, 16.0f * x, 16.0f * x + 15.0f)) continue;
                     amask |= 1ull << k;
                 }
                 if (lds_hist) atomicAdd(&s_hist[y * gx + x], 1u);
                 else atomicAdd(&tile_count[(size_t)v * T + y * gx + x], 1u);
             }
+        }
     }
     uint32_t block_total;
     const uint32_t local = block_excl_scan(tiles, s_scan, block_total);
