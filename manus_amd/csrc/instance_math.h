@@ -376,14 +376,25 @@ __device__ __forceinline__ void gather_pair_grads(uint32_t off, uint32_t cnt, co
                                                   float acc[9]) {
 #pragma unroll
     for (int k = 0; k < 9; ++k) acc[k] = 0.f;
-    for (uint32_t k = 0; k < cnt; ++k) {
-        const uint32_t slot = off + k;
-        if (slot < cap && pair_tag[slot] == epoch) {
-            const float4* r = pair_grad + (size_t)slot * 3;
-            const float4 a = r[0], b = r[1], c = r[2];
-            acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
-            acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w;
-            acc[8] += c.x;
+    // four tags in flight per step (the loop is latency bound otherwise); records are still added
+    // in ascending slot order
+    const uint32_t miss = epoch ^ 1u;
+    for (uint32_t k = 0; k < cnt; k += 4) {
+        uint32_t tg[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+            const uint32_t slot = off + k + j;
+            tg[j] = (k + j < cnt && slot < cap) ? pair_tag[slot] : miss;
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+            if (tg[j] == epoch) {
+                const float4* r = pair_grad + (size_t)(off + k + j) * 3;
+                const float4 a = r[0], b = r[1], c = r[2];
+                acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
+                acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w;
+                acc[8] += c.x;
+            }
         }
     }
 }

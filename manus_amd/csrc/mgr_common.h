@@ -69,7 +69,8 @@ struct MgrHeader {            // first 256 bytes of the workspace
     uint32_t item_head;       // backward work-queue cursor
     uint32_t queue_small;     // queue index of the first tile with fewer than 2048 pairs
     uint32_t queue_head3;     // cursor of the small-tile sort
-    uint32_t pad[6];
+    uint32_t n_active;        // Gaussians with a non-zero pair gradient in the current view group (fused backward)
+    uint32_t pad[5];
     uint32_t cls_count[34];   // tiles per size class (class = bit length of the pair count, 0 = empty)
     uint32_t cls_cursor[34];  // running cursors of the queue scatter
     uint32_t queue_giant;     // queue index of the first tile with fewer than 16384 pairs
@@ -127,7 +128,7 @@ static inline MgrLayout mgr_layout(int V, int N, int W, int H, int64_t cap) {
     L.n_contrib = o;   o += mgr_align(VP * 4);
     L.pair_tag = o;    o += mgr_align(c * 4);
     L.pair_grad = o;   o += mgr_align(c * 48);
-    L.inst_grad = o;   o += mgr_align(VN * 128);    // fused backward: 32 floats per (view, Gaussian)
+    L.inst_grad = o;   o += mgr_align(VN * 128);    // fused backward: 12 floats per (Gaussian, view) + active list
     L.total = o;
     return L;
 }

@@ -458,6 +458,305 @@ __global__ __launch_bounds__(256) void k_inst_bwd_c(
     if (st_radii) st_radii[i] = maxrad;
 }
 
+// ---------------------------------------------------------------------------
+// Fused per-instance backward, one thread per (Gaussian, view) with the G views of a Gaussian
+// in G adjacent lanes (lane = instance_local * G + view_local):
+//   * per-Gaussian loads (canonical parameters, skin weights, SH coefficients) are shared by the
+//     G lanes of a group, so a wave touches 64/G records instead of 64 per load;
+//   * per-view data (camera, bone transforms) sits in LDS, one padded slab per view;
+//   * every lane does the whole chain for its view -- pair-gradient gather, projection backward,
+//     SH backward, LBS backward -- and the per-view contributions are summed across the group
+//     with DPP (fixed tree: deterministic), by a transposing reduce-scatter when G = 8 so that
+//     lane k ends up with output k of each block of 8 and the stores of a group are contiguous;
+//   * nothing is staged through global memory between the phases.
+// `accumulate` adds to the outputs instead of writing them (view groups beyond the first).
+// ---------------------------------------------------------------------------
+template <int G>
+__device__ __forceinline__ float grp_sum(float x) {  // all lanes of the group receive the total
+    if (G >= 2) x += mgr_dpp<0xb1>(x);   // quad_perm [1,0,3,2]
+    if (G >= 4) x += mgr_dpp<0x4e>(x);   // quad_perm [2,3,0,1]
+    if (G >= 8) x += mgr_dpp<0x141>(x);  // row_half_mirror
+    return x;
+}
+
+// 8 values per lane, 8 lanes per group -> lane k of the group returns the group total of x[k]
+__device__ __forceinline__ float grp8_reduce_scatter(const float x[8], int vl) {
+    const bool b2 = (vl & 4) != 0, b1 = (vl & 2) != 0, b0 = (vl & 1) != 0;
+    float y[4], z[2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) y[k] = (b2 ? x[k + 4] : x[k]) + mgr_dpp<0x141>(b2 ? x[k] : x[k + 4]);  // partner 7 - j
+#pragma unroll
+    for (int k = 0; k < 2; ++k) z[k] = (b1 ? y[k + 2] : y[k]) + mgr_dpp<0x4e>(b1 ? y[k] : y[k + 2]);   // partner j ^ 2
+    return (b0 ? z[1] : z[0]) + mgr_dpp<0xb1>(b0 ? z[0] : z[1]);                                        // partner j ^ 1
+}
+
+// Sum x[0..7] over the group and store them at dst[0..n) (n <= 8).
+template <int G>
+__device__ __forceinline__ void grp_store8(const float x[8], int vl, bool ok, float* __restrict__ dst, int n,
+                                           bool accumulate) {
+    if (G == 8) {
+        const float t = grp8_reduce_scatter(x, vl);
+        if (ok && vl < n) dst[vl] = accumulate ? dst[vl] + t : t;
+    } else {
+        float t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = grp_sum<G>(x[k]);
+        if (ok && vl == 0) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (k < n) dst[k] = accumulate ? dst[k] + t[k] : t[k];
+        }
+    }
+}
+
+#ifndef MGR_IB_WAVES
+#define MGR_IB_WAVES 3
+#endif
+#define IG_ROUNDS 8  // lane-group rounds per workgroup of the gather (amortises the list append)
+#define IB_TSTRIDE(B) ((B) * 16 + 4)  // LDS words per view of bone transforms (+4: the G slabs fall in distinct banks)
+
+// Phase 1: gather.  Sums the pair-gradient records of every (Gaussian, view), keeps the 9 sums
+// for phase 2, appends the Gaussians that received anything in this view group to the active
+// list, writes the per-Gaussian statistics (visibility count, max radius) and -- unless
+// accumulating -- zero gradients for the Gaussians that received nothing.
+template <int G>
+__global__ __launch_bounds__(256) void k_inst_gather(
+    int v_first, int v_count, int N, int B, const int32_t* __restrict__ radii, const ushort4* __restrict__ rect,
+    const uint32_t* __restrict__ pair_off, const uint32_t* __restrict__ pair_tag,
+    const float4* __restrict__ pair_grad, uint32_t cap, uint32_t epoch, int accumulate, float4* __restrict__ iacc,
+    uint32_t* __restrict__ active_list, MgrHeader* hdr, float* __restrict__ d_xyz, float* __restrict__ d_ls,
+    float* __restrict__ d_rot, float* __restrict__ d_op, float* __restrict__ d_fdc, float* __restrict__ d_frest,
+    float* __restrict__ d_w, float* __restrict__ st_grad2d, float* __restrict__ st_vis,
+    int32_t* __restrict__ st_radii) {
+    constexpr int IPB = 256 / G;
+    __shared__ uint32_t s_list[IPB * IG_ROUNDS];
+    __shared__ uint32_t s_cnt, s_base;
+    const int tid = threadIdx.x, vl = tid & (G - 1), il = tid / G, lane = tid & 63;
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    const bool acc_out = accumulate != 0;
+#pragma unroll 1
+    for (int rnd = 0; rnd < IG_ROUNDS; ++rnd) {
+        const int i_raw = (blockIdx.x * IG_ROUNDS + rnd) * IPB + il;
+        const int i = min(i_raw, N - 1);
+        const bool ok = i_raw < N, mine = ok && vl < v_count;
+        const int v = v_first + vl;
+        float acc[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) acc[k] = 0.f;
+        int rad = 0;
+        bool any = false;
+        if (mine) {
+            const size_t vi = (size_t)v * N + i;
+            rad = radii[vi];
+            if (rad > 0) {
+                const ushort4 rc = rect[vi];
+                gather_pair_grads(pair_off[vi], (uint32_t)((rc.z - rc.x) * (rc.w - rc.y)), pair_tag, pair_grad, cap, epoch,
+                                  acc);
+#pragma unroll
+                for (int k = 0; k < 9; ++k) any = any || (acc[k] != 0.f);
+            }
+        }
+        const bool grp_any = grp_sum<G>(any ? 1.0f : 0.0f) > 0.0f;
+        const float vis = grp_sum<G>(rad > 0 ? 1.0f : 0.0f);
+        int maxrad = rad;
+        if (G >= 2) maxrad = max(maxrad, __builtin_amdgcn_update_dpp(0, maxrad, 0xb1, 0xf, 0xf, false));
+        if (G >= 4) maxrad = max(maxrad, __builtin_amdgcn_update_dpp(0, maxrad, 0x4e, 0xf, 0xf, false));
+        if (G >= 8) maxrad = max(maxrad, __builtin_amdgcn_update_dpp(0, maxrad, 0x141, 0xf, 0xf, false));
+        if (ok && grp_any) {  // phase 2 reads these back, lane for lane
+            float4* o = iacc + ((size_t)i * G + vl) * 3;
+            o[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            o[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+            o[2] = make_float4(acc[8], 0.f, 0.f, 0.f);
+        }
+        {   // active Gaussians of the block are collected in LDS (one LDS atomic per wave and round)
+            const bool lead = ok && grp_any && vl == 0;
+            const unsigned long long m = __ballot(lead);
+            if (m) {
+                const int first = __builtin_ctzll(m);
+                uint32_t base = 0;
+                if (lane == first) base = atomicAdd(&s_cnt, (uint32_t)__popcll(m));
+                base = (uint32_t)__shfl((int)base, first, 64);
+                if (lead) s_list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)i;
+            }
+        }
+        if (ok && vl == 0) {
+            if (st_vis) st_vis[i] = acc_out ? st_vis[i] + vis : vis;
+            if (st_radii) st_radii[i] = acc_out ? max(st_radii[i], maxrad) : maxrad;
+        }
+        if (ok && !grp_any && !acc_out) {  // nothing reached this Gaussian: zero gradients, G lanes interleaved
+            for (int e = vl; e < 3; e += G) { d_xyz[3 * i + e] = 0.f; d_ls[3 * i + e] = 0.f; d_fdc[(size_t)i * 3 + e] = 0.f; }
+            for (int e = vl; e < 4; e += G) d_rot[4 * i + e] = 0.f;
+            for (int e = vl; e < 45; e += G) d_frest[(size_t)i * 45 + e] = 0.f;
+            if (d_w)
+                for (int e = vl; e < B; e += G) d_w[(size_t)i * B + e] = 0.f;
+            if (vl == 0) {
+                d_op[i] = 0.f;
+                if (st_grad2d) st_grad2d[i] = 0.f;
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t cnt = s_cnt;
+    if (tid == 0 && cnt) s_base = atomicAdd(&hdr->n_active, cnt);  // one global atomic per block
+    __syncthreads();
+    for (uint32_t k = tid; k < cnt; k += 256) active_list[s_base + k] = s_list[k];
+}
+
+// Phase 2: the whole per-view backward chain for the active Gaussians only.
+template <int G, int BMAX>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MGR_IB_WAVES, MGR_IB_WAVES))) void k_inst_bwd(
+    int v_first, int v_count, int N, int B, int W, int H, const float* __restrict__ cams,
+    const float* __restrict__ xyz, const float* __restrict__ log_scale, const float* __restrict__ rot,
+    const float* __restrict__ op_logit, const float* __restrict__ f_dc, const float* __restrict__ f_rest,
+    const float* __restrict__ skin_w, const float* __restrict__ transforms, const float4* __restrict__ iacc,
+    const uint32_t* __restrict__ active_list, const MgrHeader* __restrict__ hdr, float grad2d_scale, int accumulate,
+    float* __restrict__ d_xyz, float* __restrict__ d_ls, float* __restrict__ d_rot, float* __restrict__ d_op,
+    float* __restrict__ d_fdc, float* __restrict__ d_frest, float* __restrict__ d_w, float* __restrict__ st_grad2d) {
+    constexpr int IPB = 256 / G;
+    extern __shared__ __align__(16) float s_view[];  // G x (camera 40 | transforms IB_TSTRIDE(B))
+    const int n_active = (int)hdr->n_active;
+    if ((int)blockIdx.x * IPB >= n_active) return;
+    const int tid = threadIdx.x, vl = tid & (G - 1), il = tid / G;
+    const int q = blockIdx.x * IPB + il;
+    const bool ok = q < n_active;             // lane's Gaussian exists (all lanes stay for the DPP sums)
+    const int i = (int)active_list[min(q, n_active - 1)];
+    const bool has_tf = skin_w != nullptr;
+    const int tstride = IB_TSTRIDE(B), vstride = MGR_CAM_FLOATS + (has_tf ? tstride : 0);
+    for (int k = tid; k < G * MGR_CAM_FLOATS; k += 256) {
+        const int g = k / MGR_CAM_FLOATS, e = k % MGR_CAM_FLOATS;
+        s_view[g * vstride + e] = g < v_count ? cams[(size_t)(v_first + g) * MGR_CAM_FLOATS + e] : 0.f;
+    }
+    if (has_tf)
+        for (int k = tid; k < G * B * 16; k += 256) {
+            const int g = k / (B * 16), e = k % (B * 16);
+            s_view[g * vstride + MGR_CAM_FLOATS + e] = g < v_count ? transforms[(size_t)(v_first + g) * B * 16 + e] : 0.f;
+        }
+    __syncthreads();
+    const float* const Tp = s_view + vl * vstride + MGR_CAM_FLOATS;
+
+    float acc[9];
+    bool any = false;
+    {
+        const float4* o = iacc + ((size_t)i * G + vl) * 3;
+        const float4 a = o[0], b = o[1], c = o[2];
+        acc[0] = a.x; acc[1] = a.y; acc[2] = a.z; acc[3] = a.w;
+        acc[4] = b.x; acc[5] = b.y; acc[6] = b.z; acc[7] = b.w;
+        acc[8] = c.x;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) any = any || (acc[k] != 0.f);
+        any = any && ok && vl < v_count;
+    }
+    GaussCano g;
+    cano_load(xyz, log_scale, rot, i, g);
+    const bool acc_out = accumulate != 0;
+    // The chain is cut in two so that the 48 SH sums are reduced and stored before the LBS part
+    // needs its registers (the DPP sums cannot sit inside the divergent branch).
+    float tf[12], dm[3], dc6[6], gt[12], dxyz[3] = {0.f, 0.f, 0.f};
+    {
+        float dsh[48];
+#pragma unroll
+        for (int k = 0; k < 48; ++k) dsh[k] = 0.f;
+        if (any) {  // culled, or hidden behind saturated pixels everywhere, otherwise
+            MgrCam cam;
+            {
+                const float* p = s_view + vl * vstride;
+                cam.tanfovx = p[0];
+                cam.tanfovy = p[1];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    cam.view[k] = p[2 + k];
+                    cam.proj[k] = p[18 + k];
+                }
+                cam.campos[0] = p[34]; cam.campos[1] = p[35]; cam.campos[2] = p[36];
+            }
+            float p3[3], c6[6];
+            blend_tf(has_tf ? skin_w + (size_t)i * B : nullptr, Tp, B, tf);
+            lbs_apply(tf, g, p3, c6);
+            project_backward(cam, W, H, p3, c6, acc, dm, dc6);
+            const ShCoefMem c = {f_dc + (size_t)i * 3, f_rest + (size_t)i * 45};
+            const float gc[3] = {acc[6], acc[7], acc[8]};
+            ShDir D;
+            if (has_tf) sh_dir_xyz<true>(g.x, g.y, g.z, tf, cam.campos, D);
+            else sh_dir_xyz<false>(g.x, g.y, g.z, tf, cam.campos, D);
+#pragma unroll
+            for (int k = 0; k < 12; ++k) gt[k] = 0.f;
+            sh_backward_view(c, D, has_tf, gc, dsh, dxyz, gt);
+        }
+        // SH coefficient gradient: 48 floats = f_dc (3) | f_rest (45)
+#pragma unroll
+        for (int m = 0; m < 6; ++m) {
+            if (G == 8) {
+                const float t = grp8_reduce_scatter(dsh + 8 * m, vl);
+                const int e = 8 * m + vl;
+                float* dst = e < 3 ? d_fdc + (size_t)i * 3 + e : d_frest + (size_t)i * 45 + (e - 3);
+                if (ok) *dst = acc_out ? *dst + t : t;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int e = 8 * m + k;
+                    const float t = grp_sum<G>(dsh[e]);
+                    float* dst = e < 3 ? d_fdc + (size_t)i * 3 + e : d_frest + (size_t)i * 45 + (e - 3);
+                    if (ok && vl == 0) *dst = acc_out ? *dst + t : t;
+                }
+            }
+        }
+    }
+    float ds[3] = {0.f, 0.f, 0.f};
+    float dR[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float dw[BMAX];
+    float dop = 0.f, g2 = 0.f;
+#pragma unroll
+    for (int b = 0; b < BMAX; ++b) dw[b] = 0.f;
+    if (any) {
+        float dtf[12];
+        lbs_backward_view<true>(tf, g, dm, dc6, gt, dxyz, ds, dR, dtf);
+        if (has_tf) {
+#pragma unroll
+            for (int b = 0; b < BMAX; ++b) {
+                if (b < B) {
+                    const float* T = Tp + b * 16;
+                    float a = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 12; ++k) a += dtf[k] * T[k];
+                    dw[b] = a;
+                }
+            }
+        }
+        dop = acc[5];
+        g2 = sqrtf(acc[0] * acc[0] + acc[1] * acc[1]) * grad2d_scale;
+    }
+    if (has_tf && d_w) {
+#pragma unroll
+        for (int m = 0; m < BMAX / 8; ++m) grp_store8<G>(dw + 8 * m, vl, ok, d_w + (size_t)i * B + 8 * m, B - 8 * m, acc_out);
+    }
+    {
+        const float sg = 1.0f / (1.0f + expf(-op_logit[i]));
+        // xyz (3) | d/dlog s (3) | opacity logit | screen-space gradient norm
+        const float o8[8] = {dxyz[0], dxyz[1], dxyz[2], ds[0] * g.s[0], ds[1] * g.s[1], ds[2] * g.s[2],
+                             dop * sg * (1.0f - sg), g2};
+        float t8[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t8[k] = grp_sum<G>(o8[k]);
+        float tR[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) tR[k] = grp_sum<G>(dR[k]);
+        if (ok && vl == 0) {
+            float drot[4];
+            quat_backward(g, tR, drot);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                d_xyz[3 * i + k] = acc_out ? d_xyz[3 * i + k] + t8[k] : t8[k];
+                d_ls[3 * i + k] = acc_out ? d_ls[3 * i + k] + t8[3 + k] : t8[3 + k];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) d_rot[4 * i + k] = acc_out ? d_rot[4 * i + k] + drot[k] : drot[k];
+            d_op[i] = acc_out ? d_op[i] + t8[6] : t8[6];
+            if (st_grad2d) st_grad2d[i] = acc_out ? st_grad2d[i] + t8[7] : t8[7];
+        }
+    }
+}
+
 struct CanonGrads {  // fused articulated backward: canonical inputs and leaf-gradient outputs
     int B;
     const float *xyz, *log_scale, *rot, *op_logit, *f_dc, *f_rest, *skin_w, *transforms;
@@ -506,29 +805,52 @@ static int raster_backward_impl(int V, int N, int W, int H, const float* cams, c
                        (uint32_t)cap, epoch); }
     MGR_LAUNCH_CHECK("k_blend_bwd", stream, debug);
     if (canon) {
-        float4* ig = (float4*)(ws + L.inst_grad);
-        { MGR_PROF("k_inst_bwd_a", stream);
-          hipLaunchKernelGGL(k_inst_bwd_a, dim3((N + 255) / 256, V), dim3(256), 0, stream, N, canon->B, W, H, cams,
-                             canon->xyz, canon->log_scale, canon->rot, canon->skin_w, canon->transforms, canon->radii,
-                             (const ushort4*)(ws + L.rect), (const uint32_t*)(ws + L.pair_off),
-                             (const uint32_t*)(ws + L.pair_tag), (const float4*)(ws + L.pair_grad), ig,
-                             (uint32_t)cap, epoch); }
-        { MGR_PROF("k_inst_bwd_b", stream);
-          hipLaunchKernelGGL(k_inst_bwd_b, dim3((N + 255) / 256), dim3(256), 0, stream, V, N, canon->B, cams, canon->xyz,
-                             canon->f_dc, canon->f_rest, canon->skin_w, canon->transforms, ig, canon->d_fdc,
-                             canon->d_frest); }
-        MGR_PROF("k_inst_bwd_c", stream);
-        if (canon->B <= 24)
-            hipLaunchKernelGGL(k_inst_bwd_c<24>, dim3((N + 255) / 256), dim3(256), 0, stream, V, N, canon->B, canon->xyz,
-                               canon->log_scale, canon->rot, canon->op_logit, canon->skin_w, canon->transforms,
-                               canon->radii, (const float4*)ig, canon->grad2d_scale, canon->d_xyz, canon->d_ls,
-                               canon->d_rot, canon->d_op, canon->d_w, canon->st_grad2d, canon->st_vis, canon->st_radii);
-        else
-            hipLaunchKernelGGL(k_inst_bwd_c<MGR_MAX_BONES>, dim3((N + 255) / 256), dim3(256), 0, stream, V, N, canon->B,
-                               canon->xyz, canon->log_scale, canon->rot, canon->op_logit, canon->skin_w,
-                               canon->transforms, canon->radii, (const float4*)ig, canon->grad2d_scale, canon->d_xyz,
-                               canon->d_ls, canon->d_rot, canon->d_op, canon->d_w, canon->st_grad2d, canon->st_vis,
-                               canon->st_radii);
+        // views of a Gaussian share a lane group; more than 8 views go in groups of 8, the later
+        // groups adding to the outputs of the first
+        const int Gv = V <= 1 ? 1 : V <= 2 ? 2 : V <= 4 ? 4 : 8;
+        const int ipb = 256 / Gv;
+        const size_t lds = (size_t)Gv * (MGR_CAM_FLOATS + (canon->skin_w ? IB_TSTRIDE(canon->B) : 0)) * sizeof(float);
+        float4* iacc = (float4*)(ws + L.inst_grad);
+        uint32_t* alist = (uint32_t*)(ws + L.inst_grad + (size_t)N * Gv * 48);
+        const dim3 grid((N + ipb - 1) / ipb), grid_g((N + ipb * IG_ROUNDS - 1) / (ipb * IG_ROUNDS));
+        for (int v0 = 0; v0 < V; v0 += Gv) {
+            const int vc = V - v0 < Gv ? V - v0 : Gv;
+            const int accm = v0 > 0 ? 1 : 0;
+            MGR_HIP(hipMemsetAsync(&hdr->n_active, 0, 4, stream));
+#define MGR_IG_LAUNCH(GG)                                                                                             \
+    hipLaunchKernelGGL((k_inst_gather<GG>), grid_g, dim3(256), 0, stream, v0, vc, N, canon->B, canon->radii,            \
+                       (const ushort4*)(ws + L.rect), (const uint32_t*)(ws + L.pair_off),                             \
+                       (const uint32_t*)(ws + L.pair_tag), (const float4*)(ws + L.pair_grad), (uint32_t)cap, epoch,   \
+                       accm, iacc, alist, hdr, canon->d_xyz, canon->d_ls, canon->d_rot, canon->d_op, canon->d_fdc,    \
+                       canon->d_frest, canon->d_w, canon->st_grad2d, canon->st_vis, canon->st_radii)
+#define MGR_IB_LAUNCH(GG, BB)                                                                                         \
+    hipLaunchKernelGGL((k_inst_bwd<GG, BB>), grid, dim3(256), lds, stream, v0, vc, N, canon->B, W, H, cams, canon->xyz, \
+                       canon->log_scale, canon->rot, canon->op_logit, canon->f_dc, canon->f_rest, canon->skin_w,      \
+                       canon->transforms, (const float4*)iacc, (const uint32_t*)alist, (const MgrHeader*)hdr,         \
+                       canon->grad2d_scale, accm, canon->d_xyz, canon->d_ls, canon->d_rot, canon->d_op, canon->d_fdc, \
+                       canon->d_frest, canon->d_w, canon->st_grad2d)
+            {
+                MGR_PROF("k_inst_gather", stream);
+                if (Gv == 8) MGR_IG_LAUNCH(8);
+                else if (Gv == 4) MGR_IG_LAUNCH(4);
+                else if (Gv == 2) MGR_IG_LAUNCH(2);
+                else MGR_IG_LAUNCH(1);
+            }
+            MGR_PROF("k_inst_bwd", stream);
+            if (canon->B <= 24) {
+                if (Gv == 8) MGR_IB_LAUNCH(8, 24);
+                else if (Gv == 4) MGR_IB_LAUNCH(4, 24);
+                else if (Gv == 2) MGR_IB_LAUNCH(2, 24);
+                else MGR_IB_LAUNCH(1, 24);
+            } else {
+                if (Gv == 8) MGR_IB_LAUNCH(8, MGR_MAX_BONES);
+                else if (Gv == 4) MGR_IB_LAUNCH(4, MGR_MAX_BONES);
+                else if (Gv == 2) MGR_IB_LAUNCH(2, MGR_MAX_BONES);
+                else MGR_IB_LAUNCH(1, MGR_MAX_BONES);
+            }
+#undef MGR_IB_LAUNCH
+#undef MGR_IG_LAUNCH
+        }
     } else
     { MGR_PROF("k_preprocess_bwd", stream); hipLaunchKernelGGL(k_preprocess_bwd, dim3((N + 255) / 256, V), dim3(256), 0, stream, N, W, H, cams,
                        means3D, s_means, cov3D, s_cov, (const int32_t*)nullptr,

@@ -19,7 +19,7 @@ def main():
             for r in csv.DictReader(open(f)):
                 key = (r["Dispatch_Id"], r["Counter_Name"])
                 per_dispatch[key] += float(r["Counter_Value"])
-                names[r["Dispatch_Id"]] = r["Kernel_Name"].split("(")[0]
+                names[r["Dispatch_Id"]] = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
             for (disp, cname), val in per_dispatch.items():
                 acc[names[disp]][cname].append(val)
     res = {}
