@@ -93,7 +93,7 @@ struct __attribute__((aligned(16))) MgrGRec {
 
 struct MgrLayout {
     size_t header, scan_part, grec, depth, rect, alive, pair_off, tile_count, tile_start, tile_cursor, tile_done,
-        tile_queue, chunk_start, items, ckpt, keys, keys2, groups, sorted_gid, final_T, n_contrib, pair_tag, pair_grad, inst_grad, total;
+        tile_queue, chunk_start, items, ckpt, keys, keys2, groups, sorted_gid, final_T, n_contrib, pair_tag, pair_grad, inst_grad, inst_tag, total;
 };
 
 static inline size_t mgr_align(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -128,6 +128,7 @@ static inline MgrLayout mgr_layout(int V, int N, int W, int H, int64_t cap) {
     L.n_contrib = o;   o += mgr_align(VP * 4);
     L.pair_tag = o;    o += mgr_align(c * 4);
     L.pair_grad = o;   o += mgr_align(c * 48);
+    L.inst_tag = o;    o += mgr_align(VN * 4);      // epoch of the last backward that wrote a record for (view, Gaussian)
     L.inst_grad = o;   o += mgr_align(VN * 128);    // fused backward: 12 floats per (Gaussian, view) + active list
     L.total = o;
     return L;

@@ -42,9 +42,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     const uint32_t* __restrict__ chunk_start, const float4* __restrict__ ckpt,
     const unsigned long long* __restrict__ items, MgrHeader* hdr, const float* __restrict__ out_color,
     const float* __restrict__ dL_dpix, uint32_t* __restrict__ pair_tag, float4* __restrict__ pair_grad,
-    uint32_t cap, uint32_t epoch) {
+    uint32_t* __restrict__ inst_tag, uint32_t cap, uint32_t epoch) {
     __shared__ __align__(16) float s_pair[4][32][MGR_PAIR_FLOATS];
     __shared__ int32_t s_slot[BWD_BATCH];
+    __shared__ uint32_t s_gid[BWD_BATCH];
     __shared__ uint32_t s_touch[BWD_BATCH];
     __shared__ float s_acc[4][BWD_BATCH][9];
     __shared__ uint32_t s_item;
@@ -96,7 +97,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
                 const float4 c = *((const float4*)r + 2);
                 rc[bi] = c.x;
                 // wave bi records the pair slot of entry j for the flush
-                if (wave == bi) s_slot[j] = __float_as_int(c.y) + by * __float_as_int(c.z) + bx;
+                if (wave == bi) {
+                    s_slot[j] = __float_as_int(c.y) + by * __float_as_int(c.z) + bx;
+                    s_gid[j] = gid;
+                }
             }
             if (wave == bi) s_touch[j] = 0;
         }
@@ -239,6 +243,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
                 o[1] = make_float4(r[4], r[5], r[6], r[7]);
                 o[2] = make_float4(r[8], 0.f, 0.f, 0.f);
                 pair_tag[slot] = epoch;
+                inst_tag[(size_t)v * N + s_gid[tid]] = epoch;  // "this (view, Gaussian) has records": lets the gather skip the rest
             }
         }
     }
@@ -252,7 +257,8 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
     const uint32_t* __restrict__ pair_off, const uint32_t* __restrict__ pair_tag,
     const float4* __restrict__ pair_grad, float* __restrict__ dL_dmeans3D,
     float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dcolors,
-    float* __restrict__ dL_dopacity, float* __restrict__ dL_dcov3D, uint32_t cap, uint32_t epoch) {
+    float* __restrict__ dL_dopacity, float* __restrict__ dL_dcov3D, const uint32_t* __restrict__ inst_tag,
+    uint32_t cap, uint32_t epoch) {
     const int v = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
@@ -261,7 +267,7 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
     const uint32_t cnt = (uint32_t)((rc.z - rc.x) * (rc.w - rc.y));
     float acc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float dm[3] = {0.f, 0.f, 0.f}, dc6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (cnt > 0) {
+    if (cnt > 0 && inst_tag[vi] == epoch) {  // the blend wrote at least one record for this (view, Gaussian)
         gather_pair_grads(pair_off[vi], cnt, pair_tag, pair_grad, cap, epoch, acc);
         MgrCam cam;
         mgr_load_cam(cams, v, cam);
@@ -283,180 +289,6 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
     for (int j = 0; j < 6; ++j) ov[j] = dc6[j];
 }
 
-// ---------------------------------------------------------------------------
-// Fused backward of the articulated path, two kernels.  Together: for every view, gather the
-// Gaussian's pair records, run the projection backward, the SH-colour backward and the LBS
-// backward, and sum over the views in a fixed order.  Writes the leaf gradients once:
-// d xyz (direct + view-direction paths; the skin-weight path is returned as d w),
-// d log-scale, d raw quaternion, d opacity logit, d f_dc, d f_rest, d w, and the densification
-// statistics of the reference (src/models/gaussian.py:335-338, gaussian_utils.py:469-471):
-// sum_v ||d L_v / d means2D[:, :2]||, visibility count, max radius.
-// Same math as k_preprocess_bwd + k_sh_bwd + k_lbs_bwd (instance_math.h).
-// ---------------------------------------------------------------------------
-// Phase A, one thread per (view, Gaussian): gather the pair records and run the projection
-// backward on the re-derived posed mean / covariance.  Output record (16 floats):
-// [0..2] dL/dposed_mean, [3..8] dL/dposed_cov, [9..11] dL/dcolour, [12] dL/dopacity,
-// [13] ||dL/dmeans2D.xy||, [14] 1 if the instance received any gradient.
-__global__ __launch_bounds__(256) void k_inst_bwd_a(
-    int N, int B, int W, int H, const float* __restrict__ cams, const float* __restrict__ xyz,
-    const float* __restrict__ log_scale, const float* __restrict__ rot, const float* __restrict__ skin_w,
-    const float* __restrict__ transforms, const int32_t* __restrict__ radii, const ushort4* __restrict__ rect,
-    const uint32_t* __restrict__ pair_off, const uint32_t* __restrict__ pair_tag,
-    const float4* __restrict__ pair_grad, float4* __restrict__ inst_grad, uint32_t cap, uint32_t epoch) {
-    const int v = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= N) return;
-    const size_t vi = (size_t)v * N + i;
-    float4* o = inst_grad + vi * 8;
-    float acc[9];
-    bool any = false;
-    if (radii[vi] > 0) {
-        const ushort4 rc = rect[vi];
-        gather_pair_grads(pair_off[vi], (uint32_t)((rc.z - rc.x) * (rc.w - rc.y)), pair_tag, pair_grad, cap, epoch, acc);
-#pragma unroll
-        for (int k = 0; k < 9; ++k) any = any || (acc[k] != 0.f);
-    }
-    if (!any) {  // culled, or hidden behind saturated pixels everywhere
-        o[3] = make_float4(0.f, 0.f, 0.f, 0.f);
-        return;
-    }
-    MgrCam cam;
-    mgr_load_cam(cams, v, cam);
-    GaussCano g;
-    cano_load(xyz, log_scale, rot, i, g);
-    float tf[12], p[3], c6[6], dm[3], dc6[6];
-    blend_tf(skin_w ? skin_w + (size_t)i * B : nullptr, skin_w ? transforms + (size_t)v * B * 16 : nullptr, B, tf);
-    lbs_apply(tf, g, p, c6);
-    project_backward(cam, W, H, p, c6, acc, dm, dc6);
-    o[0] = make_float4(dm[0], dm[1], dm[2], dc6[0]);
-    o[1] = make_float4(dc6[1], dc6[2], dc6[3], dc6[4]);
-    o[2] = make_float4(dc6[5], acc[6], acc[7], acc[8]);
-    o[3] = make_float4(acc[5], sqrtf(acc[0] * acc[0] + acc[1] * acc[1]), 1.0f, 0.f);
-}
-
-// Phase B, one thread per Gaussian, loop over views: SH-colour backward.  Accumulates the SH
-// coefficient gradient in registers (written once) and leaves, per view, the gradient w.r.t.
-// the canonical position through the view direction (gd) and w.r.t. the blended transform.
-__global__ __launch_bounds__(256, 2) void k_inst_bwd_b(
-    int V, int N, int B, const float* __restrict__ cams, const float* __restrict__ xyz,
-    const float* __restrict__ f_dc, const float* __restrict__ f_rest, const float* __restrict__ skin_w,
-    const float* __restrict__ transforms, float4* __restrict__ inst_grad, float* __restrict__ d_fdc,
-    float* __restrict__ d_frest) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= N) return;
-    // coefficients are re-read from memory (L1) inside the view loop: holding them would cost 48
-    // more registers next to the 48 accumulators
-    const ShCoefMem c = {f_dc + (size_t)i * 3, f_rest + (size_t)i * 45};
-    float dsh[48];
-#pragma unroll
-    for (int k = 0; k < 48; ++k) dsh[k] = 0.f;
-    const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
-    const bool has_tf = skin_w != nullptr;
-#pragma unroll 1
-    for (int v = 0; v < V; ++v) {
-        float4* rec = inst_grad + ((size_t)v * N + i) * 8;
-        if (rec[3].z == 0.f) continue;
-        const float4 r2 = rec[2];
-        const float gc[3] = {r2.y, r2.z, r2.w};
-        const float* cp = cams + (size_t)v * MGR_CAM_FLOATS + 34;
-        const float campos[3] = {cp[0], cp[1], cp[2]};
-        float tf[12];
-        blend_tf(has_tf ? skin_w + (size_t)i * B : nullptr, has_tf ? transforms + (size_t)v * B * 16 : nullptr, B, tf);
-        ShDir D;
-        if (has_tf) sh_dir_xyz<true>(x, y, z, tf, campos, D);
-        else sh_dir_xyz<false>(x, y, z, tf, campos, D);
-        float gd[3], dtf[12];
-#pragma unroll
-        for (int k = 0; k < 12; ++k) dtf[k] = 0.f;
-        sh_backward_view(c, D, has_tf, gc, dsh, gd, dtf);
-        rec[4] = make_float4(gd[0], gd[1], gd[2], 0.f);
-        rec[5] = make_float4(dtf[0], dtf[1], dtf[2], dtf[3]);
-        rec[6] = make_float4(dtf[4], dtf[5], dtf[6], dtf[7]);
-        rec[7] = make_float4(dtf[8], dtf[9], dtf[10], dtf[11]);
-    }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) d_fdc[(size_t)i * 3 + k] = dsh[k];
-#pragma unroll
-    for (int k = 0; k < 45; ++k) d_frest[(size_t)i * 45 + k] = dsh[3 + k];
-}
-
-// Phase C, one thread per Gaussian, loop over views: LBS backward (posed mean / covariance /
-// transform gradients -> canonical position, log-scale, quaternion, skin weights), opacity logit
-// and the densification statistics; sums over the views in a fixed order, writes once.
-template <int BMAX>
-__global__ __launch_bounds__(256) void k_inst_bwd_c(
-    int V, int N, int B, const float* __restrict__ xyz, const float* __restrict__ log_scale,
-    const float* __restrict__ rot, const float* __restrict__ op_logit, const float* __restrict__ skin_w,
-    const float* __restrict__ transforms, const int32_t* __restrict__ radii,
-    const float4* __restrict__ inst_grad, float grad2d_scale, float* __restrict__ d_xyz, float* __restrict__ d_ls,
-    float* __restrict__ d_rot, float* __restrict__ d_op, float* __restrict__ d_w, float* __restrict__ st_grad2d,
-    float* __restrict__ st_vis, int32_t* __restrict__ st_radii) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= N) return;
-    GaussCano g;
-    cano_load(xyz, log_scale, rot, i, g);
-    float dxyz[3] = {0.f, 0.f, 0.f}, ds[3] = {0.f, 0.f, 0.f};
-    float dR[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    float dw[BMAX];
-#pragma unroll
-    for (int b = 0; b < BMAX; ++b) dw[b] = 0.f;
-    float dop = 0.f, g2 = 0.f, vis = 0.f;
-    int maxrad = 0;
-    const bool has_tf = skin_w != nullptr;
-    for (int v = 0; v < V; ++v) {
-        const size_t vi = (size_t)v * N + i;
-        const int rad = radii[vi];
-        if (rad <= 0) continue;
-        vis += 1.0f;
-        maxrad = max(maxrad, rad);
-        const float4* rec = inst_grad + vi * 8;
-        const float4 r3 = rec[3];
-        if (r3.z == 0.f) continue;
-        const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r4 = rec[4];
-        const float dm[3] = {r0.x, r0.y, r0.z};
-        const float dc6[6] = {r0.w, r1.x, r1.y, r1.z, r1.w, r2.x};
-        dop += r3.x;
-        g2 += r3.y * grad2d_scale;
-        dxyz[0] += r4.x; dxyz[1] += r4.y; dxyz[2] += r4.z;
-        const float* Tp = has_tf ? transforms + (size_t)v * B * 16 : nullptr;
-        float tf[12], dtf[12], gt[12];
-        blend_tf(has_tf ? skin_w + (size_t)i * B : nullptr, Tp, B, tf);
-        {   // zero for the static-object path (phase B leaves these slots untouched there)
-            const float4 a = rec[5], b = rec[6], c = rec[7];
-            gt[0] = has_tf ? a.x : 0.f; gt[1] = has_tf ? a.y : 0.f; gt[2] = has_tf ? a.z : 0.f; gt[3] = has_tf ? a.w : 0.f;
-            gt[4] = has_tf ? b.x : 0.f; gt[5] = has_tf ? b.y : 0.f; gt[6] = has_tf ? b.z : 0.f; gt[7] = has_tf ? b.w : 0.f;
-            gt[8] = has_tf ? c.x : 0.f; gt[9] = has_tf ? c.y : 0.f; gt[10] = has_tf ? c.z : 0.f; gt[11] = has_tf ? c.w : 0.f;
-        }
-        lbs_backward_view<true>(tf, g, dm, dc6, gt, dxyz, ds, dR, dtf);
-        if (has_tf) {
-#pragma unroll
-            for (int b = 0; b < BMAX; ++b) {
-                if (b < B) {
-                    const float* T = Tp + (size_t)b * 16;
-                    float a = 0.f;
-#pragma unroll
-                    for (int k = 0; k < 12; ++k) a += dtf[k] * T[k];
-                    dw[b] += a;
-                }
-            }
-        }
-    }
-    d_xyz[3 * i] = dxyz[0]; d_xyz[3 * i + 1] = dxyz[1]; d_xyz[3 * i + 2] = dxyz[2];
-    d_ls[3 * i] = ds[0] * g.s[0]; d_ls[3 * i + 1] = ds[1] * g.s[1]; d_ls[3 * i + 2] = ds[2] * g.s[2];
-    float drot[4];
-    quat_backward(g, dR, drot);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) d_rot[4 * i + k] = drot[k];
-    const float sg = 1.0f / (1.0f + expf(-op_logit[i]));
-    d_op[i] = dop * sg * (1.0f - sg);
-    if (has_tf && d_w) {
-#pragma unroll
-        for (int b = 0; b < BMAX; ++b)
-            if (b < B) d_w[(size_t)i * B + b] = dw[b];
-    }
-    if (st_grad2d) st_grad2d[i] = g2;
-    if (st_vis) st_vis[i] = vis;
-    if (st_radii) st_radii[i] = maxrad;
-}
 
 // ---------------------------------------------------------------------------
 // Fused per-instance backward, one thread per (Gaussian, view) with the G views of a Gaussian
@@ -512,7 +344,10 @@ __device__ __forceinline__ void grp_store8(const float x[8], int vl, bool ok, fl
 #ifndef MGR_IB_WAVES
 #define MGR_IB_WAVES 3
 #endif
-#define IG_ROUNDS 8  // lane-group rounds per workgroup of the gather (amortises the list append)
+#ifndef IG_ROUNDS
+#define IG_ROUNDS 8
+#endif
+//  // lane-group rounds per workgroup of the gather (amortises the list append)
 #define IB_TSTRIDE(B) ((B) * 16 + 4)  // LDS words per view of bone transforms (+4: the G slabs fall in distinct banks)
 
 // Phase 1: gather.  Sums the pair-gradient records of every (Gaussian, view), keeps the 9 sums
@@ -523,7 +358,8 @@ template <int G>
 __global__ __launch_bounds__(256) void k_inst_gather(
     int v_first, int v_count, int N, int B, const int32_t* __restrict__ radii, const ushort4* __restrict__ rect,
     const uint32_t* __restrict__ pair_off, const uint32_t* __restrict__ pair_tag,
-    const float4* __restrict__ pair_grad, uint32_t cap, uint32_t epoch, int accumulate, float4* __restrict__ iacc,
+    const float4* __restrict__ pair_grad, const uint32_t* __restrict__ inst_tag, uint32_t cap, uint32_t epoch,
+    int accumulate, float4* __restrict__ iacc,
     uint32_t* __restrict__ active_list, MgrHeader* hdr, float* __restrict__ d_xyz, float* __restrict__ d_ls,
     float* __restrict__ d_rot, float* __restrict__ d_op, float* __restrict__ d_fdc, float* __restrict__ d_frest,
     float* __restrict__ d_w, float* __restrict__ st_grad2d, float* __restrict__ st_vis,
@@ -549,7 +385,7 @@ __global__ __launch_bounds__(256) void k_inst_gather(
         if (mine) {
             const size_t vi = (size_t)v * N + i;
             rad = radii[vi];
-            if (rad > 0) {
+            if (rad > 0 && inst_tag[vi] == epoch) {
                 const ushort4 rc = rect[vi];
                 gather_pair_grads(pair_off[vi], (uint32_t)((rc.z - rc.x) * (rc.w - rc.y)), pair_tag, pair_grad, cap, epoch,
                                   acc);
@@ -802,7 +638,7 @@ static int raster_backward_impl(int V, int N, int W, int H, const float* cams, c
                        (const uint32_t*)(ws + L.tile_done), (const uint32_t*)(ws + L.chunk_start),
                        (const float4*)(ws + L.ckpt), (const unsigned long long*)(ws + L.items), hdr, out_color,
                        dL_dcolor, (uint32_t*)(ws + L.pair_tag), (float4*)(ws + L.pair_grad),
-                       (uint32_t)cap, epoch); }
+                       (uint32_t*)(ws + L.inst_tag), (uint32_t)cap, epoch); }
     MGR_LAUNCH_CHECK("k_blend_bwd", stream, debug);
     if (canon) {
         // views of a Gaussian share a lane group; more than 8 views go in groups of 8, the later
@@ -820,8 +656,8 @@ static int raster_backward_impl(int V, int N, int W, int H, const float* cams, c
 #define MGR_IG_LAUNCH(GG)                                                                                             \
     hipLaunchKernelGGL((k_inst_gather<GG>), grid_g, dim3(256), 0, stream, v0, vc, N, canon->B, canon->radii,            \
                        (const ushort4*)(ws + L.rect), (const uint32_t*)(ws + L.pair_off),                             \
-                       (const uint32_t*)(ws + L.pair_tag), (const float4*)(ws + L.pair_grad), (uint32_t)cap, epoch,   \
-                       accm, iacc, alist, hdr, canon->d_xyz, canon->d_ls, canon->d_rot, canon->d_op, canon->d_fdc,    \
+                       (const uint32_t*)(ws + L.pair_tag), (const float4*)(ws + L.pair_grad),                        \
+                       (const uint32_t*)(ws + L.inst_tag), (uint32_t)cap, epoch, accm, iacc, alist, hdr, canon->d_xyz, canon->d_ls, canon->d_rot, canon->d_op, canon->d_fdc,    \
                        canon->d_frest, canon->d_w, canon->st_grad2d, canon->st_vis, canon->st_radii)
 #define MGR_IB_LAUNCH(GG, BB)                                                                                         \
     hipLaunchKernelGGL((k_inst_bwd<GG, BB>), grid, dim3(256), lds, stream, v0, vc, N, canon->B, W, H, cams, canon->xyz, \
@@ -856,7 +692,8 @@ static int raster_backward_impl(int V, int N, int W, int H, const float* cams, c
                        means3D, s_means, cov3D, s_cov, (const int32_t*)nullptr,
                        (const ushort4*)(ws + L.rect), (const uint32_t*)(ws + L.pair_off),
                        (const uint32_t*)(ws + L.pair_tag), (const float4*)(ws + L.pair_grad),
-                       dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dcov3D, (uint32_t)cap, epoch); }
+                       dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dcov3D,
+                       (const uint32_t*)(ws + L.inst_tag), (uint32_t)cap, epoch); }
     MGR_LAUNCH_CHECK("k_preprocess_bwd", stream, debug);
     return MGR_OK;
 }
