@@ -568,7 +568,7 @@ extern "C" int mgr_l1_loss_grad(int64_t count, const float* a, const float* b, f
     hipStream_t stream = (hipStream_t)stream_;
     int64_t n4 = count >> 2;
     int blocks = (int)((n4 + 255) / 256);
-    if (blocks > 4096) blocks = 4096;
+    if (blocks > 1024) blocks = 1024;  // one same-address atomic per workgroup at the end
     if (blocks < 1) blocks = 1;
     { MGR_PROF("k_l1_grad", stream); hipLaunchKernelGGL(k_l1_grad, dim3(blocks), dim3(256), 0, stream, count, (const float4*)a, (const float4*)b,
                        scale, (float4*)dL_da, loss_sum, a, b, dL_da); }

@@ -786,6 +786,21 @@ struct FwdRec {
     float c;
 };
 
+#ifdef MGR_TIMELINE
+__device__ unsigned long long g_tl[2048 * 4];
+__device__ unsigned long long g_tl2[2048 * 4];
+__device__ unsigned long long g_tl3[8192 * 4];
+extern "C" int mgr_debug_timeline(void* dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_tl), sizeof(unsigned long long) * 2048 * 4);
+}
+extern "C" int mgr_debug_timeline3(void* dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_tl3), sizeof(unsigned long long) * 8192 * 4);
+}
+extern "C" int mgr_debug_timeline2(void* dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_tl2), sizeof(unsigned long long) * 2048 * 4);
+}
+#endif
+
 __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, int gy, int VT,
                                                    const float* __restrict__ bg,
                                                    const uint32_t* __restrict__ tile_start,
@@ -811,10 +826,17 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, 
     const unsigned long long lt = (1ull << lane) - 1ull;
     float* const slab = &s_pair[wave][0][0];
 
+#ifdef MGR_TIMELINE
+    unsigned long long tl0 = wall_clock64(), ntl = 0;
+#endif
     if (tid == 0) s_next = atomicAdd(&hdr->queue_head2, 1u);
     __syncthreads();
     uint32_t item = s_next;
     while (item < n_busy) {
+#ifdef MGR_TIMELINE
+        ++ntl;
+        const unsigned long long tl_tile0 = wall_clock64();
+#endif
         const uint32_t vt = tile_queue[item];
         const int v = (int)(vt / (uint32_t)T), t = (int)(vt % (uint32_t)T);
         const int bx = t % gx, by = t / gx;
@@ -826,6 +848,10 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, 
         const mgr_v2f fpx2 = {(float)px, (float)px}, fpy2 = {(float)py, (float)py};
         const float qx0 = (float)(bx * 16 + (wave & 1) * 8), qy0 = (float)(by * 16 + (wave >> 1) * 8);
         const uint32_t ck0 = chunk_start[vt];  // checkpoint c (c >= 1) of this tile lives at ck0 + c - 1
+        // The kernel ends when the deepest tiles end, and their waves share a SIMD with up to five
+        // waves of ordinary tiles: long lists issue at raised priority, the rest fill the gaps.
+        if (nlist >= 4096u) __builtin_amdgcn_s_setprio(3);
+        else __builtin_amdgcn_s_setprio(0);
         __syncthreads();                       // everyone has read s_next
         if (tid == 0) {
             s_max = 0;
@@ -836,12 +862,16 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, 
         bool done = !inside;
         const MgrGRec* const gv = grec + (size_t)v * N;
 
-        // software pipeline: rec = record of batch k, gid_n = index of batch k+1
+        // software pipeline: rec = record of batch k, gid_n = index of batch k+1.  All pipeline
+        // loads are unconditional (indices clamped into the list): a predicated load makes hipcc
+        // drain the whole memory queue (s_waitcnt vmcnt(0)) every batch.
         FwdRec rec;
         uint32_t gid_n;
+        const uint32_t* const sg = sorted_gid + start;
+        const uint32_t lastidx = nlist - 1u;
         {
-            const uint32_t g0 = (uint32_t)lane < nlist ? sorted_gid[start + lane] : 0u;
-            gid_n = 64u + lane < nlist ? sorted_gid[start + 64u + lane] : 0u;
+            const uint32_t g0 = sg[min((uint32_t)lane, lastidx)];
+            gid_n = sg[min(64u + lane, lastidx)];
             const MgrGRec* r = gv + g0;
             rec.a = *(const float4*)r;
             rec.b = *((const float4*)r + 1);
@@ -866,13 +896,11 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, 
             }
             // issue the gathers of the following batches; they complete during the blend below
             {
-                if (off + 64u + lane < nlist) {
-                    const MgrGRec* r = gv + gid_n;
-                    rec.a = *(const float4*)r;
-                    rec.b = *((const float4*)r + 1);
-                    rec.c = r->b;
-                }
-                gid_n = off + 128u + lane < nlist ? sorted_gid[start + off + 128u + lane] : 0u;
+                const MgrGRec* r = gv + gid_n;
+                rec.a = *(const float4*)r;
+                rec.b = *((const float4*)r + 1);
+                rec.c = r->b;
+                gid_n = sg[min(off + 128u + lane, lastidx)];
             }
             const int npair = (cnt + 1) >> 1;
             for (int p = 0; p < npair; ++p) {
@@ -937,8 +965,25 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, 
         }
         __syncthreads();
         for (uint32_t c = tid; c < nchunks; c += 256) items[s_ibase + c] = ((unsigned long long)vt << 32) | c;
+#ifdef MGR_TIMELINE
+        if (tid == 0 && item < 8192) {
+            g_tl3[item * 4 + 0] = tl_tile0;
+            g_tl3[item * 4 + 1] = wall_clock64();
+            g_tl3[item * 4 + 2] = nlist;
+            g_tl3[item * 4 + 3] = tmax;
+        }
+        if (ntl == 1 && tid == 0 && blockIdx.x < 2048) {
+            g_tl2[blockIdx.x * 4 + 0] = wall_clock64();
+            g_tl2[blockIdx.x * 4 + 1] = nlist;
+            g_tl2[blockIdx.x * 4 + 2] = tmax;
+            g_tl2[blockIdx.x * 4 + 3] = item;
+        }
+#endif
         item = s_next;
     }
+#ifdef MGR_TIMELINE
+    unsigned long long tl1 = wall_clock64();
+#endif
     // empty tiles: background only
     for (uint32_t q = n_busy + blockIdx.x; q < (uint32_t)VT; q += gridDim.x) {
         const uint32_t vt = tile_queue[q];
@@ -955,6 +1000,14 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, 
         }
         if (tid == 0) tile_done[vt] = 0;
     }
+#ifdef MGR_TIMELINE
+    if (tid == 0 && blockIdx.x < 2048) {
+        g_tl[blockIdx.x * 4 + 0] = tl0;
+        g_tl[blockIdx.x * 4 + 1] = tl1;
+        g_tl[blockIdx.x * 4 + 2] = wall_clock64();
+        g_tl[blockIdx.x * 4 + 3] = ntl;
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------
