@@ -1018,6 +1018,24 @@ struct CanonInputs {  // canonical (un-posed) parameters of the fused articulate
     const float *xyz, *log_scale, *rot, *op_logit, *f_dc, *f_rest, *skin_w, *transforms;
 };
 
+// One side stream (+ fork/join events) per host thread for the kernels that can overlap.
+struct MgrSideStream {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    hipError_t init() {
+        if (stream) return hipSuccess;
+        hipError_t e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
+        if (e != hipSuccess) return e;
+        e = hipEventCreateWithFlags(&fork, hipEventDisableTiming);
+        if (e != hipSuccess) return e;
+        return hipEventCreateWithFlags(&join, hipEventDisableTiming);
+    }
+};
+static MgrSideStream& mgr_side_stream() {
+    static thread_local MgrSideStream s;
+    return s;
+}
+
 static int raster_forward_impl(int V, int N, int W, int H, const float* cams, const float* bg,
                                const float* means3D, int64_t s_means, const float* cov3D,
                                int64_t s_cov, const float* colors, int64_t s_col,
@@ -1094,6 +1112,18 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
                            (uint32_t*)(ws + L.tile_cursor), (unsigned long long*)(ws + L.keys),
                            (uint32_t)cap, lds_hist); }
         MGR_LAUNCH_CHECK("k_emit", stream, debug);
+        // The small-tile sort only depends on k_emit; it runs on a side stream next to the
+        // giant-tile split (few workgroups, long) and the LDS radix sort (one workgroup per CU),
+        // and joins before the blend.
+        MgrSideStream& side = mgr_side_stream();
+        MGR_HIP(side.init());
+        MGR_HIP(hipEventRecord(side.fork, stream));
+        MGR_HIP(hipStreamWaitEvent(side.stream, side.fork, 0));
+        { MGR_PROF("k_tile_sort_small", side.stream); hipLaunchKernelGGL(k_tile_sort_small, dim3(256 * 8), dim3(256), 0, side.stream,
+                           tile_start, (const uint32_t*)(ws + L.tile_queue),
+                           (const unsigned long long*)(ws + L.keys), (uint32_t*)(ws + L.sorted_gid), hdr,
+                           (uint32_t)cap); }
+        MGR_HIP(hipEventRecord(side.join, side.stream));
         { MGR_PROF("k_tile_split", stream); hipLaunchKernelGGL(k_tile_split, dim3(128), dim3(SORT_THREADS), 0, stream,
                            tile_start, (const uint32_t*)(ws + L.tile_queue), (unsigned long long*)(ws + L.keys),
                            (unsigned long long*)(ws + L.keys2), (uint4*)(ws + L.groups),
@@ -1102,10 +1132,7 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
                            tile_start, (const uint32_t*)(ws + L.tile_queue),
                            (const unsigned long long*)(ws + L.keys), (const unsigned long long*)(ws + L.keys2),
                            (const uint4*)(ws + L.groups), (uint32_t*)(ws + L.sorted_gid), hdr, (uint32_t)cap); }
-        { MGR_PROF("k_tile_sort_small", stream); hipLaunchKernelGGL(k_tile_sort_small, dim3(256 * 8), dim3(256), 0, stream,
-                           tile_start, (const uint32_t*)(ws + L.tile_queue),
-                           (const unsigned long long*)(ws + L.keys), (uint32_t*)(ws + L.sorted_gid), hdr,
-                           (uint32_t)cap); }
+        MGR_HIP(hipStreamWaitEvent(stream, side.join, 0));
         MGR_LAUNCH_CHECK("k_tile_sort", stream, debug);
     }
     { MGR_PROF("k_blend_fwd", stream); hipLaunchKernelGGL(k_blend_fwd, dim3(256 * 8), dim3(256), 0, stream, N, W, H, gx, gy, VT, bg, tile_start,
