@@ -27,16 +27,24 @@ __device__ __forceinline__ void quat_rot(const float q[4], float R[9]) {
     R[6] = 2.f * (x * z - r * y); R[7] = 2.f * (y * z + r * x); R[8] = 1.f - 2.f * (x * x + y * y);
 }
 
+// Row loads of the (N,3) / (N,B) / (N,45) parameter arrays: rows are only 4-byte aligned, but gfx950
+// global loads take unaligned dwordx3/x4, and one wide load costs the texture path one pass
+// instead of three or four.
+typedef float mgr_f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float mgr_f3u __attribute__((ext_vector_type(3), aligned(4)));
+
 __device__ __forceinline__ void cano_load(const float* __restrict__ xyz, const float* __restrict__ log_scale,
                                           const float* __restrict__ rot, int i, GaussCano& g) {
-    g.x = xyz[3 * i]; g.y = xyz[3 * i + 1]; g.z = xyz[3 * i + 2];
-    const float qr[4] = {rot[4 * i], rot[4 * i + 1], rot[4 * i + 2], rot[4 * i + 3]};
+    const mgr_f3u p = *(const mgr_f3u*)(xyz + 3 * (size_t)i);
+    const mgr_f3u ls = *(const mgr_f3u*)(log_scale + 3 * (size_t)i);
+    const mgr_f4u q4 = *(const mgr_f4u*)(rot + 4 * (size_t)i);
+    g.x = p.x; g.y = p.y; g.z = p.z;
+    const float qr[4] = {q4.x, q4.y, q4.z, q4.w};
     g.nrm = sqrtf(qr[0] * qr[0] + qr[1] * qr[1] + qr[2] * qr[2] + qr[3] * qr[3]);
 #pragma unroll
     for (int k = 0; k < 4; ++k) g.q[k] = qr[k] / g.nrm;
     quat_rot(g.q, g.R);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) g.s[k] = expf(log_scale[3 * i + k]);
+    g.s[0] = expf(ls.x); g.s[1] = expf(ls.y); g.s[2] = expf(ls.z);
 }
 
 // tf rows 0..2 (3x4, row-major) = sum_b w_b * T_b ; identity when w == nullptr
@@ -49,9 +57,20 @@ __device__ __forceinline__ void blend_tf(const float* __restrict__ w_row, const 
     }
 #pragma unroll
     for (int k = 0; k < 12; ++k) tf[k] = 0.f;
-    for (int b = 0; b < B; ++b) {
+    int b = 0;
+    for (; b + 4 <= B; b += 4) {  // four weights per load
+        const mgr_f4u w4 = *(const mgr_f4u*)(w_row + b);
+        const float wj[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float* T = Tp + (size_t)(b + j) * 16;  // wave-uniform address
+#pragma unroll
+            for (int k = 0; k < 12; ++k) tf[k] += wj[j] * T[k];
+        }
+    }
+    for (; b < B; ++b) {
         const float w = w_row[b];
-        const float* T = Tp + (size_t)b * 16;  // wave-uniform address
+        const float* T = Tp + (size_t)b * 16;
 #pragma unroll
         for (int k = 0; k < 12; ++k) tf[k] += w * T[k];
     }

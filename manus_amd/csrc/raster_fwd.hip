@@ -273,10 +273,17 @@ __global__ __launch_bounds__(PRE_THREADS) void k_inst_fwd(
             else sh_dir_xyz<false>(g.x, g.y, g.z, tf, cam.campos, D);
             float Y[16], c[48], rgb[3];
             sh_basis(D.d[0] / D.n, D.d[1] / D.n, D.d[2] / D.n, Y);
+            {   // 48 coefficients in 13 loads
+                const mgr_f3u d = *(const mgr_f3u*)(f_dc + (size_t)i * 3);
+                c[0] = d.x; c[1] = d.y; c[2] = d.z;
+                const float* fr = f_rest + (size_t)i * 45;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) c[k] = f_dc[(size_t)i * 3 + k];
-#pragma unroll
-            for (int k = 0; k < 45; ++k) c[3 + k] = f_rest[(size_t)i * 45 + k];
+                for (int q = 0; q < 11; ++q) {
+                    const mgr_f4u t = *(const mgr_f4u*)(fr + 4 * q);
+                    c[3 + 4 * q] = t.x; c[4 + 4 * q] = t.y; c[5 + 4 * q] = t.z; c[6 + 4 * q] = t.w;
+                }
+                c[47] = fr[44];
+            }
             sh_rgb(c, Y, rgb);
             col[0] = fmaxf(rgb[0] + 0.5f, 0.f);
             col[1] = fmaxf(rgb[1] + 0.5f, 0.f);
