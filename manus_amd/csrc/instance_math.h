@@ -390,30 +390,42 @@ __device__ __forceinline__ void project_backward(const MgrCam& cam, int W, int H
 }
 
 // Sum of this Gaussian's pair records that the backward blend wrote in this call.
+typedef uint32_t mgr_u4u __attribute__((ext_vector_type(4), aligned(4)));
+
+// Sum the pair-gradient records of one (view, Gaussian): slots [off, off + cnt), valid when their
+// tag equals the call's epoch.  Two passes per 64 slots so that neither is a chain of dependent
+// loads: (1) the tags, sixteen per step as four unaligned dwordx4 (the tag array is padded by
+// 64 bytes for the over-read), folded into a bit mask; (2) the records of the set bits, in
+// ascending slot order (fixed summation order).
 __device__ __forceinline__ void gather_pair_grads(uint32_t off, uint32_t cnt, const uint32_t* __restrict__ pair_tag,
                                                   const float4* __restrict__ pair_grad, uint32_t cap, uint32_t epoch,
                                                   float acc[9]) {
 #pragma unroll
     for (int k = 0; k < 9; ++k) acc[k] = 0.f;
-    // four tags in flight per step (the loop is latency bound otherwise); records are still added
-    // in ascending slot order
-    const uint32_t miss = epoch ^ 1u;
-    for (uint32_t k = 0; k < cnt; k += 4) {
-        uint32_t tg[4];
+    if (off >= cap) return;
+    cnt = min(cnt, cap - off);
+    for (uint32_t base = 0; base < cnt; base += 64) {
+        const uint32_t n = min(64u, cnt - base);
+        unsigned long long hit = 0ull;
+        for (uint32_t k = 0; k < n; k += 16) {
+            const mgr_u4u* tp = (const mgr_u4u*)(pair_tag + off + base + k);
+            const mgr_u4u t0 = tp[0], t1 = tp[1], t2 = tp[2], t3 = tp[3];
+            const uint32_t tg[16] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w,
+                                     t2.x, t2.y, t2.z, t2.w, t3.x, t3.y, t3.z, t3.w};
+            uint32_t m16 = 0;
 #pragma unroll
-        for (uint32_t j = 0; j < 4; ++j) {
-            const uint32_t slot = off + k + j;
-            tg[j] = (k + j < cnt && slot < cap) ? pair_tag[slot] : miss;
+            for (int j = 0; j < 16; ++j) m16 |= (tg[j] == epoch ? 1u : 0u) << j;
+            hit |= (unsigned long long)m16 << k;
         }
-#pragma unroll
-        for (uint32_t j = 0; j < 4; ++j) {
-            if (tg[j] == epoch) {
-                const float4* r = pair_grad + (size_t)(off + k + j) * 3;
-                const float4 a = r[0], b = r[1], c = r[2];
-                acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
-                acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w;
-                acc[8] += c.x;
-            }
+        if (n < 64) hit &= (1ull << n) - 1ull;
+        while (hit) {
+            const int j = __builtin_ctzll(hit);
+            hit &= hit - 1;
+            const float4* r = pair_grad + (size_t)(off + base + (uint32_t)j) * 3;
+            const float4 a = r[0], b = r[1], c = r[2];
+            acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
+            acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w;
+            acc[8] += c.x;
         }
     }
 }

@@ -126,7 +126,7 @@ static inline MgrLayout mgr_layout(int V, int N, int W, int H, int64_t cap) {
     L.sorted_gid = o;  o += mgr_align(c * 4);
     L.final_T = o;     o += mgr_align(VP * 4);
     L.n_contrib = o;   o += mgr_align(VP * 4);
-    L.pair_tag = o;    o += mgr_align(c * 4);
+    L.pair_tag = o;    o += mgr_align(c * 4 + 64);
     L.pair_grad = o;   o += mgr_align(c * 48);
     L.inst_tag = o;    o += mgr_align(VN * 4);      // epoch of the last backward that wrote a record for (view, Gaussian)
     L.inst_grad = o;   o += mgr_align(VN * 128);    // fused backward: 12 floats per (Gaussian, view) + active list
