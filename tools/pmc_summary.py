@@ -11,6 +11,10 @@ def main():
     out_json = sys.argv[sys.argv.index("--json") + 1] if "--json" in sys.argv else None
     if out_json in args:
         args.remove(out_json)
+    if "--workload" in sys.argv:
+        w = sys.argv[sys.argv.index("--workload") + 1]
+        if w in args:
+            args.remove(w)
     acc = defaultdict(lambda: defaultdict(list))
     for d in args:
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -36,7 +40,12 @@ def main():
         for k, d in res.items():
             if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
                 d["hbm_bytes_per_launch"] = (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0
-        json.dump(res, open(out_json, "w"), indent=1)
+        wl = None
+        if "--workload" in sys.argv:
+            wl = [int(x) for x in sys.argv[sys.argv.index("--workload") + 1].split(",")]
+        json.dump({"workload": wl, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), "
+                   "mean per launch; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) KB (gfx950 FETCH_SIZE correction)",
+                   "kernels": res}, open(out_json, "w"), indent=1)
 
 if __name__ == "__main__":
     main()
