@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Benchmark of the MANUS hot path on MI355X: training iterations per second, one iteration =
-V views (forward + L1 image loss + backward to the six leaf-parameter gradients, + gradient
+V views (forward + image loss (0.8 L1 + 0.2 (1-SSIM), or L1 with --loss l1) + backward to the six leaf-parameter gradients, + gradient
 all-reduce when N > 1), 300k articulated Gaussians, 1920x1080, 8 views, synthetic data.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
@@ -59,7 +59,7 @@ def kernel_algorithmic_bytes(name, N, V, R, P):
     return per.get(name)
 
 
-def cpu_baseline(scene_cpu, cam0, sample_views=1, n_views=8):
+def cpu_baseline(scene_cpu, cam0, sample_views=1, n_views=8, loss="l1+ssim"):
     """Oracle ("port") timed on the host cores: one view of the same workload — the torch
     restatement of LBS/cov/SH forward+backward (all cores) and the scalar C rasterizer oracle
     forward+backward (one core) — scaled to iterations/s for n_views views."""
@@ -83,7 +83,14 @@ def cpu_baseline(scene_cpu, cam0, sample_views=1, n_views=8):
                       o["posed_xyz"].detach().numpy(), o["posed_cov"].detach().numpy(),
                       o["colors"].detach().numpy(), o["opacity"].detach().numpy()[:, 0], np.ones(3, np.float32))
     t2 = time.time()
-    g = np.sign(ro.color - 0.5).astype(np.float32) / ro.color.size
+    if loss == "l1+ssim":   # image loss of the step on the oracle's image (torch restatement, all threads)
+        img = torch.tensor(np.ascontiguousarray(ro.color)).permute(1, 2, 0).clone().requires_grad_(True)
+        tgt = torch.full_like(img, 0.5)
+        (gi,) = torch.autograd.grad(tr.rgb_ssim_loss(img, tgt), img)
+        g = np.ascontiguousarray(gi.permute(2, 0, 1).numpy())
+    else:
+        g = np.sign(ro.color - 0.5).astype(np.float32) / ro.color.size
+    t2b = time.time()
     b = ro.backward(g)
     t3 = time.time()
     loss = ((o["posed_xyz"] * torch.tensor(b["means3D"])).sum() + (o["posed_cov"] * torch.tensor(b["cov3D"])).sum()
@@ -93,8 +100,8 @@ def cpu_baseline(scene_cpu, cam0, sample_views=1, n_views=8):
     t_view = t4 - t0
     return {"value": 1.0 / (t_view * n_views), "unit": "iters/s", "cores": threads, "kind": "port",
             "sample": "1 of %d views, N=%d, 1920x1080: torch LBS+cov+SH fwd %.2fs + bwd %.2fs (%d threads), "
-                      "scalar C rasterizer fwd %.2fs + bwd %.2fs (1 thread); value = 1/(%d x %.2fs)"
-                      % (n_views, P["_xyz"].shape[0], t1 - t0, t4 - t3, threads, t2 - t1, t3 - t2,
+                      "scalar C rasterizer fwd %.2fs + bwd %.2fs (1 thread), image loss %s %.2fs; value = 1/(%d x %.2fs)"
+                      % (n_views, P["_xyz"].shape[0], t1 - t0, t4 - t3, threads, t2 - t1, t3 - t2b, loss, t2b - t2,
                          n_views, t_view),
             "num_rendered": int(ro.num_rendered)}
 
@@ -109,6 +116,8 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--kind", default="hand")
+    ap.add_argument("--loss", default="l1+ssim", choices=["l1", "l1+ssim"],
+                    help="image loss of the step: 0.8 L1 + 0.2 (1 - SSIM) (HAND_GAUSSIAN.yaml:22-23) or L1 alone")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-all", action="store_true", help="print a per-kernel HIP-event breakdown to stderr")
     args = ap.parse_args()
@@ -142,7 +151,7 @@ def main():
         hp = HipViewCompute(pert, torch.zeros((V, 3, H, W), device=dev), ct)
         targets = torch.cat([hp.forward_views([v])[0] for v in range(V)]).contiguous()
         del hp
-    compute = HipViewCompute(scene, targets, ct)
+    compute = HipViewCompute(scene, targets, ct, loss=args.loss)
     shapes = {k: v.shape for k, v in compute.params.items()}
     step = ViewShardedStep(N, shapes, compute, V, rank=rank, world_size=world)
     V_local = len(step.local_views)
@@ -203,14 +212,14 @@ def main():
         if not args.no_cpu_baseline and world == 1 and args.kind == "hand":
             sc_cpu = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in scene.items() if k != "params"}
             sc_cpu["params"] = {k: v.detach().cpu() for k, v in scene["params"].items()}
-            cpu = cpu_baseline(sc_cpu, scene["cameras"][0], n_views=V)
+            cpu = cpu_baseline(sc_cpu, scene["cameras"][0], n_views=V, loss=args.loss)
         line = {
             "metric": "train iters/sec (fwd+bwd) 300k Gaussians @1080p, 8 views; PSNR parity",
             "value": round(args.steps / dt, 4), "unit": "iters/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "HAND_GAUSSIAN: %d Gaussians, 21-transform LBS, %d views %dx%d, one pose per view "
-                                   "(n_poses=%d), L1 image loss, fwd+bwd to leaf grads" % (N, V, W, H, n_poses),
+                                   "(n_poses=%d), image loss %s, fwd+bwd to leaf grads" % (N, V, W, H, n_poses, "0.8*L1 + 0.2*(1-SSIM)" if args.loss == "l1+ssim" else "L1"),
                        "gaussians": N, "views": V, "width": W, "height": H, "views_per_gpu": V_local,
                        "pairs_per_view": int(R_view), "parallelism": "views/%d" % world},
             "roofline": roof, "cpu_baseline": cpu,

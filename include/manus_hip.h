@@ -226,6 +226,25 @@ int mgr_l1_loss_grad(int64_t count, const float* a, const float* b, float scale,
                      float* loss_sum, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Training image loss, forward + backward in one pass:
+ *   L = grad-scaled  w_l1 * sum|pred - target|  +  w_ssim * (- sum ssim_map)
+ * over images in the rasterizer's (V,3,H,W) layout.  Replaces l1_loss
+ * (src/utils/loss_utils.py:22-27) and ssim (src/utils/loss_utils.py:57-97) as
+ * called by loss_func (src/modules/base.py:323-365) together with their
+ * autograd backward.  The reference evaluates ssim() on HWC tensors, so its
+ * 11x11 window runs over the (W,3) plane of every image row (groups = H,
+ * loss_utils.py:58); that is the statistic computed here.
+ *   dL_dpred (V,3,H,W) = grad_scale * (w_l1 * sign(pred - target) - w_ssim * d(sum ssim_map)/dpred)
+ *   sums[0] = sum|pred - target|, sums[1] = sum of the ssim map (both over V*3*H*W values),
+ * so mean L1 = sums[0]/(V*3*H*W) and the reference's ssim(...) of one view = sums[1]/(3*H*W).
+ * workspace: mgr_image_loss_workspace_bytes(V,H,W) bytes of scratch (per-workgroup sums).
+ * ------------------------------------------------------------------------ */
+size_t mgr_image_loss_workspace_bytes(int V, int H, int W);
+int mgr_image_loss(int V, int H, int W, const float* pred, const float* target, float w_l1, float w_ssim,
+                   float grad_scale, float* dL_dpred, float* sums, void* workspace, size_t workspace_bytes,
+                   void* stream);
+
+/* ------------------------------------------------------------------------
  * Measurement aid: when enabled, every kernel launched by this library is
  * bracketed by HIP events recorded on the caller's stream.
  * mgr_profile_report synchronises the stream, writes one line per kernel

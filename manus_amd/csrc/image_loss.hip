@@ -1,0 +1,270 @@
+// Fused image loss of the MANUS training step for gfx950: L1 + "SSIM" forward and backward in
+// one pass over the rendered views.
+//
+// Replaces, for images kept in the rasterizer's (V,3,H,W) layout,
+//     l1_loss(pred, gt)                         /root/reference/src/utils/loss_utils.py:22-27
+//     1 - ssim(pred, gt)                        /root/reference/src/utils/loss_utils.py:39-97
+// as they are called by loss_func               /root/reference/src/modules/base.py:323-365
+// (weights 0.8 / 0.2, config/HAND_GAUSSIAN.yaml:22-23) and their autograd backward.
+//
+// The reference calls ssim() on HWC images: `channel = img1.size(-3)` (loss_utils.py:58) is then
+// the image HEIGHT and F.conv2d(..., groups=channel) slides the 11x11 window over the (W, 3)
+// plane of every image row, zero padded by 5 in both directions.  That is what is computed here
+// (and what the oracle restates): per row h, per statistic s in {x, y, xx, yy, xy},
+//     E_s[w][c] = sum_i sum_j g[i] g[j] s[w+i-5][c+j-5]            (zero outside the plane)
+// = an 11-tap filter along w of the channel mix  sum_c' g[5+c'-c] s[w][c'].
+// The backward is the same (symmetric) filter applied to three derivative maps
+//     D1 = dS/dmu1 (total), D2 = dS/dE[xx], D3 = dS/dE[xy],
+//     dS/dx[p] = F(D1)[p] + 2 x[p] F(D2)[p] + y[p] F(D3)[p].
+//
+// One 128-thread workgroup owns 246 consecutive w of TWO image rows.  The two rows are carried as
+// the two halves of packed fp32 registers (v_pk_fma_f32: the rows are independent, so every
+// filter tap is one packed FMA), each thread produces two neighbouring positions from a sliding
+// window of 12 LDS reads instead of 2 x 11, and every intermediate stays in LDS: x, y are staged
+// for w-10..w+265 (the derivative maps are needed 5 beyond the outputs, and they need the
+// statistics 5 beyond that), only the gradient is written.  The two loss sums are written per
+// workgroup and folded by a second tiny kernel: no float atomics, the loss value is reproducible.
+#include "mgr_common.h"
+
+#define IL_T 128                    // threads
+#define IL_ND (2 * IL_T)            // 256 derivative positions, two per thread
+#define IL_H1 5                     // halo of the derivative maps
+#define IL_W (IL_ND - 2 * IL_H1)    // 246 outputs per workgroup and row
+#define IL_NX (IL_ND + 2 * IL_H1)   // 266 staged positions
+
+struct IlWindow {
+    float g[11];
+};
+
+typedef mgr_v2f v2f;
+__device__ __forceinline__ v2f il_v2(float a) { v2f r = {a, a}; return r; }
+
+__global__ __launch_bounds__(IL_T) void k_image_loss(int H, int W, const float* __restrict__ pred,
+                                                     const float* __restrict__ target, IlWindow win, float w_l1,
+                                                     float w_ssim, float grad_scale, float* __restrict__ dL_dpred,
+                                                     float2* __restrict__ partial) {
+    // channel-mixed statistics (5 x 3 rows of positions) and, later, the channel-mixed derivative
+    // maps (3 x 3); .x = image row h0, .y = image row h0 + 1
+    __shared__ v2f s_mix[5][3][IL_NX];
+    __shared__ float s_red[4];
+    const int tid = threadIdx.x;
+    const int w0 = blockIdx.x * IL_W, h0 = blockIdx.y * 2, v = blockIdx.z;
+    const bool row1 = h0 + 1 < H;
+    const size_t plane = (size_t)H * W;
+    const float* px = pred + (size_t)v * 3 * plane + (size_t)h0 * W;
+    const float* py = target + (size_t)v * 3 * plane + (size_t)h0 * W;
+    // channel mix matrix M[c][c'] = g[5 + c' - c]; g is symmetric
+    const v2f m0 = il_v2(win.g[5]), m1 = il_v2(win.g[4]), m2 = il_v2(win.g[3]);
+
+    for (int t = tid; t < IL_NX; t += IL_T) {
+        const int w = w0 - 2 * IL_H1 + t;
+        v2f x[3], y[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) x[c] = y[c] = il_v2(0.f);
+        if (w >= 0 && w < W) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                x[c].x = px[c * plane + w];
+                y[c].x = py[c * plane + w];
+                if (row1) {
+                    x[c].y = px[c * plane + W + w];
+                    y[c].y = py[c * plane + W + w];
+                }
+            }
+        }
+        const v2f q[5][3] = {{x[0], x[1], x[2]},
+                             {y[0], y[1], y[2]},
+                             {x[0] * x[0], x[1] * x[1], x[2] * x[2]},
+                             {y[0] * y[0], y[1] * y[1], y[2] * y[2]},
+                             {x[0] * y[0], x[1] * y[1], x[2] * y[2]}};
+#pragma unroll
+        for (int s5 = 0; s5 < 5; ++s5) {
+            s_mix[s5][0][t] = m0 * q[s5][0] + m1 * q[s5][1] + m2 * q[s5][2];
+            s_mix[s5][1][t] = m1 * q[s5][0] + m0 * q[s5][1] + m1 * q[s5][2];
+            s_mix[s5][2][t] = m2 * q[s5][0] + m1 * q[s5][1] + m0 * q[s5][2];
+        }
+    }
+    __syncthreads();
+
+    // statistics -> SSIM value and derivative maps at the two positions u0, u0 + 1 (w = w0 - 5 + u)
+    const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+    const int u0 = 2 * tid;
+    v2f ssim_acc = il_v2(0.f);
+    v2f d[2][3][3];  // [position][map][channel]
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        v2f e[2][5];
+#pragma unroll
+        for (int s5 = 0; s5 < 5; ++s5) {
+            v2f win12[12];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) win12[k] = s_mix[s5][c][u0 + k];
+            v2f a = il_v2(0.f), b = il_v2(0.f);
+#pragma unroll
+            for (int i = 0; i < 11; ++i) {
+                const v2f gi = il_v2(win.g[i]);
+                a += gi * win12[i];
+                b += gi * win12[i + 1];
+            }
+            e[0][s5] = a;
+            e[1][s5] = b;
+        }
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+            const int w = w0 - IL_H1 + u0 + pp;
+            const v2f mu1 = e[pp][0], mu2 = e[pp][1];
+            const v2f s11 = e[pp][2] - mu1 * mu1, s22 = e[pp][3] - mu2 * mu2, s12 = e[pp][4] - mu1 * mu2;
+            const v2f A = 2.f * mu1 * mu2 + C1, B = 2.f * s12 + C2;
+            const v2f Cc = mu1 * mu1 + mu2 * mu2 + C1, Dd = s11 + s22 + C2;
+            v2f iC, iD;
+            iC.x = 1.0f / Cc.x; iC.y = 1.0f / Cc.y;
+            iD.x = 1.0f / Dd.x; iD.y = 1.0f / Dd.y;
+            const v2f inv = iC * iD;
+            const v2f S = A * B * inv;
+            const bool okw = w >= 0 && w < W;
+            v2f keep = {okw ? 1.f : 0.f, (okw && row1) ? 1.f : 0.f};   // positions outside the image have no SSIM value
+            const bool own = u0 + pp >= IL_H1 && u0 + pp < IL_H1 + IL_W;
+            if (own) ssim_acc += S * keep;
+            d[pp][0][c] = keep * (2.f * mu2 * (B - A) * inv - S * 2.f * mu1 * iC + S * 2.f * mu1 * iD);
+            d[pp][1][c] = keep * (-S * iD);
+            d[pp][2][c] = keep * (2.f * A * inv);
+        }
+    }
+    __syncthreads();  // everyone is done reading the statistics
+    // channel mix of the derivative maps (M is symmetric), reusing s_mix[0..2]
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const v2f a = d[pp][k][0], b = d[pp][k][1], c = d[pp][k][2];
+            s_mix[k][0][u0 + pp] = m0 * a + m1 * b + m2 * c;
+            s_mix[k][1][u0 + pp] = m1 * a + m0 * b + m1 * c;
+            s_mix[k][2][u0 + pp] = m2 * a + m1 * b + m0 * c;
+        }
+    }
+    __syncthreads();
+
+    // outputs o0, o0 + 1 (w = w0 + o), derivative index = o + 5, filter taps at o + i
+    v2f l1_acc = il_v2(0.f);
+    const int o0 = 2 * tid;
+    if (o0 < IL_W) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            v2f f[2][3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                v2f win12[12];
+#pragma unroll
+                for (int j = 0; j < 12; ++j) win12[j] = s_mix[k][c][o0 + j];
+                v2f a = il_v2(0.f), b = il_v2(0.f);
+#pragma unroll
+                for (int i = 0; i < 11; ++i) {
+                    const v2f gi = il_v2(win.g[i]);
+                    a += gi * win12[i];
+                    b += gi * win12[i + 1];
+                }
+                f[0][k] = a;
+                f[1][k] = b;
+            }
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp) {
+                const int w = w0 + o0 + pp;
+                if (o0 + pp < IL_W && w < W) {
+                    v2f x, y;
+                    x.x = px[c * plane + w];
+                    y.x = py[c * plane + w];
+                    x.y = row1 ? px[c * plane + W + w] : 0.f;
+                    y.y = row1 ? py[c * plane + W + w] : 0.f;
+                    const v2f dS = f[pp][0] + 2.f * x * f[pp][1] + y * f[pp][2];
+                    const v2f df = x - y;
+                    v2f ad = {fabsf(df.x), fabsf(df.y)};
+                    l1_acc += ad;
+                    const v2f sgn = {df.x > 0.f ? 1.f : (df.x < 0.f ? -1.f : 0.f), df.y > 0.f ? 1.f : (df.y < 0.f ? -1.f : 0.f)};
+                    const v2f gr = grad_scale * (w_l1 * sgn - w_ssim * dS);
+                    float* go = dL_dpred + (size_t)v * 3 * plane + (size_t)h0 * W + c * plane + w;
+                    go[0] = gr.x;
+                    if (row1) go[W] = gr.y;
+                }
+            }
+        }
+    }
+    // workgroup sums (fixed order)
+    float l1_sum = mgr_wave_sum63(l1_acc.x + l1_acc.y);
+    float ssim_sum = mgr_wave_sum63(ssim_acc.x + ssim_acc.y);
+    if ((tid & 63) == 63) {
+        s_red[tid >> 6] = l1_sum;
+        s_red[2 + (tid >> 6)] = ssim_sum;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const size_t b = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        partial[b] = make_float2(s_red[0] + s_red[1], s_red[2] + s_red[3]);
+    }
+}
+
+// fold the per-workgroup sums: sums[0] = sum |pred - target|, sums[1] = sum of the SSIM map
+__global__ __launch_bounds__(1024) void k_image_loss_fold(int64_t n, const float2* __restrict__ partial,
+                                                          float* __restrict__ sums) {
+    __shared__ double s_a[16], s_b[16];
+    double a = 0.0, b = 0.0;
+    for (int64_t k = threadIdx.x; k < n; k += 1024) {
+        const float2 p = partial[k];
+        a += (double)p.x;
+        b += (double)p.y;
+    }
+#pragma unroll
+    for (int dlt = 32; dlt > 0; dlt >>= 1) {
+        a += __shfl_xor(a, dlt, 64);
+        b += __shfl_xor(b, dlt, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_a[threadIdx.x >> 6] = a;
+        s_b[threadIdx.x >> 6] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double ta = 0.0, tb = 0.0;
+        for (int k = 0; k < 16; ++k) {
+            ta += s_a[k];
+            tb += s_b[k];
+        }
+        sums[0] = (float)ta;
+        sums[1] = (float)tb;
+    }
+}
+
+static int64_t il_blocks(int V, int H, int W) { return (int64_t)V * ((H + 1) / 2) * ((W + IL_W - 1) / IL_W); }
+
+extern "C" size_t mgr_image_loss_workspace_bytes(int V, int H, int W) {
+    if (V <= 0 || H <= 0 || W <= 0) return 0;
+    return (size_t)il_blocks(V, H, W) * sizeof(float2);
+}
+
+extern "C" int mgr_image_loss(int V, int H, int W, const float* pred, const float* target, float w_l1, float w_ssim,
+                              float grad_scale, float* dL_dpred, float* sums, void* workspace, size_t workspace_bytes,
+                              void* stream_) {
+    if (V <= 0 || H <= 0 || W <= 0) return mgr_fail(MGR_EINVAL, "mgr_image_loss: bad sizes");
+    if (!pred || !target || !dL_dpred || !sums || !workspace) return mgr_fail(MGR_EINVAL, "mgr_image_loss: null pointer");
+    if (H > 65535 || V > 65535) return mgr_fail(MGR_EINVAL, "mgr_image_loss: H and V must fit a grid dimension");
+    if (workspace_bytes < mgr_image_loss_workspace_bytes(V, H, W))
+        return mgr_fail(MGR_ENOMEM, "mgr_image_loss: workspace too small");
+    hipStream_t stream = (hipStream_t)stream_;
+    // the reference's window: gaussian(11, 1.5) in fp32, normalised (loss_utils.py:39-47)
+    IlWindow win;
+    float sum = 0.f;
+    for (int i = 0; i < 11; ++i) {
+        win.g[i] = (float)exp(-(double)((i - 5) * (i - 5)) / (2.0 * 1.5 * 1.5));
+        sum += win.g[i];
+    }
+    for (int i = 0; i < 11; ++i) win.g[i] /= sum;
+    const dim3 grid((W + IL_W - 1) / IL_W, (H + 1) / 2, V);
+    {
+        MGR_PROF("k_image_loss", stream);
+        hipLaunchKernelGGL(k_image_loss, grid, dim3(IL_T), 0, stream, H, W, pred, target, win, w_l1, w_ssim, grad_scale,
+                           dL_dpred, (float2*)workspace);
+    }
+    hipLaunchKernelGGL(k_image_loss_fold, dim3(1), dim3(1024), 0, stream, il_blocks(V, H, W), (const float2*)workspace,
+                       sums);
+    MGR_LAUNCH_CHECK("k_image_loss", stream, 0);
+    return MGR_OK;
+}

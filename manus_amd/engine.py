@@ -91,13 +91,18 @@ class HipViewCompute:
     backward to the six leaf tensors.  All local views go through every kernel launch
     together."""
 
-    def __init__(self, scene, targets, cam_table, loss_weight=1.0, fused=True):
+    def __init__(self, scene, targets, cam_table, loss_weight=1.0, fused=True, loss="l1", w_rgb=0.8, w_ssim=0.2):
         from . import fused as fused_mod, ops, rasterizer
         self.ops, self.rz, self.fz, self.fused = ops, rasterizer, fused_mod, fused
         self.s = scene
         self.targets = targets          # (V_all,3,H,W) on the GPU
         self.cams = cam_table           # (V_all,40)
         self.loss_weight = loss_weight
+        # "l1": mean|render - gt| (rgb_loss alone); "l1+ssim": w_rgb * rgb_loss + w_ssim * ssim_loss, the
+        # image terms of config/HAND_GAUSSIAN.yaml:22-23 (src/modules/base.py:323-365), one fused kernel
+        if loss not in ("l1", "l1+ssim"):
+            raise ValueError("loss must be 'l1' or 'l1+ssim'")
+        self.loss, self.w_rgb, self.w_ssim = loss, w_rgb, w_ssim
         self.is_hand = scene.get("grid") is not None and scene["kind"] == "hand"
         self.params = {k: v.detach().clone().requires_grad_(True) for k, v in scene["params"].items()}
         self._cache = {}
@@ -143,18 +148,27 @@ class HipViewCompute:
                                     p["_features_rest"], w, sel["T"], sel["cams"], s["bg"], s["width"], s["height"],
                                     stats=stats, grad2d_scale=grad2d_scale)
 
+    def _image_loss(self, img, tgt, scale):
+        """(loss value, dL/dimg) of scale * sum over the views of the per-view image loss."""
+        per_view = img[0].numel()
+        k = self.loss_weight * scale / per_view
+        if self.loss == "l1":
+            loss_sum, g = self.ops.l1_loss_grad(img, tgt, scale=k)
+            return loss_sum[0] * k, g
+        sums, g = self.ops.image_loss_grad(img, tgt, self.w_rgb, self.w_ssim, k)
+        const = self.w_ssim * self.loss_weight * scale * img.shape[0]   # the "1 -" of 1 - ssim, once per view
+        return k * (self.w_rgb * sums[0] - self.w_ssim * sums[1]) + const, g
+
     def _call_fused(self, view_ids, scale):
         for v in self.params.values():
             v.grad = None
         stats = self.fz.ViewStats()
         img, radii = self.forward_views_fused(view_ids, stats, 1.0 / scale)
         tgt = self._select(view_ids)["targets"]
-        per_view = img[0].numel()
-        k = self.loss_weight * scale / per_view
-        loss_sum, g = self.ops.l1_loss_grad(img, tgt, scale=k)
+        loss, g = self._image_loss(img, tgt, scale)
         img.backward(g)
         return dict(grads={n: v.grad for n, v in self.params.items()}, grad2d=stats.grad2d, vis=stats.vis,
-                    radii=stats.radii, loss=loss_sum[0] * k)
+                    radii=stats.radii, loss=loss)
 
     def __call__(self, view_ids, scale=1.0):
         if self.fused:
@@ -163,12 +177,10 @@ class HipViewCompute:
             v.grad = None
         img, radii, means2D = self.forward_views(view_ids)
         tgt = self._select(view_ids)["targets"]
-        per_view = img[0].numel()
-        k = self.loss_weight * scale / per_view
-        loss_sum, g = self.ops.l1_loss_grad(img, tgt, scale=k)
+        loss, g = self._image_loss(img, tgt, scale)
         img.backward(g)
         vis = radii > 0
         g2 = means2D.grad[..., :2].norm(dim=-1) * (1.0 / scale)
         return dict(grads={n: v.grad for n, v in self.params.items()},
                     grad2d=(g2 * vis).sum(0), vis=vis.sum(0).float(),
-                    radii=radii.max(dim=0).values, loss=loss_sum[0] * k)
+                    radii=radii.max(dim=0).values, loss=loss)

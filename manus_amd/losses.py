@@ -1,0 +1,66 @@
+"""Reference-shaped image losses over the fused HIP kernel (`mgr_image_loss`).
+
+Mirrors `src/utils/loss_utils.py` of brown-ivl/manus for the two terms of the training loss that
+consume the rendered image (`loss_func`, src/modules/base.py:323-365):
+
+    l1_loss(network_output, gt)           loss_utils.py:22-27   (mean=True form)
+    ssim(img1, img2)                      loss_utils.py:57-97   (window 11, size_average=True)
+
+Both take the reference's HWC images (`render` is permuted to (H,W,3) at
+src/utils/gaussian_utils.py:418; `gt` may carry a leading batch dimension of 1) and are
+differentiable w.r.t. the first argument.  `ssim` reproduces the reference's behaviour on HWC
+input exactly: `channel = img1.size(-3)` is the image height, so the window runs over the (W,3)
+plane of each row.  GPU tensors only; there is no CPU fallback.
+"""
+import torch
+
+from . import ops
+from ._lib import ManusHipError
+
+
+def _chw(img):
+    if img.dim() == 4:
+        if img.shape[0] != 1:
+            raise ManusHipError("losses: a batched image must have batch size 1 (as in the reference)")
+        img = img[0]
+    if img.dim() != 3 or img.shape[-1] != 3:
+        raise ManusHipError("losses: images are (H,W,3) like the reference's render / gt")
+    return img.permute(2, 0, 1).contiguous()
+
+
+class _ImageLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred_hwc, gt_hwc, w_l1, w_ssim):
+        pred, gt = _chw(pred_hwc), _chw(gt_hwc)
+        n = pred.numel()
+        sums, g = ops.image_loss_grad(pred, gt, w_l1, w_ssim, 1.0 / n)
+        ctx.save_for_backward(g)
+        ctx.batched = pred_hwc.dim() == 4
+        # value of w_l1 * mean|d| + w_ssim * (-mean ssim_map); callers add the constant w_ssim
+        return (w_l1 * sums[0] - w_ssim * sums[1]) / n
+
+    @staticmethod
+    def backward(ctx, go):
+        (g,) = ctx.saved_tensors
+        gh = (g[0] * go).permute(1, 2, 0)
+        return (gh[None] if ctx.batched else gh), None, None, None
+
+
+def l1_loss(network_output, gt, mean=True):
+    """torch.abs(network_output - gt).mean()  (loss_utils.py:22-27)."""
+    if not mean:
+        raise ManusHipError("l1_loss: only the mean=True form is fused")
+    return _ImageLoss.apply(network_output, gt, 1.0, 0.0)
+
+
+def ssim(img1, img2, window_size=11, size_average=True):
+    """ssim(img1, img2) of loss_utils.py:57-97 on HWC images (see the module docstring)."""
+    if window_size != 11 or not size_average:
+        raise ManusHipError("ssim: only window_size=11, size_average=True (the reference's call) is implemented")
+    return -_ImageLoss.apply(img1, img2, 0.0, 1.0)
+
+
+def rgb_ssim_loss(pred_image, gt_image, w_rgb=0.8, w_ssim=0.2):
+    """w_rgb * l1_loss + w_ssim * (1 - ssim) in one kernel: the first two terms of
+    config/HAND_GAUSSIAN.yaml:22-23 as combined by loss_func (base.py:356-364)."""
+    return _ImageLoss.apply(pred_image, gt_image, w_rgb, w_ssim) + w_ssim

@@ -247,3 +247,44 @@ def psnr(a, b):
     """src/utils/loss_utils.py:100-108."""
     mse = torch.mean((a - b) ** 2)
     return -10.0 * torch.log10(mse)
+
+
+# ---------------------------------------------------------------------------
+# image losses (SURVEY.md 8f rank 2)
+# ---------------------------------------------------------------------------
+def ssim_window(window_size=11, sigma=1.5):
+    """gaussian(window_size, 1.5) and its outer product (loss_utils.py:39-54)."""
+    g = torch.tensor([math.exp(-((x - window_size // 2) ** 2) / float(2 * sigma ** 2)) for x in range(window_size)],
+                     dtype=torch.float32)
+    g = g / g.sum()
+    return g, (g[:, None] @ g[None, :]).float()
+
+
+def ssim_hwc(img1, img2, window_size=11):
+    """ssim() of loss_utils.py:57-97 as the reference calls it: on HWC images (base.py:347), so
+    that `channel = img1.size(-3)` = H and the grouped conv slides the window over the (W,3)
+    plane of every row (zero padding 5).  img1 (H,W,3), img2 (H,W,3) or (1,H,W,3); returns the
+    mean of the SSIM map.  Restated with an explicit per-row convolution (no groups=H trick)."""
+    if img2.dim() == 4:
+        img2 = img2[0]
+    H = img1.shape[0]
+    _, w2d = ssim_window(window_size)
+    w2d = w2d.to(img1.dtype)[None, None]
+    pad = window_size // 2
+
+    def filt(x):  # (H,W,3) -> every row is a 1-channel image of size (W,3)
+        return torch.nn.functional.conv2d(x[:, None], w2d, padding=pad)[:, 0]
+
+    mu1, mu2 = filt(img1), filt(img2)
+    s11 = filt(img1 * img1) - mu1 * mu1
+    s22 = filt(img2 * img2) - mu2 * mu2
+    s12 = filt(img1 * img2) - mu1 * mu2
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    m = ((2 * mu1 * mu2 + C1) * (2 * s12 + C2)) / ((mu1 * mu1 + mu2 * mu2 + C1) * (s11 + s22 + C2))
+    return m.mean()
+
+
+def rgb_ssim_loss(pred_hwc, gt_hwc, w_rgb=0.8, w_ssim=0.2):
+    """w_rgb * mean|pred-gt| + w_ssim * (1 - ssim): base.py:323-365 with HAND_GAUSSIAN.yaml:22-23."""
+    gt = gt_hwc[0] if gt_hwc.dim() == 4 else gt_hwc
+    return w_rgb * (pred_hwc - gt).abs().mean() + w_ssim * (1.0 - ssim_hwc(pred_hwc, gt))

@@ -19,6 +19,7 @@ Reference functions exercised (paths relative to /root/reference):
   * src/utils/sh_utils.py:57-120           eval_sh
   * src/utils/cam_utils.py:19-78           getProjectionMatrix / get_opengl_camera_attributes
   * src/utils/transforms.py:233-261,489-530,304-311  get_pose_wrt_root / euler_angles_to_matrix / project_points
+  * src/utils/loss_utils.py:22-97          l1_loss / ssim (called on HWC images like base.py:329-347)
   * data/meta_data/novel_pose.pkl, data/camera_paths/real.pkl  (known-answer data)
 """
 import os
@@ -133,7 +134,8 @@ def _import_reference():
     import src.models.gaussian as gaussian
     import src.models.hand_gaussian as hand_gaussian
     import src.modules.hand_dynamic as hand_dynamic
-    return dict(sh_utils=sh_utils, transforms=transforms, cam_utils=cam_utils,
+    import src.utils.loss_utils as loss_utils
+    return dict(loss_utils=loss_utils, sh_utils=sh_utils, transforms=transforms, cam_utils=cam_utils,
                 gaussian_utils=gaussian_utils, gaussian=gaussian,
                 hand_gaussian=hand_gaussian, hand_dynamic=hand_dynamic)
 
@@ -325,6 +327,30 @@ def make_sh_golden(mods):
     return out
 
 
+def make_image_loss_golden(mods):
+    """l1_loss and ssim exactly as loss_func calls them (src/modules/base.py:323-347):
+    pred (H,W,3), gt (1,H,W,3); values and autograd gradients w.r.t. pred."""
+    lu = mods["loss_utils"]
+    out = {}
+    for k, (H, W) in enumerate(((7, 23), (16, 40), (5, 300))):
+        g = torch.Generator().manual_seed(100 + k)
+        gt = torch.rand((1, H, W, 3), generator=g)
+        pred = (gt[0] + 0.15 * torch.randn((H, W, 3), generator=g)).clamp(0, 1.2)
+        if k == 1:
+            pred[2:5, 3:9] = gt[0, 2:5, 3:9]        # exact zeros of the L1 term
+            pred[10:, :6] = 1.0                      # flat background block
+            gt[0, 10:, :6] = 1.0
+        pred = pred.clone().requires_grad_(True)
+        l1 = lu.l1_loss(pred, gt, mean=False).mean()       # base.py:329-331
+        (g_l1,) = torch.autograd.grad(l1, pred)
+        ss = lu.ssim(pred, gt)                              # base.py:347
+        (g_ss,) = torch.autograd.grad(ss, pred)
+        out[f"pred{k}"], out[f"gt{k}"] = pred.detach().numpy(), gt.numpy()
+        out[f"l1_{k}"], out[f"ssim_{k}"] = np.float32(l1.item()), np.float32(ss.item())
+        out[f"g_l1_{k}"], out[f"g_ssim_{k}"] = g_l1.numpy(), g_ss.numpy()
+    return out
+
+
 def main():
     mods = _import_reference()
     torch.manual_seed(0)
@@ -339,6 +365,7 @@ def main():
     np.savez_compressed(os.path.join(OUT, "cameras.npz"), **make_camera_golden(mods))
     np.savez_compressed(os.path.join(OUT, "fk_novel_pose.npz"), **make_fk_golden(mods))
     np.savez_compressed(os.path.join(OUT, "sh_eval.npz"), **make_sh_golden(mods))
+    np.savez_compressed(os.path.join(OUT, "image_loss.npz"), **make_image_loss_golden(mods))
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

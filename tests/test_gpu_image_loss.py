@@ -1,0 +1,86 @@
+"""GPU: fused L1 + SSIM image loss (mgr_image_loss) against the reference's golden vectors, the
+oracle restatement, and size-independent properties at the bench resolution."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch_ref as tr
+
+from util import max_rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_reference_shaped_losses_match_golden(golden_dir):
+    """manus_amd.losses.{l1_loss, ssim} called like base.py:329-347 (pred HWC, gt (1,H,W,3))."""
+    from manus_amd import losses
+    d = np.load(os.path.join(golden_dir, "image_loss.npz"))
+    for k in range(3):
+        gt = torch.tensor(d[f"gt{k}"], device=DEV)
+        pred = torch.tensor(d[f"pred{k}"], device=DEV, requires_grad=True)
+        l1 = losses.l1_loss(pred, gt)
+        (g,) = torch.autograd.grad(l1, pred)
+        assert abs(l1.item() - float(d[f"l1_{k}"])) < 1e-6
+        np.testing.assert_allclose(g.cpu().numpy(), d[f"g_l1_{k}"], rtol=0, atol=1e-9)
+        pred = torch.tensor(d[f"pred{k}"], device=DEV, requires_grad=True)
+        ss = losses.ssim(pred, gt)
+        (g,) = torch.autograd.grad(ss, pred)
+        assert abs(ss.item() - float(d[f"ssim_{k}"])) < 5e-6          # fp32, tolerance 5e-6 absolute on a value in [-1,1]
+        assert max_rel_err(g.cpu().numpy(), d[f"g_ssim_{k}"]) < 1e-4  # gradient max-rel-err bar of the path
+        pred = torch.tensor(d[f"pred{k}"], device=DEV, requires_grad=True)
+        full = losses.rgb_ssim_loss(pred, gt, 0.8, 0.2)
+        (g,) = torch.autograd.grad(full, pred)
+        ref = 0.8 * float(d[f"l1_{k}"]) + 0.2 * (1.0 - float(d[f"ssim_{k}"]))
+        assert abs(full.item() - ref) < 5e-6
+        assert max_rel_err(g.cpu().numpy(), 0.8 * d[f"g_l1_{k}"] - 0.2 * d[f"g_ssim_{k}"]) < 1e-4
+
+
+@pytest.mark.parametrize("V,H,W", [(1, 1, 1), (2, 3, 5), (1, 9, 256), (2, 4, 257), (1, 6, 700)])
+def test_kernel_matches_oracle(V, H, W):
+    """Ragged widths (workgroup seams at 256), tiny images, several views."""
+    from manus_amd import ops
+    g = torch.Generator().manual_seed(V * 1000 + W)
+    gt = torch.rand((V, 3, H, W), generator=g)
+    pred = (gt + 0.1 * torch.randn((V, 3, H, W), generator=g)).clamp(0, 1.1)
+    sums, grad = ops.image_loss_grad(pred.to(DEV), gt.to(DEV), 0.8, 0.2, 0.37)
+    l1 = s_sum = 0.0
+    gref = torch.zeros_like(pred)
+    for v in range(V):
+        p = pred[v].permute(1, 2, 0).clone().requires_grad_(True)
+        t = gt[v].permute(1, 2, 0)
+        a = (p - t).abs().sum()
+        s = tr.ssim_hwc(p, t) * (3 * H * W)
+        (gg,) = torch.autograd.grad(0.37 * (0.8 * a - 0.2 * s), p)
+        gref[v] = gg.permute(2, 0, 1)
+        l1 += a.item(); s_sum += s.item()
+    got = sums.cpu().numpy()
+    assert abs(got[0] - l1) <= 2e-6 * max(1.0, abs(l1)) * 3
+    assert abs(got[1] - s_sum) <= 1e-5 * max(1.0, abs(s_sum))
+    assert max_rel_err(grad.cpu().numpy(), gref.numpy()) < 1e-4
+
+
+def test_full_size_properties():
+    """1920x1080, 8 views: (i) identical images: L1 = 0, SSIM map = 1 everywhere, gradient 0;
+    (ii) the result does not depend on how views are batched; (iii) run-to-run bitwise equal
+    (no float atomics: the loss value is reproducible too)."""
+    from manus_amd import ops
+    V, H, W = 8, 1080, 1920
+    g = torch.Generator(device=DEV).manual_seed(5)
+    gt = torch.rand((V, 3, H, W), device=DEV, generator=g)
+    sums, grad = ops.image_loss_grad(gt, gt, 0.8, 0.2, 1.0)
+    s = sums.cpu().numpy()
+    assert s[0] == 0.0 and abs(s[1] / (V * 3 * H * W) - 1.0) < 1e-6
+    assert float(grad.abs().max()) < 1e-5
+    pred = (gt + 0.05 * torch.randn(gt.shape, device=DEV, generator=g)).clamp(0, 1)
+    s_all, g_all = ops.image_loss_grad(pred, gt, 0.8, 0.2, 1.0)
+    s_b, g_b = ops.image_loss_grad(pred, gt, 0.8, 0.2, 1.0)
+    assert torch.equal(g_all, g_b) and torch.equal(s_all, s_b)
+    s_one, g_one = ops.image_loss_grad(pred[3:4], gt[3:4], 0.8, 0.2, 1.0)
+    assert torch.equal(g_all[3:4], g_one)
+    acc = np.zeros(2)
+    for v in range(V):
+        acc += ops.image_loss_grad(pred[v:v + 1], gt[v:v + 1], 0.8, 0.2, 1.0)[0].double().cpu().numpy()
+    np.testing.assert_allclose(s_all.double().cpu().numpy(), acc, rtol=1e-6)

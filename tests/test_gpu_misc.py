@@ -153,7 +153,8 @@ def test_l1_loss_kernel():
     assert torch.equal(g, torch.sign(a - b) / a.numel())
 
 
-def test_engine_step_matches_sequential_reference_steps():
+@pytest.mark.parametrize("loss", ["l1", "l1+ssim"])
+def test_engine_step_matches_sequential_reference_steps(loss):
     """V views in one batched step == the mean of V single-view reference-style steps."""
     from manus_amd.engine import HipViewCompute, ViewShardedStep
     from manus_amd.synthetic import camera_table, make_scene
@@ -161,9 +162,14 @@ def test_engine_step_matches_sequential_reference_steps():
                     cam_radius=0.5, sigma_range=(2e-3, 8e-3), device=DEV)
     ct = camera_table(sc["cameras"], DEV)
     tg = torch.rand((4, 3, 64, 96), device=DEV)
-    hc = HipViewCompute(sc, tg, ct)
+    hc = HipViewCompute(sc, tg, ct, loss=loss)
     shapes = {k: v.shape for k, v in hc.params.items()}
     full = ViewShardedStep(sc["N"], shapes, hc, 4).step()
+    if loss == "l1+ssim":  # loss value = mean over views of 0.8 L1 + 0.2 (1 - ssim) of the oracle restatement
+        with torch.no_grad():
+            img = torch.cat([hc.forward_views([v])[0] for v in range(4)]).cpu()
+        ref = np.mean([float(tr.rgb_ssim_loss(img[v].permute(1, 2, 0), tg[v].cpu().permute(1, 2, 0))) for v in range(4)])
+        assert abs(float(full["loss"]) - ref) < 2e-5
     acc = None
     for v in range(4):
         o = hc([v], 1.0)

@@ -92,3 +92,22 @@ def test_project_points(golden_dir):
     d = np.load(os.path.join(golden_dir, "fk_novel_pose.npz"))
     got = tr.project_points(torch.tensor(d["pp_points"]), torch.tensor(d["pp_K"]), torch.tensor(d["pp_E"])).numpy()
     np.testing.assert_allclose(got, d["pp_out"], rtol=1e-5, atol=1e-3)
+
+
+def test_image_losses_match_reference(golden_dir):
+    """l1_loss / ssim as loss_func calls them (HWC images: the SSIM window runs over the (W,3)
+    plane of each row), values and gradients, against the reference's own outputs."""
+    d = np.load(os.path.join(golden_dir, "image_loss.npz"))
+    for k in range(3):
+        pred = torch.tensor(d[f"pred{k}"], requires_grad=True)
+        gt = torch.tensor(d[f"gt{k}"])
+        ss = tr.ssim_hwc(pred, gt)
+        assert abs(ss.item() - float(d[f"ssim_{k}"])) < 2e-6
+        (g,) = torch.autograd.grad(ss, pred)
+        assert max_rel_err(g.numpy(), d[f"g_ssim_{k}"]) < 2e-5
+        pred2 = torch.tensor(d[f"pred{k}"], requires_grad=True)
+        full = tr.rgb_ssim_loss(pred2, gt, 0.8, 0.2)
+        ref = 0.8 * float(d[f"l1_{k}"]) + 0.2 * (1.0 - float(d[f"ssim_{k}"]))
+        assert abs(full.item() - ref) < 2e-6
+        (g2,) = torch.autograd.grad(full, pred2)
+        assert max_rel_err(g2.numpy(), 0.8 * d[f"g_l1_{k}"] - 0.2 * d[f"g_ssim_{k}"]) < 2e-5
