@@ -117,8 +117,8 @@ __global__ __launch_bounds__(IL_T) void k_image_loss(int H, int W, const float* 
             const v2f A = 2.f * mu1 * mu2 + C1, B = 2.f * s12 + C2;
             const v2f Cc = mu1 * mu1 + mu2 * mu2 + C1, Dd = s11 + s22 + C2;
             v2f iC, iD;
-            iC.x = 1.0f / Cc.x; iC.y = 1.0f / Cc.y;
-            iD.x = 1.0f / Dd.x; iD.y = 1.0f / Dd.y;
+            iC.x = __builtin_amdgcn_rcpf(Cc.x); iC.y = __builtin_amdgcn_rcpf(Cc.y);  // 1 ulp; the bar is 1e-4 relative
+            iD.x = __builtin_amdgcn_rcpf(Dd.x); iD.y = __builtin_amdgcn_rcpf(Dd.y);
             const v2f inv = iC * iD;
             const v2f S = A * B * inv;
             const bool okw = w >= 0 && w < W;
