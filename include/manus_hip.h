@@ -245,6 +245,48 @@ int mgr_image_loss(int V, int H, int W, const float* pred, const float* target, 
                    void* stream);
 
 /* ------------------------------------------------------------------------
+ * Optimizer step and densification of the Gaussian parameter model
+ * (src/models/gaussian.py:128-338).
+ *
+ * mgr_adam_step: one torch.optim.Adam update (betas, eps as given; no weight
+ * decay, no amsgrad; the reference uses Adam(l, lr=0, eps=1e-15),
+ * gaussian.py:142) of `n_groups` <= 8 parameter groups in one launch.
+ * counts / lrs are host arrays; params, grads, exp_avg, exp_avg_sq are host
+ * arrays of device pointers (fp32, counts[k] elements each).  `step` is the
+ * 1-based step number of this update (bias correction).
+ *
+ * mgr_reset_opacity: reset_opacity, gaussian.py:148-165 (opacity <-
+ * inverse_sigmoid(min(sigmoid(opacity), 0.01)), both moments zeroed).
+ *
+ * mgr_densify_plan + mgr_densify_apply: densify_and_prune, gaussian.py:310-333
+ * (clone :288-308, split with N=2 :254-286, prune :183-200, optimizer-state
+ * surgery :148-252).  plan classifies the N Gaussians from the densification
+ * statistics (grad = accum / denom, NaN -> 0), scans, builds the source map in
+ * `workspace` and returns (blocking) counts_host[5] = {kept originals, kept
+ * clones, split-selected, kept split parents, M = new number of Gaussians}.
+ * apply writes the M new rows of the six leaves in group order (xyz 3, f_dc 3,
+ * f_rest 45, opacity 1, scaling 3, rotation 4), of both Adam moments (zero for
+ * new rows) and of the skin weights (N,B) (may be NULL), in the reference's
+ * order [kept originals | clones | split copies 0 | split copies 1].
+ * noise: standard normals (2 * n_selected, 3), row c * n_selected + j for copy c
+ * of the j-th split-selected Gaussian (torch.normal(mean=0, std) / std of :264-266).
+ * The reference's screen-size test (:316-318) never fires -- densification_postfix
+ * has just zeroed max_radii2D (:249-251) -- and is therefore not an input.
+ * ------------------------------------------------------------------------ */
+int mgr_adam_step(int n_groups, const int64_t* counts, float* const* params, const float* const* grads,
+                  float* const* exp_avg, float* const* exp_avg_sq, const double* lrs, int64_t step, double beta1,
+                  double beta2, double eps, void* stream);
+int mgr_reset_opacity(int N, float* opacity_logit, float* exp_avg, float* exp_avg_sq, void* stream);
+size_t mgr_densify_workspace_bytes(int N);
+int mgr_densify_plan(int N, const float* grad_accum, const float* denom, const float* log_scale,
+                     const float* opacity_logit, float max_grad, float min_opacity, float extent, float percent_dense,
+                     void* workspace, size_t workspace_bytes, int64_t* counts_host, void* stream);
+int mgr_densify_apply(int N, int64_t M, int64_t n_selected, const void* workspace, const float* const* params,
+                      const float* const* exp_avg, const float* const* exp_avg_sq, float* const* new_params,
+                      float* const* new_exp_avg, float* const* new_exp_avg_sq, const float* skin, float* new_skin, int B,
+                      const float* noise, void* stream);
+
+/* ------------------------------------------------------------------------
  * Measurement aid: when enabled, every kernel launched by this library is
  * bracketed by HIP events recorded on the caller's stream.
  * mgr_profile_report synchronises the stream, writes one line per kernel

@@ -51,6 +51,13 @@ SIGNATURES = {
     "mgr_l1_loss_grad": (c_int, [c_i64, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp]),
     "mgr_image_loss_workspace_bytes": (c_sz, [c_int, c_int, c_int]),
     "mgr_image_loss": (c_int, [c_int, c_int, c_int, c_vp, c_vp, c_f32, c_f32, c_f32, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "mgr_adam_step": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, ctypes.c_double, ctypes.c_double,
+                               ctypes.c_double, c_vp]),
+    "mgr_reset_opacity": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp]),
+    "mgr_densify_workspace_bytes": (c_sz, [c_int]),
+    "mgr_densify_plan": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_f32, c_vp, c_sz, c_vp, c_vp]),
+    "mgr_densify_apply": (c_int, [c_int, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int,
+                                   c_vp, c_vp]),
     "mgr_profile_enable": (c_int, [c_int]),
     "mgr_profile_report": (c_int, [ctypes.c_char_p, c_sz, c_vp]),
 }

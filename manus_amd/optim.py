@@ -1,0 +1,190 @@
+"""Optimizer step and densification of the Gaussian parameter model over the HIP kernels of
+`csrc/optim.hip`.
+
+Mirrors the training-side half of `GaussianModel` (brown-ivl/manus, src/models/gaussian.py):
+
+    training_setup          :128-146   six Adam groups (xyz, f_dc, f_rest, opacity, scaling, rotation), eps=1e-15
+    update_learning_rate    src/utils/gaussian_utils.py:501-508 + get_expon_lr_func :212-245 (xyz schedule)
+    optimizer.step()        one fused kernel over all six groups
+    add_densification_stats :335-338   (+ the max_radii2D update of density_update, gaussian_utils.py:470-473)
+    densify_and_prune       :310-333   clone + split + prune + Adam-moment surgery: plan + apply kernels
+    reset_opacity           :148-165
+
+The leaves keep the reference's names and shapes (`_xyz (N,3)`, `_features_dc (N,1,3)`,
+`_features_rest (N,15,3)`, `_opacity (N,1)`, `_scaling (N,3)`, `_rotation (N,4)`).  GPU tensors only;
+there is no CPU or PyTorch fallback.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from ._lib import ManusHipError, check, f32c, lib, ptr, stream
+
+# group order of training_setup (gaussian.py:133-140): (group name, attribute, row width)
+GROUPS = (("xyz", "_xyz", 3), ("f_dc", "_features_dc", 3), ("f_rest", "_features_rest", 45), ("opacity", "_opacity", 1),
+          ("scaling", "_scaling", 3), ("rotation", "_rotation", 4))
+
+DEFAULT_OPTS = dict(  # config/model/gaussian/gaussian.yaml
+    position_lr_init=0.0016, position_lr_final=0.0000016, position_lr_delay_mult=0.01, position_lr_max_steps=30000,
+    feature_lr=0.0025, opacity_lr=0.05, scaling_lr=0.005, rotation_lr=0.001, percent_dense=0.000001,
+    densification_interval=100, opacity_reset_interval=3000, densify_from_step=100, densify_until_step=50000,
+    densify_grad_threshold=0.0002, min_opacity_threshold=0.005, size_threshold=20)
+
+
+def get_expon_lr_func(lr_init, lr_final, lr_delay_steps=0, lr_delay_mult=1.0, max_steps=1000000):
+    """Log-linear learning-rate decay, gaussian_utils.py:212-245 (host arithmetic, float64)."""
+
+    def helper(step):
+        if step < 0 or (lr_init == 0.0 and lr_final == 0.0):
+            return 0.0
+        delay_rate = 1.0
+        if lr_delay_steps > 0:
+            delay_rate = lr_delay_mult + (1 - lr_delay_mult) * np.sin(0.5 * np.pi * np.clip(step / lr_delay_steps, 0, 1))
+        t = np.clip(step / max_steps, 0, 1)
+        return float(delay_rate * np.exp(np.log(lr_init) * (1 - t) + np.log(lr_final) * t))
+
+    return helper
+
+
+def _ptr_array(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[ptr(t) for t in tensors])
+
+
+class GaussianOptimizer:
+    """Leaves + Adam state + densification statistics of one Gaussian model on one GPU."""
+
+    def __init__(self, params, opts=None, spatial_lr_scale=1.0, skin_weights=None, adopt=False):
+        """params: {attribute name: tensor}.  adopt=True updates the given tensors in place (they stay the
+        leaves other code holds, e.g. `engine.HipViewCompute.params`) until densification replaces them."""
+        self.opts = dict(DEFAULT_OPTS, **(opts or {}))
+        self.spatial_lr_scale = float(spatial_lr_scale)
+        self.p = {}
+        for _, attr, w in GROUPS:
+            t = params[attr]
+            if not t.is_cuda:
+                raise ManusHipError("manus_amd.optim needs GPU tensors; there is no CPU fallback")
+            self.p[attr] = t.detach() if (adopt and t.dtype == torch.float32 and t.is_contiguous()) else f32c(t.detach()).clone()
+        self.skin_weights = f32c(skin_weights).clone() if skin_weights is not None else None
+        self.training_setup()
+
+    # -- training_setup, gaussian.py:128-146 ------------------------------------------------
+    def training_setup(self):
+        o, dev = self.opts, self.device
+        self.m = {a: torch.zeros_like(self.p[a]) for _, a, _ in GROUPS}
+        self.v = {a: torch.zeros_like(self.p[a]) for _, a, _ in GROUPS}
+        self.state_step = 0                                 # steps taken (shared by the six groups)
+        self.lr = {"xyz": o["position_lr_init"] * self.spatial_lr_scale, "f_dc": o["feature_lr"],
+                   "f_rest": o["feature_lr"] / 20.0, "opacity": o["opacity_lr"], "scaling": o["scaling_lr"],
+                   "rotation": o["rotation_lr"]}
+        self.xyz_scheduler_args = get_expon_lr_func(o["position_lr_init"] * self.spatial_lr_scale,
+                                                    o["position_lr_final"] * self.spatial_lr_scale,
+                                                    lr_delay_mult=o["position_lr_delay_mult"],
+                                                    max_steps=o["position_lr_max_steps"])
+        self._reset_stats()
+
+    def _reset_stats(self):
+        n, dev = self.N, self.device
+        self.xyz_gradient_accum = torch.zeros((n, 1), dtype=torch.float32, device=dev)
+        self.denom = torch.zeros((n, 1), dtype=torch.float32, device=dev)
+        self.max_radii2D = torch.zeros((n,), dtype=torch.float32, device=dev)
+
+    @property
+    def N(self):
+        return self.p["_xyz"].shape[0]
+
+    @property
+    def device(self):
+        return self.p["_xyz"].device
+
+    def parameters(self):
+        """The six leaves by the reference's attribute names (live tensors, updated in place by step())."""
+        return self.p
+
+    # -- update_learning_rate, gaussian_utils.py:501-508 --------------------------------------
+    def update_learning_rate(self, global_step):
+        self.lr["xyz"] = self.xyz_scheduler_args(global_step)
+        return self.lr["xyz"]
+
+    # -- optimizer.step() ---------------------------------------------------------------------
+    def step(self, grads, beta1=0.9, beta2=0.999, eps=1e-15):
+        """One Adam update of all six groups from `grads` {attribute name: tensor of the leaf's shape}."""
+        g = [f32c(grads[a]) for _, a, _ in GROUPS]
+        for (_, a, _), t in zip(GROUPS, g):
+            if t.numel() != self.p[a].numel():
+                raise ManusHipError("step: gradient of %s has the wrong size" % a)
+        self.state_step += 1
+        counts = (ctypes.c_int64 * 6)(*[self.p[a].numel() for _, a, _ in GROUPS])
+        lrs = (ctypes.c_double * 6)(*[self.lr[n] for n, _, _ in GROUPS])
+        check(lib().mgr_adam_step(6, counts, _ptr_array([self.p[a] for _, a, _ in GROUPS]), _ptr_array(g),
+                                  _ptr_array([self.m[a] for _, a, _ in GROUPS]),
+                                  _ptr_array([self.v[a] for _, a, _ in GROUPS]), lrs, self.state_step, beta1, beta2, eps,
+                                  stream()), "mgr_adam_step")
+
+    # -- add_densification_stats (+ max radii), gaussian.py:335-338, gaussian_utils.py:470-473 -
+    def add_densification_stats(self, grad2d_sum, vis_count, radii_max):
+        """Accumulate the statistics of one multi-view step (`fused.ViewStats` / `ViewShardedStep` outputs):
+        sum over views of ||dL/dmeans2D[:, :2]||, number of views that saw the Gaussian, max screen radius."""
+        self.xyz_gradient_accum += grad2d_sum.reshape(-1, 1)
+        self.denom += vis_count.reshape(-1, 1).to(torch.float32)
+        self.max_radii2D = torch.maximum(self.max_radii2D, radii_max.to(torch.float32))
+
+    # -- densify_and_prune, gaussian.py:310-333 ------------------------------------------------
+    def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size=None, noise=None):
+        """Clone / split / prune exactly like the reference, including the order of the surviving rows and the
+        zero Adam moments of new rows.  `max_screen_size` is accepted for signature parity; in the reference it
+        cannot prune anything (max_radii2D is zeroed by densification_postfix before it is read, :249-251,316-318).
+        `noise`: optional standard normals (2*n_selected, 3) for the split offsets (default: torch.randn)."""
+        N, dev = self.N, self.device
+        nbytes = int(lib().mgr_densify_workspace_bytes(N))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        counts = (ctypes.c_int64 * 5)()
+        check(lib().mgr_densify_plan(N, ptr(self.xyz_gradient_accum), ptr(self.denom), ptr(self.p["_scaling"]),
+                                     ptr(self.p["_opacity"]), float(max_grad), float(min_opacity), float(extent),
+                                     float(self.opts["percent_dense"]), ptr(ws), nbytes, counts, stream()),
+              "mgr_densify_plan")
+        n_sel, M = int(counts[2]), int(counts[4])
+        if noise is None:
+            noise = torch.randn((2 * n_sel, 3), dtype=torch.float32, device=dev)
+        noise = f32c(noise)
+        if noise.numel() != 2 * n_sel * 3:
+            raise ManusHipError("densify_and_prune: noise must be (2*%d, 3)" % n_sel)
+        shp = lambda a: (M,) + tuple(self.p[a].shape[1:])
+        new_p = {a: torch.empty(shp(a), dtype=torch.float32, device=dev) for _, a, _ in GROUPS}
+        new_m = {a: torch.empty(shp(a), dtype=torch.float32, device=dev) for _, a, _ in GROUPS}
+        new_v = {a: torch.empty(shp(a), dtype=torch.float32, device=dev) for _, a, _ in GROUPS}
+        B = self.skin_weights.shape[1] if self.skin_weights is not None else 0
+        new_skin = torch.empty((M, B), dtype=torch.float32, device=dev) if B else None
+        order = [a for _, a, _ in GROUPS]
+        check(lib().mgr_densify_apply(N, M, n_sel, ptr(ws), _ptr_array([self.p[a] for a in order]),
+                                      _ptr_array([self.m[a] for a in order]), _ptr_array([self.v[a] for a in order]),
+                                      _ptr_array([new_p[a] for a in order]), _ptr_array([new_m[a] for a in order]),
+                                      _ptr_array([new_v[a] for a in order]), ptr(self.skin_weights), ptr(new_skin), B,
+                                      ptr(noise), stream()), "mgr_densify_apply")
+        self.p, self.m, self.v, self.skin_weights = new_p, new_m, new_v, new_skin
+        self._reset_stats()
+        return dict(kept=int(counts[0]), cloned=int(counts[1]), split_selected=n_sel, split_kept=int(counts[3]), total=M)
+
+    # -- reset_opacity, gaussian.py:148-165 -----------------------------------------------------
+    def reset_opacity(self):
+        check(lib().mgr_reset_opacity(self.N, ptr(self.p["_opacity"]), ptr(self.m["_opacity"]), ptr(self.v["_opacity"]),
+                                      stream()), "mgr_reset_opacity")
+
+    # -- density_update schedule, gaussian_utils.py:451-498 --------------------------------------
+    def density_update(self, stats, extent, global_step, bg_white=True):
+        """The per-step densification control flow of `density_update` on the statistics of a step
+        (dict with grad2d, vis, radii as returned by `engine.ViewShardedStep.step`).  Returns True when the
+        parameter tensors were replaced."""
+        o, changed = self.opts, False
+        if global_step < o["densify_until_step"]:
+            self.add_densification_stats(stats["grad2d"], stats["vis"], stats["radii"])
+            if global_step > o["densify_from_step"] and global_step % o["densification_interval"] == 0:
+                size_threshold = o["size_threshold"] if global_step > o["opacity_reset_interval"] else None
+                self.densify_and_prune(o["densify_grad_threshold"], o["min_opacity_threshold"], extent, size_threshold)
+                changed = True
+            if global_step % o["opacity_reset_interval"] == 0 or (bg_white and global_step == o["densify_from_step"]):
+                if global_step != 0:
+                    self.reset_opacity()
+                    changed = True
+        return changed

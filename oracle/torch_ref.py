@@ -288,3 +288,111 @@ def rgb_ssim_loss(pred_hwc, gt_hwc, w_rgb=0.8, w_ssim=0.2):
     """w_rgb * mean|pred-gt| + w_ssim * (1 - ssim): base.py:323-365 with HAND_GAUSSIAN.yaml:22-23."""
     gt = gt_hwc[0] if gt_hwc.dim() == 4 else gt_hwc
     return w_rgb * (pred_hwc - gt).abs().mean() + w_ssim * (1.0 - ssim_hwc(pred_hwc, gt))
+
+
+# ---------------------------------------------------------------------------
+# optimizer step, learning-rate schedule, densification (SURVEY.md 8f rank 1)
+# ---------------------------------------------------------------------------
+LEAVES = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")   # group order of training_setup, gaussian.py:133-140
+
+
+def expon_lr(step, lr_init, lr_final, lr_delay_steps=0, lr_delay_mult=1.0, max_steps=1000000):
+    """get_expon_lr_func(...)(step), gaussian_utils.py:212-245 (float64 like the numpy original)."""
+    if step < 0 or (lr_init == 0.0 and lr_final == 0.0):
+        return 0.0
+    delay = 1.0
+    if lr_delay_steps > 0:
+        delay = lr_delay_mult + (1 - lr_delay_mult) * np.sin(0.5 * np.pi * np.clip(step / lr_delay_steps, 0, 1))
+    t = np.clip(step / max_steps, 0, 1)
+    return float(delay * np.exp(np.log(lr_init) * (1 - t) + np.log(lr_final) * t))
+
+
+def group_lrs(opts, spatial_lr_scale, step):
+    """Learning rates of the six groups at `step`: training_setup (gaussian.py:133-146) with the xyz rate
+    replaced by the schedule (update_learning_rate, gaussian_utils.py:501-508; lr_delay_steps is left at
+    its default 0, so position_lr_delay_mult has no effect -- as in the reference)."""
+    return [expon_lr(step, opts["position_lr_init"] * spatial_lr_scale, opts["position_lr_final"] * spatial_lr_scale,
+                     max_steps=opts["position_lr_max_steps"]),
+            opts["feature_lr"], opts["feature_lr"] / 20.0, opts["opacity_lr"], opts["scaling_lr"], opts["rotation_lr"]]
+
+
+def adam_step(p, g, m, v, lr, t, beta1=0.9, beta2=0.999, eps=1e-15):
+    """One torch.optim.Adam update (no weight decay, no amsgrad) of the t-th step (t >= 1), the optimizer of
+    gaussian.py:142 (Adam(l, lr=0, eps=1e-15)); returns new (p, m, v)."""
+    m = m + (g - m) * (1 - beta1)
+    v = v * beta2 + g * g * (1 - beta2)
+    bc1, bc2 = 1 - beta1 ** t, 1 - beta2 ** t
+    denom = v.sqrt() / math.sqrt(bc2) + eps
+    return p - (lr / bc1) * (m / denom), m, v
+
+
+def _rot_from_raw_quat(r):
+    q = r / r.norm(dim=1, keepdim=True)
+    w, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                     2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                     2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], dim=1)
+    return R.reshape(-1, 3, 3)
+
+
+def densify_and_prune(state, accum, denom, max_grad, min_opacity, extent, percent_dense, noise, n_split=2):
+    """densify_and_prune of gaussian.py:310-333 (clone :288-308, split :254-286, prune :183-200, optimizer
+    surgery :148-252) on a dict of tensors:
+        state[name], state[name + "_m"], state[name + "_v"] for name in LEAVES, state["skin"] (N,B) or None.
+    noise: standard normals (n_split * n_selected, 3), row c * n_selected + j for copy c of the j-th split
+    Gaussian (the layout of `torch.normal(mean, std)` at :264-266 divided by std).
+    Returns the new state dict.  The reference's size test (max_radii2D > max_screen_size, :316-318) never
+    fires because densification_postfix has just zeroed max_radii2D (:249-251); it is therefore absent here.
+    New rows get zero Adam moments; the statistics are reset by the caller (they are all zeros afterwards)."""
+    N = state["xyz"].shape[0]
+    grads = accum / denom
+    grads[grads.isnan()] = 0.0
+    gn = grads.reshape(N, -1).norm(dim=-1)
+    smax = state["scaling"].exp().max(dim=1).values
+    clone = (gn >= max_grad) & (smax <= percent_dense * extent)
+    split = (grads.reshape(-1) >= max_grad) & (smax > percent_dense * extent)
+    sel = torch.nonzero(split)[:, 0]
+    ns = sel.shape[0]
+
+    def rows(name, idx):
+        return state[name][idx]
+
+    new = {}
+    std = state["scaling"].exp()[sel].repeat(n_split, 1)
+    samples = noise.reshape(-1, 3)[: n_split * ns] * std
+    R = _rot_from_raw_quat(state["rotation"][sel]).repeat(n_split, 1, 1)
+    child_xyz = torch.bmm(R, samples[:, :, None])[:, :, 0] + state["xyz"][sel].repeat(n_split, 1)
+    child_scaling = torch.log(state["scaling"].exp()[sel].repeat(n_split, 1) / (0.8 * n_split))
+    keep_orig = ~split
+    for name in LEAVES:
+        p = state[name]
+        rep = (n_split,) + (1,) * (p.dim() - 1)
+        child = p[sel].repeat(*rep)
+        if name == "xyz":
+            child = child_xyz
+        elif name == "scaling":
+            child = child_scaling
+        new[name] = torch.cat([p[keep_orig], p[clone], child])
+        for suf in ("_m", "_v"):
+            q = state[name + suf]
+            new[name + suf] = torch.cat([q[keep_orig], torch.zeros_like(q[clone]), torch.zeros_like(child)])
+    if state.get("skin") is not None:
+        sk = state["skin"]
+        new["skin"] = torch.cat([sk[keep_orig], sk[clone], sk[sel].repeat(n_split, 1)])
+    prune = torch.sigmoid(new["opacity"]).reshape(-1) < min_opacity
+    prune |= new["scaling"].exp().max(dim=1).values > 0.1 * extent
+    if torch.isnan(new["scaling"].mean()):
+        prune |= torch.isnan(new["scaling"]).any(dim=-1)
+    keep = ~prune
+    return {k: v[keep] for k, v in new.items()}
+
+
+def reset_opacity(state):
+    """reset_opacity of gaussian.py:148-151: opacity <- inverse_sigmoid(min(sigmoid(opacity), 0.01)), Adam moments
+    of the opacity group zeroed (:153-165)."""
+    o = torch.minimum(torch.sigmoid(state["opacity"]), torch.full_like(state["opacity"], 0.01))
+    out = dict(state)
+    out["opacity"] = torch.log(o / (1 - o))
+    out["opacity_m"] = torch.zeros_like(state["opacity"])
+    out["opacity_v"] = torch.zeros_like(state["opacity"])
+    return out

@@ -20,6 +20,8 @@ Reference functions exercised (paths relative to /root/reference):
   * src/utils/cam_utils.py:19-78           getProjectionMatrix / get_opengl_camera_attributes
   * src/utils/transforms.py:233-261,489-530,304-311  get_pose_wrt_root / euler_angles_to_matrix / project_points
   * src/utils/loss_utils.py:22-97          l1_loss / ssim (called on HWC images like base.py:329-347)
+  * src/models/gaussian.py:128-338         training_setup / Adam groups / densify_and_prune / reset_opacity
+  * src/utils/gaussian_utils.py:212-245,501-511  get_expon_lr_func / update_learning_rate
   * data/meta_data/novel_pose.pkl, data/camera_paths/real.pkl  (known-answer data)
 """
 import os
@@ -351,6 +353,116 @@ def make_image_loss_golden(mods):
     return out
 
 
+GAUSSIAN_OPTS = dict(  # config/model/gaussian/gaussian.yaml
+    sh_degree=3, position_lr_init=0.0016, position_lr_final=0.0000016, position_lr_delay_mult=0.01,
+    position_lr_max_steps=30000, feature_lr=0.0025, opacity_lr=0.05, scaling_lr=0.005, rotation_lr=0.001,
+    percent_dense=0.000001, densification_interval=100, opacity_reset_interval=3000, densify_from_step=100,
+    densify_until_step=50000, densify_grad_threshold=0.0002, min_opacity_threshold=0.005, size_threshold=20,
+    remove_outliers_step=-1, isotropic_scaling=False)
+
+
+def _make_model(mods, g, n, n_bones, percent_dense, spatial_lr_scale):
+    """A GaussianModel built without __init__ (it needs distCUDA2 / a GPU), then the reference's own
+    training_setup() (src/models/gaussian.py:128-146)."""
+    from easydict import EasyDict
+    gm = mods["gaussian"].GaussianModel
+    m = gm.__new__(gm)
+    torch.nn.Module.__init__(m)
+    m.opts = EasyDict(dict(GAUSSIAN_OPTS, percent_dense=percent_dense))
+    m.active_sh_degree, m.max_sh_degree = 3, 3
+    m.spatial_lr_scale = spatial_lr_scale
+    m.setup_functions()
+    rn = lambda *s, sc=1.0: torch.randn(*s, generator=g) * sc
+    P = torch.nn.Parameter
+    m._xyz = P(rn(n, 3, sc=0.05))
+    m._features_dc = P(rn(n, 1, 3))
+    m._features_rest = P(rn(n, 15, 3, sc=0.1))
+    # log sigma: a mix of small and large Gaussians so that both clone and split fire
+    m._scaling = P(torch.log(torch.exp(torch.rand(n, 3, generator=g) * 4.0 - 8.5)))
+    m._rotation = P(rn(n, 4))
+    m._opacity = P(rn(n, 1, sc=2.5))
+    w = torch.rand(n, n_bones, generator=g)
+    m._skin_weights = w / w.sum(1, keepdim=True)
+    m.max_radii2D = torch.zeros(n)
+    m.training_setup()
+    return m
+
+
+_LEAVES = (("_xyz", "xyz"), ("_features_dc", "f_dc"), ("_features_rest", "f_rest"), ("_opacity", "opacity"),
+           ("_scaling", "scaling"), ("_rotation", "rotation"))
+
+
+def _dump_model(m, out, tag):
+    for attr, name in _LEAVES:
+        p = getattr(m, attr)
+        out[f"{tag}_{name}"] = p.detach().numpy().copy()
+        st = m.optimizer.state.get(p, None)
+        if st is not None and "exp_avg" in st:
+            out[f"{tag}_{name}_m"] = st["exp_avg"].numpy().copy()
+            out[f"{tag}_{name}_v"] = st["exp_avg_sq"].numpy().copy()
+    out[f"{tag}_skin"] = m._skin_weights.numpy().copy()
+    out[f"{tag}_accum"] = m.xyz_gradient_accum.numpy().copy()
+    out[f"{tag}_denom"] = m.denom.numpy().copy()
+    out[f"{tag}_maxrad"] = m.max_radii2D.numpy().copy()
+
+
+def make_optimizer_golden(mods, seed, percent_dense, size_threshold):
+    """The reference's own optimizer step, learning-rate schedule, densify_and_prune and reset_opacity
+    (src/models/gaussian.py:128-338, src/utils/gaussian_utils.py:212-245,501-511) on a small model:
+    state before / after K Adam steps, after densify_and_prune (torch.normal recorded) and after
+    reset_opacity."""
+    gu = mods["gaussian_utils"]
+    g = torch.Generator().manual_seed(seed)
+    n, nb, K = 300, 21, 3
+    m = _make_model(mods, g, n, nb, percent_dense, spatial_lr_scale=1.3)
+    out = {"percent_dense": np.float32(percent_dense), "spatial_lr_scale": np.float32(1.3), "K": np.int32(K),
+           "size_threshold": np.float32(size_threshold if size_threshold else 0.0)}
+    _dump_model(m, out, "init")
+    lrs = []
+    for k in range(K):
+        step = 1 + 977 * k                      # exercise the xyz schedule away from step 0
+        gu.update_learning_rate(m.optimizer, m, step)
+        lrs.append([grp["lr"] for grp in m.optimizer.param_groups])
+        m.optimizer.zero_grad(set_to_none=True)
+        for attr, name in _LEAVES:
+            p = getattr(m, attr)
+            gr = torch.randn(p.shape, generator=g) * (1e-3 if name != "f_rest" else 1e-4)
+            gr[torch.rand(n, generator=g) < 0.4] = 0.0       # untouched Gaussians get exact zeros
+            p.grad = gr
+            out[f"grad{k}_{name}"] = gr.numpy().copy()
+        out[f"step{k}"] = np.int32(step)
+        m.optimizer.step()
+    out["lrs"] = np.asarray(lrs, np.float64)
+    _dump_model(m, out, "adam")
+    # densification statistics as add_densification_stats leaves them (gaussian.py:335-338)
+    m.xyz_gradient_accum = torch.rand(n, 1, generator=g) * 8e-4
+    m.denom = torch.randint(0, 4, (n, 1), generator=g).float()      # zeros -> NaN -> 0 (gaussian.py:312)
+    m.max_radii2D = torch.rand(n, generator=g) * 40.0
+    out["stat_accum"], out["stat_denom"], out["stat_maxrad"] = (m.xyz_gradient_accum.numpy().copy(),
+                                                                m.denom.numpy().copy(), m.max_radii2D.numpy().copy())
+    rec = {}
+    orig_normal = torch.normal
+
+    def normal_rec(mean=None, std=None, **kw):
+        r = orig_normal(mean=mean, std=std, generator=g, **kw)
+        rec["std"], rec["samples"] = std.clone(), r.clone()
+        return r
+
+    torch.normal = normal_rec
+    try:
+        extent = 0.5
+        m.densify_and_prune(m.opts.densify_grad_threshold, m.opts.min_opacity_threshold, extent, size_threshold)
+    finally:
+        torch.normal = orig_normal
+    out["extent"] = np.float32(extent)
+    out["split_std"] = rec["std"].detach().numpy().copy() if rec else np.zeros((0, 3), np.float32)
+    out["split_samples"] = rec["samples"].detach().numpy().copy() if rec else np.zeros((0, 3), np.float32)
+    _dump_model(m, out, "dens")
+    m.reset_opacity()
+    _dump_model(m, out, "reset")
+    return out
+
+
 def main():
     mods = _import_reference()
     torch.manual_seed(0)
@@ -366,6 +478,9 @@ def main():
     np.savez_compressed(os.path.join(OUT, "fk_novel_pose.npz"), **make_fk_golden(mods))
     np.savez_compressed(os.path.join(OUT, "sh_eval.npz"), **make_sh_golden(mods))
     np.savez_compressed(os.path.join(OUT, "image_loss.npz"), **make_image_loss_golden(mods))
+    # percent_dense of the shipped config (1e-6: every selected Gaussian splits) and one that also clones
+    np.savez_compressed(os.path.join(OUT, "optimizer_s0.npz"), **make_optimizer_golden(mods, 0, 0.000001, 20))
+    np.savez_compressed(os.path.join(OUT, "optimizer_s1.npz"), **make_optimizer_golden(mods, 1, 0.02, None))
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -111,3 +111,54 @@ def test_image_losses_match_reference(golden_dir):
         assert abs(full.item() - ref) < 2e-6
         (g2,) = torch.autograd.grad(full, pred2)
         assert max_rel_err(g2.numpy(), 0.8 * d[f"g_l1_{k}"] - 0.2 * d[f"g_ssim_{k}"]) < 2e-5
+
+
+GAUSSIAN_OPTS = dict(position_lr_init=0.0016, position_lr_final=0.0000016, position_lr_max_steps=30000,
+                     feature_lr=0.0025, opacity_lr=0.05, scaling_lr=0.005, rotation_lr=0.001,
+                     densify_grad_threshold=0.0002, min_opacity_threshold=0.005)   # config/model/gaussian/gaussian.yaml
+
+
+def _opt_state(d, tag):
+    st = {}
+    for n in tr.LEAVES:
+        st[n] = torch.tensor(d[f"{tag}_{n}"])
+        st[n + "_m"] = torch.tensor(d[f"{tag}_{n}_m"]) if f"{tag}_{n}_m" in d else torch.zeros_like(st[n])
+        st[n + "_v"] = torch.tensor(d[f"{tag}_{n}_v"]) if f"{tag}_{n}_v" in d else torch.zeros_like(st[n])
+    st["skin"] = torch.tensor(d[f"{tag}_skin"])
+    return st
+
+
+@pytest.mark.parametrize("name", ["optimizer_s0.npz", "optimizer_s1.npz"])
+def test_optimizer_and_densify_match_reference(golden_dir, name):
+    """Adam steps with the xyz schedule, densify_and_prune and reset_opacity restated in oracle/torch_ref.py
+    against the reference's own GaussianModel run (tests/golden/make_golden.py::make_optimizer_golden)."""
+    d = np.load(os.path.join(golden_dir, name))
+    st = _opt_state(d, "init")
+    K = int(d["K"])
+    for k in range(K):
+        lrs = tr.group_lrs(GAUSSIAN_OPTS, float(d["spatial_lr_scale"]), int(d[f"step{k}"]))
+        np.testing.assert_allclose(lrs, d["lrs"][k], rtol=1e-6)  # spatial_lr_scale is stored as fp32
+        for n, lr in zip(tr.LEAVES, lrs):
+            st[n], st[n + "_m"], st[n + "_v"] = tr.adam_step(st[n], torch.tensor(d[f"grad{k}_{n}"]), st[n + "_m"],
+                                                             st[n + "_v"], lr, k + 1)
+    for n in tr.LEAVES:
+        assert max_rel_err(st[n].numpy(), d[f"adam_{n}"]) < 2e-6, n
+        assert max_rel_err(st[n + "_m"].numpy(), d[f"adam_{n}_m"]) < 2e-6, n
+        assert max_rel_err(st[n + "_v"].numpy(), d[f"adam_{n}_v"]) < 2e-6, n
+    st = _opt_state(d, "adam")
+    std = d["split_std"]
+    noise = torch.tensor(d["split_samples"] / std) if std.size else torch.zeros((0, 3))
+    new = tr.densify_and_prune(st, torch.tensor(d["stat_accum"]), torch.tensor(d["stat_denom"]),
+                               GAUSSIAN_OPTS["densify_grad_threshold"], GAUSSIAN_OPTS["min_opacity_threshold"],
+                               float(d["extent"]), float(d["percent_dense"]), noise)
+    assert new["xyz"].shape == d["dens_xyz"].shape and new["xyz"].shape[0] != d["adam_xyz"].shape[0]
+    for n in tr.LEAVES:
+        assert max_rel_err(new[n].numpy(), d[f"dens_{n}"]) < 2e-6, n
+        np.testing.assert_array_equal(new[n + "_m"].numpy(), d[f"dens_{n}_m"])
+        np.testing.assert_array_equal(new[n + "_v"].numpy(), d[f"dens_{n}_v"])
+    np.testing.assert_array_equal(new["skin"].numpy(), d["dens_skin"])
+    assert not d["dens_accum"].any() and not d["dens_denom"].any() and not d["dens_maxrad"].any()
+    rs = tr.reset_opacity(new)
+    assert max_rel_err(rs["opacity"].numpy(), d["reset_opacity"]) < 2e-6
+    assert not d["reset_opacity_m"].any() and not d["reset_opacity_v"].any()
+    np.testing.assert_array_equal(rs["xyz_m"].numpy(), d["reset_xyz_m"])
