@@ -287,6 +287,19 @@ int mgr_densify_apply(int N, int64_t M, int64_t n_selected, const void* workspac
                       const float* noise, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Contact distance: for each of the N1 points of pt1
+ * (N1,3) the fp32 distance to its nearest point of pt2 (N2,3) and that point's
+ * index.  Replaces get_contact_dist (taichi kernel, src/utils/gaussian_utils.py:
+ * 521-549) and get_contact_map (chunked torch.cdist().min(), :514-518).  Same
+ * loop semantics: dist = sqrt(dx^2+dy^2+dz^2), strict '<' on the rooted
+ * distance (lowest index wins a tie), initial minimum 1e9 (N2 = 0 -> 1e9, index 0).
+ * out_idx (int32) may be NULL.
+ * ------------------------------------------------------------------------ */
+size_t mgr_contact_workspace_bytes(int N1, int N2);
+int mgr_contact_dist(int N1, const float* pt1, int N2, const float* pt2, float* out_dist, int32_t* out_idx,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------
  * Measurement aid: when enabled, every kernel launched by this library is
  * bracketed by HIP events recorded on the caller's stream.
  * mgr_profile_report synchronises the stream, writes one line per kernel

@@ -11,7 +11,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["raster_fwd.hip", "raster_bwd.hip", "lbs_sh.hip", "knn.hip", "image_loss.hip", "optim.hip"]
+SOURCES = ["raster_fwd.hip", "raster_bwd.hip", "lbs_sh.hip", "knn.hip", "image_loss.hip", "optim.hip", "contact.hip"]
 HEADERS = ["mgr_common.h", "instance_math.h", os.path.join("..", "..", "include", "manus_hip.h")]
 LIB = os.path.join(HERE, "libmanus_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

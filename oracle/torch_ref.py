@@ -396,3 +396,32 @@ def reset_opacity(state):
     out["opacity_m"] = torch.zeros_like(state["opacity"])
     out["opacity_v"] = torch.zeros_like(state["opacity"])
     return out
+
+
+# ---------------------------------------------------------------------------
+# contact distance
+# ---------------------------------------------------------------------------
+def contact_dist(pt1, pt2, chunk=512):
+    """get_contact_dist of gaussian_utils.py:521-549 (the taichi loop) in fp32 numpy: per point of pt1 the
+    rooted distance to the nearest point of pt2 and the lowest index attaining it (strict '<' in the loop;
+    np.argmin returns the first minimum), min_dist initialised to 1e9.  Sum order dx^2 + dy^2 + dz^2.
+    The taichi package is not in this image, so this row is pinned by the reference's other implementation of
+    the same quantity, get_contact_map (torch.cdist), through tests/golden/contact.npz (distances only)."""
+    a, b = np.asarray(pt1, np.float32), np.asarray(pt2, np.float32)
+    n1, n2 = a.shape[0], b.shape[0]
+    dist = np.full(n1, 1e9, np.float32)
+    idx = np.zeros(n1, np.int64)
+    if n2 == 0:
+        return dist, idx
+    for s in range(0, n1, chunk):
+        d = a[s:s + chunk, None, :] - b[None, :, :]
+        d2 = d[..., 0] * d[..., 0]
+        d2 = d2 + d[..., 1] * d[..., 1]
+        d2 = d2 + d[..., 2] * d[..., 2]
+        r = np.sqrt(d2)
+        j = np.argmin(r, axis=1)
+        m = r[np.arange(r.shape[0]), j]
+        ok = m < 1e9
+        dist[s:s + chunk] = np.where(ok, m, np.float32(1e9))
+        idx[s:s + chunk] = np.where(ok, j, 0)
+    return dist, idx

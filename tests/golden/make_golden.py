@@ -22,6 +22,7 @@ Reference functions exercised (paths relative to /root/reference):
   * src/utils/loss_utils.py:22-97          l1_loss / ssim (called on HWC images like base.py:329-347)
   * src/models/gaussian.py:128-338         training_setup / Adam groups / densify_and_prune / reset_opacity
   * src/utils/gaussian_utils.py:212-245,501-511  get_expon_lr_func / update_learning_rate
+  * src/utils/gaussian_utils.py:514-518    get_contact_map (torch.cdist nearest-point distance)
   * data/meta_data/novel_pose.pkl, data/camera_paths/real.pkl  (known-answer data)
 """
 import os
@@ -463,6 +464,23 @@ def make_optimizer_golden(mods, seed, percent_dense, size_threshold):
     return out
 
 
+def make_contact_golden(mods):
+    """get_contact_map (src/utils/gaussian_utils.py:514-518: chunked torch.cdist().min) on hand-like /
+    object-like clouds.  get_contact_dist itself is a taichi kernel and taichi is not in this image."""
+    gu = mods["gaussian_utils"]
+    g = torch.Generator().manual_seed(7)
+    out = {}
+    for k, (n1, n2) in enumerate(((1, 1), (37, 5), (700, 1500), (2500, 1100))):
+        pt1 = torch.randn(n1, 3, generator=g) * 0.04
+        pt2 = torch.randn(n2, 3, generator=g) * 0.04 + torch.tensor([0.03, 0.0, 0.0])
+        if k == 2:
+            pt2[100:110] = pt1[50:60]            # exact contacts
+            pt2[200] = pt2[17]                   # duplicated target point (index tie)
+        out[f"pt1_{k}"], out[f"pt2_{k}"] = pt1.numpy(), pt2.numpy()
+        out[f"dist_{k}"] = gu.get_contact_map(pt1, pt2, chunk=1024).numpy()
+    return out
+
+
 def main():
     mods = _import_reference()
     torch.manual_seed(0)
@@ -478,6 +496,7 @@ def main():
     np.savez_compressed(os.path.join(OUT, "fk_novel_pose.npz"), **make_fk_golden(mods))
     np.savez_compressed(os.path.join(OUT, "sh_eval.npz"), **make_sh_golden(mods))
     np.savez_compressed(os.path.join(OUT, "image_loss.npz"), **make_image_loss_golden(mods))
+    np.savez_compressed(os.path.join(OUT, "contact.npz"), **make_contact_golden(mods))
     # percent_dense of the shipped config (1e-6: every selected Gaussian splits) and one that also clones
     np.savez_compressed(os.path.join(OUT, "optimizer_s0.npz"), **make_optimizer_golden(mods, 0, 0.000001, 20))
     np.savez_compressed(os.path.join(OUT, "optimizer_s1.npz"), **make_optimizer_golden(mods, 1, 0.02, None))

@@ -162,3 +162,16 @@ def test_optimizer_and_densify_match_reference(golden_dir, name):
     assert max_rel_err(rs["opacity"].numpy(), d["reset_opacity"]) < 2e-6
     assert not d["reset_opacity_m"].any() and not d["reset_opacity_v"].any()
     np.testing.assert_array_equal(rs["xyz_m"].numpy(), d["reset_xyz_m"])
+
+
+def test_contact_distance_matches_reference(golden_dir):
+    """The loop restatement of get_contact_dist against the reference's other implementation of the same
+    quantity (get_contact_map = torch.cdist().min): distances agree to cdist's accuracy; the index attains it."""
+    d = np.load(os.path.join(golden_dir, "contact.npz"))
+    for k in range(4):
+        pt1, pt2 = d[f"pt1_{k}"], d[f"pt2_{k}"]
+        dist, idx = tr.contact_dist(pt1, pt2)
+        np.testing.assert_allclose(dist, d[f"dist_{k}"], rtol=2e-4, atol=5e-5)   # torch.cdist is matmul-based: exact contacts come out as ~2e-5
+        np.testing.assert_allclose(np.linalg.norm(pt1 - pt2[idx], axis=1), dist, rtol=1e-6, atol=1e-9)
+    dist, idx = tr.contact_dist(d["pt1_2"], d["pt2_2"])
+    assert (dist[50:60] == 0).all() and (idx[50:60] == np.arange(100, 110)).all()
