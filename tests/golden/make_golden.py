@@ -23,6 +23,7 @@ Reference functions exercised (paths relative to /root/reference):
   * src/models/gaussian.py:128-338         training_setup / Adam groups / densify_and_prune / reset_opacity
   * src/utils/gaussian_utils.py:212-245,501-511  get_expon_lr_func / update_learning_rate
   * src/utils/gaussian_utils.py:514-518    get_contact_map (torch.cdist nearest-point distance)
+  * src/utils/train_utils.py:165-204, src/utils/extra.py:203-242  load_checkpoint / remove_nans / find_best_checkpoint
   * data/meta_data/novel_pose.pkl, data/camera_paths/real.pkl  (known-answer data)
 """
 import os
@@ -481,6 +482,41 @@ def make_contact_golden(mods):
     return out
 
 
+def make_checkpoint_golden(mods):
+    """load_checkpoint / remove_nans_from_checkpoint (src/utils/train_utils.py:165-204) on a Lightning-shaped
+    checkpoint with NaN rows, and find_best_checkpoint (src/utils/extra.py:203-242) on a directory of names."""
+    import tempfile
+    import src.utils.train_utils as tu
+    import src.utils.extra as ex
+    g = torch.Generator().manual_seed(11)
+    n = 40
+    sd = {"model._xyz": torch.randn(n, 3, generator=g), "model._features_dc": torch.randn(n, 1, 3, generator=g),
+          "model._features_rest": torch.randn(n, 15, 3, generator=g), "model._scaling": torch.randn(n, 3, generator=g),
+          "model._rotation": torch.randn(n, 4, generator=g), "model._opacity": torch.randn(n, 1, generator=g)}
+    sd["model._xyz"][3, 1] = float("nan")
+    sd["model._features_rest"][17, 4, 2] = float("nan")
+    sd["model._opacity"][29, 0] = float("nan")
+    sd["model._scaling"][3, 0] = float("nan")
+    extra = {"num_gaussians": n, "grid_scale": torch.tensor([0.2, 0.15, 0.1]), "grid_center": torch.zeros(3),
+             "grid_points": torch.zeros(4, 3), "grid_weights": torch.rand(2, 2, 2, 21, generator=g)}
+    out = {"in_" + k.replace("model.", ""): v.numpy().copy() for k, v in sd.items()}
+    names = ["epoch=003-step=1200-loss=0.012345.ckpt", "epoch=010-step=4400-loss=0.009100.ckpt",
+             "epoch=009-step=4000-loss=0.008700.ckpt", "epoch=002-step=800-loss=0.008700.ckpt"]
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, names[0])
+        torch.save({"epoch": 3, "global_step": 1200, "state_dict": sd, "extra_params": extra}, path)
+        for nm in names[1:]:
+            open(os.path.join(td, nm), "wb").close()
+        w, e = tu.load_checkpoint(path)
+        for k, v in w.items():
+            out["out_" + k] = v.numpy().copy()
+        out["out_num_gaussians"] = np.int64(e["num_gaussians"])
+        out["best_epoch"] = os.path.basename(ex.find_best_checkpoint(td, sort_by="epoch"))
+        out["best_loss"] = os.path.basename(ex.find_best_checkpoint(td, sort_by="loss"))
+    out["names"] = np.array(names)
+    return out
+
+
 def main():
     mods = _import_reference()
     torch.manual_seed(0)
@@ -497,6 +533,7 @@ def main():
     np.savez_compressed(os.path.join(OUT, "sh_eval.npz"), **make_sh_golden(mods))
     np.savez_compressed(os.path.join(OUT, "image_loss.npz"), **make_image_loss_golden(mods))
     np.savez_compressed(os.path.join(OUT, "contact.npz"), **make_contact_golden(mods))
+    np.savez_compressed(os.path.join(OUT, "checkpoint.npz"), **make_checkpoint_golden(mods))
     # percent_dense of the shipped config (1e-6: every selected Gaussian splits) and one that also clones
     np.savez_compressed(os.path.join(OUT, "optimizer_s0.npz"), **make_optimizer_golden(mods, 0, 0.000001, 20))
     np.savez_compressed(os.path.join(OUT, "optimizer_s1.npz"), **make_optimizer_golden(mods, 1, 0.02, None))

@@ -245,3 +245,39 @@ def test_view_sharded_step_gloo_world2():
     assert torch.allclose(got["grad2d"], ref["grad2d"], rtol=1e-5)
     assert torch.equal(got["vis"], ref["vis"]) and torch.equal(got["radii"], ref["radii"])
     assert abs(float(got["loss"]) - float(ref["loss"])) < 1e-4 * max(1.0, abs(float(ref["loss"])))
+
+
+def test_checkpoint_format_matches_reference_loader(golden_dir, tmp_path):
+    """manus_amd.checkpoint against the reference's own load_checkpoint / find_best_checkpoint outputs
+    (tests/golden/checkpoint.npz): NaN rows dropped from every leaf, prefix stripped, the same file chosen
+    (including the reference's string comparison of steps / epochs)."""
+    import numpy as np
+    import torch
+    from manus_amd import checkpoint as ck
+    d = np.load(os.path.join(golden_dir, "checkpoint.npz"))
+    leaves = ["_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity"]
+    sd = {"model." + k: torch.tensor(d["in_" + k]) for k in leaves}
+    names = [str(x) for x in d["names"]]
+    torch.save({"epoch": 3, "global_step": 1200, "state_dict": sd, "extra_params": {"num_gaussians": 40}},
+               str(tmp_path / names[0]))
+    for nm in names[1:]:
+        (tmp_path / nm).write_bytes(b"")
+    w, e = ck.load_checkpoint(str(tmp_path / names[0]))
+    assert e["num_gaussians"] == int(d["out_num_gaussians"]) == w["_xyz"].shape[0]
+    for k in leaves:
+        np.testing.assert_array_equal(w[k].numpy(), d["out_" + k])
+    assert os.path.basename(ck.find_best_checkpoint(str(tmp_path), "epoch")) == str(d["best_epoch"])
+    assert os.path.basename(ck.find_best_checkpoint(str(tmp_path), "loss")) == str(d["best_loss"])
+    # round trip through the writer: the file name format and the keys the reference reads back
+    params = {k: w[k] for k in leaves}
+    grid = {"grid_scale": torch.ones(3), "grid_center": torch.zeros(3), "grid_points": torch.zeros(2, 3),
+            "grid_weights": torch.rand(2, 2, 2, 21)}
+    path = ck.save_checkpoint(str(tmp_path / "out"), params, epoch=7, step=2800, loss=0.0123456, grid=grid)
+    assert os.path.basename(path) == "epoch=007-step=2800-loss=0.012346.ckpt"
+    raw = torch.load(path, weights_only=False)
+    assert sorted(raw["state_dict"]) == sorted("model." + k for k in leaves)
+    assert raw["extra_params"]["num_gaussians"] == 37 and "grid_weights" in raw["extra_params"]
+    w2, e2 = ck.load_checkpoint(path)
+    for k in leaves:
+        np.testing.assert_array_equal(w2[k].numpy(), d["out_" + k])
+    assert ck.get_num_gaussians_from_checkpoint(path) == 37
