@@ -93,9 +93,9 @@ def cpu_baseline(scene_cpu, cam0, sample_views=1, n_views=8, loss="l1+ssim"):
     t2b = time.time()
     b = ro.backward(g)
     t3 = time.time()
-    loss = ((o["posed_xyz"] * torch.tensor(b["means3D"])).sum() + (o["posed_cov"] * torch.tensor(b["cov3D"])).sum()
+    chain = ((o["posed_xyz"] * torch.tensor(b["means3D"])).sum() + (o["posed_cov"] * torch.tensor(b["cov3D"])).sum()
             + (o["colors"] * torch.tensor(b["colors"])).sum() + (o["opacity"][:, 0] * torch.tensor(b["opacity"])).sum())
-    loss.backward()
+    chain.backward()
     t4 = time.time()
     t_view = t4 - t0
     return {"value": 1.0 / (t_view * n_views), "unit": "iters/s", "cores": threads, "kind": "port",

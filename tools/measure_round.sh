@@ -3,6 +3,7 @@
 # stats of the same bench command, and the FETCH_SIZE / WRITE_SIZE counter passes.
 # Usage: tools/measure_round.sh TAG      (outputs under gpurun_out/)
 TAG=${1:-x}
+RND=${2:-r01}
 ROOT=$(pwd)
 export TMPDIR=/tmp
 python -m pytest tests -m gpu -x -q 2>&1 | tail -3 > gpurun_out/tests_$TAG.log
