@@ -236,13 +236,15 @@ int mgr_l1_loss_grad(int64_t count, const float* a, const float* b, float scale,
  * loss_utils.py:58); that is the statistic computed here.
  *   dL_dpred (V,3,H,W) = grad_scale * (w_l1 * sign(pred - target) - w_ssim * d(sum ssim_map)/dpred)
  *   sums[0] = sum|pred - target|, sums[1] = sum of the ssim map (both over V*3*H*W values),
+ *   sums[2] = grad_scale * (w_l1 * sums[0] - w_ssim * sums[1]) + loss_offset  (the loss value whose
+ *             gradient dL_dpred is; loss_offset carries the constant of "1 - ssim"),
  * so mean L1 = sums[0]/(V*3*H*W) and the reference's ssim(...) of one view = sums[1]/(3*H*W).
  * workspace: mgr_image_loss_workspace_bytes(V,H,W) bytes of scratch (per-workgroup sums).
  * ------------------------------------------------------------------------ */
 size_t mgr_image_loss_workspace_bytes(int V, int H, int W);
 int mgr_image_loss(int V, int H, int W, const float* pred, const float* target, float w_l1, float w_ssim,
-                   float grad_scale, float* dL_dpred, float* sums, void* workspace, size_t workspace_bytes,
-                   void* stream);
+                   float grad_scale, float loss_offset, float* dL_dpred, float* sums, void* workspace,
+                   size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
  * Optimizer step and densification of the Gaussian parameter model

@@ -204,7 +204,7 @@ __global__ __launch_bounds__(IL_T) void k_image_loss(int H, int W, const float* 
 
 // fold the per-workgroup sums: sums[0] = sum |pred - target|, sums[1] = sum of the SSIM map
 __global__ __launch_bounds__(1024) void k_image_loss_fold(int64_t n, const float2* __restrict__ partial,
-                                                          float* __restrict__ sums) {
+                                                          float* __restrict__ sums, float ca, float cb, float cc) {
     __shared__ double s_a[16], s_b[16];
     double a = 0.0, b = 0.0;
     for (int64_t k = threadIdx.x; k < n; k += 1024) {
@@ -230,6 +230,7 @@ __global__ __launch_bounds__(1024) void k_image_loss_fold(int64_t n, const float
         }
         sums[0] = (float)ta;
         sums[1] = (float)tb;
+        sums[2] = (float)((double)ca * ta + (double)cb * tb + (double)cc);  // the caller's loss value, no host-side arithmetic
     }
 }
 
@@ -241,8 +242,8 @@ extern "C" size_t mgr_image_loss_workspace_bytes(int V, int H, int W) {
 }
 
 extern "C" int mgr_image_loss(int V, int H, int W, const float* pred, const float* target, float w_l1, float w_ssim,
-                              float grad_scale, float* dL_dpred, float* sums, void* workspace, size_t workspace_bytes,
-                              void* stream_) {
+                              float grad_scale, float loss_offset, float* dL_dpred, float* sums, void* workspace,
+                              size_t workspace_bytes, void* stream_) {
     if (V <= 0 || H <= 0 || W <= 0) return mgr_fail(MGR_EINVAL, "mgr_image_loss: bad sizes");
     if (!pred || !target || !dL_dpred || !sums || !workspace) return mgr_fail(MGR_EINVAL, "mgr_image_loss: null pointer");
     if (H > 65535 || V > 65535) return mgr_fail(MGR_EINVAL, "mgr_image_loss: H and V must fit a grid dimension");
@@ -264,7 +265,7 @@ extern "C" int mgr_image_loss(int V, int H, int W, const float* pred, const floa
                            dL_dpred, (float2*)workspace);
     }
     hipLaunchKernelGGL(k_image_loss_fold, dim3(1), dim3(1024), 0, stream, il_blocks(V, H, W), (const float2*)workspace,
-                       sums);
+                       sums, grad_scale * w_l1, -grad_scale * w_ssim, loss_offset);
     MGR_LAUNCH_CHECK("k_image_loss", stream, 0);
     return MGR_OK;
 }

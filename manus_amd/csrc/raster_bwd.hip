@@ -53,6 +53,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int T = gx * gy;
     const uint32_t n_items = hdr->n_items;
+    if (blockIdx.x == 0 && tid == 0) hdr->n_active = 0;  // for the gather that follows (first view group)
     const size_t P = (size_t)W * H;
     // screen-space mean gradient: d(pixel)/d(ndc) = W/2, H/2; ln2 from the log2-domain conic
     const float kx = MGR_LN2 * 0.5f * (float)W, ky = MGR_LN2 * 0.5f * (float)H;
@@ -652,7 +653,7 @@ static int raster_backward_impl(int V, int N, int W, int H, const float* cams, c
         for (int v0 = 0; v0 < V; v0 += Gv) {
             const int vc = V - v0 < Gv ? V - v0 : Gv;
             const int accm = v0 > 0 ? 1 : 0;
-            MGR_HIP(hipMemsetAsync(&hdr->n_active, 0, 4, stream));
+            if (v0 > 0) MGR_HIP(hipMemsetAsync(&hdr->n_active, 0, 4, stream));  // the first group's zero comes from k_blend_bwd
 #define MGR_IG_LAUNCH(GG)                                                                                             \
     hipLaunchKernelGGL((k_inst_gather<GG>), grid_g, dim3(256), 0, stream, v0, vc, N, canon->B, canon->radii,            \
                        (const ushort4*)(ws + L.rect), (const uint32_t*)(ws + L.pair_off),                             \

@@ -319,7 +319,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan_a(int VT, const uint32_t* __
 // Phase B: every block re-derives its base from the (few) block sums, writes tile_start /
 // chunk_start, and scatters its tiles into the size-ordered queue (largest class first, empty
 // tiles last; order inside a class is arbitrary).
-__global__ __launch_bounds__(1024) void k_tile_scan_b(int VT, int nblk, const uint32_t* __restrict__ tile_count,
+__global__ __launch_bounds__(1024) void k_tile_scan_b(int VT, int nblk, uint32_t* __restrict__ tile_count,
                                                       const uint2* __restrict__ part,
                                                       uint32_t* __restrict__ tile_start,
                                                       uint32_t* __restrict__ tile_cursor,
@@ -347,6 +347,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan_b(int VT, int nblk, const ui
     }
     __syncthreads();
     const uint32_t c = k < VT ? tile_count[k] : 0u;
+    if (k < VT) tile_count[k] = 0;  // consumed: left zero for the next forward (no per-call memset of V*T counters)
     uint32_t total, ctotal;
     const uint32_t run = block_excl_scan(c, s_scan, total);
     const uint32_t crun = block_excl_scan(c ? (c - 1) / MGR_CHUNK : 0u, s_scan, ctotal);
@@ -837,6 +838,10 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, 
     unsigned long long tl0 = wall_clock64(), ntl = 0;
 #endif
     if (tid == 0) s_next = atomicAdd(&hdr->queue_head2, 1u);
+    if (blockIdx.x == 0 && tid < 34) {  // consumed by the tile scan: zero for the next forward (no per-call memset)
+        hdr->cls_count[tid] = 0;
+        hdr->cls_cursor[tid] = 0;
+    }
     __syncthreads();
     uint32_t item = s_next;
     while (item < n_busy) {
@@ -1080,8 +1085,8 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
 
     // per-call counters (epoch lives past the first 32 bytes and persists)
     MGR_HIP(hipMemsetAsync(hdr, 0, 8, stream));
-    MGR_HIP(hipMemsetAsync(&hdr->cls_count[0], 0, sizeof(uint32_t) * 68, stream));
-    MGR_HIP(hipMemsetAsync(tile_count, 0, (size_t)VT * 4, stream));
+    // tile_count and the size-class counters are left zero by the previous forward on this workspace
+    // (k_tile_scan_b / k_blend_fwd) and by the zero-filled allocation before the first one
 
     const int lds_hist = ((size_t)T * 4 + 128 <= 150 * 1024) ? 1 : 0;
     const size_t hist_bytes = lds_hist ? (size_t)T * 4 : 0;

@@ -155,9 +155,9 @@ class HipViewCompute:
         if self.loss == "l1":
             loss_sum, g = self.ops.l1_loss_grad(img, tgt, scale=k)
             return loss_sum[0] * k, g
-        sums, g = self.ops.image_loss_grad(img, tgt, self.w_rgb, self.w_ssim, k)
         const = self.w_ssim * self.loss_weight * scale * img.shape[0]   # the "1 -" of 1 - ssim, once per view
-        return k * (self.w_rgb * sums[0] - self.w_ssim * sums[1]) + const, g
+        sums, g = self.ops.image_loss_grad(img, tgt, self.w_rgb, self.w_ssim, k, const)
+        return sums[2], g
 
     def _call_fused(self, view_ids, scale):
         for v in self.params.values():

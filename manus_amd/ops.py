@@ -210,12 +210,12 @@ def l1_loss_grad(pred, target, scale=None):
     return s, g
 
 
-def image_loss_grad(pred, target, w_l1=0.8, w_ssim=0.2, grad_scale=1.0):
+def image_loss_grad(pred, target, w_l1=0.8, w_ssim=0.2, grad_scale=1.0, loss_offset=0.0):
     """Fused L1 + SSIM image loss of the training step (loss_utils.py:22-97 as called at
     base.py:323-365), forward and backward, on (V,3,H,W) images.
 
-    Returns (sums, grad): sums[0] = sum|pred-target|, sums[1] = sum of the SSIM map (device
-    tensor of 2 floats); grad = grad_scale * d/dpred [w_l1 * sum|pred-target| - w_ssim * sum ssim_map].
+    Returns (sums, grad): sums[0] = sum|pred-target|, sums[1] = sum of the SSIM map, sums[2] =
+    grad_scale * (w_l1 * sums[0] - w_ssim * sums[1]) + loss_offset (device tensor of 3 floats); grad = grad_scale * d/dpred [w_l1 * sum|pred-target| - w_ssim * sum ssim_map].
     The SSIM statistic is the reference's: ssim() called on HWC images, i.e. the 11x11 window
     slides over the (W,3) plane of every row."""
     pred, target = f32c(pred), f32c(target)
@@ -225,9 +225,9 @@ def image_loss_grad(pred, target, w_l1=0.8, w_ssim=0.2, grad_scale=1.0):
         raise ManusHipError("image_loss_grad: pred and target must both be (V,3,H,W)")
     V, _, H, W = pred.shape
     g = torch.empty_like(pred)
-    sums = torch.empty(2, dtype=torch.float32, device=pred.device)
+    sums = torch.empty(3, dtype=torch.float32, device=pred.device)
     nbytes = int(lib().mgr_image_loss_workspace_bytes(V, H, W))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=pred.device)
-    check(lib().mgr_image_loss(V, H, W, ptr(pred), ptr(target), float(w_l1), float(w_ssim), float(grad_scale), ptr(g),
-                               ptr(sums), ptr(ws), nbytes, stream()), "mgr_image_loss")
+    check(lib().mgr_image_loss(V, H, W, ptr(pred), ptr(target), float(w_l1), float(w_ssim), float(grad_scale),
+                               float(loss_offset), ptr(g), ptr(sums), ptr(ws), nbytes, stream()), "mgr_image_loss")
     return sums, g

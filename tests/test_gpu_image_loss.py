@@ -45,7 +45,7 @@ def test_kernel_matches_oracle(V, H, W):
     g = torch.Generator().manual_seed(V * 1000 + W)
     gt = torch.rand((V, 3, H, W), generator=g)
     pred = (gt + 0.1 * torch.randn((V, 3, H, W), generator=g)).clamp(0, 1.1)
-    sums, grad = ops.image_loss_grad(pred.to(DEV), gt.to(DEV), 0.8, 0.2, 0.37)
+    sums, grad = ops.image_loss_grad(pred.to(DEV), gt.to(DEV), 0.8, 0.2, 0.37, 0.125)
     l1 = s_sum = 0.0
     gref = torch.zeros_like(pred)
     for v in range(V):
@@ -59,6 +59,8 @@ def test_kernel_matches_oracle(V, H, W):
     got = sums.cpu().numpy()
     assert abs(got[0] - l1) <= 2e-6 * max(1.0, abs(l1)) * 3
     assert abs(got[1] - s_sum) <= 1e-5 * max(1.0, abs(s_sum))
+    want = 0.37 * (0.8 * l1 - 0.2 * s_sum) + 0.125                  # the loss value the gradient belongs to
+    assert abs(got[2] - want) <= 1e-5 * max(1.0, abs(want))
     assert max_rel_err(grad.cpu().numpy(), gref.numpy()) < 1e-4
 
 
@@ -82,5 +84,5 @@ def test_full_size_properties():
     assert torch.equal(g_all[3:4], g_one)
     acc = np.zeros(2)
     for v in range(V):
-        acc += ops.image_loss_grad(pred[v:v + 1], gt[v:v + 1], 0.8, 0.2, 1.0)[0].double().cpu().numpy()
-    np.testing.assert_allclose(s_all.double().cpu().numpy(), acc, rtol=1e-6)
+        acc += ops.image_loss_grad(pred[v:v + 1], gt[v:v + 1], 0.8, 0.2, 1.0)[0][:2].double().cpu().numpy()
+    np.testing.assert_allclose(s_all[:2].double().cpu().numpy(), acc, rtol=1e-6)
