@@ -288,6 +288,14 @@ int mgr_densify_apply(int N, int64_t M, int64_t n_selected, const void* workspac
                       float* const* new_exp_avg, float* const* new_exp_avg_sq, const float* skin, float* new_skin, int B,
                       const float* noise, void* stream);
 
+/* Isotropic regulariser of loss_func (src/modules/base.py:349-356):
+ *   loss[0] = weight * mean_n (min_j s_nj / (max_j s_nj + 1e-8) - condition_number)^2, s = exp(log_scale (N,3));
+ *   d_log_scale (N,3) = its gradient (added to the existing content when accumulate != 0).
+ * workspace: mgr_isotropic_reg_workspace_bytes(N). */
+size_t mgr_isotropic_reg_workspace_bytes(int N);
+int mgr_isotropic_reg(int N, const float* log_scale, float condition_number, float weight, float* d_log_scale,
+                      int accumulate, float* loss, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------
  * Contact distance: for each of the N1 points of pt1
  * (N1,3) the fp32 distance to its nearest point of pt2 (N2,3) and that point's

@@ -58,6 +58,8 @@ SIGNATURES = {
     "mgr_densify_plan": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_f32, c_vp, c_sz, c_vp, c_vp]),
     "mgr_densify_apply": (c_int, [c_int, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int,
                                    c_vp, c_vp]),
+    "mgr_isotropic_reg_workspace_bytes": (c_sz, [c_int]),
+    "mgr_isotropic_reg": (c_int, [c_int, c_vp, c_f32, c_f32, c_vp, c_int, c_vp, c_vp, c_sz, c_vp]),
     "mgr_contact_workspace_bytes": (c_sz, [c_int, c_int]),
     "mgr_contact_dist": (c_int, [c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "mgr_profile_enable": (c_int, [c_int]),

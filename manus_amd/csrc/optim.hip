@@ -394,3 +394,71 @@ extern "C" int mgr_densify_apply(int N, int64_t M, int64_t n_selected, const voi
     MGR_LAUNCH_CHECK("k_dens_apply", stream, 0);
     return MGR_OK;
 }
+
+// ---------------------------------------------------------------------------
+// isotropic regulariser (src/modules/base.py:349-356):
+//   L = mean_n (min_j s_nj / (max_j s_nj + 1e-8) - condition_number)^2,  s = exp(log_scale)
+// value and gradient w.r.t. log_scale in one pass.  torch.max / torch.min send the gradient to the
+// first index attaining the extreme; so does this.  Per-workgroup sums + a fold: reproducible value.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_isotropic_reg(int N, const float* __restrict__ log_scale, float cond,
+                                                       float grad_scale, float* __restrict__ d_log_scale, int accumulate,
+                                                       float* __restrict__ partial) {
+    __shared__ float s_red[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float term = 0.f;
+    if (i < N) {
+        const float s[3] = {expf(log_scale[3 * i]), expf(log_scale[3 * i + 1]), expf(log_scale[3 * i + 2])};
+        int jmax = 0, jmin = 0;
+#pragma unroll
+        for (int j = 1; j < 3; ++j) {
+            if (s[j] > s[jmax]) jmax = j;
+            if (s[j] < s[jmin]) jmin = j;
+        }
+        const float den = s[jmax] + 1e-8f;
+        const float r = s[jmin] / den - cond;
+        term = r * r;
+        const float dmin = 2.f * r / den, dmax = -2.f * r * s[jmin] / (den * den);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float g = grad_scale * ((j == jmin ? dmin : 0.f) + (j == jmax ? dmax : 0.f)) * s[j];
+            d_log_scale[3 * i + j] = accumulate ? d_log_scale[3 * i + j] + g : g;
+        }
+    }
+    term = mgr_wave_sum63(term);
+    if ((threadIdx.x & 63) == 63) s_red[threadIdx.x >> 6] = term;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+
+__global__ __launch_bounds__(1024) void k_fold_sum(int n, const float* __restrict__ partial, float scale,
+                                                   float* __restrict__ out) {
+    __shared__ double s_a[16];
+    double a = 0.0;
+    for (int k = threadIdx.x; k < n; k += 1024) a += (double)partial[k];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) a += __shfl_xor(a, d, 64);
+    if ((threadIdx.x & 63) == 0) s_a[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int k = 0; k < 16; ++k) t += s_a[k];
+        out[0] = (float)(t * (double)scale);
+    }
+}
+
+extern "C" size_t mgr_isotropic_reg_workspace_bytes(int N) { return N > 0 ? (size_t)((N + 255) / 256) * 4 : 0; }
+
+extern "C" int mgr_isotropic_reg(int N, const float* log_scale, float condition_number, float weight, float* d_log_scale,
+                                 int accumulate, float* loss, void* workspace, size_t workspace_bytes, void* stream_) {
+    if (N <= 0) return mgr_fail(MGR_EINVAL, "mgr_isotropic_reg: bad size");
+    if (!log_scale || !d_log_scale || !loss || !workspace) return mgr_fail(MGR_EINVAL, "mgr_isotropic_reg: null pointer");
+    if (workspace_bytes < mgr_isotropic_reg_workspace_bytes(N)) return mgr_fail(MGR_ENOMEM, "mgr_isotropic_reg: workspace too small");
+    hipStream_t stream = (hipStream_t)stream_;
+    const int nblk = (N + 255) / 256;
+    hipLaunchKernelGGL(k_isotropic_reg, dim3(nblk), dim3(256), 0, stream, N, log_scale, condition_number, weight / (float)N,
+                       d_log_scale, accumulate, (float*)workspace);
+    hipLaunchKernelGGL(k_fold_sum, dim3(1), dim3(1024), 0, stream, nblk, (const float*)workspace, weight / (float)N, loss);
+    MGR_LAUNCH_CHECK("k_isotropic_reg", stream, 0);
+    return MGR_OK;
+}

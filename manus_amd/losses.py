@@ -64,3 +64,22 @@ def rgb_ssim_loss(pred_image, gt_image, w_rgb=0.8, w_ssim=0.2):
     """w_rgb * l1_loss + w_ssim * (1 - ssim) in one kernel: the first two terms of
     config/HAND_GAUSSIAN.yaml:22-23 as combined by loss_func (base.py:356-364)."""
     return _ImageLoss.apply(pred_image, gt_image, w_rgb, w_ssim) + w_ssim
+
+
+class _IsotropicReg(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, log_scale, condition_number):
+        loss, g = ops.isotropic_reg_grad(log_scale, condition_number, 1.0)
+        ctx.save_for_backward(g)
+        return loss[0].clone()
+
+    @staticmethod
+    def backward(ctx, go):
+        (g,) = ctx.saved_tensors
+        return g * go, None
+
+
+def isotropic_reg(log_scale, condition_number=0.4):
+    """mean((min_scale / (max_scale + 1e-8) - condition_number)**2) of base.py:349-356, taking the log-scales
+    (`model._scaling`; the reference reads `model.get_scaling = exp(_scaling)`)."""
+    return _IsotropicReg.apply(log_scale, condition_number)

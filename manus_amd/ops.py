@@ -231,3 +231,21 @@ def image_loss_grad(pred, target, w_l1=0.8, w_ssim=0.2, grad_scale=1.0, loss_off
     check(lib().mgr_image_loss(V, H, W, ptr(pred), ptr(target), float(w_l1), float(w_ssim), float(grad_scale),
                                float(loss_offset), ptr(g), ptr(sums), ptr(ws), nbytes, stream()), "mgr_image_loss")
     return sums, g
+
+
+def isotropic_reg_grad(log_scale, condition_number=0.4, weight=1.0, grad_out=None):
+    """weight * mean((min s / (max s + 1e-8) - condition_number)^2), s = exp(log_scale), and its gradient
+    w.r.t. log_scale (base.py:349-356).  grad_out: optional (N,3) tensor to ADD the gradient to.
+    Returns (loss (1,), gradient tensor)."""
+    ls = f32c(log_scale)
+    N = ls.shape[0]
+    acc = grad_out is not None
+    g = grad_out if acc else torch.empty_like(ls)
+    if acc and (g.dtype != torch.float32 or not g.is_contiguous() or g.shape != ls.shape):
+        raise ManusHipError("isotropic_reg_grad: grad_out must be a contiguous fp32 (N,3) tensor")
+    loss = torch.empty(1, dtype=torch.float32, device=ls.device)
+    nbytes = int(lib().mgr_isotropic_reg_workspace_bytes(N))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=ls.device)
+    check(lib().mgr_isotropic_reg(N, ptr(ls), float(condition_number), float(weight), ptr(g), 1 if acc else 0, ptr(loss),
+                                  ptr(ws), nbytes, stream()), "mgr_isotropic_reg")
+    return loss, g

@@ -425,3 +425,9 @@ def contact_dist(pt1, pt2, chunk=512):
         dist[s:s + chunk] = np.where(ok, m, np.float32(1e9))
         idx[s:s + chunk] = np.where(ok, j, 0)
     return dist, idx
+
+
+def isotropic_reg(log_scale, condition_number=0.4):
+    """isotropic_reg of loss_func, base.py:349-356, on the log-scales (get_scaling = exp(_scaling), gaussian.py:62-67)."""
+    s = torch.exp(log_scale)
+    return torch.mean((s.min(dim=1)[0] / (s.max(dim=1)[0] + 1e-8) - condition_number) ** 2)

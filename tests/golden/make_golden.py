@@ -28,6 +28,8 @@ Reference functions exercised (paths relative to /root/reference):
 """
 import os
 import sys
+
+sys.dont_write_bytecode = True  # never leave __pycache__ files in the read-only reference tree
 import types
 
 import numpy as np
@@ -465,6 +467,36 @@ def make_optimizer_golden(mods, seed, percent_dense, size_threshold):
     return out
 
 
+def make_loss_func_golden(mods):
+    """The reference's loss_func itself (src/modules/base.py:323-365) with the losses of
+    config/OBJ_GAUSSIAN.yaml:22-23 (['rgb_loss', 'ssim_loss', 'isotropic_reg'], [0.8, 0.2, 0.1]): the final
+    loss and its gradients w.r.t. the render and the log-scales."""
+    from easydict import EasyDict
+    base = mods["hand_dynamic"].TrainingModule.__mro__[1]          # BaseTrainingModule
+    g = torch.Generator().manual_seed(21)
+    H, W, n = 9, 50, 500
+    gt = torch.rand((1, H, W, 3), generator=g)
+    pred = (gt[0] + 0.1 * torch.randn((H, W, 3), generator=g)).clamp(0, 1).requires_grad_(True)
+    log_s = (torch.rand(n, 3, generator=g) * 4.0 - 8.5)
+    log_s[7] = log_s[7, 0]                                          # an isotropic Gaussian: max == min (tie)
+    log_s = log_s.requires_grad_(True)
+
+    class _Model:
+        opts = EasyDict(condition_number=0.4)
+
+        @property
+        def get_scaling(self):
+            return torch.exp(log_s)
+
+    fake = types.SimpleNamespace(model=_Model(), global_step=0, log=lambda *a, **k: None)
+    loss = base.loss_func(fake, {"mask": [None], "rgb": gt}, {"render": pred}, ["rgb_loss", "ssim_loss", "isotropic_reg"],
+                          [0.8, 0.2, 0.1], log_losses=False)
+    g_pred, g_s = torch.autograd.grad(loss, [pred, log_s])
+    iso = base.loss_func(fake, {"mask": [None], "rgb": gt}, {"render": pred}, ["isotropic_reg"], [1.0], log_losses=False)
+    return {"pred": pred.detach().numpy(), "gt": gt.numpy(), "log_scale": log_s.detach().numpy(),
+            "loss": np.float32(loss.item()), "iso": np.float32(iso.item()), "g_pred": g_pred.numpy(), "g_log_scale": g_s.numpy()}
+
+
 def make_contact_golden(mods):
     """get_contact_map (src/utils/gaussian_utils.py:514-518: chunked torch.cdist().min) on hand-like /
     object-like clouds.  get_contact_dist itself is a taichi kernel and taichi is not in this image."""
@@ -533,6 +565,7 @@ def main():
     np.savez_compressed(os.path.join(OUT, "sh_eval.npz"), **make_sh_golden(mods))
     np.savez_compressed(os.path.join(OUT, "image_loss.npz"), **make_image_loss_golden(mods))
     np.savez_compressed(os.path.join(OUT, "contact.npz"), **make_contact_golden(mods))
+    np.savez_compressed(os.path.join(OUT, "loss_func.npz"), **make_loss_func_golden(mods))
     np.savez_compressed(os.path.join(OUT, "checkpoint.npz"), **make_checkpoint_golden(mods))
     # percent_dense of the shipped config (1e-6: every selected Gaussian splits) and one that also clones
     np.savez_compressed(os.path.join(OUT, "optimizer_s0.npz"), **make_optimizer_golden(mods, 0, 0.000001, 20))

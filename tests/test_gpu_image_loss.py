@@ -86,3 +86,26 @@ def test_full_size_properties():
     for v in range(V):
         acc += ops.image_loss_grad(pred[v:v + 1], gt[v:v + 1], 0.8, 0.2, 1.0)[0][:2].double().cpu().numpy()
     np.testing.assert_allclose(s_all[:2].double().cpu().numpy(), acc, rtol=1e-6)
+
+
+def test_training_loss_matches_reference_loss_func(golden_dir):
+    """The three image/shape terms of the reference's loss_func (base.py:323-365; OBJ_GAUSSIAN.yaml:22-23) from the
+    fused kernels, value and gradients w.r.t. the render and the log-scales."""
+    from manus_amd import losses
+    d = np.load(os.path.join(golden_dir, "loss_func.npz"))
+    pred = torch.tensor(d["pred"], device=DEV, requires_grad=True)
+    ls = torch.tensor(d["log_scale"], device=DEV, requires_grad=True)
+    gt = torch.tensor(d["gt"], device=DEV)
+    loss = losses.rgb_ssim_loss(pred, gt, 0.8, 0.2) + 0.1 * losses.isotropic_reg(ls, 0.4)
+    assert abs(loss.item() - float(d["loss"])) < 5e-6
+    assert abs(losses.isotropic_reg(ls, 0.4).item() - float(d["iso"])) < 2e-6
+    gp, gs = torch.autograd.grad(loss, [pred, ls])
+    assert max_rel_err(gp.cpu().numpy(), d["g_pred"]) < 1e-4
+    assert max_rel_err(gs.cpu().numpy(), d["g_log_scale"]) < 1e-4
+    # accumulate form used by the engine: gradient added to an existing tensor, value from the fold kernel
+    from manus_amd import ops
+    base = torch.randn(ls.shape, device=DEV)
+    lo1, g1 = ops.isotropic_reg_grad(ls.detach(), 0.4, 0.1)
+    lo2, g2 = ops.isotropic_reg_grad(ls.detach(), 0.4, 0.1, grad_out=base.clone())
+    assert abs(lo1.item() - 0.1 * float(d["iso"])) < 2e-6 and torch.equal(lo1, lo2)
+    assert torch.allclose(g2, base + g1, rtol=0, atol=1e-7)

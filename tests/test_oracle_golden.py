@@ -175,3 +175,17 @@ def test_contact_distance_matches_reference(golden_dir):
         np.testing.assert_allclose(np.linalg.norm(pt1 - pt2[idx], axis=1), dist, rtol=1e-6, atol=1e-9)
     dist, idx = tr.contact_dist(d["pt1_2"], d["pt2_2"])
     assert (dist[50:60] == 0).all() and (idx[50:60] == np.arange(100, 110)).all()
+
+
+def test_training_loss_matches_reference_loss_func(golden_dir):
+    """0.8 rgb_loss + 0.2 ssim_loss + 0.1 isotropic_reg restated from the oracle pieces against the reference's own
+    loss_func (base.py:323-365) and its gradients."""
+    d = np.load(os.path.join(golden_dir, "loss_func.npz"))
+    pred = torch.tensor(d["pred"], requires_grad=True)
+    ls = torch.tensor(d["log_scale"], requires_grad=True)
+    loss = tr.rgb_ssim_loss(pred, torch.tensor(d["gt"]), 0.8, 0.2) + 0.1 * tr.isotropic_reg(ls, 0.4)
+    assert abs(loss.item() - float(d["loss"])) < 2e-6
+    assert abs(tr.isotropic_reg(ls, 0.4).item() - float(d["iso"])) < 2e-6
+    gp, gs = torch.autograd.grad(loss, [pred, ls])
+    assert max_rel_err(gp.numpy(), d["g_pred"]) < 2e-5
+    assert max_rel_err(gs.numpy(), d["g_log_scale"]) < 2e-5
