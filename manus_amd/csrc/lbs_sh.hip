@@ -152,19 +152,23 @@ __global__ __launch_bounds__(256) void k_skin_fwd24(int N, const float* __restri
     float acc[SKIN_BP];
 #pragma unroll
     for (int b = 0; b < SKIN_BP; ++b) acc[b] = 0.f;
+    // All 48 loads are unconditional (coordinates clamped, the weight of an outside corner set to
+    // zero = grid_sample's zero padding): predicated loads make hipcc drain the memory queue corner
+    // by corner.
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int x = s.x0 + (k & 1), y = s.y0 + ((k >> 1) & 1), z = s.z0 + (k >> 2);
-        if (x >= 0 && x < W && y >= 0 && y < H && z >= 0 && z < D) {
-            const float4* p = grid + (((size_t)z * H + y) * W + x) * (SKIN_BP / 4);
+        const bool inb = x >= 0 && x < W && y >= 0 && y < H && z >= 0 && z < D;
+        const int xc = min(max(x, 0), W - 1), yc = min(max(y, 0), H - 1), zc = min(max(z, 0), D - 1);
+        const float wk = inb ? Wk[k] : 0.f;
+        const float4* p = grid + (((size_t)zc * H + yc) * W + xc) * (SKIN_BP / 4);
 #pragma unroll
-            for (int q = 0; q < SKIN_BP / 4; ++q) {
-                const float4 c = p[q];
-                acc[4 * q + 0] += Wk[k] * c.x;
-                acc[4 * q + 1] += Wk[k] * c.y;
-                acc[4 * q + 2] += Wk[k] * c.z;
-                acc[4 * q + 3] += Wk[k] * c.w;
-            }
+        for (int q = 0; q < SKIN_BP / 4; ++q) {
+            const float4 c = p[q];
+            acc[4 * q + 0] += wk * c.x;
+            acc[4 * q + 1] += wk * c.y;
+            acc[4 * q + 2] += wk * c.z;
+            acc[4 * q + 3] += wk * c.w;
         }
     }
     float sum = 0.f;
@@ -186,30 +190,46 @@ __global__ __launch_bounds__(256) void k_skin_bwd24(int N, const float* __restri
     const TriSetup s = tri_setup(xyz, i, center, scale, D, H, W);
     float a[SKIN_BP];
 #pragma unroll
-    for (int b = 0; b < SKIN_BP; ++b) a[b] = (b < B) ? dL_dw[(size_t)i * B + b] : 0.f;
+    for (int b = 0; b < SKIN_BP; ++b) a[b] = 0.f;
+    {   // the (N,B) row in unaligned dwordx4 pieces
+        const float* row = dL_dw + (size_t)i * B;
+#pragma unroll
+        for (int q = 0; q < SKIN_BP / 4; ++q) {
+            if (4 * q + 4 <= B) {
+                const mgr_f4u t = *(const mgr_f4u*)(row + 4 * q);
+                a[4 * q] = t.x; a[4 * q + 1] = t.y; a[4 * q + 2] = t.z; a[4 * q + 3] = t.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (4 * q + e < B) a[4 * q + e] = row[4 * q + e];
+            }
+        }
+    }
     const float wx[2] = {1.0f - s.fx, s.fx}, wy[2] = {1.0f - s.fy, s.fy}, wz[2] = {1.0f - s.fz, s.fz};
     float S = 0.f, dS = 0.f, gxP = 0.f, gyP = 0.f, gzP = 0.f, gxQ = 0.f, gyQ = 0.f, gzQ = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int bx = k & 1, by = (k >> 1) & 1, bz = k >> 2;
         const int x = s.x0 + bx, y = s.y0 + by, z = s.z0 + bz;
-        if (x >= 0 && x < W && y >= 0 && y < H && z >= 0 && z < D) {
-            const float4* p = grid + (((size_t)z * H + y) * W + x) * (SKIN_BP / 4);
-            float Pk = 0.f, Qk = 0.f;
+        const float inb = (x >= 0 && x < W && y >= 0 && y < H && z >= 0 && z < D) ? 1.f : 0.f;  // zero padding
+        const int xc = min(max(x, 0), W - 1), yc = min(max(y, 0), H - 1), zc = min(max(z, 0), D - 1);
+        const float4* p = grid + (((size_t)zc * H + yc) * W + xc) * (SKIN_BP / 4);
+        float Pk = 0.f, Qk = 0.f;
 #pragma unroll
-            for (int q = 0; q < SKIN_BP / 4; ++q) {
-                const float4 c = p[q];
-                Pk += a[4 * q] * c.x + a[4 * q + 1] * c.y + a[4 * q + 2] * c.z + a[4 * q + 3] * c.w;
-                Qk += (c.x + c.y) + (c.z + c.w);
-            }
-            const float Wk = wx[bx] * wy[by] * wz[bz];
-            const float Dx = (bx ? 1.f : -1.f) * wy[by] * wz[bz];
-            const float Dy = (by ? 1.f : -1.f) * wx[bx] * wz[bz];
-            const float Dz = (bz ? 1.f : -1.f) * wx[bx] * wy[by];
-            S += Wk * Qk; dS += Wk * Pk;
-            gxP += Dx * Pk; gyP += Dy * Pk; gzP += Dz * Pk;
-            gxQ += Dx * Qk; gyQ += Dy * Qk; gzQ += Dz * Qk;
+        for (int q = 0; q < SKIN_BP / 4; ++q) {
+            const float4 c = p[q];
+            Pk += a[4 * q] * c.x + a[4 * q + 1] * c.y + a[4 * q + 2] * c.z + a[4 * q + 3] * c.w;
+            Qk += (c.x + c.y) + (c.z + c.w);
         }
+        Pk *= inb;
+        Qk *= inb;
+        const float Wk = wx[bx] * wy[by] * wz[bz];
+        const float Dx = (bx ? 1.f : -1.f) * wy[by] * wz[bz];
+        const float Dy = (by ? 1.f : -1.f) * wx[bx] * wz[bz];
+        const float Dz = (bz ? 1.f : -1.f) * wx[bx] * wy[by];
+        S += Wk * Qk; dS += Wk * Pk;
+        gxP += Dx * Pk; gyP += Dy * Pk; gzP += Dz * Pk;
+        gxQ += Dx * Qk; gyQ += Dy * Qk; gzQ += Dz * Qk;
     }
     const float invS = 1.0f / S, dot = dS * invS;
     dL_dxyz[3 * i + 0] = (gxP - dot * gxQ) * invS * (0.5f * (float)(W - 1)) / scale[0];
