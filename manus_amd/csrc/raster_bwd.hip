@@ -79,46 +79,53 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
         const bool inside = px < W && py < H;
         const mgr_v2f fpx2 = {(float)px, (float)px}, fpy2 = {(float)py, (float)py};
         const float qx0 = (float)(bx * 16 + (wave & 1) * 8), qy0 = (float)(by * 16 + (wave >> 1) * 8);
-        const size_t pix = (size_t)py * W + px;
         const MgrGRec* const gv = grec + (size_t)v * N;
 
+        // Every load of the item prologue is unconditional (indices clamped into range, results masked
+        // afterwards): predicated loads make hipcc drain the memory queue region by region, which
+        // serialises four dependent round trips per item.
         // this wave's two 64-entry batches: index and record of entry j = bi*64 + lane
         float4 ra[BWD_SW], rb[BWD_SW];
         float rc[BWD_SW];
+        {
+            uint32_t gid[BWD_SW];
 #pragma unroll
-        for (int bi = 0; bi < BWD_SW; ++bi) {
-            const int j = bi * 64 + lane;
-            ra[bi] = rb[bi] = make_float4(0.f, 0.f, 0.f, 0.f);
-            rc[bi] = 0.f;
-            if (j < cnt) {
-                const uint32_t gid = sorted_gid[start + first + j];
-                const MgrGRec* r = gv + gid;
+            for (int bi = 0; bi < BWD_SW; ++bi) gid[bi] = sorted_gid[start + first + (uint32_t)min(bi * 64 + lane, cnt - 1)];
+#pragma unroll
+            for (int bi = 0; bi < BWD_SW; ++bi) {
+                const int j = bi * 64 + lane;
+                const MgrGRec* r = gv + gid[bi];
                 ra[bi] = *(const float4*)r;
                 rb[bi] = *((const float4*)r + 1);
                 const float4 c = *((const float4*)r + 2);
                 rc[bi] = c.x;
-                // wave bi records the pair slot of entry j for the flush
-                if (wave == bi) {
-                    s_slot[j] = __float_as_int(c.y) + by * __float_as_int(c.z) + bx;
-                    s_gid[j] = gid;
+                if (wave == bi) {  // wave bi records the pair slot of entry j for the flush
+                    if (j < cnt) {
+                        s_slot[j] = __float_as_int(c.y) + by * __float_as_int(c.z) + bx;
+                        s_gid[j] = gid[bi];
+                    }
+                    s_touch[j] = 0;
                 }
             }
-            if (wave == bi) s_touch[j] = 0;
         }
         // per-pixel state in front of the chunk
         float Tr = 1.0f, pg = 0.f, Og = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f;
         uint32_t last = 0;
-        if (inside) {
-            last = n_contrib[(size_t)v * P + pix];
+        {
+            const size_t pixc = (size_t)min(py, H - 1) * W + min(px, W - 1);
+            const uint32_t nc = n_contrib[(size_t)v * P + pixc];
+            const float* gp = dL_dpix + (size_t)v * 3 * P + pixc;
+            const float* op = out_color + (size_t)v * 3 * P + pixc;
+            const float t0 = gp[0], t1 = gp[P], t2 = gp[2 * P];
+            const float o0 = op[0], o1 = op[P], o2 = op[2 * P];
+            const float4 ck = ckpt[(size_t)(chunk_start[vt] + (chunk > 0 ? chunk - 1 : 0)) * 256 + ((wave << 6) | lane)];
+            last = inside ? nc : 0u;
             if (last > first) {
-                const float* gp = dL_dpix + (size_t)v * 3 * P + pix;
-                const float* op = out_color + (size_t)v * 3 * P + pix;
-                g0 = gp[0]; g1 = gp[P]; g2 = gp[2 * P];
-                Og = op[0] * g0 + op[P] * g1 + op[2 * P] * g2;
+                g0 = t0; g1 = t1; g2 = t2;
+                Og = o0 * g0 + o1 * g1 + o2 * g2;
                 if (chunk > 0) {
-                    const float4 s = ckpt[(size_t)(chunk_start[vt] + chunk - 1) * 256 + ((wave << 6) | lane)];
-                    Tr = s.w;
-                    pg = s.x * g0 + s.y * g1 + s.z * g2;
+                    Tr = ck.w;
+                    pg = ck.x * g0 + ck.y * g1 + ck.z * g2;
                 }
             }
         }
