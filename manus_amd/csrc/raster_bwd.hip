@@ -390,13 +390,15 @@ __global__ __launch_bounds__(256) void k_inst_gather(
         for (int k = 0; k < 9; ++k) acc[k] = 0.f;
         int rad = 0;
         bool any = false;
-        if (mine) {
-            const size_t vi = (size_t)v * N + i;
-            rad = radii[vi];
-            if (rad > 0 && inst_tag[vi] == epoch) {
-                const ushort4 rc = rect[vi];
-                gather_pair_grads(pair_off[vi], (uint32_t)((rc.z - rc.x) * (rc.w - rc.y)), pair_tag, pair_grad, cap, epoch,
-                                  acc);
+        {   // the four per-(view, Gaussian) words are fetched together (clamped view index), then masked
+            const size_t vi = (size_t)min(v, v_first + v_count - 1) * N + i;
+            const int rd = radii[vi];
+            const uint32_t tg = inst_tag[vi];
+            const ushort4 rc = rect[vi];
+            const uint32_t po = pair_off[vi];
+            rad = mine ? rd : 0;
+            if (rad > 0 && tg == epoch) {
+                gather_pair_grads(po, (uint32_t)((rc.z - rc.x) * (rc.w - rc.y)), pair_tag, pair_grad, cap, epoch, acc);
 #pragma unroll
                 for (int k = 0; k < 9; ++k) any = any || (acc[k] != 0.f);
             }
