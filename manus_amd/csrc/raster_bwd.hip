@@ -349,6 +349,9 @@ __device__ __forceinline__ void grp_store8(const float x[8], int vl, bool ok, fl
     }
 }
 
+#ifndef IB_THREADS
+#define IB_THREADS 256
+#endif
 #ifndef MGR_IB_WAVES
 #define MGR_IB_WAVES 3
 #endif
@@ -451,7 +454,7 @@ __global__ __launch_bounds__(256) void k_inst_gather(
 
 // Phase 2: the whole per-view backward chain for the active Gaussians only.
 template <int G, int BMAX>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MGR_IB_WAVES, MGR_IB_WAVES))) void k_inst_bwd(
+__global__ __launch_bounds__(IB_THREADS) __attribute__((amdgpu_waves_per_eu(MGR_IB_WAVES, MGR_IB_WAVES))) void k_inst_bwd(
     int v_first, int v_count, int N, int B, int W, int H, const float* __restrict__ cams,
     const float* __restrict__ xyz, const float* __restrict__ log_scale, const float* __restrict__ rot,
     const float* __restrict__ op_logit, const float* __restrict__ f_dc, const float* __restrict__ f_rest,
@@ -459,7 +462,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MGR_IB_WAVE
     const uint32_t* __restrict__ active_list, const MgrHeader* __restrict__ hdr, float grad2d_scale, int accumulate,
     float* __restrict__ d_xyz, float* __restrict__ d_ls, float* __restrict__ d_rot, float* __restrict__ d_op,
     float* __restrict__ d_fdc, float* __restrict__ d_frest, float* __restrict__ d_w, float* __restrict__ st_grad2d) {
-    constexpr int IPB = 256 / G;
+    constexpr int IPB = IB_THREADS / G;
     extern __shared__ __align__(16) float s_view[];  // G x (camera 40 | transforms IB_TSTRIDE(B))
     const int n_active = (int)hdr->n_active;
     if ((int)blockIdx.x * IPB >= n_active) return;
@@ -469,12 +472,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MGR_IB_WAVE
     const int i = (int)active_list[min(q, n_active - 1)];
     const bool has_tf = skin_w != nullptr;
     const int tstride = IB_TSTRIDE(B), vstride = MGR_CAM_FLOATS + (has_tf ? tstride : 0);
-    for (int k = tid; k < G * MGR_CAM_FLOATS; k += 256) {
+    for (int k = tid; k < G * MGR_CAM_FLOATS; k += IB_THREADS) {
         const int g = k / MGR_CAM_FLOATS, e = k % MGR_CAM_FLOATS;
         s_view[g * vstride + e] = g < v_count ? cams[(size_t)(v_first + g) * MGR_CAM_FLOATS + e] : 0.f;
     }
     if (has_tf)
-        for (int k = tid; k < G * B * 16; k += 256) {
+        for (int k = tid; k < G * B * 16; k += IB_THREADS) {
             const int g = k / (B * 16), e = k % (B * 16);
             s_view[g * vstride + MGR_CAM_FLOATS + e] = g < v_count ? transforms[(size_t)(v_first + g) * B * 16 + e] : 0.f;
         }
@@ -658,7 +661,8 @@ static int raster_backward_impl(int V, int N, int W, int H, const float* cams, c
         const size_t lds = (size_t)Gv * (MGR_CAM_FLOATS + (canon->skin_w ? IB_TSTRIDE(canon->B) : 0)) * sizeof(float);
         float4* iacc = (float4*)(ws + L.inst_grad);
         uint32_t* alist = (uint32_t*)(ws + L.inst_grad + (size_t)N * Gv * 48);
-        const dim3 grid((N + ipb - 1) / ipb), grid_g((N + ipb * IG_ROUNDS - 1) / (ipb * IG_ROUNDS));
+        const int ipb2 = IB_THREADS / Gv;
+        const dim3 grid((N + ipb2 - 1) / ipb2), grid_g((N + ipb * IG_ROUNDS - 1) / (ipb * IG_ROUNDS));
         for (int v0 = 0; v0 < V; v0 += Gv) {
             const int vc = V - v0 < Gv ? V - v0 : Gv;
             const int accm = v0 > 0 ? 1 : 0;
@@ -670,7 +674,7 @@ static int raster_backward_impl(int V, int N, int W, int H, const float* cams, c
                        (const uint32_t*)(ws + L.inst_tag), (uint32_t)cap, epoch, accm, iacc, alist, hdr, canon->d_xyz, canon->d_ls, canon->d_rot, canon->d_op, canon->d_fdc,    \
                        canon->d_frest, canon->d_w, canon->st_grad2d, canon->st_vis, canon->st_radii)
 #define MGR_IB_LAUNCH(GG, BB)                                                                                         \
-    hipLaunchKernelGGL((k_inst_bwd<GG, BB>), grid, dim3(256), lds, stream, v0, vc, N, canon->B, W, H, cams, canon->xyz, \
+    hipLaunchKernelGGL((k_inst_bwd<GG, BB>), grid, dim3(IB_THREADS), lds, stream, v0, vc, N, canon->B, W, H, cams, canon->xyz, \
                        canon->log_scale, canon->rot, canon->op_logit, canon->f_dc, canon->f_rest, canon->skin_w,      \
                        canon->transforms, (const float4*)iacc, (const uint32_t*)alist, (const MgrHeader*)hdr,         \
                        canon->grad2d_scale, accm, canon->d_xyz, canon->d_ls, canon->d_rot, canon->d_op, canon->d_fdc, \

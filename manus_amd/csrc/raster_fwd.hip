@@ -628,15 +628,19 @@ __device__ __forceinline__ void lds_sort_emit(const unsigned long long* __restri
 // tile are then sorted by different workgroups instead of one after another.
 // Per tile: 1024 sampled keys are sorted, G-1 of them become splitters, one pass counts the group
 // sizes and one pass scatters the keys into keys2 (group-contiguous, order inside a group arbitrary).
+#define SPLIT_UNROLL 4
 __global__ __launch_bounds__(SORT_THREADS) void k_tile_split(
     const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ tile_queue,
     unsigned long long* __restrict__ keys, unsigned long long* __restrict__ keys2,
     uint4* __restrict__ groups, uint32_t* __restrict__ sorted_gid, MgrHeader* hdr, uint32_t cap) {
     __shared__ __attribute__((aligned(16))) unsigned long long s_keys[SORT_SAMPLES];
     __shared__ unsigned long long s_sp[SORT_MAX_GROUPS + 1];
-    __shared__ uint32_t s_cnt[SORT_MAX_GROUPS + 1], s_off[SORT_MAX_GROUPS + 1], s_cur[SORT_MAX_GROUPS + 1];
+    __shared__ uint32_t s_cnt[SORT_MAX_GROUPS + 1], s_off[SORT_MAX_GROUPS + 1];
+    // per-wave group counters, then per-wave write cursors: only lane 0 of the owning wave touches a row, so no
+    // atomics (a returning LDS atomic per (trip, group) was the critical path of this kernel) and a fixed key order
+    __shared__ uint32_t s_wcnt[SORT_THREADS / 64][SORT_MAX_GROUPS + 1];
     __shared__ uint32_t s_item[4];
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t qlen = hdr->queue_giant;
     for (;;) {
         __syncthreads();
@@ -655,25 +659,41 @@ __global__ __launch_bounds__(SORT_THREADS) void k_tile_split(
                 s_keys[t] = keys[start + (uint32_t)(((unsigned long long)t * n) / SORT_SAMPLES)];
             __syncthreads();
             bitonic_mirror(s_keys, SORT_SAMPLES, SORT_SAMPLES, tid, SORT_THREADS);
-            if (tid <= G) {
-                s_sp[tid] = (tid == 0) ? 0ull : (tid == G ? ~0ull : s_keys[(tid * SORT_SAMPLES) / G]);
-                s_cnt[tid] = 0;
+            if (tid <= G) s_sp[tid] = (tid == 0) ? 0ull : (tid == G ? ~0ull : s_keys[(tid * SORT_SAMPLES) / G]);
+            for (int k = tid; k < (SORT_THREADS / 64) * (SORT_MAX_GROUPS + 1); k += SORT_THREADS) (&s_wcnt[0][0])[k] = 0;
+            __syncthreads();
+            // both passes over the keys keep SPLIT_UNROLL unconditional loads in flight per thread (clamped
+            // index, masked afterwards): one predicated load per trip left the whole 1024-thread workgroup
+            // waiting a full memory round trip 2 x n/1024 times
+            for (uint32_t t0 = (uint32_t)(tid & ~63); t0 < n; t0 += SORT_THREADS * SPLIT_UNROLL) {  // group sizes
+                unsigned long long kk[SPLIT_UNROLL];
+#pragma unroll
+                for (int u = 0; u < SPLIT_UNROLL; ++u) kk[u] = keys[start + min(t0 + (uint32_t)u * SORT_THREADS + lane, n - 1u)];
+#pragma unroll
+                for (int u = 0; u < SPLIT_UNROLL; ++u) {
+                    const uint32_t t = t0 + (uint32_t)u * SORT_THREADS + lane;
+                    const int g = t < n ? sort_group(s_sp, G, kk[u]) : -1;
+                    for (int gg = 0; gg < G; ++gg) {
+                        const unsigned long long mk = __ballot(g == gg);
+                        if (lane == 0 && mk) s_wcnt[wave][gg] += (uint32_t)__popcll(mk);
+                    }
+                }
             }
             __syncthreads();
-            for (uint32_t t0 = (uint32_t)(tid & ~63); t0 < n; t0 += SORT_THREADS) {  // group sizes
-                const uint32_t t = t0 + lane;
-                const int g = t < n ? sort_group(s_sp, G, keys[start + t]) : -1;
-                for (int gg = 0; gg < G; ++gg) {
-                    const unsigned long long mk = __ballot(g == gg);
-                    if (lane == 0 && mk) atomicAdd(&s_cnt[gg], (uint32_t)__popcll(mk));
+            if (tid < G) {  // group total; the rows become exclusive prefixes over the waves = each wave's cursor
+                uint32_t run = 0;
+                for (int w = 0; w < SORT_THREADS / 64; ++w) {
+                    const uint32_t c = s_wcnt[w][tid];
+                    s_wcnt[w][tid] = run;
+                    run += c;
                 }
+                s_cnt[tid] = run;
             }
             __syncthreads();
             if (tid == 0) {
                 uint32_t run = 0, big = 0;
                 for (int g = 0; g < G; ++g) {
                     s_off[g] = run;
-                    s_cur[g] = 0;
                     run += s_cnt[g];
                     big |= s_cnt[g] > SORT_LDS_KEYS;
                 }
@@ -684,21 +704,26 @@ __global__ __launch_bounds__(SORT_THREADS) void k_tile_split(
             fallback = s_item[2] != 0;
         }
         if (!fallback) {
-            for (uint32_t t0 = (uint32_t)(tid & ~63); t0 < n; t0 += SORT_THREADS) {  // scatter
-                const uint32_t t = t0 + lane;
-                unsigned long long key = 0ull;
-                int g = -1;
-                if (t < n) {
-                    key = keys[start + t];
-                    g = sort_group(s_sp, G, key);
-                }
-                for (int gg = 0; gg < G; ++gg) {
-                    const unsigned long long mk = __ballot(g == gg);
-                    if (!mk) continue;
-                    uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(&s_cur[gg], (uint32_t)__popcll(mk));
-                    base = (uint32_t)__shfl((int)base, 0, 64);
-                    if (g == gg) keys2[start + s_off[gg] + base + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull))] = key;
+            for (uint32_t t0 = (uint32_t)(tid & ~63); t0 < n; t0 += SORT_THREADS * SPLIT_UNROLL) {  // scatter
+                unsigned long long kk[SPLIT_UNROLL];
+#pragma unroll
+                for (int u = 0; u < SPLIT_UNROLL; ++u) kk[u] = keys[start + min(t0 + (uint32_t)u * SORT_THREADS + lane, n - 1u)];
+#pragma unroll
+                for (int u = 0; u < SPLIT_UNROLL; ++u) {
+                    const uint32_t t = t0 + (uint32_t)u * SORT_THREADS + lane;
+                    const unsigned long long key = kk[u];
+                    const int g = t < n ? sort_group(s_sp, G, key) : -1;
+                    for (int gg = 0; gg < G; ++gg) {
+                        const unsigned long long mk = __ballot(g == gg);
+                        if (!mk) continue;
+                        uint32_t base = 0;
+                        if (lane == 0) {
+                            base = s_wcnt[wave][gg];
+                            s_wcnt[wave][gg] = base + (uint32_t)__popcll(mk);
+                        }
+                        base = (uint32_t)__shfl((int)base, 0, 64);
+                        if (g == gg) keys2[start + s_off[gg] + base + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull))] = key;
+                    }
                 }
             }
             if (tid < G) groups[s_item[3] + tid] = make_uint4(start + s_off[tid], s_cnt[tid], 0u, 0u);
