@@ -42,14 +42,20 @@ __device__ __forceinline__ v2f il_v2(float a) { v2f r = {a, a}; return r; }
 __global__ __launch_bounds__(IL_T) void k_image_loss(int H, int W, const float* __restrict__ pred,
                                                      const float* __restrict__ target, IlWindow win, float w_l1,
                                                      float w_ssim, float grad_scale, float* __restrict__ dL_dpred,
-                                                     float2* __restrict__ partial) {
+                                                     float2* __restrict__ partial, const uint32_t* __restrict__ work_list,
+                                                     const uint32_t* __restrict__ work_count, int gxb, int gyb) {
     // channel-mixed statistics (5 x 3 rows of positions) and, later, the channel-mixed derivative
     // maps (3 x 3); .x = image row h0, .y = image row h0 + 1
     __shared__ v2f s_mix[5][3][IL_NX];
     __shared__ float s_red[4];
     const int tid = threadIdx.x;
-    const int w0 = blockIdx.x * IL_W, h0 = blockIdx.y * 2, v = blockIdx.z;
+    const uint32_t n_work = *work_count;
+  for (uint32_t wi = blockIdx.x; wi < n_work; wi += gridDim.x) {   // the workgroups k_image_loss_scan found different
+    const uint32_t bid = work_list[wi];
+    const int bxi = (int)(bid % (uint32_t)gxb), byi = (int)((bid / (uint32_t)gxb) % (uint32_t)gyb), v = (int)(bid / (uint32_t)(gxb * gyb));
+    const int w0 = bxi * IL_W, h0 = byi * 2;
     const bool row1 = h0 + 1 < H;
+    __syncthreads();  // LDS reuse across work items
     const size_t plane = (size_t)H * W;
     const float* px = pred + (size_t)v * 3 * plane + (size_t)h0 * W;
     const float* py = target + (size_t)v * 3 * plane + (size_t)h0 * W;
@@ -196,10 +202,62 @@ __global__ __launch_bounds__(IL_T) void k_image_loss(int H, int W, const float* 
         s_red[2 + (tid >> 6)] = ssim_sum;
     }
     __syncthreads();
-    if (tid == 0) {
-        const size_t b = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-        partial[b] = make_float2(s_red[0] + s_red[1], s_red[2] + s_red[3]);
+    if (tid == 0) partial[bid] = make_float2(s_red[0] + s_red[1], s_red[2] + s_red[3]);
+  }
+}
+
+// Pass 1, no LDS, full occupancy: every (246 px x 2 rows) span whose rendered and target pixels are identical over
+// the whole +-10 px staged range -- the shared background, most of a capture-like frame -- is finished here: all
+// statistic pairs coincide, the SSIM map is 1 and at its maximum, so the gradient is 0 up to fp32 noise (the
+// reference computes ~1e-9 there) and the L1 term vanishes; the span gets zeros and its output count.  The other
+// spans are appended to the work list of k_image_loss.
+__global__ __launch_bounds__(IL_T) void k_image_loss_scan(int H, int W, const float* __restrict__ pred,
+                                                          const float* __restrict__ target, float* __restrict__ dL_dpred,
+                                                          float2* __restrict__ partial, uint32_t* __restrict__ work_list,
+                                                          uint32_t* __restrict__ work_count) {
+    __shared__ float s_red[2];
+    const int tid = threadIdx.x;
+    const int w0 = blockIdx.x * IL_W, h0 = blockIdx.y * 2, v = blockIdx.z;
+    const bool row1 = h0 + 1 < H;
+    const size_t plane = (size_t)H * W;
+    const float* px = pred + (size_t)v * 3 * plane + (size_t)h0 * W;
+    const float* py = target + (size_t)v * 3 * plane + (size_t)h0 * W;
+    // all loads unconditional (clamped position, second row folded onto the first when it does not exist) and
+    // combined without short-circuit: 36 independent loads per thread in flight
+    const int r1 = row1 ? W : 0;
+    int differs = 0;
+#pragma unroll
+    for (int k = 0; k < (IL_NX + IL_T - 1) / IL_T; ++k) {
+        const int t = min(tid + k * IL_T, IL_NX - 1);
+        const int w = min(max(w0 - 2 * IL_H1 + t, 0), W - 1);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            differs |= (px[c * plane + w] != py[c * plane + w]) ? 1 : 0;
+            differs |= (px[c * plane + r1 + w] != py[c * plane + r1 + w]) ? 1 : 0;
+        }
     }
+    const uint32_t bid = ((uint32_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (__syncthreads_or(differs)) {
+        if (tid == 0) work_list[atomicAdd(work_count, 1u)] = bid;
+        return;
+    }
+    float cnt = 0.f;
+    for (int o = tid; o < IL_W; o += IL_T) {
+        const int w = w0 + o;
+        if (w < W) {
+            float* go = dL_dpred + (size_t)v * 3 * plane + (size_t)h0 * W + w;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                go[c * plane] = 0.f;
+                if (row1) go[c * plane + W] = 0.f;
+            }
+            cnt += row1 ? 6.f : 3.f;
+        }
+    }
+    cnt = mgr_wave_sum63(cnt);
+    if ((tid & 63) == 63) s_red[tid >> 6] = cnt;
+    __syncthreads();
+    if (tid == 0) partial[bid] = make_float2(0.f, s_red[0] + s_red[1]);
 }
 
 // fold the per-workgroup sums: sums[0] = sum |pred - target|, sums[1] = sum of the SSIM map
@@ -238,7 +296,7 @@ static int64_t il_blocks(int V, int H, int W) { return (int64_t)V * ((H + 1) / 2
 
 extern "C" size_t mgr_image_loss_workspace_bytes(int V, int H, int W) {
     if (V <= 0 || H <= 0 || W <= 0) return 0;
-    return (size_t)il_blocks(V, H, W) * sizeof(float2);
+    return (size_t)il_blocks(V, H, W) * (sizeof(float2) + sizeof(uint32_t)) + 256;  // per-span sums | work list | counter
 }
 
 extern "C" int mgr_image_loss(int V, int H, int W, const float* pred, const float* target, float w_l1, float w_ssim,
@@ -259,10 +317,23 @@ extern "C" int mgr_image_loss(int V, int H, int W, const float* pred, const floa
     }
     for (int i = 0; i < 11; ++i) win.g[i] /= sum;
     const dim3 grid((W + IL_W - 1) / IL_W, (H + 1) / 2, V);
+    const int64_t nb = il_blocks(V, H, W);
+    if (nb >= (1ll << 32)) return mgr_fail(MGR_EINVAL, "mgr_image_loss: image batch too large");
+    float2* partial = (float2*)workspace;
+    uint32_t* work_list = (uint32_t*)((char*)workspace + (size_t)nb * sizeof(float2));
+    uint32_t* work_count = (uint32_t*)((char*)workspace + (size_t)nb * (sizeof(float2) + sizeof(uint32_t)) + 64);
+    MGR_HIP(hipMemsetAsync(work_count, 0, 4, stream));
+    {
+        MGR_PROF("k_image_loss_scan", stream);
+        hipLaunchKernelGGL(k_image_loss_scan, grid, dim3(IL_T), 0, stream, H, W, pred, target, dL_dpred, partial, work_list,
+                           work_count);
+    }
     {
         MGR_PROF("k_image_loss", stream);
-        hipLaunchKernelGGL(k_image_loss, grid, dim3(IL_T), 0, stream, H, W, pred, target, win, w_l1, w_ssim, grad_scale,
-                           dL_dpred, (float2*)workspace);
+        const int64_t pb = nb < 256 * 5 ? nb : 256 * 5;   // persistent: 5 workgroups of 32 KB LDS per CU
+        hipLaunchKernelGGL(k_image_loss, dim3((unsigned)pb), dim3(IL_T), 0, stream, H, W, pred, target, win, w_l1, w_ssim,
+                           grad_scale, dL_dpred, partial, (const uint32_t*)work_list, (const uint32_t*)work_count,
+                           (int)grid.x, (int)grid.y);
     }
     hipLaunchKernelGGL(k_image_loss_fold, dim3(1), dim3(1024), 0, stream, il_blocks(V, H, W), (const float2*)workspace,
                        sums, grad_scale * w_l1, -grad_scale * w_ssim, loss_offset);

@@ -109,3 +109,33 @@ def test_training_loss_matches_reference_loss_func(golden_dir):
     lo2, g2 = ops.isotropic_reg_grad(ls.detach(), 0.4, 0.1, grad_out=base.clone())
     assert abs(lo1.item() - 0.1 * float(d["iso"])) < 2e-6 and torch.equal(lo1, lo2)
     assert torch.allclose(g2, base + g1, rtol=0, atol=1e-7)
+
+
+def test_identical_background_fast_path_matches_oracle():
+    """Capture-like frame: rendered and target images share an exact background and differ in a patch.  Workgroups
+    whose whole span is identical skip the filters; the result must equal the oracle everywhere, including next
+    to the patch (spans that see a difference within +-10 px take the full path)."""
+    from manus_amd import ops
+    g = torch.Generator().manual_seed(9)
+    V, H, W = 2, 7, 1300
+    gt = torch.ones((V, 3, H, W))
+    pred = torch.ones((V, 3, H, W))
+    gt[:, :, 2:5, 600:700] = torch.rand((V, 3, 3, 100), generator=g)
+    pred[:, :, 2:6, 590:705] = torch.rand((V, 3, 4, 115), generator=g)
+    pred[1, :, 0, 0:3] = 0.5                                   # a difference at the image border
+    sums, grad = ops.image_loss_grad(pred.to(DEV), gt.to(DEV), 0.8, 0.2, 1.0)
+    l1 = s_sum = 0.0
+    gref = torch.zeros_like(pred)
+    for v in range(V):
+        p = pred[v].permute(1, 2, 0).clone().requires_grad_(True)
+        t = gt[v].permute(1, 2, 0)
+        a = (p - t).abs().sum()
+        s = tr.ssim_hwc(p, t) * (3 * H * W)
+        (gg,) = torch.autograd.grad(0.8 * a - 0.2 * s, p)
+        gref[v] = gg.permute(2, 0, 1)
+        l1 += a.item(); s_sum += s.item()
+    got = sums.cpu().numpy()
+    assert abs(got[0] - l1) <= 1e-5 * max(1.0, abs(l1))
+    assert abs(got[1] - s_sum) <= 1e-5 * abs(s_sum)
+    assert max_rel_err(grad.cpu().numpy(), gref.numpy()) < 1e-4
+    assert float(grad[0, :, 0, :500].abs().max()) == 0.0       # far from any difference: exactly zero
