@@ -141,7 +141,7 @@ int mgr_views_backward(int V, int N, int B, int W, int H, const float* cams, con
 
 /* Debug/test: byte offsets of the workspace regions, in the order header, grec, depth, rect,
  * alive, pair_off, tile_count, tile_start, tile_cursor, tile_done, tile_queue, chunk_start, items,
- * ckpt, keys, sorted_gid, final_T, n_contrib, pair_tag, pair_grad, total.  Returns the count. */
+ * ckpt, keys, sorted_gid, final_T (reserved, not written), n_contrib, pair_tag, pair_grad, total.  Returns the count. */
 int mgr_raster_layout(int V, int N, int W, int H, int64_t pair_capacity, size_t* out, int n_out);
 
 /* Blocking read-back of the workspace header after a forward: total number of

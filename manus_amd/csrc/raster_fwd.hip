@@ -983,8 +983,7 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, 
         }
         if (inside) {
             const size_t pix = (size_t)py * W + px;
-            final_T[(size_t)v * P + pix] = Tr;
-            n_contrib[(size_t)v * P + pix] = last;
+            n_contrib[(size_t)v * P + pix] = last;  // (the final transmittance is not needed by the chunk-parallel backward)
             float* o = out_color + (size_t)v * 3 * P + pix;
             o[0] = C0 + Tr * bg0;
             o[P] = C1 + Tr * bg1;
@@ -1031,8 +1030,7 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, 
         const int px = (t % gx) * 16 + (tid & 15), py = (t / gx) * 16 + (tid >> 4);
         if (px < W && py < H) {
             const size_t pix = (size_t)py * W + px;
-            final_T[(size_t)v * P + pix] = 1.0f;
-            n_contrib[(size_t)v * P + pix] = 0;
+            // no per-pixel state for empty tiles: the backward has no work item that reads it
             float* o = out_color + (size_t)v * 3 * P + pix;
             o[0] = bg0;
             o[P] = bg1;
