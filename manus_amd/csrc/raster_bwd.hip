@@ -370,7 +370,7 @@ __global__ __launch_bounds__(256) void k_inst_gather(
     int v_first, int v_count, int N, int B, const int32_t* __restrict__ radii, const ushort4* __restrict__ rect,
     const uint32_t* __restrict__ pair_off, const uint32_t* __restrict__ pair_tag,
     const float4* __restrict__ pair_grad, const uint32_t* __restrict__ inst_tag, uint32_t cap, uint32_t epoch,
-    int accumulate, float4* __restrict__ iacc,
+    int accumulate, int rounds, float4* __restrict__ iacc,
     uint32_t* __restrict__ active_list, MgrHeader* hdr, float* __restrict__ d_xyz, float* __restrict__ d_ls,
     float* __restrict__ d_rot, float* __restrict__ d_op, float* __restrict__ d_fdc, float* __restrict__ d_frest,
     float* __restrict__ d_w, float* __restrict__ st_grad2d, float* __restrict__ st_vis,
@@ -383,8 +383,8 @@ __global__ __launch_bounds__(256) void k_inst_gather(
     __syncthreads();
     const bool acc_out = accumulate != 0;
 #pragma unroll 1
-    for (int rnd = 0; rnd < IG_ROUNDS; ++rnd) {
-        const int i_raw = (blockIdx.x * IG_ROUNDS + rnd) * IPB + il;
+    for (int rnd = 0; rnd < rounds; ++rnd) {  // rounds <= IG_ROUNDS (sizes s_list); fewer when that leaves too few workgroups
+        const int i_raw = (blockIdx.x * rounds + rnd) * IPB + il;
         const int i = min(i_raw, N - 1);
         const bool ok = i_raw < N, mine = ok && vl < v_count;
         const int v = v_first + vl;
@@ -433,15 +433,23 @@ __global__ __launch_bounds__(256) void k_inst_gather(
             if (st_vis) st_vis[i] = acc_out ? st_vis[i] + vis : vis;
             if (st_radii) st_radii[i] = acc_out ? max(st_radii[i], maxrad) : maxrad;
         }
-        if (ok && !grp_any && !acc_out) {  // nothing reached this Gaussian: zero gradients, G lanes interleaved
-            for (int e = vl; e < 3; e += G) { d_xyz[3 * i + e] = 0.f; d_ls[3 * i + e] = 0.f; d_fdc[(size_t)i * 3 + e] = 0.f; }
-            for (int e = vl; e < 4; e += G) d_rot[4 * i + e] = 0.f;
-            for (int e = vl; e < 45; e += G) d_frest[(size_t)i * 45 + e] = 0.f;
+    }
+    if (!acc_out) {
+        // Zero gradients for the whole contiguous range of Gaussians this workgroup owns, fully coalesced; phase 2
+        // then overwrites the rows of the active ones (it runs after this kernel).  Row-wise zeroing of only the
+        // inactive rows was strided per lane and dominated this kernel when few views share a lane group.
+        const size_t i_lo = (size_t)blockIdx.x * rounds * IPB;
+        const size_t i_hi = min((size_t)N, i_lo + (size_t)rounds * IPB);
+        if (i_hi > i_lo) {
+            const size_t n = i_hi - i_lo;
+            for (size_t k = tid; k < n * 3; k += 256) { d_xyz[i_lo * 3 + k] = 0.f; d_ls[i_lo * 3 + k] = 0.f; d_fdc[i_lo * 3 + k] = 0.f; }
+            for (size_t k = tid; k < n * 4; k += 256) d_rot[i_lo * 4 + k] = 0.f;
+            for (size_t k = tid; k < n * 45; k += 256) d_frest[i_lo * 45 + k] = 0.f;
             if (d_w)
-                for (int e = vl; e < B; e += G) d_w[(size_t)i * B + e] = 0.f;
-            if (vl == 0) {
-                d_op[i] = 0.f;
-                if (st_grad2d) st_grad2d[i] = 0.f;
+                for (size_t k = tid; k < n * (size_t)B; k += 256) d_w[i_lo * B + k] = 0.f;
+            for (size_t k = tid; k < n; k += 256) {
+                d_op[i_lo + k] = 0.f;
+                if (st_grad2d) st_grad2d[i_lo + k] = 0.f;
             }
         }
     }
@@ -662,7 +670,10 @@ static int raster_backward_impl(int V, int N, int W, int H, const float* cams, c
         float4* iacc = (float4*)(ws + L.inst_grad);
         uint32_t* alist = (uint32_t*)(ws + L.inst_grad + (size_t)N * Gv * 48);
         const int ipb2 = IB_THREADS / Gv;
-        const dim3 grid((N + ipb2 - 1) / ipb2), grid_g((N + ipb * IG_ROUNDS - 1) / (ipb * IG_ROUNDS));
+        // gather rounds per workgroup: as many as IG_ROUNDS (amortises the list append) while >= ~1024 workgroups remain
+        int rounds = (int)((long long)N / ((long long)ipb * 1024));
+        rounds = rounds < 1 ? 1 : (rounds > IG_ROUNDS ? IG_ROUNDS : rounds);
+        const dim3 grid((N + ipb2 - 1) / ipb2), grid_g((N + ipb * rounds - 1) / (ipb * rounds));
         for (int v0 = 0; v0 < V; v0 += Gv) {
             const int vc = V - v0 < Gv ? V - v0 : Gv;
             const int accm = v0 > 0 ? 1 : 0;
@@ -671,7 +682,7 @@ static int raster_backward_impl(int V, int N, int W, int H, const float* cams, c
     hipLaunchKernelGGL((k_inst_gather<GG>), grid_g, dim3(256), 0, stream, v0, vc, N, canon->B, canon->radii,            \
                        (const ushort4*)(ws + L.rect), (const uint32_t*)(ws + L.pair_off),                             \
                        (const uint32_t*)(ws + L.pair_tag), (const float4*)(ws + L.pair_grad),                        \
-                       (const uint32_t*)(ws + L.inst_tag), (uint32_t)cap, epoch, accm, iacc, alist, hdr, canon->d_xyz, canon->d_ls, canon->d_rot, canon->d_op, canon->d_fdc,    \
+                       (const uint32_t*)(ws + L.inst_tag), (uint32_t)cap, epoch, accm, rounds, iacc, alist, hdr, canon->d_xyz, canon->d_ls, canon->d_rot, canon->d_op, canon->d_fdc,    \
                        canon->d_frest, canon->d_w, canon->st_grad2d, canon->st_vis, canon->st_radii)
 #define MGR_IB_LAUNCH(GG, BB)                                                                                         \
     hipLaunchKernelGGL((k_inst_bwd<GG, BB>), grid, dim3(IB_THREADS), lds, stream, v0, vc, N, canon->B, W, H, cams, canon->xyz, \
