@@ -77,8 +77,11 @@ const char* mgr_last_error(void);
 
 /* Bytes of workspace needed for V views of N Gaussians at W x H with room for
  * `pair_capacity` (Gaussian, tile) pairs summed over all views.  The workspace
- * must be zero-filled once when (re)allocated; afterwards it is opaque state
- * that links a forward call to its backward call. */
+ * must be zero-filled once when (re)allocated, and again before it is reused
+ * with a different (V, N, W, H, pair_capacity): it carries counters, tags and
+ * per-tile state from one call to the next (a forward leaves its tile counters
+ * zeroed for the following one instead of clearing them per call); otherwise it
+ * is opaque state that links a forward call to its backward call. */
 size_t mgr_raster_workspace_bytes(int V, int N, int W, int H, int64_t pair_capacity);
 
 /* Forward.  out_color: (V,3,H,W).  radii: (V,N) int32.  bg: 3 floats.
