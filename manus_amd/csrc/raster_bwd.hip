@@ -85,28 +85,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
         // afterwards): predicated loads make hipcc drain the memory queue region by region, which
         // serialises four dependent round trips per item.
         // this wave's two 64-entry batches: index and record of entry j = bi*64 + lane
-        float4 ra[BWD_SW], rb[BWD_SW];
-        float rc[BWD_SW];
+        // (the record of the second batch is fetched when the first one has been processed: holding both
+        // across the pair loop spilled registers at 5 waves per SIMD)
+        float4 ra, rb;
+        float rc;
+        uint32_t gid[BWD_SW];
+#pragma unroll
+        for (int bi = 0; bi < BWD_SW; ++bi) gid[bi] = sorted_gid[start + first + (uint32_t)min(bi * 64 + lane, cnt - 1)];
         {
-            uint32_t gid[BWD_SW];
-#pragma unroll
-            for (int bi = 0; bi < BWD_SW; ++bi) gid[bi] = sorted_gid[start + first + (uint32_t)min(bi * 64 + lane, cnt - 1)];
-#pragma unroll
-            for (int bi = 0; bi < BWD_SW; ++bi) {
-                const int j = bi * 64 + lane;
-                const MgrGRec* r = gv + gid[bi];
-                ra[bi] = *(const float4*)r;
-                rb[bi] = *((const float4*)r + 1);
-                const float4 c = *((const float4*)r + 2);
-                rc[bi] = c.x;
-                if (wave == bi) {  // wave bi records the pair slot of entry j for the flush
-                    if (j < cnt) {
-                        s_slot[j] = __float_as_int(c.y) + by * __float_as_int(c.z) + bx;
-                        s_gid[j] = gid[bi];
-                    }
-                    s_touch[j] = 0;
-                }
+            const MgrGRec* r = gv + gid[0];
+            ra = *(const float4*)r;
+            rb = *((const float4*)r + 1);
+            rc = (*((const float4*)r + 2)).x;
+        }
+        if (wave < BWD_SW) {  // wave bi records the pair slot of entry j = bi*64 + lane for the flush
+            const int j = wave * 64 + lane;
+            const float4 c = *((const float4*)(gv + (wave ? gid[1] : gid[0])) + 2);
+            if (j < cnt) {
+                s_slot[j] = __float_as_int(c.y) + by * __float_as_int(c.z) + bx;
+                s_gid[j] = wave ? gid[1] : gid[0];
             }
+            s_touch[j] = 0;
         }
         // per-pixel state in front of the chunk
         float Tr = 1.0f, pg = 0.f, Og = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f;
@@ -141,8 +140,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
 #pragma unroll 1
             for (int bi = 0; bi < BWD_SW; ++bi) {
                 const int j = bi * 64 + lane;
-                const float4 a4 = bi ? ra[1] : ra[0], b4 = bi ? rb[1] : rb[0];
-                const float c1 = bi ? rc[1] : rc[0];
+                if (bi) {
+                    const MgrGRec* r = gv + gid[1];
+                    ra = *(const float4*)r;
+                    rb = *((const float4*)r + 1);
+                    rc = (*((const float4*)r + 2)).x;
+                }
+                const float4 a4 = ra, b4 = rb;
+                const float c1 = rc;
                 bool alive = false;
                 if (j < cnt && first + (uint32_t)j < wlast)  // later entries are deeper than every pixel's last
                     alive = !mgr_box_dead(a4.x, a4.y, a4.z, a4.w, b4.x, mgr_qmax(b4.y), X0, Y0, X1, Y1);
