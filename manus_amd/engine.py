@@ -184,3 +184,73 @@ class HipViewCompute:
         return dict(grads={n: v.grad for n, v in self.params.items()},
                     grad2d=(g2 * vis).sum(0), vis=vis.sum(0).float(),
                     radii=radii.max(dim=0).values, loss=loss)
+
+
+class Trainer:
+    """The per-step control flow of the reference's training_step (src/modules/hand_dynamic.py:230-282) on top of
+    the kernels: multi-view step -> fused Adam step with the xyz schedule -> density_update (statistics, densify /
+    prune every `densification_interval` steps, opacity reset).  After a densification the parameter tensors are
+    new (different N): the compute object is re-pointed at them and the rasterizer workspaces of the old size are
+    released.  Multi-GPU: every rank must draw the same split noise, so rank 0's is broadcast."""
+
+    def __init__(self, compute, n_views, extent, opts=None, spatial_lr_scale=1.0, rank=0, world_size=1, group=None,
+                 bg_white=True):
+        from .optim import GaussianOptimizer
+        self.compute, self.n_views, self.extent, self.bg_white = compute, n_views, float(extent), bg_white
+        self.rank, self.world, self.group = rank, world_size, group
+        self.opt = GaussianOptimizer(compute.params, opts=opts, spatial_lr_scale=spatial_lr_scale, adopt=True)
+        self.global_step = 0
+        self._rebuild_step()
+
+    def _rebuild_step(self):
+        p = self.compute.params
+        shapes = {k: v.shape for k, v in p.items()}
+        self.stepper = ViewShardedStep(p["_xyz"].shape[0], shapes, self.compute, self.n_views, rank=self.rank,
+                                       world_size=self.world, group=self.group)
+
+    def _split_noise(self, n_sel, device):
+        noise = torch.randn((2 * n_sel, 3), dtype=torch.float32, device=device)
+        if self.world > 1:
+            dist.broadcast(noise, src=0, group=self.group)
+        return noise
+
+    def train_step(self):
+        """One optimisation step; returns the step's output dict (loss, statistics) plus "changed"."""
+        from . import rasterizer
+        out = self.stepper.step()
+        self.global_step += 1
+        self.opt.update_learning_rate(self.global_step)
+        self.opt.step(out["grads"])
+        o = self.opt.opts
+        changed = False
+        gs = self.global_step
+        if gs < o["densify_until_step"]:
+            self.opt.add_densification_stats(out["grad2d"], out["vis"], out["radii"])
+            if gs > o["densify_from_step"] and gs % o["densification_interval"] == 0:
+                size_threshold = o["size_threshold"] if gs > o["opacity_reset_interval"] else None
+                # the plan's selection count is needed before the noise can be drawn: densify_and_prune draws it
+                # itself on one GPU; with several ranks it is drawn here for the worst case and broadcast
+                noise = None
+                if self.world > 1:
+                    noise_full = self._split_noise(self.opt.N, self.opt.device)
+                    noise = noise_full
+                info = self._densify(o, size_threshold, noise)
+                changed = True
+                out["densify"] = info
+            if gs % o["opacity_reset_interval"] == 0 or (self.bg_white and gs == o["densify_from_step"]):
+                self.opt.reset_opacity()
+        if changed:
+            self.compute.params = {k: v.detach().requires_grad_(True) for k, v in self.opt.parameters().items()}
+            self.opt.p = {k: v.detach() for k, v in self.compute.params.items()}
+            rasterizer._POOL.clear()
+            rasterizer.set_sync_policy(True)   # the pair capacity of the new size has to be learnt again
+            self._rebuild_step()
+        out["changed"] = changed
+        return out
+
+    def _densify(self, o, size_threshold, noise_full):
+        if noise_full is None:
+            return self.opt.densify_and_prune(o["densify_grad_threshold"], o["min_opacity_threshold"], self.extent,
+                                              size_threshold)
+        return self.opt.densify_and_prune(o["densify_grad_threshold"], o["min_opacity_threshold"], self.extent,
+                                          size_threshold, noise=noise_full, noise_is_pool=True)

@@ -131,11 +131,13 @@ class GaussianOptimizer:
         self.max_radii2D = torch.maximum(self.max_radii2D, radii_max.to(torch.float32))
 
     # -- densify_and_prune, gaussian.py:310-333 ------------------------------------------------
-    def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size=None, noise=None):
+    def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size=None, noise=None, noise_is_pool=False):
         """Clone / split / prune exactly like the reference, including the order of the surviving rows and the
         zero Adam moments of new rows.  `max_screen_size` is accepted for signature parity; in the reference it
         cannot prune anything (max_radii2D is zeroed by densification_postfix before it is read, :249-251,316-318).
-        `noise`: optional standard normals (2*n_selected, 3) for the split offsets (default: torch.randn)."""
+        `noise`: optional standard normals (2*n_selected, 3) for the split offsets (default: torch.randn).
+        noise_is_pool=True: `noise` is a larger pool (>= 2*n_selected rows, e.g. one broadcast to all ranks before
+        the selection count is known); its first 2*n_selected rows are used."""
         N, dev = self.N, self.device
         nbytes = int(lib().mgr_densify_workspace_bytes(N))
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
@@ -148,6 +150,10 @@ class GaussianOptimizer:
         if noise is None:
             noise = torch.randn((2 * n_sel, 3), dtype=torch.float32, device=dev)
         noise = f32c(noise)
+        if noise_is_pool:
+            if noise.shape[0] < 2 * n_sel:
+                raise ManusHipError("densify_and_prune: the noise pool is smaller than 2*%d rows" % n_sel)
+            noise = noise[: 2 * n_sel].contiguous()
         if noise.numel() != 2 * n_sel * 3:
             raise ManusHipError("densify_and_prune: noise must be (2*%d, 3)" % n_sel)
         shp = lambda a: (M,) + tuple(self.p[a].shape[1:])
