@@ -324,3 +324,29 @@ def test_baseline_configs_full_size(kind, n, views):
     assert torch.isfinite(img).all() and float(img.min()) >= 0.0
     assert (radii.max(dim=0).values.to(torch.int32) == a["radii"]).all()
     assert float((img[0] == 1.0).float().mean()) > 0.2      # most of a capture-like frame is background
+
+
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_randomised_sizes_against_oracle(seed):
+    """Random image sizes (not multiples of 16, down to a single tile), Gaussian counts from 1 up, random
+    backgrounds: integer state exact, image and gradients within the path's bars."""
+    rng = np.random.default_rng(1000 + seed)
+    W, H = int(rng.integers(5, 230)), int(rng.integers(5, 150))
+    n = int(rng.choice([1, 2, 17, 300, 2500]))
+    bg = rng.uniform(0, 1, size=3).astype(np.float32)
+    cam = make_camera(W, H)
+    m, c, col, op = random_gaussians(n, seed=seed + 77)
+    gimg = rng.normal(size=(1, 3, H, W)).astype(np.float32)
+    o = _oracle(cam, m, c, col, op, bg=bg)
+    ob = o.backward(gimg[0])
+    h = _hip([cam], m, c, col, op, bg=bg, grad_img=gimg)
+    assert (h["radii"][0] == o.radii).all()
+    npairs, ranges, pl = _binning(0, 1, n, W, H)
+    assert npairs == o.num_rendered
+    _check_lists_vs_oracle(o, ranges, pl, W, H)
+    assert np.abs(h["img"][0] - o.color).max() < 5e-3 and np.mean(np.abs(h["img"][0] - o.color)) < 2e-6
+    for k in ("means3D", "cov3D", "colors", "opacity"):
+        if np.abs(ob[k]).max() > 0:
+            assert max_rel_err(h[k], ob[k]) < 1e-4, (k, W, H, n)
+    if np.abs(ob["means2D"]).max() > 0:
+        assert max_rel_err(h["means2D"][0], ob["means2D"]) < 1e-4
