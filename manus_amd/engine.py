@@ -29,7 +29,10 @@ def pack_grads(grads, N, device, out=None):
     buf = out if out is not None else torch.empty(N * GRAD_WIDTH, dtype=torch.float32, device=device)
     o = 0
     for name, w in GRAD_LAYOUT:
-        buf[o:o + N * w].copy_(grads[name].reshape(-1))
+        g = grads[name]
+        seg = buf[o:o + N * w]
+        if not (g.data_ptr() == seg.data_ptr() and g.is_contiguous()):   # already written in place (grad arena)
+            seg.copy_(g.reshape(-1))
         o += N * w
     return buf
 
@@ -58,14 +61,24 @@ class ViewShardedStep:
         self.N, self.shapes, self.compute_fn = n_gaussians, shapes, compute_fn
         self.n_views, self.rank, self.world, self.group = n_views, rank, world_size, group
         self.local_views = shard_views(n_views, rank, world_size)
+        self.always_pack = False   # tests: take the packing path without a process group
         self._flat = None
 
     def step(self):
         # compute_fn folds the 1/V of "grad = (1/V) sum_v grad L_v" into the loss scale
+        N = self.N
+        packed = self.world > 1 or self.always_pack
+        if packed and self._flat is not None and hasattr(self.compute_fn, "grad_arena"):
+            # the backward kernels write straight into the all-reduce buffer (no packing copies): one view per leaf
+            flat, o, arena = self._flat, 0, {}
+            for name, w in GRAD_LAYOUT:
+                arena[name] = flat[o:o + N * w]
+                o += N * w
+            arena["grad2d"], arena["vis"] = flat[o:o + N], flat[o + N:o + 2 * N]
+            self.compute_fn.grad_arena = arena
         out = self.compute_fn(self.local_views, 1.0 / float(self.n_views))
         dev = out["grad2d"].device
-        N = self.N
-        if self.world == 1:
+        if not packed:
             return dict(grads=out["grads"], grad2d=out["grad2d"], vis=out["vis"],
                         radii=out["radii"].to(torch.int32), loss=out["loss"])
         # one flat buffer -> one SUM all-reduce (+ one MAX all-reduce for the radii)
@@ -73,12 +86,15 @@ class ViewShardedStep:
             self._flat = torch.empty(N * (GRAD_WIDTH + 2) + 1, dtype=torch.float32, device=dev)
         flat = self._flat
         pack_grads(out["grads"], N, dev, out=flat[: N * GRAD_WIDTH])
-        flat[N * GRAD_WIDTH: N * (GRAD_WIDTH + 1)].copy_(out["grad2d"])
-        flat[N * (GRAD_WIDTH + 1): N * (GRAD_WIDTH + 2)].copy_(out["vis"])
+        for src, lo in ((out["grad2d"], N * GRAD_WIDTH), (out["vis"], N * (GRAD_WIDTH + 1))):
+            seg = flat[lo: lo + N]
+            if src.data_ptr() != seg.data_ptr():
+                seg.copy_(src)
         flat[-1:].copy_(out["loss"].reshape(1))
         radii = out["radii"].to(torch.int32)
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-        dist.all_reduce(radii, op=dist.ReduceOp.MAX, group=self.group)
+        if self.world > 1:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_reduce(radii, op=dist.ReduceOp.MAX, group=self.group)
         grads = unpack_grads(flat[: N * GRAD_WIDTH], self.shapes, N)
         return dict(grads=grads, grad2d=flat[N * GRAD_WIDTH: N * (GRAD_WIDTH + 1)],
                     vis=flat[N * (GRAD_WIDTH + 1): N * (GRAD_WIDTH + 2)], radii=radii,
@@ -105,6 +121,7 @@ class HipViewCompute:
         self.loss, self.w_rgb, self.w_ssim = loss, w_rgb, w_ssim
         self.is_hand = scene.get("grid") is not None and scene["kind"] == "hand"
         self.params = {k: v.detach().clone().requires_grad_(True) for k, v in scene["params"].items()}
+        self.grad_arena = None   # set by ViewShardedStep: preallocated gradient outputs (fused path only)
         self._cache = {}
         self.grid = ops.SkinGrid(scene["grid"], scene["grid"].device) if self.is_hand else None
 
@@ -146,7 +163,7 @@ class HipViewCompute:
         w = ops.skin_weights(p["_xyz"], self.grid, s["grid_center"], s["grid_scale"]) if self.is_hand else None
         return self.fz.render_views(p["_xyz"], p["_scaling"], p["_rotation"], p["_opacity"], p["_features_dc"],
                                     p["_features_rest"], w, sel["T"], sel["cams"], s["bg"], s["width"], s["height"],
-                                    stats=stats, grad2d_scale=grad2d_scale)
+                                    stats=stats, grad2d_scale=grad2d_scale, grad_arena=self.grad_arena)
 
     def _image_loss(self, img, tgt, scale):
         """(loss value, dL/dimg) of scale * sum over the views of the per-view image loss."""

@@ -27,7 +27,7 @@ class ViewStats:
 class _RenderViews(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xyz, log_scale, rot, opacity, f_dc, f_rest, skin_w, transforms, cams, bg, W, H, stats,
-                grad2d_scale):
+                grad2d_scale, grad_arena=None):
         xyz, log_scale, rot = f32c(xyz), f32c(log_scale), f32c(rot)
         opacity, f_dc, f_rest = f32c(opacity).reshape(-1), f32c(f_dc), f32c(f_rest)
         N, V = xyz.shape[0], cams.shape[0]
@@ -64,6 +64,7 @@ class _RenderViews(torch.autograd.Function):
             cap = int(npairs.value * 1.5) + 4096
         ctx.lease = _rz._Lease(ws)
         ctx.meta = (V, N, B, W, H, stats, float(grad2d_scale))
+        ctx.arena = grad_arena
         ctx.save_for_backward(xyz, log_scale, rot, opacity, f_dc, f_rest, skin_w, transforms, cams, bg, out, radii)
         ctx.mark_non_differentiable(radii)
         return out, radii
@@ -75,11 +76,20 @@ class _RenderViews(torch.autograd.Function):
         ws = ctx.lease.ws
         dev = xyz.device
         g_img = f32c(g_img)
-        e = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
-        d_xyz, d_ls, d_rot, d_op = e(N, 3), e(N, 3), e(N, 4), e(N)
-        d_fdc, d_frest = e(N, 1, 3), e(N, 15, 3)
+        arena = ctx.arena or {}
+
+        def e(*s, name=None):
+            # the caller's arena (e.g. segments of the flat all-reduce buffer): the kernels write there directly
+            t = arena.get(name) if name else None
+            if t is not None and t.numel() == int(torch.Size(s).numel()) and t.is_contiguous() and t.dtype == torch.float32 \
+                    and t.device == dev:
+                return t.view(s)
+            return torch.empty(s, dtype=torch.float32, device=dev)
+
+        d_xyz, d_ls, d_rot, d_op = e(N, 3), e(N, 3, name="_scaling"), e(N, 4, name="_rotation"), e(N, name="_opacity")
+        d_fdc, d_frest = e(N, 1, 3, name="_features_dc"), e(N, 15, 3, name="_features_rest")
         d_w = e(N, B) if skin_w is not None else None
-        st_g, st_v = (e(N), e(N)) if stats is not None else (None, None)
+        st_g, st_v = (e(N, name="grad2d"), e(N, name="vis")) if stats is not None else (None, None)
         st_r = torch.empty(N, dtype=torch.int32, device=dev) if stats is not None else None
         check(lib().mgr_views_backward(V, N, B, W, H, ptr(cams), ptr(bg), ptr(xyz), ptr(log_scale), ptr(rot),
                                        ptr(opacity), ptr(f_dc), ptr(f_rest), ptr(skin_w), ptr(transforms),
@@ -90,16 +100,18 @@ class _RenderViews(torch.autograd.Function):
         if stats is not None:
             stats.grad2d, stats.vis, stats.radii = st_g, st_v, st_r
         return (d_xyz, d_ls, d_rot, d_op.reshape(-1, 1), d_fdc, d_frest, d_w, None, None, None, None, None, None,
-                None)
+                None, None)
 
 
 def render_views(xyz, log_scale, rot, opacity_logit, f_dc, f_rest, skin_w, transforms, cams, bg, W, H,
-                 stats=None, grad2d_scale=1.0):
+                 stats=None, grad2d_scale=1.0, grad_arena=None):
     """Images (V,3,H,W) and radii (V,N) of V views from the canonical parameters.
 
     xyz (N,3) `_xyz`; log_scale (N,3) `_scaling`; rot (N,4) `_rotation`; opacity_logit (N,1)
     `_opacity`; f_dc (N,1,3); f_rest (N,15,3); skin_w (N,B) from `ops.skin_weights` or None for a
     static object; transforms (V,B,4,4): posed @ inv(rest) (+ identity) of the pose seen by each
-    view; cams (V,40).  `stats` (a ViewStats) receives the densification statistics in backward."""
+    view; cams (V,40).  `stats` (a ViewStats) receives the densification statistics in backward.
+    `grad_arena`: optional {leaf name | "grad2d" | "vis": preallocated fp32 tensor}; the backward kernels write those
+    outputs there instead of into fresh tensors (the multi-GPU step passes segments of its all-reduce buffer)."""
     return _RenderViews.apply(xyz, log_scale, rot, opacity_logit, f_dc, f_rest, skin_w, transforms, cams, bg,
-                              int(W), int(H), stats, grad2d_scale)
+                              int(W), int(H), stats, grad2d_scale, grad_arena)

@@ -185,3 +185,34 @@ def test_engine_step_matches_sequential_reference_steps(loss):
     assert max_rel_err(full["grad2d"].cpu().numpy(), g2.cpu().numpy()) < 1e-5
     assert torch.equal(full["vis"], vis) and torch.equal(full["radii"], rad.to(torch.int32))
     assert abs(float(full["loss"]) - float(loss) / 4) < 1e-5
+
+
+def test_packed_step_writes_gradients_in_place():
+    """The multi-GPU step's flat all-reduce buffer: from the second step on the backward kernels write most leaves
+    straight into it (grad arena).  Same numbers as the unpacked single-GPU step, and no packing copy for those
+    leaves (their gradients alias the buffer)."""
+    from manus_amd.engine import GRAD_LAYOUT, HipViewCompute, ViewShardedStep
+    from manus_amd.synthetic import camera_table, make_scene
+    sc = make_scene(n_gaussians=3000, kind="hand", seed=3, grid_res=24, n_cameras=2, width=96, height=64,
+                    cam_radius=0.5, sigma_range=(2e-3, 8e-3), device=DEV)
+    ct = camera_table(sc["cameras"], DEV)
+    tg = torch.rand((2, 3, 64, 96), device=DEV)
+    hc = HipViewCompute(sc, tg, ct, loss="l1+ssim")
+    shapes = {k: v.shape for k, v in hc.params.items()}
+    plain = ViewShardedStep(sc["N"], shapes, hc, 2).step()
+    ref = {k: v.clone() for k, v in plain["grads"].items()}
+    ref_g2, ref_vis, ref_loss = plain["grad2d"].clone(), plain["vis"].clone(), float(plain["loss"])
+    hc.grad_arena = None
+    st = ViewShardedStep(sc["N"], shapes, hc, 2)
+    st.always_pack = True
+    st.step()                      # allocates the flat buffer
+    out = st.step()                # arena in use
+    flat = st._flat
+    lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * 4
+    for name, _ in GRAD_LAYOUT:
+        assert torch.equal(out["grads"][name], ref[name]), name
+        assert lo <= out["grads"][name].data_ptr() < hi
+    assert torch.equal(out["grad2d"], ref_g2) and torch.equal(out["vis"], ref_vis)
+    assert abs(float(out["loss"]) - ref_loss) < 1e-7
+    aliased = [n for n, _ in GRAD_LAYOUT if hc.params[n].grad is not None and lo <= hc.params[n].grad.data_ptr() < hi]
+    assert set(aliased) >= {"_features_rest", "_features_dc", "_scaling", "_rotation", "_opacity"}, aliased
