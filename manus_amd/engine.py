@@ -220,6 +220,8 @@ class Trainer:
         self._rebuild_step()
 
     def _rebuild_step(self):
+        if hasattr(self.compute, "grad_arena"):
+            self.compute.grad_arena = None   # views of the previous step object's buffer (possibly another N)
         p = self.compute.params
         shapes = {k: v.shape for k, v in p.items()}
         self.stepper = ViewShardedStep(p["_xyz"].shape[0], shapes, self.compute, self.n_views, rank=self.rank,
