@@ -206,58 +206,105 @@ __global__ __launch_bounds__(IL_T) void k_image_loss(int H, int W, const float* 
   }
 }
 
-// Pass 1, no LDS, full occupancy: every (246 px x 2 rows) span whose rendered and target pixels are identical over
-// the whole +-10 px staged range -- the shared background, most of a capture-like frame -- is finished here: all
+// Pass 1, almost no LDS, full occupancy.  Every (246 px x 2 rows) span whose rendered and target pixels are identical
+// over the whole +-10 px staged range -- the shared background, most of a capture-like frame -- is finished here: all
 // statistic pairs coincide, the SSIM map is 1 and at its maximum, so the gradient is 0 up to fp32 noise (the
 // reference computes ~1e-9 there) and the L1 term vanishes; the span gets zeros and its output count.  The other
 // spans are appended to the work list of k_image_loss.
-__global__ __launch_bounds__(IL_T) void k_image_loss_scan(int H, int W, const float* __restrict__ pred,
-                                                          const float* __restrict__ target, float* __restrict__ dL_dpred,
-                                                          float2* __restrict__ partial, uint32_t* __restrict__ work_list,
-                                                          uint32_t* __restrict__ work_count) {
-    __shared__ float s_red[2];
+// One workgroup takes a whole pair of image rows: 16-byte loads along w (W % 4 == 0; otherwise dwords) mark the
+// pixels that differ in a bitmap, the spans are classified from the bitmap, zeros are written with 16-byte stores.
+#define ILS_T 256
+#define ILS_MAXW 16384
+__global__ __launch_bounds__(ILS_T) void k_image_loss_scan(int H, int W, int gxb, const float* __restrict__ pred,
+                                                           const float* __restrict__ target, float* __restrict__ dL_dpred,
+                                                           float2* __restrict__ partial, uint32_t* __restrict__ work_list,
+                                                           uint32_t* __restrict__ work_count) {
+    __shared__ uint32_t s_diff[ILS_MAXW / 32];   // bit w: pixel column w differs in some channel / row
+    __shared__ uint32_t s_ident[(ILS_MAXW / IL_W + 32) / 32];  // bit b: span b is identical
     const int tid = threadIdx.x;
-    const int w0 = blockIdx.x * IL_W, h0 = blockIdx.y * 2, v = blockIdx.z;
+    const int h0 = blockIdx.x * 2, v = blockIdx.y;
     const bool row1 = h0 + 1 < H;
     const size_t plane = (size_t)H * W;
     const float* px = pred + (size_t)v * 3 * plane + (size_t)h0 * W;
     const float* py = target + (size_t)v * 3 * plane + (size_t)h0 * W;
-    // all loads unconditional (clamped position, second row folded onto the first when it does not exist) and
-    // combined without short-circuit: 36 independent loads per thread in flight
-    const int r1 = row1 ? W : 0;
-    int differs = 0;
-#pragma unroll
-    for (int k = 0; k < (IL_NX + IL_T - 1) / IL_T; ++k) {
-        const int t = min(tid + k * IL_T, IL_NX - 1);
-        const int w = min(max(w0 - 2 * IL_H1 + t, 0), W - 1);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            differs |= (px[c * plane + w] != py[c * plane + w]) ? 1 : 0;
-            differs |= (px[c * plane + r1 + w] != py[c * plane + r1 + w]) ? 1 : 0;
-        }
-    }
-    const uint32_t bid = ((uint32_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    if (__syncthreads_or(differs)) {
-        if (tid == 0) work_list[atomicAdd(work_count, 1u)] = bid;
-        return;
-    }
-    float cnt = 0.f;
-    for (int o = tid; o < IL_W; o += IL_T) {
-        const int w = w0 + o;
-        if (w < W) {
-            float* go = dL_dpred + (size_t)v * 3 * plane + (size_t)h0 * W + w;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                go[c * plane] = 0.f;
-                if (row1) go[c * plane + W] = 0.f;
-            }
-            cnt += row1 ? 6.f : 3.f;
-        }
-    }
-    cnt = mgr_wave_sum63(cnt);
-    if ((tid & 63) == 63) s_red[tid >> 6] = cnt;
+    float* pg = dL_dpred + (size_t)v * 3 * plane + (size_t)h0 * W;
+    const int nwords = (W + 31) / 32;
+    for (int k = tid; k < nwords; k += ILS_T) s_diff[k] = 0;
+    if (tid < (int)(sizeof(s_ident) / 4)) s_ident[tid] = 0;
     __syncthreads();
-    if (tid == 0) partial[bid] = make_float2(0.f, s_red[0] + s_red[1]);
+    const int rows = row1 ? 2 : 1;
+    const bool vec = (W & 3) == 0 && ((((uintptr_t)pred) | ((uintptr_t)target) | ((uintptr_t)dL_dpred)) & 15) == 0;
+    if (vec) {
+        const int n4 = W >> 2;
+        for (int q = tid; q < n4; q += ILS_T) {
+            uint32_t d = 0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                for (int r = 0; r < rows; ++r) {
+                    const float4 a = *(const float4*)(px + c * plane + (size_t)r * W + 4 * q);
+                    const float4 b = *(const float4*)(py + c * plane + (size_t)r * W + 4 * q);
+                    d |= (a.x != b.x ? 1u : 0u) | (a.y != b.y ? 2u : 0u) | (a.z != b.z ? 4u : 0u) | (a.w != b.w ? 8u : 0u);
+                }
+            if (d) atomicOr(&s_diff[q >> 3], d << ((q & 7) * 4));
+        }
+    } else {
+        for (int w = tid; w < W; w += ILS_T) {
+            uint32_t d = 0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                for (int r = 0; r < rows; ++r) d |= px[c * plane + (size_t)r * W + w] != py[c * plane + (size_t)r * W + w] ? 1u : 0u;
+            if (d) atomicOr(&s_diff[w >> 5], 1u << (w & 31));
+        }
+    }
+    __syncthreads();
+    // classify the spans: identical iff no differing pixel in [w0 - 10, w0 + 256) (clipped to the image)
+    for (int b = tid; b < gxb; b += ILS_T) {
+        const int lo = max(b * IL_W - 2 * IL_H1, 0), hi = min(b * IL_W + IL_ND, W);  // [lo, hi)
+        uint32_t any = 0;
+        for (int k = lo >> 5; k <= (hi - 1) >> 5; ++k) {
+            uint32_t m = s_diff[k];
+            const int base = k << 5;
+            if (lo > base) m &= ~0u << (lo - base);
+            if (hi < base + 32) m &= ~0u >> (base + 32 - hi);
+            any |= m;
+        }
+        const uint32_t bid = ((uint32_t)v * gridDim.x + blockIdx.x) * (uint32_t)gxb + (uint32_t)b;
+        if (any) {
+            work_list[atomicAdd(work_count, 1u)] = bid;
+        } else {
+            atomicOr(&s_ident[b >> 5], 1u << (b & 31));
+            const int wcnt = min((b + 1) * IL_W, W) - b * IL_W;
+            partial[bid] = make_float2(0.f, (float)(wcnt * 3 * rows));
+        }
+    }
+    __syncthreads();
+    // zero gradient for the identical spans
+    if (vec) {
+        const int n4 = W >> 2;
+        for (int q = tid; q < n4; q += ILS_T) {
+            const int w = 4 * q, b0 = w / IL_W, b1 = (w + 3) / IL_W;
+            const bool i0 = (s_ident[b0 >> 5] >> (b0 & 31)) & 1u, i1 = (s_ident[b1 >> 5] >> (b1 & 31)) & 1u;
+            if (i0 && i1) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    for (int r = 0; r < rows; ++r) *(float4*)(pg + c * plane + (size_t)r * W + w) = make_float4(0.f, 0.f, 0.f, 0.f);
+            } else if (i0 || i1) {
+                for (int e = 0; e < 4; ++e) {
+                    const int be = (w + e) / IL_W;
+                    if ((s_ident[be >> 5] >> (be & 31)) & 1u)
+                        for (int c = 0; c < 3; ++c)
+                            for (int r = 0; r < rows; ++r) pg[c * plane + (size_t)r * W + w + e] = 0.f;
+                }
+            }
+        }
+    } else {
+        for (int w = tid; w < W; w += ILS_T) {
+            const int b = w / IL_W;
+            if ((s_ident[b >> 5] >> (b & 31)) & 1u)
+                for (int c = 0; c < 3; ++c)
+                    for (int r = 0; r < rows; ++r) pg[c * plane + (size_t)r * W + w] = 0.f;
+        }
+    }
 }
 
 // fold the per-workgroup sums: sums[0] = sum |pred - target|, sums[1] = sum of the SSIM map
@@ -323,10 +370,11 @@ extern "C" int mgr_image_loss(int V, int H, int W, const float* pred, const floa
     uint32_t* work_list = (uint32_t*)((char*)workspace + (size_t)nb * sizeof(float2));
     uint32_t* work_count = (uint32_t*)((char*)workspace + (size_t)nb * (sizeof(float2) + sizeof(uint32_t)) + 64);
     MGR_HIP(hipMemsetAsync(work_count, 0, 4, stream));
+    if (W > ILS_MAXW) return mgr_fail(MGR_EINVAL, "mgr_image_loss: image wider than 16384");
     {
         MGR_PROF("k_image_loss_scan", stream);
-        hipLaunchKernelGGL(k_image_loss_scan, grid, dim3(IL_T), 0, stream, H, W, pred, target, dL_dpred, partial, work_list,
-                           work_count);
+        hipLaunchKernelGGL(k_image_loss_scan, dim3(grid.y, V), dim3(ILS_T), 0, stream, H, W, (int)grid.x, pred, target, dL_dpred,
+                           partial, work_list, work_count);
     }
     {
         MGR_PROF("k_image_loss", stream);
