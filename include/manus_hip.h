@@ -26,6 +26,8 @@
  *       eval_sh, src/utils/sh_utils.py:57-104.
  *   mgr_project_points
  *       project_points, src/utils/transforms.py:304-311.
+ *   mgr_dilate_mask, mgr_points_outside_mask
+ *       dilate_mask / get_points_outside_mask, src/utils/gaussian_utils.py:35-47,101-147.
  *
  * Conventions
  *   - All pointers are DEVICE pointers unless the name ends in _host.
@@ -122,17 +124,20 @@ int mgr_raster_backward(int V, int N, int W, int H, const float* cams, const flo
  * statistics of src/models/gaussian.py:335-338 / src/utils/gaussian_utils.py:469-471.
  *   xyz (N,3), log_scale (N,3) = _scaling, rot (N,4) = _rotation (raw),
  *   opacity_logit (N) = _opacity, f_dc (N,1,3) = _features_dc, f_rest (N,15,3) = _features_rest,
- *   skin_w (N,B) or NULL (static object), transforms (V,B,16): one pose per view.
+ *   skin_w (n_articulated,B) or NULL (static object), transforms (V,B,16): one pose per view.
+ *   n_articulated <= N: the first n_articulated Gaussians are skinned, the rest are static (identity
+ *   transform, no skin-weight row): the hand+object concatenation of src/modules/composite.py:50-59.
+ *   d_skin_w is (n_articulated,B).
  * stat_grad2d (N): sum over views of ||dL/dmeans2D[:, :2]|| * grad2d_scale,
  * stat_vis (N): number of views with radius > 0, stat_radii (N): max radius (any may be NULL).
  * ------------------------------------------------------------------------ */
-int mgr_views_forward(int V, int N, int B, int W, int H, const float* cams, const float* bg,
+int mgr_views_forward(int V, int N, int B, int n_articulated, int W, int H, const float* cams, const float* bg,
                       const float* xyz, const float* log_scale, const float* rot,
                       const float* opacity_logit, const float* f_dc, const float* f_rest,
                       const float* skin_w, const float* transforms, float* out_color, int32_t* radii,
                       void* workspace, size_t workspace_bytes, int64_t pair_capacity, int debug,
                       void* stream);
-int mgr_views_backward(int V, int N, int B, int W, int H, const float* cams, const float* bg,
+int mgr_views_backward(int V, int N, int B, int n_articulated, int W, int H, const float* cams, const float* bg,
                        const float* xyz, const float* log_scale, const float* rot,
                        const float* opacity_logit, const float* f_dc, const float* f_rest,
                        const float* skin_w, const float* transforms, const int32_t* radii,
@@ -144,7 +149,9 @@ int mgr_views_backward(int V, int N, int B, int W, int H, const float* cams, con
 
 /* Debug/test: byte offsets of the workspace regions, in the order header, grec, depth, rect,
  * alive, pair_off, tile_count, tile_start, tile_cursor, tile_done, tile_queue, chunk_start, items,
- * ckpt, keys, sorted_gid, final_T (reserved, not written), n_contrib, pair_tag, pair_grad, total.  Returns the count. */
+ * ckpt, keys, sorted_gid, final_T (reserved, not written), n_contrib, pair_tag, pair_grad, total, inst_grad
+ * (fused backward: per (Gaussian, view-lane) the 9 gathered blend sums, 12 floats each, then the active list),
+ * inst_tag.  Returns the count. */
 int mgr_raster_layout(int V, int N, int W, int H, int64_t pair_capacity, size_t* out, int n_out);
 
 /* Blocking read-back of the workspace header after a forward: total number of
@@ -173,10 +180,11 @@ int mgr_raster_debug_binning_sync(const void* workspace, int V, int N, int W, in
 int mgr_skin_weights_fwd(int N, const float* xyz, const float* grid, int D, int H, int W, int B,
                          int grid_stride, const float* center3, const float* scale3, float* out_w,
                          void* stream);
-/* dL_dxyz (N,3) written (not accumulated). */
+/* dL_dxyz (N,3) written, or added to when accumulate != 0 (the training engine adds the skin-weight path
+ * to the gradient mgr_views_backward has already written for the same xyz leaf). */
 int mgr_skin_weights_bwd(int N, const float* xyz, const float* grid, int D, int H, int W, int B,
                          int grid_stride, const float* center3, const float* scale3,
-                         const float* dL_dw, float* dL_dxyz, void* stream);
+                         const float* dL_dw, float* dL_dxyz, int accumulate, void* stream);
 
 /* LBS for P poses.  transforms: (P,B,16) row-major 4x4 bone transforms
  * T_b = posed_b * inv(rest_b) (+ identity background).  skin_w (N,B) or NULL for
@@ -212,6 +220,24 @@ int mgr_sh_color_bwd(int V, int N, const float* sh, const float* xyz, int64_t st
 /* uv = (K*E*[x;1])[:2]/z for N points; K (3,3), E (3,4) row-major. */
 int mgr_project_points(int N, const float* xyz, const float* K9, const float* E12, float* uv,
                        void* stream);
+
+/* Segmentation-mask pruning test of on_after_backward (src/modules/hand_dynamic.py:193-209,
+ * src/modules/object.py:66-72).
+ * mgr_dilate_mask: dilate_mask, src/utils/gaussian_utils.py:35-47 (conv2d with a kernel_size^2 box of
+ *   ones, zero padding, > 0) on a (H,W) byte mask (non-zero = set); scratch and out are (H,W) bytes.
+ * mgr_points_outside_mask: get_points_outside_mask, src/utils/gaussian_utils.py:101-147:
+ *   out[i] = !mask[int(clamp(v_i, 0, H-1))][int(clamp(u_i, 0, W-1))] with (u,v) = project_points(xyz_i);
+ *   when any of the n_keypoints keypoints (may be 0 / NULL) lands outside the mask, all out[i] = 0
+ *   (:125-131).  mask: the (already dilated, when the caller asks for dilate=True) (H,W) byte mask. */
+int mgr_dilate_mask(int H, int W, int kernel_size, const uint8_t* mask, uint8_t* scratch, uint8_t* out,
+                    void* stream);
+int mgr_points_outside_mask(int N, const float* xyz, const float* K9, const float* E12, int H, int W,
+                            const uint8_t* mask, int n_keypoints, const float* keypoints, uint8_t* out,
+                            void* stream);
+/* out[i] = mean_k |xyz_i - keypoint_k| > thresh: the keypoint-distance pruning test,
+ * src/modules/hand_dynamic.py:210-218 (torch.cdist(posed_xyz, keypoints).mean(1) > 0.2). */
+int mgr_keypoint_far_mask(int N, const float* xyz, int n_keypoints, const float* keypoints, float thresh,
+                          uint8_t* out, void* stream);
 
 /* ------------------------------------------------------------------------
  * simple-knn: mean squared distance to the 3 nearest other points
@@ -275,17 +301,41 @@ int mgr_image_loss(int V, int H, int W, const float* pred, const float* target, 
  * order [kept originals | clones | split copies 0 | split copies 1].
  * noise: standard normals (2 * n_selected, 3), row c * n_selected + j for copy c
  * of the j-th split-selected Gaussian (torch.normal(mean=0, std) / std of :264-266).
- * The reference's screen-size test (:316-318) never fires -- densification_postfix
- * has just zeroed max_radii2D (:249-251) -- and is therefore not an input.
+ * max_screen_size: the reference's `if max_screen_size:` (:316); 0 = None.  When set, Gaussians
+ * whose largest world-space scale exceeds 0.1 * extent are pruned (big_points_ws, :318); the
+ * screen-size half (max_radii2D > max_screen_size, :317) can never fire -- densification_postfix
+ * has just zeroed max_radii2D (:249-251) -- so max_radii2D is not an input.  When 0, only the
+ * opacity test (and NaN scales, :328-329) prunes.
+ *
+ * mgr_adam_step_groups: the same update with one step count per group (steps[k] <= 0 skips
+ * group k): torch.optim.Adam keeps state["step"] per parameter, and the reference replaces
+ * leaves (reset_opacity / densify / prune run in on_after_backward, hand_dynamic.py:193-224)
+ * before optimizer.step(), which then skips the gradient-less new nn.Parameter.
+ *
+ * mgr_prune_plan: prune_points(mask), gaussian.py:185-203 (the mask_to_prune branch of
+ * density_update, gaussian_utils.py:454-459): prune_mask (N) bytes, non-zero = remove.  Builds the
+ * same source map as mgr_densify_plan (counts_host[0] = counts_host[4] = survivors); the rows are
+ * then written by mgr_densify_apply(N, M, 0, ..., noise = NULL).
+ *
+ * mgr_gather_rows: dst[o,:] = src[map[o],:] for the M rows of the plan in `workspace`, rows of
+ * `width` 4-byte words: the per-Gaussian statistics (xyz_gradient_accum, denom, max_radii2D,
+ * gaussian.py:199-203) and any other per-Gaussian side array.
  * ------------------------------------------------------------------------ */
 int mgr_adam_step(int n_groups, const int64_t* counts, float* const* params, const float* const* grads,
                   float* const* exp_avg, float* const* exp_avg_sq, const double* lrs, int64_t step, double beta1,
                   double beta2, double eps, void* stream);
+int mgr_adam_step_groups(int n_groups, const int64_t* counts, float* const* params, const float* const* grads,
+                         float* const* exp_avg, float* const* exp_avg_sq, const double* lrs, const int64_t* steps,
+                         double beta1, double beta2, double eps, void* stream);
 int mgr_reset_opacity(int N, float* opacity_logit, float* exp_avg, float* exp_avg_sq, void* stream);
 size_t mgr_densify_workspace_bytes(int N);
 int mgr_densify_plan(int N, const float* grad_accum, const float* denom, const float* log_scale,
                      const float* opacity_logit, float max_grad, float min_opacity, float extent, float percent_dense,
-                     void* workspace, size_t workspace_bytes, int64_t* counts_host, void* stream);
+                     float max_screen_size, void* workspace, size_t workspace_bytes, int64_t* counts_host,
+                     void* stream);
+int mgr_prune_plan(int N, const uint8_t* prune_mask, void* workspace, size_t workspace_bytes, int64_t* counts_host,
+                   void* stream);
+int mgr_gather_rows(int N, int64_t M, const void* workspace, const void* src, void* dst, int width, void* stream);
 int mgr_densify_apply(int N, int64_t M, int64_t n_selected, const void* workspace, const float* const* params,
                       const float* const* exp_avg, const float* const* exp_avg_sq, float* const* new_params,
                       float* const* new_exp_avg, float* const* new_exp_avg_sq, const float* skin, float* new_skin, int B,

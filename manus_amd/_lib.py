@@ -29,8 +29,8 @@ SIGNATURES = {
     "mgr_raster_backward": (c_int, [c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp,
                                     c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz,
                                     c_i64, c_int, c_vp]),
-    "mgr_views_forward": (c_int, [c_int] * 5 + [c_vp] * 12 + [c_vp, c_sz, c_i64, c_int, c_vp]),
-    "mgr_views_backward": (c_int, [c_int] * 5 + [c_vp] * 13 + [c_f32] + [c_vp] * 10 + [c_vp, c_sz, c_i64, c_int, c_vp]),
+    "mgr_views_forward": (c_int, [c_int] * 6 + [c_vp] * 12 + [c_vp, c_sz, c_i64, c_int, c_vp]),
+    "mgr_views_backward": (c_int, [c_int] * 6 + [c_vp] * 13 + [c_f32] + [c_vp] * 10 + [c_vp, c_sz, c_i64, c_int, c_vp]),
     "mgr_raster_layout": (c_int, [c_int, c_int, c_int, c_int, c_i64, ctypes.POINTER(c_sz), c_int]),
     "mgr_raster_status_sync": (c_int, [c_vp, ctypes.POINTER(c_i64), ctypes.POINTER(ctypes.c_int32), c_vp]),
     "mgr_raster_debug_binning_sync": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_i64, c_int, c_vp, c_vp,
@@ -38,7 +38,7 @@ SIGNATURES = {
     "mgr_skin_weights_fwd": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp,
                                      c_vp]),
     "mgr_skin_weights_bwd": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp,
-                                     c_vp, c_vp]),
+                                     c_vp, c_int, c_vp]),
     "mgr_lbs_cov_fwd": (c_int, [c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "mgr_lbs_cov_bwd": (c_int, [c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                 c_vp, c_vp, c_vp, c_vp]),
@@ -46,6 +46,9 @@ SIGNATURES = {
     "mgr_sh_color_bwd": (c_int, [c_int, c_int, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp,
                                  c_vp]),
     "mgr_project_points": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "mgr_dilate_mask": (c_int, [c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
+    "mgr_points_outside_mask": (c_int, [c_int, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_vp]),
+    "mgr_keypoint_far_mask": (c_int, [c_int, c_vp, c_int, c_vp, c_f32, c_vp, c_vp]),
     "mgr_knn3_workspace_bytes": (c_sz, [c_int]),
     "mgr_knn3_mean_dist2": (c_int, [c_int, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "mgr_l1_loss_grad": (c_int, [c_i64, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp]),
@@ -55,7 +58,11 @@ SIGNATURES = {
                                ctypes.c_double, c_vp]),
     "mgr_reset_opacity": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp]),
     "mgr_densify_workspace_bytes": (c_sz, [c_int]),
-    "mgr_densify_plan": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_f32, c_vp, c_sz, c_vp, c_vp]),
+    "mgr_densify_plan": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_f32, c_f32, c_vp, c_sz, c_vp, c_vp]),
+    "mgr_adam_step_groups": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_double, ctypes.c_double,
+                                      ctypes.c_double, c_vp]),
+    "mgr_prune_plan": (c_int, [c_int, c_vp, c_vp, c_sz, c_vp, c_vp]),
+    "mgr_gather_rows": (c_int, [c_int, c_i64, c_vp, c_vp, c_vp, c_int, c_vp]),
     "mgr_densify_apply": (c_int, [c_int, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int,
                                    c_vp, c_vp]),
     "mgr_isotropic_reg_workspace_bytes": (c_sz, [c_int]),

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void k_skin_bwd(int N, const float* __restrict
                                                   int B, const float* __restrict__ center,
                                                   const float* __restrict__ scale,
                                                   const float* __restrict__ dL_dw,
-                                                  float* __restrict__ dL_dxyz) {
+                                                  float* __restrict__ dL_dxyz, int accumulate) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
     const TriSetup s = tri_setup(xyz, i, center, scale, D, H, W);
@@ -119,9 +119,9 @@ __global__ __launch_bounds__(256) void k_skin_bwd(int N, const float* __restrict
         gy += gr * ddy;
         gz += gr * ddz;
     }
-    dL_dxyz[3 * i + 0] = gx * (0.5f * (float)(W - 1)) / scale[0];
-    dL_dxyz[3 * i + 1] = gy * (0.5f * (float)(H - 1)) / scale[1];
-    dL_dxyz[3 * i + 2] = gz * (0.5f * (float)(D - 1)) / scale[2];
+    dL_dxyz[3 * i + 0] = (accumulate ? dL_dxyz[3 * i + 0] : 0.f) + gx * (0.5f * (float)(W - 1)) / scale[0];
+    dL_dxyz[3 * i + 1] = (accumulate ? dL_dxyz[3 * i + 1] : 0.f) + gy * (0.5f * (float)(H - 1)) / scale[1];
+    dL_dxyz[3 * i + 2] = (accumulate ? dL_dxyz[3 * i + 2] : 0.f) + gz * (0.5f * (float)(D - 1)) / scale[2];
 }
 
 // ---------------------------------------------------------------------------
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void k_skin_bwd24(int N, const float* __restri
                                                     int B, const float* __restrict__ center,
                                                     const float* __restrict__ scale,
                                                     const float* __restrict__ dL_dw,
-                                                    float* __restrict__ dL_dxyz) {
+                                                    float* __restrict__ dL_dxyz, int accumulate) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
     const TriSetup s = tri_setup(xyz, i, center, scale, D, H, W);
@@ -232,9 +232,9 @@ __global__ __launch_bounds__(256) void k_skin_bwd24(int N, const float* __restri
         gxQ += Dx * Qk; gyQ += Dy * Qk; gzQ += Dz * Qk;
     }
     const float invS = 1.0f / S, dot = dS * invS;
-    dL_dxyz[3 * i + 0] = (gxP - dot * gxQ) * invS * (0.5f * (float)(W - 1)) / scale[0];
-    dL_dxyz[3 * i + 1] = (gyP - dot * gyQ) * invS * (0.5f * (float)(H - 1)) / scale[1];
-    dL_dxyz[3 * i + 2] = (gzP - dot * gzQ) * invS * (0.5f * (float)(D - 1)) / scale[2];
+    dL_dxyz[3 * i + 0] = (accumulate ? dL_dxyz[3 * i + 0] : 0.f) + (gxP - dot * gxQ) * invS * (0.5f * (float)(W - 1)) / scale[0];
+    dL_dxyz[3 * i + 1] = (accumulate ? dL_dxyz[3 * i + 1] : 0.f) + (gyP - dot * gyQ) * invS * (0.5f * (float)(H - 1)) / scale[1];
+    dL_dxyz[3 * i + 2] = (accumulate ? dL_dxyz[3 * i + 2] : 0.f) + (gzP - dot * gzQ) * invS * (0.5f * (float)(D - 1)) / scale[2];
 }
 
 // ---------------------------------------------------------------------------
@@ -426,6 +426,83 @@ __global__ void k_project(int N, const float* __restrict__ xyz, const float* __r
     uv[2 * i + 1] = b / c;
 }
 
+// ---------------------------------------------------------------------------
+// Segmentation-mask pruning test (src/utils/gaussian_utils.py:35-47,101-147).
+//   dilate_mask: conv2d of the {0,1} mask with an 11x11 box of ones, zero padding, > 0  ==  "any pixel of the
+//     window is set"; done separably (rows, then columns) through a byte scratch image.
+//   get_points_outside_mask: uv = project_points(xyz); x = int(clamp(u, 0, W-1)), y = int(clamp(v, 0, H-1))
+//     (float clamp, then truncation like torch's .int()); value = !mask[y][x]; if ANY keypoint projects onto a
+//     pixel outside the mask, every value is False (:125-131).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_dilate_rows(int H, int W, int r, const uint8_t* __restrict__ in,
+                                                     uint8_t* __restrict__ out) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const uint8_t* row = in + (size_t)y * W;
+    uint8_t a = 0;
+    for (int k = max(0, x - r); k <= min(W - 1, x + r); ++k) a |= row[k];
+    out[(size_t)y * W + x] = a ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void k_dilate_cols(int H, int W, int r, const uint8_t* __restrict__ in,
+                                                     uint8_t* __restrict__ out) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    uint8_t a = 0;
+    for (int k = max(0, y - r); k <= min(H - 1, y + r); ++k) a |= in[(size_t)k * W + x];
+    out[(size_t)y * W + x] = a ? 1 : 0;
+}
+
+__device__ __forceinline__ int mask_coord(float u, int n) {
+    const float c = fminf(fmaxf(u, 0.0f), (float)(n - 1));  // NaN -> 0 (fmaxf returns the non-NaN operand)
+    return (int)c;
+}
+
+__device__ __forceinline__ bool outside_mask(const float* Pm, float x, float y, float z, int H, int W,
+                                             const uint8_t* __restrict__ mask) {
+    const float a = Pm[0] * x + Pm[1] * y + Pm[2] * z + Pm[3];
+    const float b = Pm[4] * x + Pm[5] * y + Pm[6] * z + Pm[7];
+    const float c = Pm[8] * x + Pm[9] * y + Pm[10] * z + Pm[11];
+    const int px = mask_coord(a / c, W), py = mask_coord(b / c, H);
+    return mask[(size_t)py * W + px] == 0;
+}
+
+__global__ __launch_bounds__(256) void k_points_outside_mask(int N, const float* __restrict__ xyz,
+                                                             const float* __restrict__ K, const float* __restrict__ E,
+                                                             int H, int W, const uint8_t* __restrict__ mask, int n_key,
+                                                             const float* __restrict__ keypts, uint8_t* __restrict__ out) {
+    float Pm[12];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) Pm[4 * r + c] = K[3 * r] * E[c] + K[3 * r + 1] * E[4 + c] + K[3 * r + 2] * E[8 + c];
+    // every workgroup re-derives the keypoint override (a few dozen points): no second launch, no global flag
+    int key_out = 0;
+    for (int k = threadIdx.x; k < n_key; k += 256)
+        key_out |= outside_mask(Pm, keypts[3 * k], keypts[3 * k + 1], keypts[3 * k + 2], H, W, mask) ? 1 : 0;
+    const bool override_all = __syncthreads_or(key_out) != 0;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const bool o = outside_mask(Pm, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], H, W, mask);
+    out[i] = (o && !override_all) ? 1 : 0;
+}
+
+// mean_k |x_i - keypoint_k| > thresh: the keypoint-distance pruning test of on_after_backward
+// (src/modules/hand_dynamic.py:210-218: torch.cdist(posed_xyz, keypoints).mean(1) > 0.2), direct differences
+__global__ __launch_bounds__(256) void k_keypoint_far(int N, const float* __restrict__ xyz, int n_key,
+                                                      const float* __restrict__ keypts, float thresh,
+                                                      uint8_t* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+    float acc = 0.f;
+    for (int k = 0; k < n_key; ++k) {  // wave-uniform keypoint address: scalar loads
+        const float dx = x - keypts[3 * k], dy = y - keypts[3 * k + 1], dz = z - keypts[3 * k + 2];
+        acc += sqrtf(dx * dx + dy * dy + dz * dz);
+    }
+    out[i] = (acc / (float)n_key > thresh) ? 1 : 0;
+}
+
 __global__ __launch_bounds__(256) void k_l1_grad(int64_t count, const float4* __restrict__ a,
                                                  const float4* __restrict__ b, float scale,
                                                  float4* __restrict__ g, float* __restrict__ loss_sum,
@@ -484,7 +561,7 @@ extern "C" int mgr_skin_weights_fwd(int N, const float* xyz, const float* grid, 
 
 extern "C" int mgr_skin_weights_bwd(int N, const float* xyz, const float* grid, int D, int H, int W,
                                     int B, int grid_stride, const float* center3, const float* scale3,
-                                    const float* dL_dw, float* dL_dxyz, void* stream_) {
+                                    const float* dL_dw, float* dL_dxyz, int accumulate, void* stream_) {
     if (N < 0 || B <= 0 || B > MGR_MAX_BONES || D <= 0 || H <= 0 || W <= 0)
         return mgr_fail(MGR_EINVAL, "mgr_skin_weights_bwd: bad sizes");
     if (N == 0) return MGR_OK;
@@ -494,13 +571,13 @@ extern "C" int mgr_skin_weights_bwd(int N, const float* xyz, const float* grid, 
     if (grid_stride != B && grid_stride != SKIN_BP) return mgr_fail(MGR_EINVAL, "mgr_skin_weights_bwd: grid_stride must be B or 24");
     if (grid_stride == SKIN_BP && B <= SKIN_BP && ((uintptr_t)grid & 15) == 0) {
         { MGR_PROF("k_skin_bwd24", stream); hipLaunchKernelGGL(k_skin_bwd24, dim3((N + 255) / 256), dim3(256), 0, stream, N, xyz, (const float4*)grid, D, H, W, B,
-                           center3, scale3, dL_dw, dL_dxyz); }
+                           center3, scale3, dL_dw, dL_dxyz, accumulate); }
         MGR_LAUNCH_CHECK("k_skin_bwd24", stream, 0);
         return MGR_OK;
     }
     if (grid_stride != B) return mgr_fail(MGR_EINVAL, "mgr_skin_weights_bwd: padded grid must be 16-byte aligned with B <= 24");
     { MGR_PROF("k_skin_bwd", stream); hipLaunchKernelGGL(k_skin_bwd, dim3((N + 255) / 256), dim3(256), 0, stream, N, xyz, grid, D, H, W, B,
-                       center3, scale3, dL_dw, dL_dxyz); }
+                       center3, scale3, dL_dw, dL_dxyz, accumulate); }
     MGR_LAUNCH_CHECK("k_skin_bwd", stream, 0);
     return MGR_OK;
 }
@@ -575,6 +652,43 @@ extern "C" int mgr_project_points(int N, const float* xyz, const float* K9, cons
     hipStream_t stream = (hipStream_t)stream_;
     { MGR_PROF("k_project", stream); hipLaunchKernelGGL(k_project, dim3((N + 255) / 256), dim3(256), 0, stream, N, xyz, K9, E12, uv); }
     MGR_LAUNCH_CHECK("k_project", stream, 0);
+    return MGR_OK;
+}
+
+extern "C" int mgr_dilate_mask(int H, int W, int kernel_size, const uint8_t* mask, uint8_t* scratch, uint8_t* out,
+                               void* stream_) {
+    if (H <= 0 || W <= 0 || kernel_size < 1 || !(kernel_size & 1)) return mgr_fail(MGR_EINVAL, "mgr_dilate_mask: bad sizes");
+    if (!mask || !scratch || !out) return mgr_fail(MGR_EINVAL, "mgr_dilate_mask: null pointer");
+    hipStream_t stream = (hipStream_t)stream_;
+    const dim3 grid((W + 255) / 256, H);
+    hipLaunchKernelGGL(k_dilate_rows, grid, dim3(256), 0, stream, H, W, kernel_size / 2, mask, scratch);
+    hipLaunchKernelGGL(k_dilate_cols, grid, dim3(256), 0, stream, H, W, kernel_size / 2, (const uint8_t*)scratch, out);
+    MGR_LAUNCH_CHECK("k_dilate", stream, 0);
+    return MGR_OK;
+}
+
+extern "C" int mgr_points_outside_mask(int N, const float* xyz, const float* K9, const float* E12, int H, int W,
+                                       const uint8_t* mask, int n_keypoints, const float* keypoints, uint8_t* out,
+                                       void* stream_) {
+    if (N < 0 || H <= 0 || W <= 0 || n_keypoints < 0) return mgr_fail(MGR_EINVAL, "mgr_points_outside_mask: bad sizes");
+    if (N == 0) return MGR_OK;
+    if (!xyz || !K9 || !E12 || !mask || !out || (n_keypoints > 0 && !keypoints))
+        return mgr_fail(MGR_EINVAL, "mgr_points_outside_mask: null pointer");
+    hipStream_t stream = (hipStream_t)stream_;
+    hipLaunchKernelGGL(k_points_outside_mask, dim3((N + 255) / 256), dim3(256), 0, stream, N, xyz, K9, E12, H, W, mask,
+                       n_keypoints, keypoints, out);
+    MGR_LAUNCH_CHECK("k_points_outside_mask", stream, 0);
+    return MGR_OK;
+}
+
+extern "C" int mgr_keypoint_far_mask(int N, const float* xyz, int n_keypoints, const float* keypoints, float thresh,
+                                     uint8_t* out, void* stream_) {
+    if (N < 0 || n_keypoints <= 0) return mgr_fail(MGR_EINVAL, "mgr_keypoint_far_mask: bad sizes");
+    if (N == 0) return MGR_OK;
+    if (!xyz || !keypoints || !out) return mgr_fail(MGR_EINVAL, "mgr_keypoint_far_mask: null pointer");
+    hipStream_t stream = (hipStream_t)stream_;
+    hipLaunchKernelGGL(k_keypoint_far, dim3((N + 255) / 256), dim3(256), 0, stream, N, xyz, n_keypoints, keypoints, thresh, out);
+    MGR_LAUNCH_CHECK("k_keypoint_far", stream, 0);
     return MGR_OK;
 }
 

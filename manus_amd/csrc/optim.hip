@@ -24,7 +24,8 @@ struct AdamGroups {
     float* v[OPT_MAX_GROUPS];
     long long quad_end[OPT_MAX_GROUPS];  // running end, in 4-element chunks
     long long count[OPT_MAX_GROUPS];
-    float step_size[OPT_MAX_GROUPS];     // lr / (1 - beta1^t)
+    float step_size[OPT_MAX_GROUPS];     // lr / (1 - beta1^t), t = the group's own step count
+    float inv_sqrt_bc2[OPT_MAX_GROUPS];  // 1 / sqrt(1 - beta2^t)
     int n;
 };
 
@@ -39,7 +40,7 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
 }
 
 __global__ __launch_bounds__(256) void k_adam(AdamGroups G, long long total_quads, float omb1, float b2, float omb2,
-                                              float inv_sqrt_bc2, float eps) {
+                                              float eps) {
     for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < total_quads; q += (long long)gridDim.x * 256) {
         int gi = 0;
         long long base = 0;
@@ -54,7 +55,7 @@ __global__ __launch_bounds__(256) void k_adam(AdamGroups G, long long total_quad
         const float* g = G.g[gi] + e0;
         float* m = G.m[gi] + e0;
         float* v = G.v[gi] + e0;
-        const float ss = G.step_size[gi];
+        const float ss = G.step_size[gi], inv_sqrt_bc2 = G.inv_sqrt_bc2[gi];
         const bool vec = e0 + 4 <= cnt && ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0;
         if (vec) {
             float4 P = *(float4*)p, M = *(float4*)m, V = *(float4*)v;
@@ -74,20 +75,24 @@ __global__ __launch_bounds__(256) void k_adam(AdamGroups G, long long total_quad
     }
 }
 
-extern "C" int mgr_adam_step(int n_groups, const int64_t* counts, float* const* params, const float* const* grads,
-                             float* const* exp_avg, float* const* exp_avg_sq, const double* lrs, int64_t step,
-                             double beta1, double beta2, double eps, void* stream_) {
-    if (n_groups <= 0 || n_groups > OPT_MAX_GROUPS || step < 1) return mgr_fail(MGR_EINVAL, "mgr_adam_step: bad sizes");
-    if (!counts || !params || !grads || !exp_avg || !exp_avg_sq || !lrs)
+// Every group carries its own step count, like torch.optim.Adam's per-parameter state["step"]: the reference
+// replaces a leaf (reset_opacity, densification, pruning) before optimizer.step() in on_after_backward, the new
+// nn.Parameter has no .grad, and Adam skips it -- that group's count then lags the others (gaussian.py:153-165,
+// hand_dynamic.py:193-224,259-277).  steps[k] <= 0 skips group k.
+extern "C" int mgr_adam_step_groups(int n_groups, const int64_t* counts, float* const* params, const float* const* grads,
+                                    float* const* exp_avg, float* const* exp_avg_sq, const double* lrs,
+                                    const int64_t* steps, double beta1, double beta2, double eps, void* stream_) {
+    if (n_groups <= 0 || n_groups > OPT_MAX_GROUPS) return mgr_fail(MGR_EINVAL, "mgr_adam_step: bad sizes");
+    if (!counts || !params || !grads || !exp_avg || !exp_avg_sq || !lrs || !steps)
         return mgr_fail(MGR_EINVAL, "mgr_adam_step: null pointer");
     AdamGroups G;
-    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
     long long q = 0;
     G.n = n_groups;
     for (int k = 0; k < OPT_MAX_GROUPS; ++k) {
-        const bool on = k < n_groups;
+        const bool on = k < n_groups && steps[k] > 0;
         if (on && (counts[k] < 0 || (counts[k] > 0 && (!params[k] || !grads[k] || !exp_avg[k] || !exp_avg_sq[k]))))
             return mgr_fail(MGR_EINVAL, "mgr_adam_step: null group pointer");
+        const double bc1 = on ? 1.0 - pow(beta1, (double)steps[k]) : 1.0, bc2 = on ? 1.0 - pow(beta2, (double)steps[k]) : 1.0;
         G.p[k] = on ? params[k] : nullptr;
         G.g[k] = on ? grads[k] : nullptr;
         G.m[k] = on ? exp_avg[k] : nullptr;
@@ -96,6 +101,7 @@ extern "C" int mgr_adam_step(int n_groups, const int64_t* counts, float* const* 
         q += on ? (counts[k] + 3) / 4 : 0;
         G.quad_end[k] = q;
         G.step_size[k] = on ? (float)(lrs[k] / bc1) : 0.f;
+        G.inv_sqrt_bc2[k] = on ? (float)(1.0 / sqrt(bc2)) : 0.f;
     }
     if (q == 0) return MGR_OK;
     hipStream_t stream = (hipStream_t)stream_;
@@ -104,10 +110,19 @@ extern "C" int mgr_adam_step(int n_groups, const int64_t* counts, float* const* 
     {
         MGR_PROF("k_adam", stream);
         hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(256), 0, stream, G, q, (float)(1.0 - beta1), (float)beta2,
-                           (float)(1.0 - beta2), (float)(1.0 / sqrt(bc2)), (float)eps);
+                           (float)(1.0 - beta2), (float)eps);
     }
     MGR_LAUNCH_CHECK("k_adam", stream, 0);
     return MGR_OK;
+}
+
+extern "C" int mgr_adam_step(int n_groups, const int64_t* counts, float* const* params, const float* const* grads,
+                             float* const* exp_avg, float* const* exp_avg_sq, const double* lrs, int64_t step,
+                             double beta1, double beta2, double eps, void* stream_) {
+    if (n_groups <= 0 || n_groups > OPT_MAX_GROUPS || step < 1) return mgr_fail(MGR_EINVAL, "mgr_adam_step: bad sizes");
+    int64_t steps[OPT_MAX_GROUPS];
+    for (int k = 0; k < OPT_MAX_GROUPS; ++k) steps[k] = step;
+    return mgr_adam_step_groups(n_groups, counts, params, grads, exp_avg, exp_avg_sq, lrs, steps, beta1, beta2, eps, stream_);
 }
 
 // ---------------------------------------------------------------------------
@@ -162,6 +177,7 @@ __global__ __launch_bounds__(1024) void k_dens_flags(int N, const float* __restr
         const bool clone = !nan_row && fabsf(gr) >= max_grad && smax <= dense_extent;   // gaussian.py:290-293
         const bool split = !nan_row && gr >= max_grad && smax > dense_extent;           // gaussian.py:259-262
         const bool low_op = 1.0f / (1.0f + expf(-op_logit[i])) < min_opacity;
+        // big_extent = 0.1 * extent only when max_screen_size is set (gaussian.py:316-320), +inf otherwise
         const bool prune_self = low_op || smax > big_extent || nan_row;     // gaussian.py:315-327
         // children: scaling = log(exp(s) / (0.8 * 2)) (gaussian.py:268), same opacity
         const float c0 = expf(logf(s0 / 1.6f)), c1 = expf(logf(s1 / 1.6f)), c2 = expf(logf(s2 / 1.6f));
@@ -274,8 +290,8 @@ static DensLayout dens_layout(int N) {
 
 extern "C" int mgr_densify_plan(int N, const float* grad_accum, const float* denom, const float* log_scale,
                                 const float* opacity_logit, float max_grad, float min_opacity, float extent,
-                                float percent_dense, void* workspace, size_t workspace_bytes, int64_t* counts_host,
-                                void* stream_) {
+                                float percent_dense, float max_screen_size, void* workspace, size_t workspace_bytes,
+                                int64_t* counts_host, void* stream_) {
     if (N <= 0) return mgr_fail(MGR_EINVAL, "mgr_densify_plan: bad size");
     if (!grad_accum || !denom || !log_scale || !opacity_logit || !workspace || !counts_host)
         return mgr_fail(MGR_EINVAL, "mgr_densify_plan: null pointer");
@@ -285,7 +301,11 @@ extern "C" int mgr_densify_plan(int N, const float* grad_accum, const float* den
     char* ws = (char*)workspace;
     const int nblk = (N + 1023) / 1024;
     hipLaunchKernelGGL(k_dens_flags, dim3(nblk), dim3(1024), 0, stream, N, grad_accum, denom, log_scale, opacity_logit,
-                       max_grad, min_opacity, percent_dense * extent, 0.1f * extent, (uint32_t*)(ws + L.flags),
+                       max_grad, min_opacity, percent_dense * extent,
+                       // `if max_screen_size:` (gaussian.py:316): None / 0 disables BOTH size tests; the screen-size
+                       // half (max_radii2D > max_screen_size) can never fire anyway, densification_postfix has
+                       // zeroed max_radii2D by then (:249-251)
+                       max_screen_size > 0.0f ? 0.1f * extent : __builtin_huge_valf(), (uint32_t*)(ws + L.flags),
                        (uint4*)(ws + L.sums));
     hipLaunchKernelGGL(k_dens_map, dim3(nblk), dim3(1024), 0, stream, N, nblk, (const uint32_t*)(ws + L.flags),
                        (const uint4*)(ws + L.sums), (uint32_t*)(ws + L.map), (uint32_t*)(ws + L.aux),
@@ -295,6 +315,72 @@ extern "C" int mgr_densify_plan(int N, const float* grad_accum, const float* den
     MGR_HIP(hipMemcpyAsync(h, ws + L.counts, sizeof(h), hipMemcpyDeviceToHost, stream));
     MGR_HIP(hipStreamSynchronize(stream));  // the caller allocates the new tensors from these
     for (int k = 0; k < 5; ++k) counts_host[k] = h[k];
+    return MGR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// prune_points(mask) (gaussian.py:185-203): the same scan / map machinery with keep = !mask; the rows are then
+// written by mgr_densify_apply (all kind 0: parameters and both moments copied) and the per-Gaussian statistics
+// by mgr_gather_rows.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_prune_flags(int N, const uint8_t* __restrict__ mask, uint32_t* __restrict__ flags,
+                                                      uint4* __restrict__ block_sums) {
+    __shared__ uint32_t s_w[16];
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    const uint32_t f = (i < N && mask[i] == 0) ? DF_KEEP_ORIG : 0u;
+    if (i < N) flags[i] = f;
+    const unsigned long long b = __ballot(f != 0u);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = (uint32_t)__popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t a = 0;
+        for (int w = 0; w < 16; ++w) a += s_w[w];
+        block_sums[blockIdx.x] = make_uint4(a, 0u, 0u, 0u);
+    }
+}
+
+extern "C" int mgr_prune_plan(int N, const uint8_t* prune_mask, void* workspace, size_t workspace_bytes,
+                              int64_t* counts_host, void* stream_) {
+    if (N <= 0) return mgr_fail(MGR_EINVAL, "mgr_prune_plan: bad size");
+    if (!prune_mask || !workspace || !counts_host) return mgr_fail(MGR_EINVAL, "mgr_prune_plan: null pointer");
+    if (workspace_bytes < mgr_densify_workspace_bytes(N)) return mgr_fail(MGR_ENOMEM, "mgr_prune_plan: workspace too small");
+    hipStream_t stream = (hipStream_t)stream_;
+    const DensLayout L = dens_layout(N);
+    char* ws = (char*)workspace;
+    const int nblk = (N + 1023) / 1024;
+    hipLaunchKernelGGL(k_prune_flags, dim3(nblk), dim3(1024), 0, stream, N, prune_mask, (uint32_t*)(ws + L.flags),
+                       (uint4*)(ws + L.sums));
+    hipLaunchKernelGGL(k_dens_map, dim3(nblk), dim3(1024), 0, stream, N, nblk, (const uint32_t*)(ws + L.flags),
+                       (const uint4*)(ws + L.sums), (uint32_t*)(ws + L.map), (uint32_t*)(ws + L.aux),
+                       (uint32_t*)(ws + L.counts));
+    MGR_LAUNCH_CHECK("k_prune_map", stream, 0);
+    uint32_t h[5];
+    MGR_HIP(hipMemcpyAsync(h, ws + L.counts, sizeof(h), hipMemcpyDeviceToHost, stream));
+    MGR_HIP(hipStreamSynchronize(stream));
+    for (int k = 0; k < 5; ++k) counts_host[k] = h[k];
+    return MGR_OK;
+}
+
+// dst[o, :] = src[map[o] & 0x3FFFFFFF, :] for the M rows of the plan in `workspace` (rows of `width` 4-byte words)
+__global__ __launch_bounds__(256) void k_gather_rows(uint32_t M, int width, const uint32_t* __restrict__ map,
+                                                     const uint32_t* __restrict__ src, uint32_t* __restrict__ dst) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (size_t)M * width) return;
+    const uint32_t o = (uint32_t)(e / width), c = (uint32_t)(e % width);
+    dst[e] = src[(size_t)(map[o] & 0x3FFFFFFFu) * width + c];
+}
+
+extern "C" int mgr_gather_rows(int N, int64_t M, const void* workspace, const void* src, void* dst, int width,
+                               void* stream_) {
+    if (N <= 0 || M < 0 || M > 2ll * N || width <= 0) return mgr_fail(MGR_EINVAL, "mgr_gather_rows: bad sizes");
+    if (M == 0) return MGR_OK;
+    if (!workspace || !src || !dst) return mgr_fail(MGR_EINVAL, "mgr_gather_rows: null pointer");
+    hipStream_t stream = (hipStream_t)stream_;
+    const DensLayout L = dens_layout(N);
+    const size_t total = (size_t)M * width;
+    hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (uint32_t)M, width,
+                       (const uint32_t*)((const char*)workspace + L.map), (const uint32_t*)src, (uint32_t*)dst);
+    MGR_LAUNCH_CHECK("k_gather_rows", stream, 0);
     return MGR_OK;
 }
 

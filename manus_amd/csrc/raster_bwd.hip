@@ -372,7 +372,7 @@ __device__ __forceinline__ void grp_store8(const float x[8], int vl, bool ok, fl
 // accumulating -- zero gradients for the Gaussians that received nothing.
 template <int G>
 __global__ __launch_bounds__(256) void k_inst_gather(
-    int v_first, int v_count, int N, int B, const int32_t* __restrict__ radii, const ushort4* __restrict__ rect,
+    int v_first, int v_count, int N, int B, int n_art, const int32_t* __restrict__ radii, const ushort4* __restrict__ rect,
     const uint32_t* __restrict__ pair_off, const uint32_t* __restrict__ pair_tag,
     const float4* __restrict__ pair_grad, const uint32_t* __restrict__ inst_tag, uint32_t cap, uint32_t epoch,
     int accumulate, int rounds, float4* __restrict__ iacc,
@@ -450,8 +450,10 @@ __global__ __launch_bounds__(256) void k_inst_gather(
             for (size_t k = tid; k < n * 3; k += 256) { d_xyz[i_lo * 3 + k] = 0.f; d_ls[i_lo * 3 + k] = 0.f; d_fdc[i_lo * 3 + k] = 0.f; }
             for (size_t k = tid; k < n * 4; k += 256) d_rot[i_lo * 4 + k] = 0.f;
             for (size_t k = tid; k < n * 45; k += 256) d_frest[i_lo * 45 + k] = 0.f;
-            if (d_w)
-                for (size_t k = tid; k < n * (size_t)B; k += 256) d_w[i_lo * B + k] = 0.f;
+            if (d_w && i_lo < (size_t)n_art) {  // skin-weight rows exist for the articulated Gaussians only
+                const size_t na = min(i_hi, (size_t)n_art) - i_lo;
+                for (size_t k = tid; k < na * (size_t)B; k += 256) d_w[i_lo * B + k] = 0.f;
+            }
             for (size_t k = tid; k < n; k += 256) {
                 d_op[i_lo + k] = 0.f;
                 if (st_grad2d) st_grad2d[i_lo + k] = 0.f;
@@ -468,7 +470,7 @@ __global__ __launch_bounds__(256) void k_inst_gather(
 // Phase 2: the whole per-view backward chain for the active Gaussians only.
 template <int G, int BMAX>
 __global__ __launch_bounds__(IB_THREADS) __attribute__((amdgpu_waves_per_eu(MGR_IB_WAVES, MGR_IB_WAVES))) void k_inst_bwd(
-    int v_first, int v_count, int N, int B, int W, int H, const float* __restrict__ cams,
+    int v_first, int v_count, int N, int B, int n_art, int W, int H, const float* __restrict__ cams,
     const float* __restrict__ xyz, const float* __restrict__ log_scale, const float* __restrict__ rot,
     const float* __restrict__ op_logit, const float* __restrict__ f_dc, const float* __restrict__ f_rest,
     const float* __restrict__ skin_w, const float* __restrict__ transforms, const float4* __restrict__ iacc,
@@ -483,13 +485,14 @@ __global__ __launch_bounds__(IB_THREADS) __attribute__((amdgpu_waves_per_eu(MGR_
     const int q = blockIdx.x * IPB + il;
     const bool ok = q < n_active;             // lane's Gaussian exists (all lanes stay for the DPP sums)
     const int i = (int)active_list[min(q, n_active - 1)];
-    const bool has_tf = skin_w != nullptr;
-    const int tstride = IB_TSTRIDE(B), vstride = MGR_CAM_FLOATS + (has_tf ? tstride : 0);
+    const bool any_tf = skin_w != nullptr;          // workgroup-uniform: the pose slabs are staged in LDS
+    const bool has_tf = any_tf && i < n_art;        // this lane's Gaussian is articulated (uniform over its lane group)
+    const int tstride = IB_TSTRIDE(B), vstride = MGR_CAM_FLOATS + (any_tf ? tstride : 0);
     for (int k = tid; k < G * MGR_CAM_FLOATS; k += IB_THREADS) {
         const int g = k / MGR_CAM_FLOATS, e = k % MGR_CAM_FLOATS;
         s_view[g * vstride + e] = g < v_count ? cams[(size_t)(v_first + g) * MGR_CAM_FLOATS + e] : 0.f;
     }
-    if (has_tf)
+    if (any_tf)
         for (int k = tid; k < G * B * 16; k += IB_THREADS) {
             const int g = k / (B * 16), e = k % (B * 16);
             s_view[g * vstride + MGR_CAM_FLOATS + e] = g < v_count ? transforms[(size_t)(v_first + g) * B * 16 + e] : 0.f;
@@ -588,9 +591,10 @@ __global__ __launch_bounds__(IB_THREADS) __attribute__((amdgpu_waves_per_eu(MGR_
         dop = acc[5];
         g2 = sqrtf(acc[0] * acc[0] + acc[1] * acc[1]) * grad2d_scale;
     }
-    if (has_tf && d_w) {
+    if (any_tf && d_w) {  // wave-uniform branch around the DPP sums; only articulated rows own a d_w row
 #pragma unroll
-        for (int m = 0; m < BMAX / 8; ++m) grp_store8<G>(dw + 8 * m, vl, ok, d_w + (size_t)i * B + 8 * m, B - 8 * m, acc_out);
+        for (int m = 0; m < BMAX / 8; ++m)
+            grp_store8<G>(dw + 8 * m, vl, ok && has_tf, d_w + (size_t)i * B + 8 * m, B - 8 * m, acc_out);
     }
     {
         const float sg = 1.0f / (1.0f + expf(-op_logit[i]));
@@ -620,7 +624,7 @@ __global__ __launch_bounds__(IB_THREADS) __attribute__((amdgpu_waves_per_eu(MGR_
 }
 
 struct CanonGrads {  // fused articulated backward: canonical inputs and leaf-gradient outputs
-    int B;
+    int B, n_art;
     const float *xyz, *log_scale, *rot, *op_logit, *f_dc, *f_rest, *skin_w, *transforms;
     const int32_t* radii;
     float grad2d_scale;
@@ -684,13 +688,13 @@ static int raster_backward_impl(int V, int N, int W, int H, const float* cams, c
             const int accm = v0 > 0 ? 1 : 0;
             if (v0 > 0) MGR_HIP(hipMemsetAsync(&hdr->n_active, 0, 4, stream));  // the first group's zero comes from k_blend_bwd
 #define MGR_IG_LAUNCH(GG)                                                                                             \
-    hipLaunchKernelGGL((k_inst_gather<GG>), grid_g, dim3(256), 0, stream, v0, vc, N, canon->B, canon->radii,            \
+    hipLaunchKernelGGL((k_inst_gather<GG>), grid_g, dim3(256), 0, stream, v0, vc, N, canon->B, canon->n_art, canon->radii, \
                        (const ushort4*)(ws + L.rect), (const uint32_t*)(ws + L.pair_off),                             \
                        (const uint32_t*)(ws + L.pair_tag), (const float4*)(ws + L.pair_grad),                        \
                        (const uint32_t*)(ws + L.inst_tag), (uint32_t)cap, epoch, accm, rounds, iacc, alist, hdr, canon->d_xyz, canon->d_ls, canon->d_rot, canon->d_op, canon->d_fdc,    \
                        canon->d_frest, canon->d_w, canon->st_grad2d, canon->st_vis, canon->st_radii)
 #define MGR_IB_LAUNCH(GG, BB)                                                                                         \
-    hipLaunchKernelGGL((k_inst_bwd<GG, BB>), grid, dim3(IB_THREADS), lds, stream, v0, vc, N, canon->B, W, H, cams, canon->xyz, \
+    hipLaunchKernelGGL((k_inst_bwd<GG, BB>), grid, dim3(IB_THREADS), lds, stream, v0, vc, N, canon->B, canon->n_art, W, H, cams, canon->xyz, \
                        canon->log_scale, canon->rot, canon->op_logit, canon->f_dc, canon->f_rest, canon->skin_w,      \
                        canon->transforms, (const float4*)iacc, (const uint32_t*)alist, (const MgrHeader*)hdr,         \
                        canon->grad2d_scale, accm, canon->d_xyz, canon->d_ls, canon->d_rot, canon->d_op, canon->d_fdc, \
@@ -740,7 +744,7 @@ extern "C" int mgr_raster_backward(int V, int N, int W, int H, const float* cams
                                 nullptr, workspace, workspace_bytes, cap, debug, stream_);
 }
 
-extern "C" int mgr_views_backward(int V, int N, int B, int W, int H, const float* cams, const float* bg,
+extern "C" int mgr_views_backward(int V, int N, int B, int n_articulated, int W, int H, const float* cams, const float* bg,
                                   const float* xyz, const float* log_scale, const float* rot,
                                   const float* opacity_logit, const float* f_dc, const float* f_rest,
                                   const float* skin_w, const float* transforms, const int32_t* radii,
@@ -754,7 +758,8 @@ extern "C" int mgr_views_backward(int V, int N, int B, int W, int H, const float
                   (skin_w && (!transforms || !d_skin_w))))
         return mgr_fail(MGR_EINVAL, "mgr_views_backward: null pointer");
     if (skin_w && (B <= 0 || B > MGR_MAX_BONES)) return mgr_fail(MGR_EINVAL, "mgr_views_backward: bad B");
-    const CanonGrads cg = {B, xyz, log_scale, rot, opacity_logit, f_dc, f_rest, skin_w, transforms, radii,
+    if (skin_w && (n_articulated < 0 || n_articulated > N)) return mgr_fail(MGR_EINVAL, "mgr_views_backward: bad n_articulated");
+    const CanonGrads cg = {B, skin_w ? n_articulated : 0, xyz, log_scale, rot, opacity_logit, f_dc, f_rest, skin_w, transforms, radii,
                            grad2d_scale, d_xyz, d_log_scale, d_rot, d_opacity_logit, d_f_dc, d_f_rest, d_skin_w,
                            stat_grad2d, stat_vis, stat_radii};
     return raster_backward_impl(V, N, W, H, cams, bg, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, out_color,

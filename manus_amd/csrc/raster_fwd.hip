@@ -237,9 +237,11 @@ __global__ __launch_bounds__(PRE_THREADS) void k_preprocess(
 // and binning state, without writing posed means / covariances / transforms / colours to HBM.
 // Same math as k_lbs_fwd + k_sh_fwd + k_preprocess (instance_math.h).
 // skin_w == nullptr: static object (identity transform, direction = xyz - camera).
+// Rows >= n_art are static as well (the object half of a hand+object composite, src/modules/composite.py:50-59:
+// tf = identity, so inv(tf) * cam = cam exactly and the colour equals the static route's).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(PRE_THREADS) void k_inst_fwd(
-    int N, int B, int W, int H, int gx, int gy, const float* __restrict__ cams,
+    int N, int B, int n_art, int W, int H, int gx, int gy, const float* __restrict__ cams,
     const float* __restrict__ xyz, const float* __restrict__ log_scale, const float* __restrict__ rot,
     const float* __restrict__ op_logit, const float* __restrict__ f_dc, const float* __restrict__ f_rest,
     const float* __restrict__ skin_w, const float* __restrict__ transforms, MgrGRec* __restrict__ grec,
@@ -266,13 +268,14 @@ __global__ __launch_bounds__(PRE_THREADS) void k_inst_fwd(
         GaussCano g;
         cano_load(xyz, log_scale, rot, i, g);
         float tf[12], p[3], c6[6];
-        blend_tf(skin_w ? skin_w + (size_t)i * B : nullptr, skin_w ? transforms + (size_t)v * B * 16 : nullptr, B, tf);
+        const bool art = skin_w != nullptr && i < n_art;
+        blend_tf(art ? skin_w + (size_t)i * B : nullptr, art ? transforms + (size_t)v * B * 16 : nullptr, B, tf);
         lbs_apply(tf, g, p, c6);
         project_gaussian(cam, W, H, gx, gy, p, c6, po);
         op_i = 1.0f / (1.0f + expf(-op_logit[i]));
         if (po.radius > 0) {  // colour is only consumed by the blend
             ShDir D;
-            if (skin_w) sh_dir_xyz<true>(g.x, g.y, g.z, tf, cam.campos, D);
+            if (art) sh_dir_xyz<true>(g.x, g.y, g.z, tf, cam.campos, D);
             else sh_dir_xyz<false>(g.x, g.y, g.z, tf, cam.campos, D);
             float Y[16], c[48], rgb[3];
             sh_basis(D.d[0] / D.n, D.d[1] / D.n, D.d[2] / D.n, Y);
@@ -1052,7 +1055,7 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, 
 // host entry
 // ---------------------------------------------------------------------------
 struct CanonInputs {  // canonical (un-posed) parameters of the fused articulated path
-    int B;
+    int B, n_art;
     const float *xyz, *log_scale, *rot, *op_logit, *f_dc, *f_rest, *skin_w, *transforms;
 };
 
@@ -1120,7 +1123,7 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
         dim3 grid((N + PRE_THREADS - 1) / PRE_THREADS, V);
         if (canon) {
             MGR_PROF("k_inst_fwd", stream);
-            hipLaunchKernelGGL(k_inst_fwd, grid, dim3(PRE_THREADS), 128 + hist_bytes, stream, N, canon->B, W, H, gx, gy,
+            hipLaunchKernelGGL(k_inst_fwd, grid, dim3(PRE_THREADS), 128 + hist_bytes, stream, N, canon->B, canon->n_art, W, H, gx, gy,
                                cams, canon->xyz, canon->log_scale, canon->rot, canon->op_logit, canon->f_dc,
                                canon->f_rest, canon->skin_w, canon->transforms, (MgrGRec*)(ws + L.grec),
                                (float*)(ws + L.depth), (ushort4*)(ws + L.rect), (unsigned long long*)(ws + L.alive),
@@ -1192,7 +1195,7 @@ extern "C" int mgr_raster_forward(int V, int N, int W, int H, const float* cams,
                                nullptr, out_color, radii, workspace, workspace_bytes, cap, debug, stream_);
 }
 
-extern "C" int mgr_views_forward(int V, int N, int B, int W, int H, const float* cams, const float* bg,
+extern "C" int mgr_views_forward(int V, int N, int B, int n_articulated, int W, int H, const float* cams, const float* bg,
                                  const float* xyz, const float* log_scale, const float* rot,
                                  const float* opacity_logit, const float* f_dc, const float* f_rest,
                                  const float* skin_w, const float* transforms, float* out_color,
@@ -1201,7 +1204,8 @@ extern "C" int mgr_views_forward(int V, int N, int B, int W, int H, const float*
     if (N > 0 && (!xyz || !log_scale || !rot || !opacity_logit || !f_dc || !f_rest || (skin_w && !transforms)))
         return mgr_fail(MGR_EINVAL, "mgr_views_forward: null pointer");
     if (skin_w && (B <= 0 || B > MGR_MAX_BONES)) return mgr_fail(MGR_EINVAL, "mgr_views_forward: bad B");
-    const CanonInputs ci = {B, xyz, log_scale, rot, opacity_logit, f_dc, f_rest, skin_w, transforms};
+    if (skin_w && (n_articulated < 0 || n_articulated > N)) return mgr_fail(MGR_EINVAL, "mgr_views_forward: bad n_articulated");
+    const CanonInputs ci = {B, skin_w ? n_articulated : 0, xyz, log_scale, rot, opacity_logit, f_dc, f_rest, skin_w, transforms};
     return raster_forward_impl(V, N, W, H, cams, bg, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, &ci, out_color,
                                radii, workspace, workspace_bytes, cap, debug, stream_);
 }
@@ -1210,7 +1214,7 @@ extern "C" int mgr_raster_layout(int V, int N, int W, int H, int64_t cap, size_t
     const MgrLayout L = mgr_layout(V, N, W, H, cap);
     const size_t v[] = {L.header, L.grec, L.depth, L.rect, L.alive, L.pair_off, L.tile_count, L.tile_start,
                         L.tile_cursor, L.tile_done, L.tile_queue, L.chunk_start, L.items, L.ckpt, L.keys,
-                        L.sorted_gid, L.final_T, L.n_contrib, L.pair_tag, L.pair_grad, L.total};
+                        L.sorted_gid, L.final_T, L.n_contrib, L.pair_tag, L.pair_grad, L.total, L.inst_grad, L.inst_tag};
     const int n = (int)(sizeof(v) / sizeof(v[0]));
     for (int i = 0; i < n && i < n_out; ++i) out[i] = v[i];
     return n;

@@ -1,5 +1,5 @@
 """Multi-view training step: V views batched per GPU, views sharded across GPUs,
-one all-reduce of the per-Gaussian gradients (RCCL over xGMI via torch.distributed).
+ONE all-reduce of the per-Gaussian gradients per step (RCCL over xGMI via torch.distributed).
 
 The reference trains one (frame, view) per step on one GPU (config/trainer/trainer.yaml:5,
 main.py:84-87 DDP commented out).  "V views per iteration" is defined here as
@@ -9,6 +9,12 @@ and the densification statistics follow the reference's per-view rule
     xyz_gradient_accum += sum_v ||d L_v / d means2D[:, :2]||   (visible Gaussians only)
     denom              += sum_v visible_v
     max_radii2D         = max_v radii_v
+
+Collectives per step: one SUM all-reduce of the flat buffer
+    [ 59 N leaf gradients | N grad2d | N visibility counts | loss | overflow flag ]
+which the backward kernels write in place (no packing copies).  max_radii2D needs a MAX, not a SUM; max is
+associative and idempotent, so every rank keeps the running maximum over ITS views and the ranks are only
+combined (one MAX all-reduce) right before the statistic is consumed, i.e. at a densification step.
 """
 import torch
 import torch.distributed as dist
@@ -17,11 +23,28 @@ import torch.distributed as dist
 GRAD_LAYOUT = (("_xyz", 3), ("_features_dc", 3), ("_features_rest", 45), ("_opacity", 1),
                ("_scaling", 3), ("_rotation", 4))
 GRAD_WIDTH = sum(w for _, w in GRAD_LAYOUT)
+FLAT_TAIL = 2            # loss, overflow flag
+
+
+def flat_size(N):
+    return N * (GRAD_WIDTH + 2) + FLAT_TAIL
 
 
 def shard_views(n_views, rank, world_size):
     """Round-robin assignment of view indices to ranks."""
     return list(range(rank, n_views, world_size))
+
+
+def flat_views(flat, N):
+    """Named views of the flat step buffer: one contiguous segment per leaf (GRAD_LAYOUT order), the two
+    statistics, the loss and the overflow flag."""
+    out, o = {}, 0
+    for name, w in GRAD_LAYOUT:
+        out[name] = flat[o:o + N * w]
+        o += N * w
+    out["grad2d"], out["vis"] = flat[o:o + N], flat[o + N:o + 2 * N]
+    out["loss"], out["overflow"] = flat[o + 2 * N:o + 2 * N + 1], flat[o + 2 * N + 1:o + 2 * N + 2]
+    return out
 
 
 def pack_grads(grads, N, device, out=None):
@@ -46,7 +69,7 @@ def unpack_grads(buf, shapes, N):
 
 
 class ViewShardedStep:
-    """Runs `compute_fn(view_ids)` on this rank's views and reduces across ranks.
+    """Runs `compute_fn(view_ids, scale)` on this rank's views and reduces across ranks.
 
     compute_fn returns a dict with
         grads      {leaf name: scale * sum over the given views of dL_v/dleaf}
@@ -54,7 +77,11 @@ class ViewShardedStep:
         vis        (N,) number of views in which the Gaussian was visible
         radii      (N,) int32 max screen radius over views
         loss       scalar tensor, scale * sum of L_v
-    where compute_fn is called as compute_fn(view_ids, scale).
+        overflow   optional scalar tensor, non-zero when the rasterizer ran out of pair capacity
+    If compute_fn has a `grad_arena` attribute it is handed views of the flat buffer and writes them in place.
+
+    step() returns the reduced grads / grad2d / vis / loss / overflow (sums over all ranks) and the LOCAL radii
+    (max over this rank's views); `reduce_max_radii` combines the ranks when the statistic is consumed.
     """
 
     def __init__(self, n_gaussians, shapes, compute_fn, n_views, rank=0, world_size=1, group=None):
@@ -63,6 +90,18 @@ class ViewShardedStep:
         self.local_views = shard_views(n_views, rank, world_size)
         self.always_pack = False   # tests: take the packing path without a process group
         self._flat = None
+        dev = getattr(compute_fn, "device", None)
+        if dev is not None and (world_size > 1):
+            self._alloc(dev)
+
+    def _alloc(self, dev):
+        self._flat = torch.zeros(flat_size(self.N), dtype=torch.float32, device=dev)
+
+    def reduce_max_radii(self, radii):
+        """MAX over ranks of a per-Gaussian radius statistic (in place; any integer or float dtype)."""
+        if self.world > 1:
+            dist.all_reduce(radii, op=dist.ReduceOp.MAX, group=self.group)
+        return radii
 
     def step(self):
         # compute_fn folds the 1/V of "grad = (1/V) sum_v grad L_v" into the loss scale
@@ -70,42 +109,43 @@ class ViewShardedStep:
         packed = self.world > 1 or self.always_pack
         if packed and self._flat is not None and hasattr(self.compute_fn, "grad_arena"):
             # the backward kernels write straight into the all-reduce buffer (no packing copies): one view per leaf
-            flat, o, arena = self._flat, 0, {}
-            for name, w in GRAD_LAYOUT:
-                arena[name] = flat[o:o + N * w]
-                o += N * w
-            arena["grad2d"], arena["vis"] = flat[o:o + N], flat[o + N:o + 2 * N]
-            self.compute_fn.grad_arena = arena
+            self.compute_fn.grad_arena = flat_views(self._flat, N)
         out = self.compute_fn(self.local_views, 1.0 / float(self.n_views))
         dev = out["grad2d"].device
-        if not packed:
-            return dict(grads=out["grads"], grad2d=out["grad2d"], vis=out["vis"],
-                        radii=out["radii"].to(torch.int32), loss=out["loss"])
-        # one flat buffer -> one SUM all-reduce (+ one MAX all-reduce for the radii)
-        if self._flat is None or self._flat.device != dev:
-            self._flat = torch.empty(N * (GRAD_WIDTH + 2) + 1, dtype=torch.float32, device=dev)
-        flat = self._flat
-        pack_grads(out["grads"], N, dev, out=flat[: N * GRAD_WIDTH])
-        for src, lo in ((out["grad2d"], N * GRAD_WIDTH), (out["vis"], N * (GRAD_WIDTH + 1))):
-            seg = flat[lo: lo + N]
-            if src.data_ptr() != seg.data_ptr():
-                seg.copy_(src)
-        flat[-1:].copy_(out["loss"].reshape(1))
         radii = out["radii"].to(torch.int32)
+        if not packed:
+            return dict(grads=out["grads"], grad2d=out["grad2d"], vis=out["vis"], radii=radii, loss=out["loss"],
+                        overflow=out.get("overflow"))
+        if self._flat is None or self._flat.device != dev:
+            self._alloc(dev)
+        flat = self._flat
+        fv = flat_views(flat, N)
+        pack_grads(out["grads"], N, dev, out=flat[: N * GRAD_WIDTH])
+        for name in ("grad2d", "vis"):
+            if out[name].data_ptr() != fv[name].data_ptr():
+                fv[name].copy_(out[name])
+        fv["loss"].copy_(out["loss"].reshape(1))
+        ovf = out.get("overflow")
+        if ovf is None:
+            fv["overflow"].zero_()
+        else:
+            fv["overflow"].copy_(ovf.reshape(1).to(torch.float32))
         if self.world > 1:
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-            dist.all_reduce(radii, op=dist.ReduceOp.MAX, group=self.group)
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)   # the step's ONE collective
         grads = unpack_grads(flat[: N * GRAD_WIDTH], self.shapes, N)
-        return dict(grads=grads, grad2d=flat[N * GRAD_WIDTH: N * (GRAD_WIDTH + 1)],
-                    vis=flat[N * (GRAD_WIDTH + 1): N * (GRAD_WIDTH + 2)], radii=radii,
-                    loss=flat[-1])
+        return dict(grads=grads, grad2d=fv["grad2d"], vis=fv["vis"], radii=radii, loss=fv["loss"][0],
+                    overflow=fv["overflow"][0])
 
 
 class HipViewCompute:
-    """compute_fn over the HIP kernels: skin weights once, LBS per pose, SH colour and
-    rasterisation per view, L1 image loss (rgb_loss of src/modules/base.py:329-331),
-    backward to the six leaf tensors.  All local views go through every kernel launch
-    together."""
+    """compute_fn over the HIP kernels: skin weights once, LBS per pose, SH colour and rasterisation per view,
+    image loss (rgb_loss / ssim_loss of src/modules/base.py:323-365), backward to the six leaf tensors.  All local
+    views go through every kernel launch together.
+
+    scene["kind"]: "hand" (every Gaussian skinned, hand_dynamic.py:86-137), "object" (static, object.py:32-41) or
+    "composite" (the first scene["n_hand"] Gaussians skinned, the rest static with the identity transform,
+    composite.py:50-59).  fused=True runs the fused kernels through direct C-ABI calls (no autograd graph); fused=False
+    the modular operators under autograd (the reference-shaped path)."""
 
     def __init__(self, scene, targets, cam_table, loss_weight=1.0, fused=True, loss="l1", w_rgb=0.8, w_ssim=0.2):
         from . import fused as fused_mod, ops, rasterizer
@@ -119,11 +159,25 @@ class HipViewCompute:
         if loss not in ("l1", "l1+ssim"):
             raise ValueError("loss must be 'l1' or 'l1+ssim'")
         self.loss, self.w_rgb, self.w_ssim = loss, w_rgb, w_ssim
-        self.is_hand = scene.get("grid") is not None and scene["kind"] == "hand"
+        self.kind = scene["kind"]
         self.params = {k: v.detach().clone().requires_grad_(True) for k, v in scene["params"].items()}
+        N = self.params["_xyz"].shape[0]
+        has_grid = scene.get("grid") is not None
+        self.n_art = N if (self.kind == "hand" and has_grid) else (int(scene["n_hand"]) if (self.kind == "composite" and has_grid) else 0)
+        self.is_hand = self.n_art > 0
+        self.device = self.params["_xyz"].device
         self.grad_arena = None   # set by ViewShardedStep: preallocated gradient outputs (fused path only)
         self._cache = {}
         self.grid = ops.SkinGrid(scene["grid"], scene["grid"].device) if self.is_hand else None
+
+    def set_params(self, params, n_art=None):
+        """Re-point at new leaf tensors (after densification / pruning changed N)."""
+        self.params = {k: v.detach().requires_grad_(True) for k, v in params.items()}
+        if n_art is not None:
+            self.n_art = int(n_art)
+        elif self.kind == "hand" and self.is_hand:
+            self.n_art = self.params["_xyz"].shape[0]
+        self.grad_arena = None
 
     def _select(self, view_ids):
         """Per-view constants for a set of views (cached: no per-step gather copies)."""
@@ -136,6 +190,25 @@ class HipViewCompute:
             self._cache = {key: c}
         return c
 
+    # -- modular, reference-shaped path (autograd) -------------------------------------------------
+    def _posed(self, T):
+        """posed means / covariances / transforms of all Gaussians for the poses T (P,B,4,4): LBS for the first
+        n_art rows, identity for the rest."""
+        p, ops = self.params, self.ops
+        N, na = p["_xyz"].shape[0], self.n_art
+        if na == 0:
+            _, pcov1, _ = ops.lbs_cov(p["_xyz"], p["_scaling"], p["_rotation"], None, None)
+            return p["_xyz"], pcov1[0], None
+        w = ops.skin_weights(p["_xyz"][:na], self.grid, self.s["grid_center"], self.s["grid_scale"])
+        pxyz, pcov, tf = ops.lbs_cov(p["_xyz"][:na], p["_scaling"][:na], p["_rotation"][:na], w, T)
+        if na < N:   # composite.py:50-59: concat, identity tf for the object
+            P = T.shape[0]
+            _, ocov, otf = ops.lbs_cov(p["_xyz"][na:], p["_scaling"][na:], p["_rotation"][na:], None, None)
+            pxyz = torch.cat([pxyz, p["_xyz"][na:][None].expand(P, -1, -1)], dim=1)
+            pcov = torch.cat([pcov, ocov.expand(P, -1, -1)], dim=1)
+            tf = torch.cat([tf, otf.expand(P, -1, -1)], dim=1)
+        return pxyz, pcov, tf
+
     def forward_views(self, view_ids):
         s, p, ops = self.s, self.params, self.ops
         sel = self._select(view_ids)
@@ -143,24 +216,19 @@ class HipViewCompute:
         V = len(view_ids)
         feats = torch.cat([p["_features_dc"], p["_features_rest"]], dim=1)
         opac = torch.sigmoid(p["_opacity"])
-        if self.is_hand:
-            w = ops.skin_weights(p["_xyz"], self.grid, s["grid_center"], s["grid_scale"])
-            # one pose per view (the reference trains one (frame, view) per step)
-            pxyz, pcov, tf = ops.lbs_cov(p["_xyz"], p["_scaling"], p["_rotation"], w, sel["T"])
-            col = ops.sh_colors(feats, p["_xyz"], tf, cams)
-        else:
-            _, pcov1, _ = ops.lbs_cov(p["_xyz"], p["_scaling"], p["_rotation"], None, None)
-            pxyz, pcov = p["_xyz"], pcov1[0]
-            col = ops.sh_colors(feats, p["_xyz"], None, cams)
+        pxyz, pcov, tf = self._posed(sel["T"])   # one pose per view (the reference trains one (frame, view) per step)
+        col = ops.sh_colors(feats, p["_xyz"], tf, cams)
         N = p["_xyz"].shape[0]
         means2D = torch.zeros((V, N, 3), dtype=torch.float32, device=cams.device, requires_grad=True)
         img, radii = self.rz.rasterize_views(cams, pxyz, means2D, col, opac, pcov, s["bg"], s["width"], s["height"])
         return img, radii, means2D
 
     def forward_views_fused(self, view_ids, stats=None, grad2d_scale=1.0):
+        """The fused kernels behind the autograd node `fused.render_views`."""
         s, p, ops = self.s, self.params, self.ops
         sel = self._select(view_ids)
-        w = ops.skin_weights(p["_xyz"], self.grid, s["grid_center"], s["grid_scale"]) if self.is_hand else None
+        na = self.n_art
+        w = ops.skin_weights(p["_xyz"][:na], self.grid, s["grid_center"], s["grid_scale"]) if na else None
         return self.fz.render_views(p["_xyz"], p["_scaling"], p["_rotation"], p["_opacity"], p["_features_dc"],
                                     p["_features_rest"], w, sel["T"], sel["cams"], s["bg"], s["width"], s["height"],
                                     stats=stats, grad2d_scale=grad2d_scale, grad_arena=self.grad_arena)
@@ -176,20 +244,78 @@ class HipViewCompute:
         sums, g = self.ops.image_loss_grad(img, tgt, self.w_rgb, self.w_ssim, k, const)
         return sums[2], g
 
-    def _call_fused(self, view_ids, scale):
-        for v in self.params.values():
-            v.grad = None
-        stats = self.fz.ViewStats()
-        img, radii = self.forward_views_fused(view_ids, stats, 1.0 / scale)
-        tgt = self._select(view_ids)["targets"]
-        loss, g = self._image_loss(img, tgt, scale)
-        img.backward(g)
-        return dict(grads={n: v.grad for n, v in self.params.items()}, grad2d=stats.grad2d, vis=stats.vis,
-                    radii=stats.radii, loss=loss)
+    # -- fused path, direct C-ABI calls ------------------------------------------------------------
+    def _step_direct(self, view_ids, scale, g_img=None):
+        """skin weights -> mgr_views_forward -> image loss -> mgr_views_backward -> skin-weight backward, every
+        gradient written straight into the arena (the all-reduce buffer) when one is set.  g_img: optional dL/dimage
+        (V,3,H,W) used instead of the image loss (parity tests)."""
+        from ._lib import check, lib, ptr, stream
+        s, p = self.s, {k: v.detach() for k, v in self.params.items()}
+        sel = self._select(view_ids)
+        cams, T = sel["cams"], sel["T"]
+        dev = self.device
+        N, na, V = p["_xyz"].shape[0], self.n_art, len(view_ids)
+        W, H = int(s["width"]), int(s["height"])
+        arena = self.grad_arena or {}
+
+        def e(shape, name):
+            t = arena.get(name)
+            n = 1
+            for d in shape:
+                n *= d
+            if t is not None and t.numel() == n and t.is_contiguous() and t.dtype == torch.float32 and t.device == dev:
+                return t.view(shape)
+            return torch.empty(shape, dtype=torch.float32, device=dev)
+
+        sg, B, w = self.grid, 0, None
+        if na:
+            B = sg.B
+            w = torch.empty((na, B), dtype=torch.float32, device=dev)
+            check(lib().mgr_skin_weights_fwd(na, ptr(p["_xyz"]), ptr(sg.data), sg.D, sg.H, sg.W, sg.B, sg.stride,
+                                             ptr(s["grid_center"]), ptr(s["grid_scale"]), ptr(w), stream()),
+                  "mgr_skin_weights_fwd")
+        out = torch.empty((V, 3, H, W), dtype=torch.float32, device=dev)
+        radii = torch.empty((V, N), dtype=torch.int32, device=dev)
+        op = p["_opacity"].reshape(-1)
+        bg = s["bg"]
+
+        def launch(ws):
+            check(lib().mgr_views_forward(V, N, B, na, W, H, ptr(cams), ptr(bg), ptr(p["_xyz"]), ptr(p["_scaling"]),
+                                          ptr(p["_rotation"]), ptr(op), ptr(p["_features_dc"]), ptr(p["_features_rest"]),
+                                          ptr(w), ptr(T), ptr(out), ptr(radii), ptr(ws.buf), ws.nbytes, ws.cap, 0,
+                                          stream()), "mgr_views_forward")
+
+        ws, _ = self.rz.context(dev).forward(V, N, W, H, launch)
+        try:
+            if g_img is None:
+                loss, g_img = self._image_loss(out, sel["targets"], scale)
+            else:
+                loss, g_img = (out * g_img).sum(), g_img.contiguous()
+            d_xyz, d_ls, d_rot = e((N, 3), "_xyz"), e((N, 3), "_scaling"), e((N, 4), "_rotation")
+            d_op, d_fdc, d_frest = e((N, 1), "_opacity"), e((N, 1, 3), "_features_dc"), e((N, 15, 3), "_features_rest")
+            st_g, st_v = e((N,), "grad2d"), e((N,), "vis")
+            st_r = torch.empty(N, dtype=torch.int32, device=dev)
+            d_w = torch.empty((na, B), dtype=torch.float32, device=dev) if na else None
+            check(lib().mgr_views_backward(V, N, B, na, W, H, ptr(cams), ptr(bg), ptr(p["_xyz"]), ptr(p["_scaling"]),
+                                           ptr(p["_rotation"]), ptr(op), ptr(p["_features_dc"]), ptr(p["_features_rest"]),
+                                           ptr(w), ptr(T), ptr(radii), ptr(out), ptr(g_img), 1.0 / scale, ptr(d_xyz),
+                                           ptr(d_ls), ptr(d_rot), ptr(d_op), ptr(d_fdc), ptr(d_frest), ptr(d_w), ptr(st_g),
+                                           ptr(st_v), ptr(st_r), ptr(ws.buf), ws.nbytes, ws.cap, 0, stream()),
+                  "mgr_views_backward")
+            if na:   # d xyz += d w . d(trilinear weights)/d xyz  (the leaf is used twice: gaussian_utils.py:167-196)
+                check(lib().mgr_skin_weights_bwd(na, ptr(p["_xyz"]), ptr(sg.data), sg.D, sg.H, sg.W, sg.B, sg.stride,
+                                                 ptr(s["grid_center"]), ptr(s["grid_scale"]), ptr(d_w), ptr(d_xyz), 1,
+                                                 stream()), "mgr_skin_weights_bwd")
+            overflow = ws.buf[4:8].view(torch.int32)
+        finally:
+            ws.busy = False
+        self.last_image, self.last_radii = out, radii
+        return dict(grads={"_xyz": d_xyz, "_scaling": d_ls, "_rotation": d_rot, "_opacity": d_op, "_features_dc": d_fdc,
+                           "_features_rest": d_frest}, grad2d=st_g, vis=st_v, radii=st_r, loss=loss, overflow=overflow)
 
     def __call__(self, view_ids, scale=1.0):
         if self.fused:
-            return self._call_fused(view_ids, scale)
+            return self._step_direct(view_ids, scale)
         for v in self.params.values():
             v.grad = None
         img, radii, means2D = self.forward_views(view_ids)
@@ -202,21 +328,58 @@ class HipViewCompute:
                     grad2d=(g2 * vis).sum(0), vis=vis.sum(0).float(),
                     radii=radii.max(dim=0).values, loss=loss)
 
+    # -- inputs of the pruning tests (on_after_backward) ---------------------------------------------
+    def prune_views(self, view_ids):
+        """One dict per view for `density.DensityController`: camera (K, extr), mask, posed means of the view's
+        pose and its keypoints.  Views without a mask / keypoints in the scene are skipped by the controller."""
+        s = self.s
+        with torch.no_grad():
+            if self.is_hand:
+                pxyz, _, _ = self._posed(self._select(view_ids)["T"])
+            else:
+                pxyz = None
+        out = []
+        masks, keyp = s.get("masks"), s.get("keypoints")
+        for k, v in enumerate(view_ids):
+            out.append(dict(camera=s["cameras"][v], mask=masks[v] if masks is not None else None,
+                            posed_xyz=(pxyz[k, : self.n_art] if pxyz is not None else self.params["_xyz"].detach()),
+                            keypoints=keyp[v] if keyp is not None else None))
+        return out
+
 
 class Trainer:
-    """The per-step control flow of the reference's training_step (src/modules/hand_dynamic.py:230-282) on top of
-    the kernels: multi-view step -> fused Adam step with the xyz schedule -> density_update (statistics, densify /
-    prune every `densification_interval` steps, opacity reset).  After a densification the parameter tensors are
-    new (different N): the compute object is re-pointed at them and the rasterizer workspaces of the old size are
-    released.  Multi-GPU: every rank must draw the same split noise, so rank 0's is broadcast."""
+    """One optimisation step in the reference's order (src/modules/hand_dynamic.py:230-282 + Lightning's hooks):
+
+        training_step      render the views, loss, backward (+ the all-reduce)                at global_step g
+        on_after_backward  pruning tests + density_update(g)   hand_dynamic.py:193-224 / object.py:66-81
+        on_before_optimizer_step   xyz learning rate = schedule(g)   hand_dynamic.py:226-228
+        optimizer.step()   Adam; leaves that density_update has just replaced carry no gradient and are skipped
+        global_step += 1
+
+    After a densification / pruning the parameter tensors are new (different N): the compute object is re-pointed
+    at them and the rasterizer workspaces of the old size are released.  The rasterizer runs without host
+    synchronisation; every step is fenced (`rasterizer.poll`: waits for the forward only) and re-run with a larger
+    pair capacity if it overflowed, so no update is ever made from a truncated image.
+    Multi-GPU: every rank must draw the same split noise, so rank 0's is broadcast; the pruning masks are OR-ed
+    over the ranks; max_radii2D is MAX-reduced before it is consumed."""
 
     def __init__(self, compute, n_views, extent, opts=None, spatial_lr_scale=1.0, rank=0, world_size=1, group=None,
-                 bg_white=True):
+                 bg_white=True, kind=None):
+        from . import rasterizer
+        from .density import DensityController
         from .optim import GaussianOptimizer
+        global ALL_GROUPS
+        from .optim import ALL_GROUPS
         self.compute, self.n_views, self.extent, self.bg_white = compute, n_views, float(extent), bg_white
         self.rank, self.world, self.group = rank, world_size, group
         self.opt = GaussianOptimizer(compute.params, opts=opts, spatial_lr_scale=spatial_lr_scale, adopt=True)
+        kind = kind or ("object" if getattr(compute, "kind", "hand") == "object" else "hand")
+        self.density = DensityController(self.opt, extent, kind=kind, bg_white=bg_white)
         self.global_step = 0
+        self.retries = 0
+        self._rz = rasterizer
+        if getattr(compute, "fused", False) and torch.cuda.is_available():
+            rasterizer.set_sync_policy(False, getattr(compute, "device", None))
         self._rebuild_step()
 
     def _rebuild_step(self):
@@ -227,49 +390,81 @@ class Trainer:
         self.stepper = ViewShardedStep(p["_xyz"].shape[0], shapes, self.compute, self.n_views, rank=self.rank,
                                        world_size=self.world, group=self.group)
 
-    def _split_noise(self, n_sel, device):
-        noise = torch.randn((2 * n_sel, 3), dtype=torch.float32, device=device)
+    def _split_noise(self, n_rows, device):
+        noise = torch.randn((2 * n_rows, 3), dtype=torch.float32, device=device)
         if self.world > 1:
             dist.broadcast(noise, src=0, group=self.group)
         return noise
 
-    def train_step(self):
-        """One optimisation step; returns the step's output dict (loss, statistics) plus "changed"."""
-        from . import rasterizer
-        out = self.stepper.step()
-        self.global_step += 1
-        self.opt.update_learning_rate(self.global_step)
-        self.opt.step(out["grads"])
-        o = self.opt.opts
-        changed = False
-        gs = self.global_step
-        if gs < o["densify_until_step"]:
-            self.opt.add_densification_stats(out["grad2d"], out["vis"], out["radii"])
-            if gs > o["densify_from_step"] and gs % o["densification_interval"] == 0:
-                size_threshold = o["size_threshold"] if gs > o["opacity_reset_interval"] else None
-                # the plan's selection count is needed before the noise can be drawn: densify_and_prune draws it
-                # itself on one GPU; with several ranks it is drawn here for the worst case and broadcast
-                noise = None
-                if self.world > 1:
-                    noise_full = self._split_noise(self.opt.N, self.opt.device)
-                    noise = noise_full
-                info = self._densify(o, size_threshold, noise)
-                changed = True
-                out["densify"] = info
-            if gs % o["opacity_reset_interval"] == 0 or (self.bg_white and gs == o["densify_from_step"]):
-                self.opt.reset_opacity()
+    def _run_step(self):
+        """Forward + backward (+ all-reduce) with the overflow fence; re-runs the step after an overflow."""
+        for _ in range(4):
+            out = self.stepper.step()
+            local_bad = False
+            if torch.cuda.is_available() and getattr(self.compute, "fused", False):
+                try:
+                    self._rz.poll(getattr(self.compute, "device", None))
+                except RuntimeError:
+                    local_bad = True
+            bad = local_bad
+            if self.world > 1 and out.get("overflow") is not None:
+                bad = float(out["overflow"]) > 0.0     # summed over the ranks by the all-reduce: the same on all of them
+            if not bad:
+                return out
+            self.retries += 1
+        raise RuntimeError("rasterizer pair capacity still exceeded after 4 attempts")
+
+    def train_step(self, views=None):
+        """One optimisation step; returns the step's output dict (loss, statistics) plus "changed".
+        views: optional list of per-view dicts for the pruning tests (default: `compute.prune_views`)."""
+        o, gs = self.opt.opts, self.global_step
+        out = self._run_step()
+        # ---- on_after_backward ----
+        needs_tests = self.density.kind == "hand" and (gs < o["remove_seg_end"] or gs % 100 == 0) or \
+            self.density.kind == "object" and gs < o["remove_seg_end"]
+        if views is None and needs_tests and hasattr(self.compute, "prune_views"):
+            views = self.compute.prune_views(self.stepper.local_views)
+        mask = self.density.prune_mask(gs, views) if needs_tests else None
+        if self.world > 1 and needs_tests:   # every rank tested its own views: OR them
+            m8 = (mask if mask is not None else torch.zeros(self.opt.N, dtype=torch.bool, device=self.opt.device)).to(torch.uint8)
+            dist.all_reduce(m8, op=dist.ReduceOp.MAX, group=self.group)
+            mask = m8.bool() if bool(m8.any()) else None
+        will_densify = mask is None and gs < o["densify_until_step"] and gs > o["densify_from_step"] and \
+            gs % o["densification_interval"] == 0
+        stats = dict(grad2d=out["grad2d"], vis=out["vis"], radii=out["radii"])
+        noise = None
+        if will_densify and self.world > 1:
+            # the selection count is only known inside the plan: draw the worst case on rank 0 and broadcast
+            noise = self._split_noise(self.opt.N, self.opt.device)
+        n_before = self.opt.N
+        if mask is not None:
+            changed = self.opt.density_update(stats, self.extent, gs, self.bg_white, mask_to_prune=mask)
+        else:
+            if will_densify and self.world > 1:
+                # max_radii2D is a running maximum over this rank's views; combine the ranks before it is consumed
+                self.opt.add_densification_stats(out["grad2d"], out["vis"], out["radii"])
+                self.stepper.reduce_max_radii(self.opt.max_radii2D)
+                stats = dict(grad2d=torch.zeros_like(out["grad2d"]), vis=torch.zeros_like(out["vis"]),
+                             radii=torch.zeros_like(out["radii"]))
+            changed = self.opt.density_update(stats, self.extent, gs, self.bg_white, noise=noise,
+                                              noise_is_pool=noise is not None)
         if changed:
-            self.compute.params = {k: v.detach().requires_grad_(True) for k, v in self.opt.parameters().items()}
+            self.density.on_train_epoch_start()
+        resized = changed and (self.opt.N != n_before or self.opt.replaced == ALL_GROUPS)   # new leaf tensors
+        # ---- on_before_optimizer_step + optimizer.step() ----
+        self.opt.update_learning_rate(gs)
+        self.opt.step(out["grads"])       # skips the groups replaced above (all of them after a densify / prune)
+        self.global_step += 1
+        if resized:
+            n_art = None
+            if getattr(self.compute, "kind", "hand") == "composite":
+                raise RuntimeError("Trainer: densifying a composite scene is not supported (the reference optimises one model)")
+            self.compute.set_params(self.opt.parameters(), n_art)
             self.opt.p = {k: v.detach() for k, v in self.compute.params.items()}
-            rasterizer._POOL.clear()
-            rasterizer.set_sync_policy(True)   # the pair capacity of the new size has to be learnt again
+            if torch.cuda.is_available():
+                self._rz.context(getattr(self.compute, "device", None)).clear()
             self._rebuild_step()
         out["changed"] = changed
+        if changed and getattr(self.opt, "last_densify", None) is not None and will_densify:
+            out["densify"] = self.opt.last_densify
         return out
-
-    def _densify(self, o, size_threshold, noise_full):
-        if noise_full is None:
-            return self.opt.densify_and_prune(o["densify_grad_threshold"], o["min_opacity_threshold"], self.extent,
-                                              size_threshold)
-        return self.opt.densify_and_prune(o["densify_grad_threshold"], o["min_opacity_threshold"], self.extent,
-                                          size_threshold, noise=noise_full, noise_is_pool=True)

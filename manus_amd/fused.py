@@ -28,42 +28,32 @@ class _RenderViews(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xyz, log_scale, rot, opacity, f_dc, f_rest, skin_w, transforms, cams, bg, W, H, stats,
                 grad2d_scale, grad_arena=None):
+        # skin_w may cover only the first rows (hand + object composite): the rest are static
         xyz, log_scale, rot = f32c(xyz), f32c(log_scale), f32c(rot)
         opacity, f_dc, f_rest = f32c(opacity).reshape(-1), f32c(f_dc), f32c(f_rest)
         N, V = xyz.shape[0], cams.shape[0]
-        B = 0
+        B = n_art = 0
         if skin_w is not None:
             skin_w, transforms = f32c(skin_w), f32c(transforms)
-            B = skin_w.shape[1]
+            n_art, B = skin_w.shape
+            if n_art > N:
+                raise _rz._lib.ManusHipError("render_views: more skin-weight rows than Gaussians")
             if transforms.shape[0] != V or transforms.shape[1] != B:
                 raise _rz._lib.ManusHipError("render_views: transforms must be (V,B,4,4), one pose per view")
         bg = f32c(bg).reshape(-1)
         dev = xyz.device
-        key = (str(dev), V, N, W, H)
         out = torch.empty((V, 3, H, W), dtype=torch.float32, device=dev)
         radii = torch.empty((V, N), dtype=torch.int32, device=dev)
-        cap = max(_rz._CAP_HINT.get(key, 0), _rz.default_pair_capacity(V, N))
-        while True:
-            ws = _rz._POOL.acquire(dev, V, N, W, H, cap)
-            check(lib().mgr_views_forward(V, N, B, W, H, ptr(cams), ptr(bg), ptr(xyz), ptr(log_scale), ptr(rot),
+
+        def launch(ws):
+            check(lib().mgr_views_forward(V, N, B, n_art, W, H, ptr(cams), ptr(bg), ptr(xyz), ptr(log_scale), ptr(rot),
                                           ptr(opacity), ptr(f_dc), ptr(f_rest), ptr(skin_w), ptr(transforms),
                                           ptr(out), ptr(radii), ptr(ws.buf), ws.nbytes, ws.cap, 0, stream()),
                   "mgr_views_forward")
-            _rz._LAST_WS["ws"] = ws
-            if not _rz._POLICY["sync_every_forward"]:
-                break
-            import ctypes
-            npairs, ovf = ctypes.c_int64(0), ctypes.c_int32(0)
-            rc = lib().mgr_raster_status_sync(ptr(ws.buf), ctypes.byref(npairs), ctypes.byref(ovf), stream())
-            if rc == 0:
-                _rz._CAP_HINT[key] = max(_rz._CAP_HINT.get(key, 0), int(npairs.value * 1.25) + 4096)
-                break
-            if rc != -4:
-                check(rc, "mgr_raster_status_sync")
-            ws.busy = False
-            cap = int(npairs.value * 1.5) + 4096
+
+        ws, _ = _rz.context(dev).forward(V, N, W, H, launch)
         ctx.lease = _rz._Lease(ws)
-        ctx.meta = (V, N, B, W, H, stats, float(grad2d_scale))
+        ctx.meta = (V, N, B, n_art, W, H, stats, float(grad2d_scale))
         ctx.arena = grad_arena
         ctx.save_for_backward(xyz, log_scale, rot, opacity, f_dc, f_rest, skin_w, transforms, cams, bg, out, radii)
         ctx.mark_non_differentiable(radii)
@@ -72,7 +62,7 @@ class _RenderViews(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_img, _g_radii):
         xyz, log_scale, rot, opacity, f_dc, f_rest, skin_w, transforms, cams, bg, out, radii = ctx.saved_tensors
-        V, N, B, W, H, stats, g2s = ctx.meta
+        V, N, B, n_art, W, H, stats, g2s = ctx.meta
         ws = ctx.lease.ws
         dev = xyz.device
         g_img = f32c(g_img)
@@ -88,10 +78,10 @@ class _RenderViews(torch.autograd.Function):
 
         d_xyz, d_ls, d_rot, d_op = e(N, 3), e(N, 3, name="_scaling"), e(N, 4, name="_rotation"), e(N, name="_opacity")
         d_fdc, d_frest = e(N, 1, 3, name="_features_dc"), e(N, 15, 3, name="_features_rest")
-        d_w = e(N, B) if skin_w is not None else None
+        d_w = e(n_art, B) if skin_w is not None else None
         st_g, st_v = (e(N, name="grad2d"), e(N, name="vis")) if stats is not None else (None, None)
         st_r = torch.empty(N, dtype=torch.int32, device=dev) if stats is not None else None
-        check(lib().mgr_views_backward(V, N, B, W, H, ptr(cams), ptr(bg), ptr(xyz), ptr(log_scale), ptr(rot),
+        check(lib().mgr_views_backward(V, N, B, n_art, W, H, ptr(cams), ptr(bg), ptr(xyz), ptr(log_scale), ptr(rot),
                                        ptr(opacity), ptr(f_dc), ptr(f_rest), ptr(skin_w), ptr(transforms),
                                        ptr(radii), ptr(out), ptr(g_img), g2s, ptr(d_xyz), ptr(d_ls), ptr(d_rot),
                                        ptr(d_op), ptr(d_fdc), ptr(d_frest), ptr(d_w), ptr(st_g), ptr(st_v),
@@ -108,8 +98,9 @@ def render_views(xyz, log_scale, rot, opacity_logit, f_dc, f_rest, skin_w, trans
     """Images (V,3,H,W) and radii (V,N) of V views from the canonical parameters.
 
     xyz (N,3) `_xyz`; log_scale (N,3) `_scaling`; rot (N,4) `_rotation`; opacity_logit (N,1)
-    `_opacity`; f_dc (N,1,3); f_rest (N,15,3); skin_w (N,B) from `ops.skin_weights` or None for a
-    static object; transforms (V,B,4,4): posed @ inv(rest) (+ identity) of the pose seen by each
+    `_opacity`; f_dc (N,1,3); f_rest (N,15,3); skin_w (N,B) from `ops.skin_weights`, None for a
+    static object, or (n_hand,B) with n_hand < N for the hand+object composite (composite.py:50-59:
+    the first n_hand Gaussians are skinned, the rest keep the identity transform); transforms (V,B,4,4): posed @ inv(rest) (+ identity) of the pose seen by each
     view; cams (V,40).  `stats` (a ViewStats) receives the densification statistics in backward.
     `grad_arena`: optional {leaf name | "grad2d" | "vis": preallocated fp32 tensor}; the backward kernels write those
     outputs there instead of into fresh tensors (the multi-GPU step passes segments of its all-reduce buffer)."""

@@ -59,7 +59,7 @@ class _SkinWeights(torch.autograd.Function):
         g_w = f32c(g_w)
         g_xyz = torch.empty((N, 3), dtype=torch.float32, device=xyz.device)
         check(lib().mgr_skin_weights_bwd(N, ptr(xyz), ptr(sg.data), sg.D, sg.H, sg.W, sg.B, sg.stride, ptr(center),
-                                         ptr(scale), ptr(g_w), ptr(g_xyz), stream()), "mgr_skin_weights_bwd")
+                                         ptr(scale), ptr(g_w), ptr(g_xyz), 0, stream()), "mgr_skin_weights_bwd")
         return g_xyz, None, None, None
 
 

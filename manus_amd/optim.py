@@ -5,10 +5,12 @@ Mirrors the training-side half of `GaussianModel` (brown-ivl/manus, src/models/g
 
     training_setup          :128-146   six Adam groups (xyz, f_dc, f_rest, opacity, scaling, rotation), eps=1e-15
     update_learning_rate    src/utils/gaussian_utils.py:501-508 + get_expon_lr_func :212-245 (xyz schedule)
-    optimizer.step()        one fused kernel over all six groups
+    optimizer.step()        one fused kernel over all six groups (per-group step counts, like Adam's state["step"])
     add_densification_stats :335-338   (+ the max_radii2D update of density_update, gaussian_utils.py:470-473)
     densify_and_prune       :310-333   clone + split + prune + Adam-moment surgery: plan + apply kernels
+    prune_points            :185-203   compaction of leaves, moments, skin weights and statistics by a mask
     reset_opacity           :148-165
+    density_update          src/utils/gaussian_utils.py:451-498 (incl. the mask_to_prune branch)
 
 The leaves keep the reference's names and shapes (`_xyz (N,3)`, `_features_dc (N,1,3)`,
 `_features_rest (N,15,3)`, `_opacity (N,1)`, `_scaling (N,3)`, `_rotation (N,4)`).  GPU tensors only;
@@ -30,7 +32,10 @@ DEFAULT_OPTS = dict(  # config/model/gaussian/gaussian.yaml
     position_lr_init=0.0016, position_lr_final=0.0000016, position_lr_delay_mult=0.01, position_lr_max_steps=30000,
     feature_lr=0.0025, opacity_lr=0.05, scaling_lr=0.005, rotation_lr=0.001, percent_dense=0.000001,
     densification_interval=100, opacity_reset_interval=3000, densify_from_step=100, densify_until_step=50000,
-    densify_grad_threshold=0.0002, min_opacity_threshold=0.005, size_threshold=20)
+    densify_grad_threshold=0.0002, min_opacity_threshold=0.005, size_threshold=20, remove_outliers_step=-1,
+    remove_seg_end=1000)
+
+ALL_GROUPS = frozenset(n for n, _, _ in GROUPS)
 
 
 def get_expon_lr_func(lr_init, lr_final, lr_delay_steps=0, lr_delay_mult=1.0, max_steps=1000000):
@@ -49,7 +54,7 @@ def get_expon_lr_func(lr_init, lr_final, lr_delay_steps=0, lr_delay_mult=1.0, ma
 
 
 def _ptr_array(tensors):
-    return (ctypes.c_void_p * len(tensors))(*[ptr(t) for t in tensors])
+    return (ctypes.c_void_p * len(tensors))(*[ptr(t) if t is not None else None for t in tensors])
 
 
 class GaussianOptimizer:
@@ -74,7 +79,10 @@ class GaussianOptimizer:
         o, dev = self.opts, self.device
         self.m = {a: torch.zeros_like(self.p[a]) for _, a, _ in GROUPS}
         self.v = {a: torch.zeros_like(self.p[a]) for _, a, _ in GROUPS}
-        self.state_step = 0                                 # steps taken (shared by the six groups)
+        # steps taken per group: torch.optim.Adam keeps state["step"] per parameter, and a group whose leaf was
+        # replaced before optimizer.step() (reset_opacity at densify_from_step, :153-165) misses that step
+        self.group_step = {n: 0 for n, _, _ in GROUPS}
+        self.replaced = frozenset()                         # groups replaced since the last step() (no gradient yet)
         self.lr = {"xyz": o["position_lr_init"] * self.spatial_lr_scale, "f_dc": o["feature_lr"],
                    "f_rest": o["feature_lr"] / 20.0, "opacity": o["opacity_lr"], "scaling": o["scaling_lr"],
                    "rotation": o["rotation_lr"]}
@@ -98,6 +106,14 @@ class GaussianOptimizer:
     def device(self):
         return self.p["_xyz"].device
 
+    @property
+    def state_step(self):
+        return max(self.group_step.values())
+
+    @state_step.setter
+    def state_step(self, t):
+        self.group_step = {n: int(t) for n, _, _ in GROUPS}
+
     def parameters(self):
         """The six leaves by the reference's attribute names (live tensors, updated in place by step())."""
         return self.p
@@ -108,19 +124,30 @@ class GaussianOptimizer:
         return self.lr["xyz"]
 
     # -- optimizer.step() ---------------------------------------------------------------------
-    def step(self, grads, beta1=0.9, beta2=0.999, eps=1e-15):
-        """One Adam update of all six groups from `grads` {attribute name: tensor of the leaf's shape}."""
-        g = [f32c(grads[a]) for _, a, _ in GROUPS]
-        for (_, a, _), t in zip(GROUPS, g):
-            if t.numel() != self.p[a].numel():
+    def step(self, grads, beta1=0.9, beta2=0.999, eps=1e-15, skip=None):
+        """One Adam update from `grads` {attribute name: tensor of the leaf's shape}.  `skip`: group names left
+        untouched (default: the groups replaced since the last step -- the reference's optimizer.step() runs after
+        on_after_backward and skips a new nn.Parameter, which has no .grad; hand_dynamic.py:193-224,269-277)."""
+        skip = self.replaced if skip is None else frozenset(skip)
+        self.replaced = frozenset()
+        active = [(n, a) for n, a, _ in GROUPS if n not in skip]
+        if not active:
+            return
+        g = {a: f32c(grads[a]) for _, a in active}
+        for _, a in active:
+            if g[a].numel() != self.p[a].numel():
                 raise ManusHipError("step: gradient of %s has the wrong size" % a)
-        self.state_step += 1
+        for n, _ in active:
+            self.group_step[n] += 1
+        on = {n for n, _ in active}
         counts = (ctypes.c_int64 * 6)(*[self.p[a].numel() for _, a, _ in GROUPS])
         lrs = (ctypes.c_double * 6)(*[self.lr[n] for n, _, _ in GROUPS])
-        check(lib().mgr_adam_step(6, counts, _ptr_array([self.p[a] for _, a, _ in GROUPS]), _ptr_array(g),
-                                  _ptr_array([self.m[a] for _, a, _ in GROUPS]),
-                                  _ptr_array([self.v[a] for _, a, _ in GROUPS]), lrs, self.state_step, beta1, beta2, eps,
-                                  stream()), "mgr_adam_step")
+        steps = (ctypes.c_int64 * 6)(*[self.group_step[n] if n in on else 0 for n, _, _ in GROUPS])
+        check(lib().mgr_adam_step_groups(6, counts, _ptr_array([self.p[a] for _, a, _ in GROUPS]),
+                                         _ptr_array([g.get(a) for _, a, _ in GROUPS]),
+                                         _ptr_array([self.m[a] for _, a, _ in GROUPS]),
+                                         _ptr_array([self.v[a] for _, a, _ in GROUPS]), lrs, steps, beta1, beta2, eps,
+                                         stream()), "mgr_adam_step_groups")
 
     # -- add_densification_stats (+ max radii), gaussian.py:335-338, gaussian_utils.py:470-473 -
     def add_densification_stats(self, grad2d_sum, vis_count, radii_max):
@@ -131,21 +158,29 @@ class GaussianOptimizer:
         self.max_radii2D = torch.maximum(self.max_radii2D, radii_max.to(torch.float32))
 
     # -- densify_and_prune, gaussian.py:310-333 ------------------------------------------------
-    def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size=None, noise=None, noise_is_pool=False):
+    def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size=None, remove_outliers=False, noise=None,
+                          noise_is_pool=False):
         """Clone / split / prune exactly like the reference, including the order of the surviving rows and the
-        zero Adam moments of new rows.  `max_screen_size` is accepted for signature parity; in the reference it
-        cannot prune anything (max_radii2D is zeroed by densification_postfix before it is read, :249-251,316-318).
+        zero Adam moments of new rows.  `max_screen_size` falsy (None before `opacity_reset_interval`,
+        gaussian_utils.py:478-482): only low opacity (and NaN scales) prunes; set: Gaussians larger than
+        0.1 * extent in world space are pruned as well (:316-320; the max_radii2D half of that test cannot fire,
+        densification_postfix zeroes max_radii2D first, :249-251).
         `noise`: optional standard normals (2*n_selected, 3) for the split offsets (default: torch.randn).
         noise_is_pool=True: `noise` is a larger pool (>= 2*n_selected rows, e.g. one broadcast to all ranks before
-        the selection count is known); its first 2*n_selected rows are used."""
+        the selection count is known); its first 2*n_selected rows are used.
+        remove_outliers (:323-326, scikit-learn LocalOutlierFactor-style filter on the host, off in every shipped
+        config: remove_outliers_step -1) is not built."""
+        if remove_outliers:
+            raise ManusHipError("densify_and_prune: remove_outliers is not supported (SURVEY 8f: host-side "
+                                "update_mask_based_on_outliers; remove_outliers_step is -1 in every shipped config)")
         N, dev = self.N, self.device
         nbytes = int(lib().mgr_densify_workspace_bytes(N))
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         counts = (ctypes.c_int64 * 5)()
         check(lib().mgr_densify_plan(N, ptr(self.xyz_gradient_accum), ptr(self.denom), ptr(self.p["_scaling"]),
                                      ptr(self.p["_opacity"]), float(max_grad), float(min_opacity), float(extent),
-                                     float(self.opts["percent_dense"]), ptr(ws), nbytes, counts, stream()),
-              "mgr_densify_plan")
+                                     float(self.opts["percent_dense"]), float(max_screen_size or 0.0), ptr(ws), nbytes,
+                                     counts, stream()), "mgr_densify_plan")
         n_sel, M = int(counts[2]), int(counts[4])
         if noise is None:
             noise = torch.randn((2 * n_sel, 3), dtype=torch.float32, device=dev)
@@ -170,24 +205,78 @@ class GaussianOptimizer:
                                       ptr(noise), stream()), "mgr_densify_apply")
         self.p, self.m, self.v, self.skin_weights = new_p, new_m, new_v, new_skin
         self._reset_stats()
+        self.replaced = ALL_GROUPS
         return dict(kept=int(counts[0]), cloned=int(counts[1]), split_selected=n_sel, split_kept=int(counts[3]), total=M)
+
+    # -- prune_points, gaussian.py:185-203 -------------------------------------------------------
+    def prune_points(self, mask, extra=None):
+        """Remove the Gaussians where `mask` (N,) is True: leaves, both Adam moments, skin weights and the three
+        statistics keep the surviving rows in order.  `extra`: optional {name: (N, ...) 4-byte-element tensor}
+        compacted the same way (returned as a dict).  Returns the number of survivors."""
+        N, dev = self.N, self.device
+        mask = torch.as_tensor(mask, device=dev).reshape(-1)
+        if mask.numel() != N:
+            raise ManusHipError("prune_points: mask must have %d entries" % N)
+        mask = (mask != 0).to(torch.uint8).contiguous()
+        nbytes = int(lib().mgr_densify_workspace_bytes(N))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        counts = (ctypes.c_int64 * 5)()
+        check(lib().mgr_prune_plan(N, ptr(mask), ptr(ws), nbytes, counts, stream()), "mgr_prune_plan")
+        M = int(counts[4])
+        shp = lambda a: (M,) + tuple(self.p[a].shape[1:])
+        order = [a for _, a, _ in GROUPS]
+        new_p = {a: torch.empty(shp(a), dtype=torch.float32, device=dev) for a in order}
+        new_m = {a: torch.empty(shp(a), dtype=torch.float32, device=dev) for a in order}
+        new_v = {a: torch.empty(shp(a), dtype=torch.float32, device=dev) for a in order}
+        B = self.skin_weights.shape[1] if self.skin_weights is not None else 0
+        new_skin = torch.empty((M, B), dtype=torch.float32, device=dev) if B else None
+        check(lib().mgr_densify_apply(N, M, 0, ptr(ws), _ptr_array([self.p[a] for a in order]),
+                                      _ptr_array([self.m[a] for a in order]), _ptr_array([self.v[a] for a in order]),
+                                      _ptr_array([new_p[a] for a in order]), _ptr_array([new_m[a] for a in order]),
+                                      _ptr_array([new_v[a] for a in order]), ptr(self.skin_weights), ptr(new_skin), B,
+                                      None, stream()), "mgr_densify_apply")
+
+        def gather(t):
+            t = t.contiguous()
+            if t.element_size() != 4:
+                raise ManusHipError("prune_points: side arrays must have 4-byte elements")
+            out = torch.empty((M,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
+            width = int(t.numel() // max(N, 1))
+            check(lib().mgr_gather_rows(N, M, ptr(ws), ptr(t), ptr(out), width, stream()), "mgr_gather_rows")
+            return out
+
+        self.xyz_gradient_accum, self.denom = gather(self.xyz_gradient_accum), gather(self.denom)
+        self.max_radii2D = gather(self.max_radii2D)
+        extra_out = {k: gather(v) for k, v in (extra or {}).items()}
+        self.p, self.m, self.v, self.skin_weights = new_p, new_m, new_v, new_skin
+        self.replaced = ALL_GROUPS
+        self.last_prune_extra = extra_out
+        return M
 
     # -- reset_opacity, gaussian.py:148-165 -----------------------------------------------------
     def reset_opacity(self):
         check(lib().mgr_reset_opacity(self.N, ptr(self.p["_opacity"]), ptr(self.m["_opacity"]), ptr(self.v["_opacity"]),
                                       stream()), "mgr_reset_opacity")
+        self.replaced = self.replaced | {"opacity"}
 
-    # -- density_update schedule, gaussian_utils.py:451-498 --------------------------------------
-    def density_update(self, stats, extent, global_step, bg_white=True):
-        """The per-step densification control flow of `density_update` on the statistics of a step
-        (dict with grad2d, vis, radii as returned by `engine.ViewShardedStep.step`).  Returns True when the
-        parameter tensors were replaced."""
+    # -- density_update, gaussian_utils.py:451-498 -------------------------------------------------
+    def density_update(self, stats, extent, global_step, bg_white=True, mask_to_prune=None, noise=None,
+                       noise_is_pool=False):
+        """`density_update` on the statistics of a step (dict with grad2d, vis, radii as returned by
+        `engine.ViewShardedStep.step`).  mask_to_prune given: prune those Gaussians and nothing else (:454-459).
+        Returns True when leaves were replaced (`self.replaced` names the groups: the next step() skips them,
+        like the reference's optimizer.step() skips a gradient-less new nn.Parameter)."""
         o, changed = self.opts, False
+        if mask_to_prune is not None:
+            self.prune_points(mask_to_prune)
+            return True
         if global_step < o["densify_until_step"]:
             self.add_densification_stats(stats["grad2d"], stats["vis"], stats["radii"])
             if global_step > o["densify_from_step"] and global_step % o["densification_interval"] == 0:
                 size_threshold = o["size_threshold"] if global_step > o["opacity_reset_interval"] else None
-                self.densify_and_prune(o["densify_grad_threshold"], o["min_opacity_threshold"], extent, size_threshold)
+                self.last_densify = self.densify_and_prune(o["densify_grad_threshold"], o["min_opacity_threshold"], extent,
+                                                           size_threshold, global_step == o["remove_outliers_step"],
+                                                           noise=noise, noise_is_pool=noise_is_pool)
                 changed = True
             if global_step % o["opacity_reset_interval"] == 0 or (bg_white and global_step == o["densify_from_step"]):
                 if global_step != 0:

@@ -38,9 +38,11 @@ class GaussianRasterizationSettings(NamedTuple):
 
 
 # ---------------------------------------------------------------------------
-# workspace pool: one opaque byte tensor links a forward to its backward
+# per-device context: workspace pool, learnt pair capacities, overflow fences
 # ---------------------------------------------------------------------------
 class RasterWorkspace:
+    """One opaque byte tensor that links a forward to its backward."""
+
     def __init__(self, device, V, N, W, H, cap):
         self.key = (V, N, W, H)
         self.cap = int(cap)
@@ -50,56 +52,151 @@ class RasterWorkspace:
         self.busy = False
 
 
-class _Pool:
-    def __init__(self):
-        self.items = {}
+def default_pair_capacity(V, N):
+    return max(4096, 8 * V * max(N, 1))
 
-    def acquire(self, device, V, N, W, H, min_cap):
-        lst = self.items.setdefault((str(device), V, N, W, H), [])
+
+class RasterContext:
+    """All host-side rasterizer state of ONE device (SURVEY.md 8b "Threading": one host thread per device, re-entrant
+    across devices): the workspace pool, the pair capacity learnt per (V,N,W,H), the sync policy and the overflow
+    fences of forwards that ran without a host synchronisation."""
+
+    MAX_FENCES = 64
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.pool = {}
+        self.cap_hint = {}
+        self.sync_every_forward = True
+        self.last_ws = None
+        self._fences = []        # (workspace, pinned int32[2], event) per unsynchronised forward, oldest first
+        self._free_pinned = []
+
+    # -- pool ---------------------------------------------------------------------------------
+    def acquire(self, V, N, W, H, min_cap):
+        lst = self.pool.setdefault((V, N, W, H), [])
         for ws in lst:
             if not ws.busy and ws.cap >= min_cap:
                 ws.busy = True
                 return ws
-        # drop idle smaller workspaces before growing
-        lst[:] = [w for w in lst if w.busy]
-        ws = RasterWorkspace(device, V, N, W, H, min_cap)
+        lst[:] = [w for w in lst if w.busy]   # drop idle smaller workspaces before growing
+        ws = RasterWorkspace(self.device, V, N, W, H, min_cap)
         ws.busy = True
         lst.append(ws)
         return ws
 
     def clear(self):
-        self.items.clear()
+        """Forget pooled workspaces and learnt capacities (e.g. after densification changed N)."""
+        self.pool.clear()
+        self.cap_hint.clear()
+        self._fences.clear()
+        self.last_ws = None
+
+    def _learn(self, key, npairs):
+        self.cap_hint[key] = max(self.cap_hint.get(key, 0), int(npairs * 1.25) + 4096)
+
+    # -- forward driver -------------------------------------------------------------------------
+    def forward(self, V, N, W, H, launch, sync_check=True):
+        """Run `launch(ws)` (which enqueues one forward on the current stream) with a workspace large enough for
+        the pairs it produces.  sync policy True: read the pair count back (one host sync, like upstream) and
+        retry with a larger workspace on overflow; False: no host sync, an overflow fence is recorded instead
+        (`poll()` / `check_overflow()`).  Returns (workspace, pair count or None)."""
+        key = (V, N, W, H)
+        cap = max(self.cap_hint.get(key, 0), default_pair_capacity(V, N))
+        while True:
+            ws = self.acquire(V, N, W, H, cap)
+            launch(ws)
+            self.last_ws = ws
+            if not (sync_check and self.sync_every_forward):
+                self._fence(ws)
+                return ws, None
+            import ctypes
+            npairs, ovf = ctypes.c_int64(0), ctypes.c_int32(0)
+            rc = lib().mgr_raster_status_sync(ptr(ws.buf), ctypes.byref(npairs), ctypes.byref(ovf), stream())
+            if rc == 0:
+                self._learn(key, npairs.value)
+                return ws, int(npairs.value)
+            if rc != -4:
+                check(rc, "mgr_raster_status_sync")
+            ws.busy = False  # overflow: retry with room for the observed count
+            cap = int(npairs.value * 1.5) + 4096
+
+    # -- overflow fences ------------------------------------------------------------------------
+    def _fence(self, ws):
+        """Asynchronous copy of (pair count, overflow flag) to pinned host memory + an event right behind it: the
+        host can later wait for THIS forward only, while the kernels queued after it keep the GPU busy."""
+        while len(self._fences) >= self.MAX_FENCES:
+            self._resolve(self._fences.pop(0))
+        pinned = self._free_pinned.pop() if self._free_pinned else torch.empty(2, dtype=torch.int32).pin_memory()
+        pinned.copy_(ws.buf[:8].view(torch.int32), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._fences.append((ws, pinned, ev))
+
+    def _resolve(self, fence):
+        ws, pinned, ev = fence
+        ev.synchronize()
+        npairs, ovf = int(pinned[0].item()) & 0xFFFFFFFF, int(pinned[1].item())
+        self._free_pinned.append(pinned)
+        self._learn(ws.key, npairs)
+        return npairs, ovf
+
+    def poll(self):
+        """Wait for the forwards recorded so far (not for what was queued after them) and raise ManusHipError if one
+        of them overflowed its pair capacity -- its image and gradients are incomplete; the capacity hint has been
+        enlarged, so re-running the step succeeds.  Returns the pair count of the most recent forward."""
+        last, bad = 0, False
+        while self._fences:
+            npairs, ovf = self._resolve(self._fences.pop(0))
+            last, bad = npairs, bad or bool(ovf)
+        if bad:
+            raise _lib.ManusHipError("rasterizer pair capacity exceeded (retry: the capacity hint was enlarged)")
+        return last
+
+    def check_overflow(self):
+        """Blocking check of every forward since the last check (fences) and of the most recent workspace; returns
+        the most recent pair count, raises ManusHipError on overflow (after enlarging the capacity hint)."""
+        import ctypes
+        polled = self.poll()
+        ws = self.last_ws
+        if ws is None:
+            return polled
+        npairs, ovf = ctypes.c_int64(0), ctypes.c_int32(0)
+        rc = lib().mgr_raster_status_sync(ptr(ws.buf), ctypes.byref(npairs), ctypes.byref(ovf), stream())
+        self._learn(ws.key, npairs.value)
+        if rc != 0:
+            check(rc, "rasterizer overflow check (retry: capacity hint was enlarged)")
+        return int(npairs.value)
 
 
-_POOL = _Pool()
-_CAP_HINT = {}  # (device,V,N,W,H) -> last observed pair count
-_POLICY = {"sync_every_forward": True}
-_LAST_WS = {"ws": None}
+_CONTEXTS = {}
 
 
-def set_sync_policy(sync_every_forward):
+def context(device=None):
+    """The RasterContext of `device` (default: the current device)."""
+    idx = torch.cuda.current_device() if device is None else (torch.device(device).index
+                                                              if torch.device(device).index is not None
+                                                              else torch.cuda.current_device())
+    ctx = _CONTEXTS.get(idx)
+    if ctx is None:
+        ctx = _CONTEXTS[idx] = RasterContext(torch.device("cuda", idx))
+    return ctx
+
+
+def set_sync_policy(sync_every_forward, device=None):
     """True (default, drop-in behaviour): every forward reads back the pair count
     (one host sync, like the upstream extension) and transparently retries with a
     larger workspace on overflow.  False (training engine): no host sync; the
-    capacity learnt so far is used and `check_overflow()` must be polled."""
-    _POLICY["sync_every_forward"] = bool(sync_every_forward)
+    capacity learnt so far is used and `poll()` / `check_overflow()` report overflows."""
+    context(device).sync_every_forward = bool(sync_every_forward)
 
 
-def check_overflow():
-    """Blocking check of the most recent forward's workspace; returns the pair
-    count, raises ManusHipError on overflow (after enlarging the capacity hint so
-    that a retry succeeds)."""
-    import ctypes
-    ws = _LAST_WS["ws"]
-    if ws is None:
-        return 0
-    npairs, ovf = ctypes.c_int64(0), ctypes.c_int32(0)
-    rc = lib().mgr_raster_status_sync(ptr(ws.buf), ctypes.byref(npairs), ctypes.byref(ovf), stream())
-    key = (str(ws.buf.device),) + ws.key
-    _CAP_HINT[key] = max(_CAP_HINT.get(key, 0), int(npairs.value * 1.25) + 4096)
-    if rc != 0:
-        check(rc, "rasterizer overflow check (retry: capacity hint was enlarged)")
-    return int(npairs.value)
+def check_overflow(device=None):
+    return context(device).check_overflow()
+
+
+def poll(device=None):
+    return context(device).poll()
 
 
 class _Lease:
@@ -112,39 +209,23 @@ class _Lease:
         self.ws.busy = False
 
 
-def default_pair_capacity(V, N):
-    return max(4096, 8 * V * max(N, 1))
-
-
 def _run_forward(cams, V, N, W, H, bg, means3D, cov3D, colors, opacity, debug, sync_check=True):
     dev = means3D.device
-    key = (str(dev), V, N, W, H)
     out = torch.empty((V, 3, H, W), dtype=torch.float32, device=dev)
     radii = torch.empty((V, N), dtype=torch.int32, device=dev)
     s_m = means3D.stride(0) if means3D.dim() == 3 else 0
     s_c = cov3D.stride(0) if cov3D.dim() == 3 else 0
     s_col = colors.stride(0) if colors.dim() == 3 else 0
     s_o = opacity.stride(0) if opacity.dim() == 2 else 0
-    cap = max(_CAP_HINT.get(key, 0), default_pair_capacity(V, N))
-    while True:
-        ws = _POOL.acquire(dev, V, N, W, H, cap)
+
+    def launch(ws):
         check(lib().mgr_raster_forward(V, N, W, H, ptr(cams), ptr(bg), ptr(means3D), s_m, ptr(cov3D), s_c,
                                        ptr(colors), s_col, ptr(opacity), s_o, ptr(out), ptr(radii),
                                        ptr(ws.buf), ws.nbytes, ws.cap, int(bool(debug)), stream()),
               "mgr_raster_forward")
-        _LAST_WS["ws"] = ws
-        if not (sync_check and _POLICY["sync_every_forward"]):
-            return out, radii, ws, None
-        import ctypes
-        npairs, ovf = ctypes.c_int64(0), ctypes.c_int32(0)
-        rc = lib().mgr_raster_status_sync(ptr(ws.buf), ctypes.byref(npairs), ctypes.byref(ovf), stream())
-        if rc == 0:
-            _CAP_HINT[key] = max(_CAP_HINT.get(key, 0), int(npairs.value * 1.25) + 4096)
-            return out, radii, ws, int(npairs.value)
-        if rc != -4:
-            check(rc, "mgr_raster_status_sync")
-        ws.busy = False  # overflow: retry with room for the observed count
-        cap = int(npairs.value * 1.5) + 4096
+
+    ws, npairs = context(dev).forward(V, N, W, H, launch, sync_check)
+    return out, radii, ws, npairs
 
 
 def _opacity_layout(op, V, N):

@@ -176,7 +176,10 @@ def make_scene(n_gaussians=300000, kind="hand", seed=0, grid_res=128, n_cameras=
     T = torch.stack([bone_transforms(torch.as_tensor(posed[p], dtype=torch.float32), rest_t) for p in range(P)])
     centroid = (0.5 * (sk["pose_heads"][2] + sk["pose_tails"][2])).mean(0)
     cams = make_cameras(n_cameras, centroid, radius=cam_radius, width=width, height=height)
+    # keypoints of every pose: cat(heads[:1], tails) (hand_dynamic.py:199-201)
+    keyp = np.stack([np.concatenate([sk["pose_heads"][frames[p % 4]][:1], sk["pose_tails"][frames[p % 4]]], 0) for p in range(P)])
     scene = dict(params=params, N=N, n_hand=n_hand, kind=kind, grid_dims=dims,
+                 keypoints=torch.as_tensor(keyp, dtype=torch.float32).to(device),
                  grid_center=torch.as_tensor(center).to(device), grid_scale=torch.as_tensor(scale).to(device),
                  rest=rest_t.to(device), posed=torch.as_tensor(posed, dtype=torch.float32).to(device),
                  transforms=T.to(device), cameras=cams, bg=torch.ones(3, device=device), width=width,
@@ -184,3 +187,25 @@ def make_scene(n_gaussians=300000, kind="hand", seed=0, grid_res=128, n_cameras=
     if n_hand:
         scene["grid"] = make_skin_grid(heads, tails, dims, center, scale, device=device)
     return scene
+
+
+def make_masks(scene, posed_xyz, margin=9):
+    """Synthetic segmentation masks (V,H,W,1) uint8, one per camera: the pixels within `margin` of the projection of
+    any posed Gaussian mean (posed_xyz: (V,N,3) or (N,3)).  Pure data generation for the pruning-path tests."""
+    W, H = scene["width"], scene["height"]
+    out = []
+    for v, cam in enumerate(scene["cameras"]):
+        pts = posed_xyz[v] if posed_xyz.dim() == 3 else posed_xyz
+        pts = pts.detach().cpu().double()
+        K = torch.as_tensor(cam["K"], dtype=torch.float64)
+        E = torch.as_tensor(cam["extr"], dtype=torch.float64)[:3, :4]
+        q = (K @ E @ torch.cat([pts, torch.ones(pts.shape[0], 1, dtype=torch.float64)], 1).T).T
+        uv = q[:, :2] / q[:, 2:]
+        ok = (q[:, 2] > 0) & (uv[:, 0] >= 0) & (uv[:, 0] <= W - 1) & (uv[:, 1] >= 0) & (uv[:, 1] <= H - 1)
+        img = torch.zeros((H, W), dtype=torch.float32)
+        ij = uv[ok].long()
+        img[ij[:, 1], ij[:, 0]] = 1.0
+        k = 2 * margin + 1
+        img = torch.nn.functional.max_pool2d(img[None, None], k, stride=1, padding=margin)[0, 0]
+        out.append(img.to(torch.uint8)[..., None])
+    return torch.stack(out)

@@ -35,6 +35,8 @@ def lib():
         _LIB = ctypes.CDLL(build())
         for sfx in ("_f32", "_f64"):
             getattr(_LIB, "orc_forward" + sfx).restype = ctypes.c_void_p
+            getattr(_LIB, "orc_forward_geom" + sfx).restype = ctypes.c_void_p
+            getattr(_LIB, "orc_backward_geom" + sfx).restype = None
             getattr(_LIB, "orc_num_rendered" + sfx).restype = ctypes.c_long
             for fn in ("orc_free", "orc_get_geom", "orc_get_binning", "orc_get_image_state", "orc_backward"):
                 getattr(_LIB, fn + sfx).restype = None
@@ -113,6 +115,37 @@ class RasterOracle:
             self.close()
         except Exception:
             pass
+
+
+class BlendOracle(RasterOracle):
+    """The blend half of the scalar rasterizer on given screen-space state: xy (N,2) pixel centres, depth (N),
+    conic (N,3) = (A,B,C), opacity (N), radii (N) int (0 = culled), colours (N,3).  `backward` returns the per-Gaussian
+    sums the blend produces: means2D (N,3) in NDC-scaled pixels, conic (N,3), colors (N,3), opacity (N)."""
+
+    def __init__(self, W, H, xy, depth, conic, opacity, radii, colors, bg, dtype=np.float32):
+        self.dt = np.dtype(dtype)
+        self.sfx = "_f32" if self.dt == np.float32 else "_f64"
+        L = lib()
+        c = lambda a, shape: np.ascontiguousarray(np.asarray(a, dtype=self.dt).reshape(shape))
+        self.N = int(np.shape(xy)[0])
+        self.W, self.H = int(W), int(H)
+        self.gx, self.gy = (self.W + 15) // 16, (self.H + 15) // 16
+        co = np.concatenate([c(conic, (self.N, 3)), c(opacity, (self.N, 1))], axis=1)
+        self.radii = np.ascontiguousarray(np.asarray(radii, np.int32).reshape(self.N))
+        self.color = np.zeros((3, self.H, self.W), dtype=self.dt)
+        self._h = ctypes.c_void_p(getattr(L, "orc_forward_geom" + self.sfx)(
+            ctypes.c_int(self.W), ctypes.c_int(self.H), ctypes.c_int(self.N), _p(c(xy, (self.N, 2))),
+            _p(c(depth, (self.N,))), _p(np.ascontiguousarray(co)), _p(self.radii), _p(c(colors, (self.N, 3))),
+            _p(c(bg, (3,))), _p(self.color)))
+        self.num_rendered = int(getattr(L, "orc_num_rendered" + self.sfx)(self._h))
+
+    def backward(self, dL_dpix):
+        g = np.ascontiguousarray(np.asarray(dL_dpix, dtype=self.dt).reshape(3, self.H, self.W))
+        out = dict(means2D=np.zeros((self.N, 3), self.dt), conic=np.zeros((self.N, 3), self.dt),
+                   colors=np.zeros((self.N, 3), self.dt), opacity=np.zeros((self.N,), self.dt))
+        getattr(lib(), "orc_backward_geom" + self.sfx)(self._h, _p(g), _p(out["means2D"]), _p(out["conic"]),
+                                                       _p(out["colors"]), _p(out["opacity"]))
+        return out
 
 
 def knn3_mean_dist2(xyz):

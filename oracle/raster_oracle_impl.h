@@ -114,6 +114,67 @@ void FN(orc_free)(FN(OrcState) * s) {
     free(s);
 }
 
+/* K2-K6 from the per-Gaussian 2D state in `s` (xy, depth, conic_opacity, radii, rect, tiles_touched): emit and sort
+ * the (tile, depth) pairs, tile ranges, front-to-back compositing.  Shared by orc_forward (state from its own
+ * preprocess) and orc_forward_geom (state handed in). */
+static void FN(orc_bin_and_blend)(FN(OrcState) * s, const REAL* colors, const REAL* bg, REAL* out_color) {
+    const int N = s->N, W = s->W, H = s->H;
+    /* ---- K2-K5: emit (tile, depth) pairs, sort, tile ranges ----------- */
+    long total = 0;
+    for (int i = 0; i < N; ++i) total += s->tiles_touched[i];
+    s->num_rendered = total;
+    s->pairs = (FN(OrcPair)*)malloc((size_t)(total > 0 ? total : 1) * sizeof(FN(OrcPair)));
+    long off = 0;
+    for (int i = 0; i < N; ++i) {
+        if (s->radii[i] <= 0) continue;
+        for (int y = s->rect[4 * i + 1]; y < s->rect[4 * i + 3]; ++y)
+            for (int x = s->rect[4 * i]; x < s->rect[4 * i + 2]; ++x) {
+                s->pairs[off].tile = y * s->gx + x;
+                s->pairs[off].depth = s->depth[i];
+                s->pairs[off].gid = i;
+                ++off;
+            }
+    }
+    qsort(s->pairs, (size_t)total, sizeof(FN(OrcPair)), FN(orc_pair_cmp));
+    int ntiles = s->gx * s->gy;
+    s->ranges = (int*)calloc((size_t)ntiles * 2, sizeof(int));
+    for (long k = 0; k < total; ++k) {
+        int t = s->pairs[k].tile;
+        if (k == 0 || s->pairs[k - 1].tile != t) s->ranges[2 * t] = (int)k;
+        if (k == total - 1 || s->pairs[k + 1].tile != t) s->ranges[2 * t + 1] = (int)k + 1;
+    }
+
+    /* ---- K6: front-to-back alpha compositing -------------------------- */
+    s->final_T = (REAL*)malloc((size_t)W * H * sizeof(REAL));
+    s->n_contrib = (int*)malloc((size_t)W * H * sizeof(int));
+    for (int py = 0; py < H; ++py)
+        for (int px = 0; px < W; ++px) {
+            int tile = (py / 16) * s->gx + (px / 16);
+            int beg = s->ranges[2 * tile], end = s->ranges[2 * tile + 1];
+            REAL T = R(1), C[3] = {0, 0, 0};
+            int contributor = 0, last = 0;
+            for (int k = beg; k < end; ++k) {
+                int g = s->pairs[k].gid;
+                ++contributor;
+                REAL dx = s->xy[2 * g] - R(px), dy = s->xy[2 * g + 1] - R(py);
+                const REAL* co = s->conic_opacity + 4 * g;
+                REAL power = R(-0.5) * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                if (power > R(0)) continue;
+                REAL alpha = FN(orc_min)(R(0.99), co[3] * FN(orc_exp)(power));
+                if (alpha < R(1) / R(255)) continue;
+                REAL testT = T * (R(1) - alpha);
+                if (testT < R(0.0001)) break;
+                for (int ch = 0; ch < 3; ++ch) C[ch] += colors[3 * g + ch] * alpha * T;
+                T = testT;
+                last = contributor;
+            }
+            size_t pix = (size_t)py * W + px;
+            s->final_T[pix] = T;
+            s->n_contrib[pix] = last;
+            for (int ch = 0; ch < 3; ++ch) out_color[(size_t)ch * H * W + pix] = C[ch] + T * bg[ch];
+        }
+}
+
 /* Forward.  out_color is CHW (3,H,W); radii int32 (N). */
 FN(OrcState) * FN(orc_forward)(int W, int H, REAL tanfovx, REAL tanfovy, const REAL* view,
                                const REAL* proj, int N, const REAL* means3D, const REAL* cov3D,
@@ -182,60 +243,49 @@ FN(OrcState) * FN(orc_forward)(int W, int H, REAL tanfovx, REAL tanfovy, const R
         s->rect[4 * i] = x0; s->rect[4 * i + 1] = y0; s->rect[4 * i + 2] = x1; s->rect[4 * i + 3] = y1;
         total += s->tiles_touched[i];
     }
+    (void)total;
     if (radii_out) memcpy(radii_out, s->radii, (size_t)N * sizeof(int));
 
-    /* ---- K2-K5: emit (tile, depth) pairs, sort, tile ranges ----------- */
-    s->num_rendered = total;
-    s->pairs = (FN(OrcPair)*)malloc((size_t)(total > 0 ? total : 1) * sizeof(FN(OrcPair)));
-    long off = 0;
-    for (int i = 0; i < N; ++i) {
-        if (s->radii[i] <= 0) continue;
-        for (int y = s->rect[4 * i + 1]; y < s->rect[4 * i + 3]; ++y)
-            for (int x = s->rect[4 * i]; x < s->rect[4 * i + 2]; ++x) {
-                s->pairs[off].tile = y * s->gx + x;
-                s->pairs[off].depth = s->depth[i];
-                s->pairs[off].gid = i;
-                ++off;
-            }
-    }
-    qsort(s->pairs, (size_t)total, sizeof(FN(OrcPair)), FN(orc_pair_cmp));
-    int ntiles = s->gx * s->gy;
-    s->ranges = (int*)calloc((size_t)ntiles * 2, sizeof(int));
-    for (long k = 0; k < total; ++k) {
-        int t = s->pairs[k].tile;
-        if (k == 0 || s->pairs[k - 1].tile != t) s->ranges[2 * t] = (int)k;
-        if (k == total - 1 || s->pairs[k + 1].tile != t) s->ranges[2 * t + 1] = (int)k + 1;
-    }
+    FN(orc_bin_and_blend)(s, colors, bg, out_color);
+    return s;
+}
 
-    /* ---- K6: front-to-back alpha compositing -------------------------- */
-    s->final_T = (REAL*)malloc((size_t)W * H * sizeof(REAL));
-    s->n_contrib = (int*)malloc((size_t)W * H * sizeof(int));
-    for (int py = 0; py < H; ++py)
-        for (int px = 0; px < W; ++px) {
-            int tile = (py / 16) * s->gx + (px / 16);
-            int beg = s->ranges[2 * tile], end = s->ranges[2 * tile + 1];
-            REAL T = R(1), C[3] = {0, 0, 0};
-            int contributor = 0, last = 0;
-            for (int k = beg; k < end; ++k) {
-                int g = s->pairs[k].gid;
-                ++contributor;
-                REAL dx = s->xy[2 * g] - R(px), dy = s->xy[2 * g + 1] - R(py);
-                const REAL* co = s->conic_opacity + 4 * g;
-                REAL power = R(-0.5) * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
-                if (power > R(0)) continue;
-                REAL alpha = FN(orc_min)(R(0.99), co[3] * FN(orc_exp)(power));
-                if (alpha < R(1) / R(255)) continue;
-                REAL testT = T * (R(1) - alpha);
-                if (testT < R(0.0001)) break;
-                for (int ch = 0; ch < 3; ++ch) C[ch] += colors[3 * g + ch] * alpha * T;
-                T = testT;
-                last = contributor;
-            }
-            size_t pix = (size_t)py * W + px;
-            s->final_T[pix] = T;
-            s->n_contrib[pix] = last;
-            for (int ch = 0; ch < 3; ++ch) out_color[(size_t)ch * H * W + pix] = C[ch] + T * bg[ch];
-        }
+/* Forward from given 2D state: the blend (K2-K6) of SURVEY.md Appendix A on per-Gaussian screen-space inputs
+ * xy (N,2) pixel centres, depth (N), conic_opacity (N,4) = (A, B, C, opacity), radii (N) (0 = culled), colours (N,3).
+ * The tile rectangle is re-derived from (xy, radius) with the K1 rule.  Used to check a kernel that fuses its own
+ * preprocess (LBS / SH / projection) against the oracle on IDENTICAL rasterizer inputs. */
+FN(OrcState) * FN(orc_forward_geom)(int W, int H, int N, const REAL* xy, const REAL* depth, const REAL* conic_opacity,
+                                    const int* radii, const REAL* colors, const REAL* bg, REAL* out_color) {
+    FN(OrcState)* s = (FN(OrcState)*)calloc(1, sizeof(FN(OrcState)));
+    s->W = W; s->H = H; s->N = N;
+    s->gx = (W + 15) / 16; s->gy = (H + 15) / 16;
+    memcpy(s->bg, bg, sizeof(REAL) * 3);
+    size_t n = (size_t)(N > 0 ? N : 1);
+    s->colors = (REAL*)malloc(n * 3 * sizeof(REAL));
+    memcpy(s->colors, colors, (size_t)N * 3 * sizeof(REAL));
+    s->xy = (REAL*)calloc(n * 2, sizeof(REAL));
+    s->depth = (REAL*)calloc(n, sizeof(REAL));
+    s->conic_opacity = (REAL*)calloc(n * 4, sizeof(REAL));
+    s->radii = (int*)calloc(n, sizeof(int));
+    s->tiles_touched = (int*)calloc(n, sizeof(int));
+    s->rect = (int*)calloc(n * 4, sizeof(int));
+    for (int i = 0; i < N; ++i) {
+        int radius = radii[i];
+        if (radius <= 0) continue;
+        REAL ix = xy[2 * i], iy = xy[2 * i + 1];
+        int x0 = FN(orc_imin)(s->gx, FN(orc_imax)(0, (int)((ix - R(radius)) / R(16))));
+        int y0 = FN(orc_imin)(s->gy, FN(orc_imax)(0, (int)((iy - R(radius)) / R(16))));
+        int x1 = FN(orc_imin)(s->gx, FN(orc_imax)(0, (int)((ix + R(radius) + R(15)) / R(16))));
+        int y1 = FN(orc_imin)(s->gy, FN(orc_imax)(0, (int)((iy + R(radius) + R(15)) / R(16))));
+        if ((x1 - x0) * (y1 - y0) == 0) continue;
+        s->depth[i] = depth[i];
+        s->radii[i] = radius;
+        s->xy[2 * i] = ix; s->xy[2 * i + 1] = iy;
+        memcpy(s->conic_opacity + 4 * i, conic_opacity + 4 * i, 4 * sizeof(REAL));
+        s->tiles_touched[i] = (x1 - x0) * (y1 - y0);
+        s->rect[4 * i] = x0; s->rect[4 * i + 1] = y0; s->rect[4 * i + 2] = x1; s->rect[4 * i + 3] = y1;
+    }
+    FN(orc_bin_and_blend)(s, colors, bg, out_color);
     return s;
 }
 
@@ -261,21 +311,11 @@ void FN(orc_get_image_state)(const FN(OrcState) * s, REAL* final_T, int* n_contr
     if (n_contrib) memcpy(n_contrib, s->n_contrib, (size_t)s->W * s->H * sizeof(int));
 }
 
-/* Backward.  dL_dpix CHW.  Outputs: dL_dmeans3D (N,3), dL_dmeans2D (N,3; z=0),
- * dL_dcolors (N,3), dL_dopacity (N), dL_dcov3D (N,6); optional dL_dconic (N,3)
- * = the per-Gaussian (A,B,C) conic gradient before the Sigma2D chain. */
-void FN(orc_backward)(const FN(OrcState) * s, const REAL* dL_dpix, REAL* dL_dmeans3D,
-                      REAL* dL_dmeans2D, REAL* dL_dcolors, REAL* dL_dopacity, REAL* dL_dcov3D,
-                      REAL* dL_dconic_out) {
-    int N = s->N, W = s->W, H = s->H;
-    size_t n = (size_t)(N > 0 ? N : 1);
-    REAL* dconic = (REAL*)calloc(n * 3, sizeof(REAL));
-    memset(dL_dmeans3D, 0, (size_t)N * 3 * sizeof(REAL));
-    memset(dL_dmeans2D, 0, (size_t)N * 3 * sizeof(REAL));
-    memset(dL_dcolors, 0, (size_t)N * 3 * sizeof(REAL));
-    memset(dL_dopacity, 0, (size_t)N * sizeof(REAL));
-    memset(dL_dcov3D, 0, (size_t)N * 6 * sizeof(REAL));
-
+/* K7: per pixel, back to front.  Accumulates (outputs must be zeroed): dL_dmeans2D (N,3; NDC-scaled pixels, z = 0),
+ * dconic (N,3) = d/d(A,B,C), dL_dcolors (N,3), dL_dopacity (N). */
+static void FN(orc_blend_backward)(const FN(OrcState) * s, const REAL* dL_dpix, REAL* dL_dmeans2D, REAL* dconic,
+                                   REAL* dL_dcolors, REAL* dL_dopacity) {
+    const int W = s->W, H = s->H;
     /* ---- K7: back-to-front per pixel ----------------------------------- */
     REAL ddelx = R(0.5) * R(W), ddely = R(0.5) * R(H);
     for (int py = 0; py < H; ++py)
@@ -321,6 +361,36 @@ void FN(orc_backward)(const FN(OrcState) * s, const REAL* dL_dpix, REAL* dL_dmea
                 dL_dopacity[gi] += G * dalpha;
             }
         }
+
+}
+
+/* Backward of orc_forward_geom: the blend backward alone (outputs as in orc_blend_backward, fully written). */
+void FN(orc_backward_geom)(const FN(OrcState) * s, const REAL* dL_dpix, REAL* dL_dmeans2D, REAL* dL_dconic,
+                           REAL* dL_dcolors, REAL* dL_dopacity) {
+    int N = s->N;
+    memset(dL_dmeans2D, 0, (size_t)N * 3 * sizeof(REAL));
+    memset(dL_dconic, 0, (size_t)N * 3 * sizeof(REAL));
+    memset(dL_dcolors, 0, (size_t)N * 3 * sizeof(REAL));
+    memset(dL_dopacity, 0, (size_t)N * sizeof(REAL));
+    FN(orc_blend_backward)(s, dL_dpix, dL_dmeans2D, dL_dconic, dL_dcolors, dL_dopacity);
+}
+
+/* Backward.  dL_dpix CHW.  Outputs: dL_dmeans3D (N,3), dL_dmeans2D (N,3; z=0),
+ * dL_dcolors (N,3), dL_dopacity (N), dL_dcov3D (N,6); optional dL_dconic (N,3)
+ * = the per-Gaussian (A,B,C) conic gradient before the Sigma2D chain. */
+void FN(orc_backward)(const FN(OrcState) * s, const REAL* dL_dpix, REAL* dL_dmeans3D,
+                      REAL* dL_dmeans2D, REAL* dL_dcolors, REAL* dL_dopacity, REAL* dL_dcov3D,
+                      REAL* dL_dconic_out) {
+    int N = s->N;
+    size_t n = (size_t)(N > 0 ? N : 1);
+    REAL* dconic = (REAL*)calloc(n * 3, sizeof(REAL));
+    memset(dL_dmeans3D, 0, (size_t)N * 3 * sizeof(REAL));
+    memset(dL_dmeans2D, 0, (size_t)N * 3 * sizeof(REAL));
+    memset(dL_dcolors, 0, (size_t)N * 3 * sizeof(REAL));
+    memset(dL_dopacity, 0, (size_t)N * sizeof(REAL));
+    memset(dL_dcov3D, 0, (size_t)N * 6 * sizeof(REAL));
+
+    FN(orc_blend_backward)(s, dL_dpix, dL_dmeans2D, dconic, dL_dcolors, dL_dopacity);
 
     /* ---- K8 + K9: per-Gaussian preprocess backward --------------------- */
     for (int i = 0; i < N; ++i) {

@@ -157,6 +157,26 @@ def object_forward(params, cam_center):
                 opacity=torch.sigmoid(params["_opacity"]))
 
 
+def composite_forward(params, n_hand, grid, grid_center, grid_scale, posed, rest, cam_center):
+    """src/modules/composite.py:50-78 followed by the colour step of render_gaussians (gaussian_utils.py:431-449):
+    hand Gaussians (rows < n_hand) through the hand module, object Gaussians through the object module, everything
+    concatenated, tf = the blended transforms for the hand and eye(4) for the object (:58-59), colours from the
+    concatenated tensors with that tf."""
+    ph = {k: v[:n_hand] for k, v in params.items()}
+    po = {k: v[n_hand:] for k, v in params.items()}
+    w = skin_weights_from_grid(ph["_xyz"], grid_center, grid_scale, grid)
+    hx, hc, htf = lbs_forward(ph["_xyz"], ph["_scaling"], ph["_rotation"], w, bone_transforms(posed, rest))
+    ox, oc = po["_xyz"], pack_sym6(covariance_3x3(po["_scaling"], po["_rotation"]))
+    eye = torch.eye(4, dtype=htf.dtype)[None].repeat(ox.shape[0], 1, 1)
+    pxyz, pcov, tf = torch.cat([hx, ox]), torch.cat([hc, oc]), torch.cat([htf, eye])
+    cano = torch.cat([ph["_xyz"], po["_xyz"]])
+    feats = torch.cat([torch.cat([ph["_features_dc"], ph["_features_rest"]], 1),
+                       torch.cat([po["_features_dc"], po["_features_rest"]], 1)])
+    col = sh_colors(pxyz, feats, cano, cam_center, 3, tf)
+    return dict(posed_xyz=pxyz, posed_cov=pcov, tf=tf, skin_wts=w, colors=col,
+                opacity=torch.sigmoid(torch.cat([ph["_opacity"], po["_opacity"]])))
+
+
 # ---------------------------------------------------------------------------
 # cameras (src/utils/cam_utils.py:19-78)
 # ---------------------------------------------------------------------------
@@ -241,6 +261,48 @@ def project_points(points, K, extr):
     ph = F.pad(points, (0, 1), value=1.0)
     q = torch.einsum("ij,bnj->bni", P, ph)
     return (q / q[..., 2:])[..., :2]
+
+
+# ---------------------------------------------------------------------------
+# EWA projection of the external rasterizer's preprocess ("Forward per Gaussian (K1)") as a
+# differentiable torch function: only what carries gradient (no radius / rectangle / culling).  Lets the torch
+# chain (LBS, SH) be closed around a blend whose inputs were fixed, so that a kernel fusing all three can be
+# checked on identical blend decisions.  Pinned to the scalar C oracle by tests/test_oracle_raster.py.
+# ---------------------------------------------------------------------------
+def project_ewa(means3D, cov6, W, H, tanfovx, tanfovy, view, proj):
+    """means3D (N,3), cov6 (N,6) [xx,xy,xz,yy,yz,zz]; view / proj: the (4,4) world_view_transform /
+    full_proj_transform tensors (element (row r, col c) of the math matrix = M.reshape(-1)[4c + r]).
+    Returns ndc (N,2) (the quantity `means2D.grad` is taken against: pixel = ((ndc + 1) * size - 1) / 2) and
+    conic (N,3) = (A, B, C).  The blend's dL/dB is the derivative w.r.t. ONE of the two symmetric off-diagonal entries
+    (K7 accumulates -1/2 gdx dy dG, K8 doubles it again): contract the conic with `conic_grad_weights`."""
+    v, P = view.reshape(-1), proj.reshape(-1)
+    x, y, z = means3D[:, 0], means3D[:, 1], means3D[:, 2]
+    hom = lambda M, r: M[r] * x + M[4 + r] * y + M[8 + r] * z + M[12 + r]
+    pw = 1.0 / (hom(P, 3) + 0.0000001)
+    ndc = torch.stack([hom(P, 0) * pw, hom(P, 1) * pw], -1)
+    fx, fy = W / (2.0 * tanfovx), H / (2.0 * tanfovy)
+    tx, ty, tz = hom(v, 0), hom(v, 1), hom(v, 2)
+    limx, limy = 1.3 * tanfovx, 1.3 * tanfovy
+    # Outside the frustum limits t.x becomes +-lim * t.z.  The published backward multiplies dL/dt.x by x_grad_mul = 0
+    # there and keeps treating t.x as independent of t.z (Appendix A, K8): the clamped value carries NO gradient.
+    rx, ry = tx / tz, ty / tz
+    tx = torch.where((rx < -limx) | (rx > limx), (torch.clamp(rx, -limx, limx) * tz).detach(), tx)
+    ty = torch.where((ry < -limy) | (ry > limy), (torch.clamp(ry, -limy, limy) * tz).detach(), ty)
+    j00, j02 = fx / tz, -(fx * tx) / (tz * tz)
+    j11, j12 = fy / tz, -(fy * ty) / (tz * tz)
+    M0 = torch.stack([j00 * v[4 * c] + j02 * v[4 * c + 2] for c in range(3)], -1)
+    M1 = torch.stack([j11 * v[4 * c + 1] + j12 * v[4 * c + 2] for c in range(3)], -1)
+    S = torch.stack([cov6[:, 0], cov6[:, 1], cov6[:, 2], cov6[:, 1], cov6[:, 3], cov6[:, 4], cov6[:, 2], cov6[:, 4],
+                     cov6[:, 5]], -1).reshape(-1, 3, 3)
+    S0, S1 = torch.einsum("nij,nj->ni", S, M0), torch.einsum("nij,nj->ni", S, M1)
+    a = (M0 * S0).sum(-1) + 0.3
+    b = (M0 * S1).sum(-1)
+    c = (M1 * S1).sum(-1) + 0.3
+    det = a * c - b * b
+    return ndc, torch.stack([c / det, -b / det, a / det], -1)
+
+
+CONIC_GRAD_WEIGHTS = (1.0, 2.0, 1.0)   # sum_k w_k * conic_k * dconic_k closes the chain (see project_ewa)
 
 
 def psnr(a, b):
@@ -335,14 +397,17 @@ def _rot_from_raw_quat(r):
     return R.reshape(-1, 3, 3)
 
 
-def densify_and_prune(state, accum, denom, max_grad, min_opacity, extent, percent_dense, noise, n_split=2):
+def densify_and_prune(state, accum, denom, max_grad, min_opacity, extent, percent_dense, noise, n_split=2,
+                      max_screen_size=None):
     """densify_and_prune of gaussian.py:310-333 (clone :288-308, split :254-286, prune :183-200, optimizer
     surgery :148-252) on a dict of tensors:
         state[name], state[name + "_m"], state[name + "_v"] for name in LEAVES, state["skin"] (N,B) or None.
     noise: standard normals (n_split * n_selected, 3), row c * n_selected + j for copy c of the j-th split
     Gaussian (the layout of `torch.normal(mean, std)` at :264-266 divided by std).
-    Returns the new state dict.  The reference's size test (max_radii2D > max_screen_size, :316-318) never
-    fires because densification_postfix has just zeroed max_radii2D (:249-251); it is therefore absent here.
+    Returns the new state dict.  max_screen_size falsy: only low opacity (and NaN scales) prunes (`if
+    max_screen_size:`, :316); set: also big_points_ws = max scale > 0.1 * extent (:318).  The other half of that
+    branch (max_radii2D > max_screen_size, :317) never fires because densification_postfix has just zeroed
+    max_radii2D (:249-251); it is therefore absent here.
     New rows get zero Adam moments; the statistics are reset by the caller (they are all zeros afterwards)."""
     N = state["xyz"].shape[0]
     grads = accum / denom
@@ -380,11 +445,44 @@ def densify_and_prune(state, accum, denom, max_grad, min_opacity, extent, percen
         sk = state["skin"]
         new["skin"] = torch.cat([sk[keep_orig], sk[clone], sk[sel].repeat(n_split, 1)])
     prune = torch.sigmoid(new["opacity"]).reshape(-1) < min_opacity
-    prune |= new["scaling"].exp().max(dim=1).values > 0.1 * extent
+    if max_screen_size:
+        prune |= new["scaling"].exp().max(dim=1).values > 0.1 * extent
     if torch.isnan(new["scaling"].mean()):
         prune |= torch.isnan(new["scaling"]).any(dim=-1)
     keep = ~prune
     return {k: v[keep] for k, v in new.items()}
+
+
+def prune_points(state, mask):
+    """prune_points of gaussian.py:185-203 on the dict layout of densify_and_prune (every entry keeps the rows where
+    mask is False; statistics `accum`, `denom`, `maxrad` included when present)."""
+    keep = ~torch.as_tensor(mask).bool().reshape(-1)
+    return {k: (v[keep] if v is not None else None) for k, v in state.items()}
+
+
+def dilate_mask(mask, kernel_size=11):
+    """dilate_mask of gaussian_utils.py:35-47: conv2d with a box of ones, zero padding, > 0."""
+    k = torch.ones((1, 1, kernel_size, kernel_size), dtype=torch.float32)
+    m = torch.nn.functional.conv2d(mask.float()[None, None], k, padding=kernel_size // 2)[0, 0]
+    return m > 0
+
+
+def points_outside_mask(points, K, extr, mask, keypoints=None, dilate=False):
+    """get_points_outside_mask of gaussian_utils.py:101-147.  mask (H,W,1); returns (N,1) bool."""
+    if dilate:
+        mask = dilate_mask(mask[..., 0]).unsqueeze(-1).int()
+    p2d = project_points(points[None], K, extr[:3, :4])[0]
+    px = torch.clamp(p2d[..., 0], 0, mask.shape[1] - 1).int()
+    py = torch.clamp(p2d[..., 1], 0, mask.shape[0] - 1).int()
+    inv = ~mask.bool()
+    val = inv[py.long(), px.long()]
+    if keypoints is not None:
+        k2d = project_points(keypoints[None], K, extr[:3, :4])[0]
+        kx = torch.clamp(k2d[..., 0], 0, mask.shape[1] - 1).int()
+        ky = torch.clamp(k2d[..., 1], 0, mask.shape[0] - 1).int()
+        if torch.any(inv[ky.long(), kx.long()]):
+            val = torch.zeros_like(val)
+    return val
 
 
 def reset_opacity(state):

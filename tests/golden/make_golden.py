@@ -20,7 +20,9 @@ Reference functions exercised (paths relative to /root/reference):
   * src/utils/cam_utils.py:19-78           getProjectionMatrix / get_opengl_camera_attributes
   * src/utils/transforms.py:233-261,489-530,304-311  get_pose_wrt_root / euler_angles_to_matrix / project_points
   * src/utils/loss_utils.py:22-97          l1_loss / ssim (called on HWC images like base.py:329-347)
-  * src/models/gaussian.py:128-338         training_setup / Adam groups / densify_and_prune / reset_opacity
+  * src/models/gaussian.py:128-338         training_setup / Adam groups / densify_and_prune / prune_points / reset_opacity
+  * src/utils/gaussian_utils.py:35-47,101-147,451-498  dilate_mask / get_points_outside_mask / density_update
+  * src/modules/hand_dynamic.py:193-224, src/modules/object.py:66-81, src/modules/base.py:87-98  on_after_backward flow
   * src/utils/gaussian_utils.py:212-245,501-511  get_expon_lr_func / update_learning_rate
   * src/utils/gaussian_utils.py:514-518    get_contact_map (torch.cdist nearest-point distance)
   * src/utils/train_utils.py:165-204, src/utils/extra.py:203-242  load_checkpoint / remove_nans / find_best_checkpoint
@@ -141,7 +143,8 @@ def _import_reference():
     import src.models.hand_gaussian as hand_gaussian
     import src.modules.hand_dynamic as hand_dynamic
     import src.utils.loss_utils as loss_utils
-    return dict(loss_utils=loss_utils, sh_utils=sh_utils, transforms=transforms, cam_utils=cam_utils,
+    import src.modules.object as object_module
+    return dict(loss_utils=loss_utils, object_module=object_module, sh_utils=sh_utils, transforms=transforms, cam_utils=cam_utils,
                 gaussian_utils=gaussian_utils, gaussian=gaussian,
                 hand_gaussian=hand_gaussian, hand_dynamic=hand_dynamic)
 
@@ -365,14 +368,14 @@ GAUSSIAN_OPTS = dict(  # config/model/gaussian/gaussian.yaml
     remove_outliers_step=-1, isotropic_scaling=False)
 
 
-def _make_model(mods, g, n, n_bones, percent_dense, spatial_lr_scale):
+def _make_model(mods, g, n, n_bones, percent_dense, spatial_lr_scale, big=False, opts=None):
     """A GaussianModel built without __init__ (it needs distCUDA2 / a GPU), then the reference's own
     training_setup() (src/models/gaussian.py:128-146)."""
     from easydict import EasyDict
     gm = mods["gaussian"].GaussianModel
     m = gm.__new__(gm)
     torch.nn.Module.__init__(m)
-    m.opts = EasyDict(dict(GAUSSIAN_OPTS, percent_dense=percent_dense))
+    m.opts = EasyDict(dict(dict(GAUSSIAN_OPTS, percent_dense=percent_dense), **(opts or {})))
     m.active_sh_degree, m.max_sh_degree = 3, 3
     m.spatial_lr_scale = spatial_lr_scale
     m.setup_functions()
@@ -382,7 +385,11 @@ def _make_model(mods, g, n, n_bones, percent_dense, spatial_lr_scale):
     m._features_dc = P(rn(n, 1, 3))
     m._features_rest = P(rn(n, 15, 3, sc=0.1))
     # log sigma: a mix of small and large Gaussians so that both clone and split fire
-    m._scaling = P(torch.log(torch.exp(torch.rand(n, 3, generator=g) * 4.0 - 8.5)))
+    ls = torch.log(torch.exp(torch.rand(n, 3, generator=g) * 4.0 - 8.5))
+    if big:   # ~1/8 of the Gaussians straddle 0.1 * extent = 0.05 (parents above it, some split children below)
+        rows = torch.rand(n, generator=g) < 0.125
+        ls[rows, 0] = torch.log(0.03 + 0.09 * torch.rand(int(rows.sum()), generator=g))
+    m._scaling = P(ls)
     m._rotation = P(rn(n, 4))
     m._opacity = P(rn(n, 1, sc=2.5))
     w = torch.rand(n, n_bones, generator=g)
@@ -404,13 +411,14 @@ def _dump_model(m, out, tag):
         if st is not None and "exp_avg" in st:
             out[f"{tag}_{name}_m"] = st["exp_avg"].numpy().copy()
             out[f"{tag}_{name}_v"] = st["exp_avg_sq"].numpy().copy()
-    out[f"{tag}_skin"] = m._skin_weights.numpy().copy()
+    if m._skin_weights is not None:
+        out[f"{tag}_skin"] = m._skin_weights.numpy().copy()
     out[f"{tag}_accum"] = m.xyz_gradient_accum.numpy().copy()
     out[f"{tag}_denom"] = m.denom.numpy().copy()
     out[f"{tag}_maxrad"] = m.max_radii2D.numpy().copy()
 
 
-def make_optimizer_golden(mods, seed, percent_dense, size_threshold):
+def make_optimizer_golden(mods, seed, percent_dense, size_threshold, big=False):
     """The reference's own optimizer step, learning-rate schedule, densify_and_prune and reset_opacity
     (src/models/gaussian.py:128-338, src/utils/gaussian_utils.py:212-245,501-511) on a small model:
     state before / after K Adam steps, after densify_and_prune (torch.normal recorded) and after
@@ -418,7 +426,7 @@ def make_optimizer_golden(mods, seed, percent_dense, size_threshold):
     gu = mods["gaussian_utils"]
     g = torch.Generator().manual_seed(seed)
     n, nb, K = 300, 21, 3
-    m = _make_model(mods, g, n, nb, percent_dense, spatial_lr_scale=1.3)
+    m = _make_model(mods, g, n, nb, percent_dense, spatial_lr_scale=1.3, big=big)
     out = {"percent_dense": np.float32(percent_dense), "spatial_lr_scale": np.float32(1.3), "K": np.int32(K),
            "size_threshold": np.float32(size_threshold if size_threshold else 0.0)}
     _dump_model(m, out, "init")
@@ -464,6 +472,147 @@ def make_optimizer_golden(mods, seed, percent_dense, size_threshold):
     _dump_model(m, out, "dens")
     m.reset_opacity()
     _dump_model(m, out, "reset")
+    return out
+
+
+def make_prune_golden(mods):
+    """GaussianModel.prune_points (src/models/gaussian.py:167-203) after three Adam steps: leaves, both moments,
+    skin weights and the three statistics keep the unmasked rows."""
+    g = torch.Generator().manual_seed(5)
+    n, nb = 257, 21
+    m = _make_model(mods, g, n, nb, 1e-6, spatial_lr_scale=1.0)
+    for k in range(3):
+        m.optimizer.zero_grad(set_to_none=True)
+        for attr, name in _LEAVES:
+            p = getattr(m, attr)
+            p.grad = torch.randn(p.shape, generator=g) * 1e-3
+        m.optimizer.step()
+    m.xyz_gradient_accum = torch.rand(n, 1, generator=g)
+    m.denom = torch.randint(0, 4, (n, 1), generator=g).float()
+    m.max_radii2D = torch.rand(n, generator=g) * 40.0
+    out = {}
+    _dump_model(m, out, "pre")
+    mask = torch.rand(n, generator=g) < 0.3
+    mask[0], mask[-1] = True, False
+    out["mask"] = mask.numpy().copy()
+    m.prune_points(mask)
+    _dump_model(m, out, "post")
+    return out
+
+
+def _flow_camera(g, W, H):
+    """A pinhole camera looking down +z from z = -1: K (1,3,3), extr (1,3,4) with the leading batch dim the
+    dataloader adds (src/datasets/brics_dynamic.py:401)."""
+    from easydict import EasyDict
+    K = torch.tensor([[[0.9 * W, 0.0, (W - 1) / 2.0], [0.0, 0.9 * W, (H - 1) / 2.0], [0.0, 0.0, 1.0]]])
+    R = torch.tensor(_rand_rigid(np.random.default_rng(3), 1, ang=0.2, trans=0.0)[0, :3, :3])
+    extr = torch.cat([R, torch.tensor([[0.01], [-0.02], [1.0]])], 1)[None]
+    return EasyDict(K=K, extr=extr)
+
+
+def make_mask_golden(mods):
+    """get_points_outside_mask / dilate_mask (src/utils/gaussian_utils.py:35-47,101-147): object call (no keypoints,
+    no dilation), hand call (keypoints inside, dilate=True), and a keypoint outside the mask (everything kept)."""
+    gu = mods["gaussian_utils"]
+    g = torch.Generator().manual_seed(9)
+    W, H, n = 96, 64, 700
+    cam = _flow_camera(g, W, H)
+    pts = torch.randn(n, 3, generator=g) * torch.tensor([0.5, 0.35, 0.1])      # a good part projects off-image
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    blob = ((xx - 50.0) ** 2 / 30.0 ** 2 + (yy - 30.0) ** 2 / 18.0 ** 2) < 1.0
+    blob[40:44, 10:14] = True
+    mask = blob[None, :, :, None].to(torch.uint8)                               # (1,H,W,1) like batch["mask"]
+    key_in = torch.tensor([[0.02, 0.0, 0.0], [0.05, -0.03, 0.02], [-0.04, 0.02, 0.01]])
+    key_out = torch.cat([key_in, torch.tensor([[0.6, 0.5, 0.0]])])
+    out = {"K": cam.K.numpy(), "extr": cam.extr.numpy(), "points": pts.numpy(), "mask": mask.numpy(),
+           "key_in": key_in.numpy(), "key_out": key_out.numpy()}
+    out["dilated"] = gu.dilate_mask(mask[0, ..., 0]).numpy()
+    out["obj"] = gu.get_points_outside_mask(cam, pts, mask).numpy()
+    out["hand_in"] = gu.get_points_outside_mask(cam, pts, mask, key_in, dilate=True).numpy()
+    out["hand_out"] = gu.get_points_outside_mask(cam, pts, mask, key_out, dilate=True).numpy()
+    out["hand_in_nodilate"] = gu.get_points_outside_mask(cam, pts, mask, key_in, dilate=False).numpy()
+    return out
+
+
+def make_flow_golden(mods, kind):
+    """The reference's per-step control flow around the optimizer, executed by the reference itself:
+    on_after_backward (src/modules/hand_dynamic.py:193-224 / src/modules/object.py:66-81) -> density_update
+    (src/modules/base.py:87-98, src/utils/gaussian_utils.py:451-498) -> on_before_optimizer_step /
+    update_learning_rate -> optimizer.step() (a torch.optim.Adam that skips the leaves density_update has just
+    replaced), for a list of global steps with recorded per-step inputs (gradients, rasterizer by-products,
+    camera, mask, keypoints).  posed_xyz is the canonical xyz here (identity pose): the flow does not depend on LBS."""
+    from easydict import EasyDict
+    mod = mods["hand_dynamic"] if kind == "hand" else mods["object_module"]
+    TM = mod.TrainingModule
+    base = mods["hand_dynamic"].TrainingModule.__mro__[1]
+    g = torch.Generator().manual_seed(31 if kind == "hand" else 32)
+    W, H, nb = 96, 64, 21
+    n = 220 if kind == "hand" else 110
+    opts = dict(remove_seg_end=2, densify_from_step=100, densification_interval=100, opacity_reset_interval=300,
+                percent_dense=0.02)
+    m = _make_model(mods, g, n, nb, 0.02, spatial_lr_scale=1.0, big=True, opts=opts)
+    if kind == "object":
+        m._skin_weights = None
+    with torch.no_grad():
+        m._xyz.mul_(2.0)                       # spread: some Gaussians project outside the mask / far from the keypoints
+        m._xyz[:7] += torch.tensor([0.9, 0.0, 0.0])      # > 0.2 m from every keypoint on average
+    cam = _flow_camera(g, W, H)
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    mask = (((xx - 47.0) ** 2 / 40.0 ** 2 + (yy - 31.0) ** 2 / 26.0 ** 2) < 1.0)[None, :, :, None].to(torch.uint8)
+    heads = torch.randn(20, 3, generator=g) * 0.03
+    tails = heads + torch.randn(20, 3, generator=g) * 0.02
+    bones = EasyDict(heads=heads, tails=tails)
+    extent = 0.5
+    fake = types.SimpleNamespace(model=m, do_density_update=True, device="cpu",
+                                 train_data=types.SimpleNamespace(extent=extent, bg_color="white"),
+                                 trainer=types.SimpleNamespace(optimizers=[m.optimizer]))
+    fake.density_update = types.MethodType(base.density_update, fake)
+    fake.pts_mask = torch.zeros(n, dtype=torch.bool)
+    steps = [0, 1, 2, 99, 100, 101, 200, 300, 400]
+    out = {"steps": np.asarray(steps), "extent": np.float32(extent), "K": cam.K.numpy(), "extr": cam.extr.numpy(),
+           "mask": mask.numpy(), "heads": heads.numpy(), "tails": tails.numpy(), "percent_dense": np.float32(0.02),
+           "remove_seg_end": np.int32(2), "opacity_reset_interval": np.int32(300)}
+    _dump_model(m, out, "init")
+    rec = {}
+    orig_normal = torch.normal
+
+    def normal_rec(mean=None, std=None, **kw):
+        r = orig_normal(mean=mean, std=std, generator=g, **kw)
+        rec["noise"] = (r / std).clone()
+        return r
+
+    torch.normal = normal_rec
+    try:
+        for k, gs in enumerate(steps):
+            N = m.get_xyz.shape[0]
+            fake.global_step = gs
+            m.optimizer.zero_grad(set_to_none=True)
+            grads = {}
+            for attr, name in _LEAVES:
+                p = getattr(m, attr)
+                p.grad = torch.randn(p.shape, generator=g) * (1e-3 if name != "f_rest" else 1e-4)
+                grads[name] = p.grad.numpy().copy()
+            vsp = torch.zeros(N, 3, requires_grad=True)
+            vsp.grad = torch.randn(N, 3, generator=g) * 4e-4
+            radii = torch.randint(0, 30, (N,), generator=g).int()
+            rendered = {"camera": cam, "posed_xyz": m.get_xyz, "mask": mask, "bones_posed": bones,
+                        "viewspace_points": vsp, "visibility_filter": radii > 0, "radii": radii}
+            fake.rendered = rendered
+            rec.clear()
+            TM.on_after_backward(fake)
+            gu = mods["gaussian_utils"]
+            gu.update_learning_rate(m.optimizer, m, gs)          # on_before_optimizer_step
+            m.optimizer.step()
+            for name, v in grads.items():
+                out[f"s{k}_grad_{name}"] = v
+            out[f"s{k}_vsp_grad"] = vsp.grad.numpy().copy()
+            out[f"s{k}_radii"] = radii.numpy().copy()
+            out[f"s{k}_noise"] = rec["noise"].numpy().copy() if "noise" in rec else np.zeros((0, 3), np.float32)
+            out[f"s{k}_n_after"] = np.int64(m.get_xyz.shape[0])
+            print(kind, "step", gs, "N", N, "->", m.get_xyz.shape[0], "noise rows", out[f"s{k}_noise"].shape[0])
+            _dump_model(m, out, f"s{k}")
+    finally:
+        torch.normal = orig_normal
     return out
 
 
@@ -552,6 +701,14 @@ def make_checkpoint_golden(mods):
 def main():
     mods = _import_reference()
     torch.manual_seed(0)
+    if "--round2" in sys.argv:     # only the fixtures added in round 2 (the others are unchanged)
+        np.savez_compressed(os.path.join(OUT, "optimizer_s2.npz"), **make_optimizer_golden(mods, 2, 0.02, None, big=True))
+        np.savez_compressed(os.path.join(OUT, "optimizer_s3.npz"), **make_optimizer_golden(mods, 3, 0.02, 20, big=True))
+        np.savez_compressed(os.path.join(OUT, "prune_points.npz"), **make_prune_golden(mods))
+        np.savez_compressed(os.path.join(OUT, "points_outside_mask.npz"), **make_mask_golden(mods))
+        np.savez_compressed(os.path.join(OUT, "flow_hand.npz"), **make_flow_golden(mods, "hand"))
+        np.savez_compressed(os.path.join(OUT, "flow_object.npz"), **make_flow_golden(mods, "object"))
+        return
     for seed in (0, 1, 2):
         for n in (64, 1000):
             if n == 1000 and seed > 0:
@@ -570,6 +727,13 @@ def main():
     # percent_dense of the shipped config (1e-6: every selected Gaussian splits) and one that also clones
     np.savez_compressed(os.path.join(OUT, "optimizer_s0.npz"), **make_optimizer_golden(mods, 0, 0.000001, 20))
     np.savez_compressed(os.path.join(OUT, "optimizer_s1.npz"), **make_optimizer_golden(mods, 1, 0.02, None))
+    # Gaussians larger than 0.1 * extent: kept while size_threshold is None, pruned once it is set (gaussian.py:316-320)
+    np.savez_compressed(os.path.join(OUT, "optimizer_s2.npz"), **make_optimizer_golden(mods, 2, 0.02, None, big=True))
+    np.savez_compressed(os.path.join(OUT, "optimizer_s3.npz"), **make_optimizer_golden(mods, 3, 0.02, 20, big=True))
+    np.savez_compressed(os.path.join(OUT, "prune_points.npz"), **make_prune_golden(mods))
+    np.savez_compressed(os.path.join(OUT, "points_outside_mask.npz"), **make_mask_golden(mods))
+    np.savez_compressed(os.path.join(OUT, "flow_hand.npz"), **make_flow_golden(mods, "hand"))
+    np.savez_compressed(os.path.join(OUT, "flow_object.npz"), **make_flow_golden(mods, "object"))
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

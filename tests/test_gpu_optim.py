@@ -23,7 +23,7 @@ def _model(d, tag, percent_dense):
                              skin_weights=torch.tensor(d[f"{tag}_skin"], device=DEV))
 
 
-@pytest.mark.parametrize("name", ["optimizer_s0.npz", "optimizer_s1.npz"])
+@pytest.mark.parametrize("name", ["optimizer_s0.npz", "optimizer_s1.npz", "optimizer_s2.npz", "optimizer_s3.npz"])
 def test_matches_reference_run(golden_dir, name):
     """Same calls, in the same order, as the reference run recorded by make_optimizer_golden."""
     d = np.load(os.path.join(golden_dir, name))
@@ -100,6 +100,8 @@ def test_adam_and_densify_match_oracle(n):
     # densify from the oracle's state (identical inputs on both sides)
     for k in tr.LEAVES:
         go.p[ATTR[k]], go.m[ATTR[k]], go.v[ATTR[k]] = ref[k].to(DEV), ref[k + "_m"].to(DEV), ref[k + "_v"].to(DEV)
+    ref["scaling"][: max(1, n // 50), 0] = -2.5           # exp(-2.5) = 0.082 > 0.1 * extent: pruned only when size_thr is set
+    go.p["_scaling"] = ref["scaling"].to(DEV)
     accum = torch.rand(n, 1, generator=g) * 8e-4
     denom = torch.randint(0, 4, (n, 1), generator=g).float()
     go.xyz_gradient_accum, go.denom = accum.to(DEV), denom.to(DEV)
@@ -107,8 +109,9 @@ def test_adam_and_densify_match_oracle(n):
     grads_n = torch.nan_to_num(accum / denom, nan=0.0, posinf=float("inf")).reshape(-1)
     n_sel = int(((grads_n >= 0.0002) & (ref["scaling"].exp().max(1).values > 0.01 * extent)).sum())
     noise = torch.randn(2 * n_sel, 3, generator=g)
-    want = tr.densify_and_prune(ref, accum, denom, 0.0002, 0.005, extent, 0.01, noise)
-    info = go.densify_and_prune(0.0002, 0.005, extent, 20, noise=noise.to(DEV))
+    size_thr = 20 if n % 2 else None                     # both branches of `if max_screen_size:` (gaussian.py:316)
+    want = tr.densify_and_prune(ref, accum, denom, 0.0002, 0.005, extent, 0.01, noise, max_screen_size=size_thr)
+    info = go.densify_and_prune(0.0002, 0.005, extent, size_thr, noise=noise.to(DEV))
     assert info["split_selected"] == n_sel and info["total"] == want["xyz"].shape[0]
     assert info["kept"] + info["cloned"] + 2 * info["split_kept"] == info["total"]
     for k in tr.LEAVES:

@@ -49,3 +49,83 @@ def test_training_loop_learns_and_densifies():
         assert v.shape[0] == tr.opt.N and torch.isfinite(v).all(), k
     # Adam moments travelled with their rows: same count, finite
     assert tr.opt.m["_xyz"].shape[0] == tr.opt.N and torch.isfinite(tr.opt.v["_features_rest"]).all()
+
+
+def test_trainer_follows_reference_step_order_and_prunes_by_mask():
+    """on_after_backward before optimizer.step(): at step 0 (< remove_seg_end) Gaussians that project outside the
+    segmentation mask are pruned and that step's Adam update is skipped for every (replaced) leaf; the following steps
+    update all leaves; the keypoint-distance test runs at step 100.  Overflow fencing: the first step starts from the
+    default pair capacity, which a close-up scene exceeds, and must be re-run transparently."""
+    from manus_amd.engine import HipViewCompute, Trainer
+    from manus_amd.synthetic import camera_table, make_masks, make_scene
+    torch.manual_seed(0)
+    V, W, H, n = 2, 128, 96, 5000
+    sc = make_scene(n_gaussians=n, kind="hand", seed=8, grid_res=32, n_cameras=V, width=W, height=H, cam_radius=0.5,
+                    sigma_range=(4e-3, 1.2e-2), device=DEV)
+    ct = camera_table(sc["cameras"], DEV)
+    hp = HipViewCompute(sc, torch.zeros((V, 3, H, W), device=DEV), ct)
+    with torch.no_grad():
+        pxyz, _, _ = hp._posed(sc["transforms"][:V])
+        targets = torch.cat([hp.forward_views([v])[0] for v in range(V)]).contiguous()
+    # masks from all Gaussians but 25 chosen ones, which are then moved well outside the hand (still inside the grid)
+    far = torch.arange(0, n, n // 25, device=DEV)[:25]
+    keep = torch.ones(n, dtype=torch.bool, device=DEV)
+    keep[far] = False
+    sc["masks"] = make_masks(sc, pxyz[:, keep]).to(DEV)
+    lo, hi = sc["grid_center"] - 0.93 * sc["grid_scale"], sc["grid_center"] + 0.93 * sc["grid_scale"]
+    moved = sc["params"]["_xyz"][far] + torch.tensor([0.0, 0.07, 0.07], device=DEV)
+    sc["params"]["_xyz"][far] = torch.max(torch.min(moved, hi), lo)
+    compute = HipViewCompute(sc, targets, ct, loss="l1+ssim")
+    tr_ = Trainer(compute, V, extent=0.3, opts=dict(remove_seg_end=1, densify_from_step=1000), spatial_lr_scale=0.05)
+    p0 = {k: v.detach().clone() for k, v in compute.params.items()}
+    out = tr_.train_step()
+    assert out["changed"] and tr_.global_step == 1
+    n1 = tr_.opt.N
+    assert n - 400 < n1 <= n - 10, n1                   # displaced Gaussians (and little else) are gone
+    # the step that pruned made no Adam update: survivors are bit-identical to initial rows, no moment was touched
+    assert tr_.opt.group_step["xyz"] == 0 and not tr_.opt.m["_xyz"].any()
+    surv = compute.params["_xyz"].detach()
+    assert (surv[::50, None, :] == p0["_xyz"][None, :, :]).all(-1).any(1).all()
+    out = tr_.train_step()
+    assert not out["changed"] and tr_.opt.group_step["xyz"] == 1 and tr_.opt.N == n1
+    assert tr_.opt.m["_xyz"].abs().sum() > 0
+    assert float(tr_.opt.denom.sum()) > 0                 # statistics accumulate on ordinary steps
+    for _ in range(3):
+        tr_.train_step()
+    assert tr_.opt.group_step == {k: 4 for k in tr_.opt.group_step}
+    # keypoint-distance test (every 100 steps past remove_seg_end): nothing is 20 cm from the hand -> plain step
+    tr_.global_step = 100
+    out = tr_.train_step()
+    assert tr_.opt.N == n1 and np.isfinite(float(out["loss"]))
+    # white background: step densify_from_step resets the opacity (and only the opacity group misses its Adam step)
+    tr_.opt.opts["densify_from_step"] = 101
+    gs0 = dict(tr_.opt.group_step)
+    out = tr_.train_step()
+    assert out["changed"] and tr_.opt.N == n1
+    assert tr_.opt.group_step["opacity"] == gs0["opacity"] and tr_.opt.group_step["xyz"] == gs0["xyz"] + 1
+    assert float(torch.sigmoid(tr_.opt.p["_opacity"]).max()) <= 0.0100001
+
+
+def test_trainer_reruns_a_step_that_overflowed_the_pair_capacity(monkeypatch):
+    """No-sync mode: the step is fenced; an overflow (here forced by a tiny default capacity) discards the step and
+    re-runs it with the enlarged capacity -- the result equals a run that never overflowed."""
+    from manus_amd import rasterizer as rz
+    from manus_amd.engine import HipViewCompute, Trainer
+    from manus_amd.synthetic import camera_table, make_scene
+    V, W, H, n = 2, 96, 64, 3000
+    sc = make_scene(n_gaussians=n, kind="hand", seed=3, grid_res=24, n_cameras=V, width=W, height=H, cam_radius=0.5,
+                    sigma_range=(2e-3, 8e-3), device=DEV)
+    ct = camera_table(sc["cameras"], DEV)
+    tg = torch.rand((V, 3, H, W), device=DEV)
+    res = []
+    for tiny in (False, True):
+        rz.context().clear()
+        if tiny:
+            monkeypatch.setattr(rz, "default_pair_capacity", lambda V, N: 4096)
+        tr_ = Trainer(HipViewCompute(sc, tg, ct, loss="l1"), V, extent=0.3, opts=dict(remove_seg_end=0))
+        out = tr_.train_step()
+        res.append((tr_.retries, float(out["loss"]), {k: v.detach().clone() for k, v in tr_.compute.params.items()}))
+    assert res[0][0] == 0 and res[1][0] >= 1
+    assert res[0][1] == res[1][1]
+    for k in res[0][2]:
+        assert torch.equal(res[0][2][k], res[1][2][k]), k

@@ -213,8 +213,11 @@ def _worker(rank, world, port, q):
     shapes = {k: v.shape for k, v in sc["params"].items()}
     st = ViewShardedStep(300, shapes, _oracle_compute(sc), 5, rank=rank, world_size=world)
     out = st.step()
+    assert float(out["overflow"]) == 0.0
+    st.reduce_max_radii(out["radii"])        # the per-step collective carries sums only; the maximum is combined on demand
     if rank == 0:
-        q.put({k: ({n: g.clone() for n, g in v.items()} if isinstance(v, dict) else v.clone()) for k, v in out.items()})
+        q.put({k: ({n: g.clone() for n, g in v.items()} if isinstance(v, dict) else v.clone()) for k, v in out.items()
+               if v is not None})
     dist.barrier()
     dist.destroy_process_group()
 

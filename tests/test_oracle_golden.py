@@ -128,7 +128,7 @@ def _opt_state(d, tag):
     return st
 
 
-@pytest.mark.parametrize("name", ["optimizer_s0.npz", "optimizer_s1.npz"])
+@pytest.mark.parametrize("name", ["optimizer_s0.npz", "optimizer_s1.npz", "optimizer_s2.npz", "optimizer_s3.npz"])
 def test_optimizer_and_densify_match_reference(golden_dir, name):
     """Adam steps with the xyz schedule, densify_and_prune and reset_opacity restated in oracle/torch_ref.py
     against the reference's own GaussianModel run (tests/golden/make_golden.py::make_optimizer_golden)."""
@@ -150,7 +150,11 @@ def test_optimizer_and_densify_match_reference(golden_dir, name):
     noise = torch.tensor(d["split_samples"] / std) if std.size else torch.zeros((0, 3))
     new = tr.densify_and_prune(st, torch.tensor(d["stat_accum"]), torch.tensor(d["stat_denom"]),
                                GAUSSIAN_OPTS["densify_grad_threshold"], GAUSSIAN_OPTS["min_opacity_threshold"],
-                               float(d["extent"]), float(d["percent_dense"]), noise)
+                               float(d["extent"]), float(d["percent_dense"]), noise,
+                               max_screen_size=float(d["size_threshold"]) or None)
+    if name in ("optimizer_s2.npz", "optimizer_s3.npz"):   # these hold Gaussians larger than 0.1 * extent
+        big = (new["scaling"].exp().max(1).values > 0.1 * float(d["extent"])).sum()
+        assert (big > 0) == (name == "optimizer_s2.npz")    # kept while size_threshold is None, pruned once it is set
     assert new["xyz"].shape == d["dens_xyz"].shape and new["xyz"].shape[0] != d["adam_xyz"].shape[0]
     for n in tr.LEAVES:
         assert max_rel_err(new[n].numpy(), d[f"dens_{n}"]) < 2e-6, n
@@ -162,6 +166,34 @@ def test_optimizer_and_densify_match_reference(golden_dir, name):
     assert max_rel_err(rs["opacity"].numpy(), d["reset_opacity"]) < 2e-6
     assert not d["reset_opacity_m"].any() and not d["reset_opacity_v"].any()
     np.testing.assert_array_equal(rs["xyz_m"].numpy(), d["reset_xyz_m"])
+
+
+def test_prune_points_matches_reference(golden_dir):
+    """prune_points restated against GaussianModel.prune_points (gaussian.py:167-203)."""
+    d = np.load(os.path.join(golden_dir, "prune_points.npz"))
+    st = _opt_state(d, "pre")
+    st.update(accum=torch.tensor(d["pre_accum"]), denom=torch.tensor(d["pre_denom"]), maxrad=torch.tensor(d["pre_maxrad"]))
+    new = tr.prune_points(st, torch.tensor(d["mask"]))
+    assert new["xyz"].shape[0] == int((~d["mask"]).sum()) == d["post_xyz"].shape[0]
+    for n in tr.LEAVES:
+        for suf in ("", "_m", "_v"):
+            np.testing.assert_array_equal(new[n + suf].numpy(), d[f"post_{n}{suf}"])
+    for a, b in (("skin", "skin"), ("accum", "accum"), ("denom", "denom"), ("maxrad", "maxrad")):
+        np.testing.assert_array_equal(new[a].numpy(), d["post_" + b])
+
+
+def test_points_outside_mask_matches_reference(golden_dir):
+    """dilate_mask / get_points_outside_mask restated against gaussian_utils.py:35-47,101-147."""
+    d = np.load(os.path.join(golden_dir, "points_outside_mask.npz"))
+    K, E, pts, mask = (torch.tensor(d[k]) for k in ("K", "extr", "points", "mask"))
+    np.testing.assert_array_equal(tr.dilate_mask(mask[0, ..., 0]).numpy(), d["dilated"])
+    f = lambda kp, dil: tr.points_outside_mask(pts, K[0], E[0], mask[0], None if kp is None else torch.tensor(d[kp]), dil).numpy()
+    np.testing.assert_array_equal(f(None, False), d["obj"])
+    np.testing.assert_array_equal(f("key_in", True), d["hand_in"])
+    np.testing.assert_array_equal(f("key_in", False), d["hand_in_nodilate"])
+    np.testing.assert_array_equal(f("key_out", True), d["hand_out"])
+    assert d["obj"].any() and d["hand_in"].any() and not d["hand_out"].any()
+    assert d["obj"].sum() > d["hand_in"].sum()           # the dilated mask keeps more points
 
 
 def test_contact_distance_matches_reference(golden_dir):

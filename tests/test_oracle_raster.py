@@ -243,3 +243,43 @@ def test_knn_oracle_matches_sklearn():
     got = knn3_mean_dist2(pts)
     assert np.allclose(got, ref, rtol=1e-4, atol=1e-7)
     assert got[10] <= ref[10] + 1e-7
+
+
+def test_blend_oracle_and_torch_projection_close_the_chain():
+    """The two pieces added for checking fused kernels -- the blend on given 2D state (BlendOracle) and the
+    differentiable torch restatement of the projection (torch_ref.project_ewa) -- against the full scalar oracle:
+    same image from the oracle's own geometry, same (xy, conic), and the oracle's 3D gradients recovered by autograd
+    through project_ewa from the blend's per-Gaussian sums."""
+    import torch
+    from oracle import BlendOracle
+    from oracle import torch_ref as tr
+    W, H = 112, 80
+    cam = make_camera(W, H)
+    m, c, col, op = random_gaussians(1500, seed=21)
+    m[:40, 0] += 1.2                                     # some beyond the 1.3 * tanfov clamp
+    a = cam_args(cam)
+    for dt, tol in ((np.float32, 2e-5), (np.float64, 1e-10)):
+        ro = RasterOracle(a["W"], a["H"], a["tanfovx"], a["tanfovy"], a["view"], a["proj"], m, c, col, op, BG, dtype=dt)
+        g = ro.geom()
+        bo = BlendOracle(W, H, g["xy"], g["depth"], g["conic_opacity"][:, :3], g["conic_opacity"][:, 3], ro.radii, col, BG,
+                         dtype=dt)
+        assert bo.num_rendered == ro.num_rendered and (bo.color == ro.color).all()
+        gimg = np.random.default_rng(5).normal(size=(3, H, W))
+        rb, bb = ro.backward(gimg), bo.backward(gimg)
+        for k in ("means2D", "conic", "colors", "opacity"):
+            assert (rb[k] == bb[k]).all(), k
+        td = torch.float32 if dt == np.float32 else torch.float64
+        tm = torch.tensor(m, dtype=td, requires_grad=True)
+        tc = torch.tensor(c, dtype=td, requires_grad=True)
+        ndc, conic = tr.project_ewa(tm, tc, W, H, a["tanfovx"], a["tanfovy"], torch.tensor(a["view"], dtype=td),
+                                    torch.tensor(a["proj"], dtype=td))
+        vis = ro.radii > 0
+        pix = ((ndc.detach().numpy() + 1.0) * np.array([W, H]) - 1.0) * 0.5
+        assert np.abs(pix[vis] - g["xy"][vis]).max() < (1e-3 if dt == np.float32 else 1e-9)
+        assert max_rel_err(conic.detach().numpy()[vis], g["conic_opacity"][vis, :3]) < tol * 10
+        tv = torch.tensor(vis[:, None].astype(np.float64), dtype=td)
+        ((ndc * torch.tensor(bb["means2D"][:, :2], dtype=td) + 0).mul(tv).sum()
+         + (conic * torch.tensor(bb["conic"] * np.array(tr.CONIC_GRAD_WEIGHTS), dtype=td)).mul(tv).sum()).backward()
+        assert max_rel_err(tm.grad.numpy(), rb["means3D"]) < tol * 5, dt
+        # (the published backward uses 1 / (det^2 + 1e-7): a 1e-9-level departure from the exact derivative in fp64)
+        assert max_rel_err(tc.grad.numpy(), rb["cov3D"]) < max(tol * 5, 1e-8), dt
