@@ -1,5 +1,5 @@
 // Per-(view, Gaussian) math shared by the modular kernels (lbs_sh.hip, raster_*.hip) and the
-// fused per-instance kernels (fused.hip): LBS of mean/covariance, SH colour, EWA projection,
+// fused per-instance kernels (k_inst_fwd in raster_fwd.hip, k_inst_gather / k_inst_bwd in raster_bwd.hip): LBS of mean/covariance, SH colour, EWA projection,
 // and their analytic backward passes.  All functions are register-only device inlines.
 //
 // Reference semantics (brown-ivl/manus):
@@ -21,6 +21,7 @@ struct GaussCano {
 };
 
 __device__ __forceinline__ void quat_rot(const float q[4], float R[9]) {
+#pragma clang fp contract(off)
     const float r = q[0], x = q[1], y = q[2], z = q[3];
     R[0] = 1.f - 2.f * (y * y + z * z); R[1] = 2.f * (x * y - r * z); R[2] = 2.f * (x * z + r * y);
     R[3] = 2.f * (x * y + r * z); R[4] = 1.f - 2.f * (x * x + z * z); R[5] = 2.f * (y * z - r * x);
@@ -35,6 +36,7 @@ typedef float mgr_f3u __attribute__((ext_vector_type(3), aligned(4)));
 
 __device__ __forceinline__ void cano_load(const float* __restrict__ xyz, const float* __restrict__ log_scale,
                                           const float* __restrict__ rot, int i, GaussCano& g) {
+#pragma clang fp contract(off)
     const mgr_f3u p = *(const mgr_f3u*)(xyz + 3 * (size_t)i);
     const mgr_f3u ls = *(const mgr_f3u*)(log_scale + 3 * (size_t)i);
     const mgr_f4u q4 = *(const mgr_f4u*)(rot + 4 * (size_t)i);
@@ -50,6 +52,7 @@ __device__ __forceinline__ void cano_load(const float* __restrict__ xyz, const f
 // tf rows 0..2 (3x4, row-major) = sum_b w_b * T_b ; identity when w == nullptr
 __device__ __forceinline__ void blend_tf(const float* __restrict__ w_row, const float* __restrict__ Tp,
                                          int B, float tf[12]) {
+#pragma clang fp contract(off)
     if (w_row == nullptr) {
 #pragma unroll
         for (int k = 0; k < 12; ++k) tf[k] = (k == 0 || k == 5 || k == 10) ? 1.f : 0.f;
@@ -78,6 +81,7 @@ __device__ __forceinline__ void blend_tf(const float* __restrict__ w_row, const 
 
 // posed = A x + t ; Sigma' = (A R S)(A R S)^T packed [xx,xy,xz,yy,yz,zz]
 __device__ __forceinline__ void lbs_apply(const float tf[12], const GaussCano& g, float posed[3], float cov6[6]) {
+#pragma clang fp contract(off)
     posed[0] = tf[0] * g.x + tf[1] * g.y + tf[2] * g.z + tf[3];
     posed[1] = tf[4] * g.x + tf[5] * g.y + tf[6] * g.z + tf[7];
     posed[2] = tf[8] * g.x + tf[9] * g.y + tf[10] * g.z + tf[11];
@@ -291,6 +295,9 @@ struct ProjOut {
 
 __device__ __forceinline__ void project_gaussian(const MgrCam& cam, int W, int H, int gx, int gy, const float p[3],
                                                  const float c6[6], ProjOut& o) {
+    // integer decisions (radius, tile rectangle, culling) hang off this arithmetic: no fma contraction, so that every
+    // kernel that inlines it -- and the scalar oracle, built with -ffp-contract=off -- rounds identically
+#pragma clang fp contract(off)
     o.radius = 0; o.x0 = o.y0 = o.x1 = o.y1 = 0;
     o.px = o.py = o.ca = o.cb = o.cc = 0.f;
     const float* vm = cam.view;

@@ -248,6 +248,7 @@ __device__ __forceinline__ int mgr_lane() { return __builtin_amdgcn_mbcnt_hi(~0u
 __device__ __forceinline__ void mgr_ewa_rows(const MgrCam& c, float W, float H, const float p[3],
                                              float M0[3], float M1[3], float t[3], float& xmul,
                                              float& ymul, float& fx, float& fy) {
+#pragma clang fp contract(off)
     const float* v = c.view;
     fx = W / (2.0f * c.tanfovx);
     fy = H / (2.0f * c.tanfovy);
@@ -270,6 +271,7 @@ __device__ __forceinline__ void mgr_ewa_rows(const MgrCam& c, float W, float H, 
 }
 
 __device__ __forceinline__ void mgr_sym_mul(const float c6[6], const float m[3], float o[3]) {
+#pragma clang fp contract(off)
     o[0] = c6[0] * m[0] + c6[1] * m[1] + c6[2] * m[2];
     o[1] = c6[1] * m[0] + c6[3] * m[1] + c6[4] * m[2];
     o[2] = c6[2] * m[0] + c6[4] * m[1] + c6[5] * m[2];

@@ -468,7 +468,7 @@ __global__ __launch_bounds__(256) void k_inst_gather(
 }
 
 // Phase 2: the whole per-view backward chain for the active Gaussians only.
-template <int G, int BMAX>
+template <int G, int BMAX, bool MIXED>
 __global__ __launch_bounds__(IB_THREADS) __attribute__((amdgpu_waves_per_eu(MGR_IB_WAVES, MGR_IB_WAVES))) void k_inst_bwd(
     int v_first, int v_count, int N, int B, int n_art, int W, int H, const float* __restrict__ cams,
     const float* __restrict__ xyz, const float* __restrict__ log_scale, const float* __restrict__ rot,
@@ -486,7 +486,8 @@ __global__ __launch_bounds__(IB_THREADS) __attribute__((amdgpu_waves_per_eu(MGR_
     const bool ok = q < n_active;             // lane's Gaussian exists (all lanes stay for the DPP sums)
     const int i = (int)active_list[min(q, n_active - 1)];
     const bool any_tf = skin_w != nullptr;          // workgroup-uniform: the pose slabs are staged in LDS
-    const bool has_tf = any_tf && i < n_art;        // this lane's Gaussian is articulated (uniform over its lane group)
+    // this lane's Gaussian is articulated (uniform over its lane group; over the launch unless MIXED = composite)
+    const bool has_tf = any_tf && (!MIXED || i < n_art);
     const int tstride = IB_TSTRIDE(B), vstride = MGR_CAM_FLOATS + (any_tf ? tstride : 0);
     for (int k = tid; k < G * MGR_CAM_FLOATS; k += IB_THREADS) {
         const int g = k / MGR_CAM_FLOATS, e = k % MGR_CAM_FLOATS;
@@ -679,6 +680,7 @@ static int raster_backward_impl(int V, int N, int W, int H, const float* cams, c
         float4* iacc = (float4*)(ws + L.inst_grad);
         uint32_t* alist = (uint32_t*)(ws + L.inst_grad + (size_t)N * Gv * 48);
         const int ipb2 = IB_THREADS / Gv;
+        const bool mixed = canon->skin_w && canon->n_art < N;
         // gather rounds per workgroup: as many as IG_ROUNDS (amortises the list append) while >= ~1024 workgroups remain
         int rounds = (int)((long long)N / ((long long)ipb * 1024));
         rounds = rounds < 1 ? 1 : (rounds > IG_ROUNDS ? IG_ROUNDS : rounds);
@@ -694,7 +696,10 @@ static int raster_backward_impl(int V, int N, int W, int H, const float* cams, c
                        (const uint32_t*)(ws + L.inst_tag), (uint32_t)cap, epoch, accm, rounds, iacc, alist, hdr, canon->d_xyz, canon->d_ls, canon->d_rot, canon->d_op, canon->d_fdc,    \
                        canon->d_frest, canon->d_w, canon->st_grad2d, canon->st_vis, canon->st_radii)
 #define MGR_IB_LAUNCH(GG, BB)                                                                                         \
-    hipLaunchKernelGGL((k_inst_bwd<GG, BB>), grid, dim3(IB_THREADS), lds, stream, v0, vc, N, canon->B, canon->n_art, W, H, cams, canon->xyz, \
+    if (mixed) MGR_IB_LAUNCH2(GG, BB, true);                                                                          \
+    else MGR_IB_LAUNCH2(GG, BB, false)
+#define MGR_IB_LAUNCH2(GG, BB, MX)                                                                                    \
+    hipLaunchKernelGGL((k_inst_bwd<GG, BB, MX>), grid, dim3(IB_THREADS), lds, stream, v0, vc, N, canon->B, canon->n_art, W, H, cams, canon->xyz, \
                        canon->log_scale, canon->rot, canon->op_logit, canon->f_dc, canon->f_rest, canon->skin_w,      \
                        canon->transforms, (const float4*)iacc, (const uint32_t*)alist, (const MgrHeader*)hdr,         \
                        canon->grad2d_scale, accm, canon->d_xyz, canon->d_ls, canon->d_rot, canon->d_op, canon->d_fdc, \
@@ -719,6 +724,7 @@ static int raster_backward_impl(int V, int N, int W, int H, const float* cams, c
                 else MGR_IB_LAUNCH(1, MGR_MAX_BONES);
             }
 #undef MGR_IB_LAUNCH
+#undef MGR_IB_LAUNCH2
 #undef MGR_IG_LAUNCH
         }
     } else

@@ -239,7 +239,9 @@ __global__ __launch_bounds__(PRE_THREADS) void k_preprocess(
 // skin_w == nullptr: static object (identity transform, direction = xyz - camera).
 // Rows >= n_art are static as well (the object half of a hand+object composite, src/modules/composite.py:50-59:
 // tf = identity, so inv(tf) * cam = cam exactly and the colour equals the static route's).
+// MIXED = false: all Gaussians articulated (or none): the route is a kernel-argument test, uniform for the launch.
 // ---------------------------------------------------------------------------
+template <bool MIXED>
 __global__ __launch_bounds__(PRE_THREADS) void k_inst_fwd(
     int N, int B, int n_art, int W, int H, int gx, int gy, const float* __restrict__ cams,
     const float* __restrict__ xyz, const float* __restrict__ log_scale, const float* __restrict__ rot,
@@ -268,7 +270,7 @@ __global__ __launch_bounds__(PRE_THREADS) void k_inst_fwd(
         GaussCano g;
         cano_load(xyz, log_scale, rot, i, g);
         float tf[12], p[3], c6[6];
-        const bool art = skin_w != nullptr && i < n_art;
+        const bool art = skin_w != nullptr && (!MIXED || i < n_art);
         blend_tf(art ? skin_w + (size_t)i * B : nullptr, art ? transforms + (size_t)v * B * 16 : nullptr, B, tf);
         lbs_apply(tf, g, p, c6);
         project_gaussian(cam, W, H, gx, gy, p, c6, po);
@@ -1107,7 +1109,9 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
                                     152 * 1024));
         MGR_HIP(hipFuncSetAttribute((const void*)k_emit, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     152 * 1024));
-        MGR_HIP(hipFuncSetAttribute((const void*)k_inst_fwd, hipFuncAttributeMaxDynamicSharedMemorySize,
+        MGR_HIP(hipFuncSetAttribute((const void*)k_inst_fwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    152 * 1024));
+        MGR_HIP(hipFuncSetAttribute((const void*)k_inst_fwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     152 * 1024));
         attr_set = true;
     }
@@ -1123,11 +1127,16 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
         dim3 grid((N + PRE_THREADS - 1) / PRE_THREADS, V);
         if (canon) {
             MGR_PROF("k_inst_fwd", stream);
-            hipLaunchKernelGGL(k_inst_fwd, grid, dim3(PRE_THREADS), 128 + hist_bytes, stream, N, canon->B, canon->n_art, W, H, gx, gy,
-                               cams, canon->xyz, canon->log_scale, canon->rot, canon->op_logit, canon->f_dc,
-                               canon->f_rest, canon->skin_w, canon->transforms, (MgrGRec*)(ws + L.grec),
-                               (float*)(ws + L.depth), (ushort4*)(ws + L.rect), (unsigned long long*)(ws + L.alive),
-                               (uint32_t*)(ws + L.pair_off), tile_count, radii, hdr, lds_hist);
+            const bool mixed = canon->skin_w && canon->n_art < N;
+#define MGR_IF_LAUNCH(MX)                                                                                               \
+    hipLaunchKernelGGL(k_inst_fwd<MX>, grid, dim3(PRE_THREADS), 128 + hist_bytes, stream, N, canon->B, canon->n_art, W, H, \
+                       gx, gy, cams, canon->xyz, canon->log_scale, canon->rot, canon->op_logit, canon->f_dc,            \
+                       canon->f_rest, canon->skin_w, canon->transforms, (MgrGRec*)(ws + L.grec),                        \
+                       (float*)(ws + L.depth), (ushort4*)(ws + L.rect), (unsigned long long*)(ws + L.alive),            \
+                       (uint32_t*)(ws + L.pair_off), tile_count, radii, hdr, lds_hist)
+            if (mixed) MGR_IF_LAUNCH(true);
+            else MGR_IF_LAUNCH(false);
+#undef MGR_IF_LAUNCH
         } else
         { MGR_PROF("k_preprocess", stream); hipLaunchKernelGGL(k_preprocess, grid, dim3(PRE_THREADS), 128 + hist_bytes, stream, N, W, H, gx,
                            gy, cams, means3D, s_means, cov3D, s_cov, colors, s_col, opacity, s_op,

@@ -150,8 +150,10 @@ def test_fused_matches_oracle_on_identical_blend_inputs(kind, views):
         grp_active[v // 8] |= np.abs(nine(bws[v])).max(1) > 0
     for v in ids:
         r, bo, b = grec[v], bos[v], bws[v]
-        # -- image: same inputs, same decisions -> only fp32 rounding of exp / accumulation order
-        assert np.abs(img[v] - bo.color).max() < 2e-5, np.abs(img[v] - bo.color).max()
+        # -- image: same inputs -> fp32 rounding of exp / accumulation order (1e-7), plus, rarely, one pair whose alpha
+        # lies within that rounding of the 1/255 threshold and is kept on one side only (bounded by 1/255)
+        d = np.abs(img[v] - bo.color)
+        assert d.max() < 5e-3 and d.mean() < 2e-7 and np.mean(d > 2e-6) < 1e-3, (d.max(), d.mean())
         tgt = np.clip(bo.color + 0.05 * rng.normal(size=bo.color.shape), 0, 1)
         assert abs(psnr(img[v], tgt) - psnr(bo.color, tgt)) < 0.01
         # -- blend backward: the kernel's gathered per-(Gaussian, view) sums [dmean2D xy, dconic ABC, dopacity, drgb]

@@ -41,7 +41,10 @@ def test_training_loop_learns_and_densifies():
         assert np.isfinite(losses[-1])
     assert len(set(counts)) > 1, "densify_and_prune never changed the number of Gaussians"
     print("loss every 5 steps:", [round(x, 4) for x in losses[::5]], "N:", counts[::10])
-    assert min(losses[-5:]) < 0.7 * losses[0], (losses[0], losses[-5:], counts[::5])
+    # (every densification -- each 10 steps here -- replaces Gaussians by freshly split ones and the loss jumps, as in
+    # the reference; between densifications it must fall, and end below where it started)
+    assert min(losses) < 0.7 * losses[0] and losses[-1] < 0.9 * losses[0], (losses[0], losses[-5:], counts[::5])
+    assert all(losses[k + 9] < losses[k] for k in (0, 11, 21, 31, 41))
     tr.opt.reset_opacity()                                     # and the reset itself leaves a usable state
     out = tr.train_step()
     assert np.isfinite(float(out["loss"]))
@@ -67,21 +70,24 @@ def test_trainer_follows_reference_step_order_and_prunes_by_mask():
     with torch.no_grad():
         pxyz, _, _ = hp._posed(sc["transforms"][:V])
         targets = torch.cat([hp.forward_views([v])[0] for v in range(V)]).contiguous()
-    # masks from all Gaussians but 25 chosen ones, which are then moved well outside the hand (still inside the grid)
-    far = torch.arange(0, n, n // 25, device=DEV)[:25]
-    keep = torch.ones(n, dtype=torch.bool, device=DEV)
-    keep[far] = False
-    sc["masks"] = make_masks(sc, pxyz[:, keep]).to(DEV)
-    lo, hi = sc["grid_center"] - 0.93 * sc["grid_scale"], sc["grid_center"] + 0.93 * sc["grid_scale"]
-    moved = sc["params"]["_xyz"][far] + torch.tensor([0.0, 0.07, 0.07], device=DEV)
-    sc["params"]["_xyz"][far] = torch.max(torch.min(moved, hi), lo)
+    # masks: the silhouette (3 px margin) of nine tenths of the Gaussians; some of the others then project outside it
+    keep = torch.arange(n, device=DEV) % 10 != 0
+    sc["masks"] = make_masks(sc, pxyz[:, keep], margin=3).to(DEV)
+    from oracle import torch_ref as tr
+    want = torch.zeros(n, dtype=torch.bool)
+    for v in range(V):
+        c = sc["cameras"][v]
+        want |= tr.points_outside_mask(pxyz[v].cpu(), torch.tensor(c["K"], dtype=torch.float32),
+                                       torch.tensor(c["extr"], dtype=torch.float32), sc["masks"][v].cpu(),
+                                       sc["keypoints"][v].cpu(), dilate=True)[:, 0]
+    assert 10 < int(want.sum()) < n // 4, int(want.sum())
     compute = HipViewCompute(sc, targets, ct, loss="l1+ssim")
     tr_ = Trainer(compute, V, extent=0.3, opts=dict(remove_seg_end=1, densify_from_step=1000), spatial_lr_scale=0.05)
     p0 = {k: v.detach().clone() for k, v in compute.params.items()}
     out = tr_.train_step()
     assert out["changed"] and tr_.global_step == 1
     n1 = tr_.opt.N
-    assert n - 400 < n1 <= n - 10, n1                   # displaced Gaussians (and little else) are gone
+    assert abs(n1 - (n - int(want.sum()))) <= 2, (n1, int(want.sum()))   # exactly the Gaussians outside the masks (+- boundary ties)
     # the step that pruned made no Adam update: survivors are bit-identical to initial rows, no moment was touched
     assert tr_.opt.group_step["xyz"] == 0 and not tr_.opt.m["_xyz"].any()
     surv = compute.params["_xyz"].detach()
@@ -126,6 +132,6 @@ def test_trainer_reruns_a_step_that_overflowed_the_pair_capacity(monkeypatch):
         out = tr_.train_step()
         res.append((tr_.retries, float(out["loss"]), {k: v.detach().clone() for k, v in tr_.compute.params.items()}))
     assert res[0][0] == 0 and res[1][0] >= 1
-    assert res[0][1] == res[1][1]
+    assert abs(res[0][1] - res[1][1]) < 1e-6          # (the L1 loss value is summed with float atomics; gradients are not)
     for k in res[0][2]:
         assert torch.equal(res[0][2][k], res[1][2][k]), k

@@ -1,18 +1,22 @@
 #!/bin/bash
-# Round measurement pass on the GPU box: tests, smoke, bench (with cpu baseline), rocprofv3 kernel
-# stats of the same bench command, and the FETCH_SIZE / WRITE_SIZE counter passes.
-# Usage: tools/measure_round.sh TAG      (outputs under gpurun_out/)
+# Round measurement pass on the GPU box: rocprofv3 kernel stats of the bench command, the PMC counter passes
+# (separate passes, never combined with API traces), the bench itself (with the CPU oracle leg).
+# Usage: tools/measure_round.sh TAG [ROUND]      (outputs under gpurun_out/, summaries copied to profiles/)
 TAG=${1:-x}
-RND=${2:-r01}
+RND=${2:-r02}
 ROOT=$(pwd)
 export TMPDIR=/tmp
-python -m pytest tests -m gpu -x -q 2>&1 | tail -3 > gpurun_out/tests_$TAG.log
-python __graft_entry__.py smoke > gpurun_out/smoke_$TAG.log 2>&1; echo "smoke rc=$?" >> gpurun_out/smoke_$TAG.log
-tools/pmc_collect.sh traffic_$TAG "FETCH_SIZE" "WRITE_SIZE"
-python tools/pmc_summary.py gpurun_out/pmc_traffic_${TAG}_0 gpurun_out/pmc_traffic_${TAG}_1 --json gpurun_out/pmc_traffic_$TAG.json --workload 300000,8,1920,1080 > gpurun_out/pmc_traffic_$TAG.txt
-mkdir -p profiles; cp gpurun_out/pmc_traffic_$TAG.json profiles/r01_pmc_traffic.json   # bench reads this for roofline.traffic
+mkdir -p profiles gpurun_out
+# counter passes: HBM traffic (two passes: TCC slots), instruction mix + activity
+tools/pmc_collect.sh ${TAG} "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES GRBM_GUI_ACTIVE"
+python tools/pmc_summary.py gpurun_out/pmc_${TAG}_0 gpurun_out/pmc_${TAG}_1 gpurun_out/pmc_${TAG}_2 gpurun_out/pmc_${TAG}_3 \
+    --json gpurun_out/pmc_${TAG}.json --workload 300000,8,1920,1080 > gpurun_out/pmc_${TAG}.txt
+cp gpurun_out/pmc_${TAG}.json profiles/${RND}_pmc.json       # bench.py reads this for roofline.traffic / valu_issue_frac
+cp gpurun_out/pmc_${TAG}.txt profiles/${RND}_${TAG}_pmc.txt
 rm -rf gpurun_out/prof_$TAG
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof_$TAG -o run -- python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $ROOT/gpurun_out/prof_$TAG.log 2>&1)
+cp $(find gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1) profiles/${RND}_${TAG}_rocprofv3_kernel_stats.csv
 python bench.py --steps 50 --warmup 5 --profile-all > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err
-cat gpurun_out/tests_$TAG.log gpurun_out/smoke_$TAG.log | tail -5
-tail -22 gpurun_out/bench_$TAG.err; cat gpurun_out/bench_$TAG.json
+cp gpurun_out/bench_$TAG.json profiles/${RND}_${TAG}_bench.json
+grep -v amdgpu.ids gpurun_out/bench_$TAG.err > profiles/${RND}_${TAG}_bench_kernel_breakdown.txt
+tail -22 gpurun_out/bench_$TAG.err; cat gpurun_out/bench_$TAG.json; head -30 gpurun_out/pmc_${TAG}.txt

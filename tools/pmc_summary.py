@@ -23,6 +23,7 @@ def main():
             for r in csv.DictReader(open(f)):
                 key = (r["Dispatch_Id"], r["Counter_Name"])
                 per_dispatch[key] += float(r["Counter_Value"])
+                per_dispatch[(r["Dispatch_Id"], "duration_ns")] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
                 names[r["Dispatch_Id"]] = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
             for (disp, cname), val in per_dispatch.items():
                 acc[names[disp]][cname].append(val)
@@ -30,6 +31,8 @@ def main():
     for k in sorted(acc):
         if not k.startswith("k_"):
             continue
+        # (every dispatch of a kernel in the bench process has the same shape: the target images are rendered by one
+        # fused launch over all views, bench.py)
         res[k] = {c: sum(v) / len(v) for c, v in acc[k].items()}
         res[k]["launches"] = max(len(v) for v in acc[k].values())
     cols = sorted({c for k in res for c in res[k] if c != "launches"})
@@ -43,8 +46,10 @@ def main():
         wl = None
         if "--workload" in sys.argv:
             wl = [int(x) for x in sys.argv[sys.argv.index("--workload") + 1].split(",")]
-        json.dump({"workload": wl, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), "
-                   "mean per launch; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) KB (gfx950 FETCH_SIZE correction)",
+        json.dump({"workload": wl, "source": "rocprofv3 --pmc passes of `python bench.py --steps 4 --warmup 2 --no-cpu-baseline` "
+                   "(tools/pmc_collect.sh: one pass per counter group, never combined with API traces), mean per launch, "
+                   "summed over XCDs / SEs; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) KB (gfx950 FETCH_SIZE correction, "
+                   "MI355X_MICROARCH.md HBM section; gather widths uncalibrated)",
                    "kernels": res}, open(out_json, "w"), indent=1)
 
 if __name__ == "__main__":
