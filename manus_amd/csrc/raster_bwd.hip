@@ -19,6 +19,16 @@
 
 #include "instance_math.h"
 
+#ifdef MGR_STATS
+__device__ unsigned long long g_stats[16];
+extern "C" int mgr_debug_stats(unsigned long long* dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stats), sizeof(unsigned long long) * 16);
+}
+#define MGR_STAT(i, v) do { const unsigned long long v_ = (unsigned long long)(v); if (lane == 0) atomicAdd(&g_stats[i], v_); } while (0)
+#else
+#define MGR_STAT(i, v)
+#endif
+
 #define BWD_BATCH MGR_CHUNK
 #define BWD_SW (BWD_BATCH / 64)
 
@@ -153,6 +163,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
                     alive = !mgr_box_dead(a4.x, a4.y, a4.z, a4.w, b4.x, mgr_qmax(b4.y), X0, Y0, X1, Y1);
                 const unsigned long long m = __ballot(alive);
                 const int na = __popcll(m);
+                MGR_STAT(0, __popcll(__ballot(j < cnt)));   // (entry, wave) box tests
+                MGR_STAT(1, na);                              // survivors
                 if (alive) {
                     const int rank = __popcll(m & lt);
                     float* pb = slab + (rank >> 1) * MGR_PAIR_FLOATS;
@@ -171,7 +183,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
                     va = va && pa <= last;
                     vb = vb && pbpos <= last;
                     const bool anya = __ballot(va) != 0ull, anyb = __ballot(vb) != 0ull;  // wave-uniform
+                    MGR_STAT(2, 1);                                                    // pair iterations
+                    MGR_STAT(3, __popcll(__ballot(va)) + __popcll(__ballot(vb)));      // valid (entry, pixel) evaluations
+                    MGR_STAT(4, (anya ? 1 : 0) + (anyb ? 1 : 0));                      // entries with any valid pixel
                     if (!anya && !anyb) continue;
+                    MGR_STAT(5, 1);                                                    // pair iterations doing the full math
+#ifdef MGR_STATS
+                    {
+                        const unsigned long long ba = __ballot(va), bb = __ballot(vb);
+                        int blk = 0, strip = 0;
+                        const unsigned long long mk[4] = {0x0F0F0F0Full, 0xF0F0F0F0ull, 0x0F0F0F0F00000000ull, 0xF0F0F0F000000000ull};
+                        for (int q = 0; q < 4; ++q) {
+                            blk += ((ba & mk[q]) != 0) + ((bb & mk[q]) != 0);
+                            strip += (((ba >> (16 * q)) & 0xFFFFull) != 0) + (((bb >> (16 * q)) & 0xFFFFull) != 0);
+                        }
+                        MGR_STAT(6, blk);
+                        MGR_STAT(7, strip);
+                    }
+#endif
                     const mgr_v2f cr = {R3.x, R3.y}, cgn = {R3.z, R3.w}, cb = {R4.x, R4.y};
                     const mgr_v2f cg = cr * g0v + cgn * g1v + cb * g2v;
                     mgr_v2f w2, da2;

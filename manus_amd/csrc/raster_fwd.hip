@@ -904,6 +904,9 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, 
         }
         float Tr = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
         uint32_t last = 0;
+#ifdef MGR_STATS
+        uint32_t stop_pos = 0;
+#endif
         bool done = !inside;
         const MgrGRec* const gv = grec + (size_t)v * N;
 
@@ -964,6 +967,9 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, 
                     C2 += R4.x * w;
                     Tr = stop ? Tr : testT;
                     last = w > 0.0f ? __float_as_uint(R4.z) : last;
+#ifdef MGR_STATS
+                    if (stop && !done) stop_pos = __float_as_uint(R4.z);
+#endif
                     done = done || stop;
                 }
                 {   // entry b
@@ -976,6 +982,9 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, 
                     C2 += R4.y * w;
                     Tr = stop ? Tr : testT;
                     last = w > 0.0f ? __float_as_uint(R4.w) : last;
+#ifdef MGR_STATS
+                    if (stop && !done) stop_pos = __float_as_uint(R4.w);
+#endif
                     done = done || stop;
                 }
                 if (__all(done)) break;
@@ -989,6 +998,9 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, 
         if (inside) {
             const size_t pix = (size_t)py * W + px;
             n_contrib[(size_t)v * P + pix] = last;  // (the final transmittance is not needed by the chunk-parallel backward)
+#ifdef MGR_STATS
+            ((uint32_t*)final_T)[(size_t)v * P + pix] = stop_pos;  // list position where this pixel saturated (0 = never)
+#endif
             float* o = out_color + (size_t)v * 3 * P + pix;
             o[0] = C0 + Tr * bg0;
             o[P] = C1 + Tr * bg1;
