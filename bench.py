@@ -251,6 +251,9 @@ def main():
     ap.add_argument("--optimizer", action="store_true",
                     help="also run the fused Adam step inside every timed step (outside the headline metric, "
                          "which SURVEY 8d defines without the optimizer)")
+    ap.add_argument("--sh-storage", default="fp32", choices=["fp32", "fp16"],
+                    help="storage of _features_rest read by the render kernels (fp16 = BASELINE config 5's option; the "
+                         "headline number and the parity block use fp32, like the reference)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (cpu_baseline and parity)")
     ap.add_argument("--parity-views", type=int, default=2, help="views of the step run through the CPU oracle")
     ap.add_argument("--profile-all", action="store_true", help="print a per-kernel HIP-event breakdown to stderr")
@@ -286,7 +289,7 @@ def main():
         targets = hp.forward_views_fused(list(range(V)))[0].contiguous()
         del hp
     rasterizer.context(dev).clear()
-    compute = HipViewCompute(scene, targets, ct, loss=args.loss)
+    compute = HipViewCompute(scene, targets, ct, loss=args.loss, sh_storage=args.sh_storage)
     shapes = {k: v.shape for k, v in compute.params.items()}
     step = ViewShardedStep(N, shapes, compute, V, rank=rank, world_size=world)
     V_local = len(step.local_views)
@@ -300,6 +303,7 @@ def main():
             o = base_step()
             opt.update_learning_rate(opt.state_step + 1)
             opt.step(o["grads"])
+            compute.mark_params_changed()
             return o
 
         step.step = step_with_adam
@@ -381,7 +385,7 @@ def main():
             print("library kernels %.3f ms/iter of %.3f ms/iter wall" % (tot / args.steps, 1e3 * dt / args.steps),
                   file=sys.stderr)
         cpu = parity = None
-        if not args.no_cpu_baseline and world == 1 and args.kind == "hand" and not args.optimizer:
+        if not args.no_cpu_baseline and world == 1 and args.kind == "hand" and not args.optimizer and args.sh_storage == "fp32":
             # the GPU step once more on the sampled views alone (same targets, same loss, same 1/V scale), keeping the
             # images, dL/dimage and the kernels' per-instance records for the oracle
             Ks = min(args.parity_views, V)
@@ -415,7 +419,8 @@ def main():
                                    "(n_poses=%d), image loss %s, fwd+bwd to leaf grads" % (N, V, W, H, n_poses, "0.8*L1 + 0.2*(1-SSIM)" if args.loss == "l1+ssim" else "L1"),
                        "gaussians": N, "views": V, "width": W, "height": H, "views_per_gpu": V_local,
                        "pairs_per_view": int(R_view), "parallelism": "views/%d" % world,
-                       "optimizer_in_step": bool(args.optimizer), "nonfinite_grad_values": nonfinite},
+                       "optimizer_in_step": bool(args.optimizer), "sh_storage": args.sh_storage,
+                       "nonfinite_grad_values": nonfinite},
             "roofline": roof, "cpu_baseline": cpu, "parity": parity,
         }
         print(json.dumps(line))

@@ -128,16 +128,19 @@ int mgr_raster_backward(int V, int N, int W, int H, const float* cams, const flo
  *   n_articulated <= N: the first n_articulated Gaussians are skinned, the rest are static (identity
  *   transform, no skin-weight row): the hand+object concatenation of src/modules/composite.py:50-59.
  *   d_skin_w is (n_articulated,B).
+ *   sh_half != 0: f_rest points to the fp16 storage copy of _features_rest made by mgr_sh_to_half -- (N,48) halves,
+ *   16-byte aligned rows, 45 used (BASELINE config 5 "fp16 SH coeffs"; the reference has no counterpart, everything
+ *   there is fp32).  Arithmetic and d_f_rest stay fp32 (N,15,3); the optimizer owns the fp32 master copy.
  * stat_grad2d (N): sum over views of ||dL/dmeans2D[:, :2]|| * grad2d_scale,
  * stat_vis (N): number of views with radius > 0, stat_radii (N): max radius (any may be NULL).
  * ------------------------------------------------------------------------ */
-int mgr_views_forward(int V, int N, int B, int n_articulated, int W, int H, const float* cams, const float* bg,
+int mgr_views_forward(int V, int N, int B, int n_articulated, int sh_half, int W, int H, const float* cams, const float* bg,
                       const float* xyz, const float* log_scale, const float* rot,
                       const float* opacity_logit, const float* f_dc, const float* f_rest,
                       const float* skin_w, const float* transforms, float* out_color, int32_t* radii,
                       void* workspace, size_t workspace_bytes, int64_t pair_capacity, int debug,
                       void* stream);
-int mgr_views_backward(int V, int N, int B, int n_articulated, int W, int H, const float* cams, const float* bg,
+int mgr_views_backward(int V, int N, int B, int n_articulated, int sh_half, int W, int H, const float* cams, const float* bg,
                        const float* xyz, const float* log_scale, const float* rot,
                        const float* opacity_logit, const float* f_dc, const float* f_rest,
                        const float* skin_w, const float* transforms, const int32_t* radii,
@@ -146,6 +149,9 @@ int mgr_views_backward(int V, int N, int B, int n_articulated, int W, int H, con
                        float* d_f_rest, float* d_skin_w, float* stat_grad2d, float* stat_vis,
                        int32_t* stat_radii, void* workspace, size_t workspace_bytes,
                        int64_t pair_capacity, int debug, void* stream);
+
+/* f_rest (N,45) fp32 -> out_half (N,48) fp16 (round to nearest even, 3 halves of zero padding per row). */
+int mgr_sh_to_half(int N, const float* f_rest, void* out_half, void* stream);
 
 /* Debug/test: byte offsets of the workspace regions, in the order header, grec, depth, rect,
  * alive, pair_off, tile_count, tile_start, tile_cursor, tile_done, tile_queue, chunk_start, items,

@@ -8,6 +8,8 @@
 //   SH colour      src/utils/gaussian_utils.py:431-449; src/utils/sh_utils.py:57-104
 //   projection     external rasterizer, SURVEY.md Appendix A
 #pragma once
+#include <hip/hip_fp16.h>
+
 #include "mgr_common.h"
 
 #ifdef __HIPCC__
@@ -230,6 +232,15 @@ struct ShCoefMem {  // (16,3) coefficients split as f_dc (3) + f_rest (45), read
     const float* rest;
     __device__ __forceinline__ float operator[](int k) const { return k < 3 ? dc[k] : rest[k - 3]; }
 };
+
+// the same with f_rest stored as fp16, 48 halves per Gaussian (45 used; rows 16-byte aligned): BASELINE config 5's
+// "fp16 SH coeffs" storage option -- the arithmetic stays fp32
+struct ShCoefMemH {
+    const float* dc;
+    const __half* rest;
+    __device__ __forceinline__ float operator[](int k) const { return k < 3 ? dc[k] : __half2float(rest[k - 3]); }
+};
+#define MGR_SH_HALF_ROW 48
 
 template <typename C>
 __device__ __forceinline__ void sh_backward_view(const C& c, const ShDir& D, bool has_tf, const float gc[3],

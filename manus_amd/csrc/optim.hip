@@ -11,7 +11,32 @@
 // Gaussian, a two-phase scan turns the four keep flags into output positions in the reference's
 // order  [kept originals | kept clones | kept split copies 0 | kept split copies 1],  and one kernel
 // writes all new rows (parameters, both moments, skin weights) from a source map.
+#include <hip/hip_fp16.h>
+
 #include "mgr_common.h"
+
+// ---------------------------------------------------------------------------
+// fp16 storage copy of the higher-order SH coefficients (BASELINE config 5): _features_rest (N,45) fp32 -> (N,48)
+// fp16 rows (16-byte aligned, 3 halves of padding).  The optimizer keeps the fp32 master copy; this refreshes the
+// copy the render kernels read.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sh_to_half(int N, const float* __restrict__ f_rest, __half* __restrict__ out) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;   // one thread per output half
+    if (e >= (size_t)N * 48) return;
+    const size_t i = e / 48, k = e % 48;
+    out[e] = __float2half_rn(k < 45 ? f_rest[i * 45 + k] : 0.0f);
+}
+
+extern "C" int mgr_sh_to_half(int N, const float* f_rest, void* out_half, void* stream_) {
+    if (N < 0) return mgr_fail(MGR_EINVAL, "mgr_sh_to_half: bad size");
+    if (N == 0) return MGR_OK;
+    if (!f_rest || !out_half) return mgr_fail(MGR_EINVAL, "mgr_sh_to_half: null pointer");
+    hipStream_t stream = (hipStream_t)stream_;
+    const size_t total = (size_t)N * 48;
+    { MGR_PROF("k_sh_to_half", stream); hipLaunchKernelGGL(k_sh_to_half, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, N, f_rest, (__half*)out_half); }
+    MGR_LAUNCH_CHECK("k_sh_to_half", stream, 0);
+    return MGR_OK;
+}
 
 // ---------------------------------------------------------------------------
 // Adam: all groups in one launch

@@ -497,7 +497,7 @@ __global__ __launch_bounds__(256) void k_inst_gather(
 }
 
 // Phase 2: the whole per-view backward chain for the active Gaussians only.
-template <int G, int BMAX, bool MIXED>
+template <int G, int BMAX, bool MIXED, bool SH_HALF>
 __global__ __launch_bounds__(IB_THREADS) __attribute__((amdgpu_waves_per_eu(MGR_IB_WAVES, MGR_IB_WAVES))) void k_inst_bwd(
     int v_first, int v_count, int N, int B, int n_art, int W, int H, const float* __restrict__ cams,
     const float* __restrict__ xyz, const float* __restrict__ log_scale, const float* __restrict__ rot,
@@ -569,14 +569,19 @@ __global__ __launch_bounds__(IB_THREADS) __attribute__((amdgpu_waves_per_eu(MGR_
             blend_tf(has_tf ? skin_w + (size_t)i * B : nullptr, Tp, B, tf);
             lbs_apply(tf, g, p3, c6);
             project_backward(cam, W, H, p3, c6, acc, dm, dc6);
-            const ShCoefMem c = {f_dc + (size_t)i * 3, f_rest + (size_t)i * 45};
             const float gc[3] = {acc[6], acc[7], acc[8]};
             ShDir D;
             if (has_tf) sh_dir_xyz<true>(g.x, g.y, g.z, tf, cam.campos, D);
             else sh_dir_xyz<false>(g.x, g.y, g.z, tf, cam.campos, D);
 #pragma unroll
             for (int k = 0; k < 12; ++k) gt[k] = 0.f;
-            sh_backward_view(c, D, has_tf, gc, dsh, dxyz, gt);
+            if (SH_HALF) {   // f_rest stored as fp16 rows of 48
+                const ShCoefMemH c = {f_dc + (size_t)i * 3, (const __half*)f_rest + (size_t)i * MGR_SH_HALF_ROW};
+                sh_backward_view(c, D, has_tf, gc, dsh, dxyz, gt);
+            } else {
+                const ShCoefMem c = {f_dc + (size_t)i * 3, f_rest + (size_t)i * 45};
+                sh_backward_view(c, D, has_tf, gc, dsh, dxyz, gt);
+            }
         }
         // SH coefficient gradient: 48 floats = f_dc (3) | f_rest (45)
 #pragma unroll
@@ -654,7 +659,7 @@ __global__ __launch_bounds__(IB_THREADS) __attribute__((amdgpu_waves_per_eu(MGR_
 }
 
 struct CanonGrads {  // fused articulated backward: canonical inputs and leaf-gradient outputs
-    int B, n_art;
+    int B, n_art, sh_half;
     const float *xyz, *log_scale, *rot, *op_logit, *f_dc, *f_rest, *skin_w, *transforms;
     const int32_t* radii;
     float grad2d_scale;
@@ -725,10 +730,12 @@ static int raster_backward_impl(int V, int N, int W, int H, const float* cams, c
                        (const uint32_t*)(ws + L.inst_tag), (uint32_t)cap, epoch, accm, rounds, iacc, alist, hdr, canon->d_xyz, canon->d_ls, canon->d_rot, canon->d_op, canon->d_fdc,    \
                        canon->d_frest, canon->d_w, canon->st_grad2d, canon->st_vis, canon->st_radii)
 #define MGR_IB_LAUNCH(GG, BB)                                                                                         \
-    if (mixed) MGR_IB_LAUNCH2(GG, BB, true);                                                                          \
-    else MGR_IB_LAUNCH2(GG, BB, false)
-#define MGR_IB_LAUNCH2(GG, BB, MX)                                                                                    \
-    hipLaunchKernelGGL((k_inst_bwd<GG, BB, MX>), grid, dim3(IB_THREADS), lds, stream, v0, vc, N, canon->B, canon->n_art, W, H, cams, canon->xyz, \
+    if (mixed && canon->sh_half) MGR_IB_LAUNCH2(GG, BB, true, true);                                                  \
+    else if (mixed) MGR_IB_LAUNCH2(GG, BB, true, false);                                                              \
+    else if (canon->sh_half) MGR_IB_LAUNCH2(GG, BB, false, true);                                                     \
+    else MGR_IB_LAUNCH2(GG, BB, false, false)
+#define MGR_IB_LAUNCH2(GG, BB, MX, HF)                                                                                \
+    hipLaunchKernelGGL((k_inst_bwd<GG, BB, MX, HF>), grid, dim3(IB_THREADS), lds, stream, v0, vc, N, canon->B, canon->n_art, W, H, cams, canon->xyz, \
                        canon->log_scale, canon->rot, canon->op_logit, canon->f_dc, canon->f_rest, canon->skin_w,      \
                        canon->transforms, (const float4*)iacc, (const uint32_t*)alist, (const MgrHeader*)hdr,         \
                        canon->grad2d_scale, accm, canon->d_xyz, canon->d_ls, canon->d_rot, canon->d_op, canon->d_fdc, \
@@ -779,7 +786,7 @@ extern "C" int mgr_raster_backward(int V, int N, int W, int H, const float* cams
                                 nullptr, workspace, workspace_bytes, cap, debug, stream_);
 }
 
-extern "C" int mgr_views_backward(int V, int N, int B, int n_articulated, int W, int H, const float* cams, const float* bg,
+extern "C" int mgr_views_backward(int V, int N, int B, int n_articulated, int sh_half, int W, int H, const float* cams, const float* bg,
                                   const float* xyz, const float* log_scale, const float* rot,
                                   const float* opacity_logit, const float* f_dc, const float* f_rest,
                                   const float* skin_w, const float* transforms, const int32_t* radii,
@@ -794,7 +801,7 @@ extern "C" int mgr_views_backward(int V, int N, int B, int n_articulated, int W,
         return mgr_fail(MGR_EINVAL, "mgr_views_backward: null pointer");
     if (skin_w && (B <= 0 || B > MGR_MAX_BONES)) return mgr_fail(MGR_EINVAL, "mgr_views_backward: bad B");
     if (skin_w && (n_articulated < 0 || n_articulated > N)) return mgr_fail(MGR_EINVAL, "mgr_views_backward: bad n_articulated");
-    const CanonGrads cg = {B, skin_w ? n_articulated : 0, xyz, log_scale, rot, opacity_logit, f_dc, f_rest, skin_w, transforms, radii,
+    const CanonGrads cg = {B, skin_w ? n_articulated : 0, sh_half ? 1 : 0, xyz, log_scale, rot, opacity_logit, f_dc, f_rest, skin_w, transforms, radii,
                            grad2d_scale, d_xyz, d_log_scale, d_rot, d_opacity_logit, d_f_dc, d_f_rest, d_skin_w,
                            stat_grad2d, stat_vis, stat_radii};
     return raster_backward_impl(V, N, W, H, cams, bg, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, out_color,

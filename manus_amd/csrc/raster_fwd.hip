@@ -241,7 +241,7 @@ __global__ __launch_bounds__(PRE_THREADS) void k_preprocess(
 // tf = identity, so inv(tf) * cam = cam exactly and the colour equals the static route's).
 // MIXED = false: all Gaussians articulated (or none): the route is a kernel-argument test, uniform for the launch.
 // ---------------------------------------------------------------------------
-template <bool MIXED>
+template <bool MIXED, bool SH_HALF>
 __global__ __launch_bounds__(PRE_THREADS) void k_inst_fwd(
     int N, int B, int n_art, int W, int H, int gx, int gy, const float* __restrict__ cams,
     const float* __restrict__ xyz, const float* __restrict__ log_scale, const float* __restrict__ rot,
@@ -281,9 +281,23 @@ __global__ __launch_bounds__(PRE_THREADS) void k_inst_fwd(
             else sh_dir_xyz<false>(g.x, g.y, g.z, tf, cam.campos, D);
             float Y[16], c[48], rgb[3];
             sh_basis(D.d[0] / D.n, D.d[1] / D.n, D.d[2] / D.n, Y);
-            {   // 48 coefficients in 13 loads
-                const mgr_f3u d = *(const mgr_f3u*)(f_dc + (size_t)i * 3);
-                c[0] = d.x; c[1] = d.y; c[2] = d.z;
+            const mgr_f3u d = *(const mgr_f3u*)(f_dc + (size_t)i * 3);
+            c[0] = d.x; c[1] = d.y; c[2] = d.z;
+            if (SH_HALF) {   // fp16 storage: 48 halves per row (45 used), six aligned 16-byte loads
+                const uint4* hr = (const uint4*)((const __half*)f_rest + (size_t)i * MGR_SH_HALF_ROW);
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    const uint4 t = hr[q];
+                    const uint32_t w4[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int k = 8 * q + 2 * e;
+                        const __half2 h2 = *reinterpret_cast<const __half2*>(&w4[e]);
+                        if (k < 45) c[3 + k] = __low2float(h2);
+                        if (k + 1 < 45) c[4 + k] = __high2float(h2);
+                    }
+                }
+            } else {   // 45 coefficients in 12 loads
                 const float* fr = f_rest + (size_t)i * 45;
 #pragma unroll
                 for (int q = 0; q < 11; ++q) {
@@ -1069,7 +1083,7 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, 
 // host entry
 // ---------------------------------------------------------------------------
 struct CanonInputs {  // canonical (un-posed) parameters of the fused articulated path
-    int B, n_art;
+    int B, n_art, sh_half;
     const float *xyz, *log_scale, *rot, *op_logit, *f_dc, *f_rest, *skin_w, *transforms;
 };
 
@@ -1121,10 +1135,10 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
                                     152 * 1024));
         MGR_HIP(hipFuncSetAttribute((const void*)k_emit, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     152 * 1024));
-        MGR_HIP(hipFuncSetAttribute((const void*)k_inst_fwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    152 * 1024));
-        MGR_HIP(hipFuncSetAttribute((const void*)k_inst_fwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    152 * 1024));
+        MGR_HIP(hipFuncSetAttribute((const void*)k_inst_fwd<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+        MGR_HIP(hipFuncSetAttribute((const void*)k_inst_fwd<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+        MGR_HIP(hipFuncSetAttribute((const void*)k_inst_fwd<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+        MGR_HIP(hipFuncSetAttribute((const void*)k_inst_fwd<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
         attr_set = true;
     }
 
@@ -1140,14 +1154,16 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
         if (canon) {
             MGR_PROF("k_inst_fwd", stream);
             const bool mixed = canon->skin_w && canon->n_art < N;
-#define MGR_IF_LAUNCH(MX)                                                                                               \
-    hipLaunchKernelGGL(k_inst_fwd<MX>, grid, dim3(PRE_THREADS), 128 + hist_bytes, stream, N, canon->B, canon->n_art, W, H, \
+#define MGR_IF_LAUNCH(MX, HF)                                                                                           \
+    hipLaunchKernelGGL((k_inst_fwd<MX, HF>), grid, dim3(PRE_THREADS), 128 + hist_bytes, stream, N, canon->B, canon->n_art, W, H, \
                        gx, gy, cams, canon->xyz, canon->log_scale, canon->rot, canon->op_logit, canon->f_dc,            \
                        canon->f_rest, canon->skin_w, canon->transforms, (MgrGRec*)(ws + L.grec),                        \
                        (float*)(ws + L.depth), (ushort4*)(ws + L.rect), (unsigned long long*)(ws + L.alive),            \
                        (uint32_t*)(ws + L.pair_off), tile_count, radii, hdr, lds_hist)
-            if (mixed) MGR_IF_LAUNCH(true);
-            else MGR_IF_LAUNCH(false);
+            if (mixed && canon->sh_half) MGR_IF_LAUNCH(true, true);
+            else if (mixed) MGR_IF_LAUNCH(true, false);
+            else if (canon->sh_half) MGR_IF_LAUNCH(false, true);
+            else MGR_IF_LAUNCH(false, false);
 #undef MGR_IF_LAUNCH
         } else
         { MGR_PROF("k_preprocess", stream); hipLaunchKernelGGL(k_preprocess, grid, dim3(PRE_THREADS), 128 + hist_bytes, stream, N, W, H, gx,
@@ -1216,7 +1232,7 @@ extern "C" int mgr_raster_forward(int V, int N, int W, int H, const float* cams,
                                nullptr, out_color, radii, workspace, workspace_bytes, cap, debug, stream_);
 }
 
-extern "C" int mgr_views_forward(int V, int N, int B, int n_articulated, int W, int H, const float* cams, const float* bg,
+extern "C" int mgr_views_forward(int V, int N, int B, int n_articulated, int sh_half, int W, int H, const float* cams, const float* bg,
                                  const float* xyz, const float* log_scale, const float* rot,
                                  const float* opacity_logit, const float* f_dc, const float* f_rest,
                                  const float* skin_w, const float* transforms, float* out_color,
@@ -1226,7 +1242,8 @@ extern "C" int mgr_views_forward(int V, int N, int B, int n_articulated, int W, 
         return mgr_fail(MGR_EINVAL, "mgr_views_forward: null pointer");
     if (skin_w && (B <= 0 || B > MGR_MAX_BONES)) return mgr_fail(MGR_EINVAL, "mgr_views_forward: bad B");
     if (skin_w && (n_articulated < 0 || n_articulated > N)) return mgr_fail(MGR_EINVAL, "mgr_views_forward: bad n_articulated");
-    const CanonInputs ci = {B, skin_w ? n_articulated : 0, xyz, log_scale, rot, opacity_logit, f_dc, f_rest, skin_w, transforms};
+    if (sh_half && ((uintptr_t)f_rest & 15)) return mgr_fail(MGR_EINVAL, "mgr_views_forward: fp16 f_rest must be 16-byte aligned");
+    const CanonInputs ci = {B, skin_w ? n_articulated : 0, sh_half ? 1 : 0, xyz, log_scale, rot, opacity_logit, f_dc, f_rest, skin_w, transforms};
     return raster_forward_impl(V, N, W, H, cams, bg, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, &ci, out_color,
                                radii, workspace, workspace_bytes, cap, debug, stream_);
 }

@@ -147,8 +147,16 @@ class HipViewCompute:
     composite.py:50-59).  fused=True runs the fused kernels through direct C-ABI calls (no autograd graph); fused=False
     the modular operators under autograd (the reference-shaped path)."""
 
-    def __init__(self, scene, targets, cam_table, loss_weight=1.0, fused=True, loss="l1", w_rgb=0.8, w_ssim=0.2):
+    def __init__(self, scene, targets, cam_table, loss_weight=1.0, fused=True, loss="l1", w_rgb=0.8, w_ssim=0.2,
+                 sh_storage="fp32"):
         from . import fused as fused_mod, ops, rasterizer
+        # sh_storage "fp16" (BASELINE config 5): the fused kernels read an fp16 copy of _features_rest (96 B instead of
+        # 180 B per Gaussian and view group); arithmetic, gradients and the optimizer's master copy stay fp32.  The copy
+        # is refreshed lazily after the leaves changed (`mark_params_changed`).  The reference has no fp16 mode:
+        # parity is judged with "fp32".
+        if sh_storage not in ("fp32", "fp16"):
+            raise ValueError("sh_storage must be 'fp32' or 'fp16'")
+        self.sh_half, self._sh_copy, self._sh_dirty = sh_storage == "fp16", None, True
         self.ops, self.rz, self.fz, self.fused = ops, rasterizer, fused_mod, fused
         self.s = scene
         self.targets = targets          # (V_all,3,H,W) on the GPU
@@ -178,6 +186,24 @@ class HipViewCompute:
         elif self.kind == "hand" and self.is_hand:
             self.n_art = self.params["_xyz"].shape[0]
         self.grad_arena = None
+        self._sh_dirty = True
+
+    def mark_params_changed(self):
+        """The leaves were updated in place (optimizer step): derived storage copies are stale."""
+        self._sh_dirty = True
+
+    def _sh_storage(self, f_rest):
+        """(pointer source tensor, sh_half flag) for the fused kernels."""
+        if not self.sh_half:
+            return f_rest, 0
+        from ._lib import check, lib, ptr, stream
+        N = f_rest.shape[0]
+        if self._sh_copy is None or self._sh_copy.shape[0] != N:
+            self._sh_copy, self._sh_dirty = torch.empty((N, 48), dtype=torch.float16, device=f_rest.device), True
+        if self._sh_dirty:
+            check(lib().mgr_sh_to_half(N, ptr(f_rest), ptr(self._sh_copy), stream()), "mgr_sh_to_half")
+            self._sh_dirty = False
+        return self._sh_copy, 1
 
     def _select(self, view_ids):
         """Per-view constants for a set of views (cached: no per-step gather copies)."""
@@ -278,10 +304,11 @@ class HipViewCompute:
         radii = torch.empty((V, N), dtype=torch.int32, device=dev)
         op = p["_opacity"].reshape(-1)
         bg = s["bg"]
+        f_rest, sh_half = self._sh_storage(p["_features_rest"])
 
         def launch(ws):
-            check(lib().mgr_views_forward(V, N, B, na, W, H, ptr(cams), ptr(bg), ptr(p["_xyz"]), ptr(p["_scaling"]),
-                                          ptr(p["_rotation"]), ptr(op), ptr(p["_features_dc"]), ptr(p["_features_rest"]),
+            check(lib().mgr_views_forward(V, N, B, na, sh_half, W, H, ptr(cams), ptr(bg), ptr(p["_xyz"]), ptr(p["_scaling"]),
+                                          ptr(p["_rotation"]), ptr(op), ptr(p["_features_dc"]), ptr(f_rest),
                                           ptr(w), ptr(T), ptr(out), ptr(radii), ptr(ws.buf), ws.nbytes, ws.cap, 0,
                                           stream()), "mgr_views_forward")
 
@@ -296,8 +323,8 @@ class HipViewCompute:
             st_g, st_v = e((N,), "grad2d"), e((N,), "vis")
             st_r = torch.empty(N, dtype=torch.int32, device=dev)
             d_w = torch.empty((na, B), dtype=torch.float32, device=dev) if na else None
-            check(lib().mgr_views_backward(V, N, B, na, W, H, ptr(cams), ptr(bg), ptr(p["_xyz"]), ptr(p["_scaling"]),
-                                           ptr(p["_rotation"]), ptr(op), ptr(p["_features_dc"]), ptr(p["_features_rest"]),
+            check(lib().mgr_views_backward(V, N, B, na, sh_half, W, H, ptr(cams), ptr(bg), ptr(p["_xyz"]), ptr(p["_scaling"]),
+                                           ptr(p["_rotation"]), ptr(op), ptr(p["_features_dc"]), ptr(f_rest),
                                            ptr(w), ptr(T), ptr(radii), ptr(out), ptr(g_img), 1.0 / scale, ptr(d_xyz),
                                            ptr(d_ls), ptr(d_rot), ptr(d_op), ptr(d_fdc), ptr(d_frest), ptr(d_w), ptr(st_g),
                                            ptr(st_v), ptr(st_r), ptr(ws.buf), ws.nbytes, ws.cap, 0, stream()),
@@ -454,6 +481,8 @@ class Trainer:
         # ---- on_before_optimizer_step + optimizer.step() ----
         self.opt.update_learning_rate(gs)
         self.opt.step(out["grads"])       # skips the groups replaced above (all of them after a densify / prune)
+        if hasattr(self.compute, "mark_params_changed"):
+            self.compute.mark_params_changed()
         self.global_step += 1
         if resized:
             n_art = None

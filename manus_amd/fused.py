@@ -45,8 +45,10 @@ class _RenderViews(torch.autograd.Function):
         out = torch.empty((V, 3, H, W), dtype=torch.float32, device=dev)
         radii = torch.empty((V, N), dtype=torch.int32, device=dev)
 
+        sh_half = 0   # the autograd node reads the fp32 leaves (fp16 SH storage is an option of the training engine)
+
         def launch(ws):
-            check(lib().mgr_views_forward(V, N, B, n_art, W, H, ptr(cams), ptr(bg), ptr(xyz), ptr(log_scale), ptr(rot),
+            check(lib().mgr_views_forward(V, N, B, n_art, sh_half, W, H, ptr(cams), ptr(bg), ptr(xyz), ptr(log_scale), ptr(rot),
                                           ptr(opacity), ptr(f_dc), ptr(f_rest), ptr(skin_w), ptr(transforms),
                                           ptr(out), ptr(radii), ptr(ws.buf), ws.nbytes, ws.cap, 0, stream()),
                   "mgr_views_forward")
@@ -81,7 +83,8 @@ class _RenderViews(torch.autograd.Function):
         d_w = e(n_art, B) if skin_w is not None else None
         st_g, st_v = (e(N, name="grad2d"), e(N, name="vis")) if stats is not None else (None, None)
         st_r = torch.empty(N, dtype=torch.int32, device=dev) if stats is not None else None
-        check(lib().mgr_views_backward(V, N, B, n_art, W, H, ptr(cams), ptr(bg), ptr(xyz), ptr(log_scale), ptr(rot),
+        sh_half = 0
+        check(lib().mgr_views_backward(V, N, B, n_art, sh_half, W, H, ptr(cams), ptr(bg), ptr(xyz), ptr(log_scale), ptr(rot),
                                        ptr(opacity), ptr(f_dc), ptr(f_rest), ptr(skin_w), ptr(transforms),
                                        ptr(radii), ptr(out), ptr(g_img), g2s, ptr(d_xyz), ptr(d_ls), ptr(d_rot),
                                        ptr(d_op), ptr(d_fdc), ptr(d_frest), ptr(d_w), ptr(st_g), ptr(st_v),

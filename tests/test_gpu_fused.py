@@ -201,3 +201,36 @@ def test_fused_matches_oracle_on_identical_blend_inputs(kind, views):
     np.testing.assert_array_equal(out["vis"].cpu().numpy(), vis_cnt)
     np.testing.assert_array_equal(out["radii"].cpu().numpy(), radii.max(0))
     print(kind, views, "fused-vs-oracle grad max-rel-err:", {k: "%.1e" % e for k, e in errs.items()})
+
+
+@pytest.mark.parametrize("kind", ["hand", "composite"])
+def test_fp16_sh_storage_is_exact_on_representable_coefficients(kind):
+    """BASELINE config 5's "fp16 SH coeffs" is a STORAGE option (the reference has none: everything is fp32): with
+    coefficients that are exactly representable in fp16 the fp16-storage step equals the fp32-storage step to fp32
+    roundoff (same fp32 arithmetic on the same values), and with arbitrary coefficients it differs from the fp32 render by
+    no more than the storage rounding (2^-11 relative per coefficient)."""
+    from manus_amd.engine import HipViewCompute
+    sc, ct = _scene(kind, n=5000, views=3)
+    tg = torch.rand((3, 3, 64, 96), device=DEV)
+    exact = dict(sc)
+    exact["params"] = dict(sc["params"], _features_rest=sc["params"]["_features_rest"].half().float())
+    a = HipViewCompute(exact, tg, ct, loss="l1+ssim", sh_storage="fp32")([0, 1, 2], 1.0 / 3)
+    h16 = HipViewCompute(exact, tg, ct, loss="l1+ssim", sh_storage="fp16")
+    b = h16([0, 1, 2], 1.0 / 3)
+    assert h16._sh_copy.dtype == torch.float16 and h16._sh_copy.shape == (5000, 48)
+    for k in a["grads"]:   # (two instantiations of the same source: fma contraction may differ in the last bit)
+        assert max_rel_err(a["grads"][k].cpu().numpy(), b["grads"][k].cpu().numpy()) < 2e-5, k
+    assert max_rel_err(a["grad2d"].cpu().numpy(), b["grad2d"].cpu().numpy()) < 2e-5
+    assert abs(float(a["loss"]) - float(b["loss"])) < 1e-7
+    # arbitrary coefficients: the only difference is the rounding of the stored coefficients
+    f32 = HipViewCompute(sc, tg, ct, loss="l1+ssim", sh_storage="fp32")
+    f16 = HipViewCompute(sc, tg, ct, loss="l1+ssim", sh_storage="fp16")
+    f32([0, 1, 2], 1.0 / 3), f16([0, 1, 2], 1.0 / 3)
+    d = (f32.last_image - f16.last_image).abs()
+    assert 0 < float(d.max()) < 2e-3 and float(d.mean()) < 2e-5
+    # the copy follows the leaves: after an in-place update it is refreshed lazily
+    with torch.no_grad():
+        f16.params["_features_rest"].mul_(0.5)
+    f16.mark_params_changed()
+    f16([0, 1, 2], 1.0 / 3)
+    assert torch.equal(f16._sh_copy[:, :45].float(), f16.params["_features_rest"].detach().reshape(5000, 45).half().float())
