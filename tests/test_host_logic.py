@@ -202,7 +202,20 @@ def _oracle_compute(scene):
     return fn
 
 
-def _worker(rank, world, port, q):
+def _sparse(fn, n):
+    """Wrap a compute_fn so that two of every seven Gaussians receive no gradient at all (rows exactly zero, like
+    Gaussians hidden behind saturated pixels), keeping the visibility count dense."""
+    def g(view_ids, scale):
+        o = fn(view_ids, scale)
+        keep = (torch.arange(n) % 7) < 5
+        for k in o["grads"]:
+            o["grads"][k] = o["grads"][k] * keep.reshape((-1,) + (1,) * (o["grads"][k].dim() - 1))
+        o["grad2d"] = o["grad2d"] * keep
+        return o
+    return g
+
+
+def _worker(rank, world, port, q, compact=False):
     sys.path.insert(0, ROOT)
     from manus_amd.engine import ViewShardedStep
     from manus_amd.synthetic import make_scene
@@ -211,8 +224,11 @@ def _worker(rank, world, port, q):
     torch.set_num_threads(1)
     sc = make_scene(n_gaussians=300, kind="hand", seed=4, grid_res=12, n_cameras=5, width=32, height=32)
     shapes = {k: v.shape for k, v in sc["params"].items()}
-    st = ViewShardedStep(300, shapes, _oracle_compute(sc), 5, rank=rank, world_size=world)
+    fn = _oracle_compute(sc)
+    st = ViewShardedStep(300, shapes, _sparse(fn, 300) if compact else fn, 5, rank=rank, world_size=world, compact=compact)
     out = st.step()
+    if compact:
+        assert 0 < st.last_rows < 300            # fewer rows travelled than there are Gaussians
     assert float(out["overflow"]) == 0.0
     st.reduce_max_radii(out["radii"])        # the per-step collective carries sums only; the maximum is combined on demand
     if rank == 0:
@@ -222,7 +238,8 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_view_sharded_step_gloo_world2():
+@pytest.mark.parametrize("compact", [False, True])
+def test_view_sharded_step_gloo_world2(compact):
     from manus_amd.engine import GRAD_WIDTH, ViewShardedStep, shard_views
     from manus_amd.synthetic import make_scene
     assert GRAD_WIDTH == 59
@@ -231,7 +248,7 @@ def test_view_sharded_step_gloo_world2():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, compact)) for r in range(2)]
     for p in procs:
         p.start()
     got = q.get(timeout=180)
@@ -241,7 +258,8 @@ def test_view_sharded_step_gloo_world2():
     # single-process reference: all 5 views on one rank
     sc = make_scene(n_gaussians=300, kind="hand", seed=4, grid_res=12, n_cameras=5, width=32, height=32)
     shapes = {k: v.shape for k, v in sc["params"].items()}
-    ref = ViewShardedStep(300, shapes, _oracle_compute(sc), 5).step()
+    fn = _oracle_compute(sc)
+    ref = ViewShardedStep(300, shapes, _sparse(fn, 300) if compact else fn, 5).step()
     for k in ref["grads"]:
         assert got["grads"][k].shape == ref["grads"][k].shape
         assert torch.allclose(got["grads"][k], ref["grads"][k], rtol=1e-4, atol=1e-6 * float(ref["grads"][k].abs().max())), k
