@@ -52,7 +52,13 @@ def remove_nans_from_checkpoint(checkpoint):
 
 def load_checkpoint(ckpt_path, device=torch.device("cpu")):
     """(weights without the "model." prefix, extra_params) of a MANUS checkpoint (train_utils.py:193-204)."""
-    ckpt = torch.load(ckpt_path, map_location=device, weights_only=False)
+    # tensors + plain containers load under the safe unpickler; a real Lightning checkpoint may carry other pickled
+    # objects (hyper-parameter containers), for which the reference's own behaviour -- full unpickling of a file the
+    # user trained themselves -- is the fallback
+    try:
+        ckpt = torch.load(ckpt_path, map_location=device, weights_only=True)
+    except Exception:
+        ckpt = torch.load(ckpt_path, map_location=device, weights_only=False)
     ckpt = remove_nans_from_checkpoint(ckpt)
     weights = ckpt["state_dict"]
     for key in list(weights):
@@ -65,7 +71,9 @@ def get_num_gaussians_from_checkpoint(ckpt_path):
 
 
 def save_checkpoint(ckpt_dir, params, epoch, step, loss, grid=None, mano_weights=None, extra_state=None):
-    """Write a checkpoint the reference can resume from.  params: the six leaves by attribute name (`_xyz`, ...);
+    """Write a checkpoint the reference's `load_checkpoint` / `on_load_checkpoint` read back (train_utils.py:193-204,
+    hand_dynamic.py:284-293): epoch, global_step, state_dict, extra_params.  (It is not a full Lightning
+    `fit(ckpt_path=...)` resume file: no optimizer_states / loops keys.)  params: the six leaves by attribute name (`_xyz`, ...);
     grid: dict with grid_scale / grid_center / grid_points / grid_weights (voxel skin weights) or
     mano_weights: (N,B) per-Gaussian skin weights.  Returns the path."""
     sd = {}

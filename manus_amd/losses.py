@@ -46,10 +46,41 @@ class _ImageLoss(torch.autograd.Function):
         return (gh[None] if ctx.batched else gh), None, None, None
 
 
+class _L1Map(torch.Tensor):
+    """What `l1_loss(..., mean=False)` returns: the reference's loss_func takes the |pred - gt| map and reduces it
+    with torch.mean itself (base.py:329-331).  The map is never materialised: `.mean()` / `torch.mean(x)` runs the
+    fused kernel (value + gradient in one pass); any other use falls back to the explicit map of this same kernel's
+    inputs being subtracted on the device."""
+
+    @staticmethod
+    def __new__(cls, pred, gt):
+        t = torch.Tensor._make_subclass(cls, torch.empty(0, device=pred.device))
+        t._pred, t._gt = pred, gt
+        return t
+
+    def mean(self, *a, **k):
+        if a or k:
+            return torch.abs(self._pred - self._gt).mean(*a, **k)
+        return _ImageLoss.apply(self._pred, self._gt, 1.0, 0.0)
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if func is torch.mean and len(args) == 1 and not kwargs and isinstance(args[0], _L1Map):
+            return args[0].mean()
+        if func is torch.Tensor.mean and len(args) == 1 and not kwargs:
+            return args[0].mean()
+        with torch._C.DisableTorchFunctionSubclass():
+            args = tuple(torch.abs(a._pred - a._gt) if isinstance(a, _L1Map) else a for a in args)
+            return func(*args, **kwargs)
+
+
 def l1_loss(network_output, gt, mean=True):
-    """torch.abs(network_output - gt).mean()  (loss_utils.py:22-27)."""
+    """loss_utils.py:22-27: torch.abs(network_output - gt).mean() when mean=True; with mean=False the reference
+    returns the map and its caller takes torch.mean of it (base.py:329-331) -- that composition runs the same fused
+    kernel here."""
     if not mean:
-        raise ManusHipError("l1_loss: only the mean=True form is fused")
+        return _L1Map(network_output, gt)
     return _ImageLoss.apply(network_output, gt, 1.0, 0.0)
 
 

@@ -25,6 +25,14 @@ def test_reference_shaped_losses_match_golden(golden_dir):
         (g,) = torch.autograd.grad(l1, pred)
         assert abs(l1.item() - float(d[f"l1_{k}"])) < 1e-6
         np.testing.assert_allclose(g.cpu().numpy(), d[f"g_l1_{k}"], rtol=0, atol=1e-9)
+        # the form loss_func itself uses: l1_loss(pred, gt, mean=False) followed by torch.mean (base.py:329-331)
+        pred = torch.tensor(d[f"pred{k}"], device=DEV, requires_grad=True)
+        for reduce in (torch.mean, lambda m: m.mean()):
+            l1m = reduce(losses.l1_loss(pred, gt, mean=False))
+            (g,) = torch.autograd.grad(l1m, pred)
+            assert abs(l1m.item() - float(d[f"l1_{k}"])) < 1e-6
+            np.testing.assert_allclose(g.cpu().numpy(), d[f"g_l1_{k}"], rtol=0, atol=1e-9)
+        assert abs(float((losses.l1_loss(pred, gt, mean=False) * 2.0).mean()) - 2 * float(d[f"l1_{k}"])) < 1e-6  # any other use
         pred = torch.tensor(d[f"pred{k}"], device=DEV, requires_grad=True)
         ss = losses.ssim(pred, gt)
         (g,) = torch.autograd.grad(ss, pred)
