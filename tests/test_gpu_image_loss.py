@@ -32,7 +32,7 @@ def test_reference_shaped_losses_match_golden(golden_dir):
             (g,) = torch.autograd.grad(l1m, pred)
             assert abs(l1m.item() - float(d[f"l1_{k}"])) < 1e-6
             np.testing.assert_allclose(g.cpu().numpy(), d[f"g_l1_{k}"], rtol=0, atol=1e-9)
-        assert abs(float((losses.l1_loss(pred, gt, mean=False) * 2.0).mean()) - 2 * float(d[f"l1_{k}"])) < 1e-6  # any other use
+        assert abs(float((losses.l1_loss(pred, gt, mean=False) * 2.0).mean().detach()) - 2 * float(d[f"l1_{k}"])) < 1e-6  # any other use
         pred = torch.tensor(d[f"pred{k}"], device=DEV, requires_grad=True)
         ss = losses.ssim(pred, gt)
         (g,) = torch.autograd.grad(ss, pred)
