@@ -11,7 +11,7 @@ mkdir -p profiles gpurun_out
 tools/pmc_collect.sh ${TAG} "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES GRBM_GUI_ACTIVE"
 python tools/pmc_summary.py gpurun_out/pmc_${TAG}_0 gpurun_out/pmc_${TAG}_1 gpurun_out/pmc_${TAG}_2 gpurun_out/pmc_${TAG}_3 \
     --json gpurun_out/pmc_${TAG}.json --workload 300000,8,1920,1080 > gpurun_out/pmc_${TAG}.txt
-cp gpurun_out/pmc_${TAG}.json profiles/${RND}_pmc.json       # bench.py reads this for roofline.traffic / valu_issue_frac
+cp gpurun_out/pmc_${TAG}.json profiles/${RND}_pmc.json       # (on the box: so that the bench run below reads THIS pass; tools/pull_profiles.sh copies the summaries home)
 cp gpurun_out/pmc_${TAG}.txt profiles/${RND}_${TAG}_pmc.txt
 rm -rf gpurun_out/prof_$TAG
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof_$TAG -o run -- python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $ROOT/gpurun_out/prof_$TAG.log 2>&1)
