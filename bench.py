@@ -254,6 +254,8 @@ def main():
     ap.add_argument("--sh-storage", default="fp32", choices=["fp32", "fp16"],
                     help="storage of _features_rest read by the render kernels (fp16 = BASELINE config 5's option; the "
                          "headline number and the parity block use fp32, like the reference)")
+    ap.add_argument("--dense-allreduce", action="store_true",
+                    help="N > 1: all-reduce all 61 N floats instead of only the rows that received a gradient on some rank")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (cpu_baseline and parity)")
     ap.add_argument("--parity-views", type=int, default=2, help="views of the step run through the CPU oracle")
     ap.add_argument("--profile-all", action="store_true", help="print a per-kernel HIP-event breakdown to stderr")
@@ -291,7 +293,10 @@ def main():
     rasterizer.context(dev).clear()
     compute = HipViewCompute(scene, targets, ct, loss=args.loss, sh_storage=args.sh_storage)
     shapes = {k: v.shape for k, v in compute.params.items()}
-    step = ViewShardedStep(N, shapes, compute, V, rank=rank, world_size=world)
+    # N > 1: only the rows with a gradient on some rank travel (exact: the others are zero everywhere; 43 % of the rows
+    # in this scene) -- xGMI is point-to-point, the all-reduce is the part of the step that does not shrink with N
+    step = ViewShardedStep(N, shapes, compute, V, rank=rank, world_size=world,
+                           compact=world > 1 and not args.dense_allreduce)
     V_local = len(step.local_views)
     opt = None
     if args.optimizer:
@@ -419,6 +424,8 @@ def main():
                                    "(n_poses=%d), image loss %s, fwd+bwd to leaf grads" % (N, V, W, H, n_poses, "0.8*L1 + 0.2*(1-SSIM)" if args.loss == "l1+ssim" else "L1"),
                        "gaussians": N, "views": V, "width": W, "height": H, "views_per_gpu": V_local,
                        "pairs_per_view": int(R_view), "parallelism": "views/%d" % world,
+                       "allreduce": (None if world == 1 else "dense 61N floats" if args.dense_allreduce else
+                                     "rows with a gradient (%s of %d) x 60 floats + 2N bytes" % (step.last_rows, N)),
                        "optimizer_in_step": bool(args.optimizer), "sh_storage": args.sh_storage,
                        "nonfinite_grad_values": nonfinite},
             "roofline": roof, "cpu_baseline": cpu, "parity": parity,
