@@ -150,6 +150,11 @@ int mgr_views_backward(int V, int N, int B, int n_articulated, int sh_half, int 
                        int32_t* stat_radii, void* workspace, size_t workspace_bytes,
                        int64_t pair_capacity, int debug, void* stream);
 
+/* Device pointers (into the workspace) to the compacted list of Gaussians that received a gradient in the last
+ * mgr_views_backward and to its length; V <= 8. */
+int mgr_views_active_list(void* workspace, int V, int N, int W, int H, int64_t pair_capacity, const uint32_t** list,
+                          const uint32_t** count);
+
 /* f_rest (N,45) fp32 -> out_half (N,48) fp16 (round to nearest even, 3 halves of zero padding per row). */
 int mgr_sh_to_half(int N, const float* f_rest, void* out_half, void* stream);
 
@@ -191,6 +196,13 @@ int mgr_skin_weights_fwd(int N, const float* xyz, const float* grid, int D, int 
 int mgr_skin_weights_bwd(int N, const float* xyz, const float* grid, int D, int H, int W, int B,
                          int grid_stride, const float* center3, const float* scale3,
                          const float* dL_dw, float* dL_dxyz, int accumulate, void* stream);
+/* The same for the Gaussians index[0 .. *index_count) only (device list + device count <= max_count, e.g. the active
+ * list of mgr_views_active_list: rows of dL_dw that received nothing are zero and contribute nothing); entries >= N
+ * (static Gaussians of a composite) are skipped; always accumulates. */
+int mgr_skin_weights_bwd_indexed(int N, const float* xyz, const float* grid, int D, int H, int W, int B,
+                                 int grid_stride, const float* center3, const float* scale3, const float* dL_dw,
+                                 float* dL_dxyz, const uint32_t* index, const uint32_t* index_count, int max_count,
+                                 void* stream);
 
 /* LBS for P poses.  transforms: (P,B,16) row-major 4x4 bone transforms
  * T_b = posed_b * inv(rest_b) (+ identity background).  skin_w (N,B) or NULL for

@@ -86,8 +86,12 @@ __global__ __launch_bounds__(256) void k_skin_bwd(int N, const float* __restrict
                                                   int B, const float* __restrict__ center,
                                                   const float* __restrict__ scale,
                                                   const float* __restrict__ dL_dw,
-                                                  float* __restrict__ dL_dxyz, int accumulate) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+                                                  float* __restrict__ dL_dxyz, int accumulate,
+                                                  const uint32_t* __restrict__ index,
+                                                  const uint32_t* __restrict__ index_count) {
+    const int t = blockIdx.x * 256 + threadIdx.x;   // (the indexed launch covers the list's maximum length)
+    if (index ? (uint32_t)t >= *index_count : t >= N) return;
+    const int i = index ? (int)index[t] : t;
     if (i >= N) return;
     const TriSetup s = tri_setup(xyz, i, center, scale, D, H, W);
     // pass 1: S = sum raw, dot = sum_c dLdw_c * raw_c
@@ -184,8 +188,13 @@ __global__ __launch_bounds__(256) void k_skin_bwd24(int N, const float* __restri
                                                     int B, const float* __restrict__ center,
                                                     const float* __restrict__ scale,
                                                     const float* __restrict__ dL_dw,
-                                                    float* __restrict__ dL_dxyz, int accumulate) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+                                                    float* __restrict__ dL_dxyz, int accumulate,
+                                                    const uint32_t* __restrict__ index,
+                                                    const uint32_t* __restrict__ index_count) {
+    // index != nullptr: only the Gaussians index[0 .. *index_count) (the backward's active list) are processed
+    const int t = blockIdx.x * 256 + threadIdx.x;   // (the indexed launch covers the list's maximum length)
+    if (index ? (uint32_t)t >= *index_count : t >= N) return;
+    const int i = index ? (int)index[t] : t;
     if (i >= N) return;
     const TriSetup s = tri_setup(xyz, i, center, scale, D, H, W);
     float a[SKIN_BP];
@@ -559,27 +568,46 @@ extern "C" int mgr_skin_weights_fwd(int N, const float* xyz, const float* grid, 
     return MGR_OK;
 }
 
-extern "C" int mgr_skin_weights_bwd(int N, const float* xyz, const float* grid, int D, int H, int W,
-                                    int B, int grid_stride, const float* center3, const float* scale3,
-                                    const float* dL_dw, float* dL_dxyz, int accumulate, void* stream_) {
+static int skin_weights_bwd_impl(int N, const float* xyz, const float* grid, int D, int H, int W, int B, int grid_stride,
+                                 const float* center3, const float* scale3, const float* dL_dw, float* dL_dxyz,
+                                 int accumulate, const uint32_t* index, const uint32_t* index_count, int max_count,
+                                 void* stream_) {
     if (N < 0 || B <= 0 || B > MGR_MAX_BONES || D <= 0 || H <= 0 || W <= 0)
         return mgr_fail(MGR_EINVAL, "mgr_skin_weights_bwd: bad sizes");
     if (N == 0) return MGR_OK;
-    if (!xyz || !grid || !center3 || !scale3 || !dL_dw || !dL_dxyz)
+    if (!xyz || !grid || !center3 || !scale3 || !dL_dw || !dL_dxyz || (index && !index_count))
         return mgr_fail(MGR_EINVAL, "mgr_skin_weights_bwd: null pointer");
     hipStream_t stream = (hipStream_t)stream_;
+    const int n_threads = index ? max_count : N;
+    if (n_threads <= 0) return MGR_OK;
     if (grid_stride != B && grid_stride != SKIN_BP) return mgr_fail(MGR_EINVAL, "mgr_skin_weights_bwd: grid_stride must be B or 24");
     if (grid_stride == SKIN_BP && B <= SKIN_BP && ((uintptr_t)grid & 15) == 0) {
-        { MGR_PROF("k_skin_bwd24", stream); hipLaunchKernelGGL(k_skin_bwd24, dim3((N + 255) / 256), dim3(256), 0, stream, N, xyz, (const float4*)grid, D, H, W, B,
-                           center3, scale3, dL_dw, dL_dxyz, accumulate); }
+        { MGR_PROF("k_skin_bwd24", stream); hipLaunchKernelGGL(k_skin_bwd24, dim3((n_threads + 255) / 256), dim3(256), 0, stream, N, xyz, (const float4*)grid, D, H, W, B,
+                           center3, scale3, dL_dw, dL_dxyz, accumulate, index, index_count); }
         MGR_LAUNCH_CHECK("k_skin_bwd24", stream, 0);
         return MGR_OK;
     }
     if (grid_stride != B) return mgr_fail(MGR_EINVAL, "mgr_skin_weights_bwd: padded grid must be 16-byte aligned with B <= 24");
-    { MGR_PROF("k_skin_bwd", stream); hipLaunchKernelGGL(k_skin_bwd, dim3((N + 255) / 256), dim3(256), 0, stream, N, xyz, grid, D, H, W, B,
-                       center3, scale3, dL_dw, dL_dxyz, accumulate); }
+    { MGR_PROF("k_skin_bwd", stream); hipLaunchKernelGGL(k_skin_bwd, dim3((n_threads + 255) / 256), dim3(256), 0, stream, N, xyz, grid, D, H, W, B,
+                       center3, scale3, dL_dw, dL_dxyz, accumulate, index, index_count); }
     MGR_LAUNCH_CHECK("k_skin_bwd", stream, 0);
     return MGR_OK;
+}
+
+extern "C" int mgr_skin_weights_bwd(int N, const float* xyz, const float* grid, int D, int H, int W,
+                                    int B, int grid_stride, const float* center3, const float* scale3,
+                                    const float* dL_dw, float* dL_dxyz, int accumulate, void* stream_) {
+    return skin_weights_bwd_impl(N, xyz, grid, D, H, W, B, grid_stride, center3, scale3, dL_dw, dL_dxyz, accumulate, nullptr,
+                                 nullptr, 0, stream_);
+}
+
+extern "C" int mgr_skin_weights_bwd_indexed(int N, const float* xyz, const float* grid, int D, int H, int W, int B,
+                                            int grid_stride, const float* center3, const float* scale3,
+                                            const float* dL_dw, float* dL_dxyz, const uint32_t* index,
+                                            const uint32_t* index_count, int max_count, void* stream_) {
+    if (!index || !index_count || max_count < 0) return mgr_fail(MGR_EINVAL, "mgr_skin_weights_bwd_indexed: bad arguments");
+    return skin_weights_bwd_impl(N, xyz, grid, D, H, W, B, grid_stride, center3, scale3, dL_dw, dL_dxyz, 1, index, index_count,
+                                 max_count, stream_);
 }
 
 extern "C" int mgr_lbs_cov_fwd(int P, int N, int B, const float* xyz, const float* log_scale,

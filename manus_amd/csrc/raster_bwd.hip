@@ -65,8 +65,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     const uint32_t n_items = hdr->n_items;
     if (blockIdx.x == 0 && tid == 0) hdr->n_active = 0;  // for the gather that follows (first view group)
     const size_t P = (size_t)W * H;
-    // screen-space mean gradient: d(pixel)/d(ndc) = W/2, H/2; ln2 from the log2-domain conic
-    const float kx = MGR_LN2 * 0.5f * (float)W, ky = MGR_LN2 * 0.5f * (float)H;
     const unsigned long long lt = (1ull << lane) - 1ull;
     float* const slab = &s_pair[wave][0][0];
 
@@ -224,22 +222,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
                         w2.y = w;
                         da2.y = vb ? d : 0.0f;
                     }
-                    const mgr_v2f A2 = {R1.x, R1.y}, B2 = {R1.z, R1.w}, C2 = {R2.x, R2.y}, o2 = {R2.z, R2.w};
+                    // Per pixel only the five moments of q = dL/dG * G are formed; the conic / mean factors that are
+                    // constant per Gaussian are applied once per (tile, Gaussian) record in the flush below:
+                    //   dL/dmean2D.x = -W/2 (A Sx + B Sy),  dL/dmean2D.y = -H/2 (C Sy + B Sx),
+                    //   dL/dconic    = -1/2 (Sxx, Sxy, Syy)          
+                    const mgr_v2f o2 = {R2.z, R2.w};
                     const mgr_v2f v_r = w2 * g0v, v_g = w2 * g1v, v_b = w2 * g2v;
-                    const mgr_v2f dG = o2 * da2;
-                    const mgr_v2f gdx = G * dx, gdy = G * dy;
-                    const mgr_v2f Bh = B2 * 0.5f;
-                    // dG/ddx = -gdx conic.x - gdy conic.y = 2 ln2 (A gdx + B/2 gdy)
-                    const mgr_v2f v_mx = dG * (A2 * gdx + Bh * gdy) * (2.0f * kx);
-                    const mgr_v2f v_my = dG * (C2 * gdy + Bh * gdx) * (2.0f * ky);
-                    const mgr_v2f h = dG * -0.5f;
-                    const mgr_v2f hx = h * gdx, hy = h * gdy;
-                    const mgr_v2f v_ca = hx * dx, v_cb = hx * dy, v_cc = hy * dy;
                     const mgr_v2f v_op = G * da2;
+                    const mgr_v2f q = o2 * v_op;
+                    const mgr_v2f qx = q * dx, qy = q * dy;
+                    const mgr_v2f s_xx = qx * dx, s_xy = qx * dy, s_yy = qy * dy;
                     // slots 0..7 by the two-at-a-time exchange reduction, slot 8 (blue) for both
                     // entries at once: halves exchanged, then summed inside each 32-lane half
-                    const float w8a = mgr_wave_reduce8(v_mx.x, v_my.x, v_ca.x, v_cb.x, v_cc.x, v_op.x, v_r.x, v_g.x, lane);
-                    const float w8b = mgr_wave_reduce8(v_mx.y, v_my.y, v_ca.y, v_cb.y, v_cc.y, v_op.y, v_r.y, v_g.y, lane);
+                    const float w8a = mgr_wave_reduce8(qx.x, qy.x, s_xx.x, s_xy.x, s_yy.x, v_op.x, v_r.x, v_g.x, lane);
+                    const float w8b = mgr_wave_reduce8(qx.y, qy.y, s_xx.y, s_xy.y, s_yy.y, v_op.y, v_r.y, v_g.y, lane);
                     float ba = v_b.x, bb = v_b.y;
                     mgr_swap32(ba, bb);
                     float b9 = ba + bb;              // lanes 0-31: entry a, lanes 32-63: entry b
@@ -280,9 +276,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
 #pragma unroll
                         for (int c = 0; c < 9; ++c) r[c] += s_acc[w][tid][c];
                     }
+                // r = [Sx, Sy, Sxx, Sxy, Syy, dopacity, dr, dg, db]: apply the per-Gaussian factors
+                const MgrGRec* rec = gv + s_gid[tid];
+                const float4 ra4 = *(const float4*)rec;
+                const float cA = ra4.z, cB = ra4.w, cC = (*((const float4*)rec + 1)).x;
+                const float mx = (-0.5f * (float)W) * (cA * r[0] + cB * r[1]);
+                const float my = (-0.5f * (float)H) * (cC * r[1] + cB * r[0]);
                 float4* o = pair_grad + (size_t)slot * 3;
-                o[0] = make_float4(r[0], r[1], r[2], r[3]);
-                o[1] = make_float4(r[4], r[5], r[6], r[7]);
+                o[0] = make_float4(mx, my, -0.5f * r[2], -0.5f * r[3]);
+                o[1] = make_float4(-0.5f * r[4], r[5], r[6], r[7]);
                 o[2] = make_float4(r[8], 0.f, 0.f, 0.f);
                 pair_tag[slot] = epoch;
                 inst_tag[(size_t)v * N + s_gid[tid]] = epoch;  // "this (view, Gaussian) has records": lets the gather skip the rest
@@ -771,6 +773,20 @@ static int raster_backward_impl(int V, int N, int W, int H, const float* cams, c
                        dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dcov3D,
                        (const uint32_t*)(ws + L.inst_tag), (uint32_t)cap, epoch); }
     MGR_LAUNCH_CHECK("k_preprocess_bwd", stream, debug);
+    return MGR_OK;
+}
+
+// Device pointers to the list of Gaussians that received a gradient in the most recent mgr_views_backward on this
+// workspace and to its length (valid for V <= 8: one view group; more views leave the last group's list).
+extern "C" int mgr_views_active_list(void* workspace, int V, int N, int W, int H, int64_t cap, const uint32_t** list,
+                                     const uint32_t** count) {
+    if (!workspace || !list || !count || V <= 0 || N <= 0) return mgr_fail(MGR_EINVAL, "mgr_views_active_list: bad arguments");
+    if (V > 8) return mgr_fail(MGR_EINVAL, "mgr_views_active_list: only defined for up to 8 views (one lane group)");
+    const MgrLayout L = mgr_layout(V, N, W, H, cap);
+    const int Gv = V <= 1 ? 1 : V <= 2 ? 2 : V <= 4 ? 4 : 8;
+    char* ws = (char*)workspace;
+    *list = (const uint32_t*)(ws + L.inst_grad + (size_t)N * Gv * 48);
+    *count = &((const MgrHeader*)(ws + L.header))->n_active;
     return MGR_OK;
 }
 

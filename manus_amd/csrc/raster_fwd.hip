@@ -602,10 +602,15 @@ __device__ __forceinline__ void lds_radix_sort(unsigned long long (&keys)[E], ui
         for (int r = 0; r < E; ++r) keys[r] = s_keys[wave * (64 * E) + r * 64 + lane];
         __syncthreads();
     }
-    // keys -> LDS in final order, then order equal-depth neighbours by Gaussian index
+    // keys -> LDS in final order (by depth bits; equal depths still in arbitrary order: lds_sort_ties below)
 #pragma unroll
     for (int r = 0; r < E; ++r) s_keys[wave * (64 * E) + r * 64 + lane] = keys[r];
     __syncthreads();
+}
+
+// Equal-depth neighbours ordered by Gaussian index (the upstream tie-break): odd-even sweeps until nothing moves.
+// Exact depth ties are rare, so the caller only comes here after it has seen one while writing the result out.
+__device__ __forceinline__ void lds_sort_ties(unsigned long long* s_keys, uint32_t n, int tid) {
     for (;;) {
         int changed = 0;
         for (int phase = 0; phase < 2; ++phase) {
@@ -638,8 +643,21 @@ __device__ __forceinline__ void lds_sort_emit(const unsigned long long* __restri
     else if (n <= 8192u) MGR_RADIX_CASE(8)
     else MGR_RADIX_CASE(16)
 #undef MGR_RADIX_CASE
-    for (uint32_t t = (uint32_t)tid; t < n; t += 1024u) out[t] = (uint32_t)s_keys[t];
-    __syncthreads();
+    // write the ids out and look for an out-of-order equal-depth pair on the way (one pass, no extra barrier rounds)
+    int tie = 0;
+    for (uint32_t t = (uint32_t)tid; t < n; t += 1024u) {
+        const unsigned long long x = s_keys[t];
+        out[t] = (uint32_t)x;
+        if (t + 1 < n) {
+            const unsigned long long y = s_keys[t + 1];
+            tie |= ((x >> 32) == (y >> 32) && x > y) ? 1 : 0;
+        }
+    }
+    if (__syncthreads_or(tie)) {
+        lds_sort_ties(s_keys, n, tid);
+        for (uint32_t t = (uint32_t)tid; t < n; t += 1024u) out[t] = (uint32_t)s_keys[t];
+        __syncthreads();
+    }
 }
 
 // Giant segments (>= SORT_LDS_KEYS pairs): regroup the keys by depth range so that every group fits

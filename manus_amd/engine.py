@@ -379,7 +379,17 @@ class HipViewCompute:
                                            ptr(d_ls), ptr(d_rot), ptr(d_op), ptr(d_fdc), ptr(d_frest), ptr(d_w), ptr(st_g),
                                            ptr(st_v), ptr(st_r), ptr(ws.buf), ws.nbytes, ws.cap, 0, stream()),
                   "mgr_views_backward")
-            if na:   # d xyz += d w . d(trilinear weights)/d xyz  (the leaf is used twice: gaussian_utils.py:167-196)
+            if na and V <= 8:
+                # d xyz += d w . d(trilinear weights)/d xyz (the leaf is used twice: gaussian_utils.py:167-196), for the
+                # Gaussians that received a gradient only (the others' d_w rows are zero): the backward's active list
+                import ctypes
+                lst, cnt = ctypes.c_void_p(), ctypes.c_void_p()
+                check(lib().mgr_views_active_list(ptr(ws.buf), V, N, W, H, ws.cap, ctypes.byref(lst), ctypes.byref(cnt)),
+                      "mgr_views_active_list")
+                check(lib().mgr_skin_weights_bwd_indexed(na, ptr(p["_xyz"]), ptr(sg.data), sg.D, sg.H, sg.W, sg.B, sg.stride,
+                                                         ptr(s["grid_center"]), ptr(s["grid_scale"]), ptr(d_w), ptr(d_xyz),
+                                                         lst, cnt, N, stream()), "mgr_skin_weights_bwd_indexed")
+            elif na:
                 check(lib().mgr_skin_weights_bwd(na, ptr(p["_xyz"]), ptr(sg.data), sg.D, sg.H, sg.W, sg.B, sg.stride,
                                                  ptr(s["grid_center"]), ptr(s["grid_scale"]), ptr(d_w), ptr(d_xyz), 1,
                                                  stream()), "mgr_skin_weights_bwd")
