@@ -930,9 +930,14 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, 
         if (nlist >= 4096u) __builtin_amdgcn_s_setprio(3);
         else __builtin_amdgcn_s_setprio(0);
         __syncthreads();                       // everyone has read s_next
+        // The next ticket is drawn early (its latency hidden behind this tile) only for short lists.  Behind a long
+        // list an early ticket reserves one of the NEXT largest tiles for as long as this one takes: measured with the
+        // per-tile timeline, half of the tiles of more than 4096 pairs started 50-150 us late that way and one of
+        // them ended the kernel.  Long lists draw their ticket when they are done.
+        const bool early_ticket = nlist < 2048u;
         if (tid == 0) {
             s_max = 0;
-            s_next = atomicAdd(&hdr->queue_head2, 1u);  // next tile's index arrives while this one is blended
+            if (early_ticket) s_next = atomicAdd(&hdr->queue_head2, 1u);
         }
         float Tr = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
         uint32_t last = 0;
@@ -1048,6 +1053,7 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, 
         const uint32_t nchunks = (tmax + MGR_CHUNK - 1) / MGR_CHUNK;
         if (tid == 0) {
             tile_done[vt] = tmax;
+            if (!early_ticket) s_next = atomicAdd(&hdr->queue_head2, 1u);
             // backward work items: one per MGR_CHUNK entries actually consumed by this tile
             s_ibase = nchunks ? atomicAdd(&hdr->n_items, nchunks) : 0u;
         }
