@@ -927,7 +927,10 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, 
         const uint32_t ck0 = chunk_start[vt];  // checkpoint c (c >= 1) of this tile lives at ck0 + c - 1
         // The kernel ends when the deepest tiles end, and their waves share a SIMD with up to five
         // waves of ordinary tiles: long lists issue at raised priority, the rest fill the gaps.
-        if (nlist >= 4096u) __builtin_amdgcn_s_setprio(3);
+        // (graded by list length; measured: 0.369 ms with one threshold at 4096, 0.361 ms graded)
+        if (nlist >= 8192u) __builtin_amdgcn_s_setprio(3);
+        else if (nlist >= 2048u) __builtin_amdgcn_s_setprio(2);
+        else if (nlist >= 512u) __builtin_amdgcn_s_setprio(1);
         else __builtin_amdgcn_s_setprio(0);
         __syncthreads();                       // everyone has read s_next
         // The next ticket is drawn early (its latency hidden behind this tile) only for short lists.  Behind a long
