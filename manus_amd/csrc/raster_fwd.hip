@@ -514,6 +514,11 @@ __device__ __forceinline__ void bitonic_mirror(KeyPtr a, uint32_t n, uint32_t np
 
 // group index of a key among ascending splitters sp[1..G-1] (sp[g] = first key of group g)
 __device__ __forceinline__ int sort_group(const unsigned long long* sp, int G, unsigned long long key) {
+    if (G <= 8) {  // few groups (the usual case): count the splitters at or below the key -- uniform LDS addresses, no
+        int g = 0;  // data-dependent loop
+        for (int j = 1; j < G; ++j) g += key >= sp[j] ? 1 : 0;
+        return g;
+    }
     int lo = 0, hi = G - 1;  // invariant: key belongs to a group in [lo, hi]
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
@@ -660,12 +665,27 @@ __device__ __forceinline__ void lds_sort_emit(const unsigned long long* __restri
     }
 }
 
+#ifdef MGR_TIMELINE
+__device__ unsigned long long g_tl[2048 * 4];
+__device__ unsigned long long g_tl2[2048 * 4];
+__device__ unsigned long long g_tl3[8192 * 4];
+extern "C" int mgr_debug_timeline(void* dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_tl), sizeof(unsigned long long) * 2048 * 4);
+}
+extern "C" int mgr_debug_timeline3(void* dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_tl3), sizeof(unsigned long long) * 8192 * 4);
+}
+extern "C" int mgr_debug_timeline2(void* dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_tl2), sizeof(unsigned long long) * 2048 * 4);
+}
+#endif
+
 // Giant segments (>= SORT_LDS_KEYS pairs): regroup the keys by depth range so that every group fits
 // the LDS sort, and hand the groups to k_tile_sort as independent work items — the groups of one
 // tile are then sorted by different workgroups instead of one after another.
 // Per tile: 1024 sampled keys are sorted, G-1 of them become splitters, one pass counts the group
 // sizes and one pass scatters the keys into keys2 (group-contiguous, order inside a group arbitrary).
-#define SPLIT_UNROLL 4
+#define SPLIT_UNROLL 10
 __global__ __launch_bounds__(SORT_THREADS) void k_tile_split(
     const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ tile_queue,
     unsigned long long* __restrict__ keys, unsigned long long* __restrict__ keys2,
@@ -684,24 +704,40 @@ __global__ __launch_bounds__(SORT_THREADS) void k_tile_split(
         if (tid == 0) s_item[0] = atomicAdd(&hdr->split_head, 1u);
         __syncthreads();
         const uint32_t item = s_item[0];
+#ifdef MGR_TIMELINE
+        const unsigned long long tsp0 = wall_clock64();
+        if (item >= qlen && tid == 0 && blockIdx.x < 2048) { g_tl2[blockIdx.x * 4 + 2] = tsp0; }
+#endif
         if (item >= qlen) break;
         const uint32_t vt = tile_queue[item];
         const uint32_t start = min(tile_start[vt], cap), end = min(tile_start[vt + 1], cap);
         const uint32_t n = end - start;
         if (n == 0) continue;
         const int G = (int)((n + SORT_LDS_KEYS / 2 - 1) / (SORT_LDS_KEYS / 2));
+#ifdef MGR_TIMELINE
+        unsigned long long tq[6]; tq[0] = wall_clock64();
+#define TQ(k) tq[k] = wall_clock64()
+#else
+#define TQ(k)
+#endif
         bool fallback = G > SORT_MAX_GROUPS || n <= SORT_SAMPLES;
         if (!fallback) {
             for (uint32_t t = tid; t < SORT_SAMPLES; t += SORT_THREADS)
                 s_keys[t] = keys[start + (uint32_t)(((unsigned long long)t * n) / SORT_SAMPLES)];
             __syncthreads();
+            TQ(1);
             bitonic_mirror(s_keys, SORT_SAMPLES, SORT_SAMPLES, tid, SORT_THREADS);
+            TQ(2);
             if (tid <= G) s_sp[tid] = (tid == 0) ? 0ull : (tid == G ? ~0ull : s_keys[(tid * SORT_SAMPLES) / G]);
             for (int k = tid; k < (SORT_THREADS / 64) * (SORT_MAX_GROUPS + 1); k += SORT_THREADS) (&s_wcnt[0][0])[k] = 0;
             __syncthreads();
             // both passes over the keys keep SPLIT_UNROLL unconditional loads in flight per thread (clamped
             // index, masked afterwards): one predicated load per trip left the whole 1024-thread workgroup
             // waiting a full memory round trip 2 x n/1024 times
+            // The wave's group counters live in a register (lane g holds group g; G <= 64): a read-modify-write of an
+            // LDS counter by lane 0 per (key, group) was a chain of dependent LDS round trips -- 26 + 58 us per giant
+            // tile in the two passes (per-phase timeline, -DMGR_TIMELINE).
+            uint32_t wcnt = 0;
             for (uint32_t t0 = (uint32_t)(tid & ~63); t0 < n; t0 += SORT_THREADS * SPLIT_UNROLL) {  // group sizes
                 unsigned long long kk[SPLIT_UNROLL];
 #pragma unroll
@@ -711,12 +747,14 @@ __global__ __launch_bounds__(SORT_THREADS) void k_tile_split(
                     const uint32_t t = t0 + (uint32_t)u * SORT_THREADS + lane;
                     const int g = t < n ? sort_group(s_sp, G, kk[u]) : -1;
                     for (int gg = 0; gg < G; ++gg) {
-                        const unsigned long long mk = __ballot(g == gg);
-                        if (lane == 0 && mk) s_wcnt[wave][gg] += (uint32_t)__popcll(mk);
+                        const uint32_t c = (uint32_t)__popcll(__ballot(g == gg));
+                        wcnt += lane == gg ? c : 0u;
                     }
                 }
             }
+            if (lane < G) s_wcnt[wave][lane] = wcnt;
             __syncthreads();
+            TQ(3);
             if (tid < G) {  // group total; the rows become exclusive prefixes over the waves = each wave's cursor
                 uint32_t run = 0;
                 for (int w = 0; w < SORT_THREADS / 64; ++w) {
@@ -741,6 +779,8 @@ __global__ __launch_bounds__(SORT_THREADS) void k_tile_split(
             fallback = s_item[2] != 0;
         }
         if (!fallback) {
+            // lane g: this wave's write cursor inside group g (absolute position in keys2)
+            uint32_t wcur = lane < G ? start + s_off[lane] + s_wcnt[wave][lane] : 0u;
             for (uint32_t t0 = (uint32_t)(tid & ~63); t0 < n; t0 += SORT_THREADS * SPLIT_UNROLL) {  // scatter
                 unsigned long long kk[SPLIT_UNROLL];
 #pragma unroll
@@ -753,17 +793,18 @@ __global__ __launch_bounds__(SORT_THREADS) void k_tile_split(
                     for (int gg = 0; gg < G; ++gg) {
                         const unsigned long long mk = __ballot(g == gg);
                         if (!mk) continue;
-                        uint32_t base = 0;
-                        if (lane == 0) {
-                            base = s_wcnt[wave][gg];
-                            s_wcnt[wave][gg] = base + (uint32_t)__popcll(mk);
-                        }
-                        base = (uint32_t)__shfl((int)base, 0, 64);
-                        if (g == gg) keys2[start + s_off[gg] + base + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull))] = key;
+                        const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)wcur, gg);
+                        if (g == gg) keys2[base + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull))] = key;
+                        wcur += lane == gg ? (uint32_t)__popcll(mk) : 0u;
                     }
                 }
             }
             if (tid < G) groups[s_item[3] + tid] = make_uint4(start + s_off[tid], s_cnt[tid], 0u, 0u);
+#ifdef MGR_TIMELINE
+            TQ(4);
+            if (tid == 0 && blockIdx.x < 2048) { g_tl2[blockIdx.x * 4 + 0] = tsp0; g_tl2[blockIdx.x * 4 + 1] = wall_clock64(); g_tl2[blockIdx.x * 4 + 3] = n; }
+            if (tid == 0 && item < 2048) { g_tl[item * 4 + 0] = tq[1] - tq[0]; g_tl[item * 4 + 1] = tq[2] - tq[1]; g_tl[item * 4 + 2] = tq[3] - tq[2]; g_tl[item * 4 + 3] = ((tq[4] - tq[3]) << 32) | n; }
+#endif
         } else {
             // last resort (pathological depth distributions): in-place network in global memory
             uint32_t npad = 1;
@@ -859,20 +900,6 @@ struct FwdRec {
     float c;
 };
 
-#ifdef MGR_TIMELINE
-__device__ unsigned long long g_tl[2048 * 4];
-__device__ unsigned long long g_tl2[2048 * 4];
-__device__ unsigned long long g_tl3[8192 * 4];
-extern "C" int mgr_debug_timeline(void* dst) {
-    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_tl), sizeof(unsigned long long) * 2048 * 4);
-}
-extern "C" int mgr_debug_timeline3(void* dst) {
-    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_tl3), sizeof(unsigned long long) * 8192 * 4);
-}
-extern "C" int mgr_debug_timeline2(void* dst) {
-    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_tl2), sizeof(unsigned long long) * 2048 * 4);
-}
-#endif
 
 __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, int gy, int VT,
                                                    const float* __restrict__ bg,
@@ -1069,7 +1096,7 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, 
             g_tl3[item * 4 + 2] = nlist;
             g_tl3[item * 4 + 3] = tmax;
         }
-        if (ntl == 1 && tid == 0 && blockIdx.x < 2048) {
+        if (MGR_TIMELINE == 2 && ntl == 1 && tid == 0 && blockIdx.x < 2048) {   // (g_tl2 is shared with k_tile_split: -DMGR_TIMELINE=2 selects the blend)
             g_tl2[blockIdx.x * 4 + 0] = wall_clock64();
             g_tl2[blockIdx.x * 4 + 1] = nlist;
             g_tl2[blockIdx.x * 4 + 2] = tmax;
@@ -1097,7 +1124,7 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, 
         if (tid == 0) tile_done[vt] = 0;
     }
 #ifdef MGR_TIMELINE
-    if (tid == 0 && blockIdx.x < 2048) {
+    if (MGR_TIMELINE == 2 && tid == 0 && blockIdx.x < 2048) {
         g_tl[blockIdx.x * 4 + 0] = tl0;
         g_tl[blockIdx.x * 4 + 1] = tl1;
         g_tl[blockIdx.x * 4 + 2] = wall_clock64();
@@ -1224,15 +1251,17 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
         MGR_HIP(side.init());
         MGR_HIP(hipEventRecord(side.fork, stream));
         MGR_HIP(hipStreamWaitEvent(side.stream, side.fork, 0));
+        // (the split is launched first so that its few 1024-thread workgroups are placed before the small-tile sort
+        // fills the CUs: launched after it, they waited for room and the kernel took three times its own work)
+        { MGR_PROF("k_tile_split", stream); hipLaunchKernelGGL(k_tile_split, dim3(128), dim3(SORT_THREADS), 0, stream,
+                           tile_start, (const uint32_t*)(ws + L.tile_queue), (unsigned long long*)(ws + L.keys),
+                           (unsigned long long*)(ws + L.keys2), (uint4*)(ws + L.groups),
+                           (uint32_t*)(ws + L.sorted_gid), hdr, (uint32_t)cap); }
         { MGR_PROF("k_tile_sort_small", side.stream); hipLaunchKernelGGL(k_tile_sort_small, dim3(256 * 8), dim3(256), 0, side.stream,
                            tile_start, (const uint32_t*)(ws + L.tile_queue),
                            (const unsigned long long*)(ws + L.keys), (uint32_t*)(ws + L.sorted_gid), hdr,
                            (uint32_t)cap); }
         MGR_HIP(hipEventRecord(side.join, side.stream));
-        { MGR_PROF("k_tile_split", stream); hipLaunchKernelGGL(k_tile_split, dim3(128), dim3(SORT_THREADS), 0, stream,
-                           tile_start, (const uint32_t*)(ws + L.tile_queue), (unsigned long long*)(ws + L.keys),
-                           (unsigned long long*)(ws + L.keys2), (uint4*)(ws + L.groups),
-                           (uint32_t*)(ws + L.sorted_gid), hdr, (uint32_t)cap); }
         { MGR_PROF("k_tile_sort", stream); hipLaunchKernelGGL(k_tile_sort, dim3(256), dim3(SORT_THREADS), SORT_LDS_KEYS * 8 + 16 * 256 * 4 + 256, stream,
                            tile_start, (const uint32_t*)(ws + L.tile_queue),
                            (const unsigned long long*)(ws + L.keys), (const unsigned long long*)(ws + L.keys2),
