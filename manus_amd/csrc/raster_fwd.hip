@@ -395,7 +395,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan_b(int VT, int nblk, uint32_t
         hdr->item_head = 0;
         hdr->queue_len = s_cbase[0];  // class 0 (empty tiles) starts after all non-empty ones
         hdr->queue_small = s_cbase[11]; // classes <= 11: fewer than 2048 pairs
-        hdr->queue_giant = s_cbase[14]; // classes >= 15: at least 16384 pairs
+        hdr->queue_giant = s_cbase[13]; // classes >= 14: at least 8192 pairs (split into depth groups before sorting)
         hdr->n_groups = 0;
         hdr->split_head = 0;
         hdr->group_head = 0;
@@ -476,7 +476,9 @@ __global__ __launch_bounds__(EMIT_THREADS) void k_emit(int N, int gx, int gy,
 // tail beyond n behaves as +inf without being stored.
 // ---------------------------------------------------------------------------
 #define SORT_THREADS 1024
-#define SORT_LDS_KEYS 16384
+#define SORT_LDS_KEYS 8192
+#define RS_THREADS 512   // threads of the LDS radix sort (two workgroups share a CU: one's barrier stalls are covered by the other)
+#define RS_WAVES (RS_THREADS / 64)
 
 template <typename KeyPtr>
 __device__ __forceinline__ void bitonic_mirror(KeyPtr a, uint32_t n, uint32_t npad, int tid,
@@ -554,18 +556,18 @@ __device__ __forceinline__ void lds_radix_sort(unsigned long long (&keys)[E], ui
         o |= (uint32_t)__shfl_xor((int)o, sft, 64);
         a &= (uint32_t)__shfl_xor((int)a, sft, 64);
     }
-    if (lane == 0) { s_cnt[wave] = o; s_cnt[16 + wave] = a; }
+    if (lane == 0) { s_cnt[wave] = o; s_cnt[RS_WAVES + wave] = a; }
     __syncthreads();
     o = 0u; a = ~0u;
 #pragma unroll
-    for (int w = 0; w < 16; ++w) { o |= s_cnt[w]; a &= s_cnt[16 + w]; }
+    for (int w = 0; w < RS_WAVES; ++w) { o |= s_cnt[w]; a &= s_cnt[RS_WAVES + w]; }
     const uint32_t varying = o ^ a;  // bits that differ between some two real keys
     __syncthreads();
 #pragma unroll 1
     for (int pass = 0; pass < 4; ++pass) {
         if (((varying >> (8 * pass)) & 0xFFu) == 0u) continue;  // uniform across the block
         const int sh = 32 + 8 * pass;
-        for (int q = tid; q < 16 * 256; q += 1024) s_cnt[q] = 0;
+        for (int q = tid; q < RS_WAVES * 256; q += RS_THREADS) s_cnt[q] = 0;
         __syncthreads();
         uint32_t rnk[E / 2];  // two 16-bit in-wave ranks per register
 #pragma unroll
@@ -580,7 +582,7 @@ __device__ __forceinline__ void lds_radix_sort(unsigned long long (&keys)[E], ui
             }
             const int leader = __builtin_ctzll(m);
             uint32_t prev = 0;
-            if (lane == leader) prev = atomicAdd(&s_cnt[d * 16 + wave], (uint32_t)__popcll(m));
+            if (lane == leader) prev = atomicAdd(&s_cnt[d * RS_WAVES + wave], (uint32_t)__popcll(m));
             prev = (uint32_t)__shfl((int)prev, leader, 64);
             const uint32_t rk = prev + (uint32_t)__popcll(m & lt);
             if (r & 1) rnk[r >> 1] |= rk << 16;
@@ -600,7 +602,7 @@ __device__ __forceinline__ void lds_radix_sort(unsigned long long (&keys)[E], ui
 #pragma unroll
         for (int r = 0; r < E; ++r) {
             const uint32_t d = (uint32_t)(keys[r] >> sh) & 0xFFu;
-            s_keys[s_cnt[d * 16 + wave] + ((rnk[r >> 1] >> (16 * (r & 1))) & 0xFFFFu)] = keys[r];
+            s_keys[s_cnt[d * RS_WAVES + wave] + ((rnk[r >> 1] >> (16 * (r & 1))) & 0xFFFFu)] = keys[r];
         }
         __syncthreads();
 #pragma unroll
@@ -619,7 +621,7 @@ __device__ __forceinline__ void lds_sort_ties(unsigned long long* s_keys, uint32
     for (;;) {
         int changed = 0;
         for (int phase = 0; phase < 2; ++phase) {
-            for (uint32_t i = (uint32_t)phase + 2u * (uint32_t)tid; i + 1 < n; i += 2048u) {
+            for (uint32_t i = (uint32_t)phase + 2u * (uint32_t)tid; i + 1 < n; i += 2u * RS_THREADS) {
                 const unsigned long long x = s_keys[i], y = s_keys[i + 1];
                 if ((x >> 32) == (y >> 32) && x > y) { s_keys[i] = y; s_keys[i + 1] = x; changed = 1; }
             }
@@ -643,14 +645,14 @@ __device__ __forceinline__ void lds_sort_emit(const unsigned long long* __restri
         }                                                                                        \
         lds_radix_sort<EE>(k, n, s_keys, s_cnt, s_scan, tid);                                    \
     }
-    if (n <= 2048u) MGR_RADIX_CASE(2)
-    else if (n <= 4096u) MGR_RADIX_CASE(4)
-    else if (n <= 8192u) MGR_RADIX_CASE(8)
+    if (n <= 2u * RS_THREADS) MGR_RADIX_CASE(2)
+    else if (n <= 4u * RS_THREADS) MGR_RADIX_CASE(4)
+    else if (n <= 8u * RS_THREADS) MGR_RADIX_CASE(8)
     else MGR_RADIX_CASE(16)
 #undef MGR_RADIX_CASE
     // write the ids out and look for an out-of-order equal-depth pair on the way (one pass, no extra barrier rounds)
     int tie = 0;
-    for (uint32_t t = (uint32_t)tid; t < n; t += 1024u) {
+    for (uint32_t t = (uint32_t)tid; t < n; t += (uint32_t)RS_THREADS) {
         const unsigned long long x = s_keys[t];
         out[t] = (uint32_t)x;
         if (t + 1 < n) {
@@ -660,7 +662,7 @@ __device__ __forceinline__ void lds_sort_emit(const unsigned long long* __restri
     }
     if (__syncthreads_or(tie)) {
         lds_sort_ties(s_keys, n, tid);
-        for (uint32_t t = (uint32_t)tid; t < n; t += 1024u) out[t] = (uint32_t)s_keys[t];
+        for (uint32_t t = (uint32_t)tid; t < n; t += (uint32_t)RS_THREADS) out[t] = (uint32_t)s_keys[t];
         __syncthreads();
     }
 }
@@ -818,14 +820,14 @@ __global__ __launch_bounds__(SORT_THREADS) void k_tile_split(
 }
 
 // Segments of [2048, 16384) pairs and the depth groups of the giant tiles: one LDS sort each.
-__global__ __launch_bounds__(SORT_THREADS) void k_tile_sort(
+__global__ __launch_bounds__(RS_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_tile_sort(
     const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ tile_queue,
     const unsigned long long* __restrict__ keys, const unsigned long long* __restrict__ keys2,
     const uint4* __restrict__ groups, uint32_t* __restrict__ sorted_gid, MgrHeader* hdr, uint32_t cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     unsigned long long* s_keys = (unsigned long long*)s_raw;
     uint32_t* s_cnt = (uint32_t*)(s_raw + (size_t)SORT_LDS_KEYS * 8);  // 16 x 256 counters (all LDS in the one array)
-    uint32_t* s_scan = s_cnt + 16 * 256;                                // 32 words
+    uint32_t* s_scan = s_cnt + RS_WAVES * 256;                          // 32 words
     uint32_t* s_item = s_scan + 32;
     const int tid = threadIdx.x;
     const uint32_t n_groups = hdr->n_groups, q0 = hdr->queue_giant, q1 = hdr->queue_small;
@@ -1184,7 +1186,7 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
     static bool attr_set = false;
     if (!attr_set) {
         MGR_HIP(hipFuncSetAttribute((const void*)k_tile_sort, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    SORT_LDS_KEYS * 8 + 16 * 256 * 4 + 256));
+                                    SORT_LDS_KEYS * 8 + RS_WAVES * 256 * 4 + 256));
         MGR_HIP(hipFuncSetAttribute((const void*)k_preprocess, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     152 * 1024));
         MGR_HIP(hipFuncSetAttribute((const void*)k_emit, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1253,7 +1255,7 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
         MGR_HIP(hipStreamWaitEvent(side.stream, side.fork, 0));
         // (the split is launched first so that its few 1024-thread workgroups are placed before the small-tile sort
         // fills the CUs: launched after it, they waited for room and the kernel took three times its own work)
-        { MGR_PROF("k_tile_split", stream); hipLaunchKernelGGL(k_tile_split, dim3(128), dim3(SORT_THREADS), 0, stream,
+        { MGR_PROF("k_tile_split", stream); hipLaunchKernelGGL(k_tile_split, dim3(256), dim3(SORT_THREADS), 0, stream,
                            tile_start, (const uint32_t*)(ws + L.tile_queue), (unsigned long long*)(ws + L.keys),
                            (unsigned long long*)(ws + L.keys2), (uint4*)(ws + L.groups),
                            (uint32_t*)(ws + L.sorted_gid), hdr, (uint32_t)cap); }
@@ -1262,7 +1264,7 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
                            (const unsigned long long*)(ws + L.keys), (uint32_t*)(ws + L.sorted_gid), hdr,
                            (uint32_t)cap); }
         MGR_HIP(hipEventRecord(side.join, side.stream));
-        { MGR_PROF("k_tile_sort", stream); hipLaunchKernelGGL(k_tile_sort, dim3(256), dim3(SORT_THREADS), SORT_LDS_KEYS * 8 + 16 * 256 * 4 + 256, stream,
+        { MGR_PROF("k_tile_sort", stream); hipLaunchKernelGGL(k_tile_sort, dim3(512), dim3(RS_THREADS), SORT_LDS_KEYS * 8 + RS_WAVES * 256 * 4 + 256, stream,
                            tile_start, (const uint32_t*)(ws + L.tile_queue),
                            (const unsigned long long*)(ws + L.keys), (const unsigned long long*)(ws + L.keys2),
                            (const uint4*)(ws + L.groups), (uint32_t*)(ws + L.sorted_gid), hdr, (uint32_t)cap); }
