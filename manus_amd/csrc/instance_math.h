@@ -70,14 +70,14 @@ __device__ __forceinline__ void blend_tf(const float* __restrict__ w_row, const 
         for (int j = 0; j < 4; ++j) {
             const float* T = Tp + (size_t)(b + j) * 16;  // wave-uniform address
 #pragma unroll
-            for (int k = 0; k < 12; ++k) tf[k] += wj[j] * T[k];
-        }
+            for (int k = 0; k < 12; ++k) tf[k] = __builtin_fmaf(wj[j], T[k], tf[k]);  // explicit fma: the same rounding in
+        }                                                                            // every kernel, half the instructions
     }
     for (; b < B; ++b) {
         const float w = w_row[b];
         const float* T = Tp + (size_t)b * 16;
 #pragma unroll
-        for (int k = 0; k < 12; ++k) tf[k] += w * T[k];
+        for (int k = 0; k < 12; ++k) tf[k] = __builtin_fmaf(w, T[k], tf[k]);
     }
 }
 
