@@ -256,6 +256,9 @@ def main():
                          "headline number and the parity block use fp32, like the reference)")
     ap.add_argument("--dense-allreduce", action="store_true",
                     help="N > 1: all-reduce all 61 N floats instead of only the rows that received a gradient on some rank")
+    ap.add_argument("--sharded-adam", action="store_true",
+                    help="N > 1 with --optimizer: reduce-scatter the gradients, Adam on the owned 1/N of the elements, "
+                         "all-gather the parameters (instead of all-reduce + the full Adam step on every rank)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (cpu_baseline and parity)")
     ap.add_argument("--parity-views", type=int, default=2, help="views of the step run through the CPU oracle")
     ap.add_argument("--profile-all", action="store_true", help="print a per-kernel HIP-event breakdown to stderr")
@@ -295,19 +298,28 @@ def main():
     shapes = {k: v.shape for k, v in compute.params.items()}
     # N > 1: only the rows with a gradient on some rank travel (exact: the others are zero everywhere; 43 % of the rows
     # in this scene) -- xGMI is point-to-point, the all-reduce is the part of the step that does not shrink with N
+    sharded = args.sharded_adam and args.optimizer and world > 1
     step = ViewShardedStep(N, shapes, compute, V, rank=rank, world_size=world,
-                           compact=world > 1 and not args.dense_allreduce)
+                           compact=world > 1 and not args.dense_allreduce and not sharded, scatter=sharded)
     V_local = len(step.local_views)
     opt = None
     if args.optimizer:
         from manus_amd.optim import GaussianOptimizer
         opt = GaussianOptimizer(compute.params, adopt=True)
         base_step = step.step
+        if sharded:
+            opt.flatten(step.padded_g)
+            compute.set_params(opt.parameters())
+            opt.p = {k: v.detach() for k, v in compute.params.items()}
 
         def step_with_adam():
             o = base_step()
             opt.update_learning_rate(opt.state_step + 1)
-            opt.step(o["grads"])
+            if sharded:
+                opt.step_range(step._store, *step.owned)
+                step.all_gather_params(opt.pflat)
+            else:
+                opt.step(o["grads"])
             compute.mark_params_changed()
             return o
 
@@ -424,7 +436,7 @@ def main():
                                    "(n_poses=%d), image loss %s, fwd+bwd to leaf grads" % (N, V, W, H, n_poses, "0.8*L1 + 0.2*(1-SSIM)" if args.loss == "l1+ssim" else "L1"),
                        "gaussians": N, "views": V, "width": W, "height": H, "views_per_gpu": V_local,
                        "pairs_per_view": int(R_view), "parallelism": "views/%d" % world,
-                       "allreduce": (None if world == 1 else "dense 61N floats" if args.dense_allreduce else
+                       "allreduce": (None if world == 1 else "reduce-scatter + sharded Adam + all-gather" if sharded else "dense 61N floats" if args.dense_allreduce else
                                      "rows with a gradient (%s of %d) x 60 floats + 2N bytes" % (step.last_rows, N)),
                        "optimizer_in_step": bool(args.optimizer), "sh_storage": args.sh_storage,
                        "nonfinite_grad_values": nonfinite},

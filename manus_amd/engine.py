@@ -78,30 +78,56 @@ class ViewShardedStep:
         radii      (N,) int32 max screen radius over views
         loss       scalar tensor, scale * sum of L_v
         overflow   optional scalar tensor, non-zero when the rasterizer ran out of pair capacity
-    If compute_fn has a `grad_arena` attribute it is handed views of the flat buffer and writes them in place.
+    If compute_fn has a `grad_arena` attribute it is handed views of the step buffer and writes them in place.
 
     step() returns the reduced grads / grad2d / vis / loss / overflow (sums over all ranks) and the LOCAL radii
     (max over this rank's views); `reduce_max_radii` combines the ranks when the statistic is consumed.
+
+    Reduction modes (world_size > 1):
+        default        one SUM all-reduce of [59 N gradients | N grad2d | N vis | loss | overflow]
+        compact=True   only the rows with a gradient on some rank travel (see `_compact_all_reduce`)
+        scatter=True   sharded optimizer step: a reduce-scatter of the gradient part leaves every rank with the summed
+                       slice it owns (`owned`, element range of the flat gradient buffer; the returned grads are then
+                       only valid inside that slice) + one small all-reduce of the statistics; the caller updates the
+                       parameters it owns and all-gathers them with `all_gather_params`.
     """
 
-    def __init__(self, n_gaussians, shapes, compute_fn, n_views, rank=0, world_size=1, group=None, compact=False):
+    def __init__(self, n_gaussians, shapes, compute_fn, n_views, rank=0, world_size=1, group=None, compact=False,
+                 scatter=False):
         self.N, self.shapes, self.compute_fn = n_gaussians, shapes, compute_fn
         self.n_views, self.rank, self.world, self.group = n_views, rank, world_size, group
         self.local_views = shard_views(n_views, rank, world_size)
         self.always_pack = False   # tests: take the packing path without a process group
-        # compact=True: only the rows that received a gradient on SOME rank travel (in the bench scene 43 % of the
-        # Gaussians with 8 views on one GPU, fewer per rank: the rest are hidden behind saturated pixels and their rows
-        # are exactly zero everywhere).  One small MAX all-reduce of the row mask + one host read of the row count,
-        # then the SUM all-reduce of 61 floats per surviving row instead of per Gaussian.
         self.compact = bool(compact)
+        self.scatter = bool(scatter) and world_size > 1
         self.last_rows = None
-        self._flat = None
+        self._store = None
+        n_g = self.N * GRAD_WIDTH
+        self.padded_g = (n_g + world_size - 1) // world_size * world_size      # reduce-scatter needs equal slices
+        c = self.padded_g // world_size
+        self.owned = (rank * c, min((rank + 1) * c, n_g))
         dev = getattr(compute_fn, "device", None)
         if dev is not None and (world_size > 1):
             self._alloc(dev)
 
     def _alloc(self, dev):
-        self._flat = torch.zeros(flat_size(self.N), dtype=torch.float32, device=dev)
+        # [ 59 N gradients | padding to a multiple of the world size | N grad2d | N vis | loss | overflow ]
+        self._store = torch.zeros(self.padded_g + 2 * self.N + FLAT_TAIL, dtype=torch.float32, device=dev)
+
+    @property
+    def _flat(self):   # (tests look at the buffer the kernels write into)
+        return self._store
+
+    def _views(self):
+        N, st = self.N, self._store
+        out, o = {}, 0
+        for name, w in GRAD_LAYOUT:
+            out[name] = st[o:o + N * w]
+            o += N * w
+        o = self.padded_g
+        out["grad2d"], out["vis"] = st[o:o + N], st[o + N:o + 2 * N]
+        out["loss"], out["overflow"] = st[o + 2 * N:o + 2 * N + 1], st[o + 2 * N + 1:o + 2 * N + 2]
+        return out
 
     def reduce_max_radii(self, radii):
         """MAX over ranks of a per-Gaussian radius statistic (in place; any integer or float dtype)."""
@@ -109,24 +135,37 @@ class ViewShardedStep:
             dist.all_reduce(radii, op=dist.ReduceOp.MAX, group=self.group)
         return radii
 
+    def all_gather_params(self, store):
+        """In place on a parameter buffer laid out like the gradient part (`padded_g` floats): every rank contributes
+        the slice it owns."""
+        c = self.padded_g // self.world
+        mine = store[self.rank * c:(self.rank + 1) * c]
+        if dist.get_backend(self.group) == "gloo":      # (CPU / single-GPU tests; RCCL takes the one-call form)
+            parts = [torch.empty_like(mine) for _ in range(self.world)]
+            dist.all_gather(parts, mine.clone(), group=self.group)
+            for r, t in enumerate(parts):
+                store[r * c:(r + 1) * c].copy_(t)
+        else:
+            dist.all_gather_into_tensor(store, mine, group=self.group)
+
     def step(self):
         # compute_fn folds the 1/V of "grad = (1/V) sum_v grad L_v" into the loss scale
         N = self.N
         packed = self.world > 1 or self.always_pack
-        if packed and self._flat is not None and hasattr(self.compute_fn, "grad_arena"):
-            # the backward kernels write straight into the all-reduce buffer (no packing copies): one view per leaf
-            self.compute_fn.grad_arena = flat_views(self._flat, N)
+        if packed and self._store is not None and hasattr(self.compute_fn, "grad_arena"):
+            # the backward kernels write straight into the step buffer (no packing copies): one view per leaf
+            self.compute_fn.grad_arena = self._views()
         out = self.compute_fn(self.local_views, 1.0 / float(self.n_views))
         dev = out["grad2d"].device
         radii = out["radii"].to(torch.int32)
         if not packed:
             return dict(grads=out["grads"], grad2d=out["grad2d"], vis=out["vis"], radii=radii, loss=out["loss"],
                         overflow=out.get("overflow"))
-        if self._flat is None or self._flat.device != dev:
+        if self._store is None or self._store.device != dev:
             self._alloc(dev)
-        flat = self._flat
-        fv = flat_views(flat, N)
-        pack_grads(out["grads"], N, dev, out=flat[: N * GRAD_WIDTH])
+        st, n_g = self._store, N * GRAD_WIDTH
+        fv = self._views()
+        pack_grads(out["grads"], N, dev, out=st[:n_g])
         for name in ("grad2d", "vis"):
             if out[name].data_ptr() != fv[name].data_ptr():
                 fv[name].copy_(out[name])
@@ -136,12 +175,20 @@ class ViewShardedStep:
             fv["overflow"].zero_()
         else:
             fv["overflow"].copy_(ovf.reshape(1).to(torch.float32))
-        if self.world > 1 or (self.always_pack and self.compact):
-            if self.compact:
-                self._compact_all_reduce(flat, fv)
+        if self.scatter:
+            c = self.padded_g // self.world
+            mine = st[self.rank * c:(self.rank + 1) * c]
+            if dist.get_backend(self.group) == "gloo":      # gloo has no reduce-scatter: same sums, more bytes
+                dist.all_reduce(st[:self.padded_g], op=dist.ReduceOp.SUM, group=self.group)
             else:
-                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)   # the step's ONE collective
-        grads = unpack_grads(flat[: N * GRAD_WIDTH], self.shapes, N)
+                dist.reduce_scatter_tensor(mine, st[:self.padded_g], op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_reduce(st[self.padded_g:], op=dist.ReduceOp.SUM, group=self.group)    # 2 N + 2 floats
+        elif self.world > 1 or (self.always_pack and self.compact):
+            if self.compact:
+                self._compact_all_reduce(st, fv)
+            else:
+                dist.all_reduce(st, op=dist.ReduceOp.SUM, group=self.group)   # the step's ONE collective
+        grads = unpack_grads(st[:n_g], self.shapes, N)
         return dict(grads=grads, grad2d=fv["grad2d"], vis=fv["vis"], radii=radii, loss=fv["loss"][0],
                     overflow=fv["overflow"][0])
 
@@ -175,7 +222,7 @@ def _compact_all_reduce(self, flat, fv):
         torch.index_select(fv[name].view(N, w), 0, idx, out=seg)
         segs.append((name, w, seg))
         o += n * w
-    buf[o:o + FLAT_TAIL].copy_(flat[-FLAT_TAIL:])
+    buf[o:o + FLAT_TAIL].copy_(flat[-FLAT_TAIL:])   # (loss, overflow: the last two floats of the step buffer)
     if self.world > 1:
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
     for name, w, seg in segs:                                                # rows outside the union are zero everywhere
@@ -451,8 +498,12 @@ class Trainer:
     over the ranks; max_radii2D is MAX-reduced before it is consumed."""
 
     def __init__(self, compute, n_views, extent, opts=None, spatial_lr_scale=1.0, rank=0, world_size=1, group=None,
-                 bg_white=True, kind=None, compact_allreduce=False):
-        self.compact_allreduce = compact_allreduce
+                 bg_white=True, kind=None, compact_allreduce=False, sharded_adam=False):
+        # sharded_adam (world_size > 1): reduce-scatter of the gradients -> every rank takes the Adam step on the 1/world
+        # of the parameter elements it owns -> all-gather of the parameters.  The same bytes on the wire as the
+        # all-reduce (which is a reduce-scatter followed by an all-gather), 1/world of the optimizer work per rank.
+        self.compact_allreduce = compact_allreduce and not sharded_adam
+        self.sharded_adam = bool(sharded_adam) and world_size > 1
         from . import rasterizer
         from .density import DensityController
         from .optim import GaussianOptimizer
@@ -476,7 +527,12 @@ class Trainer:
         p = self.compute.params
         shapes = {k: v.shape for k, v in p.items()}
         self.stepper = ViewShardedStep(p["_xyz"].shape[0], shapes, self.compute, self.n_views, rank=self.rank,
-                                       world_size=self.world, group=self.group, compact=self.compact_allreduce)
+                                       world_size=self.world, group=self.group, compact=self.compact_allreduce,
+                                       scatter=self.sharded_adam)
+        if self.sharded_adam:   # leaves and moments as views of flat buffers laid out like the gradient buffer
+            self.opt.flatten(self.stepper.padded_g)
+            self.compute.set_params(self.opt.parameters())
+            self.opt.p = {k: v.detach() for k, v in self.compute.params.items()}
 
     def _split_noise(self, n_rows, device):
         noise = torch.randn((2 * n_rows, 3), dtype=torch.float32, device=device)
@@ -502,6 +558,14 @@ class Trainer:
             self.retries += 1
         raise RuntimeError("rasterizer pair capacity still exceeded after 4 attempts")
 
+    def gather_moments(self):
+        """Sharded optimizer step: each rank keeps only the Adam moments of the elements it owns up to date.  Before
+        the rows move (prune / densify: ownership is by element range, so it moves with them), and before a checkpoint,
+        the ranks exchange their slices."""
+        if self.sharded_adam:
+            self.stepper.all_gather_params(self.opt.mflat)
+            self.stepper.all_gather_params(self.opt.vflat)
+
     def train_step(self, views=None):
         """One optimisation step; returns the step's output dict (loss, statistics) plus "changed".
         views: optional list of per-view dicts for the pruning tests (default: `compute.prune_views`)."""
@@ -525,6 +589,8 @@ class Trainer:
             # the selection count is only known inside the plan: draw the worst case on rank 0 and broadcast
             noise = self._split_noise(self.opt.N, self.opt.device)
         n_before = self.opt.N
+        if self.sharded_adam and (mask is not None or will_densify):
+            self.gather_moments()     # rows are about to move: every rank needs the moments of every row
         if mask is not None:
             changed = self.opt.density_update(stats, self.extent, gs, self.bg_white, mask_to_prune=mask)
         else:
@@ -541,7 +607,15 @@ class Trainer:
         resized = changed and (self.opt.N != n_before or self.opt.replaced == ALL_GROUPS)   # new leaf tensors
         # ---- on_before_optimizer_step + optimizer.step() ----
         self.opt.update_learning_rate(gs)
-        self.opt.step(out["grads"])       # skips the groups replaced above (all of them after a densify / prune)
+        if self.sharded_adam:
+            if self.opt.replaced == ALL_GROUPS:
+                self.opt.replaced = frozenset()          # every leaf is new: no gradient, no step (like opt.step)
+            else:
+                lo, hi = self.stepper.owned
+                self.opt.step_range(self.stepper._store, lo, hi)
+                self.stepper.all_gather_params(self.opt.pflat)
+        else:
+            self.opt.step(out["grads"])   # skips the groups replaced above (all of them after a densify / prune)
         if hasattr(self.compute, "mark_params_changed"):
             self.compute.mark_params_changed()
         self.global_step += 1

@@ -149,6 +149,53 @@ class GaussianOptimizer:
                                          _ptr_array([self.v[a] for _, a, _ in GROUPS]), lrs, steps, beta1, beta2, eps,
                                          stream()), "mgr_adam_step_groups")
 
+    # -- sharded step: flat storage + Adam on an element range -------------------------------------------
+    def flatten(self, padded):
+        """Re-home the six leaves and both moments in three flat buffers of `padded` floats, group after group in
+        training_setup order (= the layout of the engine's gradient buffer), so that an optimizer step can be taken
+        on any element range and the parameters all-gathered as one tensor.  The leaves stay views with the
+        reference's shapes."""
+        dev = self.device
+        flats = [torch.zeros(padded, dtype=torch.float32, device=dev) for _ in range(3)]
+        for store, flat in zip((self.p, self.m, self.v), flats):
+            o = 0
+            for _, a, _ in GROUPS:
+                t = store[a]
+                flat[o:o + t.numel()].copy_(t.reshape(-1))
+                store[a] = flat[o:o + t.numel()].view(t.shape)
+                o += t.numel()
+        self.pflat, self.mflat, self.vflat = flats
+        return self.pflat
+
+    def step_range(self, grad_flat, lo, hi, beta1=0.9, beta2=0.999, eps=1e-15, skip=None):
+        """Adam on the elements [lo, hi) of the flat parameter buffer (`flatten` first) from the same elements of
+        `grad_flat`; every rank of a sharded step calls this with its own range, so the per-group step counts advance
+        for every group that is not skipped, whether or not the range touches it."""
+        skip = self.replaced if skip is None else frozenset(skip)
+        self.replaced = frozenset()
+        counts, ps, gs, ms, vs, steps, lrs = [], [], [], [], [], [], []
+        o = 0
+        for n, a, _ in GROUPS:
+            size = self.p[a].numel()
+            on = n not in skip
+            if on:
+                self.group_step[n] += 1
+            a0, a1 = max(lo, o), min(hi, o + size)
+            take = on and a1 > a0
+            counts.append(a1 - a0 if take else 0)
+            ps.append(self.pflat[a0:a1] if take else None)
+            gs.append(grad_flat[a0:a1] if take else None)
+            ms.append(self.mflat[a0:a1] if take else None)
+            vs.append(self.vflat[a0:a1] if take else None)
+            steps.append(self.group_step[n] if take else 0)
+            lrs.append(self.lr[n])
+            o += size
+        if not any(counts):
+            return
+        check(lib().mgr_adam_step_groups(6, (ctypes.c_int64 * 6)(*counts), _ptr_array(ps), _ptr_array(gs), _ptr_array(ms),
+                                         _ptr_array(vs), (ctypes.c_double * 6)(*lrs), (ctypes.c_int64 * 6)(*steps), beta1,
+                                         beta2, eps, stream()), "mgr_adam_step_groups")
+
     # -- add_densification_stats (+ max radii), gaussian.py:335-338, gaussian_utils.py:470-473 -
     def add_densification_stats(self, grad2d_sum, vis_count, radii_max):
         """Accumulate the statistics of one multi-view step (`fused.ViewStats` / `ViewShardedStep` outputs):

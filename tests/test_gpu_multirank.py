@@ -28,7 +28,7 @@ def _free_port():
     return p
 
 
-def _build(rank, world, compact):
+def _build(rank, world, compact, sharded=False):
     from manus_amd.engine import HipViewCompute, Trainer
     from manus_amd.synthetic import camera_table, make_masks, make_scene
     sc = make_scene(n_gaussians=N0, kind="hand", seed=21, grid_res=24, n_cameras=V, width=W, height=H, cam_radius=0.5,
@@ -44,7 +44,7 @@ def _build(rank, world, compact):
     sc["masks"] = make_masks(sc, sc["keypoints"][:V], margin=6).to(DEV)
     compute = HipViewCompute(sc, targets, ct, loss="l1+ssim")
     return Trainer(compute, V, extent=0.3, opts=OPTS, spatial_lr_scale=0.05, bg_white=False, rank=rank, world_size=world,
-                   compact_allreduce=compact)
+                   compact_allreduce=compact, sharded_adam=sharded)
 
 
 def _run(tr, steps=5):
@@ -56,13 +56,13 @@ def _run(tr, steps=5):
     return hist
 
 
-def _worker(rank, world, port, q, compact):
+def _worker(rank, world, port, q, compact, sharded=False):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
-    tr = _build(rank, world, compact)
+    tr = _build(rank, world, compact, sharded)
     assert tr.stepper.local_views == list(range(rank, V, world))
     hist = _run(tr)
     # identical state on every rank: compare through the process group itself
@@ -71,26 +71,29 @@ def _worker(rank, world, port, q, compact):
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         assert torch.equal(lo, hi), k
+    tr.gather_moments()              # (sharded step: a rank only keeps the moments of its own slice current)
     for t in (tr.opt.xyz_gradient_accum, tr.opt.denom, tr.opt.m["_features_rest"]):
         lo, hi = t.clone(), t.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         assert torch.equal(lo, hi)
     if rank == 0:
-        q.put((hist, {k: v.detach().cpu() for k, v in tr.opt.p.items()}, tr.stepper.last_rows))
+        q.put((hist, {k: v.detach().cpu().numpy() for k, v in tr.opt.p.items()}, tr.stepper.last_rows))   # by value
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("compact", [False, True])
-def test_two_ranks_train_identically_through_prune_and_densify(compact):
+@pytest.mark.parametrize("compact,sharded", [(False, False), (True, False), (False, True)])
+def test_two_ranks_train_identically_through_prune_and_densify(compact, sharded):
+    """dense all-reduce / row-compacted all-reduce / sharded optimizer step (reduce-scatter -> Adam on the owned slice
+    -> all-gather of the parameters)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, compact)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, compact, sharded)) for r in range(2)]
     for p in procs:
         p.start()
-    hist, params, rows = q.get(timeout=600)
+    hist, params, rows = q.get(timeout=240)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -110,5 +113,5 @@ def test_two_ranks_train_identically_through_prune_and_densify(compact):
         assert abs(a[1] - b[1]) < 1e-4 * max(1.0, abs(b[1]))
     if ns == [h[0] for h in ref_hist]:
         for k, v in ref.opt.p.items():
-            d = (params[k] - v.detach().cpu()).abs().max() / (v.abs().max().cpu() + 1e-12)
+            d = (torch.from_numpy(params[k]) - v.detach().cpu()).abs().max() / (v.abs().max().cpu() + 1e-12)
             assert float(d) < 1e-3, (k, float(d))
