@@ -215,20 +215,33 @@ def _sparse(fn, n):
     return g
 
 
-def _worker(rank, world, port, q, compact=False):
+NG = 301      # 59 * 301 is odd: the scatter layout needs its padding with two ranks
+
+
+def _worker(rank, world, port, q, mode="dense"):
+    compact = mode == "compact"
     sys.path.insert(0, ROOT)
     from manus_amd.engine import ViewShardedStep
     from manus_amd.synthetic import make_scene
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(1)
-    sc = make_scene(n_gaussians=300, kind="hand", seed=4, grid_res=12, n_cameras=5, width=32, height=32)
+    sc = make_scene(n_gaussians=NG, kind="hand", seed=4, grid_res=12, n_cameras=5, width=32, height=32)
     shapes = {k: v.shape for k, v in sc["params"].items()}
     fn = _oracle_compute(sc)
-    st = ViewShardedStep(300, shapes, _sparse(fn, 300) if compact else fn, 5, rank=rank, world_size=world, compact=compact)
+    st = ViewShardedStep(NG, shapes, _sparse(fn, NG) if compact else fn, 5, rank=rank, world_size=world, compact=compact,
+                         scatter=mode == "scatter")
     out = st.step()
     if compact:
-        assert 0 < st.last_rows < 300            # fewer rows travelled than there are Gaussians
+        assert 0 < st.last_rows < NG             # fewer rows travelled than there are Gaussians
+    if mode == "scatter":
+        c = (59 * NG + 1) // 2
+        assert st.padded_g == 2 * c and st.owned == (rank * c, min((rank + 1) * c, 59 * NG))   # the pad element has no owner
+        # the parameter all-gather: every rank contributes its slice of a buffer laid out like the gradients
+        buf = torch.full((st.padded_g,), float("nan"))
+        buf[rank * c:(rank + 1) * c] = torch.arange(rank * c, (rank + 1) * c, dtype=torch.float32)
+        st.all_gather_params(buf)
+        assert torch.equal(buf, torch.arange(st.padded_g, dtype=torch.float32))
     assert float(out["overflow"]) == 0.0
     st.reduce_max_radii(out["radii"])        # the per-step collective carries sums only; the maximum is combined on demand
     if rank == 0:
@@ -238,8 +251,9 @@ def _worker(rank, world, port, q, compact=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("compact", [False, True])
-def test_view_sharded_step_gloo_world2(compact):
+@pytest.mark.parametrize("mode", ["dense", "compact", "scatter"])
+def test_view_sharded_step_gloo_world2(mode):
+    compact = mode == "compact"
     from manus_amd.engine import GRAD_WIDTH, ViewShardedStep, shard_views
     from manus_amd.synthetic import make_scene
     assert GRAD_WIDTH == 59
@@ -248,7 +262,7 @@ def test_view_sharded_step_gloo_world2(compact):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, compact)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, mode)) for r in range(2)]
     for p in procs:
         p.start()
     got = q.get(timeout=180)
@@ -256,10 +270,10 @@ def test_view_sharded_step_gloo_world2(compact):
         p.join(timeout=120)
         assert p.exitcode == 0
     # single-process reference: all 5 views on one rank
-    sc = make_scene(n_gaussians=300, kind="hand", seed=4, grid_res=12, n_cameras=5, width=32, height=32)
+    sc = make_scene(n_gaussians=NG, kind="hand", seed=4, grid_res=12, n_cameras=5, width=32, height=32)
     shapes = {k: v.shape for k, v in sc["params"].items()}
     fn = _oracle_compute(sc)
-    ref = ViewShardedStep(300, shapes, _sparse(fn, 300) if compact else fn, 5).step()
+    ref = ViewShardedStep(NG, shapes, _sparse(fn, NG) if compact else fn, 5).step()
     for k in ref["grads"]:
         assert got["grads"][k].shape == ref["grads"][k].shape
         assert torch.allclose(got["grads"][k], ref["grads"][k], rtol=1e-4, atol=1e-6 * float(ref["grads"][k].abs().max())), k
