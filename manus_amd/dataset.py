@@ -1,0 +1,496 @@
+"""Sequence reader for MANUS-Grasps captures (dataloader half): the reference's
+`src/datasets/brics_dynamic.py::Dataset` over the same on-disk schema, feeding `engine.HipViewCompute`.
+
+Schema of one action file (brics_dynamic.py:173-188, 224-263, 343-403):
+
+    frames/<frame no>/images/<camera>     (h, w, 4) uint8 RGBA crop
+    frames/<frame no>/bbox/<camera>       (4,) int  xmin, ymin, xmax, ymax of the crop in the full image
+    frames/<frame no>/metadata/{bnames, bnames_parent, rest_heads, rest_tails, rest_matrixs, pose_heads, pose_tails,
+                                pose_matrixs, eulers, root_translation, root_rotation}
+    K/<camera> (3,3)     extr/<camera> (3,4)     mano_rest/<key>
+
+The reference opens `<action>.hdf5` with h5py.  h5py is an optional import here: everything below talks to the file
+through the small mapping protocol h5py groups offer (`g[name]`, `g.keys()`, `g.get`, `g.items()`, `dataset[:]`), and
+`TreeStore` offers the same protocol over one `.npz` whose keys are the '/'-joined paths -- the container used for the
+synthetic sequences of the tests and for captures converted on a machine that has h5py (`convert_hdf5`).
+Host-side IO only; nothing here is on the per-step path."""
+import json
+import os
+import re
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import transforms as T
+from .cam_utils import get_opengl_camera_attributes, get_scene_extent
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# containers
+# ---------------------------------------------------------------------------------------------------------------------
+class _Node:
+    """A group of a TreeStore: children by name, h5py.Group protocol."""
+
+    def __init__(self, arrays, prefix):
+        self._a, self._p = arrays, prefix
+        names = []
+        for k in arrays:
+            if k.startswith(prefix):
+                head = k[len(prefix):].split("/", 1)[0]
+                if head not in names:
+                    names.append(head)
+        self._names = sorted(names)  # by name, like h5py's default iteration order
+
+    def keys(self):
+        return list(self._names)
+
+    def __iter__(self):
+        return iter(self._names)
+
+    def __len__(self):
+        return len(self._names)
+
+    def __contains__(self, name):
+        return name in self._names
+
+    def __getitem__(self, name):
+        full = self._p + name
+        if full in self._a:
+            return self._a[full]                    # numpy array: `[:]`, `[idx]` behave like an h5py dataset
+        if name not in self._names:
+            raise KeyError(full)
+        return _Node(self._a, full + "/")
+
+    def get(self, name, default=None):
+        return self[name] if name in self._names else default
+
+    def items(self):
+        return [(n, self[n]) for n in self._names]
+
+
+class TreeStore(_Node):
+    """Read-only h5py.File look-alike over an .npz of '/'-joined paths (context manager like h5py.File)."""
+
+    def __init__(self, path, mode="r"):
+        if mode != "r":
+            raise ValueError("TreeStore is read-only; write with write_tree()")
+        with np.load(path, allow_pickle=False) as z:
+            arrays = {k: z[k] for k in z.files}
+        super().__init__(arrays, "")
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+def write_tree(path, arrays):
+    """arrays: {'/'-joined path: ndarray} -> one uncompressed .npz, written to exactly `path` (np.savez would append
+    '.npz')."""
+    with open(path, "wb") as f:
+        np.savez(f, **arrays)
+
+
+def open_sequence(path):
+    """An action file by content: .npz container -> TreeStore, otherwise HDF5 through h5py (fails loudly without it)."""
+    with open(path, "rb") as f:
+        magic = f.read(4)
+    if magic[:2] == b"PK":
+        return TreeStore(path)
+    try:
+        import h5py
+    except ImportError as e:
+        raise RuntimeError("%s is an HDF5 file and h5py is not installed here; convert it with "
+                           "manus_amd.dataset.convert_hdf5 on a machine that has h5py" % path) from e
+    return h5py.File(path, "r")
+
+
+def convert_hdf5(src, dst):
+    """Flatten an HDF5 action file into the .npz container (needs h5py)."""
+    import h5py
+    out = {}
+
+    def visit(name, obj):
+        if isinstance(obj, h5py.Dataset):
+            a = obj[()]
+            out[name] = a.astype("S") if a.dtype.kind == "O" else a
+    with h5py.File(src, "r") as f:
+        f.visititems(visit)
+    write_tree(dst, out)
+
+
+def natural_key(s):
+    """Sort key of natsort.natsorted for the names met here (digit runs compare as integers)."""
+    return [(0, int(t), "") if t.isdigit() else (1, 0, t) for t in re.split(r"(\d+)", str(s)) if t != ""]
+
+
+def natsorted(names):
+    return sorted(names, key=natural_key)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# structures (src/utils/structures.py:8-47)
+# ---------------------------------------------------------------------------------------------------------------------
+def _index_fields(obj, idx):
+    return type(obj)(**{k: (None if v is None else v[idx]) for k, v in obj.__dict__.items()})
+
+
+@dataclass
+class Bones:
+    bnames: np.ndarray
+    heads: np.ndarray
+    tails: np.ndarray
+    transforms: np.ndarray
+    eulers: np.ndarray = None
+    eulers_c: np.ndarray = None
+    root_translation: np.ndarray = None
+    root_rotation: np.ndarray = None
+    kintree: dict = None
+
+    def __getitem__(self, idx):
+        return _index_fields(self, idx)
+
+
+@dataclass
+class Cameras:
+    cam_name: np.ndarray
+    K: np.ndarray
+    extr: np.ndarray
+    fovx: float
+    fovy: float
+    width: int
+    height: int
+    world_view_transform: np.ndarray
+    projection_matrix: np.ndarray
+    full_proj_transform: np.ndarray
+    camera_center: np.ndarray
+
+    def __getitem__(self, idx):
+        return _index_fields(self, idx)
+
+
+def to_tensor(var, dtype=torch.float32):
+    """extra.py:56-82 for the cases met here: arrays / lists of numbers become tensors, dataclasses are converted
+    field by field (in place, like the reference), strings and dicts of non-numbers stay."""
+    if hasattr(var, "__dataclass_fields__"):
+        for k, v in var.__dict__.items():
+            if v is not None:
+                setattr(var, k, to_tensor(v, dtype))
+        return var
+    if isinstance(var, np.ndarray):
+        if var.ndim > 0 and var.dtype.kind in "fiub":
+            return torch.tensor(var, dtype=dtype)
+        return var
+    if isinstance(var, (list, tuple)):
+        try:
+            return torch.tensor(var, dtype=dtype)
+        except (TypeError, ValueError):
+            return var
+    return var
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# pose helpers (src/utils/transforms.py:145-198, 371-419, 478-486)
+# ---------------------------------------------------------------------------------------------------------------------
+DOF_XZ = ("bone_0", "bone_1", "bone_2", "bone_5", "bone_9", "bone_13", "bone_17")
+DOF_X = ("bone_3", "bone_6", "bone_7", "bone_10", "bone_11", "bone_14", "bone_15", "bone_18", "bone_19")
+
+
+def apply_constraints_to_poses(euler, bnames, dof_xz=DOF_XZ, dof_xyz=(), dof_x=DOF_X):
+    """(F, J, 3) Euler angles -> (F, n_dof) free angles, bones in `bnames` order (transforms.py:371-419; note the
+    single-DoF bones keep the Z angle, column 2)."""
+    cols = []
+    for i, bn in enumerate(bnames):
+        if bn in dof_xyz:
+            cols += [euler[:, i, 0], euler[:, i, 1], euler[:, i, 2]]
+        elif bn in dof_xz:
+            cols += [euler[:, i, 0], euler[:, i, 2]]
+        elif bn in dof_x:
+            cols += [euler[:, i, 2]]
+    width = 2 * len(dof_xz) + 3 * len(dof_xyz) + len(dof_x)
+    out = np.zeros((euler.shape[0], width), dtype=np.float32)
+    for c, col in enumerate(cols):
+        out[:, c] = col
+    return out
+
+
+def matrix_to_quaternion(m):
+    """Rotation matrices (..., 3, 3) -> quaternions (..., 4), real part first: of the four algebraically equal
+    candidates (one per component taken as the pivot) the one with the largest pivot (transforms.py:145-198)."""
+    if m.shape[-2:] != (3, 3):
+        raise ValueError(f"Invalid rotation matrix shape {m.shape}.")
+    batch = m.shape[:-2]
+    f = m.reshape(-1, 9)
+    m00, m01, m02, m10, m11, m12, m20, m21, m22 = f.unbind(-1)
+    sq = torch.stack([1.0 + m00 + m11 + m22, 1.0 + m00 - m11 - m22, 1.0 - m00 + m11 - m22, 1.0 - m00 - m11 + m22], -1)
+    q_abs = torch.sqrt(sq.clamp_min(0.0))
+    pivot = q_abs.argmax(-1)
+    rows = torch.stack([
+        torch.stack([q_abs[:, 0] ** 2, m21 - m12, m02 - m20, m10 - m01], -1),
+        torch.stack([m21 - m12, q_abs[:, 1] ** 2, m10 + m01, m02 + m20], -1),
+        torch.stack([m02 - m20, m10 + m01, q_abs[:, 2] ** 2, m12 + m21], -1),
+        torch.stack([m10 - m01, m20 + m02, m21 + m12, q_abs[:, 3] ** 2], -1)], -2)          # (n, 4 candidates, 4)
+    cand = rows / (2.0 * q_abs.clamp_min(0.1))[..., None]
+    return cand[torch.arange(f.shape[0]), pivot].reshape(batch + (4,))
+
+
+def euler_angles_to_quats(euler):
+    return matrix_to_quaternion(T.euler_angles_to_matrix(euler, "XYZ", intrinsic=True))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the dataset
+# ---------------------------------------------------------------------------------------------------------------------
+DEFAULT_OPTS = dict(sequences="all", split_by_action=False, num_time_steps=-1, split_ratio=-1.0,
+                    rand_views_per_timestep=-1, n_bones=20, resize_factor=1.0, bg_color="white", width=1920,
+                    height=1080, near=0.01, far=100.0, subject="subject")
+
+
+def _area_resize(img, factor):
+    """cv2.resize(..., fx=f, fy=f, INTER_AREA) for f = 1 (identity) and f = 1/k (mean over k x k blocks, rounded like
+    cv2 does for uint8).  Other factors need OpenCV."""
+    if factor == 1.0:
+        return img
+    k = round(1.0 / factor)
+    if k >= 2 and abs(1.0 / k - factor) < 1e-9 and img.shape[0] % k == 0 and img.shape[1] % k == 0:
+        h, w = img.shape[0] // k, img.shape[1] // k
+        m = img.reshape(h, k, w, k, -1).astype(np.float64).mean((1, 3))
+        return np.floor(m + 0.5).astype(img.dtype) if img.dtype.kind in "ui" else m.astype(img.dtype)
+    try:
+        import cv2
+    except ImportError as e:
+        raise RuntimeError("resize_factor %r needs OpenCV (only 1 and 1/k on divisible sizes are built in)" % factor) from e
+    return cv2.resize(img, (0, 0), fx=factor, fy=factor, interpolation=cv2.INTER_AREA)
+
+
+class SequenceDataset(torch.utils.data.Dataset):
+    """brics_dynamic.py::Dataset: one subject, several actions, every (action, frame, camera) one item (or one item per
+    (action, frame) with `rand_views_per_timestep` random cameras)."""
+
+    def __init__(self, root_dir, opts=None, split="train", split_file_dir=None):
+        o = dict(DEFAULT_OPTS)
+        o.update(opts or {})
+        self.opts, self.split, self.root_dir = o, split, root_dir
+        self.training = split == "train"
+        self.resize_factor, self.bg_color = o["resize_factor"], o["bg_color"]
+        self.width, self.height, self.subject_id = o["width"], o["height"], o["subject"]
+        self.split_file_dir = split_file_dir
+        self.actions, self.index_list, self.metadata_dict, to_choose = self.dataset_index_list(
+            root_dir, split, o["num_time_steps"], o["split_ratio"], o["rand_views_per_timestep"])
+        self.get_all_cameras(to_choose)
+
+    # -- brics_dynamic.py:145-213 ---------------------------------------------------------------------------
+    def _path(self, action):
+        for ext in (".hdf5", ".npz"):
+            p = os.path.join(self.root_dir, action + ext)
+            if os.path.exists(p):
+                return p
+        raise FileNotFoundError(os.path.join(self.root_dir, action + ".hdf5"))
+
+    def dataset_index_list(self, root_dir, split, num_time_steps, split_ratio, rand_views_per_timestep):
+        o = self.opts
+        actions = natsorted([fp for fp in os.listdir(root_dir) if fp.endswith((".hdf5", ".npz"))])
+        if o["sequences"] != "all":
+            wanted = [a for a in o["sequences"]]
+            actions = [f for a in wanted for f in actions if f.rsplit(".", 1)[0] == a]
+        if len(actions) == 1 and o["split_by_action"]:
+            split_ratio = -1
+        if split_ratio > 0 and o["split_by_action"]:
+            cut = int(split_ratio * len(actions))
+            actions = actions[:cut] if split == "train" else actions[cut:]
+        index_list, metadata_dict, to_choose = [], {}, []
+        for action_path in actions:
+            action = action_path.split(".")[0]
+            metadata_dict[action] = {}
+            with open_sequence(os.path.join(root_dir, action_path)) as file:
+                frame_nos = list(file["frames"].keys())
+                cam_names = list(file.get("K").keys())
+                for fno in frame_nos:
+                    md = self.fetch_metadata(file["frames"][fno]["metadata"])
+                    md["frame_id"], md["action"] = fno, action
+                    metadata_dict[action][fno] = md
+            frame_nos = natsorted(frame_nos)
+            if num_time_steps < 0 or num_time_steps > len(frame_nos):
+                to_choose = frame_nos
+            else:
+                to_choose = frame_nos[::(len(frame_nos) // num_time_steps)]
+            for fno in to_choose:
+                if rand_views_per_timestep < 0:
+                    index_list.extend((action, fno, view) for view in cam_names)
+                else:
+                    index_list.append((action, fno, None))
+        if not o["split_by_action"]:
+            if split_ratio > 0:
+                cut = int(split_ratio * len(index_list))
+                index_list = index_list[:cut] if split == "train" else index_list[cut:]
+            if self.split_file_dir is not None:      # the reference always drops ./<split>_split.json in the cwd
+                with open(os.path.join(self.split_file_dir, "%s_split.json" % split), "w") as f:
+                    json.dump(index_list, f)
+        return actions, index_list, metadata_dict, to_choose
+
+    # -- brics_dynamic.py:215-263 ---------------------------------------------------------------------------
+    def get_all_cameras(self, to_choose):
+        action = self.index_list[0][0]               # the rig is the same for every action
+        cols = {}
+        with open_sequence(self._path(action)) as file:
+            self.mano_data = {k: v[:] for k, v in file.get("mano_rest").items()} if file.get("mano_rest") is not None else {}
+            Ks, extrs = file.get("K"), file.get("extr")
+            self.cam_names = list(Ks.keys())
+            self.cam2idx = {c: i for i, c in enumerate(self.cam_names)}
+            for _ in to_choose:                      # (the reference repeats the rig once per chosen time step)
+                for cam in self.cam_names:
+                    attrs = get_opengl_camera_attributes(Ks[cam][:], extrs[cam][:], self.width, self.height,
+                                                         resize_factor=self.resize_factor)
+                    for k, v in attrs.items():
+                        cols.setdefault(k, []).append(v)
+                    cols.setdefault("cam_name", []).append(cam)
+        self.all_cameras = Cameras(**{k: np.stack(v, 0) for k, v in cols.items()})
+        self.extent = get_scene_extent(self.all_cameras.camera_center)
+
+    def __len__(self):
+        return len(self.index_list)
+
+    def __getitem__(self, idx):
+        return self.fetch_data(idx)
+
+    def fetch_data_by_frame(self, action, frame_id, cam_name):
+        try:
+            return self.fetch_data(self.index_list.index((action, frame_id, cam_name)))
+        except (ValueError, KeyError):
+            return None
+
+    # -- brics_dynamic.py:279-327 ---------------------------------------------------------------------------
+    def fetch_metadata(self, metadata):
+        def names(key):
+            return [n[0].decode("UTF-8") if isinstance(n[0], bytes) else str(n[0]) for n in metadata[key][:].tolist()]
+        bnames, parents = np.array(names("bnames")), names("bnames_parent")
+        ids = np.arange(self.opts["n_bones"]).tolist()
+        rest = Bones(bnames=bnames, heads=metadata["rest_heads"][ids], tails=metadata["rest_tails"][ids],
+                     transforms=metadata["rest_matrixs"][ids])
+        eulers = metadata["eulers"][:]
+        r_T, r_R = metadata["root_translation"][:], metadata["root_rotation"][:]
+        posed = Bones(bnames=bnames, heads=metadata["pose_heads"][ids], tails=metadata["pose_tails"][ids],
+                      transforms=metadata["pose_matrixs"][ids], eulers=eulers,
+                      eulers_c=apply_constraints_to_poses(eulers[None], bnames), root_translation=r_T, root_rotation=r_R,
+                      kintree=T.build_kintree(bnames, parents))
+        quats = euler_angles_to_quats(torch.tensor(np.concatenate([eulers, r_R[None]], 0), dtype=torch.float32))
+        return {"bones_rest": rest, "bones_posed": posed, "pose_latent": quats.flatten()}
+
+    # -- brics_dynamic.py:334-373 ---------------------------------------------------------------------------
+    def get_bg_color(self):
+        if self.bg_color == "random":
+            return np.random.rand(3).astype(np.float32)
+        if self.bg_color == "white":
+            return np.ones(3, np.float32)
+        if self.bg_color == "black":
+            return np.zeros(3, np.float32)
+        raise ValueError("bg_color %r" % (self.bg_color,))
+
+    def fetch_images(self, data, cam_name):
+        """The RGBA crop pasted at its bbox into a full frame, resized, scaled to [0,1] and composited on the background
+        colour (the alpha channel is returned untouched: it is the segmentation mask)."""
+        img = np.zeros((self.height, self.width, 4), dtype=np.uint8)
+        xmin, ymin, xmax, ymax = (int(t) for t in data["bbox"][cam_name][:])
+        img[ymin:ymax, xmin:xmax, :] = data["images"][cam_name][:]
+        img = _area_resize(img, self.resize_factor) / 255.0
+        bkgd = self.get_bg_color()
+        alpha = img[..., 3:]
+        img[..., :3] = img[..., :3] * alpha + bkgd * (1.0 - alpha)
+        return img
+
+    # -- brics_dynamic.py:375-424 ---------------------------------------------------------------------------
+    def get_data_from_h5(self, index):
+        action, frame_id, cam_name = self.index_list[index]
+        if cam_name is None:
+            cams = list(np.random.default_rng().choice(self.cam_names, size=self.opts["rand_views_per_timestep"], replace=False))
+        else:
+            cams = [cam_name]
+        with open_sequence(self._path(action)) as file:
+            data = file.get("frames")[str(frame_id)]
+            rgba = np.array([self.fetch_images(data, c) for c in cams])
+        cameras = self.all_cameras[[self.cam2idx[c] for c in cams]]
+        return rgba, cameras, self.metadata_dict[action][str(frame_id)], [self.subject_id, action, frame_id, cams]
+
+    def fetch_data(self, index):
+        rgba, camera, md, info = self.get_data_from_h5(index)
+        rest, posed = Bones(**md["bones_rest"].__dict__), Bones(**md["bones_posed"].__dict__)   # (to_tensor converts in place)
+        return {"info": info, "rgb": to_tensor(rgba[..., :3]), "mask": to_tensor(rgba[..., 3:]), "camera": to_tensor(camera),
+                "scaling_modifier": 1.0, "bg_color": to_tensor(self.get_bg_color()), "bones_rest": to_tensor(rest),
+                "bones_posed": to_tensor(posed), "pose_latent": md["pose_latent"]}
+
+    # -- hand-off to the engine --------------------------------------------------------------------------------
+    def view_batch(self, indices, device="cpu"):
+        """Items -> what `engine.HipViewCompute` consumes for one step: targets (V,3,H,W), masks (V,H,W), the camera
+        dicts, posed bone transforms (V,J,4,4) and keypoints (V,J+1,3) = first head + all tails
+        (hand_dynamic.py:199-204)."""
+        items = [self.fetch_data(i) for i in indices]
+        cams = []
+        for it in items:
+            c = it["camera"]
+            cams.append({k: (v[0] if torch.is_tensor(v) else v[0]) for k, v in c.__dict__.items()})
+        return {
+            "targets": torch.stack([it["rgb"][0].permute(2, 0, 1) for it in items]).to(device),
+            "masks": torch.stack([it["mask"][0, ..., 0] for it in items]).to(device),
+            "cameras": cams,
+            "posed": torch.stack([it["bones_posed"].transforms for it in items]).to(device),
+            "rest": items[0]["bones_rest"].transforms.to(device),
+            "keypoints": torch.stack([torch.cat([it["bones_posed"].heads[:1], it["bones_posed"].tails], 0) for it in items]).to(device),
+        }
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# synthetic sequences in the capture schema (tests, examples)
+# ---------------------------------------------------------------------------------------------------------------------
+def synthetic_sequence(seed, n_frames=3, n_cams=4, width=64, height=48, n_bones=20, frame_start=8):
+    """{path: array} of one action file: a random 20-bone skeleton posed per frame by forward kinematics, `n_cams`
+    cameras on a ring, RGBA crops with an elliptical alpha mask."""
+    rng = np.random.default_rng(seed)
+    arr = {}
+    names = ["bone_%d" % i for i in range(n_bones)]
+    parents = ["None" if i % 4 == 0 else "bone_%d" % (i - 1) for i in range(n_bones)]
+    rest = np.tile(np.eye(4, dtype=np.float32), (n_bones, 1, 1))
+    rest[:, :3, 3] = rng.normal(0, 0.05, (n_bones, 3)).astype(np.float32)
+    rest[:, :3, :3] = T.euler_angles_to_matrix(torch.tensor(rng.normal(0, 0.4, (n_bones, 3)), dtype=torch.float32), "XYZ").numpy()
+    heads = rest[:, :3, 3].copy()
+    tails = heads + rest[:, :3, 1] * 0.03
+    kintree = T.build_kintree(names, parents)
+    for f in range(n_frames):
+        fno = str(frame_start + 3 * f)
+        eul = rng.normal(0, 0.3, (n_bones, 3)).astype(np.float32)
+        r_R = rng.normal(0, 0.2, 3).astype(np.float32)
+        r_T = rng.normal(0, 0.02, 3).astype(np.float32)
+        pose = T.get_pose_wrt_root(torch.tensor(rest), T.euler_angles_to_matrix(torch.tensor(eul), "XYZ", intrinsic=True)[None],
+                                   T.euler_angles_to_matrix(torch.tensor(r_R), "XYZ", intrinsic=True)[None],
+                                   torch.tensor(r_T)[None], kintree)[0].numpy()
+        ph = pose[:, :3, 3].copy()
+        md = {"bnames": np.array(names, dtype="S")[:, None], "bnames_parent": np.array(parents, dtype="S")[:, None],
+              "rest_heads": heads, "rest_tails": tails, "rest_matrixs": rest, "pose_heads": ph,
+              "pose_tails": ph + pose[:, :3, 1] * 0.03, "pose_matrixs": pose, "eulers": eul, "root_translation": r_T,
+              "root_rotation": r_R}
+        for k, v in md.items():
+            arr["frames/%s/metadata/%s" % (fno, k)] = v
+        for c in range(n_cams):
+            cam = "cam%02d" % c
+            w, h = int(rng.integers(width // 4, width // 2)), int(rng.integers(height // 4, height // 2))
+            x0, y0 = int(rng.integers(0, width - w)), int(rng.integers(0, height - h))
+            yy, xx = np.mgrid[0:h, 0:w]
+            inside = ((xx - w / 2) / (w / 2)) ** 2 + ((yy - h / 2) / (h / 2)) ** 2 <= 1.0
+            crop = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+            crop[..., 3] = np.where(inside, 255, rng.integers(0, 2, (h, w)) * 40).astype(np.uint8)
+            arr["frames/%s/images/%s" % (fno, cam)] = crop
+            arr["frames/%s/bbox/%s" % (fno, cam)] = np.array([x0, y0, x0 + w, y0 + h], np.int64)
+    for c in range(n_cams):
+        cam = "cam%02d" % c
+        a = 2 * np.pi * c / n_cams
+        pos = np.array([0.6 * np.cos(a), 0.6 * np.sin(a), 0.25])
+        z = -pos / np.linalg.norm(pos)
+        x = np.cross(z, [0, 0, 1.0]); x /= np.linalg.norm(x)
+        y = np.cross(z, x)
+        R = np.stack([x, y, z], 0)
+        arr["K/" + cam] = np.array([[90.0 + c, 0, width / 2 - 0.5], [0, 90.0 + c, height / 2 - 0.5], [0, 0, 1]], np.float64)
+        arr["extr/" + cam] = np.concatenate([R, (-R @ pos)[:, None]], 1).astype(np.float64)
+    arr["mano_rest/verts"] = rng.normal(0, 0.05, (30, 3)).astype(np.float32)
+    arr["mano_rest/weights"] = rng.random((30, 16)).astype(np.float32)
+    return arr

@@ -26,6 +26,7 @@ Reference functions exercised (paths relative to /root/reference):
   * src/utils/gaussian_utils.py:212-245,501-511  get_expon_lr_func / update_learning_rate
   * src/utils/gaussian_utils.py:514-518    get_contact_map (torch.cdist nearest-point distance)
   * src/utils/train_utils.py:165-204, src/utils/extra.py:203-242  load_checkpoint / remove_nans / find_best_checkpoint
+  * src/datasets/brics_dynamic.py:30-66,145-424  Dataset (index list, cameras, metadata, images) on tests/golden/seq/
   * data/meta_data/novel_pose.pkl, data/camera_paths/real.pkl  (known-answer data)
 """
 import os
@@ -698,9 +699,74 @@ def make_checkpoint_golden(mods):
     return out
 
 
+def make_dataset_golden(mods):
+    """src/datasets/brics_dynamic.py::Dataset run on two synthetic action files in the capture schema
+    (tests/golden/seq/*.npz, written here by manus_amd.dataset.synthetic_sequence).  h5py / natsort / cv2 are absent
+    from this image: h5py.File is bound to the .npz container reader (same group protocol), natsorted to a plain natural
+    sort, cv2.resize to the identity (resize_factor = 1)."""
+    import tempfile
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from manus_amd import dataset as D
+    seq_dir = os.path.join(OUT, "seq")
+    os.makedirs(seq_dir, exist_ok=True)
+    tmp = tempfile.mkdtemp()
+    for action, seed in (("grasp_2", 11), ("grasp_10", 12)):
+        arr = D.synthetic_sequence(seed)
+        D.write_tree(os.path.join(seq_dir, action + ".npz"), arr)
+        D.write_tree(os.path.join(tmp, action + ".hdf5"), arr)
+    sys.modules["h5py"].File = D.TreeStore
+    import re
+    sys.modules["natsort"].natsorted = lambda xs: sorted(
+        xs, key=lambda s: [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", s)])
+    sys.modules["cv2"].resize = lambda img, dsize, fx=1.0, fy=1.0, interpolation=None: img
+    import src.datasets.brics_dynamic as bd
+    from easydict import EasyDict
+    out = {}
+    cwd = os.getcwd()
+    os.chdir(tempfile.mkdtemp())   # the reference drops <split>_split.json into the cwd (not the data directory)
+    try:
+        cfgs = {"a": dict(num_time_steps=2, split_ratio=0.75, sequences="all", split_by_action=False),
+                "b": dict(num_time_steps=-1, split_ratio=0.5, sequences=["grasp_10"], split_by_action=True)}
+        for tag, c in cfgs.items():
+            for split in ("train", "val"):
+                opts = EasyDict(resize_factor=1.0, near=0.01, far=100.0, bg_color="white", subject="s1", width=64, height=48,
+                                root_dir=tmp, rand_views_per_timestep=-1, n_bones=20, **c)
+                ds = bd.Dataset(opts, split)
+                k = "%s_%s_" % (tag, split)
+                out[k + "index"] = np.array(["|".join(map(str, t)) for t in ds.index_list])
+                out[k + "actions"] = np.array(ds.actions)
+                out[k + "extent"] = np.float64(ds.extent)
+                out[k + "cam_names"] = np.array(ds.cam_names)
+                for f in ("K", "extr", "fovx", "fovy", "world_view_transform", "projection_matrix", "full_proj_transform",
+                          "camera_center"):
+                    out[k + "cams_" + f] = np.asarray(getattr(ds.all_cameras, f))
+                for idx in sorted({0, len(ds) // 2, len(ds) - 1}):
+                    d = ds[idx]
+                    kk = k + "item%d_" % idx
+                    out[kk + "rgb"] = d["rgb"].numpy()
+                    out[kk + "mask"] = d["mask"].numpy()
+                    out[kk + "bg"] = d["bg_color"].numpy()
+                    out[kk + "pose_latent"] = d["pose_latent"].numpy()
+                    out[kk + "info"] = np.array([str(d["info"][0]), str(d["info"][1]), str(d["info"][2]), str(d["info"][3][0])])
+                    for f in ("K", "extr", "world_view_transform", "full_proj_transform", "camera_center", "fovx"):
+                        out[kk + "cam_" + f] = np.asarray(getattr(d["camera"], f))
+                    for f in ("heads", "tails", "transforms"):
+                        out[kk + "rest_" + f] = getattr(d["bones_rest"], f).numpy()
+                    for f in ("heads", "tails", "transforms", "eulers", "eulers_c", "root_translation", "root_rotation"):
+                        out[kk + "posed_" + f] = getattr(d["bones_posed"], f).numpy()
+                    kt = d["bones_posed"].kintree
+                    out[kk + "kintree"] = np.array([int(kt[str(i)]) for i in range(20)])
+    finally:
+        os.chdir(cwd)
+    return out
+
+
 def main():
     mods = _import_reference()
     torch.manual_seed(0)
+    if "--dataset" in sys.argv:    # round 2: the sequence reader (SURVEY 8 f4)
+        np.savez_compressed(os.path.join(OUT, "dataset.npz"), **make_dataset_golden(mods))
+        return
     if "--round2" in sys.argv:     # only the fixtures added in round 2 (the others are unchanged)
         np.savez_compressed(os.path.join(OUT, "optimizer_s2.npz"), **make_optimizer_golden(mods, 2, 0.02, None, big=True))
         np.savez_compressed(os.path.join(OUT, "optimizer_s3.npz"), **make_optimizer_golden(mods, 3, 0.02, 20, big=True))

@@ -1,0 +1,110 @@
+"""CPU: the sequence reader (manus_amd/dataset.py) against the reference's own
+`src/datasets/brics_dynamic.py::Dataset` run on the same two action files (tests/golden/seq/*.npz; outputs in
+tests/golden/dataset.npz, generator tests/golden/make_golden.py --dataset)."""
+import json
+import os
+import shutil
+
+import numpy as np
+import pytest
+import torch
+
+from manus_amd import dataset as D
+
+CFGS = {"a": dict(num_time_steps=2, split_ratio=0.75, sequences="all", split_by_action=False),
+        "b": dict(num_time_steps=-1, split_ratio=0.5, sequences=["grasp_10"], split_by_action=True)}
+BASE = dict(resize_factor=1.0, bg_color="white", subject="s1", width=64, height=48, rand_views_per_timestep=-1, n_bones=20)
+
+
+@pytest.fixture()
+def seq_dir(golden_dir, tmp_path):
+    for f in os.listdir(os.path.join(golden_dir, "seq")):
+        shutil.copy(os.path.join(golden_dir, "seq", f), tmp_path / f)
+    return str(tmp_path)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+@pytest.mark.parametrize("split", ["train", "val"])
+def test_dataset_matches_reference(golden_dir, seq_dir, tag, split):
+    g = np.load(os.path.join(golden_dir, "dataset.npz"))
+    ds = D.SequenceDataset(seq_dir, dict(BASE, **CFGS[tag]), split)
+    k = "%s_%s_" % (tag, split)
+    assert ["|".join(map(str, t)) for t in ds.index_list] == list(g[k + "index"])
+    assert [a.rsplit(".", 1)[0] for a in ds.actions] == [a.rsplit(".", 1)[0] for a in g[k + "actions"]]
+    assert list(ds.cam_names) == list(g[k + "cam_names"])
+    assert abs(float(ds.extent) - float(g[k + "extent"])) < 1e-12
+    for f in ("K", "extr", "fovx", "fovy", "world_view_transform", "projection_matrix", "full_proj_transform", "camera_center"):
+        np.testing.assert_allclose(np.asarray(getattr(ds.all_cameras, f)), g[k + "cams_" + f], rtol=1e-12, atol=1e-12)
+    items = sorted({0, len(ds) // 2, len(ds) - 1})
+    assert all(k + "item%d_rgb" % i in g for i in items)
+    for idx in items:
+        d, kk = ds[idx], k + "item%d_" % idx
+        assert torch.equal(d["rgb"], torch.tensor(g[kk + "rgb"])) and torch.equal(d["mask"], torch.tensor(g[kk + "mask"]))
+        assert d["rgb"].dtype == torch.float32 and d["rgb"].shape == (1, 48, 64, 3) and d["mask"].shape == (1, 48, 64, 1)
+        assert torch.equal(d["bg_color"], torch.tensor(g[kk + "bg"]))
+        assert [str(d["info"][0]), str(d["info"][1]), str(d["info"][2]), str(d["info"][3][0])] == list(g[kk + "info"])
+        np.testing.assert_allclose(d["pose_latent"].numpy(), g[kk + "pose_latent"], atol=1e-6)
+        for f in ("K", "extr", "world_view_transform", "full_proj_transform", "camera_center", "fovx"):
+            np.testing.assert_allclose(np.asarray(getattr(d["camera"], f)), g[kk + "cam_" + f], rtol=1e-6, atol=1e-7)
+        for f in ("heads", "tails", "transforms"):
+            assert torch.equal(getattr(d["bones_rest"], f), torch.tensor(g[kk + "rest_" + f]))
+        for f in ("heads", "tails", "transforms", "eulers", "eulers_c", "root_translation", "root_rotation"):
+            assert torch.equal(getattr(d["bones_posed"], f), torch.tensor(g[kk + "posed_" + f])), f
+        assert [int(d["bones_posed"].kintree[str(i)]) for i in range(20)] == list(g[kk + "kintree"])
+
+
+def test_tree_store_protocol_and_helpers(seq_dir, tmp_path):
+    with D.open_sequence(os.path.join(seq_dir, "grasp_2.npz")) as f:
+        assert sorted(f.keys()) == ["K", "extr", "frames", "mano_rest"]
+        assert f["frames"].keys() == ["11", "14", "8"]          # by name, like h5py; natsorted orders them for use
+        assert D.natsorted(f["frames"].keys()) == ["8", "11", "14"]
+        assert f.get("nope") is None and "K" in f and len(f["K"]) == 4
+        assert f["frames"]["8"]["metadata"]["rest_matrixs"][:].shape == (20, 4, 4)
+        assert dict(f["mano_rest"].items())["verts"].shape == (30, 3)
+        with pytest.raises(KeyError):
+            f["frames"]["9"]
+    assert D.natsorted(["a10", "a2", "b1", "a1"]) == ["a1", "a2", "a10", "b1"]
+    # an HDF5 file without h5py: a loud, explained failure (this image has no h5py)
+    p = tmp_path / "x.hdf5"
+    p.write_bytes(b"\x89HDF\r\n\x1a\n" + b"\0" * 64)
+    try:
+        import h5py  # noqa: F401
+    except ImportError:
+        with pytest.raises(RuntimeError, match="h5py"):
+            D.open_sequence(str(p))
+    # area resize: 1/k block means with cv2's rounding; other factors need OpenCV
+    img = np.arange(4 * 6 * 4, dtype=np.uint8).reshape(4, 6, 4)
+    half = D._area_resize(img, 0.5)
+    assert half.shape == (2, 3, 4) and half[0, 0, 0] == int(np.floor((0 + 4 + 24 + 28) / 4 + 0.5))
+    assert D._area_resize(img, 1.0) is img
+    # quaternions: unit norm, real part first, round trip through the rotation they encode
+    e = torch.randn(50, 3, generator=torch.Generator().manual_seed(0))
+    q = D.euler_angles_to_quats(e)
+    assert torch.allclose(q.norm(dim=-1), torch.ones(50), atol=1e-6)
+    from manus_amd import transforms as T
+    R = T.euler_angles_to_matrix(e, "XYZ", intrinsic=True)
+    w, x, y, z = q.unbind(-1)
+    R2 = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                      2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                      2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], -1).reshape(-1, 3, 3)
+    assert torch.allclose(R, R2, atol=1e-5)
+
+
+def test_random_views_split_file_and_view_batch(seq_dir, tmp_path):
+    ds = D.SequenceDataset(seq_dir, dict(BASE, num_time_steps=-1, rand_views_per_timestep=3), "train",
+                           split_file_dir=str(tmp_path))
+    assert len(ds) == 2 * 3 and all(t[2] is None for t in ds.index_list)      # one item per (action, frame)
+    d = ds[1]
+    assert d["rgb"].shape == (3, 48, 64, 3) and len(set(d["info"][3])) == 3 and d["camera"].K.shape == (3, 3, 3)
+    assert json.load(open(tmp_path / "train_split.json")) == [list(t) for t in ds.index_list]
+    ds1 = D.SequenceDataset(seq_dir, dict(BASE, sequences=["grasp_2"]), "train")
+    assert len(ds1) == 3 * 4 and ds1.fetch_data_by_frame("grasp_2", "8", "cam01") is not None
+    assert ds1.fetch_data_by_frame("grasp_2", "9", "cam01") is None
+    b = ds1.view_batch([0, 1, 5])
+    assert b["targets"].shape == (3, 3, 48, 64) and b["masks"].shape == (3, 48, 64) and b["posed"].shape == (3, 20, 4, 4)
+    assert b["keypoints"].shape == (3, 21, 3) and len(b["cameras"]) == 3 and b["rest"].shape == (20, 4, 4)
+    assert torch.equal(b["keypoints"][0, 0], ds1[0]["bones_posed"].heads[0])
+    # the synthetic writer reproduces the committed fixture byte for byte
+    arr = D.synthetic_sequence(11)
+    with D.open_sequence(os.path.join(seq_dir, "grasp_2.npz")) as f:
+        assert np.array_equal(f["frames"]["8"]["images"]["cam02"], arr["frames/8/images/cam02"])
