@@ -93,8 +93,14 @@ struct __attribute__((aligned(16))) MgrGRec {
 
 struct MgrLayout {
     size_t header, scan_part, grec, depth, rect, alive, pair_off, tile_count, tile_start, tile_cursor, tile_done,
-        tile_queue, chunk_start, items, ckpt, keys, keys2, groups, sorted_gid, final_T, n_contrib, pair_tag, pair_grad, inst_grad, inst_tag, total;
+        tile_queue, chunk_start, items, ckpt, keys, keys2, groups, sorted_gid, final_T, n_contrib, pair_tag, pair_grad, inst_grad, inst_tag,
+        db_count, db_cursor, db_start, db_nvis, db_bbox, db_keys, db_order, bin_mat, total;
 };
+
+// Depth-ordered binning (raster_fwd.hip, "ordered" route): the instances of a view are sorted by depth once, then
+// scattered to the tile lists in that order, instead of sorting every tile list.
+#define MGR_DB_BUCKETS 8192   // depth buckets per view of the instance sort (1024 per octave of z above the 0.2 cull plane)
+#define MGR_BIN_BLOCK 1024    // depth-consecutive instances per row of the (block, tile) count matrix
 
 static inline size_t mgr_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -130,6 +136,17 @@ static inline MgrLayout mgr_layout(int V, int N, int W, int H, int64_t cap) {
     L.pair_grad = o;   o += mgr_align(c * 48);
     L.inst_tag = o;    o += mgr_align(VN * 4);      // epoch of the last backward that wrote a record for (view, Gaussian)
     L.inst_grad = o;   o += mgr_align(VN * 128);    // fused backward: 12 floats per (Gaussian, view) + active list
+    {
+        const size_t VB = (size_t)V * MGR_DB_BUCKETS, nblk = ((size_t)(N > 0 ? N : 1) + MGR_BIN_BLOCK - 1) / MGR_BIN_BLOCK;
+        L.db_count = o;  o += mgr_align(VB * 4);
+        L.db_cursor = o; o += mgr_align(VB * 4);
+        L.db_start = o;  o += mgr_align((VB + 1) * 4);
+        L.db_nvis = o;   o += mgr_align((size_t)V * 4);
+        L.db_bbox = o;   o += mgr_align((size_t)V * 8);      // bounding box of the view's non-empty tiles (x0, y0, w, h)
+        L.db_keys = o;   o += mgr_align(VN * 8);      // (depth bits, Gaussian) keys grouped by depth bucket
+        L.db_order = o;  o += mgr_align(VN * 4);      // Gaussians of each view in (depth, index) order
+        L.bin_mat = o;   o += mgr_align((size_t)V * nblk * gx * gy * 4);   // pairs per (block of the order, tile) -> list offsets
+    }
     L.total = o;
     return L;
 }

@@ -15,6 +15,8 @@
 //    overflow raises a flag in the workspace header.
 #include "instance_math.h"
 
+#include <cstdlib>
+#include <cstring>
 #include <map>
 #include <string>
 #include <vector>
@@ -885,6 +887,365 @@ __global__ __launch_bounds__(256) void k_tile_sort_small(
 }
 
 // ---------------------------------------------------------------------------
+// K3'/K4': depth-ordered binning (the default route; k_emit + the per-tile sorts above remain as the
+// route for images whose tile grid does not fit an LDS histogram, and for A/B runs: MGR_BINNING=sorted).
+//
+// Every tile list must come out in (depth, Gaussian index) order.  The per-tile sorts order ~R = 5.4 N
+// pairs per view; here the N instances of a view are sorted ONCE by (depth, index) and the pairs are then
+// *generated in that order*, so that no list needs sorting:
+//   1. k_dbin_count / k_dbin_scan / k_dbin_scatter: instances -> 8192 monotone depth buckets per view
+//      (float bits of z >> 13: 1024 buckets per octave above the 0.2 cull plane);
+//   2. k_dbin_sort: LDS radix sort (lds_sort_emit) of groups of 8 consecutive buckets -> db_order;
+//   3. k_bin_count: per block of MGR_BIN_BLOCK depth-consecutive instances, the pairs per tile (LDS
+//      histogram) -> one row of the (block, tile) matrix;  k_bin_scan: column-wise exclusive scan on top
+//      of tile_start -> the row becomes the block's first slot in every tile list;
+//   4. k_bin_scatter: one wave per block walks its instances in order; the lanes take the tiles of the
+//      instance, a returning LDS add on the tile's cursor hands out the slot.  LDS operations of one wave
+//      complete in program order, so the slots of a tile are handed out in instance order.  Four instances
+//      of at most 16 tiles share a step (16 lanes each, their LDS adds issued one instance after the other).
+// The result is bit-identical to the sorted route (unique keys: there is one correct order).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t db_bucket(float z) {
+    const uint32_t b = __float_as_uint(z) >> 13, b0 = 0x3E4CCCCDu >> 13;   // 0.2f
+    return b > b0 ? min(b - b0, (uint32_t)MGR_DB_BUCKETS - 1u) : 0u;
+}
+// an instance takes part when it has at least one non-null tile
+__device__ __forceinline__ bool db_takes_part(int radius, ushort4 rc, unsigned long long am) {
+    const uint32_t tiles = (uint32_t)((rc.z - rc.x) * (rc.w - rc.y));
+    return radius > 0 && tiles > 0u && (tiles > 64u || am != 0ull);
+}
+
+#define DB_PER 8   // instances per thread of the bucket count / scatter kernels (one LDS histogram flush per 8192 instances)
+__global__ __launch_bounds__(1024) void k_dbin_count(int N, const int32_t* __restrict__ radii,
+                                                     const float* __restrict__ depth, const ushort4* __restrict__ rect,
+                                                     const unsigned long long* __restrict__ alive,
+                                                     uint32_t* __restrict__ db_count) {
+    __shared__ uint32_t s_hist[MGR_DB_BUCKETS];
+    const int v = blockIdx.y, tid = threadIdx.x;
+    for (int k = tid; k < MGR_DB_BUCKETS; k += 1024) s_hist[k] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < DB_PER; ++r) {
+        const int i = (blockIdx.x * DB_PER + r) * 1024 + tid;
+        if (i < N) {
+            const size_t vi = (size_t)v * N + i;
+            if (db_takes_part(radii[vi], rect[vi], alive[vi])) atomicAdd(&s_hist[db_bucket(depth[vi])], 1u);
+        }
+    }
+    __syncthreads();
+    for (int k = tid; k < MGR_DB_BUCKETS; k += 1024) {
+        const uint32_t c = s_hist[k];
+        if (c) atomicAdd(&db_count[(size_t)v * MGR_DB_BUCKETS + k], c);
+    }
+}
+
+// one workgroup per view: bucket offsets inside the view's segment, the number of participating instances (the
+// counters are consumed: left zero for the next forward), and the bounding box of the view's non-empty tiles
+__global__ __launch_bounds__(1024) void k_dbin_scan(int gx, int T, const uint32_t* __restrict__ tile_start,
+                                                    uint32_t* __restrict__ db_count, uint32_t* __restrict__ db_cursor,
+                                                    uint32_t* __restrict__ db_start, uint32_t* __restrict__ db_nvis,
+                                                    ushort4* __restrict__ db_bbox) {
+    __shared__ uint32_t s_scan[32];
+    __shared__ uint32_t s_box[4];
+    const int v = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) { s_box[0] = 0xFFFFu; s_box[1] = 0xFFFFu; s_box[2] = 0u; s_box[3] = 0u; }
+    constexpr int PER = MGR_DB_BUCKETS / 1024;
+    uint32_t c[PER], sum = 0;
+    uint32_t* cnt = db_count + (size_t)v * MGR_DB_BUCKETS + tid * PER;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) { c[k] = cnt[k]; sum += c[k]; cnt[k] = 0; }
+    uint32_t total;
+    uint32_t run = block_excl_scan(sum, s_scan, total);   // (contains the barrier that publishes s_box)
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        db_start[(size_t)v * (MGR_DB_BUCKETS + 1) + tid * PER + k] = run;
+        db_cursor[(size_t)v * MGR_DB_BUCKETS + tid * PER + k] = 0;
+        run += c[k];
+    }
+    uint32_t x0 = 0xFFFFu, y0 = 0xFFFFu, x1 = 0u, y1 = 0u;
+    for (int t = tid; t < T; t += 1024) {
+        if (tile_start[(size_t)v * T + t + 1] > tile_start[(size_t)v * T + t]) {
+            const uint32_t y = (uint32_t)t / (uint32_t)gx, x = (uint32_t)t - y * (uint32_t)gx;
+            x0 = min(x0, x); y0 = min(y0, y); x1 = max(x1, x + 1); y1 = max(y1, y + 1);
+        }
+    }
+    if (x1 > 0u) { atomicMin(&s_box[0], x0); atomicMin(&s_box[1], y0); atomicMax(&s_box[2], x1); atomicMax(&s_box[3], y1); }
+    __syncthreads();
+    if (tid == 0) {
+        db_start[(size_t)v * (MGR_DB_BUCKETS + 1) + MGR_DB_BUCKETS] = total;
+        db_nvis[v] = total;
+        const bool any = s_box[2] > 0u;   // box = (x0, y0, width, height); empty view: 0 x 0
+        db_bbox[v] = any ? make_ushort4((unsigned short)s_box[0], (unsigned short)s_box[1], (unsigned short)(s_box[2] - s_box[0]),
+                                        (unsigned short)(s_box[3] - s_box[1]))
+                         : make_ushort4(0, 0, 0, 0);
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_dbin_scatter(int N, const int32_t* __restrict__ radii,
+                                                       const float* __restrict__ depth, const ushort4* __restrict__ rect,
+                                                       const unsigned long long* __restrict__ alive,
+                                                       const uint32_t* __restrict__ db_start, uint32_t* __restrict__ db_cursor,
+                                                       unsigned long long* __restrict__ db_keys) {
+    __shared__ uint32_t s_hist[MGR_DB_BUCKETS];
+    const int v = blockIdx.y, tid = threadIdx.x;
+    for (int k = tid; k < MGR_DB_BUCKETS; k += 1024) s_hist[k] = 0;
+    __syncthreads();
+    float z[DB_PER];
+    uint32_t on = 0;
+#pragma unroll
+    for (int r = 0; r < DB_PER; ++r) {
+        const int i = (blockIdx.x * DB_PER + r) * 1024 + tid;
+        z[r] = 0.f;
+        if (i < N) {
+            const size_t vi = (size_t)v * N + i;
+            z[r] = depth[vi];
+            if (db_takes_part(radii[vi], rect[vi], alive[vi])) {
+                on |= 1u << r;
+                atomicAdd(&s_hist[db_bucket(z[r])], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (int k = tid; k < MGR_DB_BUCKETS; k += 1024) {
+        const uint32_t c = s_hist[k];
+        if (c) s_hist[k] = db_start[(size_t)v * (MGR_DB_BUCKETS + 1) + k] + atomicAdd(&db_cursor[(size_t)v * MGR_DB_BUCKETS + k], c);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < DB_PER; ++r) {
+        if ((on >> r) & 1u) {
+            const int i = (blockIdx.x * DB_PER + r) * 1024 + tid;
+            const uint32_t pos = atomicAdd(&s_hist[db_bucket(z[r])], 1u);
+            db_keys[(size_t)v * N + pos] = ((unsigned long long)__float_as_uint(z[r]) << 32) | (unsigned)i;
+        }
+    }
+}
+
+// Sort the bucketed keys.  Item (view, c) takes the buckets whose first key lies in [c, c + 1) * DB_CHUNK of the view's
+// segment: whole buckets, about DB_CHUNK keys, every bucket in exactly one item.  One LDS sort when that is at most
+// SORT_LDS_KEYS keys; bucket by bucket otherwise; a single bucket beyond SORT_LDS_KEYS (all Gaussians in one depth
+// plane) falls back to the in-place bitonic network in global memory.
+#define DB_CHUNK 2048
+__device__ __forceinline__ uint32_t db_lower_bound(const uint32_t* __restrict__ st, uint32_t key) {
+    uint32_t lo = 0, hi = MGR_DB_BUCKETS;   // first bucket b in [0, MGR_DB_BUCKETS] with st[b] >= key (st is non-decreasing)
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (st[mid] >= key) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+__global__ __launch_bounds__(RS_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_dbin_sort(
+    int N, int chunks_per_view, int n_items, const uint32_t* __restrict__ db_start, const uint32_t* __restrict__ db_nvis,
+    unsigned long long* __restrict__ db_keys, uint32_t* __restrict__ db_order) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    unsigned long long* s_keys = (unsigned long long*)s_raw;
+    uint32_t* s_cnt = (uint32_t*)(s_raw + (size_t)SORT_LDS_KEYS * 8);
+    uint32_t* s_scan = s_cnt + RS_WAVES * 256;
+    const int tid = threadIdx.x;
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int v = item % (n_items / chunks_per_view), ch = item / (n_items / chunks_per_view);   // view-minor: neighbours differ in view
+        const uint32_t nvis = db_nvis[v];
+        if ((uint32_t)ch * DB_CHUNK >= nvis) continue;
+        const uint32_t* st = db_start + (size_t)v * (MGR_DB_BUCKETS + 1);
+        const uint32_t b0 = ch == 0 ? 0u : db_lower_bound(st, (uint32_t)ch * DB_CHUNK);
+        const uint32_t b1 = db_lower_bound(st, (uint32_t)(ch + 1) * DB_CHUNK);
+        if (b1 <= b0) continue;
+        const uint32_t lo = st[b0], hi = st[b1];
+        if (hi == lo) continue;
+        unsigned long long* keys = db_keys + (size_t)v * N;
+        uint32_t* out = db_order + (size_t)v * N;
+        const uint32_t parts = (hi - lo <= (uint32_t)SORT_LDS_KEYS) ? 1u : b1 - b0;
+        for (uint32_t p = 0; p < parts; ++p) {
+            const uint32_t a = parts == 1u ? lo : st[b0 + p], n = (parts == 1u ? hi : st[b0 + p + 1]) - a;
+            if (n == 0) continue;
+            __syncthreads();
+            if (n <= (uint32_t)SORT_LDS_KEYS) {
+                lds_sort_emit(keys + a, n, s_keys, s_cnt, s_scan, tid, out + a);
+            } else {
+                uint32_t npad = 1;
+                while (npad < n) npad <<= 1;
+                bitonic_mirror(keys + a, n, npad, tid, RS_THREADS);   // (global memory: __syncthreads orders it for the block)
+                for (uint32_t t = tid; t < n; t += RS_THREADS) out[a + t] = (uint32_t)keys[a + t];
+            }
+        }
+    }
+}
+
+// The (block, tile) matrix only spans the bounding box of a view's non-empty tiles; a view whose box has at most
+// BIN_SMALL_TILES tiles is handled by the SMALL instantiation (8 KB of LDS: many workgroups per CU), the others by the
+// one with LDS for the whole grid.  Both are launched; each returns at once for the views of the other.
+#define BIN_SMALL_TILES 2048
+__device__ __forceinline__ bool bin_mine(ushort4 box, bool small_variant) {
+    const uint32_t tb = (uint32_t)box.z * (uint32_t)box.w;
+    return tb > 0u && (tb <= (uint32_t)BIN_SMALL_TILES) == small_variant;
+}
+
+// pairs per (block of depth-consecutive instances, tile of the box)
+template <bool SMALL>
+__global__ __launch_bounds__(MGR_BIN_BLOCK) void k_bin_count(int N, int T, int nblk,
+                                                             const uint32_t* __restrict__ db_nvis,
+                                                             const ushort4* __restrict__ db_bbox,
+                                                             const uint32_t* __restrict__ db_order,
+                                                             const ushort4* __restrict__ rect,
+                                                             const unsigned long long* __restrict__ alive,
+                                                             uint32_t* __restrict__ bin_mat) {
+    extern __shared__ uint32_t s_mem[];
+    uint32_t* s_hist = s_mem;
+    const int v = blockIdx.y, b = blockIdx.x, tid = threadIdx.x;
+    const ushort4 box = db_bbox[v];
+    if (!bin_mine(box, SMALL)) return;
+    const uint32_t nvis = db_nvis[v], p = (uint32_t)b * MGR_BIN_BLOCK + tid;
+    if ((uint32_t)b * MGR_BIN_BLOCK >= nvis) return;
+    const int TB = (int)box.z * (int)box.w, bw = box.z;
+    for (int k = tid; k < TB; k += MGR_BIN_BLOCK) s_hist[k] = 0;
+    __syncthreads();
+    if (p < nvis) {
+        const size_t vi = (size_t)v * N + db_order[(size_t)v * N + p];
+        const ushort4 rc = rect[vi];
+        const unsigned long long am = alive[vi];
+        const bool small = (uint32_t)((rc.z - rc.x) * (rc.w - rc.y)) <= 64u;
+        int k = 0;
+        for (int y = rc.y; y < rc.w; ++y)
+            for (int x = rc.x; x < rc.z; ++x, ++k)
+                if (!small || ((am >> k) & 1ull)) atomicAdd(&s_hist[(y - box.y) * bw + (x - box.x)], 1u);
+    }
+    __syncthreads();
+    uint32_t* row = bin_mat + ((size_t)v * nblk + b) * T;
+    for (int k = tid; k < TB; k += MGR_BIN_BLOCK) row[k] = s_hist[k];
+}
+
+// column-wise exclusive scan over the blocks of a view, starting at the tile's list start
+__global__ __launch_bounds__(256) void k_bin_scan(int gx, int T, int nblk, const uint32_t* __restrict__ db_nvis,
+                                                  const ushort4* __restrict__ db_bbox,
+                                                  const uint32_t* __restrict__ tile_start,
+                                                  uint32_t* __restrict__ bin_mat) {
+    const int v = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
+    const ushort4 box = db_bbox[v];
+    if (k >= (int)box.z * (int)box.w) return;
+    const int ty = k / (int)box.z, tx = k - ty * (int)box.z;
+    const int nb = (int)((db_nvis[v] + MGR_BIN_BLOCK - 1) / MGR_BIN_BLOCK);
+    uint32_t run = tile_start[(size_t)v * T + (size_t)(box.y + ty) * gx + box.x + tx];
+    uint32_t* col = bin_mat + (size_t)v * nblk * T + k;
+    int b = 0;
+    for (; b + 4 <= nb; b += 4) {
+        const uint32_t c0 = col[(size_t)b * T], c1 = col[(size_t)(b + 1) * T], c2 = col[(size_t)(b + 2) * T],
+                       c3 = col[(size_t)(b + 3) * T];
+        col[(size_t)b * T] = run;
+        col[(size_t)(b + 1) * T] = run + c0;
+        col[(size_t)(b + 2) * T] = run + c0 + c1;
+        col[(size_t)(b + 3) * T] = run + c0 + c1 + c2;
+        run += c0 + c1 + c2 + c3;
+    }
+    for (; b < nb; ++b) {
+        const uint32_t c = col[(size_t)b * T];
+        col[(size_t)b * T] = run;
+        run += c;
+    }
+}
+
+// one wave per block: instances in order, slots from returning LDS adds on the block's per-tile cursors
+struct BinRec {
+    uint32_t xy, wh, alo, ahi, gid, tiles;   // x0 | y0 << 16 (signed halves, relative to the box), w | h << 16, alive mask, Gaussian, tiles
+};
+__device__ __forceinline__ int bin_x0(uint32_t xy) { return (int)(short)(xy & 0xFFFFu); }
+__device__ __forceinline__ int bin_y0(uint32_t xy) { return (int)xy >> 16; }
+__device__ __forceinline__ BinRec bin_load(int N, int v, uint32_t p, uint32_t nvis, ushort4 box,
+                                           const uint32_t* __restrict__ db_order, const ushort4* __restrict__ rect,
+                                           const unsigned long long* __restrict__ alive) {
+    BinRec r = {0u, 0u, 0u, 0u, 0u, 0u};
+    if (p < nvis) {
+        const uint32_t gid = db_order[(size_t)v * N + p];
+        const size_t vi = (size_t)v * N + gid;
+        const ushort4 rc = rect[vi];
+        const unsigned long long am = alive[vi];
+        const uint32_t w = rc.z - rc.x, h = rc.w - rc.y;
+        // relative to the box; negative when the rectangle starts outside it (those tiles are null: the box spans the
+        // non-null tiles only), hence signed halves
+        r.xy = ((uint32_t)((int)rc.x - (int)box.x) & 0xFFFFu) | ((uint32_t)((int)rc.y - (int)box.y) << 16);
+        r.wh = w | (h << 16);
+        r.tiles = w * h;
+        r.alo = (uint32_t)am; r.ahi = (uint32_t)(am >> 32);
+        r.gid = gid;
+    }
+    return r;
+}
+template <bool SMALL>
+__global__ __launch_bounds__(64) void k_bin_scatter(int N, int T, int nblk, const uint32_t* __restrict__ db_nvis,
+                                                    const ushort4* __restrict__ db_bbox,
+                                                    const uint32_t* __restrict__ db_order,
+                                                    const ushort4* __restrict__ rect,
+                                                    const unsigned long long* __restrict__ alive,
+                                                    const uint32_t* __restrict__ bin_mat,
+                                                    uint32_t* __restrict__ sorted_gid, uint32_t cap) {
+    extern __shared__ uint32_t s_mem[];
+    BinRec* s_rec = (BinRec*)s_mem;                          // 64 staged instances
+    uint32_t* s_cur = s_mem + 64 * (sizeof(BinRec) / 4);     // cursors of the box's tiles (absolute list slots)
+    const int v = blockIdx.y, b = blockIdx.x, lane = threadIdx.x;
+    const ushort4 box = db_bbox[v];
+    if (!bin_mine(box, SMALL)) return;
+    const uint32_t nvis = db_nvis[v], p0 = (uint32_t)b * MGR_BIN_BLOCK;
+    if (p0 >= nvis) return;
+    const uint32_t p1 = min(p0 + (uint32_t)MGR_BIN_BLOCK, nvis), bw = box.z;
+    BinRec nxt = bin_load(N, v, p0 + lane, nvis, box, db_order, rect, alive);
+    {
+        const int TB = (int)box.z * (int)box.w;
+        const uint32_t* row = bin_mat + ((size_t)v * nblk + b) * T;
+        for (int k = lane; k < TB; k += 64) s_cur[k] = row[k];
+    }
+    const int g = lane >> 4, kq = lane & 15;
+#pragma unroll 1
+    for (uint32_t base = p0; base < p1; base += 64) {
+        const BinRec r = nxt;
+        __builtin_amdgcn_wave_barrier();
+        s_rec[lane] = r;
+        __builtin_amdgcn_wave_barrier();
+        if (base + 64 < p1) nxt = bin_load(N, v, base + 64 + lane, nvis, box, db_order, rect, alive);   // in flight during this batch
+        const unsigned long long quad_ok = __ballot(r.tiles <= 16u);    // (empty lanes past nvis: tiles = 0)
+        int i = 0;
+#pragma unroll 1
+        while (i < 64) {
+            if ((i & 3) == 0 && ((quad_ok >> i) & 0xFull) == 0xFull) {
+                // four instances, 16 lanes each; their LDS adds are issued one instance after the other
+                const BinRec q = s_rec[i + g];
+                const uint32_t w = q.wh & 0xFFFFu;
+                const uint32_t ty = (uint32_t)(((float)kq + 0.5f) * __frcp_rn((float)max(w, 1u)));   // kq / w, exact for kq < 16
+                const uint32_t tx = kq - ty * w;
+                const unsigned long long am = ((unsigned long long)q.ahi << 32) | q.alo;
+                const bool valid = (uint32_t)kq < q.tiles && ((am >> kq) & 1ull);
+                uint32_t* cur = &s_cur[valid ? (bin_y0(q.xy) + (int)ty) * (int)bw + bin_x0(q.xy) + (int)tx : 0];
+                uint32_t pa = 0, pb = 0, pc = 0, pd = 0;
+                if (valid && g == 0) pa = atomicAdd(cur, 1u);
+                __builtin_amdgcn_wave_barrier();
+                if (valid && g == 1) pb = atomicAdd(cur, 1u);
+                __builtin_amdgcn_wave_barrier();
+                if (valid && g == 2) pc = atomicAdd(cur, 1u);
+                __builtin_amdgcn_wave_barrier();
+                if (valid && g == 3) pd = atomicAdd(cur, 1u);
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t pos = pa | pb | pc | pd;
+                if (valid && pos < cap) sorted_gid[pos] = q.gid;
+                i += 4;
+            } else {
+                const BinRec q = s_rec[i];
+                if (q.tiles) {
+                    const uint32_t w = q.wh & 0xFFFFu;
+                    const unsigned long long am = ((unsigned long long)q.ahi << 32) | q.alo;
+                    const bool small = q.tiles <= 64u;
+                    for (uint32_t k = (uint32_t)lane; k < q.tiles; k += 64) {
+                        const uint32_t ty = k / w, tx = k - ty * w;
+                        if (small && !((am >> k) & 1ull)) continue;
+                        const uint32_t pos = atomicAdd(&s_cur[(bin_y0(q.xy) + (int)ty) * (int)bw + bin_x0(q.xy) + (int)tx], 1u);
+                        if (pos < cap) sorted_gid[pos] = q.gid;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                i += 1;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // K5: front-to-back alpha compositing, one 16x16 tile at a time per 256-thread workgroup.
 //  * persistent workgroups: non-empty tiles are pulled from the size-ordered queue (largest
 //    first), then the empty tiles are background-filled with a static stride;
@@ -1195,6 +1556,10 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
         MGR_HIP(hipFuncSetAttribute((const void*)k_inst_fwd<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
         MGR_HIP(hipFuncSetAttribute((const void*)k_inst_fwd<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
         MGR_HIP(hipFuncSetAttribute((const void*)k_inst_fwd<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+        MGR_HIP(hipFuncSetAttribute((const void*)k_dbin_sort, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    SORT_LDS_KEYS * 8 + RS_WAVES * 256 * 4 + 256));
+        MGR_HIP(hipFuncSetAttribute((const void*)k_bin_count<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+        MGR_HIP(hipFuncSetAttribute((const void*)k_bin_scatter<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
         attr_set = true;
     }
 
@@ -1238,7 +1603,53 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
                            (uint32_t*)(ws + L.chunk_start), hdr, (uint32_t)cap); }
     }
     MGR_LAUNCH_CHECK("k_tile_scan", stream, debug);
-    if (N > 0) {
+    // depth-ordered binning unless the tile grid does not fit the LDS cursors (or MGR_BINNING=sorted asks for the per-tile sorts)
+    const char* binning_env = getenv("MGR_BINNING");   // read per call: tests flip it between two forwards
+    const bool ordered_env = !(binning_env && strcmp(binning_env, "sorted") == 0);
+    const bool ordered = ordered_env && lds_hist && (size_t)T * 4 + 64 * sizeof(BinRec) <= 150 * 1024;
+    if (N > 0 && ordered) {
+        const int nblk = (N + MGR_BIN_BLOCK - 1) / MGR_BIN_BLOCK;
+        const float* depth = (const float*)(ws + L.depth);
+        const ushort4* rect = (const ushort4*)(ws + L.rect);
+        const unsigned long long* alive = (const unsigned long long*)(ws + L.alive);
+        uint32_t* db_count = (uint32_t*)(ws + L.db_count);
+        uint32_t* db_cursor = (uint32_t*)(ws + L.db_cursor);
+        uint32_t* db_start = (uint32_t*)(ws + L.db_start);
+        uint32_t* db_nvis = (uint32_t*)(ws + L.db_nvis);
+        unsigned long long* db_keys = (unsigned long long*)(ws + L.db_keys);
+        uint32_t* db_order = (uint32_t*)(ws + L.db_order);
+        uint32_t* bin_mat = (uint32_t*)(ws + L.bin_mat);
+        ushort4* db_bbox = (ushort4*)(ws + L.db_bbox);
+        const dim3 grid_n((N + 1024 * DB_PER - 1) / (1024 * DB_PER), V), grid_b(nblk, V);
+        const int chunks = (N + DB_CHUNK - 1) / DB_CHUNK;
+        const size_t rec_bytes = 64 * sizeof(BinRec);
+        { MGR_PROF("k_dbin_count", stream); hipLaunchKernelGGL(k_dbin_count, grid_n, dim3(1024), 0, stream, N, (const int32_t*)radii, depth, rect, alive, db_count); }
+        { MGR_PROF("k_dbin_scan", stream); hipLaunchKernelGGL(k_dbin_scan, dim3(V), dim3(1024), 0, stream, gx, T, (const uint32_t*)tile_start, db_count, db_cursor,
+                           db_start, db_nvis, db_bbox); }
+        { MGR_PROF("k_dbin_scatter", stream); hipLaunchKernelGGL(k_dbin_scatter, grid_n, dim3(1024), 0, stream, N, (const int32_t*)radii, depth, rect, alive,
+                           (const uint32_t*)db_start, db_cursor, db_keys); }
+        { MGR_PROF("k_dbin_sort", stream); hipLaunchKernelGGL(k_dbin_sort, dim3(1024), dim3(RS_THREADS), SORT_LDS_KEYS * 8 + RS_WAVES * 256 * 4 + 256, stream,
+                           N, chunks, V * chunks, (const uint32_t*)db_start, (const uint32_t*)db_nvis, db_keys, db_order); }
+        MGR_LAUNCH_CHECK("k_dbin_sort", stream, debug);
+        const bool big_possible = T > BIN_SMALL_TILES;   // a box of more than BIN_SMALL_TILES tiles can only exist then
+        { MGR_PROF("k_bin_count", stream);
+          hipLaunchKernelGGL((k_bin_count<true>), grid_b, dim3(MGR_BIN_BLOCK), (size_t)BIN_SMALL_TILES * 4, stream, N, T, nblk, (const uint32_t*)db_nvis,
+                             (const ushort4*)db_bbox, (const uint32_t*)db_order, rect, alive, bin_mat);
+          if (big_possible)
+              hipLaunchKernelGGL((k_bin_count<false>), grid_b, dim3(MGR_BIN_BLOCK), (size_t)T * 4, stream, N, T, nblk, (const uint32_t*)db_nvis,
+                                 (const ushort4*)db_bbox, (const uint32_t*)db_order, rect, alive, bin_mat); }
+        { MGR_PROF("k_bin_scan", stream); hipLaunchKernelGGL(k_bin_scan, dim3((T + 255) / 256, V), dim3(256), 0, stream, gx, T, nblk, (const uint32_t*)db_nvis,
+                           (const ushort4*)db_bbox, (const uint32_t*)tile_start, bin_mat); }
+        { MGR_PROF("k_bin_scatter", stream);
+          hipLaunchKernelGGL((k_bin_scatter<true>), grid_b, dim3(64), (size_t)BIN_SMALL_TILES * 4 + rec_bytes, stream, N, T, nblk,
+                             (const uint32_t*)db_nvis, (const ushort4*)db_bbox, (const uint32_t*)db_order, rect, alive, (const uint32_t*)bin_mat,
+                             (uint32_t*)(ws + L.sorted_gid), (uint32_t)cap);
+          if (big_possible)
+              hipLaunchKernelGGL((k_bin_scatter<false>), grid_b, dim3(64), (size_t)T * 4 + rec_bytes, stream, N, T, nblk,
+                                 (const uint32_t*)db_nvis, (const ushort4*)db_bbox, (const uint32_t*)db_order, rect, alive, (const uint32_t*)bin_mat,
+                                 (uint32_t*)(ws + L.sorted_gid), (uint32_t)cap); }
+        MGR_LAUNCH_CHECK("k_bin_scatter", stream, debug);
+    } else if (N > 0) {
         dim3 grid((N + EMIT_THREADS - 1) / EMIT_THREADS, V);
         { MGR_PROF("k_emit", stream); hipLaunchKernelGGL(k_emit, grid, dim3(EMIT_THREADS), hist_bytes + 16, stream, N, gx, gy,
                            (const float*)(ws + L.depth), (const ushort4*)(ws + L.rect),
