@@ -162,7 +162,9 @@ int mgr_sh_to_half(int N, const float* f_rest, void* out_half, void* stream);
  * alive, pair_off, tile_count, tile_start, tile_cursor, tile_done, tile_queue, chunk_start, items,
  * ckpt, keys, sorted_gid, final_T (reserved, not written), n_contrib, pair_tag, pair_grad, total, inst_grad
  * (fused backward: per (Gaussian, view-lane) the 9 gathered blend sums, 12 floats each, then the active list),
- * inst_tag.  Returns the count. */
+ * inst_tag, db_nvis (per view: instances with at least one non-null tile), db_bbox (per view: ushort4 x0, y0, w, h of the
+ * non-empty tiles), db_order (per view: those instances in (depth, index) order) -- the last three belong to the
+ * depth-ordered binning.  Returns the count. */
 int mgr_raster_layout(int V, int N, int W, int H, int64_t pair_capacity, size_t* out, int n_out);
 
 /* Blocking read-back of the workspace header after a forward: total number of

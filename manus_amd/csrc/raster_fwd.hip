@@ -1169,6 +1169,59 @@ __device__ __forceinline__ BinRec bin_load(int N, int v, uint32_t p, uint32_t nv
     }
     return r;
 }
+// Slots for one batch of 64 instances, instance by instance (the general route: any rectangle size, any grid).
+// Four instances of at most 16 tiles share a step (16 lanes each, their LDS adds issued one instance after the other).
+__device__ __forceinline__ void bin_batch_by_instance(const BinRec& r, const BinRec* s_rec, uint32_t* s_cur, int bw, int lane,
+                                                      uint32_t* __restrict__ sorted_gid, uint32_t cap) {
+    const int g = lane >> 4, kq = lane & 15;
+    const unsigned long long quad_ok = __ballot(r.tiles <= 16u);    // (empty lanes past nvis: tiles = 0)
+    int i = 0;
+#pragma unroll 1
+    while (i < 64) {
+        if ((i & 3) == 0 && ((quad_ok >> i) & 0xFull) == 0xFull) {
+            const BinRec q = s_rec[i + g];
+            const uint32_t w = q.wh & 0xFFFFu;
+            const uint32_t ty = (uint32_t)(((float)kq + 0.5f) * __frcp_rn((float)max(w, 1u)));   // kq / w, exact for kq < 16
+            const uint32_t tx = kq - ty * w;
+            const unsigned long long am = ((unsigned long long)q.ahi << 32) | q.alo;
+            const bool valid = (uint32_t)kq < q.tiles && ((am >> kq) & 1ull);
+            uint32_t* cur = &s_cur[valid ? (bin_y0(q.xy) + (int)ty) * bw + bin_x0(q.xy) + (int)tx : 0];
+            uint32_t pa = 0, pb = 0, pc = 0, pd = 0;
+            if (valid && g == 0) pa = atomicAdd(cur, 1u);
+            __builtin_amdgcn_wave_barrier();
+            if (valid && g == 1) pb = atomicAdd(cur, 1u);
+            __builtin_amdgcn_wave_barrier();
+            if (valid && g == 2) pc = atomicAdd(cur, 1u);
+            __builtin_amdgcn_wave_barrier();
+            if (valid && g == 3) pd = atomicAdd(cur, 1u);
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t pos = pa | pb | pc | pd;
+            if (valid && pos < cap) sorted_gid[pos] = q.gid;
+            i += 4;
+        } else {
+            const BinRec q = s_rec[i];
+            if (q.tiles) {
+                const uint32_t w = q.wh & 0xFFFFu;
+                const unsigned long long am = ((unsigned long long)q.ahi << 32) | q.alo;
+                const bool small = q.tiles <= 64u;
+                for (uint32_t k = (uint32_t)lane; k < q.tiles; k += 64) {
+                    const uint32_t ty = k / w, tx = k - ty * w;
+                    if (small && !((am >> k) & 1ull)) continue;
+                    const uint32_t pos = atomicAdd(&s_cur[(bin_y0(q.xy) + (int)ty) * bw + bin_x0(q.xy) + (int)tx], 1u);
+                    if (pos < cap) sorted_gid[pos] = q.gid;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            i += 1;
+        }
+    }
+}
+
+// SMALL boxes: the batch's pairs are first expanded into an LDS list in instance order (every lane walks its own
+// alive mask), then taken 64 at a time with all lanes busy.  Lanes of a step that hit the same tile find each other
+// through a 64-bit lane mask per tile (LDS OR, then read back): the lowest lane adds the group's size to the tile's
+// cursor and the others take base + (number of lower lanes in the group) -- the order of the list, i.e. of the instances.
+#define BIN_PAIR_CAP 1024
 template <bool SMALL>
 __global__ __launch_bounds__(64) void k_bin_scatter(int N, int T, int nblk, const uint32_t* __restrict__ db_nvis,
                                                     const ushort4* __restrict__ db_bbox,
@@ -1177,22 +1230,28 @@ __global__ __launch_bounds__(64) void k_bin_scatter(int N, int T, int nblk, cons
                                                     const unsigned long long* __restrict__ alive,
                                                     const uint32_t* __restrict__ bin_mat,
                                                     uint32_t* __restrict__ sorted_gid, uint32_t cap) {
-    extern __shared__ uint32_t s_mem[];
-    BinRec* s_rec = (BinRec*)s_mem;                          // 64 staged instances
-    uint32_t* s_cur = s_mem + 64 * (sizeof(BinRec) / 4);     // cursors of the box's tiles (absolute list slots)
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_mem[];
+    BinRec* s_rec = (BinRec*)s_mem;                                     // 64 staged instances
+    unsigned long long* s_mask = (unsigned long long*)(s_mem + 64 * (sizeof(BinRec) / 4));   // SMALL: lane mask per tile
+    uint32_t* s_pairs = (uint32_t*)(s_mask + (SMALL ? BIN_SMALL_TILES : 0));                  // SMALL: the batch's pairs
+    uint32_t* s_cur = s_pairs + (SMALL ? BIN_PAIR_CAP : 0);            // cursors of the box's tiles (absolute list slots)
     const int v = blockIdx.y, b = blockIdx.x, lane = threadIdx.x;
     const ushort4 box = db_bbox[v];
     if (!bin_mine(box, SMALL)) return;
     const uint32_t nvis = db_nvis[v], p0 = (uint32_t)b * MGR_BIN_BLOCK;
     if (p0 >= nvis) return;
-    const uint32_t p1 = min(p0 + (uint32_t)MGR_BIN_BLOCK, nvis), bw = box.z;
+    const uint32_t p1 = min(p0 + (uint32_t)MGR_BIN_BLOCK, nvis);
+    const int bw = box.z;
     BinRec nxt = bin_load(N, v, p0 + lane, nvis, box, db_order, rect, alive);
     {
         const int TB = (int)box.z * (int)box.w;
         const uint32_t* row = bin_mat + ((size_t)v * nblk + b) * T;
-        for (int k = lane; k < TB; k += 64) s_cur[k] = row[k];
+        for (int k = lane; k < TB; k += 64) {
+            s_cur[k] = row[k];
+            if (SMALL) s_mask[k] = 0ull;
+        }
     }
-    const int g = lane >> 4, kq = lane & 15;
+    const unsigned long long lt = (1ull << lane) - 1ull;
 #pragma unroll 1
     for (uint32_t base = p0; base < p1; base += 64) {
         const BinRec r = nxt;
@@ -1200,48 +1259,56 @@ __global__ __launch_bounds__(64) void k_bin_scatter(int N, int T, int nblk, cons
         s_rec[lane] = r;
         __builtin_amdgcn_wave_barrier();
         if (base + 64 < p1) nxt = bin_load(N, v, base + 64 + lane, nvis, box, db_order, rect, alive);   // in flight during this batch
-        const unsigned long long quad_ok = __ballot(r.tiles <= 16u);    // (empty lanes past nvis: tiles = 0)
-        int i = 0;
-#pragma unroll 1
-        while (i < 64) {
-            if ((i & 3) == 0 && ((quad_ok >> i) & 0xFull) == 0xFull) {
-                // four instances, 16 lanes each; their LDS adds are issued one instance after the other
-                const BinRec q = s_rec[i + g];
-                const uint32_t w = q.wh & 0xFFFFu;
-                const uint32_t ty = (uint32_t)(((float)kq + 0.5f) * __frcp_rn((float)max(w, 1u)));   // kq / w, exact for kq < 16
-                const uint32_t tx = kq - ty * w;
-                const unsigned long long am = ((unsigned long long)q.ahi << 32) | q.alo;
-                const bool valid = (uint32_t)kq < q.tiles && ((am >> kq) & 1ull);
-                uint32_t* cur = &s_cur[valid ? (bin_y0(q.xy) + (int)ty) * (int)bw + bin_x0(q.xy) + (int)tx : 0];
-                uint32_t pa = 0, pb = 0, pc = 0, pd = 0;
-                if (valid && g == 0) pa = atomicAdd(cur, 1u);
-                __builtin_amdgcn_wave_barrier();
-                if (valid && g == 1) pb = atomicAdd(cur, 1u);
-                __builtin_amdgcn_wave_barrier();
-                if (valid && g == 2) pc = atomicAdd(cur, 1u);
-                __builtin_amdgcn_wave_barrier();
-                if (valid && g == 3) pd = atomicAdd(cur, 1u);
-                __builtin_amdgcn_wave_barrier();
-                const uint32_t pos = pa | pb | pc | pd;
-                if (valid && pos < cap) sorted_gid[pos] = q.gid;
-                i += 4;
-            } else {
-                const BinRec q = s_rec[i];
-                if (q.tiles) {
-                    const uint32_t w = q.wh & 0xFFFFu;
-                    const unsigned long long am = ((unsigned long long)q.ahi << 32) | q.alo;
-                    const bool small = q.tiles <= 64u;
-                    for (uint32_t k = (uint32_t)lane; k < q.tiles; k += 64) {
-                        const uint32_t ty = k / w, tx = k - ty * w;
-                        if (small && !((am >> k) & 1ull)) continue;
-                        const uint32_t pos = atomicAdd(&s_cur[(bin_y0(q.xy) + (int)ty) * (int)bw + bin_x0(q.xy) + (int)tx], 1u);
-                        if (pos < cap) sorted_gid[pos] = q.gid;
+        bool listed = false;
+        if (SMALL) {
+            const unsigned long long am = ((unsigned long long)r.ahi << 32) | r.alo;
+            const bool big = r.tiles > 64u;
+            const uint32_t cnt = (r.tiles == 0u || big) ? 0u : (uint32_t)__popcll(am);
+            uint32_t incl = cnt;   // inclusive wave scan
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
+                if (lane >= d) incl += o;
+            }
+            const uint32_t P = (uint32_t)__shfl((int)incl, 63, 64);
+            if (__ballot(big) == 0ull && P <= (uint32_t)BIN_PAIR_CAP) {
+                listed = true;
+                {   // expand: pairs of lane's instance at [incl - cnt, incl), tiles in row-major order of the rectangle
+                    uint32_t o = incl - cnt;
+                    const uint32_t w = r.wh & 0xFFFFu;
+                    const float rw = __frcp_rn((float)max(w, 1u));
+                    const int x0 = bin_x0(r.xy), y0 = bin_y0(r.xy);
+                    unsigned long long m = cnt ? am : 0ull;
+                    while (m) {
+                        const uint32_t k = (uint32_t)__builtin_ctzll(m);
+                        m &= m - 1ull;
+                        const uint32_t ty = (uint32_t)(((float)k + 0.5f) * rw), tx = k - ty * w;   // k / w, exact for k < 64
+                        s_pairs[o++] = (uint32_t)((y0 + (int)ty) * bw + x0 + (int)tx) | ((uint32_t)lane << 16);
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
-                i += 1;
+#pragma unroll 1
+                for (uint32_t c = 0; c < P; c += 64) {
+                    const bool valid = c + lane < P;
+                    const uint32_t pr = valid ? s_pairs[c + lane] : 0u;
+                    const uint32_t t = pr & 0xFFFFu;
+                    if (valid) atomicOr(&s_mask[t], 1ull << lane);
+                    __builtin_amdgcn_wave_barrier();
+                    const unsigned long long mm = valid ? s_mask[t] : (1ull << lane);
+                    const uint32_t rank = (uint32_t)__popcll(mm & lt);
+                    const bool leader = valid && rank == 0u;
+                    uint32_t first = 0u;
+                    if (leader) first = atomicAdd(&s_cur[t], (uint32_t)__popcll(mm));
+                    __builtin_amdgcn_wave_barrier();
+                    if (leader) s_mask[t] = 0ull;
+                    first = (uint32_t)__shfl((int)first, __builtin_ctzll(mm), 64);
+                    const uint32_t gid = (uint32_t)__shfl((int)r.gid, (int)(pr >> 16), 64);
+                    const uint32_t pos = first + rank;
+                    if (valid && pos < cap) sorted_gid[pos] = gid;
+                }
             }
         }
+        if (!listed) bin_batch_by_instance(r, s_rec, s_cur, bw, lane, sorted_gid, cap);
     }
 }
 
@@ -1641,7 +1708,7 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
         { MGR_PROF("k_bin_scan", stream); hipLaunchKernelGGL(k_bin_scan, dim3((T + 255) / 256, V), dim3(256), 0, stream, gx, T, nblk, (const uint32_t*)db_nvis,
                            (const ushort4*)db_bbox, (const uint32_t*)tile_start, bin_mat); }
         { MGR_PROF("k_bin_scatter", stream);
-          hipLaunchKernelGGL((k_bin_scatter<true>), grid_b, dim3(64), (size_t)BIN_SMALL_TILES * 4 + rec_bytes, stream, N, T, nblk,
+          hipLaunchKernelGGL((k_bin_scatter<true>), grid_b, dim3(64), (size_t)BIN_SMALL_TILES * 12 + BIN_PAIR_CAP * 4 + rec_bytes, stream, N, T, nblk,
                              (const uint32_t*)db_nvis, (const ushort4*)db_bbox, (const uint32_t*)db_order, rect, alive, (const uint32_t*)bin_mat,
                              (uint32_t*)(ws + L.sorted_gid), (uint32_t)cap);
           if (big_possible)
@@ -1721,7 +1788,8 @@ extern "C" int mgr_raster_layout(int V, int N, int W, int H, int64_t cap, size_t
     const MgrLayout L = mgr_layout(V, N, W, H, cap);
     const size_t v[] = {L.header, L.grec, L.depth, L.rect, L.alive, L.pair_off, L.tile_count, L.tile_start,
                         L.tile_cursor, L.tile_done, L.tile_queue, L.chunk_start, L.items, L.ckpt, L.keys,
-                        L.sorted_gid, L.final_T, L.n_contrib, L.pair_tag, L.pair_grad, L.total, L.inst_grad, L.inst_tag};
+                        L.sorted_gid, L.final_T, L.n_contrib, L.pair_tag, L.pair_grad, L.total, L.inst_grad, L.inst_tag,
+                        L.db_nvis, L.db_bbox, L.db_order};
     const int n = (int)(sizeof(v) / sizeof(v[0]));
     for (int i = 0; i < n && i < n_out; ++i) out[i] = v[i];
     return n;
