@@ -30,6 +30,9 @@ def build(force=False, verbose=False):
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    stamp = os.path.join(objdir, "flags.txt")    # objects built with other flags (MGR_EXTRA_FLAGS) are stale too
+    if not os.path.exists(stamp) or open(stamp).read() != " ".join(FLAGS):
+        force = True
     objs = []
     procs = []
     for src in SOURCES:
@@ -47,6 +50,8 @@ def build(force=False, verbose=False):
             raise RuntimeError("hipcc failed on %s:\n%s" % (src, out.decode()))
         if verbose and out:
             print(out.decode())
+    with open(stamp, "w") as f:
+        f.write(" ".join(FLAGS))
     if force or procs or _stale(LIB, objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         subprocess.check_call(cmd)

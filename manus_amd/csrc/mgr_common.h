@@ -94,7 +94,7 @@ struct __attribute__((aligned(16))) MgrGRec {
 struct MgrLayout {
     size_t header, scan_part, grec, depth, rect, alive, pair_off, tile_count, tile_start, tile_cursor, tile_done,
         tile_queue, chunk_start, items, ckpt, keys, keys2, groups, sorted_gid, final_T, n_contrib, pair_tag, pair_grad, inst_grad, inst_tag,
-        db_count, db_cursor, db_start, db_nvis, db_bbox, db_keys, db_order, bin_mat, total;
+        db_count, db_cursor, db_start, db_nvis, db_bbox, db_keys, db_order, db_rec, bin_mat, total;
 };
 
 // Depth-ordered binning (raster_fwd.hip, "ordered" route): the instances of a view are sorted by depth once, then
@@ -145,6 +145,7 @@ static inline MgrLayout mgr_layout(int V, int N, int W, int H, int64_t cap) {
         L.db_bbox = o;   o += mgr_align((size_t)V * 8);      // bounding box of the view's non-empty tiles (x0, y0, w, h)
         L.db_keys = o;   o += mgr_align(VN * 8);      // (depth bits, Gaussian) keys grouped by depth bucket
         L.db_order = o;  o += mgr_align(VN * 4);      // Gaussians of each view in (depth, index) order
+        L.db_rec = o;    o += mgr_align(VN * 16);     // their tile rectangles and alive masks, in that order
         L.bin_mat = o;   o += mgr_align((size_t)V * nblk * gx * gy * 4);   // pairs per (block of the order, tile) -> list offsets
     }
     L.total = o;

@@ -1080,65 +1080,115 @@ __device__ __forceinline__ bool bin_mine(ushort4 box, bool small_variant) {
     return tb > 0u && (tb <= (uint32_t)BIN_SMALL_TILES) == small_variant;
 }
 
-// pairs per (block of depth-consecutive instances, tile of the box)
+// pairs per (block of depth-consecutive instances, tile of the box); 256 threads take four instances each (the gathers
+// of all four in flight together), eight workgroups per CU
+#define BCNT_THREADS 256
+#define BCNT_PER (MGR_BIN_BLOCK / BCNT_THREADS)
 template <bool SMALL>
-__global__ __launch_bounds__(MGR_BIN_BLOCK) void k_bin_count(int N, int T, int nblk,
-                                                             const uint32_t* __restrict__ db_nvis,
-                                                             const ushort4* __restrict__ db_bbox,
-                                                             const uint32_t* __restrict__ db_order,
-                                                             const ushort4* __restrict__ rect,
-                                                             const unsigned long long* __restrict__ alive,
-                                                             uint32_t* __restrict__ bin_mat) {
+__global__ __launch_bounds__(BCNT_THREADS) void k_bin_count(int N, int T, int nblk,
+                                                            const uint32_t* __restrict__ db_nvis,
+                                                            const ushort4* __restrict__ db_bbox,
+                                                            const uint32_t* __restrict__ db_order,
+                                                            const ushort4* __restrict__ rect,
+                                                            const unsigned long long* __restrict__ alive,
+                                                            uint4* __restrict__ db_rec, uint32_t* __restrict__ bin_mat) {
     extern __shared__ uint32_t s_mem[];
     uint32_t* s_hist = s_mem;
     const int v = blockIdx.y, b = blockIdx.x, tid = threadIdx.x;
     const ushort4 box = db_bbox[v];
     if (!bin_mine(box, SMALL)) return;
-    const uint32_t nvis = db_nvis[v], p = (uint32_t)b * MGR_BIN_BLOCK + tid;
+    const uint32_t nvis = db_nvis[v];
     if ((uint32_t)b * MGR_BIN_BLOCK >= nvis) return;
     const int TB = (int)box.z * (int)box.w, bw = box.z;
-    for (int k = tid; k < TB; k += MGR_BIN_BLOCK) s_hist[k] = 0;
+    uint32_t gid[BCNT_PER];
+#pragma unroll
+    for (int r = 0; r < BCNT_PER; ++r) {
+        const uint32_t p = (uint32_t)b * MGR_BIN_BLOCK + r * BCNT_THREADS + tid;
+        gid[r] = p < nvis ? db_order[(size_t)v * N + p] : 0u;
+    }
+    ushort4 rc[BCNT_PER];
+    unsigned long long am[BCNT_PER];
+#pragma unroll
+    for (int r = 0; r < BCNT_PER; ++r) {
+        rc[r] = rect[(size_t)v * N + gid[r]];
+        am[r] = alive[(size_t)v * N + gid[r]];
+    }
+    for (int k = tid; k < TB; k += BCNT_THREADS) s_hist[k] = 0;
     __syncthreads();
-    if (p < nvis) {
-        const size_t vi = (size_t)v * N + db_order[(size_t)v * N + p];
-        const ushort4 rc = rect[vi];
-        const unsigned long long am = alive[vi];
-        const bool small = (uint32_t)((rc.z - rc.x) * (rc.w - rc.y)) <= 64u;
-        int k = 0;
-        for (int y = rc.y; y < rc.w; ++y)
-            for (int x = rc.x; x < rc.z; ++x, ++k)
-                if (!small || ((am >> k) & 1ull)) atomicAdd(&s_hist[(y - box.y) * bw + (x - box.x)], 1u);
+#pragma unroll
+    for (int r = 0; r < BCNT_PER; ++r) {
+        const uint32_t p = (uint32_t)b * MGR_BIN_BLOCK + r * BCNT_THREADS + tid;
+        if (p < nvis) {
+            // the gathered rectangle and mask, in depth order, for k_bin_scatter (which then reads them coalesced)
+            const uint32_t w = rc[r].z - rc[r].x, h = rc[r].w - rc[r].y;
+            db_rec[(size_t)v * N + p] = make_uint4((uint32_t)rc[r].x | ((uint32_t)rc[r].y << 16), w | (h << 16), (uint32_t)am[r],
+                                                   (uint32_t)(am[r] >> 32));
+            const int org = ((int)rc[r].y - (int)box.y) * bw + (int)rc[r].x - (int)box.x;
+            if (w * h <= 64u) {
+                const float rw = __frcp_rn((float)max(w, 1u));
+                unsigned long long m = am[r];
+                while (m) {
+                    const uint32_t k = (uint32_t)__builtin_ctzll(m);
+                    m &= m - 1ull;
+                    const uint32_t ty = (uint32_t)(((float)k + 0.5f) * rw), tx = k - ty * w;   // k / w, exact for k < 64
+                    atomicAdd(&s_hist[org + (int)ty * bw + (int)tx], 1u);
+                }
+            } else {
+                for (uint32_t y = 0; y < h; ++y)
+                    for (uint32_t x = 0; x < w; ++x) atomicAdd(&s_hist[org + (int)y * bw + (int)x], 1u);
+            }
+        }
     }
     __syncthreads();
     uint32_t* row = bin_mat + ((size_t)v * nblk + b) * T;
-    for (int k = tid; k < TB; k += MGR_BIN_BLOCK) row[k] = s_hist[k];
+    for (int k = tid; k < TB; k += BCNT_THREADS) row[k] = s_hist[k];
 }
 
-// column-wise exclusive scan over the blocks of a view, starting at the tile's list start
-__global__ __launch_bounds__(256) void k_bin_scan(int gx, int T, int nblk, const uint32_t* __restrict__ db_nvis,
-                                                  const ushort4* __restrict__ db_bbox,
-                                                  const uint32_t* __restrict__ tile_start,
-                                                  uint32_t* __restrict__ bin_mat) {
-    const int v = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
+// column-wise exclusive scan over the blocks of a view, starting at the tile's list start.  A workgroup takes 32 columns;
+// its 8 waves each sum an eighth of the rows (loads of a wave: 32 columns x 2 rows, coalesced), the partial sums meet in
+// LDS, and every wave then rewrites its rows as running offsets.
+#define BSCAN_COLS 32
+#define BSCAN_SEGS 16
+__global__ __launch_bounds__(BSCAN_COLS * BSCAN_SEGS) void k_bin_scan(int gx, int T, int nblk, const uint32_t* __restrict__ db_nvis,
+                                                                      const ushort4* __restrict__ db_bbox,
+                                                                      const uint32_t* __restrict__ tile_start,
+                                                                      uint32_t* __restrict__ bin_mat) {
+    __shared__ uint32_t s_part[BSCAN_SEGS][BSCAN_COLS];
+    const int v = blockIdx.y, col = threadIdx.x & (BSCAN_COLS - 1), seg = threadIdx.x / BSCAN_COLS;
+    const int k = blockIdx.x * BSCAN_COLS + col;
     const ushort4 box = db_bbox[v];
-    if (k >= (int)box.z * (int)box.w) return;
-    const int ty = k / (int)box.z, tx = k - ty * (int)box.z;
+    const int TB = (int)box.z * (int)box.w;
+    if (blockIdx.x * BSCAN_COLS >= TB) return;
+    const bool on = k < TB;
     const int nb = (int)((db_nvis[v] + MGR_BIN_BLOCK - 1) / MGR_BIN_BLOCK);
+    const int per = (nb + BSCAN_SEGS - 1) / BSCAN_SEGS, b0 = min(seg * per, nb), b1 = min(b0 + per, nb);
+    uint32_t* colp = bin_mat + (size_t)v * nblk * T + (on ? k : 0);
+    uint32_t sum = 0;
+    if (on) {
+        int b = b0;
+        for (; b + 4 <= b1; b += 4)
+            sum += colp[(size_t)b * T] + colp[(size_t)(b + 1) * T] + colp[(size_t)(b + 2) * T] + colp[(size_t)(b + 3) * T];
+        for (; b < b1; ++b) sum += colp[(size_t)b * T];
+    }
+    s_part[seg][col] = sum;
+    __syncthreads();
+    if (!on) return;
+    const int ty = k / (int)box.z, tx = k - ty * (int)box.z;
     uint32_t run = tile_start[(size_t)v * T + (size_t)(box.y + ty) * gx + box.x + tx];
-    uint32_t* col = bin_mat + (size_t)v * nblk * T + k;
-    int b = 0;
-    for (; b + 4 <= nb; b += 4) {
-        const uint32_t c0 = col[(size_t)b * T], c1 = col[(size_t)(b + 1) * T], c2 = col[(size_t)(b + 2) * T],
-                       c3 = col[(size_t)(b + 3) * T];
-        col[(size_t)b * T] = run;
-        col[(size_t)(b + 1) * T] = run + c0;
-        col[(size_t)(b + 2) * T] = run + c0 + c1;
-        col[(size_t)(b + 3) * T] = run + c0 + c1 + c2;
+    for (int j = 0; j < seg; ++j) run += s_part[j][col];
+    int b = b0;
+    for (; b + 4 <= b1; b += 4) {
+        const uint32_t c0 = colp[(size_t)b * T], c1 = colp[(size_t)(b + 1) * T], c2 = colp[(size_t)(b + 2) * T],
+                       c3 = colp[(size_t)(b + 3) * T];
+        colp[(size_t)b * T] = run;
+        colp[(size_t)(b + 1) * T] = run + c0;
+        colp[(size_t)(b + 2) * T] = run + c0 + c1;
+        colp[(size_t)(b + 3) * T] = run + c0 + c1 + c2;
         run += c0 + c1 + c2 + c3;
     }
-    for (; b < nb; ++b) {
-        const uint32_t c = col[(size_t)b * T];
-        col[(size_t)b * T] = run;
+    for (; b < b1; ++b) {
+        const uint32_t c = colp[(size_t)b * T];
+        colp[(size_t)b * T] = run;
         run += c;
     }
 }
@@ -1150,22 +1200,18 @@ struct BinRec {
 __device__ __forceinline__ int bin_x0(uint32_t xy) { return (int)(short)(xy & 0xFFFFu); }
 __device__ __forceinline__ int bin_y0(uint32_t xy) { return (int)xy >> 16; }
 __device__ __forceinline__ BinRec bin_load(int N, int v, uint32_t p, uint32_t nvis, ushort4 box,
-                                           const uint32_t* __restrict__ db_order, const ushort4* __restrict__ rect,
-                                           const unsigned long long* __restrict__ alive) {
+                                           const uint32_t* __restrict__ db_order, const uint4* __restrict__ db_rec) {
     BinRec r = {0u, 0u, 0u, 0u, 0u, 0u};
     if (p < nvis) {
-        const uint32_t gid = db_order[(size_t)v * N + p];
-        const size_t vi = (size_t)v * N + gid;
-        const ushort4 rc = rect[vi];
-        const unsigned long long am = alive[vi];
-        const uint32_t w = rc.z - rc.x, h = rc.w - rc.y;
+        const uint4 q = db_rec[(size_t)v * N + p];      // two independent coalesced loads
+        r.gid = db_order[(size_t)v * N + p];
+        const uint32_t w = q.y & 0xFFFFu, h = q.y >> 16;
         // relative to the box; negative when the rectangle starts outside it (those tiles are null: the box spans the
         // non-null tiles only), hence signed halves
-        r.xy = ((uint32_t)((int)rc.x - (int)box.x) & 0xFFFFu) | ((uint32_t)((int)rc.y - (int)box.y) << 16);
-        r.wh = w | (h << 16);
+        r.xy = ((uint32_t)((int)(q.x & 0xFFFFu) - (int)box.x) & 0xFFFFu) | ((uint32_t)((int)(q.x >> 16) - (int)box.y) << 16);
+        r.wh = q.y;
         r.tiles = w * h;
-        r.alo = (uint32_t)am; r.ahi = (uint32_t)(am >> 32);
-        r.gid = gid;
+        r.alo = q.z; r.ahi = q.w;
     }
     return r;
 }
@@ -1217,24 +1263,32 @@ __device__ __forceinline__ void bin_batch_by_instance(const BinRec& r, const Bin
     }
 }
 
-// SMALL boxes: the batch's pairs are first expanded into an LDS list in instance order (every lane walks its own
-// alive mask), then taken 64 at a time with all lanes busy.  Lanes of a step that hit the same tile find each other
-// through a 64-bit lane mask per tile (LDS OR, then read back): the lowest lane adds the group's size to the tile's
-// cursor and the others take base + (number of lower lanes in the group) -- the order of the list, i.e. of the instances.
+// The usual route (no rectangle of more than 64 tiles in the batch, at most BIN_PAIR_CAP pairs): the batch's pairs are
+// expanded into an LDS list in instance order (every lane walks its own alive mask), then taken 64 at a time with all
+// lanes busy.  About a dozen tiles per step are hit by more than one lane (measured on the bench scene), so the lanes
+// of a tile must be ranked: through a per-tile lane mask in LDS when the box is SMALL; otherwise by one returning add
+// per pair in whatever order the hardware serves the lanes, the cursor read back (a pair alone on its tile sees
+// cursor == slot + 1), and the shared tiles put right one at a time (ballot of the tile's lanes -> slot = cursor - group
+// size + number of lower lanes, i.e. list = instance order).
 #define BIN_PAIR_CAP 1024
+#ifdef BIN_PROF
+__device__ unsigned long long g_binprof[8 * 4096];
+#define BP(k) { const long long now_ = wall_clock64(); acc_[k] += now_ - tp_; tp_ = now_; }
+#else
+#define BP(k)
+#endif
 template <bool SMALL>
 __global__ __launch_bounds__(64) void k_bin_scatter(int N, int T, int nblk, const uint32_t* __restrict__ db_nvis,
                                                     const ushort4* __restrict__ db_bbox,
                                                     const uint32_t* __restrict__ db_order,
-                                                    const ushort4* __restrict__ rect,
-                                                    const unsigned long long* __restrict__ alive,
+                                                    const uint4* __restrict__ db_rec,
                                                     const uint32_t* __restrict__ bin_mat,
                                                     uint32_t* __restrict__ sorted_gid, uint32_t cap) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_mem[];
-    BinRec* s_rec = (BinRec*)s_mem;                                     // 64 staged instances
+    BinRec* s_rec = (BinRec*)s_mem;                                     // 64 staged instances (by-instance route)
     unsigned long long* s_mask = (unsigned long long*)(s_mem + 64 * (sizeof(BinRec) / 4));   // SMALL: lane mask per tile
-    uint32_t* s_pairs = (uint32_t*)(s_mask + (SMALL ? BIN_SMALL_TILES : 0));                  // SMALL: the batch's pairs
-    uint32_t* s_cur = s_pairs + (SMALL ? BIN_PAIR_CAP : 0);            // cursors of the box's tiles (absolute list slots)
+    uint32_t* s_pairs = (uint32_t*)(s_mask + (SMALL ? BIN_SMALL_TILES : 0));                  // the batch's pairs: tile | lane << 16
+    uint32_t* s_cur = s_pairs + BIN_PAIR_CAP;                           // cursors of the box's tiles (absolute list slots)
     const int v = blockIdx.y, b = blockIdx.x, lane = threadIdx.x;
     const ushort4 box = db_bbox[v];
     if (!bin_mine(box, SMALL)) return;
@@ -1242,74 +1296,134 @@ __global__ __launch_bounds__(64) void k_bin_scatter(int N, int T, int nblk, cons
     if (p0 >= nvis) return;
     const uint32_t p1 = min(p0 + (uint32_t)MGR_BIN_BLOCK, nvis);
     const int bw = box.z;
-    BinRec nxt = bin_load(N, v, p0 + lane, nvis, box, db_order, rect, alive);
+    BinRec nxt = bin_load(N, v, p0 + lane, nvis, box, db_order, db_rec);
     {
         const int TB = (int)box.z * (int)box.w;
         const uint32_t* row = bin_mat + ((size_t)v * nblk + b) * T;
-        for (int k = lane; k < TB; k += 64) {
-            s_cur[k] = row[k];
-            if (SMALL) s_mask[k] = 0ull;
+        int k = lane;
+        for (; k + 192 < TB; k += 256) {   // four loads in flight
+            const uint32_t a0 = row[k], a1 = row[k + 64], a2 = row[k + 128], a3 = row[k + 192];
+            s_cur[k] = a0; s_cur[k + 64] = a1; s_cur[k + 128] = a2; s_cur[k + 192] = a3;
         }
+        for (; k < TB; k += 64) s_cur[k] = row[k];
+        if (SMALL) for (k = lane; k < TB; k += 64) s_mask[k] = 0ull;
     }
     const unsigned long long lt = (1ull << lane) - 1ull;
+#ifdef BIN_PROF
+    long long acc_[6] = {0, 0, 0, 0, 0, 0};
+    const long long t00_ = wall_clock64();
+    long long tp_ = t00_;
+#endif
 #pragma unroll 1
     for (uint32_t base = p0; base < p1; base += 64) {
         const BinRec r = nxt;
-        __builtin_amdgcn_wave_barrier();
-        s_rec[lane] = r;
-        __builtin_amdgcn_wave_barrier();
-        if (base + 64 < p1) nxt = bin_load(N, v, base + 64 + lane, nvis, box, db_order, rect, alive);   // in flight during this batch
-        bool listed = false;
-        if (SMALL) {
-            const unsigned long long am = ((unsigned long long)r.ahi << 32) | r.alo;
-            const bool big = r.tiles > 64u;
-            const uint32_t cnt = (r.tiles == 0u || big) ? 0u : (uint32_t)__popcll(am);
-            uint32_t incl = cnt;   // inclusive wave scan
+        BP(0)
+        if (base + 64 < p1) nxt = bin_load(N, v, base + 64 + lane, nvis, box, db_order, db_rec);   // in flight during this batch
+        const unsigned long long am = ((unsigned long long)r.ahi << 32) | r.alo;
+        const bool big = r.tiles > 64u;
+        const uint32_t cnt = (r.tiles == 0u || big) ? 0u : (uint32_t)__popcll(am);
+        uint32_t incl = cnt;   // inclusive wave scan
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
-                if (lane >= d) incl += o;
-            }
-            const uint32_t P = (uint32_t)__shfl((int)incl, 63, 64);
-            if (__ballot(big) == 0ull && P <= (uint32_t)BIN_PAIR_CAP) {
-                listed = true;
-                {   // expand: pairs of lane's instance at [incl - cnt, incl), tiles in row-major order of the rectangle
-                    uint32_t o = incl - cnt;
-                    const uint32_t w = r.wh & 0xFFFFu;
-                    const float rw = __frcp_rn((float)max(w, 1u));
-                    const int x0 = bin_x0(r.xy), y0 = bin_y0(r.xy);
-                    unsigned long long m = cnt ? am : 0ull;
-                    while (m) {
-                        const uint32_t k = (uint32_t)__builtin_ctzll(m);
-                        m &= m - 1ull;
-                        const uint32_t ty = (uint32_t)(((float)k + 0.5f) * rw), tx = k - ty * w;   // k / w, exact for k < 64
-                        s_pairs[o++] = (uint32_t)((y0 + (int)ty) * bw + x0 + (int)tx) | ((uint32_t)lane << 16);
-                    }
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
+            if (lane >= d) incl += o;
+        }
+        const uint32_t P = (uint32_t)__shfl((int)incl, 63, 64);
+        BP(1)
+        if (__ballot(big) == 0ull && P <= (uint32_t)BIN_PAIR_CAP) {
+            {   // expand: pairs of lane's instance at [incl - cnt, incl), tiles in row-major order of the rectangle
+                uint32_t o = incl - cnt;
+                const uint32_t w = r.wh & 0xFFFFu;
+                const float rw = __frcp_rn((float)max(w, 1u));
+                const int org = bin_y0(r.xy) * bw + bin_x0(r.xy);
+                unsigned long long m = cnt ? am : 0ull;
+                while (m) {
+                    const uint32_t k = (uint32_t)__builtin_ctzll(m);
+                    m &= m - 1ull;
+                    const uint32_t ty = (uint32_t)(((float)k + 0.5f) * rw), tx = k - ty * w;   // k / w, exact for k < 64
+                    s_pairs[o++] = (uint32_t)(org + (int)ty * bw + (int)tx) | ((uint32_t)lane << 16);
                 }
-                __builtin_amdgcn_wave_barrier();
+            }
+            __builtin_amdgcn_wave_barrier();
+            BP(2)
+            uint32_t pr_n = lane < P ? s_pairs[lane] : 0u;
+            if (SMALL) {
+                // Lanes of a step on the same tile find each other through the tile's 64-bit lane mask (LDS OR, read back):
+                // the lowest lane adds the group's size to the cursor, the others take its result + their rank in the mask.
+                // The returning add of step c is still in flight while the masks of step c + 1 are built and read.
+                uint32_t first_p = 0u, rank_p = 0u, gid_p = 0u, src_p = 0u;   // step c - 1: add result pending
+                bool valid_p = false;
 #pragma unroll 1
-                for (uint32_t c = 0; c < P; c += 64) {
+                for (uint32_t c = 0; c < P + 64; c += 64) {
                     const bool valid = c + lane < P;
-                    const uint32_t pr = valid ? s_pairs[c + lane] : 0u;
+                    const uint32_t pr = pr_n;
+                    if (c + 64 < P) pr_n = (c + 64 + lane < P) ? s_pairs[c + 64 + lane] : 0u;   // next step's pairs
                     const uint32_t t = pr & 0xFFFFu;
                     if (valid) atomicOr(&s_mask[t], 1ull << lane);
                     __builtin_amdgcn_wave_barrier();
-                    const unsigned long long mm = valid ? s_mask[t] : (1ull << lane);
+                    const unsigned long long mm = valid ? *(volatile unsigned long long*)&s_mask[t] : (1ull << lane);
                     const uint32_t rank = (uint32_t)__popcll(mm & lt);
                     const bool leader = valid && rank == 0u;
                     uint32_t first = 0u;
-                    if (leader) first = atomicAdd(&s_cur[t], (uint32_t)__popcll(mm));
-                    __builtin_amdgcn_wave_barrier();
-                    if (leader) s_mask[t] = 0ull;
-                    first = (uint32_t)__shfl((int)first, __builtin_ctzll(mm), 64);
+                    if (leader) {
+                        first = atomicAdd(&s_cur[t], (uint32_t)__popcll(mm));
+                        s_mask[t] = 0ull;
+                    }
                     const uint32_t gid = (uint32_t)__shfl((int)r.gid, (int)(pr >> 16), 64);
-                    const uint32_t pos = first + rank;
-                    if (valid && pos < cap) sorted_gid[pos] = gid;
+                    // finish step c - 1
+                    if (c > 0) {
+                        const uint32_t f = (uint32_t)__shfl((int)first_p, (int)src_p, 64);
+                        const uint32_t pos = f + rank_p;
+                        if (valid_p && pos < cap) sorted_gid[pos] = gid_p;
+                    }
+                    first_p = first; rank_p = rank; gid_p = gid; valid_p = valid;
+                    src_p = (uint32_t)__builtin_ctzll(mm);
                 }
+            } else {
+#pragma unroll 1
+            for (uint32_t c = 0; c < P; c += 64) {
+                const bool valid = c + lane < P;
+                const uint32_t pr = pr_n;
+                if (c + 64 < P) pr_n = (c + 64 + lane < P) ? s_pairs[c + 64 + lane] : 0u;   // next step's pairs
+                const uint32_t t = pr & 0xFFFFu;
+                uint32_t pos = 0u, cend = 1u;
+                if (valid) {
+                    pos = atomicAdd(&s_cur[t], 1u);
+                    cend = *(volatile uint32_t*)&s_cur[t];   // after the adds of every lane of this step (LDS: in order)
+                }
+                const uint32_t gid = (uint32_t)__shfl((int)r.gid, (int)(pr >> 16), 64);
+                unsigned long long todo = __ballot(valid && cend - pos > 1u);
+                while (todo) {   // wave-uniform: one tile with several lanes per turn
+                    const int first = __builtin_ctzll(todo);
+                    const uint32_t tstar = (uint32_t)__builtin_amdgcn_readlane((int)t, first);
+                    const bool in = valid && t == tstar;
+                    const unsigned long long grp = __ballot(in);
+                    if (in) pos = cend - (uint32_t)__popcll(grp) + (uint32_t)__popcll(grp & lt);
+                    todo &= ~grp;
+                }
+                if (valid && pos < cap) sorted_gid[pos] = gid;
             }
+            }
+            BP(3)
+        } else {
+            __builtin_amdgcn_wave_barrier();
+            s_rec[lane] = r;
+            __builtin_amdgcn_wave_barrier();
+            bin_batch_by_instance(r, s_rec, s_cur, bw, lane, sorted_gid, cap);
+            BP(4)
         }
-        if (!listed) bin_batch_by_instance(r, s_rec, s_cur, bw, lane, sorted_gid, cap);
     }
+#ifdef BIN_PROF
+    {
+        const int wid = blockIdx.y * gridDim.x + blockIdx.x;
+        if (lane == 0 && wid < 4096) {
+            for (int k = 0; k < 5; ++k) g_binprof[wid * 8 + k] = (unsigned long long)acc_[k];
+            g_binprof[wid * 8 + 5] = (unsigned long long)(tp_ - t00_);
+            g_binprof[wid * 8 + 6] = (unsigned long long)t00_;
+            g_binprof[wid * 8 + 7] = (unsigned long long)tp_;
+        }
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -1673,7 +1787,7 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
     // depth-ordered binning unless the tile grid does not fit the LDS cursors (or MGR_BINNING=sorted asks for the per-tile sorts)
     const char* binning_env = getenv("MGR_BINNING");   // read per call: tests flip it between two forwards
     const bool ordered_env = !(binning_env && strcmp(binning_env, "sorted") == 0);
-    const bool ordered = ordered_env && lds_hist && (size_t)T * 4 + 64 * sizeof(BinRec) <= 150 * 1024;
+    const bool ordered = ordered_env && lds_hist && T <= 65535 && (size_t)T * 4 + BIN_PAIR_CAP * 4 + 64 * sizeof(BinRec) <= 150 * 1024;
     if (N > 0 && ordered) {
         const int nblk = (N + MGR_BIN_BLOCK - 1) / MGR_BIN_BLOCK;
         const float* depth = (const float*)(ws + L.depth);
@@ -1686,6 +1800,7 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
         unsigned long long* db_keys = (unsigned long long*)(ws + L.db_keys);
         uint32_t* db_order = (uint32_t*)(ws + L.db_order);
         uint32_t* bin_mat = (uint32_t*)(ws + L.bin_mat);
+        uint4* db_rec = (uint4*)(ws + L.db_rec);
         ushort4* db_bbox = (ushort4*)(ws + L.db_bbox);
         const dim3 grid_n((N + 1024 * DB_PER - 1) / (1024 * DB_PER), V), grid_b(nblk, V);
         const int chunks = (N + DB_CHUNK - 1) / DB_CHUNK;
@@ -1700,20 +1815,20 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
         MGR_LAUNCH_CHECK("k_dbin_sort", stream, debug);
         const bool big_possible = T > BIN_SMALL_TILES;   // a box of more than BIN_SMALL_TILES tiles can only exist then
         { MGR_PROF("k_bin_count", stream);
-          hipLaunchKernelGGL((k_bin_count<true>), grid_b, dim3(MGR_BIN_BLOCK), (size_t)BIN_SMALL_TILES * 4, stream, N, T, nblk, (const uint32_t*)db_nvis,
-                             (const ushort4*)db_bbox, (const uint32_t*)db_order, rect, alive, bin_mat);
+          hipLaunchKernelGGL((k_bin_count<true>), grid_b, dim3(BCNT_THREADS), (size_t)BIN_SMALL_TILES * 4, stream, N, T, nblk, (const uint32_t*)db_nvis,
+                             (const ushort4*)db_bbox, (const uint32_t*)db_order, rect, alive, db_rec, bin_mat);
           if (big_possible)
-              hipLaunchKernelGGL((k_bin_count<false>), grid_b, dim3(MGR_BIN_BLOCK), (size_t)T * 4, stream, N, T, nblk, (const uint32_t*)db_nvis,
-                                 (const ushort4*)db_bbox, (const uint32_t*)db_order, rect, alive, bin_mat); }
-        { MGR_PROF("k_bin_scan", stream); hipLaunchKernelGGL(k_bin_scan, dim3((T + 255) / 256, V), dim3(256), 0, stream, gx, T, nblk, (const uint32_t*)db_nvis,
+              hipLaunchKernelGGL((k_bin_count<false>), grid_b, dim3(BCNT_THREADS), (size_t)T * 4, stream, N, T, nblk, (const uint32_t*)db_nvis,
+                                 (const ushort4*)db_bbox, (const uint32_t*)db_order, rect, alive, db_rec, bin_mat); }
+        { MGR_PROF("k_bin_scan", stream); hipLaunchKernelGGL(k_bin_scan, dim3((T + BSCAN_COLS - 1) / BSCAN_COLS, V), dim3(BSCAN_COLS * BSCAN_SEGS), 0, stream, gx, T, nblk, (const uint32_t*)db_nvis,
                            (const ushort4*)db_bbox, (const uint32_t*)tile_start, bin_mat); }
         { MGR_PROF("k_bin_scatter", stream);
           hipLaunchKernelGGL((k_bin_scatter<true>), grid_b, dim3(64), (size_t)BIN_SMALL_TILES * 12 + BIN_PAIR_CAP * 4 + rec_bytes, stream, N, T, nblk,
-                             (const uint32_t*)db_nvis, (const ushort4*)db_bbox, (const uint32_t*)db_order, rect, alive, (const uint32_t*)bin_mat,
+                             (const uint32_t*)db_nvis, (const ushort4*)db_bbox, (const uint32_t*)db_order, (const uint4*)db_rec, (const uint32_t*)bin_mat,
                              (uint32_t*)(ws + L.sorted_gid), (uint32_t)cap);
           if (big_possible)
-              hipLaunchKernelGGL((k_bin_scatter<false>), grid_b, dim3(64), (size_t)T * 4 + rec_bytes, stream, N, T, nblk,
-                                 (const uint32_t*)db_nvis, (const ushort4*)db_bbox, (const uint32_t*)db_order, rect, alive, (const uint32_t*)bin_mat,
+              hipLaunchKernelGGL((k_bin_scatter<false>), grid_b, dim3(64), (size_t)T * 4 + BIN_PAIR_CAP * 4 + rec_bytes, stream, N, T, nblk,
+                                 (const uint32_t*)db_nvis, (const ushort4*)db_bbox, (const uint32_t*)db_order, (const uint4*)db_rec, (const uint32_t*)bin_mat,
                                  (uint32_t*)(ws + L.sorted_gid), (uint32_t)cap); }
         MGR_LAUNCH_CHECK("k_bin_scatter", stream, debug);
     } else if (N > 0) {
@@ -1784,6 +1899,12 @@ extern "C" int mgr_views_forward(int V, int N, int B, int n_articulated, int sh_
                                radii, workspace, workspace_bytes, cap, debug, stream_);
 }
 
+#ifdef BIN_PROF
+extern "C" int mgr_binprof(unsigned long long* out) {
+    MGR_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_binprof), 8 * 8 * 4096));
+    return 0;
+}
+#endif
 extern "C" int mgr_raster_layout(int V, int N, int W, int H, int64_t cap, size_t* out, int n_out) {
     const MgrLayout L = mgr_layout(V, N, W, H, cap);
     const size_t v[] = {L.header, L.grec, L.depth, L.rect, L.alive, L.pair_off, L.tile_count, L.tile_start,

@@ -399,9 +399,11 @@ def test_randomised_sizes_against_oracle(seed):
         assert max_rel_err(h["means2D"][0], ob["means2D"]) < 1e-4
 
 
-@pytest.mark.parametrize("kind,n,views,size", [("hand", 300000, 3, (1920, 1080)), ("object", 60000, 2, (1000, 700)),
-                                               ("hand", 5000, 2, (96, 64))])
-def test_ordered_binning_equals_sorted_route(kind, n, views, size, monkeypatch):
+@pytest.mark.parametrize("kind,n,views,size,sigma", [("hand", 300000, 3, (1920, 1080), None), ("object", 60000, 2, (1000, 700), None),
+                                                     ("hand", 5000, 2, (96, 64), None),
+                                                     # rectangles of more than 16 and more than 64 tiles, boxes of more than 2048 tiles
+                                                     ("object", 3000, 2, (1000, 900), (5e-3, 6e-2))])
+def test_ordered_binning_equals_sorted_route(kind, n, views, size, sigma, monkeypatch):
     """The depth-ordered binning (instances sorted once, pairs generated in order) and the per-tile sorts must produce
     the same tile lists entry for entry -- the (depth, index) keys are unique, so there is exactly one correct order --
     and therefore bit-identical images."""
@@ -409,8 +411,10 @@ def test_ordered_binning_equals_sorted_route(kind, n, views, size, monkeypatch):
     from manus_amd.engine import HipViewCompute
     from manus_amd.synthetic import camera_table, make_scene
     W, H = size
-    sc = make_scene(n_gaussians=n, kind=kind, seed=5, n_cameras=views, width=W, height=H, device=DEV,
-                    **({} if W > 1000 else dict(grid_res=24, cam_radius=0.5)))
+    kw = {} if W > 1000 else dict(grid_res=24, cam_radius=0.5)
+    if sigma is not None:
+        kw["sigma_range"] = sigma
+    sc = make_scene(n_gaussians=n, kind=kind, seed=5, n_cameras=views, width=W, height=H, device=DEV, **kw)
     ct = camera_table(sc["cameras"], DEV)
     hc = HipViewCompute(sc, torch.zeros((views, 3, H, W), device=DEV), ct, loss="l1")
     rz.set_sync_policy(True)
@@ -428,6 +432,12 @@ def test_ordered_binning_equals_sorted_route(kind, n, views, size, monkeypatch):
         assert 0 < total <= ws.cap
         gid = ws.buf[L["sorted_gid"]: L["sorted_gid"] + 4 * total].view(torch.int32).clone()
         got[route] = (img, ts, gid)
+        if sigma is not None and route == "ordered":      # the scene does exercise the general routes
+            rect = ws.buf[L["rect"]: L["rect"] + 8 * views * n].view(torch.int16).view(-1, 4).int()
+            tiles = (rect[:, 2] - rect[:, 0]) * (rect[:, 3] - rect[:, 1])
+            assert int((tiles > 64).sum()) > 50 and int(((tiles > 16) & (tiles <= 64)).sum()) > 50
+            bb = ws.buf[L["db_bbox"]: L["db_bbox"] + 8 * views].view(torch.int16).view(-1, 4).int()
+            assert int((bb[:, 2] * bb[:, 3]).max()) > 2048
     assert torch.equal(got["sorted"][1], got["ordered"][1])
     neq = (got["sorted"][2] != got["ordered"][2]).nonzero()
     assert neq.numel() == 0, (int(neq.numel()), neq[:5].flatten().tolist())
