@@ -100,7 +100,9 @@ struct MgrLayout {
 // Depth-ordered binning (raster_fwd.hip, "ordered" route): the instances of a view are sorted by depth once, then
 // scattered to the tile lists in that order, instead of sorting every tile list.
 #define MGR_DB_BUCKETS 8192   // depth buckets per view of the instance sort (1024 per octave of z above the 0.2 cull plane)
-#define MGR_BIN_BLOCK 1024    // depth-consecutive instances per row of the (block, tile) count matrix
+#define MGR_BIN_BLOCK 1024    // depth-consecutive instances per row of the (block, tile) count matrix (at most)
+// rows of 256 instances when there are few instances in all (one or two views per rank): k_bin_scatter runs one wave per row
+static inline int mgr_bin_block(int V, int N) { return (long long)V * (long long)N >= 500000ll ? MGR_BIN_BLOCK : 256; }
 
 static inline size_t mgr_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -137,7 +139,7 @@ static inline MgrLayout mgr_layout(int V, int N, int W, int H, int64_t cap) {
     L.inst_tag = o;    o += mgr_align(VN * 4);      // epoch of the last backward that wrote a record for (view, Gaussian)
     L.inst_grad = o;   o += mgr_align(VN * 128);    // fused backward: 12 floats per (Gaussian, view) + active list
     {
-        const size_t VB = (size_t)V * MGR_DB_BUCKETS, nblk = ((size_t)(N > 0 ? N : 1) + MGR_BIN_BLOCK - 1) / MGR_BIN_BLOCK;
+        const size_t VB = (size_t)V * MGR_DB_BUCKETS, bb = (size_t)mgr_bin_block(V, N), nblk = ((size_t)(N > 0 ? N : 1) + bb - 1) / bb;
         L.db_count = o;  o += mgr_align(VB * 4);
         L.db_cursor = o; o += mgr_align(VB * 4);
         L.db_start = o;  o += mgr_align((VB + 1) * 4);

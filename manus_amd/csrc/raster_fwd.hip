@@ -1025,7 +1025,7 @@ __global__ __launch_bounds__(1024) void k_dbin_scatter(int N, const int32_t* __r
 // segment: whole buckets, about DB_CHUNK keys, every bucket in exactly one item.  One LDS sort when that is at most
 // SORT_LDS_KEYS keys; bucket by bucket otherwise; a single bucket beyond SORT_LDS_KEYS (all Gaussians in one depth
 // plane) falls back to the in-place bitonic network in global memory.
-#define DB_CHUNK 2048
+#define DB_CHUNK 2048        // (512 when there are few instances in all: more, shorter items)
 __device__ __forceinline__ uint32_t db_lower_bound(const uint32_t* __restrict__ st, uint32_t key) {
     uint32_t lo = 0, hi = MGR_DB_BUCKETS;   // first bucket b in [0, MGR_DB_BUCKETS] with st[b] >= key (st is non-decreasing)
     while (lo < hi) {
@@ -1035,7 +1035,7 @@ __device__ __forceinline__ uint32_t db_lower_bound(const uint32_t* __restrict__ 
     return lo;
 }
 __global__ __launch_bounds__(RS_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_dbin_sort(
-    int N, int chunks_per_view, int n_items, const uint32_t* __restrict__ db_start, const uint32_t* __restrict__ db_nvis,
+    int N, int chunk, int chunks_per_view, int n_items, const uint32_t* __restrict__ db_start, const uint32_t* __restrict__ db_nvis,
     unsigned long long* __restrict__ db_keys, uint32_t* __restrict__ db_order) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     unsigned long long* s_keys = (unsigned long long*)s_raw;
@@ -1045,10 +1045,10 @@ __global__ __launch_bounds__(RS_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
         const int v = item % (n_items / chunks_per_view), ch = item / (n_items / chunks_per_view);   // view-minor: neighbours differ in view
         const uint32_t nvis = db_nvis[v];
-        if ((uint32_t)ch * DB_CHUNK >= nvis) continue;
+        if ((uint32_t)ch * (uint32_t)chunk >= nvis) continue;
         const uint32_t* st = db_start + (size_t)v * (MGR_DB_BUCKETS + 1);
-        const uint32_t b0 = ch == 0 ? 0u : db_lower_bound(st, (uint32_t)ch * DB_CHUNK);
-        const uint32_t b1 = db_lower_bound(st, (uint32_t)(ch + 1) * DB_CHUNK);
+        const uint32_t b0 = ch == 0 ? 0u : db_lower_bound(st, (uint32_t)ch * (uint32_t)chunk);
+        const uint32_t b1 = db_lower_bound(st, (uint32_t)(ch + 1) * (uint32_t)chunk);
         if (b1 <= b0) continue;
         const uint32_t lo = st[b0], hi = st[b1];
         if (hi == lo) continue;
@@ -1085,7 +1085,7 @@ __device__ __forceinline__ bool bin_mine(ushort4 box, bool small_variant) {
 #define BCNT_THREADS 256
 #define BCNT_PER (MGR_BIN_BLOCK / BCNT_THREADS)
 template <bool SMALL>
-__global__ __launch_bounds__(BCNT_THREADS) void k_bin_count(int N, int T, int nblk,
+__global__ __launch_bounds__(BCNT_THREADS) void k_bin_count(int N, int T, int nblk, int bb,
                                                             const uint32_t* __restrict__ db_nvis,
                                                             const ushort4* __restrict__ db_bbox,
                                                             const uint32_t* __restrict__ db_order,
@@ -1098,13 +1098,13 @@ __global__ __launch_bounds__(BCNT_THREADS) void k_bin_count(int N, int T, int nb
     const ushort4 box = db_bbox[v];
     if (!bin_mine(box, SMALL)) return;
     const uint32_t nvis = db_nvis[v];
-    if ((uint32_t)b * MGR_BIN_BLOCK >= nvis) return;
+    if ((uint32_t)b * (uint32_t)bb >= nvis) return;
     const int TB = (int)box.z * (int)box.w, bw = box.z;
     uint32_t gid[BCNT_PER];
 #pragma unroll
     for (int r = 0; r < BCNT_PER; ++r) {
-        const uint32_t p = (uint32_t)b * MGR_BIN_BLOCK + r * BCNT_THREADS + tid;
-        gid[r] = p < nvis ? db_order[(size_t)v * N + p] : 0u;
+        const uint32_t p = (uint32_t)b * (uint32_t)bb + r * BCNT_THREADS + tid;
+        gid[r] = (r * BCNT_THREADS < bb && p < nvis) ? db_order[(size_t)v * N + p] : 0u;
     }
     ushort4 rc[BCNT_PER];
     unsigned long long am[BCNT_PER];
@@ -1117,8 +1117,8 @@ __global__ __launch_bounds__(BCNT_THREADS) void k_bin_count(int N, int T, int nb
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < BCNT_PER; ++r) {
-        const uint32_t p = (uint32_t)b * MGR_BIN_BLOCK + r * BCNT_THREADS + tid;
-        if (p < nvis) {
+        const uint32_t p = (uint32_t)b * (uint32_t)bb + r * BCNT_THREADS + tid;
+        if (r * BCNT_THREADS < bb && p < nvis) {
             // the gathered rectangle and mask, in depth order, for k_bin_scatter (which then reads them coalesced)
             const uint32_t w = rc[r].z - rc[r].x, h = rc[r].w - rc[r].y;
             db_rec[(size_t)v * N + p] = make_uint4((uint32_t)rc[r].x | ((uint32_t)rc[r].y << 16), w | (h << 16), (uint32_t)am[r],
@@ -1149,7 +1149,7 @@ __global__ __launch_bounds__(BCNT_THREADS) void k_bin_count(int N, int T, int nb
 // LDS, and every wave then rewrites its rows as running offsets.
 #define BSCAN_COLS 32
 #define BSCAN_SEGS 16
-__global__ __launch_bounds__(BSCAN_COLS * BSCAN_SEGS) void k_bin_scan(int gx, int T, int nblk, const uint32_t* __restrict__ db_nvis,
+__global__ __launch_bounds__(BSCAN_COLS * BSCAN_SEGS) void k_bin_scan(int gx, int T, int nblk, int bb, const uint32_t* __restrict__ db_nvis,
                                                                       const ushort4* __restrict__ db_bbox,
                                                                       const uint32_t* __restrict__ tile_start,
                                                                       uint32_t* __restrict__ bin_mat) {
@@ -1160,7 +1160,7 @@ __global__ __launch_bounds__(BSCAN_COLS * BSCAN_SEGS) void k_bin_scan(int gx, in
     const int TB = (int)box.z * (int)box.w;
     if (blockIdx.x * BSCAN_COLS >= TB) return;
     const bool on = k < TB;
-    const int nb = (int)((db_nvis[v] + MGR_BIN_BLOCK - 1) / MGR_BIN_BLOCK);
+    const int nb = (int)((db_nvis[v] + (uint32_t)bb - 1u) / (uint32_t)bb);
     const int per = (nb + BSCAN_SEGS - 1) / BSCAN_SEGS, b0 = min(seg * per, nb), b1 = min(b0 + per, nb);
     uint32_t* colp = bin_mat + (size_t)v * nblk * T + (on ? k : 0);
     uint32_t sum = 0;
@@ -1278,7 +1278,7 @@ __device__ unsigned long long g_binprof[8 * 4096];
 #define BP(k)
 #endif
 template <bool SMALL>
-__global__ __launch_bounds__(64) void k_bin_scatter(int N, int T, int nblk, const uint32_t* __restrict__ db_nvis,
+__global__ __launch_bounds__(64) void k_bin_scatter(int N, int T, int nblk, int bb, const uint32_t* __restrict__ db_nvis,
                                                     const ushort4* __restrict__ db_bbox,
                                                     const uint32_t* __restrict__ db_order,
                                                     const uint4* __restrict__ db_rec,
@@ -1292,9 +1292,9 @@ __global__ __launch_bounds__(64) void k_bin_scatter(int N, int T, int nblk, cons
     const int v = blockIdx.y, b = blockIdx.x, lane = threadIdx.x;
     const ushort4 box = db_bbox[v];
     if (!bin_mine(box, SMALL)) return;
-    const uint32_t nvis = db_nvis[v], p0 = (uint32_t)b * MGR_BIN_BLOCK;
+    const uint32_t nvis = db_nvis[v], p0 = (uint32_t)b * (uint32_t)bb;
     if (p0 >= nvis) return;
-    const uint32_t p1 = min(p0 + (uint32_t)MGR_BIN_BLOCK, nvis);
+    const uint32_t p1 = min(p0 + (uint32_t)bb, nvis);
     const int bw = box.z;
     BinRec nxt = bin_load(N, v, p0 + lane, nvis, box, db_order, db_rec);
     {
@@ -1789,7 +1789,7 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
     const bool ordered_env = !(binning_env && strcmp(binning_env, "sorted") == 0);
     const bool ordered = ordered_env && lds_hist && T <= 65535 && (size_t)T * 4 + BIN_PAIR_CAP * 4 + 64 * sizeof(BinRec) <= 150 * 1024;
     if (N > 0 && ordered) {
-        const int nblk = (N + MGR_BIN_BLOCK - 1) / MGR_BIN_BLOCK;
+        const int bb = mgr_bin_block(V, N), nblk = (N + bb - 1) / bb;
         const float* depth = (const float*)(ws + L.depth);
         const ushort4* rect = (const ushort4*)(ws + L.rect);
         const unsigned long long* alive = (const unsigned long long*)(ws + L.alive);
@@ -1803,7 +1803,7 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
         uint4* db_rec = (uint4*)(ws + L.db_rec);
         ushort4* db_bbox = (ushort4*)(ws + L.db_bbox);
         const dim3 grid_n((N + 1024 * DB_PER - 1) / (1024 * DB_PER), V), grid_b(nblk, V);
-        const int chunks = (N + DB_CHUNK - 1) / DB_CHUNK;
+        const int chunk = bb == MGR_BIN_BLOCK ? DB_CHUNK : 512, chunks = (N + chunk - 1) / chunk;
         const size_t rec_bytes = 64 * sizeof(BinRec);
         { MGR_PROF("k_dbin_count", stream); hipLaunchKernelGGL(k_dbin_count, grid_n, dim3(1024), 0, stream, N, (const int32_t*)radii, depth, rect, alive, db_count); }
         { MGR_PROF("k_dbin_scan", stream); hipLaunchKernelGGL(k_dbin_scan, dim3(V), dim3(1024), 0, stream, gx, T, (const uint32_t*)tile_start, db_count, db_cursor,
@@ -1811,23 +1811,23 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
         { MGR_PROF("k_dbin_scatter", stream); hipLaunchKernelGGL(k_dbin_scatter, grid_n, dim3(1024), 0, stream, N, (const int32_t*)radii, depth, rect, alive,
                            (const uint32_t*)db_start, db_cursor, db_keys); }
         { MGR_PROF("k_dbin_sort", stream); hipLaunchKernelGGL(k_dbin_sort, dim3(1024), dim3(RS_THREADS), SORT_LDS_KEYS * 8 + RS_WAVES * 256 * 4 + 256, stream,
-                           N, chunks, V * chunks, (const uint32_t*)db_start, (const uint32_t*)db_nvis, db_keys, db_order); }
+                           N, chunk, chunks, V * chunks, (const uint32_t*)db_start, (const uint32_t*)db_nvis, db_keys, db_order); }
         MGR_LAUNCH_CHECK("k_dbin_sort", stream, debug);
         const bool big_possible = T > BIN_SMALL_TILES;   // a box of more than BIN_SMALL_TILES tiles can only exist then
         { MGR_PROF("k_bin_count", stream);
-          hipLaunchKernelGGL((k_bin_count<true>), grid_b, dim3(BCNT_THREADS), (size_t)BIN_SMALL_TILES * 4, stream, N, T, nblk, (const uint32_t*)db_nvis,
+          hipLaunchKernelGGL((k_bin_count<true>), grid_b, dim3(BCNT_THREADS), (size_t)BIN_SMALL_TILES * 4, stream, N, T, nblk, bb, (const uint32_t*)db_nvis,
                              (const ushort4*)db_bbox, (const uint32_t*)db_order, rect, alive, db_rec, bin_mat);
           if (big_possible)
-              hipLaunchKernelGGL((k_bin_count<false>), grid_b, dim3(BCNT_THREADS), (size_t)T * 4, stream, N, T, nblk, (const uint32_t*)db_nvis,
+              hipLaunchKernelGGL((k_bin_count<false>), grid_b, dim3(BCNT_THREADS), (size_t)T * 4, stream, N, T, nblk, bb, (const uint32_t*)db_nvis,
                                  (const ushort4*)db_bbox, (const uint32_t*)db_order, rect, alive, db_rec, bin_mat); }
-        { MGR_PROF("k_bin_scan", stream); hipLaunchKernelGGL(k_bin_scan, dim3((T + BSCAN_COLS - 1) / BSCAN_COLS, V), dim3(BSCAN_COLS * BSCAN_SEGS), 0, stream, gx, T, nblk, (const uint32_t*)db_nvis,
+        { MGR_PROF("k_bin_scan", stream); hipLaunchKernelGGL(k_bin_scan, dim3((T + BSCAN_COLS - 1) / BSCAN_COLS, V), dim3(BSCAN_COLS * BSCAN_SEGS), 0, stream, gx, T, nblk, bb, (const uint32_t*)db_nvis,
                            (const ushort4*)db_bbox, (const uint32_t*)tile_start, bin_mat); }
         { MGR_PROF("k_bin_scatter", stream);
-          hipLaunchKernelGGL((k_bin_scatter<true>), grid_b, dim3(64), (size_t)BIN_SMALL_TILES * 12 + BIN_PAIR_CAP * 4 + rec_bytes, stream, N, T, nblk,
+          hipLaunchKernelGGL((k_bin_scatter<true>), grid_b, dim3(64), (size_t)BIN_SMALL_TILES * 12 + BIN_PAIR_CAP * 4 + rec_bytes, stream, N, T, nblk, bb,
                              (const uint32_t*)db_nvis, (const ushort4*)db_bbox, (const uint32_t*)db_order, (const uint4*)db_rec, (const uint32_t*)bin_mat,
                              (uint32_t*)(ws + L.sorted_gid), (uint32_t)cap);
           if (big_possible)
-              hipLaunchKernelGGL((k_bin_scatter<false>), grid_b, dim3(64), (size_t)T * 4 + BIN_PAIR_CAP * 4 + rec_bytes, stream, N, T, nblk,
+              hipLaunchKernelGGL((k_bin_scatter<false>), grid_b, dim3(64), (size_t)T * 4 + BIN_PAIR_CAP * 4 + rec_bytes, stream, N, T, nblk, bb,
                                  (const uint32_t*)db_nvis, (const ushort4*)db_bbox, (const uint32_t*)db_order, (const uint4*)db_rec, (const uint32_t*)bin_mat,
                                  (uint32_t*)(ws + L.sorted_gid), (uint32_t)cap); }
         MGR_LAUNCH_CHECK("k_bin_scatter", stream, debug);
