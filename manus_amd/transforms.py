@@ -4,37 +4,37 @@ tensors; the reference also runs these on the host/offline)."""
 import torch
 
 
+_AXIS_ROWS = {   # rotation about one axis as (row, col) -> +cos / -sin / +sin / 1 / 0
+    "X": ("1", "0", "0", "0", "c", "-s", "0", "s", "c"),
+    "Y": ("c", "0", "s", "0", "1", "0", "-s", "0", "c"),
+    "Z": ("c", "-s", "0", "s", "c", "0", "0", "0", "1"),
+}
+
+
 def _axis_angle_rotation(axis, angle):
-    """transforms.py:533-558."""
+    """Rotation matrices (..., 3, 3) about one coordinate axis (transforms.py:533-558)."""
+    if axis not in _AXIS_ROWS:
+        raise ValueError("axis must be X, Y or Z, got %r" % (axis,))
     c, s = torch.cos(angle), torch.sin(angle)
-    o, z = torch.ones_like(angle), torch.zeros_like(angle)
-    if axis == "X":
-        flat = (o, z, z, z, c, -s, z, s, c)
-    elif axis == "Y":
-        flat = (c, z, s, z, o, z, -s, z, c)
-    elif axis == "Z":
-        flat = (c, -s, z, s, c, z, z, z, o)
-    else:
-        raise ValueError("letter must be either X, Y or Z.")
-    return torch.stack(flat, -1).reshape(angle.shape + (3, 3))
+    entry = {"c": c, "s": s, "-s": -s, "1": torch.ones_like(angle), "0": torch.zeros_like(angle)}
+    return torch.stack([entry[e] for e in _AXIS_ROWS[axis]], -1).reshape(angle.shape + (3, 3))
 
 
 def euler_angles_to_matrix(euler_angles, convention, intrinsic=False):
-    """transforms.py:489-530 (intrinsic = reversed convention on flipped angles)."""
-    if intrinsic:
-        convention = convention[::-1]
-        euler_angles = euler_angles.flip(-1)
+    """Euler angles (..., 3) in radians -> rotation matrices (..., 3, 3), one axis letter per angle
+    (transforms.py:489-530).  intrinsic=True: the same rotation read as intrinsic, i.e. the reversed axis order applied
+    to the reversed angles."""
     if euler_angles.dim() == 0 or euler_angles.shape[-1] != 3:
-        raise ValueError("Invalid input euler angles.")
-    if len(convention) != 3:
-        raise ValueError("Convention must have 3 letters.")
-    if convention[1] in (convention[0], convention[2]):
-        raise ValueError(f"Invalid convention {convention}.")
-    for letter in convention:
-        if letter not in ("X", "Y", "Z"):
-            raise ValueError(f"Invalid letter {letter} in convention string.")
-    m = [_axis_angle_rotation(c, e) for c, e in zip(convention, torch.unbind(euler_angles, -1))]
-    return torch.matmul(torch.matmul(m[0], m[1]), m[2])
+        raise ValueError("euler_angles must have a last dimension of 3, got shape %s" % (tuple(euler_angles.shape),))
+    axes = str(convention)
+    if len(axes) != 3 or any(a not in _AXIS_ROWS for a in axes):
+        raise ValueError("convention must be three letters out of X, Y, Z, got %r" % (convention,))
+    if axes[1] == axes[0] or axes[1] == axes[2]:
+        raise ValueError("convention %r repeats an axis in neighbouring positions" % (convention,))
+    if intrinsic:
+        axes, euler_angles = axes[::-1], euler_angles.flip(-1)
+    r0, r1, r2 = (_axis_angle_rotation(a, e) for a, e in zip(axes, euler_angles.unbind(-1)))
+    return r0 @ r1 @ r2
 
 
 def build_kintree(bnames, bnames_parent):

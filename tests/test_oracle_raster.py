@@ -283,3 +283,58 @@ def test_blend_oracle_and_torch_projection_close_the_chain():
         assert max_rel_err(tm.grad.numpy(), rb["means3D"]) < tol * 5, dt
         # (the published backward uses 1 / (det^2 + 1e-7): a 1e-9-level departure from the exact derivative in fp64)
         assert max_rel_err(tc.grad.numpy(), rb["cov3D"]) < max(tol * 5, 1e-8), dt
+
+
+def test_fp64_finite_differences_beyond_the_tanfov_clamp():
+    """The 1.3 * tanfov clamp in isolation: Gaussians whose view-space x/z or y/z lies outside the clamp are projected
+    with the clamped ratio in the EWA Jacobian.  Their projected means are off screen; only their (large) footprints
+    reach it, so every gradient flows through the covariance path that contains the clamp.  fp64 oracle vs central
+    differences: the in-plane components and the covariance gradient are exact derivatives.  The depth component is
+    NOT, by the operator's definition (Appendix A): the forward uses t.x = clamp(t.x / t.z) * t.z, which moves with t.z,
+    while the backward treats the clamped coordinate as a constant (its gradient multiplier is 0).  The test pins that
+    behaviour: a 'corrected' backward would differ from the reference operator."""
+    W, H = 64, 48
+    cam = make_camera(W, H, pos=(0, 0, -2.0), target=(0, 0, 0), focal=60.0)
+    a = cam_args(cam)
+    z = 2.0
+    limx, limy = 1.3 * a["tanfovx"], 1.3 * a["tanfovy"]
+    # two beyond the x clamp (either side), one beyond the y clamp, one inside for reference (distinct depths)
+    m = np.array([[1.45 * a["tanfovx"] * z, 0.05, 0.0], [-1.6 * a["tanfovx"] * z * 1.05, -0.1, 0.1],
+                  [0.1, 1.5 * a["tanfovy"] * z * 0.975, -0.05], [0.2, 0.1, 0.3]], np.float64)
+    view = np.asarray(a["view"], np.float64).reshape(4, 4).T        # column-major float[16]
+    tv = (view @ np.c_[m, np.ones(4)].T).T
+    assert abs(tv[0, 0] / tv[0, 2]) > limx and abs(tv[1, 0] / tv[1, 2]) > limx and abs(tv[2, 1] / tv[2, 2]) > limy
+    assert abs(tv[3, 0] / tv[3, 2]) < limx and abs(tv[3, 1] / tv[3, 2]) < limy
+    c = np.concatenate([_iso(0.45), _iso(0.5), _iso(0.4), _iso(0.15)]).astype(np.float64)
+    c[:, 1] = [0.02, -0.03, 0.01, 0.0]                            # a little anisotropy
+    col = np.array([[0.9, 0.2, 0.1], [0.1, 0.8, 0.3], [0.2, 0.3, 0.9], [0.5, 0.5, 0.5]])
+    op = np.array([0.6, 0.5, 0.7, 0.4])
+    gimg = np.random.default_rng(3).normal(size=(3, H, W))
+    o = _render(cam, m, c, col, op, dtype=np.float64)
+    assert (o.radii > 0).all()
+    b = o.backward(gimg)
+
+    def L(mm, cc):
+        return float((_render(cam, mm, cc, col, op, dtype=np.float64).color * gimg).sum())
+
+    def fd(which, idx):
+        out = []
+        for eps in (1e-6, 3e-7, 4e-6):
+            p, q = [m.copy(), c.copy()], [m.copy(), c.copy()]
+            p[which][idx] += eps
+            q[which][idx] -= eps
+            out.append((L(*p) - L(*q)) / (2 * eps))
+        return out
+
+    def close(refs, val, tol=2e-4):
+        return any(abs(r - val) < tol * max(1.0, abs(r)) for r in refs)
+
+    for k in range(4):
+        for j in range(2):      # view x, y (the camera looks down +z: world axes = view axes here)
+            assert close(fd(0, (k, j)), b["means3D"][k, j]), ("means3D", k, j)
+        for j in range(6):
+            assert close(fd(1, (k, j)), b["cov3D"][k, j]), ("cov3D", k, j)
+    assert close(fd(0, (3, 2)), b["means3D"][3, 2])                 # inside the clamp: the depth component is exact too
+    off = [k for k in range(3) if not close(fd(0, (k, 2)), b["means3D"][k, 2], 1e-3)]
+    assert len(off) >= 2, off                                       # beyond it: the operator's own (inexact) definition
+    assert np.abs(b["means3D"][:3]).max() > 1e-3                    # the clamped ones do receive gradients
