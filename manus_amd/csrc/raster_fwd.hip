@@ -1025,7 +1025,7 @@ __global__ __launch_bounds__(1024) void k_dbin_scatter(int N, const int32_t* __r
 // segment: whole buckets, about DB_CHUNK keys, every bucket in exactly one item.  One LDS sort when that is at most
 // SORT_LDS_KEYS keys; bucket by bucket otherwise; a single bucket beyond SORT_LDS_KEYS (all Gaussians in one depth
 // plane) falls back to the in-place bitonic network in global memory.
-#define DB_CHUNK 2048        // (512 when there are few instances in all: more, shorter items)
+#define DB_CHUNK 2048        // (1024 when there are few instances in all: more, shorter items)
 __device__ __forceinline__ uint32_t db_lower_bound(const uint32_t* __restrict__ st, uint32_t key) {
     uint32_t lo = 0, hi = MGR_DB_BUCKETS;   // first bucket b in [0, MGR_DB_BUCKETS] with st[b] >= key (st is non-decreasing)
     while (lo < hi) {
@@ -1803,7 +1803,7 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
         uint4* db_rec = (uint4*)(ws + L.db_rec);
         ushort4* db_bbox = (ushort4*)(ws + L.db_bbox);
         const dim3 grid_n((N + 1024 * DB_PER - 1) / (1024 * DB_PER), V), grid_b(nblk, V);
-        const int chunk = bb == MGR_BIN_BLOCK ? DB_CHUNK : 512, chunks = (N + chunk - 1) / chunk;
+        const int chunk = bb == MGR_BIN_BLOCK ? DB_CHUNK : 1024, chunks = (N + chunk - 1) / chunk;
         const size_t rec_bytes = 64 * sizeof(BinRec);
         { MGR_PROF("k_dbin_count", stream); hipLaunchKernelGGL(k_dbin_count, grid_n, dim3(1024), 0, stream, N, (const int32_t*)radii, depth, rect, alive, db_count); }
         { MGR_PROF("k_dbin_scan", stream); hipLaunchKernelGGL(k_dbin_scan, dim3(V), dim3(1024), 0, stream, gx, T, (const uint32_t*)tile_start, db_count, db_cursor,
