@@ -963,10 +963,17 @@ __global__ __launch_bounds__(1024) void k_dbin_scan(int gx, int T, const uint32_
         run += c[k];
     }
     uint32_t x0 = 0xFFFFu, y0 = 0xFFFFu, x1 = 0u, y1 = 0u;
-    for (int t = tid; t < T; t += 1024) {
-        if (tile_start[(size_t)v * T + t + 1] > tile_start[(size_t)v * T + t]) {
-            const uint32_t y = (uint32_t)t / (uint32_t)gx, x = (uint32_t)t - y * (uint32_t)gx;
-            x0 = min(x0, x); y0 = min(y0, y); x1 = max(x1, x + 1); y1 = max(y1, y + 1);
+    for (int t0 = tid * 8; t0 < T; t0 += 8192) {   // eight consecutive tiles per thread: nine loads in flight, one round trip
+        uint32_t ts[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) ts[k] = tile_start[(size_t)v * T + min(t0 + k, T)];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int t = t0 + k;
+            if (t < T && ts[k + 1] > ts[k]) {
+                const uint32_t y = (uint32_t)t / (uint32_t)gx, x = (uint32_t)t - y * (uint32_t)gx;
+                x0 = min(x0, x); y0 = min(y0, y); x1 = max(x1, x + 1); y1 = max(y1, y + 1);
+            }
         }
     }
     if (x1 > 0u) { atomicMin(&s_box[0], x0); atomicMin(&s_box[1], y0); atomicMax(&s_box[2], x1); atomicMax(&s_box[3], y1); }
