@@ -338,7 +338,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    _lib.profile_enable(True)                 # HIP events around every library kernel, on its stream
+    # HIP events on the kernel's own stream: around the dominant kernel only (the roofline's duration), around every
+    # library kernel with --profile-all (26 bracketed launches per step cost ~0.1 ms of the step)
+    _lib.profile_enable(True, only=None if args.profile_all else DOMINANT)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):

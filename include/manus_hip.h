@@ -389,6 +389,10 @@ int mgr_contact_dist(int N1, const float* pt1, int N2, const float* pt2, float* 
  * "name count total_ms\n" into buf (NUL terminated) and clears the records.
  * ------------------------------------------------------------------------ */
 int mgr_profile_enable(int on);
+/* Bracket only the kernel of this name (as it appears in the report); NULL or "" = every kernel.  Two events per
+ * bracketed launch cost a few microseconds of GPU time each: a run that is itself being timed should name the one
+ * kernel it needs. */
+int mgr_profile_filter(const char* kernel_name);
 int mgr_profile_report(char* buf_host, size_t len, void* stream);
 
 #ifdef __cplusplus

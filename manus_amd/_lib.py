@@ -74,11 +74,14 @@ SIGNATURES = {
     "mgr_contact_workspace_bytes": (c_sz, [c_int, c_int]),
     "mgr_contact_dist": (c_int, [c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "mgr_profile_enable": (c_int, [c_int]),
+    "mgr_profile_filter": (c_int, [ctypes.c_char_p]),
     "mgr_profile_report": (c_int, [ctypes.c_char_p, c_sz, c_vp]),
 }
 
 
-def profile_enable(on):
+def profile_enable(on, only=None):
+    """HIP events around the library's kernel launches; `only`: just the kernel of that name."""
+    check(lib().mgr_profile_filter(only.encode() if only else None), "mgr_profile_filter")
     check(lib().mgr_profile_enable(int(bool(on))), "mgr_profile_enable")
 
 

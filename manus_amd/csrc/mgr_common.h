@@ -43,10 +43,11 @@ static inline int mgr_fail(int code, const char* fmt, const char* a = "", const 
 void mgr_prof_begin(const char* name, hipStream_t stream);
 void mgr_prof_end(hipStream_t stream);
 extern int g_mgr_prof_on;
+bool mgr_prof_match(const char* name);   // mgr_profile_filter: only the named kernel (empty = all of them)
 struct MgrProfScope {
     hipStream_t s;
     bool on;
-    MgrProfScope(const char* name, hipStream_t stream) : s(stream), on(g_mgr_prof_on != 0) {
+    MgrProfScope(const char* name, hipStream_t stream) : s(stream), on(g_mgr_prof_on != 0 && mgr_prof_match(name)) {
         if (on) mgr_prof_begin(name, s);
     }
     ~MgrProfScope() {

@@ -48,8 +48,16 @@ void mgr_prof_end(hipStream_t stream) {
     if (!g_prof_recs.empty() && g_prof_recs.back().b) (void)hipEventRecord(g_prof_recs.back().b, stream);
 }
 
+static std::string g_prof_filter;
+bool mgr_prof_match(const char* name) { return g_prof_filter.empty() || g_prof_filter == name; }
+
 extern "C" int mgr_profile_enable(int on) {
     g_mgr_prof_on = on ? 1 : 0;
+    return MGR_OK;
+}
+
+extern "C" int mgr_profile_filter(const char* kernel_name) {
+    g_prof_filter = kernel_name ? kernel_name : "";
     return MGR_OK;
 }
 

@@ -16,7 +16,10 @@ cp gpurun_out/pmc_${TAG}.txt profiles/${RND}_${TAG}_pmc.txt
 rm -rf gpurun_out/prof_$TAG
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof_$TAG -o run -- python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $ROOT/gpurun_out/prof_$TAG.log 2>&1)
 cp $(find gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1) profiles/${RND}_${TAG}_rocprofv3_kernel_stats.csv
-python bench.py --steps 50 --warmup 5 --profile-all > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err
+# the bench line as the driver runs it (events around the dominant kernel only), then the per-kernel breakdown
+# (--profile-all: events around all ~26 launches of a step, which costs ~0.1 ms per step)
+python bench.py --steps 50 --warmup 5 > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err0
+python bench.py --steps 50 --warmup 5 --profile-all --no-cpu-baseline > gpurun_out/bench_${TAG}_all.json 2> gpurun_out/bench_$TAG.err
 cp gpurun_out/bench_$TAG.json profiles/${RND}_${TAG}_bench.json
 grep -v amdgpu.ids gpurun_out/bench_$TAG.err > profiles/${RND}_${TAG}_bench_kernel_breakdown.txt
 tail -22 gpurun_out/bench_$TAG.err; cat gpurun_out/bench_$TAG.json; head -30 gpurun_out/pmc_${TAG}.txt
