@@ -259,6 +259,9 @@ def main():
     ap.add_argument("--sharded-adam", action="store_true",
                     help="N > 1 with --optimizer: reduce-scatter the gradients, Adam on the owned 1/N of the elements, "
                          "all-gather the parameters (instead of all-reduce + the full Adam step on every rank)")
+    ap.add_argument("--dense-loss-scan", action="store_true",
+                    help="image loss without the rasterizer's tile occupancy: compares rendered and target image everywhere "
+                         "to find the spans that need work (the default settles spans under empty tiles from the target alone)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (cpu_baseline and parity)")
     ap.add_argument("--parity-views", type=int, default=2, help="views of the step run through the CPU oracle")
     ap.add_argument("--profile-all", action="store_true", help="print a per-kernel HIP-event breakdown to stderr")
@@ -294,7 +297,7 @@ def main():
         targets = hp.forward_views_fused(list(range(V)))[0].contiguous()
         del hp
     rasterizer.context(dev).clear()
-    compute = HipViewCompute(scene, targets, ct, loss=args.loss, sh_storage=args.sh_storage)
+    compute = HipViewCompute(scene, targets, ct, loss=args.loss, sh_storage=args.sh_storage, sparse_loss=not args.dense_loss_scan)
     shapes = {k: v.shape for k, v in compute.params.items()}
     # N > 1: only the rows with a gradient on some rank travel (exact: the others are zero everywhere; 43 % of the rows
     # in this scene) -- xGMI is point-to-point, the all-reduce is the part of the step that does not shrink with N
@@ -441,6 +444,7 @@ def main():
                        "allreduce": (None if world == 1 else "reduce-scatter + sharded Adam + all-gather" if sharded else "dense 61N floats" if args.dense_allreduce else
                                      "rows with a gradient (%s of %d) x 60 floats + 2N bytes" % (step.last_rows, N)),
                        "optimizer_in_step": bool(args.optimizer), "sh_storage": args.sh_storage,
+                       "loss_span_list": "full comparison of rendered and target image" if args.dense_loss_scan else "tile occupancy of the forward + target background",
                        "nonfinite_grad_values": nonfinite},
             "roofline": roof, "cpu_baseline": cpu, "parity": parity,
         }

@@ -294,6 +294,16 @@ size_t mgr_image_loss_workspace_bytes(int V, int H, int W);
 int mgr_image_loss(int V, int H, int W, const float* pred, const float* target, float w_l1, float w_ssim,
                    float grad_scale, float loss_offset, float* dL_dpred, float* sums, void* workspace,
                    size_t workspace_bytes, void* stream);
+/* The same loss when `pred` is the image mgr_raster_forward / mgr_views_forward has just rendered with background bg3
+ * and tile_start points at that forward's tile-list offsets (workspace + mgr_raster_layout()[7]; V * T + 1 words,
+ * T = ceil(W/16) * ceil(H/16)).  Where every tile under a span of the loss holds no Gaussian the rendered pixels ARE
+ * the background colour, so the span only has to be compared with the target's background: the rendered image is not
+ * read there, and no zero gradient is written.  sums are those of mgr_image_loss.  dL_dpred is written wherever a tile
+ * holds a Gaussian (everywhere the backward pass reads it) and wherever the target differs from the background; it is
+ * left untouched under empty tiles whose target is background. */
+int mgr_image_loss_tiles(int V, int H, int W, const float* pred, const float* target, const float* bg3,
+                         const uint32_t* tile_start, float w_l1, float w_ssim, float grad_scale, float loss_offset,
+                         float* dL_dpred, float* sums, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
  * Optimizer step and densification of the Gaussian parameter model

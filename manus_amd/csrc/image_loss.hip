@@ -25,6 +25,7 @@
 // statistics 5 beyond that), only the gradient is written.  The two loss sums are written per
 // workgroup and folded by a second tiny kernel: no float atomics, the loss value is reproducible.
 #include "mgr_common.h"
+#include <cstdlib>
 
 #define IL_T 128                    // threads
 #define IL_ND (2 * IL_T)            // 256 derivative positions, two per thread
@@ -307,6 +308,92 @@ __global__ __launch_bounds__(ILS_T) void k_image_loss_scan(int H, int W, int gxb
     }
 }
 
+// Pass 1 when the rendered image comes from this library's rasterizer and its tile lists are at hand
+// (mgr_image_loss_tiles): a span is "identical" when every 16x16 tile under its +-10 px staged range is EMPTY -- the
+// rasterizer writes exactly the background colour there -- and the target equals that colour over the range.  The
+// rendered image is not read at all, the target only under empty tiles, and nothing is written for identical spans:
+// their gradient is never read either (the backward blend only visits tiles that hold Gaussians).  Spans under
+// non-empty tiles go to the work list without being looked at.
+__global__ __launch_bounds__(ILS_T) void k_image_loss_list(int H, int W, int gxb, const float* __restrict__ target,
+                                                           const float* __restrict__ bg, const uint32_t* __restrict__ tile_start,
+                                                           float2* __restrict__ partial, uint32_t* __restrict__ work_list,
+                                                           uint32_t* __restrict__ work_count) {
+    __shared__ uint32_t s_diff[ILS_MAXW / 32];   // bit w: target column w differs from the background in some channel / row
+    __shared__ uint32_t s_cand[(ILS_MAXW / IL_W + 32) / 32];   // bit b: every tile under span b is empty
+    __shared__ uint32_t s_n, s_base;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_n = 0;
+    const int h0 = blockIdx.x * 2, v = blockIdx.y;
+    const bool row1 = h0 + 1 < H;
+    const size_t plane = (size_t)H * W;
+    const float* py = target + (size_t)v * 3 * plane + (size_t)h0 * W;
+    const int nwords = (W + 31) / 32;
+    const int gxt = (W + 15) / 16, T = gxt * ((H + 15) / 16);
+    const uint32_t* trow = tile_start + (size_t)v * T + (size_t)(h0 >> 4) * gxt;   // both rows of the pair lie in this tile row
+    for (int k = tid; k < nwords; k += ILS_T) s_diff[k] = 0;
+    if (tid < (int)(sizeof(s_cand) / 4)) s_cand[tid] = 0;
+    __syncthreads();
+    for (int b = tid; b < gxb; b += ILS_T) {
+        const int lo = max(b * IL_W - 2 * IL_H1, 0), hi = min(b * IL_W + IL_ND, W);  // [lo, hi)
+        const int t0 = lo >> 4, t1 = (hi - 1) >> 4;
+        if (trow[t1 + 1] == trow[t0]) atomicOr(&s_cand[b >> 5], 1u << (b & 31));   // consecutive tiles: one difference of the scan
+    }
+    // the target against the background colour, everywhere (ungated loads: the tile test above and these are one round
+    // trip; 85 % of a capture-like frame lies under empty tiles anyway)
+    const int rows = row1 ? 2 : 1;
+    const float b0 = bg[0], b1 = bg[1], b2 = bg[2];
+    const bool vec = (W & 3) == 0 && (((uintptr_t)target) & 15) == 0;
+    if (vec) {
+        const int n4 = W >> 2;
+        for (int q = tid; q < n4; q += ILS_T) {
+            uint32_t d = 0;
+            for (int rr = 0; rr < rows; ++rr) {
+                const float4 c0 = *(const float4*)(py + (size_t)rr * W + 4 * q), c1 = *(const float4*)(py + plane + (size_t)rr * W + 4 * q),
+                             c2 = *(const float4*)(py + 2 * plane + (size_t)rr * W + 4 * q);
+                d |= ((c0.x != b0 || c1.x != b1 || c2.x != b2) ? 1u : 0u) | ((c0.y != b0 || c1.y != b1 || c2.y != b2) ? 2u : 0u) |
+                     ((c0.z != b0 || c1.z != b1 || c2.z != b2) ? 4u : 0u) | ((c0.w != b0 || c1.w != b1 || c2.w != b2) ? 8u : 0u);
+            }
+            if (d) atomicOr(&s_diff[q >> 3], d << ((q & 7) * 4));
+        }
+    } else {
+        for (int w = tid; w < W; w += ILS_T) {
+            uint32_t d = 0;
+            for (int rr = 0; rr < rows; ++rr)
+                d |= (py[(size_t)rr * W + w] != b0 || py[plane + (size_t)rr * W + w] != b1 || py[2 * plane + (size_t)rr * W + w] != b2) ? 1u : 0u;
+            if (d) atomicOr(&s_diff[w >> 5], 1u << (w & 31));
+        }
+    }
+    __syncthreads();
+    // classify; the listed spans of the row pair take ONE slot range of the global list (one returning atomic per
+    // workgroup: thousands of them on a single counter cost more than reading the target)
+    uint32_t my_rank[(ILS_MAXW / IL_W + ILS_T) / ILS_T];
+    int nmine = 0;
+    for (int b = tid; b < gxb; b += ILS_T, ++nmine) {
+        const int lo = max(b * IL_W - 2 * IL_H1, 0), hi = min(b * IL_W + IL_ND, W);  // [lo, hi)
+        uint32_t any = ((s_cand[b >> 5] >> (b & 31)) & 1u) ? 0u : 1u;
+        for (int k = lo >> 5; k <= (hi - 1) >> 5 && !any; ++k) {
+            uint32_t m = s_diff[k];
+            const int base = k << 5;
+            if (lo > base) m &= ~0u << (lo - base);
+            if (hi < base + 32) m &= ~0u >> (base + 32 - hi);
+            any |= m;
+        }
+        my_rank[nmine] = any ? atomicAdd(&s_n, 1u) : 0xFFFFFFFFu;
+        if (!any) {
+            const uint32_t bid = ((uint32_t)v * gridDim.x + blockIdx.x) * (uint32_t)gxb + (uint32_t)b;
+            const int wcnt = min((b + 1) * IL_W, W) - b * IL_W;
+            partial[bid] = make_float2(0.f, (float)(wcnt * 3 * rows));
+        }
+    }
+    __syncthreads();
+    if (tid == 0 && s_n) s_base = atomicAdd(work_count, s_n);
+    __syncthreads();
+    nmine = 0;
+    for (int b = tid; b < gxb; b += ILS_T, ++nmine)
+        if (my_rank[nmine] != 0xFFFFFFFFu)
+            work_list[s_base + my_rank[nmine]] = ((uint32_t)v * gridDim.x + blockIdx.x) * (uint32_t)gxb + (uint32_t)b;
+}
+
 // fold the per-workgroup sums: sums[0] = sum |pred - target|, sums[1] = sum of the SSIM map
 __global__ __launch_bounds__(1024) void k_image_loss_fold(int64_t n, const float2* __restrict__ partial,
                                                           float* __restrict__ sums, float ca, float cb, float cc) {
@@ -346,9 +433,9 @@ extern "C" size_t mgr_image_loss_workspace_bytes(int V, int H, int W) {
     return (size_t)il_blocks(V, H, W) * (sizeof(float2) + sizeof(uint32_t)) + 256;  // per-span sums | work list | counter
 }
 
-extern "C" int mgr_image_loss(int V, int H, int W, const float* pred, const float* target, float w_l1, float w_ssim,
-                              float grad_scale, float loss_offset, float* dL_dpred, float* sums, void* workspace,
-                              size_t workspace_bytes, void* stream_) {
+static int image_loss_impl(int V, int H, int W, const float* pred, const float* target, const float* bg3,
+                           const uint32_t* tile_start, float w_l1, float w_ssim, float grad_scale, float loss_offset,
+                           float* dL_dpred, float* sums, void* workspace, size_t workspace_bytes, void* stream_) {
     if (V <= 0 || H <= 0 || W <= 0) return mgr_fail(MGR_EINVAL, "mgr_image_loss: bad sizes");
     if (!pred || !target || !dL_dpred || !sums || !workspace) return mgr_fail(MGR_EINVAL, "mgr_image_loss: null pointer");
     if (H > 65535 || V > 65535) return mgr_fail(MGR_EINVAL, "mgr_image_loss: H and V must fit a grid dimension");
@@ -371,7 +458,11 @@ extern "C" int mgr_image_loss(int V, int H, int W, const float* pred, const floa
     uint32_t* work_count = (uint32_t*)((char*)workspace + (size_t)nb * (sizeof(float2) + sizeof(uint32_t)) + 64);
     MGR_HIP(hipMemsetAsync(work_count, 0, 4, stream));
     if (W > ILS_MAXW) return mgr_fail(MGR_EINVAL, "mgr_image_loss: image wider than 16384");
-    {
+    if (tile_start) {
+        MGR_PROF("k_image_loss_list", stream);
+        hipLaunchKernelGGL(k_image_loss_list, dim3(grid.y, V), dim3(ILS_T), 0, stream, H, W, (int)grid.x, target, bg3, tile_start,
+                           partial, work_list, work_count);
+    } else {
         MGR_PROF("k_image_loss_scan", stream);
         hipLaunchKernelGGL(k_image_loss_scan, dim3(grid.y, V), dim3(ILS_T), 0, stream, H, W, (int)grid.x, pred, target, dL_dpred,
                            partial, work_list, work_count);
@@ -387,4 +478,19 @@ extern "C" int mgr_image_loss(int V, int H, int W, const float* pred, const floa
                        sums, grad_scale * w_l1, -grad_scale * w_ssim, loss_offset);
     MGR_LAUNCH_CHECK("k_image_loss", stream, 0);
     return MGR_OK;
+}
+
+extern "C" int mgr_image_loss(int V, int H, int W, const float* pred, const float* target, float w_l1, float w_ssim,
+                              float grad_scale, float loss_offset, float* dL_dpred, float* sums, void* workspace,
+                              size_t workspace_bytes, void* stream_) {
+    return image_loss_impl(V, H, W, pred, target, nullptr, nullptr, w_l1, w_ssim, grad_scale, loss_offset, dL_dpred, sums,
+                           workspace, workspace_bytes, stream_);
+}
+
+extern "C" int mgr_image_loss_tiles(int V, int H, int W, const float* pred, const float* target, const float* bg3,
+                                    const uint32_t* tile_start, float w_l1, float w_ssim, float grad_scale, float loss_offset,
+                                    float* dL_dpred, float* sums, void* workspace, size_t workspace_bytes, void* stream_) {
+    if (!bg3 || !tile_start) return mgr_fail(MGR_EINVAL, "mgr_image_loss_tiles: null pointer");
+    return image_loss_impl(V, H, W, pred, target, bg3, tile_start, w_l1, w_ssim, grad_scale, loss_offset, dL_dpred, sums,
+                           workspace, workspace_bytes, stream_);
 }

@@ -245,8 +245,12 @@ class HipViewCompute:
     the modular operators under autograd (the reference-shaped path)."""
 
     def __init__(self, scene, targets, cam_table, loss_weight=1.0, fused=True, loss="l1", w_rgb=0.8, w_ssim=0.2,
-                 sh_storage="fp32"):
+                 sh_storage="fp32", sparse_loss=True):
         from . import fused as fused_mod, ops, rasterizer
+        # sparse_loss: the fused step hands the forward's tile-list offsets to the image loss, which then settles the
+        # spans under empty tiles from the target alone (exact: the rasterizer writes the background colour there) and
+        # leaves their gradient unwritten (the backward never reads it).  False: the loss reads both images everywhere.
+        self.sparse_loss, self._ts_off = bool(sparse_loss), {}
         # sh_storage "fp16" (BASELINE config 5): the fused kernels read an fp16 copy of _features_rest (96 B instead of
         # 180 B per Gaussian and view group); arithmetic, gradients and the optimizer's master copy stay fp32.  The copy
         # is refreshed lazily after the leaves changed (`mark_params_changed`).  The reference has no fp16 mode:
@@ -356,16 +360,29 @@ class HipViewCompute:
                                     p["_features_rest"], w, sel["T"], sel["cams"], s["bg"], s["width"], s["height"],
                                     stats=stats, grad2d_scale=grad2d_scale, grad_arena=self.grad_arena)
 
-    def _image_loss(self, img, tgt, scale):
-        """(loss value, dL/dimg) of scale * sum over the views of the per-view image loss."""
+    def _image_loss(self, img, tgt, scale, tiles=None):
+        """(loss value, dL/dimg) of scale * sum over the views of the per-view image loss.  tiles = (bg, device address
+        of the tile-list offsets of the forward that rendered img): spans under empty tiles are not read (ops.image_loss_grad)."""
         per_view = img[0].numel()
         k = self.loss_weight * scale / per_view
         if self.loss == "l1":
             loss_sum, g = self.ops.l1_loss_grad(img, tgt, scale=k)
             return loss_sum[0] * k, g
         const = self.w_ssim * self.loss_weight * scale * img.shape[0]   # the "1 -" of 1 - ssim, once per view
-        sums, g = self.ops.image_loss_grad(img, tgt, self.w_rgb, self.w_ssim, k, const)
+        bg, ts = tiles if (tiles is not None and self.sparse_loss) else (None, None)
+        sums, g = self.ops.image_loss_grad(img, tgt, self.w_rgb, self.w_ssim, k, const, bg=bg, tile_start_ptr=ts)
         return sums[2], g
+
+    def _tile_start_ptr(self, ws, V, N, W, H):
+        key = (V, N, W, H, ws.cap)
+        off = self._ts_off.get(key)
+        if off is None:
+            import ctypes
+            from ._lib import lib
+            arr = (ctypes.c_size_t * 32)()
+            lib().mgr_raster_layout(V, N, W, H, ws.cap, arr, 32)
+            off = self._ts_off[key] = int(arr[7])
+        return ws.buf.data_ptr() + off
 
     # -- fused path, direct C-ABI calls ------------------------------------------------------------
     def _step_direct(self, view_ids, scale, g_img=None):
@@ -412,7 +429,7 @@ class HipViewCompute:
         ws, _ = self.rz.context(dev).forward(V, N, W, H, launch)
         try:
             if g_img is None:
-                loss, g_img = self._image_loss(out, sel["targets"], scale)
+                loss, g_img = self._image_loss(out, sel["targets"], scale, tiles=(bg, self._tile_start_ptr(ws, V, N, W, H)))
             else:
                 loss, g_img = (out * g_img).sum(), g_img.contiguous()
             d_xyz, d_ls, d_rot = e((N, 3), "_xyz"), e((N, 3), "_scaling"), e((N, 4), "_rotation")

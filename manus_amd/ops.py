@@ -11,6 +11,8 @@ Each op mirrors one block of MANUS Python code (reference tree brown-ivl/manus):
 
 All of them require GPU tensors; there is no CPU or PyTorch fallback.
 """
+import ctypes
+
 import torch
 
 from ._lib import MGR_MAX_BONES, ManusHipError, check, f32c, lib, ptr, stream
@@ -210,14 +212,18 @@ def l1_loss_grad(pred, target, scale=None):
     return s, g
 
 
-def image_loss_grad(pred, target, w_l1=0.8, w_ssim=0.2, grad_scale=1.0, loss_offset=0.0):
+def image_loss_grad(pred, target, w_l1=0.8, w_ssim=0.2, grad_scale=1.0, loss_offset=0.0, bg=None, tile_start_ptr=None):
     """Fused L1 + SSIM image loss of the training step (loss_utils.py:22-97 as called at
     base.py:323-365), forward and backward, on (V,3,H,W) images.
 
     Returns (sums, grad): sums[0] = sum|pred-target|, sums[1] = sum of the SSIM map, sums[2] =
     grad_scale * (w_l1 * sums[0] - w_ssim * sums[1]) + loss_offset (device tensor of 3 floats); grad = grad_scale * d/dpred [w_l1 * sum|pred-target| - w_ssim * sum ssim_map].
     The SSIM statistic is the reference's: ssim() called on HWC images, i.e. the 11x11 window
-    slides over the (W,3) plane of every row."""
+    slides over the (W,3) plane of every row.
+
+    bg (3 floats on the device) + tile_start_ptr (device address of the tile-list offsets of the forward that rendered
+    `pred`): `mgr_image_loss_tiles` -- spans under empty tiles are settled from the target alone and their gradient is
+    left unwritten (nothing reads it); the sums are the same."""
     pred, target = f32c(pred), f32c(target)
     if pred.dim() == 3:
         pred, target = pred[None], target[None]
@@ -228,6 +234,11 @@ def image_loss_grad(pred, target, w_l1=0.8, w_ssim=0.2, grad_scale=1.0, loss_off
     sums = torch.empty(3, dtype=torch.float32, device=pred.device)
     nbytes = int(lib().mgr_image_loss_workspace_bytes(V, H, W))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=pred.device)
+    if tile_start_ptr is not None and bg is not None:
+        check(lib().mgr_image_loss_tiles(V, H, W, ptr(pred), ptr(target), ptr(f32c(bg)), ctypes.c_void_p(int(tile_start_ptr)),
+                                         float(w_l1), float(w_ssim), float(grad_scale), float(loss_offset), ptr(g), ptr(sums),
+                                         ptr(ws), nbytes, stream()), "mgr_image_loss_tiles")
+        return sums, g
     check(lib().mgr_image_loss(V, H, W, ptr(pred), ptr(target), float(w_l1), float(w_ssim), float(grad_scale),
                                float(loss_offset), ptr(g), ptr(sums), ptr(ws), nbytes, stream()), "mgr_image_loss")
     return sums, g

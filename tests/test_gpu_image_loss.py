@@ -147,3 +147,57 @@ def test_identical_background_fast_path_matches_oracle():
     assert abs(got[1] - s_sum) <= 1e-5 * abs(s_sum)
     assert max_rel_err(grad.cpu().numpy(), gref.numpy()) < 1e-4
     assert float(grad[0, :, 0, :500].abs().max()) == 0.0       # far from any difference: exactly zero
+
+
+def test_tile_aware_loss_equals_the_full_comparison():
+    """mgr_image_loss_tiles (spans under empty tiles settled from the target alone, their gradient left unwritten)
+    against mgr_image_loss on a rendered scene: same sums; the same gradient wherever a tile holds a Gaussian or the
+    target differs from the background; and the training step's leaf gradients do not change (bitwise)."""
+    from manus_amd import ops, rasterizer as rz
+    from manus_amd.engine import HipViewCompute
+    from manus_amd.synthetic import camera_table, make_scene
+    V, W, H, n = 3, 500, 330, 4000      # W not a multiple of 16 or 246, H not a multiple of 16
+    sc = make_scene(n_gaussians=n, kind="hand", seed=9, grid_res=24, n_cameras=V, width=W, height=H, cam_radius=0.9,
+                    sigma_range=(2e-3, 8e-3), device=DEV)
+    ct = camera_table(sc["cameras"], DEV)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    tgt_scene = dict(sc)
+    tgt_scene["params"] = {k: (v + 0.02 * v.abs().mean() * torch.randn(v.shape, generator=g).to(DEV)) for k, v in sc["params"].items()}
+    with torch.no_grad():
+        targets = HipViewCompute(tgt_scene, torch.zeros((V, 3, H, W), device=DEV), ct).forward_views_fused(list(range(V)))[0].contiguous()
+    targets[1, :, 5:9, 440:470] = 0.25          # target foreground where nothing is rendered (empty tiles)
+    rz.set_sync_policy(True)
+    res = {}
+    for sparse in (False, True):
+        hc = HipViewCompute(sc, targets, ct, loss="l1+ssim", sparse_loss=sparse)
+        out = hc._step_direct(list(range(V)), 1.0 / V)
+        res[sparse] = ({k: v.clone() for k, v in out["grads"].items()}, out["loss"].clone(), out["grad2d"].clone())
+    for k in res[False][0]:
+        assert torch.equal(res[False][0][k], res[True][0][k]), k
+    assert torch.equal(res[False][2], res[True][2])
+    assert abs(float(res[False][1]) - float(res[True][1])) <= 2e-7 * abs(float(res[False][1]))
+    # the operator itself, on the last forward's image and tile lists
+    ws = rz.context().last_ws
+    img = hc.last_image
+    ts_ptr = hc._tile_start_ptr(ws, V, n, W, H)
+    s0, g0 = ops.image_loss_grad(img, targets, 0.8, 0.2, 0.37, 0.11)
+    g1 = torch.full_like(img, float("nan"))
+    # (ops allocates its own gradient tensor: call the ABI with a NaN-filled one to see what is written)
+    import ctypes
+    from manus_amd._lib import check, lib, ptr, stream
+    sums = torch.empty(3, device=DEV)
+    nbytes = int(lib().mgr_image_loss_workspace_bytes(V, H, W))
+    wsb = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    check(lib().mgr_image_loss_tiles(V, H, W, ptr(img), ptr(targets), ptr(sc["bg"]), ctypes.c_void_p(ts_ptr), 0.8, 0.2, 0.37,
+                                     0.11, ptr(g1), ptr(sums), ptr(wsb), nbytes, stream()), "mgr_image_loss_tiles")
+    assert torch.allclose(sums, s0, rtol=2e-7, atol=0)
+    written = ~torch.isnan(g1)
+    # (a span that is identical under NON-empty tiles is zero-filled by the full comparison and computed here: fp32
+    # noise of the order 1e-9 instead of exact zeros, like the reference's own result there)
+    assert float((g1[written] - g0[written]).abs().max()) < 1e-6
+    both = written & (g0 != 0)
+    assert torch.equal(g1[both], g0[both])
+    assert not g0[~written].any()                       # what was left unwritten is zero in the full comparison
+    frac = float(written.float().mean())
+    assert 0.02 < frac < 0.9, frac                      # most of the frame is background and was skipped
+    assert written[1, :, 5:9, 440:470].all()            # the target-only foreground was computed (it counts in the loss)
