@@ -304,6 +304,15 @@ int mgr_image_loss(int V, int H, int W, const float* pred, const float* target, 
 int mgr_image_loss_tiles(int V, int H, int W, const float* pred, const float* target, const float* bg3,
                          const uint32_t* tile_start, float w_l1, float w_ssim, float grad_scale, float loss_offset,
                          float* dL_dpred, float* sums, void* workspace, size_t workspace_bytes, void* stream);
+/* mgr_image_loss_tiles in two calls.  _list builds the span list: it needs the forward's tile offsets but not its
+ * image, so it can run on another stream while the forward blend runs (mgr_views_forward / mgr_raster_forward with
+ * debug bit 1 = "stop before the blend", then bit 2 = "the blend only").  _finish does the rest on that list (same
+ * workspace; the caller orders it after both the list and the blend). */
+int mgr_image_loss_tiles_list(int V, int H, int W, const float* target, const float* bg3, const uint32_t* tile_start,
+                              void* workspace, size_t workspace_bytes, void* stream);
+int mgr_image_loss_tiles_finish(int V, int H, int W, const float* pred, const float* target, float w_l1, float w_ssim,
+                                float grad_scale, float loss_offset, float* dL_dpred, float* sums, void* workspace,
+                                size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
  * Optimizer step and densification of the Gaussian parameter model

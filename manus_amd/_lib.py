@@ -60,6 +60,9 @@ SIGNATURES = {
     "mgr_image_loss": (c_int, [c_int, c_int, c_int, c_vp, c_vp, c_f32, c_f32, c_f32, c_f32, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "mgr_image_loss_tiles": (c_int, [c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_f32, c_vp, c_vp, c_vp, c_sz,
                                      c_vp]),
+    "mgr_image_loss_tiles_list": (c_int, [c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "mgr_image_loss_tiles_finish": (c_int, [c_int, c_int, c_int, c_vp, c_vp, c_f32, c_f32, c_f32, c_f32, c_vp, c_vp, c_vp, c_sz,
+                                            c_vp]),
     "mgr_adam_step": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, ctypes.c_double, ctypes.c_double,
                                ctypes.c_double, c_vp]),
     "mgr_reset_opacity": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp]),

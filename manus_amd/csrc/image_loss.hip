@@ -435,9 +435,10 @@ extern "C" size_t mgr_image_loss_workspace_bytes(int V, int H, int W) {
 
 static int image_loss_impl(int V, int H, int W, const float* pred, const float* target, const float* bg3,
                            const uint32_t* tile_start, float w_l1, float w_ssim, float grad_scale, float loss_offset,
-                           float* dL_dpred, float* sums, void* workspace, size_t workspace_bytes, void* stream_) {
+                           float* dL_dpred, float* sums, void* workspace, size_t workspace_bytes, void* stream_, int phase = 0) {
+    // phase 0: everything; 1: the span list only (needs target, bg3, tile_start, workspace); 2: the rest, on a list already built
     if (V <= 0 || H <= 0 || W <= 0) return mgr_fail(MGR_EINVAL, "mgr_image_loss: bad sizes");
-    if (!pred || !target || !dL_dpred || !sums || !workspace) return mgr_fail(MGR_EINVAL, "mgr_image_loss: null pointer");
+    if (!target || !workspace || (phase != 1 && (!pred || !dL_dpred || !sums))) return mgr_fail(MGR_EINVAL, "mgr_image_loss: null pointer");
     if (H > 65535 || V > 65535) return mgr_fail(MGR_EINVAL, "mgr_image_loss: H and V must fit a grid dimension");
     if (workspace_bytes < mgr_image_loss_workspace_bytes(V, H, W))
         return mgr_fail(MGR_ENOMEM, "mgr_image_loss: workspace too small");
@@ -456,9 +457,10 @@ static int image_loss_impl(int V, int H, int W, const float* pred, const float* 
     float2* partial = (float2*)workspace;
     uint32_t* work_list = (uint32_t*)((char*)workspace + (size_t)nb * sizeof(float2));
     uint32_t* work_count = (uint32_t*)((char*)workspace + (size_t)nb * (sizeof(float2) + sizeof(uint32_t)) + 64);
-    MGR_HIP(hipMemsetAsync(work_count, 0, 4, stream));
     if (W > ILS_MAXW) return mgr_fail(MGR_EINVAL, "mgr_image_loss: image wider than 16384");
-    if (tile_start) {
+    if (phase != 2) MGR_HIP(hipMemsetAsync(work_count, 0, 4, stream));
+    if (phase == 2) {
+    } else if (tile_start) {
         MGR_PROF("k_image_loss_list", stream);
         hipLaunchKernelGGL(k_image_loss_list, dim3(grid.y, V), dim3(ILS_T), 0, stream, H, W, (int)grid.x, target, bg3, tile_start,
                            partial, work_list, work_count);
@@ -467,6 +469,7 @@ static int image_loss_impl(int V, int H, int W, const float* pred, const float* 
         hipLaunchKernelGGL(k_image_loss_scan, dim3(grid.y, V), dim3(ILS_T), 0, stream, H, W, (int)grid.x, pred, target, dL_dpred,
                            partial, work_list, work_count);
     }
+    if (phase == 1) return MGR_OK;
     {
         MGR_PROF("k_image_loss", stream);
         const int64_t pb = nb < 256 * 5 ? nb : 256 * 5;   // persistent: 5 workgroups of 32 KB LDS per CU
@@ -493,4 +496,20 @@ extern "C" int mgr_image_loss_tiles(int V, int H, int W, const float* pred, cons
     if (!bg3 || !tile_start) return mgr_fail(MGR_EINVAL, "mgr_image_loss_tiles: null pointer");
     return image_loss_impl(V, H, W, pred, target, bg3, tile_start, w_l1, w_ssim, grad_scale, loss_offset, dL_dpred, sums,
                            workspace, workspace_bytes, stream_);
+}
+
+/* The two halves of mgr_image_loss_tiles: the span list needs the forward's tile offsets but not its image, so it can be
+ * built on another stream while the forward blend runs (engine: mgr_views_forward split at the blend). */
+extern "C" int mgr_image_loss_tiles_list(int V, int H, int W, const float* target, const float* bg3, const uint32_t* tile_start,
+                                         void* workspace, size_t workspace_bytes, void* stream_) {
+    if (!bg3 || !tile_start) return mgr_fail(MGR_EINVAL, "mgr_image_loss_tiles_list: null pointer");
+    return image_loss_impl(V, H, W, nullptr, target, bg3, tile_start, 0.f, 0.f, 0.f, 0.f, nullptr, nullptr, workspace,
+                           workspace_bytes, stream_, 1);
+}
+
+extern "C" int mgr_image_loss_tiles_finish(int V, int H, int W, const float* pred, const float* target, float w_l1, float w_ssim,
+                                           float grad_scale, float loss_offset, float* dL_dpred, float* sums, void* workspace,
+                                           size_t workspace_bytes, void* stream_) {
+    return image_loss_impl(V, H, W, pred, target, nullptr, nullptr, w_l1, w_ssim, grad_scale, loss_offset, dL_dpred, sums,
+                           workspace, workspace_bytes, stream_, 2);
 }

@@ -1725,6 +1725,10 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
                                int32_t* radii, void* workspace, size_t workspace_bytes,
                                int64_t cap, int debug, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    // debug bit 0: synchronise and check after every kernel; bit 1: stop before the blend (instance kernels and binning
+    // only); bit 2: the blend only (after a call with bit 1 on the same workspace and arguments)
+    const bool do_bin = !(debug & 4), do_blend = !(debug & 2);
+    debug &= 1;
     if (V <= 0 || N < 0 || W <= 0 || H <= 0 || cap < 0 || cap > 0xFFFFFFF0ll)
         return mgr_fail(MGR_EINVAL, "mgr_raster_forward: bad sizes");
     if (!cams || !bg || !out_color || !workspace ||
@@ -1759,6 +1763,7 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
         attr_set = true;
     }
 
+    if (do_bin) {
     // per-call counters (epoch lives past the first 32 bytes and persists)
     MGR_HIP(hipMemsetAsync(hdr, 0, 8, stream));
     // tile_count and the size-class counters are left zero by the previous forward on this workspace
@@ -1879,6 +1884,8 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
         MGR_HIP(hipStreamWaitEvent(stream, side.join, 0));
         MGR_LAUNCH_CHECK("k_tile_sort", stream, debug);
     }
+    }   // do_bin
+    if (!do_blend) return MGR_OK;
     { MGR_PROF("k_blend_fwd", stream); hipLaunchKernelGGL(k_blend_fwd, dim3(256 * 8), dim3(256), 0, stream, N, W, H, gx, gy, VT, bg, tile_start,
                        (const uint32_t*)(ws + L.tile_queue), (const uint32_t*)(ws + L.sorted_gid), (const MgrGRec*)(ws + L.grec), out_color,
                        (float*)(ws + L.final_T), (uint32_t*)(ws + L.n_contrib),

@@ -16,6 +16,8 @@ which the backward kernels write in place (no packing copies).  max_radii2D need
 associative and idempotent, so every rank keeps the running maximum over ITS views and the ranks are only
 combined (one MAX all-reduce) right before the statistic is consumed, i.e. at a densification step.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -245,12 +247,15 @@ class HipViewCompute:
     the modular operators under autograd (the reference-shaped path)."""
 
     def __init__(self, scene, targets, cam_table, loss_weight=1.0, fused=True, loss="l1", w_rgb=0.8, w_ssim=0.2,
-                 sh_storage="fp32", sparse_loss=True):
+                 sh_storage="fp32", sparse_loss=True, overlap_loss=True):
         from . import fused as fused_mod, ops, rasterizer
         # sparse_loss: the fused step hands the forward's tile-list offsets to the image loss, which then settles the
         # spans under empty tiles from the target alone (exact: the rasterizer writes the background colour there) and
         # leaves their gradient unwritten (the backward never reads it).  False: the loss reads both images everywhere.
         self.sparse_loss, self._ts_off = bool(sparse_loss), {}
+        # overlap_loss: that span list is built on a second stream while the forward blend runs (MANUS_OVERLAP_LOSS=0
+        # in the environment switches it off for A/B runs)
+        self.overlap_loss, self._side = bool(overlap_loss) and os.environ.get("MANUS_OVERLAP_LOSS", "1") != "0", None
         # sh_storage "fp16" (BASELINE config 5): the fused kernels read an fp16 copy of _features_rest (96 B instead of
         # 180 B per Gaussian and view group); arithmetic, gradients and the optimizer's master copy stay fp32.  The copy
         # is refreshed lazily after the leaves changed (`mark_params_changed`).  The reference has no fp16 mode:
@@ -420,15 +425,45 @@ class HipViewCompute:
         bg = s["bg"]
         f_rest, sh_half = self._sh_storage(p["_features_rest"])
 
-        def launch(ws):
+        # The span list of the image loss needs the forward's tile offsets but not its image: with overlap_loss it is
+        # built on a second stream while the forward blend runs (forward split at the blend, debug bits 1 / 2).
+        overlap = g_img is None and self.loss == "l1+ssim" and self.sparse_loss and self.overlap_loss
+
+        def fwd(ws, phase):
             check(lib().mgr_views_forward(V, N, B, na, sh_half, W, H, ptr(cams), ptr(bg), ptr(p["_xyz"]), ptr(p["_scaling"]),
                                           ptr(p["_rotation"]), ptr(op), ptr(p["_features_dc"]), ptr(f_rest),
-                                          ptr(w), ptr(T), ptr(out), ptr(radii), ptr(ws.buf), ws.nbytes, ws.cap, 0,
+                                          ptr(w), ptr(T), ptr(out), ptr(radii), ptr(ws.buf), ws.nbytes, ws.cap, phase,
                                           stream()), "mgr_views_forward")
+
+        def launch(ws):
+            fwd(ws, 2 if overlap else 0)
 
         ws, _ = self.rz.context(dev).forward(V, N, W, H, launch)
         try:
-            if g_img is None:
+            if overlap:
+                import ctypes
+                tgt = sel["targets"]
+                nbytes = int(lib().mgr_image_loss_workspace_bytes(V, H, W))
+                lws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                g_img = torch.empty_like(out)
+                sums = torch.empty(3, dtype=torch.float32, device=dev)
+                cur = torch.cuda.current_stream(dev)
+                if self._side is None:
+                    self._side = torch.cuda.Stream(device=dev)
+                self._side.wait_stream(cur)
+                with torch.cuda.stream(self._side):
+                    check(lib().mgr_image_loss_tiles_list(V, H, W, ptr(tgt), ptr(bg), ctypes.c_void_p(self._tile_start_ptr(ws, V, N, W, H)),
+                                                          ptr(lws), nbytes, stream()), "mgr_image_loss_tiles_list")
+                fwd(ws, 4)                                  # the blend, next to the list
+                cur.wait_stream(self._side)
+                lws.record_stream(self._side)
+                per_view = out[0].numel()
+                k = self.loss_weight * scale / per_view
+                const = self.w_ssim * self.loss_weight * scale * V
+                check(lib().mgr_image_loss_tiles_finish(V, H, W, ptr(out), ptr(tgt), self.w_rgb, self.w_ssim, k, const, ptr(g_img),
+                                                        ptr(sums), ptr(lws), nbytes, stream()), "mgr_image_loss_tiles_finish")
+                loss = sums[2]
+            elif g_img is None:
                 loss, g_img = self._image_loss(out, sel["targets"], scale, tiles=(bg, self._tile_start_ptr(ws, V, N, W, H)))
             else:
                 loss, g_img = (out * g_img).sum(), g_img.contiguous()
