@@ -1,15 +1,16 @@
-// Rasterizer forward for gfx950: preprocess -> tile scan/queue -> emit -> per-tile
-// LDS sort -> alpha blend.  All V views of a call are batched into every launch.
+// Rasterizer forward for gfx950: preprocess -> tile scan/queue -> depth-ordered binning (or: emit ->
+// per-tile LDS sort) -> alpha blend.  All V views of a call are batched into every launch.
 //
 // Replaces diff_gaussian_rasterization._C.rasterize_gaussians as called from
 // /root/reference/src/utils/gaussian_utils.py:393-416 (algorithm: SURVEY.md App. A).
 //
 // Design (MI355X-first, not the upstream CUDA layout):
-//  * no global 64-bit radix sort: pairs are bucketed straight into their tile's
-//    segment (block-aggregated LDS histograms -> one global atomic per (block,tile)),
-//    then each tile is sorted on its own in LDS by the unique key
-//    (depth_bits << 32 | gaussian_index), which reproduces the upstream stable
-//    (tile|depth) order exactly and makes the result independent of atomic order;
+//  * no global 64-bit radix sort of the (Gaussian, tile) pairs, and by default no sort of the pairs at all:
+//    the instances of a view are sorted once by the unique key (depth_bits << 32 | gaussian_index) and the
+//    pairs are scattered to the tile lists in that order ("depth-ordered binning", K3'/K4' below), which
+//    reproduces the upstream stable (tile|depth) order exactly.  The round-1 route remains (MGR_BINNING=sorted
+//    and very large tile grids): pairs bucketed straight into their tile's segment (block-aggregated LDS
+//    histograms -> one global atomic per (block,tile)), then each tile sorted on its own in LDS by that key;
 //  * per-(view,Gaussian) data the blend kernels gather is one 48-byte record;
 //  * no host synchronisation: the pair count stays on the device, capacity
 //    overflow raises a flag in the workspace header.
@@ -903,13 +904,14 @@ __global__ __launch_bounds__(256) void k_tile_sort_small(
 // *generated in that order*, so that no list needs sorting:
 //   1. k_dbin_count / k_dbin_scan / k_dbin_scatter: instances -> 8192 monotone depth buckets per view
 //      (float bits of z >> 13: 1024 buckets per octave above the 0.2 cull plane);
-//   2. k_dbin_sort: LDS radix sort (lds_sort_emit) of groups of 8 consecutive buckets -> db_order;
+//   2. k_dbin_sort: LDS radix sorts (lds_sort_emit) of runs of whole buckets, about DB_CHUNK keys each -> db_order;
 //   3. k_bin_count: per block of MGR_BIN_BLOCK depth-consecutive instances, the pairs per tile (LDS
 //      histogram) -> one row of the (block, tile) matrix;  k_bin_scan: column-wise exclusive scan on top
 //      of tile_start -> the row becomes the block's first slot in every tile list;
-//   4. k_bin_scatter: one wave per block walks its instances in order; the lanes take the tiles of the
-//      instance, a returning LDS add on the tile's cursor hands out the slot.  LDS operations of one wave
-//      complete in program order, so the slots of a tile are handed out in instance order.  Four instances
+//   4. k_bin_scatter: one wave per block takes its instances 64 at a time, expands their pairs into an LDS
+//      list in instance order and hands out the slots 64 pairs per step from per-tile cursors in LDS, ranking
+//      the lanes that share a tile (see the kernel).  LDS operations of one wave complete in program order,
+//      which is what makes the steps of a block sequential.  The general fallback walks instance by instance: four instances
 //      of at most 16 tiles share a step (16 lanes each, their LDS adds issued one instance after the other).
 // The result is bit-identical to the sorted route (unique keys: there is one correct order).
 // ---------------------------------------------------------------------------
