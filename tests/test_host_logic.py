@@ -245,7 +245,9 @@ def _worker(rank, world, port, q, mode="dense"):
     assert float(out["overflow"]) == 0.0
     st.reduce_max_radii(out["radii"])        # the per-step collective carries sums only; the maximum is combined on demand
     if rank == 0:
-        q.put({k: ({n: g.clone() for n, g in v.items()} if isinstance(v, dict) else v.clone()) for k, v in out.items()
+        # numpy: by value (a torch tensor travels as a file descriptor the consumer must fetch while this process lives)
+        q.put({k: ({n: g.detach().numpy().copy() for n, g in v.items()} if isinstance(v, dict) else v.detach().numpy().copy())
+               for k, v in out.items()
                if v is not None})
     dist.barrier()
     dist.destroy_process_group()
@@ -266,6 +268,8 @@ def test_view_sharded_step_gloo_world2(mode):
     for p in procs:
         p.start()
     got = q.get(timeout=180)
+    got = {k: ({n: torch.from_numpy(np.asarray(g)) for n, g in v.items()} if isinstance(v, dict) else torch.from_numpy(np.asarray(v)))
+           for k, v in got.items()}
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
