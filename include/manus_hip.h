@@ -91,7 +91,13 @@ size_t mgr_raster_workspace_bytes(int V, int N, int W, int H, int64_t pair_capac
  * opacity (N) — each with its per-view stride.
  * If the number of pairs exceeds pair_capacity the image is still written but
  * is incomplete and the overflow flag is raised: check with
- * mgr_raster_status_sync and retry with a larger workspace. */
+ * mgr_raster_status_sync and retry with a larger workspace.
+ * debug (here and in mgr_views_forward) is a bit set: 1 = synchronise and check after every kernel (upstream's
+ * `debug=True`); 2 = stop before the blend (projection and binning only: radii, the pair total and the tile lists are
+ * final, out_color is not written); 4 = the blend only, after a call with bit 2 on the same workspace and arguments.
+ * Bits 2 / 4 let a caller put work that needs the tile lists but not the image next to the blend (the image loss's
+ * span list, mgr_image_loss_tiles_list).  The tile lists come from the depth-ordered binning; MGR_BINNING=sorted in
+ * the environment selects the per-tile sorts instead (identical lists). */
 int mgr_raster_forward(int V, int N, int W, int H, const float* cams, const float* bg,
                        const float* means3D, int64_t stride_means3D, const float* cov3D,
                        int64_t stride_cov3D, const float* colors, int64_t stride_colors,
