@@ -206,6 +206,8 @@ def make_masks(scene, posed_xyz, margin=9):
         ij = uv[ok].long()
         img[ij[:, 1], ij[:, 0]] = 1.0
         k = 2 * margin + 1
-        img = torch.nn.functional.max_pool2d(img[None, None], k, stride=1, padding=margin)[0, 0]
+        # (a square window: the maximum over rows, then over columns -- 2k instead of k*k comparisons per pixel)
+        img = torch.nn.functional.max_pool2d(img[None, None], (k, 1), stride=1, padding=(margin, 0))
+        img = torch.nn.functional.max_pool2d(img, (1, k), stride=1, padding=(0, margin))[0, 0]
         out.append(img.to(torch.uint8)[..., None])
     return torch.stack(out)

