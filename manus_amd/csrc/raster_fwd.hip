@@ -260,15 +260,25 @@ __global__ __launch_bounds__(PRE_THREADS) void k_inst_fwd(
     const float* __restrict__ skin_w, const float* __restrict__ transforms, MgrGRec* __restrict__ grec,
     float* __restrict__ depth, ushort4* __restrict__ rect, unsigned long long* __restrict__ alive,
     uint32_t* __restrict__ pair_off, uint32_t* __restrict__ tile_count, int32_t* __restrict__ radii,
-    MgrHeader* hdr, int lds_hist) {
+    MgrHeader* hdr, int lds_hist, int V) {
     extern __shared__ uint32_t s_mem[];
     uint32_t* s_scan = s_mem;
     uint32_t* s_hist = s_mem + 32;
-    const int v = blockIdx.y, tid = threadIdx.x;
-    const int i = blockIdx.x * PRE_THREADS + tid;
+    // XCD-aware block order.  The V views of a range of 512 Gaussians read the same canonical rows (320 B per
+    // Gaussian, the SH coefficients most of it): workgroup b runs on XCD b % 8 (observed dispatch order, used for
+    // speed only), so the ranges are dealt out to the XCDs (range r -> XCD r % 8) and the V workgroups of a range
+    // follow each other on that XCD -- views 2..V find the rows in its L2 (a range is 169 KB, an XCD holds ~16 ranges
+    // in flight, its L2 is 4 MB).  With (range, view) = (blockIdx.x, blockIdx.y) the next view of a range came 586
+    // workgroups later on some other XCD and every view fetched its rows from memory again.
+    const int tid = threadIdx.x;
+    const int nrange = (N + PRE_THREADS - 1) / PRE_THREADS;
+    const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+    const int range = (k / V) * 8 + xcd, v = k % V;
+    if (range >= nrange) return;   // (the grid is padded to 8 * ceil(nrange / 8) * V workgroups)
+    const int i = range * PRE_THREADS + tid;
     const int T = gx * gy;
     if (lds_hist) {
-        for (int k = tid; k < T; k += PRE_THREADS) s_hist[k] = 0;
+        for (int k2 = tid; k2 < T; k2 += PRE_THREADS) s_hist[k2] = 0;
     }
     __syncthreads();
     MgrCam cam;
@@ -1779,11 +1789,11 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
             MGR_PROF("k_inst_fwd", stream);
             const bool mixed = canon->skin_w && canon->n_art < N;
 #define MGR_IF_LAUNCH(MX, HF)                                                                                           \
-    hipLaunchKernelGGL((k_inst_fwd<MX, HF>), grid, dim3(PRE_THREADS), 128 + hist_bytes, stream, N, canon->B, canon->n_art, W, H, \
+    hipLaunchKernelGGL((k_inst_fwd<MX, HF>), dim3(8 * ((grid.x + 7) / 8) * V), dim3(PRE_THREADS), 128 + hist_bytes, stream, N, canon->B, canon->n_art, W, H, \
                        gx, gy, cams, canon->xyz, canon->log_scale, canon->rot, canon->op_logit, canon->f_dc,            \
                        canon->f_rest, canon->skin_w, canon->transforms, (MgrGRec*)(ws + L.grec),                        \
                        (float*)(ws + L.depth), (ushort4*)(ws + L.rect), (unsigned long long*)(ws + L.alive),            \
-                       (uint32_t*)(ws + L.pair_off), tile_count, radii, hdr, lds_hist)
+                       (uint32_t*)(ws + L.pair_off), tile_count, radii, hdr, lds_hist, V)
             if (mixed && canon->sh_half) MGR_IF_LAUNCH(true, true);
             else if (mixed) MGR_IF_LAUNCH(true, false);
             else if (canon->sh_half) MGR_IF_LAUNCH(false, true);
