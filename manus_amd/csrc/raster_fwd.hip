@@ -1118,10 +1118,19 @@ __global__ __launch_bounds__(BCNT_THREADS) void k_bin_count(int N, int T, int nb
                                                             const uint32_t* __restrict__ db_order,
                                                             const ushort4* __restrict__ rect,
                                                             const unsigned long long* __restrict__ alive,
-                                                            uint4* __restrict__ db_rec, uint32_t* __restrict__ bin_mat) {
+                                                            uint4* __restrict__ db_rec, uint32_t* __restrict__ bin_mat, int xcd_order) {
     extern __shared__ uint32_t s_mem[];
     uint32_t* s_hist = s_mem;
-    const int v = blockIdx.y, b = blockIdx.x, tid = threadIdx.x;
+    // xcd_order (1-D grid): XCD-aware order for a multiple of 8 views -- the rectangle / mask gathers below are random over
+    // the view's arrays (4.8 MB at 300 k Gaussians, about one XCD's L2): workgroup w runs on XCD w % 8, so XCD x takes
+    // the views x, x + 8, ... and keeps their arrays to itself
+    const int tid = threadIdx.x;
+    int v = blockIdx.y, b = blockIdx.x;
+    if (xcd_order) {
+        const int q = blockIdx.x >> 3;
+        v = (blockIdx.x & 7) + 8 * (q / nblk);
+        b = q % nblk;
+    }
     const ushort4 box = db_bbox[v];
     if (!bin_mine(box, SMALL)) return;
     const uint32_t nvis = db_nvis[v];
@@ -1847,11 +1856,12 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
         MGR_LAUNCH_CHECK("k_dbin_sort", stream, debug);
         const bool big_possible = T > BIN_SMALL_TILES;   // a box of more than BIN_SMALL_TILES tiles can only exist then
         { MGR_PROF("k_bin_count", stream);
-          hipLaunchKernelGGL((k_bin_count<true>), grid_b, dim3(BCNT_THREADS), (size_t)BIN_SMALL_TILES * 4, stream, N, T, nblk, bb, (const uint32_t*)db_nvis,
-                             (const ushort4*)db_bbox, (const uint32_t*)db_order, rect, alive, db_rec, bin_mat);
+          const dim3 grid_c = (V % 8 == 0) ? dim3(nblk * V) : grid_b;   // (XCD-aware order, see the kernel)
+          hipLaunchKernelGGL((k_bin_count<true>), grid_c, dim3(BCNT_THREADS), (size_t)BIN_SMALL_TILES * 4, stream, N, T, nblk, bb, (const uint32_t*)db_nvis,
+                             (const ushort4*)db_bbox, (const uint32_t*)db_order, rect, alive, db_rec, bin_mat, V % 8 == 0 ? 1 : 0);
           if (big_possible)
-              hipLaunchKernelGGL((k_bin_count<false>), grid_b, dim3(BCNT_THREADS), (size_t)T * 4, stream, N, T, nblk, bb, (const uint32_t*)db_nvis,
-                                 (const ushort4*)db_bbox, (const uint32_t*)db_order, rect, alive, db_rec, bin_mat); }
+              hipLaunchKernelGGL((k_bin_count<false>), grid_c, dim3(BCNT_THREADS), (size_t)T * 4, stream, N, T, nblk, bb, (const uint32_t*)db_nvis,
+                                 (const ushort4*)db_bbox, (const uint32_t*)db_order, rect, alive, db_rec, bin_mat, V % 8 == 0 ? 1 : 0); }
         { MGR_PROF("k_bin_scan", stream); hipLaunchKernelGGL(k_bin_scan, dim3((T + BSCAN_COLS - 1) / BSCAN_COLS, V), dim3(BSCAN_COLS * BSCAN_SEGS), 0, stream, gx, T, nblk, bb, (const uint32_t*)db_nvis,
                            (const ushort4*)db_bbox, (const uint32_t*)tile_start, bin_mat); }
         { MGR_PROF("k_bin_scatter", stream);
