@@ -59,9 +59,9 @@ def test_fused_run_to_run_determinism():
     assert abs(float(a["loss"]) - float(b["loss"])) < 1e-6  # the loss scalar is summed with float atomics
 
 
-@pytest.mark.parametrize("views", [1, 5, 8, 11])
+@pytest.mark.parametrize("views", [1, 5, 8, 11, 16])
 def test_fused_equals_modular_view_counts(views):
-    """Lane-group sizes 1, 8 (5 and 8 views) and more than 8 views (two view groups: the second accumulates)."""
+    """Lane-group sizes 1, 8 (5 and 8 views) and more than 8 views (two view groups: the second accumulates; 16 = two full groups, the XCD-aware block orders with more than one view per XCD)."""
     from manus_amd.engine import HipViewCompute
     sc, ct = _scene("hand", n=3000, views=views)
     tg = torch.rand((views, 3, 64, 96), device=DEV)
