@@ -1313,36 +1313,46 @@ __device__ unsigned long long g_binprof[8 * 4096];
 #else
 #define BP(k)
 #endif
+// Two waves per block: wave 0 (producer) reads the instances, scans their pair counts and expands the pair list of
+// batch i + 1 while wave 1 (consumer) hands out the slots of batch i -- the cursors and masks are only ever touched by
+// the consumer, so the order argument is unchanged; the two batches live in the two halves of a double buffer and the
+// waves meet at one workgroup barrier per batch.
+#define BIN_SC_THREADS 128
+#define BIN_SC_FIXED_BYTES (2 * 64 * sizeof(BinRec) + 2 * BIN_PAIR_CAP * 4 + 2 * 64 * 4 + 16)
 template <bool SMALL>
-__global__ __launch_bounds__(64) void k_bin_scatter(int N, int T, int nblk, int bb, const uint32_t* __restrict__ db_nvis,
-                                                    const ushort4* __restrict__ db_bbox,
-                                                    const uint32_t* __restrict__ db_order,
-                                                    const uint4* __restrict__ db_rec,
-                                                    const uint32_t* __restrict__ bin_mat,
-                                                    uint32_t* __restrict__ sorted_gid, uint32_t cap) {
+__global__ __launch_bounds__(BIN_SC_THREADS) void k_bin_scatter(int N, int T, int nblk, int bb, const uint32_t* __restrict__ db_nvis,
+                                                                const ushort4* __restrict__ db_bbox,
+                                                                const uint32_t* __restrict__ db_order,
+                                                                const uint4* __restrict__ db_rec,
+                                                                const uint32_t* __restrict__ bin_mat,
+                                                                uint32_t* __restrict__ sorted_gid, uint32_t cap) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_mem[];
-    BinRec* s_rec = (BinRec*)s_mem;                                     // 64 staged instances (by-instance route)
-    unsigned long long* s_mask = (unsigned long long*)(s_mem + 64 * (sizeof(BinRec) / 4));   // SMALL: lane mask per tile
-    uint32_t* s_pairs = (uint32_t*)(s_mask + (SMALL ? BIN_SMALL_TILES : 0));                  // the batch's pairs: tile | lane << 16
-    uint32_t* s_cur = s_pairs + BIN_PAIR_CAP;                           // cursors of the box's tiles (absolute list slots)
-    const int v = blockIdx.y, b = blockIdx.x, lane = threadIdx.x;
+    BinRec* s_rec = (BinRec*)s_mem;                                     // [2][64] staged instances (by-instance route)
+    unsigned long long* s_mask = (unsigned long long*)(s_mem + 2 * 64 * (sizeof(BinRec) / 4));   // SMALL: lane mask per tile
+    uint32_t* s_pairs = (uint32_t*)(s_mask + (SMALL ? BIN_SMALL_TILES : 0));                      // [2][CAP] pairs: tile | lane << 16
+    uint32_t* s_gid = s_pairs + 2 * BIN_PAIR_CAP;                       // [2][64] Gaussians of the batch
+    uint32_t* s_info = s_gid + 2 * 64;                                  // [2] pairs of the batch, or ~0: by-instance route
+    uint32_t* s_cur = s_info + 4;                                       // cursors of the box's tiles (absolute list slots)
+    const int v = blockIdx.y, b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const ushort4 box = db_bbox[v];
     if (!bin_mine(box, SMALL)) return;
     const uint32_t nvis = db_nvis[v], p0 = (uint32_t)b * (uint32_t)bb;
     if (p0 >= nvis) return;
     const uint32_t p1 = min(p0 + (uint32_t)bb, nvis);
     const int bw = box.z;
-    BinRec nxt = bin_load(N, v, p0 + lane, nvis, box, db_order, db_rec);
+    const int nbatch = (int)((p1 - p0 + 63u) / 64u);
+    BinRec nxt = {0u, 0u, 0u, 0u, 0u, 0u};
+    if (wave == 0) nxt = bin_load(N, v, p0 + lane, nvis, box, db_order, db_rec);
     {
         const int TB = (int)box.z * (int)box.w;
         const uint32_t* row = bin_mat + ((size_t)v * nblk + b) * T;
-        int k = lane;
-        for (; k + 192 < TB; k += 256) {   // four loads in flight
-            const uint32_t a0 = row[k], a1 = row[k + 64], a2 = row[k + 128], a3 = row[k + 192];
-            s_cur[k] = a0; s_cur[k + 64] = a1; s_cur[k + 128] = a2; s_cur[k + 192] = a3;
+        int k = tid;
+        for (; k + 3 * BIN_SC_THREADS < TB; k += 4 * BIN_SC_THREADS) {   // four loads in flight
+            const uint32_t a0 = row[k], a1 = row[k + BIN_SC_THREADS], a2 = row[k + 2 * BIN_SC_THREADS], a3 = row[k + 3 * BIN_SC_THREADS];
+            s_cur[k] = a0; s_cur[k + BIN_SC_THREADS] = a1; s_cur[k + 2 * BIN_SC_THREADS] = a2; s_cur[k + 3 * BIN_SC_THREADS] = a3;
         }
-        for (; k < TB; k += 64) s_cur[k] = row[k];
-        if (SMALL) for (k = lane; k < TB; k += 64) s_mask[k] = 0ull;
+        for (; k < TB; k += BIN_SC_THREADS) s_cur[k] = row[k];
+        if (SMALL) for (k = tid; k < TB; k += BIN_SC_THREADS) s_mask[k] = 0ull;
     }
     const unsigned long long lt = (1ull << lane) - 1ull;
 #ifdef BIN_PROF
@@ -1351,112 +1361,128 @@ __global__ __launch_bounds__(64) void k_bin_scatter(int N, int T, int nblk, int 
     long long tp_ = t00_;
 #endif
 #pragma unroll 1
-    for (uint32_t base = p0; base < p1; base += 64) {
-        const BinRec r = nxt;
-        BP(0)
-        if (base + 64 < p1) nxt = bin_load(N, v, base + 64 + lane, nvis, box, db_order, db_rec);   // in flight during this batch
-        const unsigned long long am = ((unsigned long long)r.ahi << 32) | r.alo;
-        const bool big = r.tiles > 64u;
-        const uint32_t cnt = (r.tiles == 0u || big) ? 0u : (uint32_t)__popcll(am);
-        uint32_t incl = cnt;   // inclusive wave scan
+    for (int it = 0; it <= nbatch; ++it) {
+        __syncthreads();   // batch it - 1 is expanded (and, the first time, the cursors are loaded); batch it - 2 is consumed
+        BP(5)
+        if (wave == 0) {
+            if (it < nbatch) {   // ---- producer: batch `it` into buffer it & 1
+                const int d = it & 1;
+                const BinRec r = nxt;
+                BP(0)
+                if (it + 1 < nbatch) nxt = bin_load(N, v, p0 + 64u * (uint32_t)(it + 1) + lane, nvis, box, db_order, db_rec);
+                const unsigned long long am = ((unsigned long long)r.ahi << 32) | r.alo;
+                const bool big = r.tiles > 64u;
+                const uint32_t cnt = (r.tiles == 0u || big) ? 0u : (uint32_t)__popcll(am);
+                uint32_t incl = cnt;   // inclusive wave scan
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
-            if (lane >= d) incl += o;
-        }
-        const uint32_t P = (uint32_t)__shfl((int)incl, 63, 64);
-        BP(1)
-        if (__ballot(big) == 0ull && P <= (uint32_t)BIN_PAIR_CAP) {
-            {   // expand: pairs of lane's instance at [incl - cnt, incl), tiles in row-major order of the rectangle
-                uint32_t o = incl - cnt;
-                const uint32_t w = r.wh & 0xFFFFu;
-                const float rw = __frcp_rn((float)max(w, 1u));
-                const int org = bin_y0(r.xy) * bw + bin_x0(r.xy);
-                unsigned long long m = cnt ? am : 0ull;
-                while (m) {
-                    const uint32_t k = (uint32_t)__builtin_ctzll(m);
-                    m &= m - 1ull;
-                    const uint32_t ty = (uint32_t)(((float)k + 0.5f) * rw), tx = k - ty * w;   // k / w, exact for k < 64
-                    s_pairs[o++] = (uint32_t)(org + (int)ty * bw + (int)tx) | ((uint32_t)lane << 16);
+                for (int dd = 1; dd < 64; dd <<= 1) {
+                    const uint32_t o = (uint32_t)__shfl_up((int)incl, dd, 64);
+                    if (lane >= dd) incl += o;
                 }
+                const uint32_t P = (uint32_t)__shfl((int)incl, 63, 64);
+                BP(1)
+                if (__ballot(big) == 0ull && P <= (uint32_t)BIN_PAIR_CAP) {
+                    // expand: pairs of lane's instance at [incl - cnt, incl), tiles in row-major order of the rectangle
+                    uint32_t* pl = s_pairs + d * BIN_PAIR_CAP;
+                    uint32_t o = incl - cnt;
+                    const uint32_t w = r.wh & 0xFFFFu;
+                    const float rw = __frcp_rn((float)max(w, 1u));
+                    const int org = bin_y0(r.xy) * bw + bin_x0(r.xy);
+                    unsigned long long m = cnt ? am : 0ull;
+                    while (m) {
+                        const uint32_t k = (uint32_t)__builtin_ctzll(m);
+                        m &= m - 1ull;
+                        const uint32_t ty = (uint32_t)(((float)k + 0.5f) * rw), tx = k - ty * w;   // k / w, exact for k < 64
+                        pl[o++] = (uint32_t)(org + (int)ty * bw + (int)tx) | ((uint32_t)lane << 16);
+                    }
+                    s_gid[d * 64 + lane] = r.gid;
+                    if (lane == 0) s_info[d] = P;
+                } else {
+                    s_rec[d * 64 + lane] = r;
+                    if (lane == 0) s_info[d] = 0xFFFFFFFFu;
+                }
+                BP(2)
             }
-            __builtin_amdgcn_wave_barrier();
-            BP(2)
-            uint32_t pr_n = lane < P ? s_pairs[lane] : 0u;
-            if (SMALL) {
-                // Lanes of a step on the same tile find each other through the tile's 64-bit lane mask (LDS OR, read back):
-                // the lowest lane adds the group's size to the cursor, the others take its result + their rank in the mask.
-                // The returning add of step c is still in flight while the masks of step c + 1 are built and read.
-                uint32_t first_p = 0u, rank_p = 0u, gid_p = 0u, src_p = 0u;   // step c - 1: add result pending
-                bool valid_p = false;
+        } else if (it >= 1) {   // ---- consumer: batch it - 1 from buffer (it - 1) & 1
+            const int d = (it - 1) & 1;
+            const uint32_t P = s_info[d];
+            if (P != 0xFFFFFFFFu) {
+                const uint32_t* pl = s_pairs + d * BIN_PAIR_CAP;
+                const uint32_t* gl = s_gid + d * 64;
+                uint32_t pr_n = lane < P ? pl[lane] : 0u;
+                if (SMALL) {
+                    // Lanes of a step on the same tile find each other through the tile's 64-bit lane mask (LDS OR, read back):
+                    // the lowest lane adds the group's size to the cursor, the others take its result + their rank in the mask.
+                    // The returning add of step c is still in flight while the masks of step c + 1 are built and read.
+                    uint32_t first_p = 0u, rank_p = 0u, gid_p = 0u, src_p = 0u;   // step c - 1: add result pending
+                    bool valid_p = false;
 #pragma unroll 1
-                for (uint32_t c = 0; c < P + 64; c += 64) {
-                    const bool valid = c + lane < P;
-                    const uint32_t pr = pr_n;
-                    if (c + 64 < P) pr_n = (c + 64 + lane < P) ? s_pairs[c + 64 + lane] : 0u;   // next step's pairs
-                    const uint32_t t = pr & 0xFFFFu;
-                    if (valid) atomicOr(&s_mask[t], 1ull << lane);
-                    __builtin_amdgcn_wave_barrier();
-                    const unsigned long long mm = valid ? *(volatile unsigned long long*)&s_mask[t] : (1ull << lane);
-                    const uint32_t rank = (uint32_t)__popcll(mm & lt);
-                    const bool leader = valid && rank == 0u;
-                    uint32_t first = 0u;
-                    if (leader) {
-                        first = atomicAdd(&s_cur[t], (uint32_t)__popcll(mm));
-                        s_mask[t] = 0ull;
+                    for (uint32_t c = 0; c < P + 64; c += 64) {
+                        const bool valid = c + lane < P;
+                        const uint32_t pr = pr_n;
+                        if (c + 64 < P) pr_n = (c + 64 + lane < P) ? pl[c + 64 + lane] : 0u;   // next step's pairs
+                        const uint32_t t = pr & 0xFFFFu;
+                        if (valid) atomicOr(&s_mask[t], 1ull << lane);
+                        __builtin_amdgcn_wave_barrier();
+                        const unsigned long long mm = valid ? *(volatile unsigned long long*)&s_mask[t] : (1ull << lane);
+                        const uint32_t rank = (uint32_t)__popcll(mm & lt);
+                        const bool leader = valid && rank == 0u;
+                        uint32_t first = 0u;
+                        if (leader) {
+                            first = atomicAdd(&s_cur[t], (uint32_t)__popcll(mm));
+                            s_mask[t] = 0ull;
+                        }
+                        const uint32_t gid = gl[pr >> 16];
+                        // finish step c - 1
+                        if (c > 0) {
+                            const uint32_t f = (uint32_t)__shfl((int)first_p, (int)src_p, 64);
+                            const uint32_t pos = f + rank_p;
+                            if (valid_p && pos < cap) sorted_gid[pos] = gid_p;
+                        }
+                        first_p = first; rank_p = rank; gid_p = gid; valid_p = valid;
+                        src_p = (uint32_t)__builtin_ctzll(mm);
                     }
-                    const uint32_t gid = (uint32_t)__shfl((int)r.gid, (int)(pr >> 16), 64);
-                    // finish step c - 1
-                    if (c > 0) {
-                        const uint32_t f = (uint32_t)__shfl((int)first_p, (int)src_p, 64);
-                        const uint32_t pos = f + rank_p;
-                        if (valid_p && pos < cap) sorted_gid[pos] = gid_p;
+                } else {
+#pragma unroll 1
+                    for (uint32_t c = 0; c < P; c += 64) {
+                        const bool valid = c + lane < P;
+                        const uint32_t pr = pr_n;
+                        if (c + 64 < P) pr_n = (c + 64 + lane < P) ? pl[c + 64 + lane] : 0u;   // next step's pairs
+                        const uint32_t t = pr & 0xFFFFu;
+                        uint32_t pos = 0u, cend = 1u;
+                        if (valid) {
+                            pos = atomicAdd(&s_cur[t], 1u);
+                            cend = *(volatile uint32_t*)&s_cur[t];   // after the adds of every lane of this step (LDS: in order)
+                        }
+                        const uint32_t gid = gl[pr >> 16];
+                        unsigned long long todo = __ballot(valid && cend - pos > 1u);
+                        while (todo) {   // wave-uniform: one tile with several lanes per turn
+                            const int first = __builtin_ctzll(todo);
+                            const uint32_t tstar = (uint32_t)__builtin_amdgcn_readlane((int)t, first);
+                            const bool in = valid && t == tstar;
+                            const unsigned long long grp = __ballot(in);
+                            if (in) pos = cend - (uint32_t)__popcll(grp) + (uint32_t)__popcll(grp & lt);
+                            todo &= ~grp;
+                        }
+                        if (valid && pos < cap) sorted_gid[pos] = gid;
                     }
-                    first_p = first; rank_p = rank; gid_p = gid; valid_p = valid;
-                    src_p = (uint32_t)__builtin_ctzll(mm);
                 }
+                BP(3)
             } else {
-#pragma unroll 1
-            for (uint32_t c = 0; c < P; c += 64) {
-                const bool valid = c + lane < P;
-                const uint32_t pr = pr_n;
-                if (c + 64 < P) pr_n = (c + 64 + lane < P) ? s_pairs[c + 64 + lane] : 0u;   // next step's pairs
-                const uint32_t t = pr & 0xFFFFu;
-                uint32_t pos = 0u, cend = 1u;
-                if (valid) {
-                    pos = atomicAdd(&s_cur[t], 1u);
-                    cend = *(volatile uint32_t*)&s_cur[t];   // after the adds of every lane of this step (LDS: in order)
-                }
-                const uint32_t gid = (uint32_t)__shfl((int)r.gid, (int)(pr >> 16), 64);
-                unsigned long long todo = __ballot(valid && cend - pos > 1u);
-                while (todo) {   // wave-uniform: one tile with several lanes per turn
-                    const int first = __builtin_ctzll(todo);
-                    const uint32_t tstar = (uint32_t)__builtin_amdgcn_readlane((int)t, first);
-                    const bool in = valid && t == tstar;
-                    const unsigned long long grp = __ballot(in);
-                    if (in) pos = cend - (uint32_t)__popcll(grp) + (uint32_t)__popcll(grp & lt);
-                    todo &= ~grp;
-                }
-                if (valid && pos < cap) sorted_gid[pos] = gid;
+                const BinRec r = s_rec[d * 64 + lane];
+                bin_batch_by_instance(r, s_rec + d * 64, s_cur, bw, lane, sorted_gid, cap);
+                BP(4)
             }
-            }
-            BP(3)
-        } else {
-            __builtin_amdgcn_wave_barrier();
-            s_rec[lane] = r;
-            __builtin_amdgcn_wave_barrier();
-            bin_batch_by_instance(r, s_rec, s_cur, bw, lane, sorted_gid, cap);
-            BP(4)
         }
     }
 #ifdef BIN_PROF
     {
         const int wid = blockIdx.y * gridDim.x + blockIdx.x;
-        if (lane == 0 && wid < 4096) {
-            for (int k = 0; k < 5; ++k) g_binprof[wid * 8 + k] = (unsigned long long)acc_[k];
-            g_binprof[wid * 8 + 5] = (unsigned long long)(tp_ - t00_);
-            g_binprof[wid * 8 + 6] = (unsigned long long)t00_;
-            g_binprof[wid * 8 + 7] = (unsigned long long)tp_;
+        if (lane == 0 && wid < 4096) {   // producer: 0 wait for records, 1 scan, 2 expansion; consumer: 3 steps, 4 by instance; 5 barrier waits (producer's)
+            if (wave == 0) { g_binprof[wid * 8 + 0] = acc_[0]; g_binprof[wid * 8 + 1] = acc_[1]; g_binprof[wid * 8 + 2] = acc_[2];
+                             g_binprof[wid * 8 + 5] = (unsigned long long)(tp_ - t00_); g_binprof[wid * 8 + 6] = (unsigned long long)t00_;
+                             g_binprof[wid * 8 + 7] = (unsigned long long)tp_; }
+            else { g_binprof[wid * 8 + 3] = acc_[3]; g_binprof[wid * 8 + 4] = acc_[4]; }
         }
     }
 #endif
@@ -1828,7 +1854,7 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
     // depth-ordered binning unless the tile grid does not fit the LDS cursors (or MGR_BINNING=sorted asks for the per-tile sorts)
     const char* binning_env = getenv("MGR_BINNING");   // read per call: tests flip it between two forwards
     const bool ordered_env = !(binning_env && strcmp(binning_env, "sorted") == 0);
-    const bool ordered = ordered_env && lds_hist && T <= 65535 && (size_t)T * 4 + BIN_PAIR_CAP * 4 + 64 * sizeof(BinRec) <= 150 * 1024;
+    const bool ordered = ordered_env && lds_hist && T <= 65535 && (size_t)T * 4 + BIN_SC_FIXED_BYTES <= 150 * 1024;
     if (N > 0 && ordered) {
         const int bb = mgr_bin_block(V, N), nblk = (N + bb - 1) / bb;
         const float* depth = (const float*)(ws + L.depth);
@@ -1845,7 +1871,7 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
         ushort4* db_bbox = (ushort4*)(ws + L.db_bbox);
         const dim3 grid_n((N + 1024 * DB_PER - 1) / (1024 * DB_PER), V), grid_b(nblk, V);
         const int chunk = bb == MGR_BIN_BLOCK ? DB_CHUNK : 1024, chunks = (N + chunk - 1) / chunk;
-        const size_t rec_bytes = 64 * sizeof(BinRec);
+        const size_t rec_bytes = BIN_SC_FIXED_BYTES;
         { MGR_PROF("k_dbin_count", stream); hipLaunchKernelGGL(k_dbin_count, grid_n, dim3(1024), 0, stream, N, (const int32_t*)radii, depth, rect, alive, db_count); }
         { MGR_PROF("k_dbin_scan", stream); hipLaunchKernelGGL(k_dbin_scan, dim3(V), dim3(1024), 0, stream, gx, T, (const uint32_t*)tile_start, db_count, db_cursor,
                            db_start, db_nvis, db_bbox); }
@@ -1865,11 +1891,11 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
         { MGR_PROF("k_bin_scan", stream); hipLaunchKernelGGL(k_bin_scan, dim3((T + BSCAN_COLS - 1) / BSCAN_COLS, V), dim3(BSCAN_COLS * BSCAN_SEGS), 0, stream, gx, T, nblk, bb, (const uint32_t*)db_nvis,
                            (const ushort4*)db_bbox, (const uint32_t*)tile_start, bin_mat); }
         { MGR_PROF("k_bin_scatter", stream);
-          hipLaunchKernelGGL((k_bin_scatter<true>), grid_b, dim3(64), (size_t)BIN_SMALL_TILES * 12 + BIN_PAIR_CAP * 4 + rec_bytes, stream, N, T, nblk, bb,
+          hipLaunchKernelGGL((k_bin_scatter<true>), grid_b, dim3(BIN_SC_THREADS), (size_t)BIN_SMALL_TILES * 12 + rec_bytes, stream, N, T, nblk, bb,
                              (const uint32_t*)db_nvis, (const ushort4*)db_bbox, (const uint32_t*)db_order, (const uint4*)db_rec, (const uint32_t*)bin_mat,
                              (uint32_t*)(ws + L.sorted_gid), (uint32_t)cap);
           if (big_possible)
-              hipLaunchKernelGGL((k_bin_scatter<false>), grid_b, dim3(64), (size_t)T * 4 + BIN_PAIR_CAP * 4 + rec_bytes, stream, N, T, nblk, bb,
+              hipLaunchKernelGGL((k_bin_scatter<false>), grid_b, dim3(BIN_SC_THREADS), (size_t)T * 4 + rec_bytes, stream, N, T, nblk, bb,
                                  (const uint32_t*)db_nvis, (const ushort4*)db_bbox, (const uint32_t*)db_order, (const uint4*)db_rec, (const uint32_t*)bin_mat,
                                  (uint32_t*)(ws + L.sorted_gid), (uint32_t)cap); }
         MGR_LAUNCH_CHECK("k_bin_scatter", stream, debug);
