@@ -19,6 +19,6 @@ for it in range(3):
     a = np.array(list(out), dtype=np.float64).reshape(4096, 8)[:2344]
     a = a[a[:, 5] > 0]
     t0 = a[:, 6].min()
-    print("waves", len(a), "ticks (100 MHz) mean per phase [wait nxt, prefetch+scan, expand, steps, by-instance]:", a[:, :5].mean(0).round(1).tolist(),
+    print("waves", len(a), "ticks (100 MHz) mean per phase [producer: wait for records, scan, expansion; consumer: ranked steps, by-instance]:", a[:, :5].mean(0).round(1).tolist(),
           "loop total", a[:, 5].mean().round(1), "start min/mean/max", (a[:, 6] - t0).min(), (a[:, 6] - t0).mean().round(0), (a[:, 6] - t0).max(),
           "end max", (a[:, 7] - t0).max())
