@@ -11,7 +11,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmanus_hip.so")
+_VARIANT = os.environ.get("MANUS_HIP_VARIANT", "")   # instrumented builds (tools/instr), never set in production
+LIB_PATH = os.path.join(_HERE, "libmanus_hip%s.so" % ("_" + _VARIANT if _VARIANT else ""))
 _LIB = None
 
 MGR_CAM_FLOATS = 40

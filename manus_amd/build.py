@@ -13,7 +13,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["raster_fwd.hip", "raster_bwd.hip", "lbs_sh.hip", "knn.hip", "image_loss.hip", "optim.hip", "contact.hip"]
 HEADERS = ["mgr_common.h", "instance_math.h", os.path.join("..", "..", "include", "manus_hip.h")]
-LIB = os.path.join(HERE, "libmanus_hip.so")
+# MGR_VARIANT=name builds an instrumented copy (libmanus_hip_<name>.so, objects under build_<name>/) next to the product
+# library; MANUS_HIP_VARIANT=name makes _lib load it (tools/instr only)
+VARIANT = os.environ.get("MGR_VARIANT", "")
+LIB = os.path.join(HERE, "libmanus_hip%s.so" % ("_" + VARIANT if VARIANT else ""))
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = (os.environ.get("MGR_EXTRA_FLAGS", "").split()) + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall",
          "-Wno-unused-function"]
@@ -27,7 +30,7 @@ def _stale(target, deps):
 
 
 def build(force=False, verbose=False):
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build" + ("_" + VARIANT if VARIANT else ""))
     os.makedirs(objdir, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     stamp = os.path.join(objdir, "flags.txt")    # objects built with other flags (MGR_EXTRA_FLAGS) are stale too

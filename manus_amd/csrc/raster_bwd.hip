@@ -24,6 +24,11 @@ __device__ unsigned long long g_stats[16];
 extern "C" int mgr_debug_stats(unsigned long long* dst) {
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stats), sizeof(unsigned long long) * 16);
 }
+__device__ unsigned long long g_bhist[3][65];
+extern "C" int mgr_debug_bhist(unsigned long long* dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_bhist), sizeof(unsigned long long) * 3 * 65);
+}
+#define BH(r, c, v) do { const int c_ = (c); const unsigned long long v_ = (unsigned long long)(v); if (lane == 0) atomicAdd(&g_bhist[r][c_], v_); } while (0)
 #define MGR_STAT(i, v) do { const unsigned long long v_ = (unsigned long long)(v); if (lane == 0) atomicAdd(&g_stats[i], v_); } while (0)
 #else
 #define MGR_STAT(i, v)
@@ -142,6 +147,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
         __syncthreads();  // s_touch cleared
 
         int bx0, by0, bx1, by1;
+#ifdef MGR_STATS
+        BH(0, __popcll(__ballot(last > first)), 1);
+#endif
         if (mgr_quad_bbox(__ballot(last > first), bx0, by0, bx1, by1)) {
             const float X0 = qx0 + (float)bx0, Y0 = qy0 + (float)by0, X1 = qx0 + (float)bx1, Y1 = qy0 + (float)by1;
             const mgr_v2f g0v = {g0, g0}, g1v = {g1, g1}, g2v = {g2, g2};
@@ -182,6 +190,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
                     vb = vb && pbpos <= last;
                     const bool anya = __ballot(va) != 0ull, anyb = __ballot(vb) != 0ull;  // wave-uniform
                     MGR_STAT(2, 1);                                                    // pair iterations
+#ifdef MGR_STATS
+                    BH(1, __popcll(__ballot(last > first)), 1);
+                    BH(2, __popcll(__ballot(va)), 1);
+                    BH(2, __popcll(__ballot(vb)), 1);
+#endif
                     MGR_STAT(3, __popcll(__ballot(va)) + __popcll(__ballot(vb)));      // valid (entry, pixel) evaluations
                     MGR_STAT(4, (anya ? 1 : 0) + (anyb ? 1 : 0));                      // entries with any valid pixel
                     if (!anya && !anyb) continue;

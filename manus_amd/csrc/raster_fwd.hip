@@ -1506,6 +1506,14 @@ struct FwdRec {
     float c;
 };
 
+#ifdef MGR_STATS
+__device__ unsigned long long g_fhist[5][65];
+extern "C" int mgr_debug_fhist(unsigned long long* dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_fhist), sizeof(unsigned long long) * 5 * 65);
+}
+#define FH(r, c, v) do { const int c_ = (c); const unsigned long long v_ = (unsigned long long)(v); if (lane == 0) atomicAdd(&g_fhist[r][c_], v_); } while (0)
+#endif
+
 
 __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, int gy, int VT,
                                                    const float* __restrict__ bg,
@@ -1624,12 +1632,23 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, 
                 gid_n = sg[min(off + 128u + lane, lastidx)];
             }
             const int npair = (cnt + 1) >> 1;
+#ifdef MGR_STATS
+            const int n_act = __popcll(__ballot(!done));
+            FH(0, n_act, 1);
+            FH(4, n_act, cnt);
+            int steps_ = 0;
+#endif
             for (int p = 0; p < npair; ++p) {
                 const float4* pp = (const float4*)(slab + p * MGR_PAIR_FLOATS);
                 const float4 R0 = pp[0], R1 = pp[1], R2 = pp[2], R3 = pp[3], R4 = pp[4];
                 mgr_v2f dx, dy, G, al;
                 bool va, vb;
                 mgr_pair_alpha(R0, R1, R2, fpx2, fpy2, dx, dy, G, al, va, vb);
+#ifdef MGR_STATS
+                ++steps_;
+                FH(3, __popcll(__ballot(va && !done)), 1);
+                FH(3, __popcll(__ballot(vb && !done)), 1);
+#endif
                 {   // entry a
                     const float a = (va && !done) ? al.x : 0.0f;
                     const float testT = Tr * (1.0f - a);
@@ -1662,6 +1681,10 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, 
                 }
                 if (__all(done)) break;
             }
+#ifdef MGR_STATS
+            FH(1, n_act, steps_);
+            if (off >= 2048u) FH(2, n_act, steps_);
+#endif
             // pixel state in front of the next chunk (prefix colour + transmittance): lets the
             // backward pass process every MGR_CHUNK-entry chunk of the list independently
             const uint32_t nextpos = off + 64u;

@@ -281,6 +281,10 @@ class HipViewCompute:
         self.is_hand = self.n_art > 0
         self.device = self.params["_xyz"].device
         self.grad_arena = None   # set by ViewShardedStep: preallocated gradient outputs (fused path only)
+        # sync_check True: every fused forward reads the pair count back and retries on overflow (like the drop-in
+        # operator).  A Trainer sets it False on ITS compute object: no host sync, the forward leaves an overflow fence
+        # that Trainer._run_step polls.  (The device-wide policy of rasterizer.set_sync_policy is left alone.)
+        self.sync_check = True
         self._cache = {}
         self.grid = ops.SkinGrid(scene["grid"], scene["grid"].device) if self.is_hand else None
 
@@ -438,7 +442,7 @@ class HipViewCompute:
         def launch(ws):
             fwd(ws, 2 if overlap else 0)
 
-        ws, _ = self.rz.context(dev).forward(V, N, W, H, launch)
+        ws, _ = self.rz.context(dev).forward(V, N, W, H, launch, sync_check=self.sync_check)
         try:
             if overlap:
                 import ctypes
@@ -564,13 +568,18 @@ class Trainer:
         self.compute, self.n_views, self.extent, self.bg_white = compute, n_views, float(extent), bg_white
         self.rank, self.world, self.group = rank, world_size, group
         self.opt = GaussianOptimizer(compute.params, opts=opts, spatial_lr_scale=spatial_lr_scale, adopt=True)
+        # A composite scene (hand + object in one launch) has no density control in the reference: composite.py has no
+        # on_after_backward / density_update and its training_step is `pass` (composite.py:80-81); the two models are
+        # densified by their own modules.  The Trainer therefore only renders, reduces and takes the Adam step there --
+        # decided here, before any state exists, and independent of `opts` (densify_from_step etc. are ignored).
+        self.density_enabled = getattr(compute, "kind", "hand") != "composite"
         kind = kind or ("object" if getattr(compute, "kind", "hand") == "object" else "hand")
         self.density = DensityController(self.opt, extent, kind=kind, bg_white=bg_white)
         self.global_step = 0
         self.retries = 0
         self._rz = rasterizer
-        if getattr(compute, "fused", False) and torch.cuda.is_available():
-            rasterizer.set_sync_policy(False, getattr(compute, "device", None))
+        if getattr(compute, "fused", False) and hasattr(compute, "sync_check"):
+            compute.sync_check = False      # this trainer's forwards are fenced and polled in _run_step (no global policy flip)
         self._rebuild_step()
 
     def _rebuild_step(self):
@@ -623,6 +632,19 @@ class Trainer:
         views: optional list of per-view dicts for the pruning tests (default: `compute.prune_views`)."""
         o, gs = self.opt.opts, self.global_step
         out = self._run_step()
+        if not self.density_enabled:     # composite: render + reduce + Adam only (see __init__)
+            self.opt.update_learning_rate(gs)
+            if self.sharded_adam:
+                lo, hi = self.stepper.owned
+                self.opt.step_range(self.stepper._store, lo, hi)
+                self.stepper.all_gather_params(self.opt.pflat)
+            else:
+                self.opt.step(out["grads"])
+            if hasattr(self.compute, "mark_params_changed"):
+                self.compute.mark_params_changed()
+            self.global_step += 1
+            out["changed"] = False
+            return out
         # ---- on_after_backward ----
         needs_tests = self.density.kind == "hand" and (gs < o["remove_seg_end"] or gs % 100 == 0) or \
             self.density.kind == "object" and gs < o["remove_seg_end"]
@@ -672,10 +694,7 @@ class Trainer:
             self.compute.mark_params_changed()
         self.global_step += 1
         if resized:
-            n_art = None
-            if getattr(self.compute, "kind", "hand") == "composite":
-                raise RuntimeError("Trainer: densifying a composite scene is not supported (the reference optimises one model)")
-            self.compute.set_params(self.opt.parameters(), n_art)
+            self.compute.set_params(self.opt.parameters(), None)
             self.opt.p = {k: v.detach() for k, v in self.compute.params.items()}
             if torch.cuda.is_available():
                 self._rz.context(getattr(self.compute, "device", None)).clear()

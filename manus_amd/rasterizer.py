@@ -71,6 +71,7 @@ class RasterContext:
         self.last_ws = None
         self._fences = []        # (workspace, pinned int32[2], event) per unsynchronised forward, oldest first
         self._free_pinned = []
+        self._evicted_overflow = False   # an overflow seen while retiring old fences: raised by the next poll()
 
     # -- pool ---------------------------------------------------------------------------------
     def acquire(self, V, N, W, H, min_cap):
@@ -90,6 +91,7 @@ class RasterContext:
         self.pool.clear()
         self.cap_hint.clear()
         self._fences.clear()
+        self._evicted_overflow = False
         self.last_ws = None
 
     def _learn(self, key, npairs):
@@ -126,7 +128,8 @@ class RasterContext:
         """Asynchronous copy of (pair count, overflow flag) to pinned host memory + an event right behind it: the
         host can later wait for THIS forward only, while the kernels queued after it keep the GPU busy."""
         while len(self._fences) >= self.MAX_FENCES:
-            self._resolve(self._fences.pop(0))
+            _, ovf = self._resolve(self._fences.pop(0))
+            self._evicted_overflow = self._evicted_overflow or bool(ovf)
         pinned = self._free_pinned.pop() if self._free_pinned else torch.empty(2, dtype=torch.int32).pin_memory()
         pinned.copy_(ws.buf[:8].view(torch.int32), non_blocking=True)
         ev = torch.cuda.Event()
@@ -145,7 +148,8 @@ class RasterContext:
         """Wait for the forwards recorded so far (not for what was queued after them) and raise ManusHipError if one
         of them overflowed its pair capacity -- its image and gradients are incomplete; the capacity hint has been
         enlarged, so re-running the step succeeds.  Returns the pair count of the most recent forward."""
-        last, bad = 0, False
+        last, bad = 0, self._evicted_overflow
+        self._evicted_overflow = False
         while self._fences:
             npairs, ovf = self._resolve(self._fences.pop(0))
             last, bad = npairs, bad or bool(ovf)
