@@ -78,7 +78,12 @@ struct MgrHeader {            // first 256 bytes of the workspace
     uint32_t n_groups;        // depth groups produced by k_tile_split for the giant tiles
     uint32_t split_head, group_head;
     uint32_t pad2[56 - 8 - 68 + 64 - 4];
+    // work-queue counters of the backward blend, one per 256-byte line: same-address global atomics are served one
+    // after the other (~11 ns each on this chip, device-wide: 79 000 tickets on one counter were measured to take
+    // 0.9 ms), so a queue that hands out tens of thousands of wave-sized items is spread over MGR_NCTR addresses
+    uint32_t qctr[16 * 64];
 };
+#define MGR_NCTR 16
 
 // 48-byte per-(view,Gaussian) record gathered by the blend kernels
 struct __attribute__((aligned(16))) MgrGRec {
@@ -90,7 +95,7 @@ struct __attribute__((aligned(16))) MgrGRec {
     int32_t pad;
 };
 
-#define MGR_CHUNK 128        // list entries per backward work item / forward checkpoint interval
+#define MGR_CHUNK 64         // list entries per backward work item / forward checkpoint interval (one batch of the blend waves)
 
 struct MgrLayout {
     size_t header, scan_part, grec, depth, rect, alive, pair_off, tile_count, tile_start, tile_cursor, tile_done,
@@ -127,7 +132,7 @@ static inline MgrLayout mgr_layout(int V, int N, int W, int H, int64_t cap) {
     L.tile_done = o;   o += mgr_align(VT * 4);
     L.tile_queue = o;  o += mgr_align(VT * 4);
     L.chunk_start = o; o += mgr_align((VT + 1) * 4);
-    L.items = o;       o += mgr_align((c / MGR_CHUNK + VT + 1) * 8);
+    L.items = o;       o += mgr_align((c / MGR_CHUNK + VT + 1) * 32);   // 32-byte record per (tile, chunk) work item of the backward blend
     L.ckpt = o;        o += mgr_align((c / MGR_CHUNK + 1) * 256 * 16);  // float4 per pixel per checkpoint
     L.keys = o;        o += mgr_align(c * 8);
     L.keys2 = o;       o += mgr_align(c * 8);       // giant tiles: keys regrouped by depth range
@@ -262,6 +267,37 @@ __device__ __forceinline__ float mgr_wave_reduce8(float x0, float x1, float x2, 
 __device__ __forceinline__ float mgr_readlane63(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+
+// ---------------------------------------------------------------------------
+// Interleaved work queue for persistent WAVES.  n_units work units are handed out through MGR_NCTR counters;
+// ticket t of counter c is unit t * MGR_NCTR + c.  A wave starts at its home counter and moves on to the next one
+// when it runs dry, peeking before it pays for an atomic.  `issue` only sends the atomic; `resolve` reads the
+// answer -- in between lies the work that hides its round trip.
+// ---------------------------------------------------------------------------
+struct MgrQueue {
+    uint32_t* ctr;
+    uint32_t n_units;
+    int c, left;
+    __device__ __forceinline__ void init(uint32_t* counters, uint32_t n, int home) {
+        ctr = counters; n_units = n; c = home % MGR_NCTR; left = MGR_NCTR;
+    }
+    __device__ __forceinline__ uint32_t issue(int lane) const {   // raw ticket, valid in lane 0
+        uint32_t t = 0;
+        if (lane == 0) t = atomicAdd(ctr + c * 64, 1u);
+        return t;
+    }
+    __device__ __forceinline__ uint32_t resolve(uint32_t raw, int lane) {   // unit index, or 0xFFFFFFFF when all is handed out
+        uint32_t u = (uint32_t)__builtin_amdgcn_readfirstlane((int)raw) * MGR_NCTR + (uint32_t)c;
+        while (u >= n_units) {
+            if (--left <= 0) return 0xFFFFFFFFu;
+            c = (c + 1) % MGR_NCTR;
+            const uint32_t cur = __hip_atomic_load(ctr + c * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cur * MGR_NCTR + (uint32_t)c >= n_units) { u = 0xFFFFFFFFu; continue; }
+            u = (uint32_t)__builtin_amdgcn_readfirstlane((int)issue(lane)) * MGR_NCTR + (uint32_t)c;
+        }
+        return u;
+    }
+};
 
 __device__ __forceinline__ int mgr_lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 

@@ -34,36 +34,81 @@ extern "C" int mgr_debug_bhist(unsigned long long* dst) {
 #define MGR_STAT(i, v)
 #endif
 
-#define BWD_BATCH MGR_CHUNK
-#define BWD_SW (BWD_BATCH / 64)
+#ifdef BWD_PROF
+// wall_clock64 (100 MHz) per wave and phase of k_blend_bwd: 0 ticket + item record, 1 entry loads + accumulator reset,
+// 2 per-quadrant prologue + box test / compaction, 3 pair loop, 5 flush; 6 items, 7 waves
+__device__ unsigned long long g_bprof[8];
+extern "C" int mgr_debug_bprof(unsigned long long* dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_bprof), sizeof(unsigned long long) * 8);
+}
+#define BP(k) { const long long now_ = wall_clock64(); acc_[k] += now_ - tp_; tp_ = now_; }
+#else
+#define BP(k)
+#endif
 
-// Work item = (tile, chunk of MGR_CHUNK list entries).  The forward pass saved, per pixel, the
+template <int G>
+__device__ __forceinline__ float grp_sum(float x) {  // all lanes of the group receive the total
+    if (G >= 2) x += mgr_dpp<0xb1>(x);   // quad_perm [1,0,3,2]
+    if (G >= 4) x += mgr_dpp<0x4e>(x);   // quad_perm [2,3,0,1]
+    if (G >= 8) x += mgr_dpp<0x141>(x);  // row_half_mirror
+    return x;
+}
+
+// 8 values per lane, 8 lanes per group -> lane k of the group returns the group total of x[k]
+__device__ __forceinline__ float grp8_reduce_scatter(const float x[8], int vl) {
+    const bool b2 = (vl & 4) != 0, b1 = (vl & 2) != 0, b0 = (vl & 1) != 0;
+    float y[4], z[2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) y[k] = (b2 ? x[k + 4] : x[k]) + mgr_dpp<0x141>(b2 ? x[k] : x[k + 4]);  // partner 7 - j
+#pragma unroll
+    for (int k = 0; k < 2; ++k) z[k] = (b1 ? y[k + 2] : y[k]) + mgr_dpp<0x4e>(b1 ? y[k] : y[k + 2]);   // partner j ^ 2
+    return (b0 ? z[1] : z[0]) + mgr_dpp<0xb1>(b0 ? z[0] : z[1]);                                        // partner j ^ 1
+}
+
+
+// Work item = (tile, chunk of MGR_CHUNK = 64 list entries) = one WAVE.  The forward pass saved, per pixel, the
 // prefix colour and transmittance in front of every chunk, so chunks are independent:
 //   T_i        transmittance in front of entry i (forward recurrence from the checkpoint)
 //   w_i        = alpha_i * T_i
 //   suffix_i   = (output pixel) - (prefix colour through i) = everything behind i incl. background
 //   dL/dalpha_i = T_i (c_i . g) - (suffix_i . g) / (1 - alpha_i)
 // which is the upstream back-to-front recurrence rearranged.
-// Persistent workgroups pull items from a queue; wave w owns the 8x8 quadrant (w&1, w>>1).  Like
-// the forward pass each wave walks the chunk on its own: 64 entries per batch, tested against the
-// bounding box of the quadrant's pixels that reach this chunk (mgr_box_dead), survivors compacted
-// pairwise into the wave's LDS slab, two entries per step with packed fp32 math.  The 64 pixels
-// of a wave are reduced with lane-half exchanges + DPP, the 4 waves through LDS in a fixed order,
-// and one 48-byte record per (tile, Gaussian) pair is written, tagged with the call's epoch.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_blend_bwd(
-    int N, int W, int H, int gx, int gy, const uint32_t* __restrict__ tile_start,
-    const uint32_t* __restrict__ sorted_gid, const MgrGRec* __restrict__ grec,
-    const uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ tile_done,
-    const uint32_t* __restrict__ chunk_start, const float4* __restrict__ ckpt,
-    const unsigned long long* __restrict__ items, MgrHeader* hdr, const float* __restrict__ out_color,
-    const float* __restrict__ dL_dpix, uint32_t* __restrict__ pair_tag, float4* __restrict__ pair_grad,
-    uint32_t* __restrict__ inst_tag, uint32_t cap, uint32_t epoch) {
+//
+// Persistent waves pull item records from the queue the forward blend appended.  Lane j holds entry j of the chunk
+// (index, record, pair slot) for the whole item; the wave then visits the four 8x8 quadrants of the tile one after
+// the other (skipping those whose pixels all ended before the chunk): entries are tested against the bounding box of
+// the quadrant's pixels that reach the chunk (mgr_box_dead), survivors compacted pairwise into the wave's LDS slab, and
+// the per-Gaussian sums over the 64 pixels are formed in two phases per group of 4 pair steps (8 entries):
+//   phase 1, lane = pixel: alpha and the sequential transmittance part for two entries per step (packed fp32),
+//            leaving (G dL/dalpha, alpha T) of both entries per pixel in an LDS exchange row;
+//   phase 2, lane = (entry, pixel column): the 8 lanes of an entry each run down their column of the quadrant (dx is
+//            constant along a column: only sum v, sum v dy, sum v dy^2 and the three colour sums are accumulated per
+//            lane), a transposing reduction over the 8 lanes leaves one of the nine sums in each lane, and the lanes add
+//            them to the entry's accumulator row in LDS (same wave, program order: deterministic).
+// After the fourth quadrant lane j applies the per-Gaussian factors and writes ONE 48-byte record per (tile, Gaussian)
+// pair, tagged with the call's epoch.
+//
+// Up to round 2 the four quadrants were four waves of a workgroup that met at three barriers per item, and every
+// pair step reduced its 18 values across the 64 lanes (45 of ~117 VALU instructions).  Measured per wave (-DBWD_PROF):
+// 41 % of the time computing, 25 % waiting for the slowest quadrant, 16 % in the flush, 18 % in the prologue's
+// latency.  Here a wave depends on nobody, the list segment and the records are fetched once per item instead of
+// once per quadrant, and the cross-lane part of the reduction is 8 lanes wide.
+#define BWD_BATCH MGR_CHUNK
+#define BWD_ROW 288   // floats per exchange row: 64 px x (v_a, w_a, v_b, w_b) + 32 so that two rows cover all 64 banks
+#ifndef BWD_WAVES
+#define BWD_WAVES 4
+#endif
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BWD_WAVES, BWD_WAVES))) void k_blend_bwd(
+    int N, int W, int H, int gx, int gy, const uint32_t* __restrict__ sorted_gid, const MgrGRec* __restrict__ grec,
+    const uint32_t* __restrict__ n_contrib, const float4* __restrict__ ckpt, const uint4* __restrict__ items,
+    MgrHeader* hdr, const float* __restrict__ out_color, const float* __restrict__ dL_dpix,
+    uint32_t* __restrict__ pair_tag, float4* __restrict__ pair_grad, uint32_t* __restrict__ inst_tag, uint32_t cap,
+    uint32_t epoch) {
     __shared__ __align__(16) float s_pair[4][32][MGR_PAIR_FLOATS];
-    __shared__ int32_t s_slot[BWD_BATCH];
-    __shared__ uint32_t s_gid[BWD_BATCH];
-    __shared__ uint32_t s_touch[BWD_BATCH];
+    __shared__ __align__(16) float s_xch[4][4 * BWD_ROW];
     __shared__ float s_acc[4][BWD_BATCH][9];
-    __shared__ uint32_t s_item;
+    __shared__ uint32_t s_flag[4][BWD_BATCH];
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int T = gx * gy;
@@ -72,115 +117,122 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     const size_t P = (size_t)W * H;
     const unsigned long long lt = (1ull << lane) - 1ull;
     float* const slab = &s_pair[wave][0][0];
+    float* const xch = &s_xch[wave][0];
+    float* const acc = &s_acc[wave][0][0];
+    uint32_t* const flag = &s_flag[wave][0];
+    const int e2 = lane >> 3, pc = lane & 7;   // phase-2 role: entry slot of the group (exchange row e2 >> 1, half e2 & 1), pixel column
+#ifdef BWD_PROF
+    long long acc_[6] = {0, 0, 0, 0, 0, 0}, tp_ = wall_clock64(), nit_ = 0;
+#endif
 
-    for (;;) {
-        __syncthreads();  // previous item fully flushed
-        if (tid == 0) s_item = atomicAdd(&hdr->item_head, 1u);
-        __syncthreads();
-        const uint32_t item = s_item;
-        if (item >= n_items) break;
-        const unsigned long long it = items[item];
-        const uint32_t vt = (uint32_t)(it >> 32), chunk = (uint32_t)it;
+    MgrQueue queue;
+    queue.init(hdr->qctr, n_items, (int)blockIdx.x);
+    uint32_t item = queue.resolve(queue.issue(lane), lane);
+    while (item != 0xFFFFFFFFu) {
+        const uint32_t next_raw = queue.issue(lane);   // the next ticket's round trip hides behind this item
+        const uint4 recA = items[2 * (size_t)item], recB = items[2 * (size_t)item + 1];
+        const uint32_t vt = recA.x, chunk = recA.y;
+        const uint32_t mxq[4] = {recB.x, recB.y, recB.z, recB.w};
         const int v = (int)(vt / (uint32_t)T), t = (int)(vt % (uint32_t)T);
         const int bx = t % gx, by = t / gx;
-        const uint32_t nproc = tile_done[vt];
-        const uint32_t start = min(tile_start[vt], cap);
         const uint32_t first = chunk * BWD_BATCH;             // list position of the chunk's first entry
-        const int cnt = (int)min((uint32_t)BWD_BATCH, nproc - first);
-        const int px = bx * 16 + (wave & 1) * 8 + (lane & 7);
-        const int py = by * 16 + (wave >> 1) * 8 + (lane >> 3);
-        const bool inside = px < W && py < H;
-        const mgr_v2f fpx2 = {(float)px, (float)px}, fpy2 = {(float)py, (float)py};
-        const float qx0 = (float)(bx * 16 + (wave & 1) * 8), qy0 = (float)(by * 16 + (wave >> 1) * 8);
+        const uint32_t tmax = max(max(mxq[0], mxq[1]), max(mxq[2], mxq[3]));
+        const int cnt = (int)min((uint32_t)BWD_BATCH, tmax - first);
         const MgrGRec* const gv = grec + (size_t)v * N;
-
-        // Every load of the item prologue is unconditional (indices clamped into range, results masked
-        // afterwards): predicated loads make hipcc drain the memory queue region by region, which
-        // serialises four dependent round trips per item.
-        // this wave's two 64-entry batches: index and record of entry j = bi*64 + lane
-        // (the record of the second batch is fetched when the first one has been processed: holding both
-        // across the pair loop spilled registers at 5 waves per SIMD)
-        float4 ra, rb;
-        float rc;
-        uint32_t gid[BWD_SW];
-#pragma unroll
-        for (int bi = 0; bi < BWD_SW; ++bi) gid[bi] = sorted_gid[start + first + (uint32_t)min(bi * 64 + lane, cnt - 1)];
+#ifdef BWD_PROF
+        ++nit_;
+#endif
+        BP(0);
+        // lane j: entry j of the chunk (clamped index: the loads are unconditional, the results masked)
+        const uint32_t gid = sorted_gid[recA.z + (uint32_t)min(lane, cnt - 1)];
+        float4 ra, rb, rcz;   // (x, y, conic A, B | conic C, opacity, colour r, g | colour b, slot base, rect width, -)
         {
-            const MgrGRec* r = gv + gid[0];
+            const MgrGRec* r = gv + gid;
             ra = *(const float4*)r;
             rb = *((const float4*)r + 1);
-            rc = (*((const float4*)r + 2)).x;
+            rcz = *((const float4*)r + 2);
         }
-        if (wave < BWD_SW) {  // wave bi records the pair slot of entry j = bi*64 + lane for the flush
-            const int j = wave * 64 + lane;
-            const float4 c = *((const float4*)(gv + (wave ? gid[1] : gid[0])) + 2);
-            if (j < cnt) {
-                s_slot[j] = __float_as_int(c.y) + by * __float_as_int(c.z) + bx;
-                s_gid[j] = wave ? gid[1] : gid[0];
-            }
-            s_touch[j] = 0;
-        }
-        // per-pixel state in front of the chunk
-        float Tr = 1.0f, pg = 0.f, Og = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f;
-        uint32_t last = 0;
-        {
-            const size_t pixc = (size_t)min(py, H - 1) * W + min(px, W - 1);
-            const uint32_t nc = n_contrib[(size_t)v * P + pixc];
-            const float* gp = dL_dpix + (size_t)v * 3 * P + pixc;
-            const float* op = out_color + (size_t)v * 3 * P + pixc;
-            const float t0 = gp[0], t1 = gp[P], t2 = gp[2 * P];
-            const float o0 = op[0], o1 = op[P], o2 = op[2 * P];
-            const float4 ck = ckpt[(size_t)(chunk_start[vt] + (chunk > 0 ? chunk - 1 : 0)) * 256 + ((wave << 6) | lane)];
-            last = inside ? nc : 0u;
-            if (last > first) {
-                g0 = t0; g1 = t1; g2 = t2;
-                Og = o0 * g0 + o1 * g1 + o2 * g2;
-                if (chunk > 0) {
-                    Tr = ck.w;
-                    pg = ck.x * g0 + ck.y * g1 + ck.z * g2;
-                }
-            }
-        }
-        uint32_t wlast = last;  // deepest contributor of this wave's quadrant
+        // accumulator rows of the 64 entries
 #pragma unroll
-        for (int d = 32; d > 0; d >>= 1) wlast = max(wlast, (uint32_t)__shfl_xor((int)wlast, d, 64));
-        __syncthreads();  // s_touch cleared
+        for (int k = 0; k < 9; ++k) acc[k * 64 + lane] = 0.f;
+        flag[lane] = 0u;
+        const int32_t slot = __float_as_int(rcz.y) + by * __float_as_int(rcz.z) + bx;
+        const float qmax_e = mgr_qmax(rb.y);
+        BP(1);
 
-        int bx0, by0, bx1, by1;
-#ifdef MGR_STATS
-        BH(0, __popcll(__ballot(last > first)), 1);
-#endif
-        if (mgr_quad_bbox(__ballot(last > first), bx0, by0, bx1, by1)) {
-            const float X0 = qx0 + (float)bx0, Y0 = qy0 + (float)by0, X1 = qx0 + (float)bx1, Y1 = qy0 + (float)by1;
-            const mgr_v2f g0v = {g0, g0}, g1v = {g1, g1}, g2v = {g2, g2};
 #pragma unroll 1
-            for (int bi = 0; bi < BWD_SW; ++bi) {
-                const int j = bi * 64 + lane;
-                if (bi) {
-                    const MgrGRec* r = gv + gid[1];
-                    ra = *(const float4*)r;
-                    rb = *((const float4*)r + 1);
-                    rc = (*((const float4*)r + 2)).x;
+        for (int quad = 0; quad < 4; ++quad) {
+            if (mxq[quad] <= first) continue;   // (wave-uniform) no pixel of this quadrant reaches the chunk
+            const int px = bx * 16 + (quad & 1) * 8 + (lane & 7);
+            const int py = by * 16 + (quad >> 1) * 8 + (lane >> 3);
+            const bool inside = px < W && py < H;
+            const mgr_v2f fpx2 = {(float)px, (float)px}, fpy2 = {(float)py, (float)py};
+            const float qx0 = (float)(bx * 16 + (quad & 1) * 8), qy0 = (float)(by * 16 + (quad >> 1) * 8);
+            // per-pixel state in front of the chunk
+            float Tr = 1.0f, pg = 0.f, Og = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f;
+            uint32_t last = 0;
+            {
+                const size_t pixc = (size_t)min(py, H - 1) * W + min(px, W - 1);
+                const uint32_t nc = n_contrib[(size_t)v * P + pixc];
+                const float* gp = dL_dpix + (size_t)v * 3 * P + pixc;
+                const float* op = out_color + (size_t)v * 3 * P + pixc;
+                const float t0 = gp[0], t1 = gp[P], t2 = gp[2 * P];
+                const float o0 = op[0], o1 = op[P], o2 = op[2 * P];
+                const float4 ck = ckpt[(size_t)recA.w * 256 + ((quad << 6) | lane)];
+                last = inside ? nc : 0u;
+                if (last > first) {
+                    g0 = t0; g1 = t1; g2 = t2;
+                    Og = o0 * g0 + o1 * g1 + o2 * g2;
+                    if (chunk > 0) {
+                        Tr = ck.w;
+                        pg = ck.x * g0 + ck.y * g1 + ck.z * g2;
+                    }
                 }
-                const float4 a4 = ra, b4 = rb;
-                const float c1 = rc;
-                bool alive = false;
-                if (j < cnt && first + (uint32_t)j < wlast)  // later entries are deeper than every pixel's last
-                    alive = !mgr_box_dead(a4.x, a4.y, a4.z, a4.w, b4.x, mgr_qmax(b4.y), X0, Y0, X1, Y1);
-                const unsigned long long m = __ballot(alive);
-                const int na = __popcll(m);
-                MGR_STAT(0, __popcll(__ballot(j < cnt)));   // (entry, wave) box tests
-                MGR_STAT(1, na);                              // survivors
-                if (alive) {
-                    const int rank = __popcll(m & lt);
-                    float* pb = slab + (rank >> 1) * MGR_PAIR_FLOATS;
-                    mgr_pair_store(pb, rank & 1, a4.x, a4.y, a4.z, a4.w, b4.x, b4.y, b4.z, b4.w, c1,
-                                   first + (uint32_t)j + 1u);  // 1-based list position
-                    if ((na & 1) && rank == na - 1) mgr_pair_pad(pb);
+            }
+            uint32_t wlast = last;  // deepest contributor of this quadrant
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) wlast = max(wlast, (uint32_t)__shfl_xor((int)wlast, d, 64));
+            int bx0, by0, bx1, by1;
+            if (!mgr_quad_bbox(__ballot(last > first), bx0, by0, bx1, by1)) continue;
+            // dL/dpixel of this lane's phase-2 column (pixels (pc, 0..7) of the quadrant), through the exchange buffer
+            float gr0[8], gr1[8], gr2[8];
+            {
+                float4* const sg = (float4*)xch;
+                sg[lane] = make_float4(g0, g1, g2, 0.f);
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float4 t4 = sg[i * 8 + pc];
+                    gr0[i] = t4.x; gr1[i] = t4.y; gr2[i] = t4.z;
                 }
-                const int npair = (na + 1) >> 1;
-                for (int p = 0; p < npair; ++p) {
-                    const float4* pp = (const float4*)(slab + p * MGR_PAIR_FLOATS);
+                __builtin_amdgcn_wave_barrier();
+            }
+            const float fx_col = qx0 + (float)pc;
+            const mgr_v2f g0v = {g0, g0}, g1v = {g1, g1}, g2v = {g2, g2};
+            bool alive = false;
+            if (lane < cnt && first + (uint32_t)lane < wlast)  // later entries are deeper than every pixel's last
+                alive = !mgr_box_dead(ra.x, ra.y, ra.z, ra.w, rb.x, qmax_e, qx0 + (float)bx0, qy0 + (float)by0,
+                                      qx0 + (float)bx1, qy0 + (float)by1);
+            const unsigned long long m = __ballot(alive);
+            const int na = __popcll(m);
+            MGR_STAT(0, __popcll(__ballot(lane < cnt)));   // (entry, quadrant) box tests
+            MGR_STAT(1, na);                                 // survivors
+            if (alive) {
+                const int rank = __popcll(m & lt);
+                float* pb = slab + (rank >> 1) * MGR_PAIR_FLOATS;
+                mgr_pair_store(pb, rank & 1, ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w, rcz.x,
+                               first + (uint32_t)lane + 1u);  // 1-based list position
+                if ((na & 1) && rank == na - 1) mgr_pair_pad(pb);
+            }
+            const int npair = (na + 1) >> 1;
+            BP(2);
+#pragma unroll 1
+            for (int p0 = 0; p0 < npair; p0 += 4) {
+                const int np = min(4, npair - p0);
+                uint32_t tmask = 0;   // bit 2r + h: entry h of exchange row r is valid at some pixel
+                // ---- phase 1: lane = pixel ----
+                for (int r = 0; r < np; ++r) {
+                    const float4* pp = (const float4*)(slab + (p0 + r) * MGR_PAIR_FLOATS);
                     const float4 R0 = pp[0], R1 = pp[1], R2 = pp[2], R3 = pp[3], R4 = pp[4];
                     mgr_v2f dx, dy, G, al;
                     bool va, vb;
@@ -190,28 +242,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
                     vb = vb && pbpos <= last;
                     const bool anya = __ballot(va) != 0ull, anyb = __ballot(vb) != 0ull;  // wave-uniform
                     MGR_STAT(2, 1);                                                    // pair iterations
-#ifdef MGR_STATS
-                    BH(1, __popcll(__ballot(last > first)), 1);
-                    BH(2, __popcll(__ballot(va)), 1);
-                    BH(2, __popcll(__ballot(vb)), 1);
-#endif
                     MGR_STAT(3, __popcll(__ballot(va)) + __popcll(__ballot(vb)));      // valid (entry, pixel) evaluations
                     MGR_STAT(4, (anya ? 1 : 0) + (anyb ? 1 : 0));                      // entries with any valid pixel
                     if (!anya && !anyb) continue;
                     MGR_STAT(5, 1);                                                    // pair iterations doing the full math
-#ifdef MGR_STATS
-                    {
-                        const unsigned long long ba = __ballot(va), bb = __ballot(vb);
-                        int blk = 0, strip = 0;
-                        const unsigned long long mk[4] = {0x0F0F0F0Full, 0xF0F0F0F0ull, 0x0F0F0F0F00000000ull, 0xF0F0F0F000000000ull};
-                        for (int q = 0; q < 4; ++q) {
-                            blk += ((ba & mk[q]) != 0) + ((bb & mk[q]) != 0);
-                            strip += (((ba >> (16 * q)) & 0xFFFFull) != 0) + (((bb >> (16 * q)) & 0xFFFFull) != 0);
-                        }
-                        MGR_STAT(6, blk);
-                        MGR_STAT(7, strip);
-                    }
-#endif
+                    tmask |= ((anya ? 1u : 0u) | (anyb ? 2u : 0u)) << (2 * r);
                     const mgr_v2f cr = {R3.x, R3.y}, cgn = {R3.z, R3.w}, cb = {R4.x, R4.y};
                     const mgr_v2f cg = cr * g0v + cgn * g1v + cb * g2v;
                     mgr_v2f w2, da2;
@@ -235,75 +270,81 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
                         w2.y = w;
                         da2.y = vb ? d : 0.0f;
                     }
-                    // Per pixel only the five moments of q = dL/dG * G are formed; the conic / mean factors that are
-                    // constant per Gaussian are applied once per (tile, Gaussian) record in the flush below:
-                    //   dL/dmean2D.x = -W/2 (A Sx + B Sy),  dL/dmean2D.y = -H/2 (C Sy + B Sx),
-                    //   dL/dconic    = -1/2 (Sxx, Sxy, Syy)          
-                    const mgr_v2f o2 = {R2.z, R2.w};
-                    const mgr_v2f v_r = w2 * g0v, v_g = w2 * g1v, v_b = w2 * g2v;
-                    const mgr_v2f v_op = G * da2;
-                    const mgr_v2f q = o2 * v_op;
-                    const mgr_v2f qx = q * dx, qy = q * dy;
-                    const mgr_v2f s_xx = qx * dx, s_xy = qx * dy, s_yy = qy * dy;
-                    // slots 0..7 by the two-at-a-time exchange reduction, slot 8 (blue) for both
-                    // entries at once: halves exchanged, then summed inside each 32-lane half
-                    const float w8a = mgr_wave_reduce8(qx.x, qy.x, s_xx.x, s_xy.x, s_yy.x, v_op.x, v_r.x, v_g.x, lane);
-                    const float w8b = mgr_wave_reduce8(qx.y, qy.y, s_xx.y, s_xy.y, s_yy.y, v_op.y, v_r.y, v_g.y, lane);
-                    float ba = v_b.x, bb = v_b.y;
-                    mgr_swap32(ba, bb);
-                    float b9 = ba + bb;              // lanes 0-31: entry a, lanes 32-63: entry b
-                    b9 += mgr_dpp<0xb1>(b9);         // quad_perm [1,0,3,2]
-                    b9 += mgr_dpp<0x4e>(b9);         // quad_perm [2,3,0,1]
-                    b9 += mgr_dpp<0x141>(b9);        // row_half_mirror
-                    b9 += mgr_dpp<0x140>(b9);        // row_mirror
-                    b9 += mgr_dpp<0x142, 0xa>(b9);   // row_bcast:15 -> rows 1,3: totals in lanes 31 / 63
-                    const int ja = (int)(pa - 1u - first), jb = (int)(pbpos - 1u - first);
-                    if (anya) {
-                        if ((lane & 7) == 0) s_acc[wave][ja][MGR_R8_SLOT(lane >> 3)] = w8a;
-                        if (lane == 31) {
-                            s_acc[wave][ja][8] = b9;
-                            atomicOr(&s_touch[ja], 1u << wave);
-                        }
+                    const mgr_v2f v_op = G * da2;   // dL/dopacity share; times the opacity = q = dL/dG G (applied in the flush)
+                    *(float4*)(xch + r * BWD_ROW + lane * 4) = make_float4(v_op.x, w2.x, v_op.y, w2.y);
+                }
+                if (tmask == 0u) continue;
+                __builtin_amdgcn_wave_barrier();
+                // ---- phase 2: lane = (entry e2, pixel column pc) ----
+                // moments of v = G dL/dalpha about the Gaussian's centre; dx is constant along a column
+                {
+                    const int prow = min(p0 + (e2 >> 1), npair - 1), h = e2 & 1;
+                    const float* pbs = slab + prow * MGR_PAIR_FLOATS;
+                    const float xe = pbs[0 + h], ye = pbs[2 + h];
+                    const uint32_t pos = __float_as_uint(pbs[18 + h]);
+                    const float dxc = xe - fx_col, dy0 = ye - qy0;
+                    const float* src = xch + (e2 >> 1) * BWD_ROW + pc * 4 + h * 2;
+                    float A0 = 0.f, A1 = 0.f, A2 = 0.f, sr = 0.f, sgn = 0.f, sb = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float2 vw = *(const float2*)(src + i * 32);
+                        const float dyi = dy0 - (float)i;
+                        const float t1 = vw.x * dyi;
+                        A0 += vw.x;
+                        A1 += t1;
+                        A2 += t1 * dyi;
+                        sr += vw.y * gr0[i];
+                        sgn += vw.y * gr1[i];
+                        sb += vw.y * gr2[i];
                     }
-                    if (anyb) {
-                        if ((lane & 7) == 0) s_acc[wave][jb][MGR_R8_SLOT(lane >> 3)] = w8b;
-                        if (lane == 63) {
-                            s_acc[wave][jb][8] = b9;
-                            atomicOr(&s_touch[jb], 1u << wave);
+                    const float Sx = dxc * A0;
+                    const float x8[8] = {Sx, A1, Sx * dxc, dxc * A1, A2, A0, sr, sgn};
+                    const float tot = grp8_reduce_scatter(x8, pc);
+                    const float b9 = grp_sum<8>(sb);
+                    if ((tmask >> e2) & 1u) {
+                        const int ja = (int)(pos - 1u - first);
+                        __hip_atomic_fetch_add(acc + pc * 64 + ja, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        if (pc == 0) {
+                            __hip_atomic_fetch_add(acc + 8 * 64 + ja, b9, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                            flag[ja] = 1u;
                         }
                     }
                 }
+                __builtin_amdgcn_wave_barrier();
             }
+            BP(3);
         }
-        __syncthreads();
-        if (tid < cnt) {
-            const uint32_t fl = s_touch[tid];
-            const int32_t slot = s_slot[tid];
-            if (fl && slot >= 0 && (uint32_t)slot < cap) {
-                float r[9];
+        // ---- flush: lane j = entry j ----
+        __builtin_amdgcn_wave_barrier();
+        if (lane < cnt && flag[lane] != 0u && slot >= 0 && (uint32_t)slot < cap) {
+            float r[9];
 #pragma unroll
-                for (int c = 0; c < 9; ++c) r[c] = 0.f;
+            for (int c = 0; c < 9; ++c) r[c] = acc[c * 64 + lane];
+            // r = [Sx, Sy, Sxx, Sxy, Syy] of v = G dL/dalpha (q = opacity * v), dL/dopacity, dL/dcolour; the per-Gaussian factors:
+            //   dL/dmean2D.x = -W/2 (A Sx + B Sy),  dL/dmean2D.y = -H/2 (C Sy + B Sx),  dL/dconic = -1/2 (Sxx, Sxy, Syy)   (App. A, K7)
 #pragma unroll
-                for (int w = 0; w < 4; ++w)  // fixed wave order: deterministic sum
-                    if (fl & (1u << w)) {
-#pragma unroll
-                        for (int c = 0; c < 9; ++c) r[c] += s_acc[w][tid][c];
-                    }
-                // r = [Sx, Sy, Sxx, Sxy, Syy, dopacity, dr, dg, db]: apply the per-Gaussian factors
-                const MgrGRec* rec = gv + s_gid[tid];
-                const float4 ra4 = *(const float4*)rec;
-                const float cA = ra4.z, cB = ra4.w, cC = (*((const float4*)rec + 1)).x;
-                const float mx = (-0.5f * (float)W) * (cA * r[0] + cB * r[1]);
-                const float my = (-0.5f * (float)H) * (cC * r[1] + cB * r[0]);
-                float4* o = pair_grad + (size_t)slot * 3;
-                o[0] = make_float4(mx, my, -0.5f * r[2], -0.5f * r[3]);
-                o[1] = make_float4(-0.5f * r[4], r[5], r[6], r[7]);
-                o[2] = make_float4(r[8], 0.f, 0.f, 0.f);
-                pair_tag[slot] = epoch;
-                inst_tag[(size_t)v * N + s_gid[tid]] = epoch;  // "this (view, Gaussian) has records": lets the gather skip the rest
-            }
+            for (int c = 0; c < 5; ++c) r[c] *= rb.y;
+            const float cA = ra.z, cB = ra.w, cC = rb.x;
+            const float mx = (-0.5f * (float)W) * (cA * r[0] + cB * r[1]);
+            const float my = (-0.5f * (float)H) * (cC * r[1] + cB * r[0]);
+            float4* o = pair_grad + (size_t)slot * 3;
+            o[0] = make_float4(mx, my, -0.5f * r[2], -0.5f * r[3]);
+            o[1] = make_float4(-0.5f * r[4], r[5], r[6], r[7]);
+            o[2] = make_float4(r[8], 0.f, 0.f, 0.f);
+            pair_tag[slot] = epoch;
+            inst_tag[(size_t)v * N + gid] = epoch;  // "this (view, Gaussian) has records": lets the gather skip the rest
         }
+        __builtin_amdgcn_wave_barrier();
+        BP(5);
+        item = queue.resolve(next_raw, lane);
     }
+#ifdef BWD_PROF
+    if (lane == 0) {
+        for (int k = 0; k < 6; ++k) atomicAdd(&g_bprof[k], (unsigned long long)acc_[k]);
+        atomicAdd(&g_bprof[6], (unsigned long long)nit_);
+        atomicAdd(&g_bprof[7], 1ull);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -360,25 +401,6 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
 //   * nothing is staged through global memory between the phases.
 // `accumulate` adds to the outputs instead of writing them (view groups beyond the first).
 // ---------------------------------------------------------------------------
-template <int G>
-__device__ __forceinline__ float grp_sum(float x) {  // all lanes of the group receive the total
-    if (G >= 2) x += mgr_dpp<0xb1>(x);   // quad_perm [1,0,3,2]
-    if (G >= 4) x += mgr_dpp<0x4e>(x);   // quad_perm [2,3,0,1]
-    if (G >= 8) x += mgr_dpp<0x141>(x);  // row_half_mirror
-    return x;
-}
-
-// 8 values per lane, 8 lanes per group -> lane k of the group returns the group total of x[k]
-__device__ __forceinline__ float grp8_reduce_scatter(const float x[8], int vl) {
-    const bool b2 = (vl & 4) != 0, b1 = (vl & 2) != 0, b0 = (vl & 1) != 0;
-    float y[4], z[2];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) y[k] = (b2 ? x[k + 4] : x[k]) + mgr_dpp<0x141>(b2 ? x[k] : x[k + 4]);  // partner 7 - j
-#pragma unroll
-    for (int k = 0; k < 2; ++k) z[k] = (b1 ? y[k + 2] : y[k]) + mgr_dpp<0x4e>(b1 ? y[k] : y[k + 2]);   // partner j ^ 2
-    return (b0 ? z[1] : z[0]) + mgr_dpp<0xb1>(b0 ? z[0] : z[1]);                                        // partner j ^ 1
-}
-
 // Sum x[0..7] over the group and store them at dst[0..n) (n <= 8).
 template <int G>
 __device__ __forceinline__ void grp_store8(const float x[8], int vl, bool ok, float* __restrict__ dst, int n,
@@ -711,12 +733,10 @@ static int raster_backward_impl(int V, int N, int W, int H, const float* cams, c
     uint32_t epoch = g_epoch.fetch_add(1) + 1;
     if (epoch == 0) epoch = g_epoch.fetch_add(1) + 1;
 
-    MGR_HIP(hipMemsetAsync(&hdr->item_head, 0, 4, stream));
-    { MGR_PROF("k_blend_bwd", stream); hipLaunchKernelGGL(k_blend_bwd, dim3(256 * 5), dim3(256), 0, stream, N, W, H, gx, gy,
-                       (const uint32_t*)(ws + L.tile_start), (const uint32_t*)(ws + L.sorted_gid),
-                       (const MgrGRec*)(ws + L.grec), (const uint32_t*)(ws + L.n_contrib),
-                       (const uint32_t*)(ws + L.tile_done), (const uint32_t*)(ws + L.chunk_start),
-                       (const float4*)(ws + L.ckpt), (const unsigned long long*)(ws + L.items), hdr, out_color,
+    MGR_HIP(hipMemsetAsync(hdr->qctr, 0, sizeof(hdr->qctr), stream));   // queue counters of the blend
+    { MGR_PROF("k_blend_bwd", stream); hipLaunchKernelGGL(k_blend_bwd, dim3(256 * BWD_WAVES), dim3(256), 0, stream, N, W, H, gx, gy,
+                       (const uint32_t*)(ws + L.sorted_gid), (const MgrGRec*)(ws + L.grec), (const uint32_t*)(ws + L.n_contrib),
+                       (const float4*)(ws + L.ckpt), (const uint4*)(ws + L.items), hdr, out_color,
                        dL_dcolor, (uint32_t*)(ws + L.pair_tag), (float4*)(ws + L.pair_grad),
                        (uint32_t*)(ws + L.inst_tag), (uint32_t)cap, epoch); }
     MGR_LAUNCH_CHECK("k_blend_bwd", stream, debug);

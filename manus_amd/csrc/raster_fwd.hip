@@ -1527,10 +1527,10 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, 
                                                    uint32_t* __restrict__ tile_done,
                                                    const uint32_t* __restrict__ chunk_start,
                                                    float4* __restrict__ ckpt,
-                                                   unsigned long long* __restrict__ items, MgrHeader* hdr,
+                                                   uint4* __restrict__ items, MgrHeader* hdr,
                                                    uint32_t cap) {
     __shared__ __align__(16) float s_pair[4][32][MGR_PAIR_FLOATS];
-    __shared__ uint32_t s_max, s_next, s_ibase;
+    __shared__ uint32_t s_qmx[4], s_next, s_ibase;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int T = gx * gy;
     const uint32_t n_busy = hdr->queue_len;
@@ -1579,10 +1579,7 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, 
         // per-tile timeline, half of the tiles of more than 4096 pairs started 50-150 us late that way and one of
         // them ended the kernel.  Long lists draw their ticket when they are done.
         const bool early_ticket = nlist < 2048u;
-        if (tid == 0) {
-            s_max = 0;
-            if (early_ticket) s_next = atomicAdd(&hdr->queue_head2, 1u);
-        }
+        if (tid == 0 && early_ticket) s_next = atomicAdd(&hdr->queue_head2, 1u);
         float Tr = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
         uint32_t last = 0;
 #ifdef MGR_STATS
@@ -1702,13 +1699,14 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, 
             o[P] = C1 + Tr * bg1;
             o[2 * P] = C2 + Tr * bg2;
         }
-        // per-tile depth actually consumed (drives the backward pass)
+        // list depth each quadrant consumed; the tile's maximum drives the backward pass
         uint32_t mx = last;
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
-        if (lane == 0) atomicMax(&s_max, mx);
+        if (lane == 0) s_qmx[wave] = mx;
         __syncthreads();
-        const uint32_t tmax = s_max;
+        const uint4 qmx = make_uint4(s_qmx[0], s_qmx[1], s_qmx[2], s_qmx[3]);
+        const uint32_t tmax = max(max(qmx.x, qmx.y), max(qmx.z, qmx.w));
         const uint32_t nchunks = (tmax + MGR_CHUNK - 1) / MGR_CHUNK;
         if (tid == 0) {
             tile_done[vt] = tmax;
@@ -1717,7 +1715,12 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, 
             s_ibase = nchunks ? atomicAdd(&hdr->n_items, nchunks) : 0u;
         }
         __syncthreads();
-        for (uint32_t c = tid; c < nchunks; c += 256) items[s_ibase + c] = ((unsigned long long)vt << 32) | c;
+        // 32-byte record per (tile, chunk): (tile, chunk, list offset of the chunk's first entry, checkpoint in front of
+        // the chunk | entries consumed by each quadrant) -- everything the item's prologue needs in one load
+        for (uint32_t c = tid; c < nchunks; c += 256) {
+            items[2 * (size_t)(s_ibase + c)] = make_uint4(vt, c, start + c * MGR_CHUNK, ck0 + (c > 0 ? c - 1 : 0));
+            items[2 * (size_t)(s_ibase + c) + 1] = qmx;
+        }
 #ifdef MGR_TIMELINE
         if (tid == 0 && item < 8192) {
             g_tl3[item * 4 + 0] = tl_tile0;
@@ -1961,7 +1964,7 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
                        (const uint32_t*)(ws + L.tile_queue), (const uint32_t*)(ws + L.sorted_gid), (const MgrGRec*)(ws + L.grec), out_color,
                        (float*)(ws + L.final_T), (uint32_t*)(ws + L.n_contrib),
                        (uint32_t*)(ws + L.tile_done), (const uint32_t*)(ws + L.chunk_start),
-                       (float4*)(ws + L.ckpt), (unsigned long long*)(ws + L.items), hdr, (uint32_t)cap); }
+                       (float4*)(ws + L.ckpt), (uint4*)(ws + L.items), hdr, (uint32_t)cap); }
     MGR_LAUNCH_CHECK("k_blend_fwd", stream, debug);
     return MGR_OK;
 }
