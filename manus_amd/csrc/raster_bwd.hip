@@ -160,9 +160,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BWD_WAVES, 
         const float qmax_e = mgr_qmax(rb.y);
         BP(1);
 
+        // quadrants with a pixel that reaches the chunk (wave-uniform); the per-pixel state of the next one is fetched
+        // while the current one is processed
+        uint32_t qmask = (mxq[0] > first ? 1u : 0u) | (mxq[1] > first ? 2u : 0u) | (mxq[2] > first ? 4u : 0u) | (mxq[3] > first ? 8u : 0u);
+        struct PxState {
+            uint32_t nc;
+            float t0, t1, t2, o0, o1, o2;
+            float4 ck;
+        };
+        auto load_px = [&](int quad, PxState& q) {
+            const int px = bx * 16 + (quad & 1) * 8 + (lane & 7);
+            const int py = by * 16 + (quad >> 1) * 8 + (lane >> 3);
+            const size_t pixc = (size_t)min(py, H - 1) * W + min(px, W - 1);
+            q.nc = n_contrib[(size_t)v * P + pixc];
+            const float* gp = dL_dpix + (size_t)v * 3 * P + pixc;
+            const float* op = out_color + (size_t)v * 3 * P + pixc;
+            q.t0 = gp[0]; q.t1 = gp[P]; q.t2 = gp[2 * P];
+            q.o0 = op[0]; q.o1 = op[P]; q.o2 = op[2 * P];
+            q.ck = ckpt[(size_t)recA.w * 256 + ((quad << 6) | lane)];
+        };
+        PxState pxn;
+        load_px(qmask ? __builtin_ctz(qmask) : 0, pxn);
 #pragma unroll 1
-        for (int quad = 0; quad < 4; ++quad) {
-            if (mxq[quad] <= first) continue;   // (wave-uniform) no pixel of this quadrant reaches the chunk
+        while (qmask) {
+            const int quad = __builtin_ctz(qmask);
+            qmask &= qmask - 1u;
+            const PxState pxs = pxn;
+            load_px(qmask ? __builtin_ctz(qmask) : quad, pxn);   // (the last quadrant re-reads its own: harmless, never waited for)
             const int px = bx * 16 + (quad & 1) * 8 + (lane & 7);
             const int py = by * 16 + (quad >> 1) * 8 + (lane >> 3);
             const bool inside = px < W && py < H;
@@ -172,20 +196,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BWD_WAVES, 
             float Tr = 1.0f, pg = 0.f, Og = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f;
             uint32_t last = 0;
             {
-                const size_t pixc = (size_t)min(py, H - 1) * W + min(px, W - 1);
-                const uint32_t nc = n_contrib[(size_t)v * P + pixc];
-                const float* gp = dL_dpix + (size_t)v * 3 * P + pixc;
-                const float* op = out_color + (size_t)v * 3 * P + pixc;
-                const float t0 = gp[0], t1 = gp[P], t2 = gp[2 * P];
-                const float o0 = op[0], o1 = op[P], o2 = op[2 * P];
-                const float4 ck = ckpt[(size_t)recA.w * 256 + ((quad << 6) | lane)];
-                last = inside ? nc : 0u;
+                last = inside ? pxs.nc : 0u;
                 if (last > first) {
-                    g0 = t0; g1 = t1; g2 = t2;
-                    Og = o0 * g0 + o1 * g1 + o2 * g2;
+                    g0 = pxs.t0; g1 = pxs.t1; g2 = pxs.t2;
+                    Og = pxs.o0 * g0 + pxs.o1 * g1 + pxs.o2 * g2;
                     if (chunk > 0) {
-                        Tr = ck.w;
-                        pg = ck.x * g0 + ck.y * g1 + ck.z * g2;
+                        Tr = pxs.ck.w;
+                        pg = pxs.ck.x * g0 + pxs.ck.y * g1 + pxs.ck.z * g2;
                     }
                 }
             }
