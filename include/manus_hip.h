@@ -186,6 +186,14 @@ int mgr_raster_debug_binning_sync(const void* workspace, int V, int N, int W, in
                                   int64_t pair_capacity, int view, int32_t* tile_ranges_host,
                                   int32_t* point_list_host, int64_t max_pairs, void* stream);
 
+/* Debug/test: the blend kernels' own evaluation of alpha for n (Gaussian record, pixel) pairs -- the device function
+ * both blend kernels call, exp through v_exp_f32 in the log2 domain.  rec (n,6) = pixel centre x, y, conic A, B, C,
+ * opacity; px, py (n) pixel coordinates; out: alpha (n) and valid (n) = 1 when the pair passes the kernels' tests
+ * (power <= 0 and alpha >= 1/255).  Lets a parity test decide which side of the threshold the
+ * kernels took for pairs that sit within rounding of it.  All pointers are device pointers. */
+int mgr_debug_pair_alpha(int n, const float* rec, const int32_t* px, const int32_t* py, float* alpha, int32_t* valid,
+                         void* stream);
+
 /* ------------------------------------------------------------------------
  * Articulation: skin weights, LBS of means + covariances, SH colour
  * ------------------------------------------------------------------------ */

@@ -441,18 +441,24 @@ __device__ __forceinline__ void mgr_pair_pad(float* pb) {
     for (int f = 0; f < 10; ++f) pb[2 * f + 1] = 0.0f;
 }
 
-// alpha of two entries at one pixel; pw = log2 of the Gaussian falloff (valid entries have pw <= 0)
+// alpha of two entries at one pixel; pw = log2 of the Gaussian falloff (valid entries have pw <= 0).
+// The keep / skip decisions (pw <= 0, alpha >= 1/255) must come out the same in every kernel that inlines this -- the
+// forward blend, the backward blend, the debug entry a parity test asks for the device's decision -- so the exponent is
+// written with explicit fused multiply-adds and contraction is off: left to the compiler, dx*t + u*dy may become
+// fma(dx, t, u*dy) in one kernel and fma(u, dy, dx*t) in another (observed: the debug kernel and the blend disagreed
+// on a pair whose alpha equals 1/255 to eight digits).
 __device__ __forceinline__ void mgr_pair_alpha(const float4 R0, const float4 R1, const float4 R2, mgr_v2f fpx2,
                                                mgr_v2f fpy2, mgr_v2f& dx, mgr_v2f& dy, mgr_v2f& G, mgr_v2f& al,
                                                bool& va, bool& vb) {
+#pragma clang fp contract(off)
     const mgr_v2f x2 = {R0.x, R0.y}, y2 = {R0.z, R0.w}, A2 = {R1.x, R1.y}, B2 = {R1.z, R1.w}, C2 = {R2.x, R2.y},
                   o2 = {R2.z, R2.w};
     dx = x2 - fpx2;
     dy = y2 - fpy2;
     mgr_v2f t = A2 * dx;
-    t = B2 * dy + t;
+    t = __builtin_elementwise_fma(B2, dy, t);
     const mgr_v2f u = C2 * dy;
-    const mgr_v2f pw = dx * t + u * dy;
+    const mgr_v2f pw = __builtin_elementwise_fma(dx, t, u * dy);
     G.x = __builtin_amdgcn_exp2f(fminf(pw.x, 0.0f));
     G.y = __builtin_amdgcn_exp2f(fminf(pw.y, 0.0f));
     al = o2 * G;

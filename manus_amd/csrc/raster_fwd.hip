@@ -2012,6 +2012,34 @@ extern "C" int mgr_raster_layout(int V, int N, int W, int H, int64_t cap, size_t
     return n;
 }
 
+__global__ void k_debug_pair_alpha(int n, const float* __restrict__ rec, const int32_t* __restrict__ px,
+                                   const int32_t* __restrict__ py, float* __restrict__ alpha, int32_t* __restrict__ valid) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float pb[MGR_PAIR_FLOATS];
+    const float* r = rec + (size_t)i * 6;
+    mgr_pair_store(pb, 0, r[0], r[1], r[2], r[3], r[4], r[5], 0.f, 0.f, 0.f, 1u);   // the staging the blend kernels use
+    mgr_pair_pad(pb);
+    const float4 R0 = make_float4(pb[0], pb[1], pb[2], pb[3]), R1 = make_float4(pb[4], pb[5], pb[6], pb[7]),
+                 R2 = make_float4(pb[8], pb[9], pb[10], pb[11]);
+    const mgr_v2f fpx2 = {(float)px[i], (float)px[i]}, fpy2 = {(float)py[i], (float)py[i]};
+    mgr_v2f dx, dy, G, al;
+    bool va, vb;
+    mgr_pair_alpha(R0, R1, R2, fpx2, fpy2, dx, dy, G, al, va, vb);
+    alpha[i] = al.x;
+    valid[i] = va ? 1 : 0;
+}
+
+extern "C" int mgr_debug_pair_alpha(int n, const float* rec, const int32_t* px, const int32_t* py, float* alpha,
+                                    int32_t* valid, void* stream_) {
+    if (n < 0 || (n > 0 && (!rec || !px || !py || !alpha || !valid))) return mgr_fail(MGR_EINVAL, "mgr_debug_pair_alpha: bad arguments");
+    if (n == 0) return MGR_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    hipLaunchKernelGGL(k_debug_pair_alpha, dim3((n + 255) / 256), dim3(256), 0, stream, n, rec, px, py, alpha, valid);
+    MGR_LAUNCH_CHECK("k_debug_pair_alpha", stream, 0);
+    return MGR_OK;
+}
+
 extern "C" int mgr_raster_status_sync(const void* workspace, int64_t* num_pairs, int32_t* overflow,
                                       void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;

@@ -38,6 +38,8 @@ def lib():
             getattr(_LIB, "orc_forward_geom" + sfx).restype = ctypes.c_void_p
             getattr(_LIB, "orc_backward_geom" + sfx).restype = None
             getattr(_LIB, "orc_num_rendered" + sfx).restype = ctypes.c_long
+            getattr(_LIB, "orc_collect_ambiguous" + sfx).restype = ctypes.c_long
+            getattr(_LIB, "orc_reblend_with_overrides" + sfx).restype = None
             for fn in ("orc_free", "orc_get_geom", "orc_get_binning", "orc_get_image_state", "orc_backward"):
                 getattr(_LIB, fn + sfx).restype = None
         _LIB.orc_knn3_mean_dist2.restype = None
@@ -104,6 +106,37 @@ class RasterOracle:
             self._h, _p(g), _p(out["means3D"]), _p(out["means2D"]), _p(out["colors"]),
             _p(out["opacity"]), _p(out["cov3D"]), _p(out["conic"]))
         return out
+
+    # -- test aids for the alpha-threshold flip argument (tests/test_gpu_flips.py) ----------------------------------
+    def ambiguous_pairs(self, eps=1e-4):
+        """(pixel index, Gaussian, alpha) of the pairs the forward walk evaluated with |255 alpha - 1| <= eps."""
+        cap = 1 << 16
+        while True:
+            pix, gid = np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+            al = np.zeros(cap, self.dt)
+            c_real = ctypes.c_float if self.dt == np.float32 else ctypes.c_double
+            n = int(getattr(lib(), "orc_collect_ambiguous" + self.sfx)(self._h, c_real(eps), ctypes.c_long(cap), _p(pix), _p(gid),
+                                                                          _p(al)))
+            if n <= cap:
+                return pix[:n], gid[:n], al[:n]
+            cap = n
+
+    def reblend(self, pix, gid, keep, colors, bg, forced_last=None):
+        """Force the outcome of the alpha >= 1/255 test for the given (pixel, Gaussian) pairs -- and, with `forced_last`
+        (H,W) int, the Gaussian every pixel's walk ends on as its last contributor (-1: none) -- and composite again; `self.color` and the state the
+        backward reads follow the forced decisions.  Returns (pixels whose own T < 1e-4 decision differed, those among
+        them whose test value was not within rounding of the threshold)."""
+        order = np.lexsort((np.asarray(gid), np.asarray(pix)))
+        pix = np.ascontiguousarray(np.asarray(pix, np.int32)[order])
+        gid = np.ascontiguousarray(np.asarray(gid, np.int32)[order])
+        keep = np.ascontiguousarray(np.asarray(keep, np.int32)[order])
+        colors = np.ascontiguousarray(np.asarray(colors, self.dt).reshape(self.N, 3))
+        bg = np.ascontiguousarray(np.asarray(bg, self.dt).reshape(3))
+        fl = None if forced_last is None else np.ascontiguousarray(np.asarray(forced_last, np.int32).reshape(self.H * self.W))
+        sf, sv = ctypes.c_long(0), ctypes.c_long(0)
+        getattr(lib(), "orc_reblend_with_overrides" + self.sfx)(self._h, ctypes.c_int(len(pix)), _p(pix), _p(gid), _p(keep), _p(fl),
+                                                                _p(colors), _p(bg), _p(self.color), ctypes.byref(sf), ctypes.byref(sv))
+        return int(sf.value), int(sv.value)
 
     def close(self):
         if self._h:

@@ -44,7 +44,28 @@ typedef struct FN(OrcState) {
     /* image state */
     REAL *final_T;
     int *n_contrib;
+    /* test aid: forced outcomes of the alpha >= 1/255 test for listed (pixel, Gaussian) pairs, sorted by (pixel, gid);
+     * empty in every parity run that is not closing a threshold-flip argument (orc_set_overrides) */
+    int n_over;
+    int *over_pix, *over_gid, *over_keep;
+    /* test aid: per pixel the Gaussian the walk has to end on as its last contributor (-1 = no contributor; array NULL =
+     * own rule); a pixel whose own T < 1e-4 decision differs is counted in stop_flips, and in stop_violations when its
+     * test value was NOT within rounding of 1e-4 */
+    int* forced_last;
+    long stop_flips, stop_violations;
 } FN(OrcState);
+
+/* -1 = no override for this pair, else 0 (drop) / 1 (keep) */
+static int FN(orc_override)(const FN(OrcState) * s, int pix, int gid) {
+    int lo = 0, hi = s->n_over - 1;
+    while (lo <= hi) {
+        int mid = (lo + hi) / 2;
+        if (s->over_pix[mid] < pix || (s->over_pix[mid] == pix && s->over_gid[mid] < gid)) lo = mid + 1;
+        else if (s->over_pix[mid] == pix && s->over_gid[mid] == gid) return s->over_keep[mid];
+        else hi = mid - 1;
+    }
+    return -1;
+}
 
 static REAL FN(orc_exp)(REAL x) { return (sizeof(REAL) == 4) ? (REAL)expf((float)x) : (REAL)exp((double)x); }
 static REAL FN(orc_sqrt)(REAL x) { return (sizeof(REAL) == 4) ? (REAL)sqrtf((float)x) : (REAL)sqrt((double)x); }
@@ -111,14 +132,16 @@ void FN(orc_free)(FN(OrcState) * s) {
     free(s->means3D); free(s->cov3D); free(s->colors); free(s->xy); free(s->depth);
     free(s->conic_opacity); free(s->radii); free(s->tiles_touched); free(s->rect);
     free(s->pairs); free(s->ranges); free(s->final_T); free(s->n_contrib);
+    free(s->over_pix); free(s->over_gid); free(s->over_keep); free(s->forced_last);
     free(s);
 }
 
 /* K2-K6 from the per-Gaussian 2D state in `s` (xy, depth, conic_opacity, radii, rect, tiles_touched): emit and sort
  * the (tile, depth) pairs, tile ranges, front-to-back compositing.  Shared by orc_forward (state from its own
  * preprocess) and orc_forward_geom (state handed in). */
+static void FN(orc_blend_forward)(FN(OrcState) * s, const REAL* colors, const REAL* bg, REAL* out_color);
 static void FN(orc_bin_and_blend)(FN(OrcState) * s, const REAL* colors, const REAL* bg, REAL* out_color) {
-    const int N = s->N, W = s->W, H = s->H;
+    const int N = s->N;
     /* ---- K2-K5: emit (tile, depth) pairs, sort, tile ranges ----------- */
     long total = 0;
     for (int i = 0; i < N; ++i) total += s->tiles_touched[i];
@@ -144,15 +167,23 @@ static void FN(orc_bin_and_blend)(FN(OrcState) * s, const REAL* colors, const RE
         if (k == total - 1 || s->pairs[k + 1].tile != t) s->ranges[2 * t + 1] = (int)k + 1;
     }
 
-    /* ---- K6: front-to-back alpha compositing -------------------------- */
-    s->final_T = (REAL*)malloc((size_t)W * H * sizeof(REAL));
-    s->n_contrib = (int*)malloc((size_t)W * H * sizeof(int));
+    FN(orc_blend_forward)(s, colors, bg, out_color);
+}
+
+/* ---- K6: front-to-back alpha compositing over the tile ranges in `s` ---- */
+static void FN(orc_blend_forward)(FN(OrcState) * s, const REAL* colors, const REAL* bg, REAL* out_color) {
+    const int W = s->W, H = s->H;
+    if (!s->final_T) s->final_T = (REAL*)malloc((size_t)W * H * sizeof(REAL));
+    if (!s->n_contrib) s->n_contrib = (int*)malloc((size_t)W * H * sizeof(int));
     for (int py = 0; py < H; ++py)
         for (int px = 0; px < W; ++px) {
             int tile = (py / 16) * s->gx + (px / 16);
             int beg = s->ranges[2 * tile], end = s->ranges[2 * tile + 1];
             REAL T = R(1), C[3] = {0, 0, 0};
             int contributor = 0, last = 0;
+            const int forcing = s->forced_last != NULL;
+            const int forced_gid = forcing ? s->forced_last[py * W + px] : -1;
+            int seen_last = forced_gid < 0, flipped = 0;   /* seen_last: the forced last contributor has been composited */
             for (int k = beg; k < end; ++k) {
                 int g = s->pairs[k].gid;
                 ++contributor;
@@ -161,9 +192,26 @@ static void FN(orc_bin_and_blend)(FN(OrcState) * s, const REAL* colors, const RE
                 REAL power = R(-0.5) * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
                 if (power > R(0)) continue;
                 REAL alpha = FN(orc_min)(R(0.99), co[3] * FN(orc_exp)(power));
-                if (alpha < R(1) / R(255)) continue;
+                int keep = alpha >= R(1) / R(255);
+                if (s->n_over) {
+                    int ov = FN(orc_override)(s, py * W + px, g);
+                    if (ov >= 0) keep = ov;
+                }
+                if (!keep) continue;
                 REAL testT = T * (R(1) - alpha);
-                if (testT < R(0.0001)) break;
+                int stop = testT < R(0.0001);
+                if (forcing) {
+                    const int fstop = seen_last;
+                    if (g == forced_gid) seen_last = 1;
+                    if (fstop != stop && !flipped) {
+                        flipped = 1;
+                        ++s->stop_flips;
+                        REAL dev = testT / R(0.0001) - R(1);
+                        if (dev > R(1e-4) || dev < R(-1e-4)) ++s->stop_violations;
+                    }
+                    stop = fstop;
+                }
+                if (stop) break;
                 for (int ch = 0; ch < 3; ++ch) C[ch] += colors[3 * g + ch] * alpha * T;
                 T = testT;
                 last = contributor;
@@ -291,6 +339,67 @@ FN(OrcState) * FN(orc_forward_geom)(int W, int H, int N, const REAL* xy, const R
 
 long FN(orc_num_rendered)(const FN(OrcState) * s) { return s->num_rendered; }
 
+/* ---- test aids for the threshold-flip argument (tests/test_gpu_flips.py) --------------------------------------
+ * The kernels evaluate exp through v_exp_f32 in the log2 domain, this oracle through expf: on bit-identical inputs
+ * the two can disagree on alpha >= 1/255 only for pairs whose alpha lies within rounding of the threshold.
+ * orc_collect_ambiguous lists the (pixel, Gaussian) pairs the forward walk evaluated with |alpha * 255 - 1| <= eps;
+ * orc_reblend_with_overrides forces the outcome of the test for given pairs (sorted by (pixel, gid)) and composites
+ * again -- forward state, image and the following backward then follow the forced decisions.  The same holds for the
+ * second threshold, T (1 - alpha) < 1e-4: with `forced_last` (the kernels' n_contrib) every pixel's walk ends on the
+ * given contributor, and the pixels whose own decision differed are counted -- together with those among them whose
+ * test value was NOT within 1e-4 (relative) of the threshold, which must be none. */
+long FN(orc_collect_ambiguous)(const FN(OrcState) * s, REAL eps, long cap, int* pix_out, int* gid_out, REAL* alpha_out) {
+    const int W = s->W, H = s->H;
+    long n = 0;
+    for (int py = 0; py < H; ++py)
+        for (int px = 0; px < W; ++px) {
+            int tile = (py / 16) * s->gx + (px / 16);
+            int beg = s->ranges[2 * tile], end = s->ranges[2 * tile + 1];
+            REAL T = R(1);
+            for (int k = beg; k < end; ++k) {
+                int g = s->pairs[k].gid;
+                REAL dx = s->xy[2 * g] - R(px), dy = s->xy[2 * g + 1] - R(py);
+                const REAL* co = s->conic_opacity + 4 * g;
+                REAL power = R(-0.5) * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                if (power > R(0)) continue;
+                REAL alpha = FN(orc_min)(R(0.99), co[3] * FN(orc_exp)(power));
+                REAL d = alpha * R(255) - R(1);
+                if (d <= eps && d >= -eps) {
+                    if (n < cap) { pix_out[n] = py * W + px; gid_out[n] = g; alpha_out[n] = alpha; }
+                    ++n;
+                }
+                if (alpha < R(1) / R(255)) continue;
+                REAL testT = T * (R(1) - alpha);
+                if (testT < R(0.0001)) break;
+                T = testT;
+            }
+        }
+    return n;
+}
+
+void FN(orc_reblend_with_overrides)(FN(OrcState) * s, int n, const int* pix, const int* gid, const int* keep,
+                                    const int* forced_last, const REAL* colors, const REAL* bg, REAL* out_color,
+                                    long* stop_flips, long* stop_violations) {
+    free(s->forced_last);
+    s->forced_last = NULL;
+    if (forced_last) {
+        s->forced_last = (int*)malloc((size_t)s->W * s->H * sizeof(int));
+        memcpy(s->forced_last, forced_last, (size_t)s->W * s->H * sizeof(int));
+    }
+    s->stop_flips = s->stop_violations = 0;
+    free(s->over_pix); free(s->over_gid); free(s->over_keep);
+    s->n_over = n;
+    s->over_pix = (int*)malloc((size_t)(n > 0 ? n : 1) * sizeof(int));
+    s->over_gid = (int*)malloc((size_t)(n > 0 ? n : 1) * sizeof(int));
+    s->over_keep = (int*)malloc((size_t)(n > 0 ? n : 1) * sizeof(int));
+    memcpy(s->over_pix, pix, (size_t)n * sizeof(int));
+    memcpy(s->over_gid, gid, (size_t)n * sizeof(int));
+    memcpy(s->over_keep, keep, (size_t)n * sizeof(int));
+    FN(orc_blend_forward)(s, colors, bg, out_color);
+    if (stop_flips) *stop_flips = s->stop_flips;
+    if (stop_violations) *stop_violations = s->stop_violations;
+}
+
 void FN(orc_get_geom)(const FN(OrcState) * s, REAL* xy, REAL* depth, REAL* conic_opacity,
                       int* tiles_touched, int* rect) {
     if (xy) memcpy(xy, s->xy, (size_t)s->N * 2 * sizeof(REAL));
@@ -336,7 +445,12 @@ static void FN(orc_blend_backward)(const FN(OrcState) * s, const REAL* dL_dpix, 
                 if (power > R(0)) continue;
                 REAL G = FN(orc_exp)(power);
                 REAL alpha = FN(orc_min)(R(0.99), co[3] * G);
-                if (alpha < R(1) / R(255)) continue;
+                int keep = alpha >= R(1) / R(255);
+                if (s->n_over) {
+                    int ov = FN(orc_override)(s, py * W + px, gi);
+                    if (ov >= 0) keep = ov;
+                }
+                if (!keep) continue;
                 T = T / (R(1) - alpha);
                 REAL dch = alpha * T, dalpha = 0;
                 for (int ch = 0; ch < 3; ++ch) {

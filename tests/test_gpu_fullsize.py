@@ -1,0 +1,97 @@
+"""GPU: oracle parity at the BASELINE.json sizes (1920x1080), asserted -- not only printed by bench.py.
+
+  config 2  static object, 100 000 Gaussians, 1 view: the drop-in operator path (rasterize_views) against the full
+            scalar rasterizer (projection + binning + blend, forward and backward) on identical rasterizer inputs;
+  config 3  articulated hand, 300 000 Gaussians: the fused path (2 of the 8 views; one oracle view costs ~2 s) against
+            the oracle on identical blend inputs;
+  config 4  hand + object composite, 500 000 Gaussians, 1 view: the same.
+
+Bars: radii / pair count exact, PSNR delta < 0.01 dB, gradient max-rel-err < 1e-4 (north_star); pairs whose alpha sits
+within rounding of the 1/255 threshold are forced to the kernels' outcome on the oracle side (tests/fused_oracle.py)."""
+import ctypes
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from fused_oracle import align_threshold_decisions, assert_north_star, kernel_last_gaussian, layout, run_fused_vs_oracle
+from util import cam_args, cam_table_np, max_rel_err, psnr
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+W, H = 1920, 1080
+
+
+def test_config2_object_100k_operator_path_vs_full_oracle():
+    from manus_amd import rasterizer as rz
+    from manus_amd.rasterizer import rasterize_views
+    from manus_amd.synthetic import make_scene
+    from oracle import RasterOracle
+    from oracle import torch_ref as tr
+    n = 100000
+    sc = make_scene(n_gaussians=n, kind="object", seed=2, n_cameras=1, device="cpu")
+    c = sc["cameras"][0]
+    o = tr.object_forward(sc["params"], torch.tensor(np.asarray(c["camera_center"], np.float32)))
+    m, cov = o["posed_xyz"].detach().numpy(), o["posed_cov"].detach().numpy()
+    col, op = o["colors"].detach().numpy(), o["opacity"].detach().numpy()[:, 0]
+    bg = np.ones(3, np.float32)
+    a = cam_args(c)
+    ro = RasterOracle(a["W"], a["H"], a["tanfovx"], a["tanfovy"], a["view"], a["proj"], m, cov, col, op, bg)
+    # ---- the HIP operator on the same inputs
+    rz.set_sync_policy(True)
+    ct = torch.from_numpy(cam_table_np([c])).to(DEV)
+    tm, tc = torch.tensor(m, device=DEV, requires_grad=True), torch.tensor(cov, device=DEV, requires_grad=True)
+    tcol, top = torch.tensor(col, device=DEV, requires_grad=True), torch.tensor(op, device=DEV, requires_grad=True)
+    m2d = torch.zeros((1, n, 3), device=DEV, requires_grad=True)
+    img, radii = rasterize_views(ct, tm, m2d, tcol, top, tc, torch.tensor(bg, device=DEV), W, H)
+    g = np.random.default_rng(4).normal(size=(1, 3, H, W)).astype(np.float32)
+    img.backward(torch.tensor(g, device=DEV))
+    torch.cuda.synchronize()
+    # integer state: exact
+    np.testing.assert_array_equal(radii[0].cpu().numpy(), ro.radii)
+    assert rz.check_overflow() == ro.num_rendered
+    # ---- threshold flips: the oracle's ambiguous pairs, decided by the device on the KERNEL's records
+    ws = rz.context().last_ws
+    L = layout(1, n, W, H, ws.cap)
+    grec = ws.buf[L["grec"]: L["grec"] + n * 48].view(torch.float32).reshape(n, 12).cpu().numpy()
+    geo = ro.geom()
+    vis = ro.radii > 0
+    assert np.abs(grec[vis, 0:2] - geo["xy"][vis]).max() < 1e-3 and max_rel_err(grec[vis, 2:5], geo["conic_opacity"][vis, :3]) < 1e-5
+    ncontrib = ws.buf[L["n_contrib"]: L["n_contrib"] + W * H * 4].view(torch.int32).reshape(H, W).cpu().numpy()
+    amb, flips, stop_flips, stop_viol = align_threshold_decisions(ro, grec, col, bg, W, kernel_last_gaussian(0, 1, n, W, H, ncontrib))
+    assert stop_viol == 0
+    ob = ro.backward(g[0])
+    im = img[0].detach().cpu().numpy()
+    d = np.abs(im - ro.color)
+    tgt = np.clip(ro.color + 0.05 * np.random.default_rng(1).normal(size=ro.color.shape), 0, 1)
+    assert abs(psnr(im, tgt) - psnr(ro.color, tgt)) < 0.01
+    assert d.mean() < 2e-7 and d.max() < 2e-4, (d.mean(), d.max())
+    errs = {k: max_rel_err(t.grad.cpu().numpy().reshape(ob[k].shape), ob[k]) for k, t in
+            (("means3D", tm), ("cov3D", tc), ("colors", tcol), ("opacity", top))}
+    errs["means2D"] = max_rel_err(m2d.grad[0].cpu().numpy(), ob["means2D"])
+    print("config 2 full size: pairs", ro.num_rendered, "ambiguous", amb, "alpha flips", flips, "stop flips", stop_flips, {k: "%.1e" % e for k, e in errs.items()})
+    for k, e in errs.items():
+        assert e < 1e-4, (k, errs)
+
+
+def test_config3_hand_300k_fused_vs_oracle_identical_blend_inputs():
+    res = run_fused_vs_oracle("hand", 2, 300000, W, H, seed=0, grid_res=128, cam_radius=1.2, sigma_range=(5e-4, 4e-3), n_cameras=8)
+    print("config 3 full size:", {k: (v if not isinstance(v, dict) else {q: "%.1e" % e for q, e in v.items()}) for k, v in res.items()})
+    assert_north_star(res, "config3")
+    assert min(res["num_rendered"]) > 2000000
+    # With the threshold decisions aligned NO leaf row is off by more than 2e-5 of its tensor's scale.  Without the
+    # alignment the same run shows isolated rows at the 1e-3 level (measured: 3 flipped pairs among ~2000 within 2e-4 of
+    # the threshold at this size): every such row owed its deviation to a flipped (pixel, Gaussian) pair.
+    assert max(res["rows_over_2e5"].values()) == 0.0, res["rows_over_2e5"]
+    raw = run_fused_vs_oracle("hand", 2, 300000, W, H, seed=0, grid_res=128, cam_radius=1.2, sigma_range=(5e-4, 4e-3), n_cameras=8,
+                              account_flips=False)
+    print("config 3 without the alignment:", {k: "%.1e" % e for k, e in raw["grads"].items()}, raw["rows_over_2e5"])
+    if max(raw["grads"].values()) > 1e-4 or max(raw["rows_over_2e5"].values()) > 0:
+        assert res["flips"] + res["stop_flips"] > 0
+
+
+def test_config4_composite_500k_fused_vs_oracle_identical_blend_inputs():
+    res = run_fused_vs_oracle("composite", 1, 500000, W, H, seed=0, grid_res=128, cam_radius=1.2, sigma_range=(5e-4, 4e-3), n_cameras=7)
+    print("config 4 full size:", {k: (v if not isinstance(v, dict) else {q: "%.1e" % e for q, e in v.items()}) for k, v in res.items()})
+    assert_north_star(res, "config4")

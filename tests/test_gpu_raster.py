@@ -304,7 +304,7 @@ def test_closeup_deep_tiles_parity():
 def test_baseline_configs_full_size(kind, n, views):
     """BASELINE.json configs 2 (static object, 100k, 1 view), 3 (articulated hand, 300k, 8 views) and 4 (hand+object
     composite, 500k; 53 cameras over 8 ranks = 7 or 6 views per rank) at 1920x1080 through size-independent
-    properties (the scalar oracle would need minutes per view): finite, bit-reproducible, linear in dL/dimage, tile
+    properties (the oracle comparison at these sizes is tests/test_gpu_fullsize.py): finite, bit-reproducible, linear in dL/dimage, tile
     lists sorted by depth and made of valid, visible Gaussians, background where nothing lands, statistics consistent
     with the radii, exactly-zero gradient rows for Gaussians no view sees, and the fused image equal to the modular
     operators' (which are checked against the oracle at sizes it can run)."""
