@@ -43,8 +43,21 @@
  *     (`world_view_transform`, `full_proj_transform`, src/utils/cam_utils.py:58-63:
  *     row-major storage of the transposed matrix == column-major math matrix,
  *     element (row r, col c) at [4*c + r]).
- *   - Launches are asynchronous on `stream`; no hidden streams, no library-owned
- *     device memory.  The only host synchronisation is in the *_sync helpers.
+ *   - Launches are asynchronous on `stream`; the only host synchronisation is in
+ *     the *_sync helpers.  No library-owned device memory.  What the library does
+ *     own, all of it host-side:
+ *       * a process-wide call counter (the epoch that tags gradient records) and
+ *         the profiling switch of mgr_profile_*;
+ *       * per device: the "function attributes set" flag (dynamic LDS above 64 KB
+ *         is requested on the first forward that runs on a device);
+ *       * per (host thread, device), created on first use and only by the per-tile
+ *         sort route of the forward (MGR_BINNING=sorted, or a tile grid too large
+ *         for the depth-ordered route): ONE non-blocking side stream with a fork
+ *         and a join event.  It forks from `stream` and joins it again inside the
+ *         call, so the caller sees plain stream order.  The default route, and every
+ *         other entry point, launches on `stream` only.
+ *     Calls on different devices from different host threads do not share any of
+ *     the per-device state (one process per GPU, or one thread per GPU, both work).
  */
 #ifndef MANUS_HIP_H
 #define MANUS_HIP_H

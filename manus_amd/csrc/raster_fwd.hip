@@ -14,6 +14,8 @@
 //  * per-(view,Gaussian) data the blend kernels gather is one 48-byte record;
 //  * no host synchronisation: the pair count stays on the device, capacity
 //    overflow raises a flag in the workspace header.
+#include <atomic>
+
 #include "instance_math.h"
 
 #include <cstdlib>
@@ -1786,9 +1788,10 @@ struct MgrSideStream {
         return hipEventCreateWithFlags(&join, hipEventDisableTiming);
     }
 };
-static MgrSideStream& mgr_side_stream() {
-    static thread_local MgrSideStream s;
-    return s;
+#define MGR_MAX_DEVICES 64
+static MgrSideStream& mgr_side_stream(int device) {   // one per (host thread, device): streams and events belong to a device
+    static thread_local MgrSideStream s[MGR_MAX_DEVICES];
+    return s[device];
 }
 
 static int raster_forward_impl(int V, int N, int W, int H, const float* cams, const float* bg,
@@ -1817,8 +1820,12 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
     uint32_t* tile_start = (uint32_t*)(ws + L.tile_start);
     const int VT = V * T;
 
-    static bool attr_set = false;
-    if (!attr_set) {
+    // function attributes are per device: set once for each device a forward runs on (first call on that device)
+    static std::atomic<bool> attr_set[MGR_MAX_DEVICES];
+    int device = 0;
+    MGR_HIP(hipGetDevice(&device));
+    if (device < 0 || device >= MGR_MAX_DEVICES) return mgr_fail(MGR_EINVAL, "mgr_raster_forward: device index out of range");
+    if (!attr_set[device].load(std::memory_order_acquire)) {
         MGR_HIP(hipFuncSetAttribute((const void*)k_tile_sort, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     SORT_LDS_KEYS * 8 + RS_WAVES * 256 * 4 + 256));
         MGR_HIP(hipFuncSetAttribute((const void*)k_preprocess, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1833,7 +1840,7 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
                                     SORT_LDS_KEYS * 8 + RS_WAVES * 256 * 4 + 256));
         MGR_HIP(hipFuncSetAttribute((const void*)k_bin_count<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
         MGR_HIP(hipFuncSetAttribute((const void*)k_bin_scatter<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
-        attr_set = true;
+        attr_set[device].store(true, std::memory_order_release);
     }
 
     if (do_bin) {
@@ -1936,7 +1943,7 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
         // The small-tile sort only depends on k_emit; it runs on a side stream next to the
         // giant-tile split (few workgroups, long) and the LDS radix sort (one workgroup per CU),
         // and joins before the blend.
-        MgrSideStream& side = mgr_side_stream();
+        MgrSideStream& side = mgr_side_stream(device);
         MGR_HIP(side.init());
         MGR_HIP(hipEventRecord(side.fork, stream));
         MGR_HIP(hipStreamWaitEvent(side.stream, side.fork, 0));

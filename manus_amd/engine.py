@@ -32,9 +32,29 @@ def flat_size(N):
     return N * (GRAD_WIDTH + 2) + FLAT_TAIL
 
 
-def shard_views(n_views, rank, world_size):
-    """Round-robin assignment of view indices to ranks."""
-    return list(range(rank, n_views, world_size))
+def shard_views(n_views, rank, world_size, weights=None):
+    """View indices of `rank`.  Without weights: round-robin.  With weights (one cost per view, identical on every
+    rank -- e.g. `view_costs` of the measured pair counts): greedy longest-processing-time assignment, the heaviest
+    view first, each to the rank with the smallest load so far (ties: the lowest rank; views of a rank in ascending
+    order), so that a rig whose cameras see the hand at very different sizes does not leave ranks idle (SURVEY.md 8e:
+    "pad or balance by measured R per view")."""
+    if weights is None:
+        return list(range(rank, n_views, world_size))
+    w = [float(x) for x in weights]
+    assert len(w) == n_views
+    load, mine = [0.0] * world_size, [[] for _ in range(world_size)]
+    for v in sorted(range(n_views), key=lambda i: (-w[i], i)):
+        r = min(range(world_size), key=lambda k: (load[k], k))
+        load[r] += w[v]
+        mine[r].append(v)
+    return sorted(mine[rank])
+
+
+def view_costs(pairs_per_view, n_gaussians):
+    """Cost model of one view for `shard_views`: the blend / binning kernels scale with the view's (tile, Gaussian) pairs,
+    the per-instance kernels with N.  Measured on the 300k / 1080p bench (profiles/): 0.16 ms per 2.6 M pairs against
+    0.066 ms per 300k Gaussians, i.e. one Gaussian costs as much as 3.5 pairs."""
+    return [float(p) + 3.5 * float(n_gaussians) for p in pairs_per_view]
 
 
 def flat_views(flat, N):
@@ -95,10 +115,10 @@ class ViewShardedStep:
     """
 
     def __init__(self, n_gaussians, shapes, compute_fn, n_views, rank=0, world_size=1, group=None, compact=False,
-                 scatter=False):
+                 scatter=False, view_weights=None):
         self.N, self.shapes, self.compute_fn = n_gaussians, shapes, compute_fn
         self.n_views, self.rank, self.world, self.group = n_views, rank, world_size, group
-        self.local_views = shard_views(n_views, rank, world_size)
+        self.local_views = shard_views(n_views, rank, world_size, view_weights)
         self.always_pack = False   # tests: take the packing path without a process group
         self.compact = bool(compact)
         self.scatter = bool(scatter) and world_size > 1
@@ -518,6 +538,32 @@ class HipViewCompute:
                     grad2d=(g2 * vis).sum(0), vis=vis.sum(0).float(),
                     radii=radii.max(dim=0).values, loss=loss)
 
+    def pairs_per_view(self, view_ids=None, group=8):
+        """Surviving (tile, Gaussian) pairs of every view (forward only, in groups of `group` views): the weights of the
+        balanced view assignment.  Deterministic, so every rank computes the same list."""
+        import ctypes
+        from ._lib import lib
+        ids = list(range(self.cams.shape[0])) if view_ids is None else list(view_ids)
+        W, H = int(self.s["width"]), int(self.s["height"])
+        T = ((W + 15) // 16) * ((H + 15) // 16)
+        N = self.params["_xyz"].shape[0]
+        out = []
+        keep = self.sync_check
+        self.sync_check = True
+        try:
+            with torch.no_grad():
+                for k in range(0, len(ids), group):
+                    part = ids[k:k + group]
+                    self.forward_views_fused(part)
+                    ws = self.rz.context(self.device).last_ws
+                    arr = (ctypes.c_size_t * 32)()
+                    lib().mgr_raster_layout(len(part), N, W, H, ws.cap, arr, 32)
+                    ts = ws.buf[int(arr[7]): int(arr[7]) + 4 * (len(part) * T + 1)].view(torch.int32)[::T].cpu().tolist()
+                    out += [int(b - a) for a, b in zip(ts[:-1], ts[1:])]
+        finally:
+            self.sync_check = keep
+        return out
+
     # -- inputs of the pruning tests (on_after_backward) ---------------------------------------------
     def prune_views(self, view_ids):
         """One dict per view for `density.DensityController`: camera (K, extr), mask, posed means of the view's
@@ -554,7 +600,7 @@ class Trainer:
     over the ranks; max_radii2D is MAX-reduced before it is consumed."""
 
     def __init__(self, compute, n_views, extent, opts=None, spatial_lr_scale=1.0, rank=0, world_size=1, group=None,
-                 bg_white=True, kind=None, compact_allreduce=False, sharded_adam=False):
+                 bg_white=True, kind=None, compact_allreduce=False, sharded_adam=False, view_weights=None):
         # sharded_adam (world_size > 1): reduce-scatter of the gradients -> every rank takes the Adam step on the 1/world
         # of the parameter elements it owns -> all-gather of the parameters.  The same bytes on the wire as the
         # all-reduce (which is a reduce-scatter followed by an all-gather), 1/world of the optimizer work per rank.
@@ -566,6 +612,7 @@ class Trainer:
         global ALL_GROUPS
         from .optim import ALL_GROUPS
         self.compute, self.n_views, self.extent, self.bg_white = compute, n_views, float(extent), bg_white
+        self.view_weights = view_weights   # per-view costs for the balanced assignment (shard_views); None = round-robin
         self.rank, self.world, self.group = rank, world_size, group
         self.opt = GaussianOptimizer(compute.params, opts=opts, spatial_lr_scale=spatial_lr_scale, adopt=True)
         # A composite scene (hand + object in one launch) has no density control in the reference: composite.py has no
@@ -589,7 +636,7 @@ class Trainer:
         shapes = {k: v.shape for k, v in p.items()}
         self.stepper = ViewShardedStep(p["_xyz"].shape[0], shapes, self.compute, self.n_views, rank=self.rank,
                                        world_size=self.world, group=self.group, compact=self.compact_allreduce,
-                                       scatter=self.sharded_adam)
+                                       scatter=self.sharded_adam, view_weights=self.view_weights)
         if self.sharded_adam:   # leaves and moments as views of flat buffers laid out like the gradient buffer
             self.opt.flatten(self.stepper.padded_g)
             self.compute.set_params(self.opt.parameters())

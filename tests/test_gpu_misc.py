@@ -220,3 +220,45 @@ def test_packed_step_writes_gradients_in_place():
     assert float(out["overflow"]) == 0.0
     raw = hc(st.local_views, 0.5)  # what the kernels themselves return: views of the flat buffer
     assert all(lo <= raw["grads"][n].data_ptr() < hi for n, _ in GRAD_LAYOUT)
+
+
+def test_forward_from_another_host_thread_and_after_device_churn():
+    """include/manus_hip.h "Conventions": the library's own state is host-side and per device / per (thread, device).
+    A forward issued from a second host thread (fresh thread-local side stream; the per-tile sort route is the one that
+    uses it) after set_device churn gives the bit-identical image of the main thread's default route."""
+    import os
+    import threading
+    from manus_amd.rasterizer import rasterize_views
+    from util import cam_table_np, make_camera, random_gaussians
+    cam = make_camera(160, 96)
+    m, c, col, op = random_gaussians(3000, seed=5)
+    ct = torch.from_numpy(cam_table_np([cam])).to(DEV)
+    args = [torch.tensor(x, device=DEV) for x in (m, col, op, c)]
+    bg = torch.ones(3, device=DEV)
+
+    def render():
+        m2d = torch.zeros((1, 3000, 3), device=DEV)
+        with torch.no_grad():
+            img, radii = rasterize_views(ct, args[0], m2d, args[1], args[2], args[3], bg, 160, 96)
+        torch.cuda.synchronize()
+        return img.cpu(), radii.cpu()
+
+    ref = render()
+    out = {}
+
+    def worker():
+        for _ in range(3):
+            torch.cuda.set_device(0)
+        os.environ["MGR_BINNING"] = "sorted"
+        try:
+            with torch.cuda.stream(torch.cuda.Stream(device=DEV)):
+                out["sorted"] = render()
+        finally:
+            os.environ.pop("MGR_BINNING", None)
+        out["ordered"] = render()
+
+    t = threading.Thread(target=worker)
+    t.start()
+    t.join()
+    for k in ("sorted", "ordered"):
+        assert torch.equal(out[k][0], ref[0]) and torch.equal(out[k][1], ref[1]), k

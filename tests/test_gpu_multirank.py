@@ -177,3 +177,23 @@ def test_two_ranks_composite_scene_uneven_view_shards():
     for k, v in ref.opt.p.items():
         d = (torch.from_numpy(params[k]) - v.detach().cpu()).abs().max() / (v.abs().max().cpu() + 1e-12)
         assert float(d) < 1e-3, (k, float(d))
+
+
+def test_bench_runs_under_torch_distributed_run_with_two_ranks():
+    """The driver's multi-GPU command line (python -m torch.distributed.run ... bench.py --gpus N) on a tiny
+    configuration, two ranks sharing this GPU through gloo: it must not die on a Python error and must print one JSON
+    line with the fields the driver reads (the timing itself means nothing here)."""
+    import json
+    import subprocess
+    env = dict(os.environ, MANUS_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--gaussians", "6000", "--views", "5", "--width", "160", "--height", "96", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["headline"] is False
+    assert d["config"]["view_assignment"].startswith("balanced") and d["config"]["allreduce"]["mode"] in ("dense", "compact")
+    assert set(d["config"]["allreduce"]["ms_per_step_by_mode"]) == {"dense", "compact"}

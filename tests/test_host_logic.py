@@ -320,3 +320,23 @@ def test_checkpoint_format_matches_reference_loader(golden_dir, tmp_path):
     for k in leaves:
         np.testing.assert_array_equal(w2[k].numpy(), d["out_" + k])
     assert ck.get_num_gaussians_from_checkpoint(path) == 37
+
+
+def test_balanced_view_assignment_is_a_partition_and_balances_the_load():
+    """shard_views with weights (balance by measured pairs per view): every view goes to exactly one rank,
+    every rank computes the same assignment, and the heaviest rank carries at most the mean load plus one view."""
+    from manus_amd.engine import shard_views, view_costs
+    rng = np.random.default_rng(3)
+    for n_views, world in ((8, 8), (53, 8), (7, 2), (5, 3), (3, 4)):
+        pairs = rng.integers(200000, 5000000, size=n_views)
+        w = view_costs(pairs, 300000)
+        parts = [shard_views(n_views, r, world, w) for r in range(world)]
+        assert sorted(v for p in parts for v in p) == list(range(n_views))
+        loads = [sum(w[v] for v in p) for p in parts]
+        assert max(loads) <= sum(w) / world + max(w) + 1e-6
+        if n_views >= world:
+            assert all(len(p) >= 1 for p in parts)
+        # round-robin (no weights) is unchanged
+        assert shard_views(n_views, 1 % world, world) == list(range(1 % world, n_views, world))
+    # equal weights: as many views per rank as round-robin gives
+    assert sorted(len(shard_views(53, r, 8, [1.0] * 53)) for r in range(8)) == [6, 6, 6, 7, 7, 7, 7, 7]
