@@ -50,19 +50,27 @@ def remove_nans_from_checkpoint(checkpoint):
     return checkpoint
 
 
-def load_checkpoint(ckpt_path, device=torch.device("cpu")):
-    """(weights without the "model." prefix, extra_params) of a MANUS checkpoint (train_utils.py:193-204)."""
-    # tensors + plain containers load under the safe unpickler; a real Lightning checkpoint may carry other pickled
-    # objects (hyper-parameter containers), for which the reference's own behaviour -- full unpickling of a file the
-    # user trained themselves -- is the fallback
+def load_checkpoint(ckpt_path, device=torch.device("cpu"), allow_pickle=False, return_checkpoint=False):
+    """(weights without the "model." prefix, extra_params) of a MANUS checkpoint (train_utils.py:193-204).
+
+    Tensors and plain containers load under torch's safe unpickler.  A real Lightning checkpoint may carry other pickled
+    objects (hyper-parameter containers); the reference unpickles those unconditionally (torch.load of a file the user
+    trained themselves).  Here that is opt-in: allow_pickle=True -- a file the safe loader rejects is exactly the one that
+    can execute code while loading.  return_checkpoint=True also returns the whole dict (optimizer state written by
+    `save_checkpoint(optimizer=...)` sits under "manus_amd_optimizer")."""
     try:
         ckpt = torch.load(ckpt_path, map_location=device, weights_only=True)
-    except Exception:
+    except Exception as e:
+        if not allow_pickle:
+            raise RuntimeError("%s holds pickled objects the safe loader refuses (%s); pass allow_pickle=True if you trust "
+                               "the file" % (ckpt_path, e)) from e
         ckpt = torch.load(ckpt_path, map_location=device, weights_only=False)
     ckpt = remove_nans_from_checkpoint(ckpt)
     weights = ckpt["state_dict"]
     for key in list(weights):
         weights[key.replace("model.", "")] = weights.pop(key)
+    if return_checkpoint:
+        return weights, ckpt.get("extra_params", {}), ckpt
     return weights, ckpt.get("extra_params", {})
 
 
@@ -70,7 +78,7 @@ def get_num_gaussians_from_checkpoint(ckpt_path):
     return load_checkpoint(ckpt_path)[1]["num_gaussians"]
 
 
-def save_checkpoint(ckpt_dir, params, epoch, step, loss, grid=None, mano_weights=None, extra_state=None):
+def save_checkpoint(ckpt_dir, params, epoch, step, loss, grid=None, mano_weights=None, extra_state=None, optimizer=None):
     """Write a checkpoint the reference's `load_checkpoint` / `on_load_checkpoint` read back (train_utils.py:193-204,
     hand_dynamic.py:284-293): epoch, global_step, state_dict, extra_params.  (It is not a full Lightning
     `fit(ckpt_path=...)` resume file: no optimizer_states / loops keys.)  params: the six leaves by attribute name (`_xyz`, ...);
@@ -86,6 +94,10 @@ def save_checkpoint(ckpt_dir, params, epoch, step, loss, grid=None, mano_weights
     elif mano_weights is not None:
         extra["mano_weights"] = mano_weights.detach().cpu()
     ckpt = {"epoch": int(epoch), "global_step": int(step), "state_dict": sd, "extra_params": extra}
+    if optimizer is not None:
+        # what a resume needs beyond the leaves: both Adam moments, the per-group step counts and the densification
+        # statistics (`GaussianOptimizer.state_dict`); a resume without them restarts the moments from zero
+        ckpt["manus_amd_optimizer"] = optimizer.state_dict()
     if extra_state:
         ckpt.update(extra_state)
     os.makedirs(ckpt_dir, exist_ok=True)

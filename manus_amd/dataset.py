@@ -30,17 +30,12 @@ from .cam_utils import get_opengl_camera_attributes, get_scene_extent
 # containers
 # ---------------------------------------------------------------------------------------------------------------------
 class _Node:
-    """A group of a TreeStore: children by name, h5py.Group protocol."""
+    """A group of a TreeStore: children by name, h5py.Group protocol.  `arrays` maps '/'-joined paths to arrays (read
+    lazily from the .npz on first access), `index` maps every group prefix to its sorted child names (built once)."""
 
-    def __init__(self, arrays, prefix):
-        self._a, self._p = arrays, prefix
-        names = []
-        for k in arrays:
-            if k.startswith(prefix):
-                head = k[len(prefix):].split("/", 1)[0]
-                if head not in names:
-                    names.append(head)
-        self._names = sorted(names)  # by name, like h5py's default iteration order
+    def __init__(self, arrays, prefix, index):
+        self._a, self._p, self._idx = arrays, prefix, index
+        self._names = index.get(prefix, [])  # by name, like h5py's default iteration order
 
     def keys(self):
         return list(self._names)
@@ -60,7 +55,7 @@ class _Node:
             return self._a[full]                    # numpy array: `[:]`, `[idx]` behave like an h5py dataset
         if name not in self._names:
             raise KeyError(full)
-        return _Node(self._a, full + "/")
+        return _Node(self._a, full + "/", self._idx)
 
     def get(self, name, default=None):
         return self[name] if name in self._names else default
@@ -75,15 +70,39 @@ class TreeStore(_Node):
     def __init__(self, path, mode="r"):
         if mode != "r":
             raise ValueError("TreeStore is read-only; write with write_tree()")
-        with np.load(path, allow_pickle=False) as z:
-            arrays = {k: z[k] for k in z.files}
-        super().__init__(arrays, "")
+        self._z = np.load(path, allow_pickle=False)     # kept open: members are decompressed when they are indexed
+        index = {}
+        for k in self._z.files:
+            parts = k.split("/")
+            for d in range(len(parts)):
+                index.setdefault("/".join(parts[:d]) + ("/" if d else ""), set()).add(parts[d])
+        index = {pre: sorted(ch) for pre, ch in index.items()}
+        super().__init__(_LazyArrays(self._z), "", index)
+
+    def close(self):
+        self._z.close()
 
     def __enter__(self):
         return self
 
     def __exit__(self, *exc):
-        return False
+        return False     # (stays open: open_sequence caches one store per file)
+
+
+class _LazyArrays:
+    """Mapping view of an NpzFile that loads (and memoises) a member on first access."""
+
+    def __init__(self, z):
+        self._z, self._names, self._cache = z, set(z.files), {}
+
+    def __contains__(self, k):
+        return k in self._names
+
+    def __getitem__(self, k):
+        a = self._cache.get(k)
+        if a is None:
+            a = self._cache[k] = self._z[k]
+        return a
 
 
 def write_tree(path, arrays):
@@ -93,12 +112,19 @@ def write_tree(path, arrays):
         np.savez(f, **arrays)
 
 
+_STORES = {}
+
+
 def open_sequence(path):
     """An action file by content: .npz container -> TreeStore, otherwise HDF5 through h5py (fails loudly without it)."""
     with open(path, "rb") as f:
         magic = f.read(4)
     if magic[:2] == b"PK":
-        return TreeStore(path)
+        key = (os.path.abspath(path), os.path.getmtime(path))
+        st = _STORES.get(key)
+        if st is None:
+            st = _STORES[key] = TreeStore(path)     # one store per action file (the Dataset opens it on every __getitem__)
+        return st
     try:
         import h5py
     except ImportError as e:
@@ -137,38 +163,7 @@ def _index_fields(obj, idx):
     return type(obj)(**{k: (None if v is None else v[idx]) for k, v in obj.__dict__.items()})
 
 
-@dataclass
-class Bones:
-    bnames: np.ndarray
-    heads: np.ndarray
-    tails: np.ndarray
-    transforms: np.ndarray
-    eulers: np.ndarray = None
-    eulers_c: np.ndarray = None
-    root_translation: np.ndarray = None
-    root_rotation: np.ndarray = None
-    kintree: dict = None
-
-    def __getitem__(self, idx):
-        return _index_fields(self, idx)
-
-
-@dataclass
-class Cameras:
-    cam_name: np.ndarray
-    K: np.ndarray
-    extr: np.ndarray
-    fovx: float
-    fovy: float
-    width: int
-    height: int
-    world_view_transform: np.ndarray
-    projection_matrix: np.ndarray
-    full_proj_transform: np.ndarray
-    camera_center: np.ndarray
-
-    def __getitem__(self, idx):
-        return _index_fields(self, idx)
+from .structures import Bones, Cameras  # noqa: E402,F401  (one definition: src/utils/structures.py:7-47)
 
 
 def to_tensor(var, dtype=torch.float32):
@@ -438,6 +433,42 @@ class SequenceDataset(torch.utils.data.Dataset):
             "rest": items[0]["bones_rest"].transforms.to(device),
             "keypoints": torch.stack([torch.cat([it["bones_posed"].heads[:1], it["bones_posed"].tails], 0) for it in items]).to(device),
         }
+
+
+def hand_scene_from_batch(batch, bones_rest, n_gaussians, grid_res=32, seed=0, device="cuda:0", sigma_range=(2e-3, 6e-3)):
+    """The scene dict `engine.HipViewCompute` / `engine.Trainer` consume, from one `SequenceDataset.view_batch` and the
+    capture's rest skeleton (`ds[i]["bones_rest"]`): Gaussians initialised on the bones like `sample_gaussians_on_bones_func`
+    (train_utils.py:104-139), a skin-weight voxel grid with `build_voxel_grid`'s geometry (brics_dynamic.py:99-144; the
+    weights themselves are the synthetic softmax of `synthetic.make_skin_grid`, MANO's nearest-vertex weights are not
+    built here), the per-view bone transforms posed @ inv(rest) + identity (hand_dynamic.py:93-102), the dataset's own
+    targets, masks, cameras and keypoints.  Returns (scene, targets (V,3,H,W))."""
+    import math
+    from . import synthetic as S
+    gen = torch.Generator().manual_seed(seed)
+    heads, tails = bones_rest.heads.cpu().numpy(), bones_rest.tails.cpu().numpy()
+    rest = bones_rest.transforms.cpu().float()
+    per = max(2, int(math.ceil(n_gaussians / 30.0)))
+    xyz = S.sample_on_bones(heads, tails, rest.numpy(), per, gen)
+    xyz = xyz[torch.randperm(xyz.shape[0], generator=gen)[:n_gaussians]]
+    dims, center, scale = S.grid_geometry(heads, tails, res=grid_res)
+    lo, hi = torch.tensor(center - 0.95 * scale), torch.tensor(center + 0.95 * scale)
+    xyz = torch.max(torch.min(xyz, hi), lo).float()
+    N = xyz.shape[0]
+    lo_s, hi_s = math.log(sigma_range[0]), math.log(sigma_range[1])
+    params = {"_xyz": xyz, "_scaling": (torch.rand((N, 3), generator=gen) * (hi_s - lo_s) + lo_s).float(),
+              "_rotation": torch.randn((N, 4), generator=gen), "_opacity": 1.5 * torch.randn((N, 1), generator=gen),
+              "_features_dc": torch.randn((N, 1, 3), generator=gen), "_features_rest": 0.1 * torch.randn((N, 15, 3), generator=gen)}
+    posed = batch["posed"].cpu().float()
+    tf = torch.stack([T.bone_transforms(posed[v], rest) for v in range(posed.shape[0])])
+    cams = [{k: (v.cpu().numpy() if torch.is_tensor(v) else v) for k, v in c.items()} for c in batch["cameras"]]
+    H, W = batch["targets"].shape[-2:]
+    scene = dict(params={k: v.to(device) for k, v in params.items()}, N=N, n_hand=N, kind="hand", grid_dims=dims,
+                 grid=S.make_skin_grid(heads, tails, dims, center, scale, device=device),
+                 grid_center=torch.as_tensor(center).to(device), grid_scale=torch.as_tensor(scale).to(device),
+                 rest=rest.to(device), posed=posed.to(device), transforms=tf.to(device), cameras=cams,
+                 bg=torch.ones(3, device=device), width=int(W), height=int(H), heads=heads, tails=tails,
+                 keypoints=batch["keypoints"].float().to(device), masks=batch["masks"].to(device))
+    return scene, batch["targets"].float().to(device).contiguous()
 
 
 # ---------------------------------------------------------------------------------------------------------------------

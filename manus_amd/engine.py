@@ -229,6 +229,8 @@ def _compact_all_reduce(self, flat, fv):
     at most the number of views, so a byte carries it); (2) the SUM all-reduce of the 60 floats (59 gradients + the
     2D-gradient norm) of the rows that are active on some rank."""
     N = self.N
+    if self.n_views > 255:
+        raise ValueError("compact all-reduce carries the visibility count in one byte: at most 255 views per step (use the dense mode)")
     small = torch.cat([_row_mask(fv, N), fv["vis"].to(torch.uint8)])
     if self.world > 1:
         dist.all_reduce(small, op=dist.ReduceOp.SUM, group=self.group)

@@ -118,6 +118,29 @@ class GaussianOptimizer:
         """The six leaves by the reference's attribute names (live tensors, updated in place by step())."""
         return self.p
 
+    # -- resume -------------------------------------------------------------------------------
+    def state_dict(self):
+        """Everything a resume needs beyond the leaves (CPU tensors): both Adam moments, the per-group step counts, the
+        learning rates and the densification statistics.  (The reference resumes through Lightning, whose checkpoint
+        carries torch.optim.Adam's exp_avg / exp_avg_sq / step per parameter: the same content.)"""
+        c = lambda t: t.detach().cpu().clone()
+        return {"exp_avg": {a: c(t) for a, t in self.m.items()}, "exp_avg_sq": {a: c(t) for a, t in self.v.items()},
+                "group_step": dict(self.group_step), "lr": dict(self.lr),
+                "xyz_gradient_accum": c(self.xyz_gradient_accum), "denom": c(self.denom), "max_radii2D": c(self.max_radii2D)}
+
+    def load_state_dict(self, sd):
+        """Inverse of `state_dict` on an optimizer built over leaves with the same number of rows."""
+        for a in self.m:
+            if tuple(sd["exp_avg"][a].shape) != tuple(self.m[a].shape):
+                raise ValueError("optimizer state of %s has shape %s, the leaf %s" % (a, tuple(sd["exp_avg"][a].shape), tuple(self.m[a].shape)))
+            self.m[a].copy_(sd["exp_avg"][a])
+            self.v[a].copy_(sd["exp_avg_sq"][a])
+        self.group_step = {n: int(t) for n, t in sd["group_step"].items()}
+        self.lr.update(sd["lr"])
+        self.xyz_gradient_accum.copy_(sd["xyz_gradient_accum"])
+        self.denom.copy_(sd["denom"])
+        self.max_radii2D.copy_(sd["max_radii2D"])
+
     # -- update_learning_rate, gaussian_utils.py:501-508 --------------------------------------
     def update_learning_rate(self, global_step):
         self.lr["xyz"] = self.xyz_scheduler_args(global_step)

@@ -34,4 +34,4 @@ class Cameras:
     camera_center: Any
 
     def __getitem__(self, idx):
-        return Cameras(**{k: v[idx] for k, v in self.__dict__.items()})
+        return Cameras(**{k: (v[idx] if v is not None else None) for k, v in self.__dict__.items()})

@@ -340,3 +340,30 @@ def test_balanced_view_assignment_is_a_partition_and_balances_the_load():
         assert shard_views(n_views, 1 % world, world) == list(range(1 % world, n_views, world))
     # equal weights: as many views per rank as round-robin gives
     assert sorted(len(shard_views(53, r, 8, [1.0] * 53)) for r in range(8)) == [6, 6, 6, 7, 7, 7, 7, 7]
+
+
+def test_checkpoint_loader_refuses_pickled_objects_unless_asked(tmp_path):
+    """A file the safe unpickler rejects is the one that can run code while loading: full unpickling is opt-in."""
+    import argparse
+    from manus_amd import checkpoint as ck
+    sd = {"model." + k: torch.zeros(s) for k, s in (("_xyz", (4, 3)), ("_features_dc", (4, 1, 3)), ("_features_rest", (4, 15, 3)),
+                                                    ("_scaling", (4, 3)), ("_rotation", (4, 4)), ("_opacity", (4, 1)))}
+    path = str(tmp_path / "epoch=000-step=1-loss=0.5.ckpt")
+    torch.save({"epoch": 0, "global_step": 1, "state_dict": sd, "extra_params": {"num_gaussians": 4},
+                "hyper_parameters": argparse.Namespace(lr=1.0)}, path)
+    with pytest.raises(RuntimeError, match="allow_pickle"):
+        ck.load_checkpoint(path)
+    w, e = ck.load_checkpoint(path, allow_pickle=True)
+    assert e["num_gaussians"] == 4 and w["_xyz"].shape == (4, 3)
+
+
+def test_sequence_container_is_read_lazily_and_opened_once(golden_dir, tmp_path):
+    import shutil
+    from manus_amd import dataset as D
+    p = str(tmp_path / "grasp_2.npz")
+    shutil.copy(os.path.join(golden_dir, "seq", "grasp_2.npz"), p)
+    a, b = D.open_sequence(p), D.open_sequence(p)
+    assert a is b                                             # one store per action file
+    assert len(a._a._cache) == 0                              # nothing decompressed yet
+    _ = a["frames"]["8"]["metadata"]["rest_matrixs"][:]
+    assert list(a._a._cache) == ["frames/8/metadata/rest_matrixs"]
