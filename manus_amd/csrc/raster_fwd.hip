@@ -1517,6 +1517,18 @@ extern "C" int mgr_debug_fhist(unsigned long long* dst) {
 #endif
 
 
+#ifdef FWD_PROF
+// wall_clock64 (100 MHz) per wave and phase of k_blend_fwd: 0 ticket + tile prologue, 1 box test / compaction (+ waiting for
+// the batch's records), 2 pair loop, 3 checkpoint + loop overhead, 4 waiting for the tile's other quadrants, 5 tile
+// epilogue (image stores, items); 6 tiles, 7 waves
+__device__ unsigned long long g_fprof[8];
+extern "C" int mgr_debug_fprof(unsigned long long* dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_fprof), sizeof(unsigned long long) * 8);
+}
+#define FP(k) { const long long now_ = wall_clock64(); facc_[k] += now_ - ftp_; ftp_ = now_; }
+#else
+#define FP(k)
+#endif
 __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, int gy, int VT,
                                                    const float* __restrict__ bg,
                                                    const uint32_t* __restrict__ tile_start,
@@ -1544,6 +1556,9 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, 
 
 #ifdef MGR_TIMELINE
     unsigned long long tl0 = wall_clock64(), ntl = 0;
+#endif
+#ifdef FWD_PROF
+    long long facc_[6] = {0, 0, 0, 0, 0, 0}, ftp_ = wall_clock64(), fnt_ = 0;
 #endif
     if (tid == 0) s_next = atomicAdd(&hdr->queue_head2, 1u);
     if (blockIdx.x == 0 && tid < 34) {  // consumed by the tile scan: zero for the next forward (no per-call memset)
@@ -1605,6 +1620,11 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, 
             rec.b = *((const float4*)r + 1);
             rec.c = r->b;
         }
+#ifdef FWD_PROF
+        ++fnt_;
+        if (rec.c == 12345.678f) break;   // (forces the first records to be here before the clock is read)
+#endif
+        FP(0);
         for (uint32_t off = 0; off < nlist; off += 64) {
             // bounding box of this quadrant's pixels that are still accumulating
             int bx0, by0, bx1, by1;
@@ -1631,6 +1651,7 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, 
                 gid_n = sg[min(off + 128u + lane, lastidx)];
             }
             const int npair = (cnt + 1) >> 1;
+            FP(1);
 #ifdef MGR_STATS
             const int n_act = __popcll(__ballot(!done));
             FH(0, n_act, 1);
@@ -1684,12 +1705,15 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, 
             FH(1, n_act, steps_);
             if (off >= 2048u) FH(2, n_act, steps_);
 #endif
+            FP(2);
             // pixel state in front of the next chunk (prefix colour + transmittance): lets the
             // backward pass process every MGR_CHUNK-entry chunk of the list independently
             const uint32_t nextpos = off + 64u;
             if ((nextpos % MGR_CHUNK) == 0 && nextpos < nlist)
                 ckpt[(size_t)(ck0 + nextpos / MGR_CHUNK - 1) * 256 + pslot] = make_float4(C0, C1, C2, Tr);
+            FP(3);
         }
+        FP(3);
         if (inside) {
             const size_t pix = (size_t)py * W + px;
             n_contrib[(size_t)v * P + pix] = last;  // (the final transmittance is not needed by the chunk-parallel backward)
@@ -1706,7 +1730,9 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, 
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
         if (lane == 0) s_qmx[wave] = mx;
+        FP(5);
         __syncthreads();
+        FP(4);
         const uint4 qmx = make_uint4(s_qmx[0], s_qmx[1], s_qmx[2], s_qmx[3]);
         const uint32_t tmax = max(max(qmx.x, qmx.y), max(qmx.z, qmx.w));
         const uint32_t nchunks = (tmax + MGR_CHUNK - 1) / MGR_CHUNK;
@@ -1738,7 +1764,15 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, 
         }
 #endif
         item = s_next;
+        FP(5);
     }
+#ifdef FWD_PROF
+    if (lane == 0) {
+        for (int k = 0; k < 6; ++k) atomicAdd(&g_fprof[k], (unsigned long long)facc_[k]);
+        atomicAdd(&g_fprof[6], (unsigned long long)fnt_);
+        atomicAdd(&g_fprof[7], 1ull);
+    }
+#endif
 #ifdef MGR_TIMELINE
     unsigned long long tl1 = wall_clock64();
 #endif

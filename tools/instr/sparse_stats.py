@@ -1,6 +1,6 @@
 """-DMGR_STATS build: how sparse are the blend kernels' steps?  Histograms over the number of pixels of a wave's 8x8
-quadrant that are still active (forward) / reach the chunk (backward), weighted by batches and pair steps, and over the
-number of pixels for which an evaluated list entry is valid."""
+quadrant that are still active in the forward blend, weighted by batches and pair steps, and over the number of pixels for
+which an evaluated list entry is valid."""
 import sys, os, ctypes, torch, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from manus_amd import _lib
@@ -17,9 +17,9 @@ def grab(fn, rows):
     fn(z)
     return np.array(list(z), dtype=np.int64).reshape(rows, 65)
 hc(ids, 1.0 / V); torch.cuda.synchronize()
-f0 = grab(dll.mgr_debug_fhist, 5); b0 = grab(dll.mgr_debug_bhist, 3)
+f0 = grab(dll.mgr_debug_fhist, 5)
 hc(ids, 1.0 / V); torch.cuda.synchronize()
-f = grab(dll.mgr_debug_fhist, 5) - f0; b = grab(dll.mgr_debug_bhist, 3) - b0
+f = grab(dll.mgr_debug_fhist, 5) - f0
 def show(name, h):
     tot = h.sum()
     cum = np.cumsum(h) / max(1, tot)
@@ -30,7 +30,4 @@ show("fwd pair steps by active pixels     ", f[1])
 show("fwd pair steps (pos>=2048) by active", f[2])
 show("fwd evaluated entries by valid px   ", f[3])
 show("fwd survivors by active pixels      ", f[4])
-show("bwd (item,wave) by reaching pixels  ", b[0])
-show("bwd pair iters by reaching pixels   ", b[1])
-show("bwd evaluated entries by valid px   ", b[2])
-np.save("gpurun_out/sparse_fhist.npy", f); np.save("gpurun_out/sparse_bhist.npy", b)
+np.save("gpurun_out/sparse_fhist.npy", f)
