@@ -484,7 +484,7 @@ def main():
             for k, (c, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
                 print("%-20s %6d launches %9.3f ms avg %8.4f ms  %5.1f%%" % (k, c, ms, ms / c, 100 * ms / tot),
                       file=sys.stderr)
-            print("library kernels %.3f ms/iter of %.3f ms/iter wall" % (tot / args.steps, 1e3 * dt / args.steps),
+            print("library kernels %.3f ms/iter of %.3f ms/iter wall" % (tot / (args.steps * REPEATS), 1e3 * dt / args.steps),
                   file=sys.stderr)
         cpu = parity = None
         if not args.no_cpu_baseline and world == 1 and args.kind == "hand" and not args.optimizer and args.sh_storage == "fp32":
