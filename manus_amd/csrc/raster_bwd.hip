@@ -320,9 +320,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BWD_WAVES, 
                     const float b9 = grp_sum<8>(sb);
                     if ((tmask >> e2) & 1u) {
                         const int ja = (int)(pos - 1u - first);
-                        __hip_atomic_fetch_add(acc + pc * 64 + ja, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        __hip_atomic_fetch_add(acc + ja * 9 + pc, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                         if (pc == 0) {
-                            __hip_atomic_fetch_add(acc + 8 * 64 + ja, b9, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                            __hip_atomic_fetch_add(acc + ja * 9 + 8, b9, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                             flag[ja] = 1u;
                         }
                     }
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BWD_WAVES, 
         if (lane < cnt && flag[lane] != 0u && slot >= 0 && (uint32_t)slot < cap) {
             float r[9];
 #pragma unroll
-            for (int c = 0; c < 9; ++c) r[c] = acc[c * 64 + lane];
+            for (int c = 0; c < 9; ++c) r[c] = acc[lane * 9 + c];
             // r = [Sx, Sy, Sxx, Sxy, Syy] of v = G dL/dalpha (q = opacity * v), dL/dopacity, dL/dcolour; the per-Gaussian factors:
             //   dL/dmean2D.x = -W/2 (A Sx + B Sy),  dL/dmean2D.y = -H/2 (C Sy + B Sx),  dL/dconic = -1/2 (Sxx, Sxy, Syy)   (App. A, K7)
 #pragma unroll

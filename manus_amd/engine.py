@@ -115,13 +115,16 @@ class ViewShardedStep:
     """
 
     def __init__(self, n_gaussians, shapes, compute_fn, n_views, rank=0, world_size=1, group=None, compact=False,
-                 scatter=False, view_weights=None):
+                 scatter=False, view_weights=None, force_collectives=False):
         self.N, self.shapes, self.compute_fn = n_gaussians, shapes, compute_fn
         self.n_views, self.rank, self.world, self.group = n_views, rank, world_size, group
         self.local_views = shard_views(n_views, rank, world_size, view_weights)
         self.always_pack = False   # tests: take the packing path without a process group
+        # force_collectives: issue every collective even in a world of one rank (a single-process "nccl" group on a one-GPU
+        # box runs RCCL's all-reduce / reduce-scatter / all-gather code paths with the dtypes and in-place forms used here)
+        self.force = bool(force_collectives)
         self.compact = bool(compact)
-        self.scatter = bool(scatter) and world_size > 1
+        self.scatter = bool(scatter) and (world_size > 1 or self.force)
         self.last_rows = None
         self._store = None
         n_g = self.N * GRAD_WIDTH
@@ -129,7 +132,7 @@ class ViewShardedStep:
         c = self.padded_g // world_size
         self.owned = (rank * c, min((rank + 1) * c, n_g))
         dev = getattr(compute_fn, "device", None)
-        if dev is not None and (world_size > 1):
+        if dev is not None and (world_size > 1 or self.force):
             self._alloc(dev)
 
     def _alloc(self, dev):
@@ -153,7 +156,7 @@ class ViewShardedStep:
 
     def reduce_max_radii(self, radii):
         """MAX over ranks of a per-Gaussian radius statistic (in place; any integer or float dtype)."""
-        if self.world > 1:
+        if self.world > 1 or self.force:
             dist.all_reduce(radii, op=dist.ReduceOp.MAX, group=self.group)
         return radii
 
@@ -173,7 +176,7 @@ class ViewShardedStep:
     def step(self):
         # compute_fn folds the 1/V of "grad = (1/V) sum_v grad L_v" into the loss scale
         N = self.N
-        packed = self.world > 1 or self.always_pack
+        packed = self.world > 1 or self.always_pack or self.force
         if packed and self._store is not None and hasattr(self.compute_fn, "grad_arena"):
             # the backward kernels write straight into the step buffer (no packing copies): one view per leaf
             self.compute_fn.grad_arena = self._views()
@@ -205,7 +208,7 @@ class ViewShardedStep:
             else:
                 dist.reduce_scatter_tensor(mine, st[:self.padded_g], op=dist.ReduceOp.SUM, group=self.group)
             dist.all_reduce(st[self.padded_g:], op=dist.ReduceOp.SUM, group=self.group)    # 2 N + 2 floats
-        elif self.world > 1 or (self.always_pack and self.compact):
+        elif self.world > 1 or self.force or (self.always_pack and self.compact):
             if self.compact:
                 self._compact_all_reduce(st, fv)
             else:
@@ -232,7 +235,7 @@ def _compact_all_reduce(self, flat, fv):
     if self.n_views > 255:
         raise ValueError("compact all-reduce carries the visibility count in one byte: at most 255 views per step (use the dense mode)")
     small = torch.cat([_row_mask(fv, N), fv["vis"].to(torch.uint8)])
-    if self.world > 1:
+    if self.world > 1 or self.force:
         dist.all_reduce(small, op=dist.ReduceOp.SUM, group=self.group)
     fv["vis"].copy_(small[N:])
     idx = torch.nonzero(small[:N], as_tuple=False)[:, 0]                     # (host sync: the collective's size)
@@ -247,7 +250,7 @@ def _compact_all_reduce(self, flat, fv):
         segs.append((name, w, seg))
         o += n * w
     buf[o:o + FLAT_TAIL].copy_(flat[-FLAT_TAIL:])   # (loss, overflow: the last two floats of the step buffer)
-    if self.world > 1:
+    if self.world > 1 or self.force:
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
     for name, w, seg in segs:                                                # rows outside the union are zero everywhere
         fv[name].zero_()

@@ -197,3 +197,62 @@ def test_bench_runs_under_torch_distributed_run_with_two_ranks():
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["headline"] is False
     assert d["config"]["view_assignment"].startswith("balanced") and d["config"]["allreduce"]["mode"] in ("dense", "compact")
     assert set(d["config"]["allreduce"]["ms_per_step_by_mode"]) == {"dense", "compact"}
+
+
+_RCCL_ONE_RANK = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", sys.argv[2]
+import torch, torch.distributed as dist
+from manus_amd.engine import HipViewCompute, ViewShardedStep
+from manus_amd.optim import GaussianOptimizer
+from manus_amd.synthetic import camera_table, make_scene
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1)          # RCCL, one rank
+DEV = "cuda:0"
+V, W, H, N = 3, 96, 64, 3000
+sc = make_scene(n_gaussians=N, kind="hand", seed=4, grid_res=24, n_cameras=V, width=W, height=H, cam_radius=0.5, sigma_range=(3e-3, 9e-3), device=DEV)
+ct = camera_table(sc["cameras"], DEV)
+tg = torch.rand((V, 3, H, W), device=DEV, generator=torch.Generator(device=DEV).manual_seed(2))
+def run(**kw):
+    hc = HipViewCompute(sc, tg, ct, loss="l1+ssim")
+    shapes = {k: v.shape for k, v in hc.params.items()}
+    st = ViewShardedStep(N, shapes, hc, V, rank=0, world_size=1, **kw)
+    out = st.step()
+    torch.cuda.synchronize()
+    return st, hc, {k: v.clone() for k, v in out["grads"].items()}, out["grad2d"].clone(), out["vis"].clone(), float(out["loss"]), out["radii"].clone()
+_, _, g0, s0, v0, l0, r0 = run()
+for kw in (dict(force_collectives=True), dict(force_collectives=True, compact=True)):
+    st, hc, g, s, v, l, r = run(**kw)
+    for k in g0:
+        assert torch.equal(g[k].reshape(g0[k].shape), g0[k]), (kw, k)      # a sum over one rank is the identity
+    assert torch.equal(s, s0) and torch.equal(v, v0) and abs(l - l0) < 1e-7 and torch.equal(r, r0), kw
+    rr = st.reduce_max_radii(r.clone())
+    assert torch.equal(rr, r0)
+# sharded optimizer step: reduce_scatter_tensor (in place on the owned slice) + all_gather_into_tensor
+st, hc, g, s, v, l, r = run(force_collectives=True, scatter=True)
+assert st.owned == (0, N * 59)
+for k in g0:
+    assert torch.equal(g[k].reshape(g0[k].shape), g0[k]), ("scatter", k)
+opt = GaussianOptimizer(hc.params, adopt=True)
+opt.flatten(st.padded_g)
+before = opt.pflat.clone()
+opt.step_range(st._store, *st.owned)
+st.all_gather_params(opt.pflat)
+torch.cuda.synchronize()
+assert not torch.equal(opt.pflat, before) and torch.isfinite(opt.pflat).all()
+dist.destroy_process_group()
+print("RCCL-ONE-RANK-OK")
+"""
+
+
+def test_every_collective_runs_on_rccl_in_a_world_of_one():
+    """The gloo tests take the alternate branches (no reduce-scatter, list all-gather).  A single-process "nccl" group is
+    RCCL with one rank: the float and uint8 SUM all-reduces, the MAX all-reduce, reduce_scatter_tensor in place on the
+    owned slice and all_gather_into_tensor run through RCCL's own code with the dtypes and aliasing used by the step
+    (sums over one rank must be the identity, bit for bit).  Multi-rank RCCL over xGMI remains the driver's to measure."""
+    import subprocess
+    r = subprocess.run([sys.executable, "-c", _RCCL_ONE_RANK, ROOT, str(_free_port())], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0 and "RCCL-ONE-RANK-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
