@@ -99,7 +99,7 @@ struct __attribute__((aligned(16))) MgrGRec {
 
 struct MgrLayout {
     size_t header, scan_part, grec, depth, rect, alive, pair_off, tile_count, tile_start, tile_cursor, tile_done,
-        tile_queue, chunk_start, items, ckpt, keys, keys2, groups, sorted_gid, final_T, n_contrib, pair_tag, pair_grad, inst_grad, inst_tag,
+        tile_queue, tile_qrec, chunk_start, items, ckpt, keys, keys2, groups, sorted_gid, final_T, n_contrib, pair_tag, pair_grad, inst_grad, inst_tag,
         db_count, db_cursor, db_start, db_nvis, db_bbox, db_keys, db_order, db_rec, bin_mat, total;
 };
 
@@ -131,6 +131,7 @@ static inline MgrLayout mgr_layout(int V, int N, int W, int H, int64_t cap) {
     L.tile_cursor = o; o += mgr_align(VT * 4);
     L.tile_done = o;   o += mgr_align(VT * 4);
     L.tile_queue = o;  o += mgr_align(VT * 4);
+    L.tile_qrec = o;   o += mgr_align(VT * 16);       // queue records of the forward blend: (tile, list offset, list length, first checkpoint)
     L.chunk_start = o; o += mgr_align((VT + 1) * 4);
     L.items = o;       o += mgr_align((c / MGR_CHUNK + VT + 1) * 32);   // 32-byte record per (tile, chunk) work item of the backward blend
     L.ckpt = o;        o += mgr_align((c / MGR_CHUNK + 1) * 256 * 16);  // float4 per pixel per checkpoint

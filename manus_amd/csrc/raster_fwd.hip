@@ -137,6 +137,7 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t val, uint32_t* s_wa
 // ---------------------------------------------------------------------------
 // Workgroup sizes of the per-instance kernels (measured on the bench workload: k_inst_fwd 0.245 / 0.173 / 0.189 ms
 // at 1024 / 512 / 256 threads, k_emit 0.100 / 0.105 / 0.175 ms: the LDS tile histogram is flushed once per workgroup).
+#define MGR_FWD_GRID (256 * 8)   // persistent workgroups of k_blend_fwd
 #define PRE_THREADS 512
 #define EMIT_THREADS 1024
 
@@ -368,7 +369,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan_b(int VT, int nblk, uint32_t
                                                       const uint2* __restrict__ part,
                                                       uint32_t* __restrict__ tile_start,
                                                       uint32_t* __restrict__ tile_cursor,
-                                                      uint32_t* __restrict__ tile_queue,
+                                                      uint32_t* __restrict__ tile_queue, uint4* __restrict__ tile_qrec,
                                                       uint32_t* __restrict__ chunk_start, MgrHeader* hdr,
                                                       uint32_t cap) {
     __shared__ uint32_t s_scan[32];
@@ -409,7 +410,13 @@ __global__ __launch_bounds__(1024) void k_tile_scan_b(int VT, int nblk, uint32_t
     __syncthreads();
     if (tid < 34) s_gb[tid] = s_lc[tid] ? atomicAdd(&hdr->cls_cursor[tid], s_lc[tid]) : 0u;
     __syncthreads();
-    if (k < VT) tile_queue[s_cbase[cls] + s_gb[cls] + rank] = (uint32_t)k;
+    if (k < VT) {
+        const uint32_t qslot = s_cbase[cls] + s_gb[cls] + rank;
+        tile_queue[qslot] = (uint32_t)k;
+        // what the forward blend needs to start on the tile, in one load: (tile, list offset, list length, first checkpoint)
+        const uint32_t st = min(s_base[0] + run, cap), en = min(s_base[0] + run + c, cap);
+        tile_qrec[qslot] = make_uint4((uint32_t)k, st, en - st, s_base[1] + crun);
+    }
     if (blockIdx.x == 0 && tid == 0) {
         tile_start[VT] = s_tot[0];
         chunk_start[VT] = s_tot[1];
@@ -423,7 +430,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan_b(int VT, int nblk, uint32_t
         hdr->split_head = 0;
         hdr->group_head = 0;
         hdr->queue_head = 0;
-        hdr->queue_head2 = 0;
+        hdr->queue_head2 = MGR_FWD_GRID;   // k_blend_fwd: workgroup b starts with queue entry b
         hdr->queue_head3 = s_cbase[11];
     }
 }
@@ -1533,6 +1540,7 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, 
                                                    const float* __restrict__ bg,
                                                    const uint32_t* __restrict__ tile_start,
                                                    const uint32_t* __restrict__ tile_queue,
+                                                   const uint4* __restrict__ tile_qrec,
                                                    const uint32_t* __restrict__ sorted_gid,
                                                    const MgrGRec* __restrict__ grec,
                                                    float* __restrict__ out_color,
@@ -1560,29 +1568,39 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, 
 #ifdef FWD_PROF
     long long facc_[6] = {0, 0, 0, 0, 0, 0}, ftp_ = wall_clock64(), fnt_ = 0;
 #endif
-    if (tid == 0) s_next = atomicAdd(&hdr->queue_head2, 1u);
+    // the first tile of a workgroup is its own index (the tile scan starts the queue cursor at the grid size): 2048
+    // workgroups drawing their first ticket from one counter at the same moment are served one after the other
+    if (tid == 0) s_next = blockIdx.x;
     if (blockIdx.x == 0 && tid < 34) {  // consumed by the tile scan: zero for the next forward (no per-call memset)
         hdr->cls_count[tid] = 0;
         hdr->cls_cursor[tid] = 0;
     }
     __syncthreads();
+    // Tile prologue pipeline.  A tile used to start with four dependent round trips (queue entry -> list bounds -> list
+    // indices -> Gaussian records: 7 us of a mean 52 us per tile, -DFWD_PROF).  The queue now holds self-contained records
+    // (tile, list offset, list length, first checkpoint: one scalar load), and when the next ticket is known before the
+    // tile ends (short lists draw it early) the next tile's record and its first two batches of list indices are fetched
+    // in the epilogue, while thread 0 waits for its atomics: only the Gaussian records remain at the top of the loop.
     uint32_t item = s_next;
+    const uint32_t last_q = (n_busy ? n_busy : 1u) - 1u;
+    uint4 qrec = tile_qrec[min(item, last_q)];
+    bool have_gid = false;
+    uint32_t pf_g0 = 0, pf_g1 = 0;
     while (item < n_busy) {
 #ifdef MGR_TIMELINE
         ++ntl;
         const unsigned long long tl_tile0 = wall_clock64();
 #endif
-        const uint32_t vt = tile_queue[item];
+        const uint32_t vt = qrec.x;
         const int v = (int)(vt / (uint32_t)T), t = (int)(vt % (uint32_t)T);
         const int bx = t % gx, by = t / gx;
-        const uint32_t start = min(tile_start[vt], cap), end = min(tile_start[vt + 1], cap);
-        const uint32_t nlist = end - start;
+        const uint32_t start = qrec.y, nlist = qrec.z;
         const int px = bx * 16 + (wave & 1) * 8 + (lane & 7);
         const int py = by * 16 + (wave >> 1) * 8 + (lane >> 3);
         const bool inside = px < W && py < H;
         const mgr_v2f fpx2 = {(float)px, (float)px}, fpy2 = {(float)py, (float)py};
         const float qx0 = (float)(bx * 16 + (wave & 1) * 8), qy0 = (float)(by * 16 + (wave >> 1) * 8);
-        const uint32_t ck0 = chunk_start[vt];  // checkpoint c (c >= 1) of this tile lives at ck0 + c - 1
+        const uint32_t ck0 = qrec.w;  // checkpoint c (c >= 1) of this tile lives at ck0 + c - 1
         // The kernel ends when the deepest tiles end, and their waves share a SIMD with up to five
         // waves of ordinary tiles: long lists issue at raised priority, the rest fill the gaps.
         // (graded by list length; measured: 0.369 ms with one threshold at 4096, 0.361 ms graded)
@@ -1613,8 +1631,8 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, 
         const uint32_t* const sg = sorted_gid + start;
         const uint32_t lastidx = nlist - 1u;
         {
-            const uint32_t g0 = sg[min((uint32_t)lane, lastidx)];
-            gid_n = sg[min(64u + lane, lastidx)];
+            const uint32_t g0 = have_gid ? pf_g0 : sg[min((uint32_t)lane, lastidx)];
+            gid_n = have_gid ? pf_g1 : sg[min(64u + lane, lastidx)];
             const MgrGRec* r = gv + g0;
             rec.a = *(const float4*)r;
             rec.b = *((const float4*)r + 1);
@@ -1738,9 +1756,27 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, 
         const uint32_t nchunks = (tmax + MGR_CHUNK - 1) / MGR_CHUNK;
         if (tid == 0) {
             tile_done[vt] = tmax;
-            if (!early_ticket) s_next = atomicAdd(&hdr->queue_head2, 1u);
+            // both atomics are sent before either answer is waited for
+            uint32_t tk = 0, ib = 0;
+            if (!early_ticket) tk = atomicAdd(&hdr->queue_head2, 1u);
             // backward work items: one per MGR_CHUNK entries actually consumed by this tile
-            s_ibase = nchunks ? atomicAdd(&hdr->n_items, nchunks) : 0u;
+            if (nchunks) ib = atomicAdd(&hdr->n_items, nchunks);
+            if (!early_ticket) s_next = tk;
+            s_ibase = ib;
+        }
+        // the next tile's record and first list indices, while thread 0 waits (an early ticket is in s_next since before the
+        // barrier above)
+        uint4 nrec = qrec;
+        have_gid = false;
+        if (early_ticket) {
+            const uint32_t nxt = s_next;
+            nrec = tile_qrec[min(nxt, last_q)];
+            if (nxt < n_busy) {
+                const uint32_t nl1 = nrec.z - 1u;
+                pf_g0 = sorted_gid[nrec.y + min((uint32_t)lane, nl1)];
+                pf_g1 = sorted_gid[nrec.y + min(64u + lane, nl1)];
+                have_gid = true;
+            }
         }
         __syncthreads();
         // 32-byte record per (tile, chunk): (tile, chunk, list offset of the chunk's first entry, checkpoint in front of
@@ -1764,6 +1800,7 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, 
         }
 #endif
         item = s_next;
+        qrec = early_ticket ? nrec : tile_qrec[min(item, last_q)];
         FP(5);
     }
 #ifdef FWD_PROF
@@ -1914,7 +1951,7 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
         uint2* part = (uint2*)(ws + L.scan_part);
         { MGR_PROF("k_tile_scan_a", stream); hipLaunchKernelGGL(k_tile_scan_a, dim3(nblk), dim3(1024), 0, stream, VT, tile_count, part, hdr); }
         { MGR_PROF("k_tile_scan_b", stream); hipLaunchKernelGGL(k_tile_scan_b, dim3(nblk), dim3(1024), 0, stream, VT, nblk, tile_count, part,
-                           tile_start, (uint32_t*)(ws + L.tile_cursor), (uint32_t*)(ws + L.tile_queue),
+                           tile_start, (uint32_t*)(ws + L.tile_cursor), (uint32_t*)(ws + L.tile_queue), (uint4*)(ws + L.tile_qrec),
                            (uint32_t*)(ws + L.chunk_start), hdr, (uint32_t)cap); }
     }
     MGR_LAUNCH_CHECK("k_tile_scan", stream, debug);
@@ -2001,8 +2038,8 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
     }
     }   // do_bin
     if (!do_blend) return MGR_OK;
-    { MGR_PROF("k_blend_fwd", stream); hipLaunchKernelGGL(k_blend_fwd, dim3(256 * 8), dim3(256), 0, stream, N, W, H, gx, gy, VT, bg, tile_start,
-                       (const uint32_t*)(ws + L.tile_queue), (const uint32_t*)(ws + L.sorted_gid), (const MgrGRec*)(ws + L.grec), out_color,
+    { MGR_PROF("k_blend_fwd", stream); hipLaunchKernelGGL(k_blend_fwd, dim3(MGR_FWD_GRID), dim3(256), 0, stream, N, W, H, gx, gy, VT, bg, tile_start,
+                       (const uint32_t*)(ws + L.tile_queue), (const uint4*)(ws + L.tile_qrec), (const uint32_t*)(ws + L.sorted_gid), (const MgrGRec*)(ws + L.grec), out_color,
                        (float*)(ws + L.final_T), (uint32_t*)(ws + L.n_contrib),
                        (uint32_t*)(ws + L.tile_done), (const uint32_t*)(ws + L.chunk_start),
                        (float4*)(ws + L.ckpt), (uint4*)(ws + L.items), hdr, (uint32_t)cap); }

@@ -35,3 +35,12 @@ print("start times of queue idx 0..20:", [int(b[i,0]-t0) for i in range(20)])
 print("nlist of queue idx 1500..1560:", [int(b[i,2]) for i in range(1500,1560,6)])
 big=idx[b[idx,2]>4096]; print("queue idx range of nlist>4096:", big.min(), big.max(), len(big))
 print("number of tiles with start<2000:", (st<2000).sum())
+# per-workgroup view (-DMGR_TIMELINE=2): when each workgroup entered the tile loop, left it, ended; tiles per workgroup
+L.mgr_debug_timeline(buf2 := (ctypes.c_ulonglong*(2048*4))())
+g=np.array(buf2[:],dtype=np.int64).reshape(2048,4); g=g[g[:,2]>0]
+print("workgroups", len(g), "enter loop (min/median/max ticks)", int((g[:,0]-t0).min()), int(np.median(g[:,0]-t0)), int((g[:,0]-t0).max()),
+      "leave loop", int((g[:,1]-t0).min()), int(np.median(g[:,1]-t0)), int((g[:,1]-t0).max()), "end", int((g[:,2]-t0).max()),
+      "tiles per workgroup min/median/max", int(g[:,3].min()), int(np.median(g[:,3])), int(g[:,3].max()))
+h,_=np.histogram(g[:,0]-t0, bins=10, range=(0, (g[:,2]-t0).max())); print("workgroup entry histogram", h)
+h,_=np.histogram(g[:,1]-t0, bins=10, range=(0, (g[:,2]-t0).max())); print("workgroup loop-exit histogram", h)
+h,_=np.histogram(start, bins=10, range=(0,end.max())); print("tile start histogram", h)
