@@ -346,7 +346,21 @@ __global__ __launch_bounds__(PRE_THREADS) void k_inst_fwd(
 // ---------------------------------------------------------------------------
 // Phase A: per-block sums of (pairs, checkpoint chunks) over 1024 tiles, and the global
 // histogram of size classes.
+//
+// Queue key.  The forward blend takes the tiles largest first (LPT), and what a tile costs is the list depth its pixels
+// consume, not the list's length: the per-tile timeline (-DMGR_TIMELINE=2) showed lists of 4 000-8 000 entries that saturate
+// after 300-900 (30-90 us) at the head of the queue while never-saturating lists of 3 000-4 000 entries (120 us) started at
+// 0.25 of a 0.39 ms kernel and ended it.  The depth a tile consumed in the PREVIOUS forward on this workspace (tile_done,
+// still in place when the scan runs) predicts it well whenever consecutive steps render similar views -- a fixed camera
+// rig, a slowly changing model.  It is a scheduling hint only: a wrong hint costs balance, never correctness; a fresh
+// workspace (all zero) or a tile that was empty falls back to the list length.
+// (Only with the depth-ordered binning: the per-tile sort route cuts its queue at list LENGTH classes.)
+__device__ __forceinline__ uint32_t mgr_queue_key(uint32_t count, uint32_t prev_done, int use_hint) {
+    return (use_hint && count && prev_done) ? min(count, prev_done) : count;
+}
+
 __global__ __launch_bounds__(1024) void k_tile_scan_a(int VT, const uint32_t* __restrict__ tile_count,
+                                                      const uint32_t* __restrict__ tile_done, int use_hint,
                                                       uint2* __restrict__ part, MgrHeader* hdr) {
     __shared__ uint32_t s_scan[32];
     __shared__ uint32_t s_cls[34];
@@ -354,7 +368,8 @@ __global__ __launch_bounds__(1024) void k_tile_scan_a(int VT, const uint32_t* __
     if (tid < 34) s_cls[tid] = 0;
     __syncthreads();
     const uint32_t c = k < VT ? tile_count[k] : 0u;
-    if (k < VT) atomicAdd(&s_cls[c ? 32 - __clz(c) : 0], 1u);
+    const uint32_t key = mgr_queue_key(c, k < VT ? tile_done[k] : 0u, use_hint);
+    if (k < VT) atomicAdd(&s_cls[key ? 32 - __clz(key) : 0], 1u);
     uint32_t total, ctotal;
     (void)block_excl_scan(c, s_scan, total);
     (void)block_excl_scan(c ? (c - 1) / MGR_CHUNK : 0u, s_scan, ctotal);
@@ -370,6 +385,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan_b(int VT, int nblk, uint32_t
                                                       uint32_t* __restrict__ tile_start,
                                                       uint32_t* __restrict__ tile_cursor,
                                                       uint32_t* __restrict__ tile_queue, uint4* __restrict__ tile_qrec,
+                                                      const uint32_t* __restrict__ tile_done, int use_hint,
                                                       uint32_t* __restrict__ chunk_start, MgrHeader* hdr,
                                                       uint32_t cap) {
     __shared__ uint32_t s_scan[32];
@@ -399,7 +415,8 @@ __global__ __launch_bounds__(1024) void k_tile_scan_b(int VT, int nblk, uint32_t
     const uint32_t crun = block_excl_scan(c ? (c - 1) / MGR_CHUNK : 0u, s_scan, ctotal);
     // queue slot = class base + this block's base inside the class (ONE global atomic per
     // (block, class)) + rank inside the block (LDS atomic)
-    const int cls = c ? 32 - __clz(c) : 0;
+    const uint32_t key = mgr_queue_key(c, k < VT ? tile_done[k] : 0u, use_hint);
+    const int cls = key ? 32 - __clz(key) : 0;
     uint32_t rank = 0;
     if (k < VT) {
         tile_start[k] = s_base[0] + run;
@@ -1813,7 +1830,8 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, 
 #ifdef MGR_TIMELINE
     unsigned long long tl1 = wall_clock64();
 #endif
-    // empty tiles: background only
+    // empty tiles: background only.  (Measured: the kernel takes 0.351 ms without this fill, 0.372 with it -- at the end,
+    // as here, or spread over the kernel a few tiles after every blended one: it is the 180 MB, not their timing.)
     for (uint32_t q = n_busy + blockIdx.x; q < (uint32_t)VT; q += gridDim.x) {
         const uint32_t vt = tile_queue[q];
         const int v = (int)(vt / (uint32_t)T), t = (int)(vt % (uint32_t)T);
@@ -1914,14 +1932,18 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
         attr_set[device].store(true, std::memory_order_release);
     }
 
+    const int lds_hist = ((size_t)T * 4 + 128 <= 150 * 1024) ? 1 : 0;
+    // depth-ordered binning unless the tile grid does not fit the LDS cursors (or MGR_BINNING=sorted asks for the per-tile sorts)
+    const char* binning_env = getenv("MGR_BINNING");   // read per call: tests flip it between two forwards
+    const bool ordered_env = !(binning_env && strcmp(binning_env, "sorted") == 0);
+    const bool ordered = ordered_env && lds_hist && T <= 65535 && (size_t)T * 4 + BIN_SC_FIXED_BYTES <= 150 * 1024;
+    const size_t hist_bytes = lds_hist ? (size_t)T * 4 : 0;
     if (do_bin) {
     // per-call counters (epoch lives past the first 32 bytes and persists)
     MGR_HIP(hipMemsetAsync(hdr, 0, 8, stream));
     // tile_count and the size-class counters are left zero by the previous forward on this workspace
     // (k_tile_scan_b / k_blend_fwd) and by the zero-filled allocation before the first one
 
-    const int lds_hist = ((size_t)T * 4 + 128 <= 150 * 1024) ? 1 : 0;
-    const size_t hist_bytes = lds_hist ? (size_t)T * 4 : 0;
     if (N > 0) {
         dim3 grid((N + PRE_THREADS - 1) / PRE_THREADS, V);
         if (canon) {
@@ -1949,16 +1971,14 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
     {
         const int nblk = (VT + 1023) / 1024;
         uint2* part = (uint2*)(ws + L.scan_part);
-        { MGR_PROF("k_tile_scan_a", stream); hipLaunchKernelGGL(k_tile_scan_a, dim3(nblk), dim3(1024), 0, stream, VT, tile_count, part, hdr); }
+        const int use_hint = ordered ? 1 : 0;
+        { MGR_PROF("k_tile_scan_a", stream); hipLaunchKernelGGL(k_tile_scan_a, dim3(nblk), dim3(1024), 0, stream, VT, tile_count,
+                           (const uint32_t*)(ws + L.tile_done), use_hint, part, hdr); }
         { MGR_PROF("k_tile_scan_b", stream); hipLaunchKernelGGL(k_tile_scan_b, dim3(nblk), dim3(1024), 0, stream, VT, nblk, tile_count, part,
                            tile_start, (uint32_t*)(ws + L.tile_cursor), (uint32_t*)(ws + L.tile_queue), (uint4*)(ws + L.tile_qrec),
-                           (uint32_t*)(ws + L.chunk_start), hdr, (uint32_t)cap); }
+                           (const uint32_t*)(ws + L.tile_done), use_hint, (uint32_t*)(ws + L.chunk_start), hdr, (uint32_t)cap); }
     }
     MGR_LAUNCH_CHECK("k_tile_scan", stream, debug);
-    // depth-ordered binning unless the tile grid does not fit the LDS cursors (or MGR_BINNING=sorted asks for the per-tile sorts)
-    const char* binning_env = getenv("MGR_BINNING");   // read per call: tests flip it between two forwards
-    const bool ordered_env = !(binning_env && strcmp(binning_env, "sorted") == 0);
-    const bool ordered = ordered_env && lds_hist && T <= 65535 && (size_t)T * 4 + BIN_SC_FIXED_BYTES <= 150 * 1024;
     if (N > 0 && ordered) {
         const int bb = mgr_bin_block(V, N), nblk = (N + bb - 1) / bb;
         const float* depth = (const float*)(ws + L.depth);
