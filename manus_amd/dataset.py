@@ -421,18 +421,148 @@ class SequenceDataset(torch.utils.data.Dataset):
         dicts, posed bone transforms (V,J,4,4) and keypoints (V,J+1,3) = first head + all tails
         (hand_dynamic.py:199-204)."""
         items = [self.fetch_data(i) for i in indices]
-        cams = []
-        for it in items:
-            c = it["camera"]
-            cams.append({k: (v[0] if torch.is_tensor(v) else v[0]) for k, v in c.__dict__.items()})
-        return {
-            "targets": torch.stack([it["rgb"][0].permute(2, 0, 1) for it in items]).to(device),
-            "masks": torch.stack([it["mask"][0, ..., 0] for it in items]).to(device),
-            "cameras": cams,
+        out = _skeleton_batch(items, device, camera_row=0)
+        out["targets"] = torch.stack([it["rgb"][0].permute(2, 0, 1) for it in items]).to(device)
+        out["masks"] = torch.stack([it["mask"][0, ..., 0] for it in items]).to(device)
+        return out
+
+
+def _skeleton_batch(items, device, camera_row=None):
+    """Cameras, posed / rest bone transforms and keypoints of a list of dataset items (train items hold a 1-camera
+    table per item: `camera_row=0`; evaluation items hold one camera)."""
+    cams = []
+    for it in items:
+        c = it["camera"].__dict__
+        cams.append({k: (v if camera_row is None else v[camera_row]) for k, v in c.items()})
+    return {"cameras": cams,
             "posed": torch.stack([it["bones_posed"].transforms for it in items]).to(device),
             "rest": items[0]["bones_rest"].transforms.to(device),
-            "keypoints": torch.stack([torch.cat([it["bones_posed"].heads[:1], it["bones_posed"].tails], 0) for it in items]).to(device),
-        }
+            "keypoints": torch.stack([torch.cat([it["bones_posed"].heads[:1], it["bones_posed"].tails], 0) for it in items]).to(device)}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# evaluation trajectories (src/datasets/brics_dynamic.py:485-696)
+# ---------------------------------------------------------------------------------------------------------------------
+def convert_armature_space_to_world_space(md):
+    """Rest / posed skeleton tables from armature space into world space: every 4x4 is left-multiplied by the matching
+    `*_matrix_world`, heads and tails are mapped as points (transforms.py:561-590).  Returns a new dict; float64 in,
+    float64 out like the reference's numpy einsums."""
+    out = dict(md)
+    Rw, Pw = np.asarray(md["rest_matrix_world"]), np.asarray(md["pose_matrix_world"])
+    out["rest_matrixs"] = Rw @ np.asarray(md["rest_matrixs"])
+    out["pose_matrixs"] = Pw @ np.asarray(md["pose_matrixs"])
+    for mat, keys in ((Rw, ("rest_tails", "rest_heads")), (Pw, ("pose_tails", "pose_heads"))):
+        for k in keys:
+            p = np.asarray(md[k])
+            h = np.concatenate([p, np.ones(p.shape[:-1] + (1,))], -1)[..., None]
+            out[k] = (mat @ h)[..., :3, 0]
+    return out
+
+
+def _load_table(path):
+    """A camera-path / skeleton table: the reference's joblib pickle, or the same dict as one `.npz`."""
+    if path.endswith(".npz"):
+        with np.load(path, allow_pickle=False) as z:
+            return {k: z[k] for k in z.files}
+    if path.endswith(".txt"):
+        raise NotImplementedError("calibration .txt camera files go through cv2.getOptimalNewCameraMatrix in the reference "
+                                  "(brics_dynamic.py:513-533); OpenCV is absent here -- convert the file to intrs / extrs first")
+    import joblib
+    return joblib.load(path)
+
+
+EVAL_OPTS = dict(resize_factor=1.0, color_bkgd_aug="white", frame_sample_rate=1, test_on_canonical_pose=False,
+                 subject="subject", contact_render_type="default", n_bones=20, width=1080, height=1080)
+
+
+class TestDataset(torch.utils.data.Dataset):
+    """The reference's `TestDataset` (brics_dynamic.py:485-696): no images, one item per camera of a camera path, each
+    paired with a frame of a skeleton trajectory -- what the evaluation / rendering entry points iterate.
+
+    opts: `cam_path` (dict of `intrs` (n,4) fx fy cx cy and `extrs` (n,3,4)), `metadata_path` (skeleton table in armature
+    space incl. `rest_matrix_world` / `pose_matrix_world`), `cano_cam_path` (one camera), `frame_sample_rate`,
+    `test_on_canonical_pose`, `contact_render_type` ("gt_eval": the last 250 `frame_nums`; "acc_gt_eval": every frame;
+    anything else: the camera path thinned by `frame_sample_rate`, skeleton frames stepped to cover it), `color_bkgd_aug`,
+    `subject`.  Paths are used as given (the reference resolves them against its own checkout).  The image size is
+    1080 x 1080 like the reference's."""
+    __test__ = False   # (not a pytest class)
+
+    def __init__(self, opts, split="train"):
+        o = dict(EVAL_OPTS)
+        o.update(opts or {})
+        self.opts = o
+        self.resize_factor, self.bg_color = o["resize_factor"], o["color_bkgd_aug"]
+        self.frame_sample_rate, self.test_on_canonical_pose = o["frame_sample_rate"], o["test_on_canonical_pose"]
+        self.width, self.height, self.n_bones = o["width"], o["height"], o["n_bones"]
+        self.subject_id, self.mode = o["subject"], o["contact_render_type"]
+        cam_data, cano = _load_table(o["cam_path"]), _load_table(o["cano_cam_path"])
+        md = convert_armature_space_to_world_space(_load_table(o["metadata_path"]))
+        parts = os.path.normpath(o["metadata_path"]).split(os.sep)
+        action = parts[-2] if len(parts) > 1 else ""
+        cam_names = [str(c) for c in cam_data["cam_name"]] if (self.mode == "acc_gt_eval" and "cam_name" in cam_data) else None
+        J = self.n_bones
+        bnames = [str(n) for n in np.asarray(md["bnames"]).tolist()]
+        self.bones_rest = to_tensor(Bones(bnames=bnames, heads=md["rest_heads"][:J], tails=md["rest_tails"][:J],
+                                          transforms=md["rest_matrixs"][:J]))
+        Ks, extrs = cam_data["intrs"], cam_data["extrs"]
+        n_pose = md["pose_tails"].shape[0]
+        if self.mode == "gt_eval":
+            frame_ids = selected = np.asarray(md["frame_nums"][-250:])
+            self.n_frames = len(selected)
+        elif self.mode == "acc_gt_eval":
+            self.n_frames = len(extrs)
+            frame_ids = selected = np.arange(n_pose)
+        else:
+            self.n_frames = len(extrs[:: self.frame_sample_rate])
+            step = 1 if n_pose < self.n_frames else -(-n_pose // self.n_frames)
+            frame_ids = selected = np.arange(0, n_pose, step)
+        heads, tails, mats = md["pose_heads"][selected], md["pose_tails"][selected], md["pose_matrixs"][selected]
+        value = to_tensor(np.concatenate([np.asarray(md["root_rotation"])[:, None, :], np.asarray(md["eulers"])], 1))
+        quats = euler_angles_to_quats(value)
+        pose_latent = quats.reshape(-1, quats.shape[1] * quats.shape[2])[selected]
+        self.infos, self.bones_posed_list, self.pose_latent_list = [], [], []
+        cols = {}
+        for i in range(self.n_frames):
+            idx = min(i, tails.shape[0] - 1)      # a path longer than the trajectory holds the last pose
+            self.infos.append([self.subject_id, action, str(frame_ids[idx]), cam_names[i] if cam_names is not None else str(i)])
+            self.pose_latent_list.append(pose_latent[idx])
+            if self.test_on_canonical_pose:
+                self.bones_posed_list.append(self.bones_rest)
+            else:
+                self.bones_posed_list.append(to_tensor(Bones(bnames=bnames, heads=heads[idx, :J], tails=tails[idx, :J],
+                                                             transforms=mats[idx, :J])))
+            fx, fy, cx, cy = Ks[i]
+            K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1]])
+            attr = get_opengl_camera_attributes(K, np.asarray(extrs[i]), self.width, self.height, resize_factor=1.0)
+            for k, v in attr.items():
+                cols.setdefault(k, []).append(v)
+            cols.setdefault("cam_name", []).append(str(i))
+        self.all_cameras = to_tensor(Cameras(**{k: np.stack(v, 0) for k, v in cols.items()}))
+        cK = cano["intrs"][0]
+        cattr = get_opengl_camera_attributes(np.array([[cK[0], 0, cK[2]], [0, cK[1], cK[3]], [0, 0, 1]]),
+                                             np.asarray(cano["extrs"][0]), self.width, self.height)
+        cc = {k: np.stack([v], 0) for k, v in cattr.items()}
+        cc["cam_name"] = np.stack(["0"], 0)
+        self.cano_camera = to_tensor(Cameras(**cc))
+
+    def __len__(self):
+        return self.n_frames
+
+    def __getitem__(self, index):
+        return self.fetch_data(index)
+
+    def fetch_data(self, index):
+        return {"idx": index, "info": self.infos[index], "camera": self.all_cameras[index], "cano_camera": self.cano_camera,
+                "scaling_modifier": 1.0, "bones_rest": self.bones_rest, "bones_posed": self.bones_posed_list[index],
+                "pose_latent": self.pose_latent_list[index],
+                "bg_color": torch.tensor([1.0, 1.0, 1.0]) if self.bg_color == "white" else torch.tensor([0.0, 0.0, 0.0])}
+
+    def view_batch(self, indices, device="cpu"):
+        """Items -> the cameras / poses / keypoints `hand_scene_from_batch` and `engine.HipViewCompute` consume (no
+        targets or masks: this dataset holds no images)."""
+        out = _skeleton_batch([self.fetch_data(i) for i in indices], device)
+        out["width"], out["height"] = self.width, self.height
+        return out
 
 
 def hand_scene_from_batch(batch, bones_rest, n_gaussians, grid_res=32, seed=0, device="cuda:0", sigma_range=(2e-3, 6e-3)):
@@ -461,13 +591,17 @@ def hand_scene_from_batch(batch, bones_rest, n_gaussians, grid_res=32, seed=0, d
     posed = batch["posed"].cpu().float()
     tf = torch.stack([T.bone_transforms(posed[v], rest) for v in range(posed.shape[0])])
     cams = [{k: (v.cpu().numpy() if torch.is_tensor(v) else v) for k, v in c.items()} for c in batch["cameras"]]
-    H, W = batch["targets"].shape[-2:]
+    has_img = "targets" in batch
+    H, W = batch["targets"].shape[-2:] if has_img else (batch["height"], batch["width"])
     scene = dict(params={k: v.to(device) for k, v in params.items()}, N=N, n_hand=N, kind="hand", grid_dims=dims,
                  grid=S.make_skin_grid(heads, tails, dims, center, scale, device=device),
                  grid_center=torch.as_tensor(center).to(device), grid_scale=torch.as_tensor(scale).to(device),
                  rest=rest.to(device), posed=posed.to(device), transforms=tf.to(device), cameras=cams,
                  bg=torch.ones(3, device=device), width=int(W), height=int(H), heads=heads, tails=tails,
-                 keypoints=batch["keypoints"].float().to(device), masks=batch["masks"].to(device))
+                 keypoints=batch["keypoints"].float().to(device))
+    if not has_img:                       # evaluation trajectory: nothing to compare against
+        return scene, None
+    scene["masks"] = batch["masks"].to(device)
     return scene, batch["targets"].float().to(device).contiguous()
 
 

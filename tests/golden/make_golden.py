@@ -761,11 +761,78 @@ def make_dataset_golden(mods):
     return out
 
 
+def make_testdataset_golden(mods):
+    """src/datasets/brics_dynamic.py::TestDataset (485-696) on a thinned copy of the reference's own evaluation inputs
+    (data/camera_paths/real.pkl: every 18th camera -> 14; data/meta_data/novel_pose.pkl: every 21st frame -> 12, plus a
+    synthetic `frame_nums` column for the gt_eval mode; data/camera_paths/cano_camera.pkl as is).  The thinned tables
+    are committed as tests/golden/eval_inputs/*.npz (data); the reference reads the same tables from temporary joblib
+    pickles.  h5py / natsort / cv2 are stubs (never touched on this path)."""
+    import tempfile
+    import joblib
+    import src.datasets.brics_dynamic as bd
+    from easydict import EasyDict
+    cam = joblib.load(os.path.join(REF, "data/camera_paths/real.pkl"))
+    cano = joblib.load(os.path.join(REF, "data/camera_paths/cano_camera.pkl"))
+    md = joblib.load(os.path.join(REF, "data/meta_data/novel_pose.pkl"))
+    cam_t = {"intrs": np.asarray(cam["intrs"], np.float64)[::18][:14], "extrs": np.asarray(cam["extrs"], np.float64)[::18][:14]}
+    assert cam_t["intrs"].shape[0] == 14
+    cano_t = {"intrs": np.asarray(cano["intrs"], np.float64), "extrs": np.asarray(cano["extrs"], np.float64)}
+    md_t = {}
+    for k, v in md.items():
+        v = np.asarray(v)
+        if v.shape[:1] == (251,):
+            v = v[::21][:12]
+        md_t[k] = np.array([str(x) for x in v]) if v.dtype.kind in "OU" else v
+    md_t["frame_nums"] = np.array([4, 0, 9, 2, 11, 7, 1, 10, 3, 8])   # (used as row indices, brics_dynamic.py:565-582)
+    ind = os.path.join(OUT, "eval_inputs")
+    os.makedirs(ind, exist_ok=True)
+    np.savez_compressed(os.path.join(ind, "camera_path.npz"), **cam_t)
+    np.savez_compressed(os.path.join(ind, "cano_camera.npz"), **cano_t)
+    np.savez_compressed(os.path.join(ind, "novel_pose.npz"), **md_t)
+    tmp = os.path.join(tempfile.mkdtemp(), "eval_inputs")
+    os.makedirs(tmp)
+    md_p = dict(md_t)
+    md_p["bnames_parent"] = np.array([None if x == "None" else x for x in md_t["bnames_parent"]], dtype=object)
+    joblib.dump({k: list(v) for k, v in cam_t.items()}, os.path.join(tmp, "camera_path.pkl"))
+    joblib.dump({k: list(v) for k, v in cano_t.items()}, os.path.join(tmp, "cano_camera.pkl"))
+    joblib.dump(md_p, os.path.join(tmp, "novel_pose.pkl"))
+    cases = {"a": dict(frame_sample_rate=2, test_on_canonical_pose=False, contact_render_type="default", color_bkgd_aug="white"),
+             "b": dict(frame_sample_rate=1, test_on_canonical_pose=True, contact_render_type="default", color_bkgd_aug="black"),
+             "c": dict(frame_sample_rate=1, test_on_canonical_pose=False, contact_render_type="gt_eval", color_bkgd_aug="white"),
+             "d": dict(frame_sample_rate=3, test_on_canonical_pose=False, contact_render_type="acc_gt_eval", color_bkgd_aug="white")}
+    out = {}
+    for tag, c in cases.items():
+        opts = EasyDict(resize_factor=1.0, subject="s1", cam_path=os.path.join(tmp, "camera_path.pkl"),
+                        metadata_path=os.path.join(tmp, "novel_pose.pkl"), cano_cam_path=os.path.join(tmp, "cano_camera.pkl"), **c)
+        ds = bd.TestDataset(opts, "test")
+        k = tag + "_"
+        out[k + "len"] = np.int64(len(ds))
+        out[k + "infos"] = np.array(["|".join(map(str, i)) for i in ds.infos])
+        for f in ("K", "extr", "fovx", "fovy", "width", "height", "world_view_transform", "projection_matrix",
+                  "full_proj_transform", "camera_center"):
+            out[k + "cams_" + f] = np.asarray(getattr(ds.all_cameras, f))
+            out[k + "cano_" + f] = np.asarray(getattr(ds.cano_camera, f))
+        out[k + "cams_cam_name"] = np.array([str(x) for x in ds.all_cameras.cam_name])
+        for f in ("heads", "tails", "transforms"):
+            out[k + "rest_" + f] = getattr(ds.bones_rest, f).numpy()
+            out[k + "posed_" + f] = np.stack([getattr(b, f).numpy() for b in ds.bones_posed_list])
+        out[k + "pose_latent"] = np.stack([p.numpy() for p in ds.pose_latent_list])
+        d = ds[len(ds) - 1]
+        out[k + "item_bg"] = d["bg_color"].numpy()
+        out[k + "item_idx"] = np.int64(d["idx"])
+        out[k + "item_cam_K"] = np.asarray(d["camera"].K)
+        out[k + "item_keys"] = np.array(sorted(d.keys()))
+    return out
+
+
 def main():
     mods = _import_reference()
     torch.manual_seed(0)
     if "--dataset" in sys.argv:    # round 2: the sequence reader (SURVEY 8 f4)
         np.savez_compressed(os.path.join(OUT, "dataset.npz"), **make_dataset_golden(mods))
+        return
+    if "--testdataset" in sys.argv:    # round 3: evaluation trajectories (SURVEY 8 f4)
+        np.savez_compressed(os.path.join(OUT, "testdataset.npz"), **make_testdataset_golden(mods))
         return
     if "--round2" in sys.argv:     # only the fixtures added in round 2 (the others are unchanged)
         np.savez_compressed(os.path.join(OUT, "optimizer_s2.npz"), **make_optimizer_golden(mods, 2, 0.02, None, big=True))

@@ -108,3 +108,59 @@ def test_random_views_split_file_and_view_batch(seq_dir, tmp_path):
     arr = D.synthetic_sequence(11)
     with D.open_sequence(os.path.join(seq_dir, "grasp_2.npz")) as f:
         assert np.array_equal(f["frames"]["8"]["images"]["cam02"], arr["frames/8/images/cam02"])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# evaluation trajectories: brics_dynamic.py::TestDataset (485-696); fixture tests/golden/testdataset.npz
+# (generator: tests/golden/make_golden.py --testdataset), inputs tests/golden/eval_inputs/*.npz
+# ---------------------------------------------------------------------------------------------------------------------
+EVAL_CASES = {"a": dict(frame_sample_rate=2, test_on_canonical_pose=False, contact_render_type="default", color_bkgd_aug="white"),
+              "b": dict(frame_sample_rate=1, test_on_canonical_pose=True, contact_render_type="default", color_bkgd_aug="black"),
+              "c": dict(frame_sample_rate=1, test_on_canonical_pose=False, contact_render_type="gt_eval", color_bkgd_aug="white"),
+              "d": dict(frame_sample_rate=3, test_on_canonical_pose=False, contact_render_type="acc_gt_eval", color_bkgd_aug="white")}
+
+
+@pytest.mark.parametrize("tag", sorted(EVAL_CASES))
+def test_eval_trajectory_dataset_matches_reference(golden_dir, tag):
+    from manus_amd import dataset as D
+    g = np.load(os.path.join(golden_dir, "testdataset.npz"))
+    ind = os.path.join(golden_dir, "eval_inputs")
+    ds = D.TestDataset(dict(subject="s1", cam_path=os.path.join(ind, "camera_path.npz"), cano_cam_path=os.path.join(ind, "cano_camera.npz"),
+                            metadata_path=os.path.join(ind, "novel_pose.npz"), **EVAL_CASES[tag]))
+    k = tag + "_"
+    assert len(ds) == int(g[k + "len"])
+    assert ["|".join(map(str, i)) for i in ds.infos] == list(g[k + "infos"])
+    for f in ("K", "extr", "fovx", "fovy", "width", "height", "world_view_transform", "projection_matrix", "full_proj_transform",
+              "camera_center"):
+        np.testing.assert_array_equal(np.asarray(getattr(ds.all_cameras, f)), g[k + "cams_" + f], err_msg=f)
+        np.testing.assert_array_equal(np.asarray(getattr(ds.cano_camera, f)), g[k + "cano_" + f], err_msg="cano " + f)
+    assert [str(x) for x in ds.all_cameras.cam_name] == list(g[k + "cams_cam_name"])
+    for f in ("heads", "tails", "transforms"):
+        np.testing.assert_array_equal(getattr(ds.bones_rest, f).numpy(), g[k + "rest_" + f])
+        np.testing.assert_array_equal(np.stack([getattr(b, f).numpy() for b in ds.bones_posed_list]), g[k + "posed_" + f])
+    np.testing.assert_allclose(np.stack([p.numpy() for p in ds.pose_latent_list]), g[k + "pose_latent"], rtol=0, atol=1e-6)
+    d = ds[len(ds) - 1]
+    assert sorted(d.keys()) == list(g[k + "item_keys"])
+    np.testing.assert_array_equal(d["bg_color"].numpy(), g[k + "item_bg"])
+    assert d["idx"] == int(g[k + "item_idx"]) and d["scaling_modifier"] == 1.0
+    np.testing.assert_array_equal(np.asarray(d["camera"].K), g[k + "item_cam_K"])
+    assert d["bones_rest"] is ds.bones_rest and d["cano_camera"] is ds.cano_camera
+
+
+def test_armature_to_world_is_a_point_and_frame_map(golden_dir):
+    from manus_amd import dataset as D
+    with np.load(os.path.join(golden_dir, "eval_inputs", "novel_pose.npz")) as z:
+        md = {k: z[k] for k in z.files}
+    w = D.convert_armature_space_to_world_space(md)
+    h = np.concatenate([md["pose_heads"], np.ones(md["pose_heads"].shape[:-1] + (1,))], -1)
+    np.testing.assert_allclose(w["pose_heads"], np.einsum("fjab,fjb->fja", md["pose_matrix_world"], h)[..., :3], atol=1e-12)
+    np.testing.assert_allclose(w["rest_matrixs"], np.einsum("jab,jbc->jac", md["rest_matrix_world"], md["rest_matrixs"]), atol=1e-12)
+    assert md["rest_matrixs"] is not w["rest_matrixs"] and "frame_nums" in w     # input left alone, other columns kept
+
+
+def test_eval_dataset_refuses_calibration_text_files(golden_dir, tmp_path):
+    from manus_amd import dataset as D
+    ind = os.path.join(golden_dir, "eval_inputs")
+    with pytest.raises(NotImplementedError, match="OpenCV"):
+        D.TestDataset(dict(cam_path=str(tmp_path / "calib.txt"), cano_cam_path=os.path.join(ind, "cano_camera.npz"),
+                           metadata_path=os.path.join(ind, "novel_pose.npz"), contact_render_type="acc_gt_eval"))

@@ -311,3 +311,32 @@ def test_checkpoint_carries_the_optimizer_state(tmp_path):
     for k in a.opt.p:
         assert torch.equal(a.opt.p[k], b.opt.p[k]), k
         assert torch.equal(a.opt.m[k], b.opt.m[k]), k
+
+
+def test_eval_trajectory_dataset_renders_through_the_kernels(golden_dir):
+    """SURVEY 8 f4, evaluation half: `dataset.TestDataset` (brics_dynamic.py:485-696) over the reference's own camera
+    path and novel-pose skeleton (thinned: tests/golden/eval_inputs) -> `view_batch` -> `engine.HipViewCompute` at the
+    reference's 1080 x 1080; the hand is in frame from every camera and the fused and per-operator routes agree."""
+    import os
+    from manus_amd import dataset as D
+    from manus_amd.engine import HipViewCompute
+    from manus_amd.synthetic import camera_table
+    ind = os.path.join(golden_dir, "eval_inputs")
+    ds = D.TestDataset(dict(cam_path=os.path.join(ind, "camera_path.npz"), cano_cam_path=os.path.join(ind, "cano_camera.npz"),
+                            metadata_path=os.path.join(ind, "novel_pose.npz"), frame_sample_rate=2))
+    ids = [0, 3, len(ds) - 1]
+    batch = ds.view_batch(ids)
+    scene, targets = D.hand_scene_from_batch(batch, ds.bones_rest, 20000, grid_res=24, seed=2, device=DEV)
+    assert targets is None and (scene["width"], scene["height"]) == (1080, 1080)
+    ct = camera_table(scene["cameras"], DEV)
+    blank = torch.zeros((len(ids), 3, 1080, 1080), device=DEV)
+    with torch.no_grad():
+        im_m, rad_m, _ = HipViewCompute(scene, blank, ct, fused=False).forward_views([0, 1, 2])
+        im_f, rad_f = HipViewCompute(scene, blank, ct, fused=True).forward_views_fused([0, 1, 2])
+    assert torch.equal(rad_m, rad_f)
+    d = (im_m - im_f).abs()
+    assert float(d.max()) < 5e-3 and float(d.mean()) < 2e-6
+    for v in range(len(ids)):
+        covered = (im_f[v] < 0.999).any(0).float().mean()
+        assert 0.002 < float(covered) < 0.9, (v, float(covered))          # the hand, on a white background
+        assert int((rad_f[v] > 0).sum()) > 1000
