@@ -450,7 +450,7 @@ __device__ __forceinline__ void mgr_pair_pad(float* pb) {
 // on a pair whose alpha equals 1/255 to eight digits).
 __device__ __forceinline__ void mgr_pair_alpha(const float4 R0, const float4 R1, const float4 R2, mgr_v2f fpx2,
                                                mgr_v2f fpy2, mgr_v2f& dx, mgr_v2f& dy, mgr_v2f& G, mgr_v2f& al,
-                                               bool& va, bool& vb) {
+                                               bool& va, bool& vb, mgr_v2f* pw_out = nullptr) {
 #pragma clang fp contract(off)
     const mgr_v2f x2 = {R0.x, R0.y}, y2 = {R0.z, R0.w}, A2 = {R1.x, R1.y}, B2 = {R1.z, R1.w}, C2 = {R2.x, R2.y},
                   o2 = {R2.z, R2.w};
@@ -460,13 +460,15 @@ __device__ __forceinline__ void mgr_pair_alpha(const float4 R0, const float4 R1,
     t = __builtin_elementwise_fma(B2, dy, t);
     const mgr_v2f u = C2 * dy;
     const mgr_v2f pw = __builtin_elementwise_fma(dx, t, u * dy);
-    G.x = __builtin_amdgcn_exp2f(fminf(pw.x, 0.0f));
-    G.y = __builtin_amdgcn_exp2f(fminf(pw.y, 0.0f));
+    // min(2^pw, 1) = 2^min(pw, 0) bit for bit; written as a clamp to [0, 1] it is the `clamp` bit of v_exp_f32 (no v_min)
+    G.x = __builtin_fminf(__builtin_fmaxf(__builtin_amdgcn_exp2f(pw.x), 0.0f), 1.0f);
+    G.y = __builtin_fminf(__builtin_fmaxf(__builtin_amdgcn_exp2f(pw.y), 0.0f), 1.0f);
     al = o2 * G;
     al.x = fminf(0.99f, al.x);
     al.y = fminf(0.99f, al.y);
     va = pw.x <= 0.0f && al.x >= 1.0f / 255.0f;
     vb = pw.y <= 0.0f && al.y >= 1.0f / 255.0f;
+    if (pw_out) *pw_out = pw;
 }
 
 // natural exponential through v_exp_f32 (arguments here lie in [-12, 0])

@@ -46,6 +46,14 @@ extern "C" int mgr_debug_bprof(unsigned long long* dst) {
 #define BP(k)
 #endif
 
+// 1 when any bit of a wave-uniform lane mask is set -- on the scalar unit (written in C the compiler turns the
+// comparison into a per-lane select followed by v_readfirstlane)
+__device__ __forceinline__ uint32_t mgr_any64(unsigned long long m) {
+    uint32_t r;
+    asm("s_cmp_lg_u64 %1, 0\n\ts_cselect_b32 %0, 1, 0" : "=s"(r) : "s"(m) : "scc");
+    return r;
+}
+
 template <int G>
 __device__ __forceinline__ float grp_sum(float x) {  // all lanes of the group receive the total
     if (G >= 2) x += mgr_dpp<0xb1>(x);   // quad_perm [1,0,3,2]
@@ -80,8 +88,9 @@ __device__ __forceinline__ float grp8_reduce_scatter(const float x[8], int vl) {
 // the quadrant's pixels that reach the chunk (mgr_box_dead), survivors compacted pairwise into the wave's LDS slab, and
 // the per-Gaussian sums over the 64 pixels are formed in two phases per group of 4 pair steps (8 entries):
 //   phase 1, lane = pixel: alpha and the sequential transmittance part for two entries per step (packed fp32),
-//            leaving (G dL/dalpha, alpha T) of both entries per pixel in an LDS exchange row;
-//   phase 2, lane = (entry, pixel column): the 8 lanes of an entry each run down their column of the quadrant (dx is
+//            leaving (G dL/dalpha, alpha T) of both entries per pixel in an LDS exchange row (four planes, [column][row]);
+//   phase 2, lane = (entry, pixel column): the 8 lanes of an entry each run down their column of the quadrant, two rows
+//            per step in packed fp32 (dx is
 //            constant along a column: only sum v, sum v dy, sum v dy^2 and the three colour sums are accumulated per
 //            lane), a transposing reduction over the 8 lanes leaves one of the nine sums in each lane, and the lanes add
 //            them to the entry's accumulator row in LDS (same wave, program order: deterministic).
@@ -94,7 +103,12 @@ __device__ __forceinline__ float grp8_reduce_scatter(const float x[8], int vl) {
 // latency.  Here a wave depends on nobody, the list segment and the records are fetched once per item instead of
 // once per quadrant, and the cross-lane part of the reduction is 8 lanes wide.
 #define BWD_BATCH MGR_CHUNK
-#define BWD_ROW 288   // floats per exchange row: 64 px x (v_a, w_a, v_b, w_b) + 32 so that two rows cover all 64 banks
+// One exchange row per pair step: four planes of 64 floats (v_a, w_a, v_b, w_b; v = G dL/dalpha, w = alpha T), a pixel at
+// [column * 8 + row] so that a phase-2 lane reads two rows of its column with one 8-byte load.  Plane b starts at 130 and
+// rows are 260 floats apart: the 32 lanes of a half-wave (2 exchange rows x 2 entries x 8 columns) then touch 64 distinct banks.
+#define BWD_ROW 260
+#define BWD_PLANE_W 64
+#define BWD_PLANE_B 130
 #ifndef BWD_WAVES
 #define BWD_WAVES 4
 #endif
@@ -212,18 +226,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BWD_WAVES, 
             int bx0, by0, bx1, by1;
             if (!mgr_quad_bbox(__ballot(last > first), bx0, by0, bx1, by1)) continue;
             // dL/dpixel of this lane's phase-2 column (pixels (pc, 0..7) of the quadrant), through the exchange buffer
-            float gr0[8], gr1[8], gr2[8];
+            mgr_v2f gr0[4], gr1[4], gr2[4];   // rows (2k, 2k + 1) of the column
             {
                 float4* const sg = (float4*)xch;
                 sg[lane] = make_float4(g0, g1, g2, 0.f);
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const float4 t4 = sg[i * 8 + pc];
-                    gr0[i] = t4.x; gr1[i] = t4.y; gr2[i] = t4.z;
+                for (int k = 0; k < 4; ++k) {
+                    const float4 t4 = sg[(2 * k) * 8 + pc], u4 = sg[(2 * k + 1) * 8 + pc];
+                    gr0[k] = mgr_v2f{t4.x, u4.x}; gr1[k] = mgr_v2f{t4.y, u4.y}; gr2[k] = mgr_v2f{t4.z, u4.z};
                 }
                 __builtin_amdgcn_wave_barrier();
             }
+            const int xoff = (lane & 7) * 8 + (lane >> 3);   // this pixel's place in a plane
             const float fx_col = qx0 + (float)pc;
             const mgr_v2f g0v = {g0, g0}, g1v = {g1, g1}, g2v = {g2, g2};
             bool alive = false;
@@ -254,41 +269,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BWD_WAVES, 
                     mgr_v2f dx, dy, G, al;
                     bool va, vb;
                     mgr_pair_alpha(R0, R1, R2, fpx2, fpy2, dx, dy, G, al, va, vb);
-                    const uint32_t pa = __float_as_uint(R4.z), pbpos = __float_as_uint(R4.w);
-                    va = va && pa <= last;
-                    vb = vb && pbpos <= last;
-                    const bool anya = __ballot(va) != 0ull, anyb = __ballot(vb) != 0ull;  // wave-uniform
+                    // valid = alpha kept by the forward rule AND at or in front of the pixel's last contributor; the list
+                    // position of a skipped alpha is replaced by UINT_MAX so that ONE compare yields the lane mask
+                    const uint32_t ka = va ? __float_as_uint(R4.z) : 0xFFFFFFFFu, kb = vb ? __float_as_uint(R4.w) : 0xFFFFFFFFu;
+                    va = ka <= last;
+                    vb = kb <= last;
+                    const unsigned long long ma = __builtin_amdgcn_ballot_w64(va), mb = __builtin_amdgcn_ballot_w64(vb);
+                    const uint32_t anya = mgr_any64(ma), anyb = mgr_any64(mb);  // wave-uniform
                     MGR_STAT(2, 1);                                                    // pair iterations
                     MGR_STAT(3, __popcll(__ballot(va)) + __popcll(__ballot(vb)));      // valid (entry, pixel) evaluations
-                    MGR_STAT(4, (anya ? 1 : 0) + (anyb ? 1 : 0));                      // entries with any valid pixel
-                    if (!anya && !anyb) continue;
+                    MGR_STAT(4, anya + anyb);                      // entries with any valid pixel
+                    if ((ma | mb) == 0ull) continue;
                     MGR_STAT(5, 1);                                                    // pair iterations doing the full math
-                    tmask |= ((anya ? 1u : 0u) | (anyb ? 2u : 0u)) << (2 * r);
+                    tmask |= (anya | (anyb << 1)) << (2 * r);
                     const mgr_v2f cr = {R3.x, R3.y}, cgn = {R3.z, R3.w}, cb = {R4.x, R4.y};
                     const mgr_v2f cg = cr * g0v + cgn * g1v + cb * g2v;
-                    mgr_v2f w2, da2;
-                    {
-                        const float a = va ? al.x : 0.0f;
-                        const float w = a * Tr;
-                        pg += w * cg.x;  // prefix . g through this entry
-                        const float oma = 1.0f - a;
-                        const float d = Tr * cg.x - (Og - pg) * __builtin_amdgcn_rcpf(oma);
-                        Tr *= oma;
-                        w2.x = w;
-                        da2.x = va ? d : 0.0f;
-                    }
-                    {
-                        const float a = vb ? al.y : 0.0f;
-                        const float w = a * Tr;
-                        pg += w * cg.y;
-                        const float oma = 1.0f - a;
-                        const float d = Tr * cg.y - (Og - pg) * __builtin_amdgcn_rcpf(oma);
-                        Tr *= oma;
-                        w2.y = w;
-                        da2.y = vb ? d : 0.0f;
-                    }
+                    // both entries side by side; only the transmittance and the prefix chain from a to b
+                    const mgr_v2f a2 = {va ? al.x : 0.0f, vb ? al.y : 0.0f};
+                    const mgr_v2f oma = 1.0f - a2;
+                    const mgr_v2f rc = {__builtin_amdgcn_rcpf(oma.x), __builtin_amdgcn_rcpf(oma.y)};
+                    const mgr_v2f T2 = {Tr, Tr * oma.x};          // transmittance in front of a, of b
+                    Tr = T2.y * oma.y;
+                    const mgr_v2f w2 = a2 * T2;
+                    const mgr_v2f wc = w2 * cg;
+                    mgr_v2f P2;                                   // prefix . g through a, through b
+                    P2.x = pg + wc.x;
+                    P2.y = P2.x + wc.y;
+                    pg = P2.y;
+                    const mgr_v2f d2 = T2 * cg - (Og - P2) * rc;
+                    const mgr_v2f da2 = {va ? d2.x : 0.0f, vb ? d2.y : 0.0f};
                     const mgr_v2f v_op = G * da2;   // dL/dopacity share; times the opacity = q = dL/dG G (applied in the flush)
-                    *(float4*)(xch + r * BWD_ROW + lane * 4) = make_float4(v_op.x, w2.x, v_op.y, w2.y);
+                    float* const xr = xch + r * BWD_ROW + xoff;
+                    xr[0] = v_op.x; xr[BWD_PLANE_W] = w2.x;
+                    xr[BWD_PLANE_B] = v_op.y; xr[BWD_PLANE_B + BWD_PLANE_W] = w2.y;
                 }
                 if (tmask == 0u) continue;
                 __builtin_amdgcn_wave_barrier();
@@ -300,20 +313,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BWD_WAVES, 
                     const float xe = pbs[0 + h], ye = pbs[2 + h];
                     const uint32_t pos = __float_as_uint(pbs[18 + h]);
                     const float dxc = xe - fx_col, dy0 = ye - qy0;
-                    const float* src = xch + (e2 >> 1) * BWD_ROW + pc * 4 + h * 2;
-                    float A0 = 0.f, A1 = 0.f, A2 = 0.f, sr = 0.f, sgn = 0.f, sb = 0.f;
+                    const float* src = xch + (e2 >> 1) * BWD_ROW + h * BWD_PLANE_B + pc * 8;
+                    mgr_v2f DY = {dy0, dy0 - 1.0f};
+                    mgr_v2f B0 = {0.f, 0.f}, B1 = {0.f, 0.f}, B2 = {0.f, 0.f}, Cr = {0.f, 0.f}, Cg = {0.f, 0.f}, Cb = {0.f, 0.f};
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const float2 vw = *(const float2*)(src + i * 32);
-                        const float dyi = dy0 - (float)i;
-                        const float t1 = vw.x * dyi;
-                        A0 += vw.x;
-                        A1 += t1;
-                        A2 += t1 * dyi;
-                        sr += vw.y * gr0[i];
-                        sgn += vw.y * gr1[i];
-                        sb += vw.y * gr2[i];
+                    for (int k = 0; k < 4; ++k) {   // rows 2k and 2k + 1 side by side
+                        const mgr_v2f vv = *(const mgr_v2f*)(src + 2 * k), ww = *(const mgr_v2f*)(src + BWD_PLANE_W + 2 * k);
+                        const mgr_v2f t1 = vv * DY;
+                        B0 += vv;
+                        B1 += t1;
+                        B2 += t1 * DY;
+                        Cr += ww * gr0[k];
+                        Cg += ww * gr1[k];
+                        Cb += ww * gr2[k];
+                        DY -= 2.0f;
                     }
+                    const float A0 = B0.x + B0.y, A1 = B1.x + B1.y, A2 = B2.x + B2.y;
+                    const float sr = Cr.x + Cr.y, sgn = Cg.x + Cg.y, sb = Cb.x + Cb.y;
                     const float Sx = dxc * A0;
                     const float x8[8] = {Sx, A1, Sx * dxc, dxc * A1, A2, A0, sr, sgn};
                     const float tot = grp8_reduce_scatter(x8, pc);
