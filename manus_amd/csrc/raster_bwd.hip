@@ -103,12 +103,17 @@ __device__ __forceinline__ float grp8_reduce_scatter(const float x[8], int vl) {
 // latency.  Here a wave depends on nobody, the list segment and the records are fetched once per item instead of
 // once per quadrant, and the cross-lane part of the reduction is 8 lanes wide.
 #define BWD_BATCH MGR_CHUNK
-// One exchange row per pair step: four planes of 64 floats (v_a, w_a, v_b, w_b; v = G dL/dalpha, w = alpha T), a pixel at
-// [column * 8 + row] so that a phase-2 lane reads two rows of its column with one 8-byte load.  Plane b starts at 130 and
-// rows are 260 floats apart: the 32 lanes of a half-wave (2 exchange rows x 2 entries x 8 columns) then touch 64 distinct banks.
-#define BWD_ROW 260
+// One exchange row per pair step: four planes of 64 floats (v_a, w_a, v_b, w_b; v = G dL/dalpha, w = alpha T).  Pixel
+// (column c, row i) sits at 4 c + 32 (i / 4) + i % 4: a phase-2 lane (entry, column) fetches rows 0..3 and 4..7 of its
+// column with two ds_read_b128 per plane and adds them up two rows at a time in packed fp32.  Banks (MI355X_MICROARCH,
+// LDS): the stores are ds_write_b32, 32 lanes per cycle on (address / 4) mod 32 -- rows 0..3 of the eight columns are 32
+// consecutive dwords; a ds_read_b128 serves 16 lanes per cycle on 64 banks, and with planes a and b 128 floats apart and
+// rows 288 apart the four (exchange row, entry) x four columns of a lane group take 16 different 16-byte slots.
+// (Measured on the way: [column * 8 + row] planes read with ds_read2_b64 cost 29 M conflict cycles of 197 M per launch;
+// a conflict-free variant of that, still on ds_read2_b64's 128 B/clk path, 0.4345 ms.)
+#define BWD_ROW 288
 #define BWD_PLANE_W 64
-#define BWD_PLANE_B 130
+#define BWD_PLANE_B 128
 #ifndef BWD_WAVES
 #define BWD_WAVES 4
 #endif
@@ -227,18 +232,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BWD_WAVES, 
             if (!mgr_quad_bbox(__ballot(last > first), bx0, by0, bx1, by1)) continue;
             // dL/dpixel of this lane's phase-2 column (pixels (pc, 0..7) of the quadrant), through the exchange buffer
             mgr_v2f gr0[4], gr1[4], gr2[4];   // rows (2k, 2k + 1) of the column
+            const int xoff = 4 * (lane & 7) + 32 * (lane >> 5) + ((lane >> 3) & 3);   // this pixel's place in a plane
             {
-                float4* const sg = (float4*)xch;
-                sg[lane] = make_float4(g0, g1, g2, 0.f);
+                xch[xoff] = g0; xch[64 + xoff] = g1; xch[128 + xoff] = g2;   // three planes, same layout as the exchange rows
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float4 t4 = sg[(2 * k) * 8 + pc], u4 = sg[(2 * k + 1) * 8 + pc];
-                    gr0[k] = mgr_v2f{t4.x, u4.x}; gr1[k] = mgr_v2f{t4.y, u4.y}; gr2[k] = mgr_v2f{t4.z, u4.z};
+                for (int j = 0; j < 2; ++j) {
+                    const float4 a4 = *(const float4*)(xch + 4 * pc + 32 * j), b4 = *(const float4*)(xch + 64 + 4 * pc + 32 * j),
+                                 c4 = *(const float4*)(xch + 128 + 4 * pc + 32 * j);
+                    gr0[2 * j] = mgr_v2f{a4.x, a4.y}; gr0[2 * j + 1] = mgr_v2f{a4.z, a4.w};
+                    gr1[2 * j] = mgr_v2f{b4.x, b4.y}; gr1[2 * j + 1] = mgr_v2f{b4.z, b4.w};
+                    gr2[2 * j] = mgr_v2f{c4.x, c4.y}; gr2[2 * j + 1] = mgr_v2f{c4.z, c4.w};
                 }
                 __builtin_amdgcn_wave_barrier();
             }
-            const int xoff = (lane & 7) * 8 + (lane >> 3);   // this pixel's place in a plane
             const float fx_col = qx0 + (float)pc;
             const mgr_v2f g0v = {g0, g0}, g1v = {g1, g1}, g2v = {g2, g2};
             bool alive = false;
@@ -313,20 +320,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BWD_WAVES, 
                     const float xe = pbs[0 + h], ye = pbs[2 + h];
                     const uint32_t pos = __float_as_uint(pbs[18 + h]);
                     const float dxc = xe - fx_col, dy0 = ye - qy0;
-                    const float* src = xch + (e2 >> 1) * BWD_ROW + h * BWD_PLANE_B + pc * 8;
+                    const float* src = xch + (e2 >> 1) * BWD_ROW + h * BWD_PLANE_B + 4 * pc;
                     mgr_v2f DY = {dy0, dy0 - 1.0f};
                     mgr_v2f B0 = {0.f, 0.f}, B1 = {0.f, 0.f}, B2 = {0.f, 0.f}, Cr = {0.f, 0.f}, Cg = {0.f, 0.f}, Cb = {0.f, 0.f};
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {   // rows 2k and 2k + 1 side by side
-                        const mgr_v2f vv = *(const mgr_v2f*)(src + 2 * k), ww = *(const mgr_v2f*)(src + BWD_PLANE_W + 2 * k);
-                        const mgr_v2f t1 = vv * DY;
-                        B0 += vv;
-                        B1 += t1;
-                        B2 += t1 * DY;
-                        Cr += ww * gr0[k];
-                        Cg += ww * gr1[k];
-                        Cb += ww * gr2[k];
-                        DY -= 2.0f;
+                    for (int j = 0; j < 2; ++j) {   // rows 4j .. 4j + 3, two side by side
+                        const float4 v4 = *(const float4*)(src + 32 * j), w4 = *(const float4*)(src + BWD_PLANE_W + 32 * j);
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const int k = 2 * j + q;
+                            const mgr_v2f vv = q ? mgr_v2f{v4.z, v4.w} : mgr_v2f{v4.x, v4.y};
+                            const mgr_v2f ww = q ? mgr_v2f{w4.z, w4.w} : mgr_v2f{w4.x, w4.y};
+                            const mgr_v2f t1 = vv * DY;
+                            B0 += vv;
+                            B1 += t1;
+                            B2 += t1 * DY;
+                            Cr += ww * gr0[k];
+                            Cg += ww * gr1[k];
+                            Cb += ww * gr2[k];
+                            DY -= 2.0f;
+                        }
                     }
                     const float A0 = B0.x + B0.y, A1 = B1.x + B1.y, A2 = B2.x + B2.y;
                     const float sr = Cr.x + Cr.y, sgn = Cg.x + Cg.y, sb = Cb.x + Cb.y;
