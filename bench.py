@@ -35,7 +35,8 @@ def pmc_counters(kernel, N, V, W, H):
     ((2*FETCH_SIZE + WRITE_SIZE) KB, the guide's gfx950 FETCH_SIZE correction) and the VALU issue fraction
     4 * SQ_INSTS_VALU / (1024 SIMDs * cycles): a wave64 VALU instruction occupies its SIMD for 4 cycles (transcendentals
     longer: a lower bound); cycles = the dispatch's duration in the same pass x 2.4 GHz (the peak engine clock; profiled
-    passes run slower, MI355X_MICROARCH.md: again a lower bound)."""
+    passes run slower, MI355X_MICROARCH.md: again a lower bound); and the share of cycles the CUs' LDS arrays were busy
+    (SQ_LDS_IDX_ACTIVE)."""
     try:
         d = json.load(open(PMC_FILE))
         if d.get("workload") != [N, V, W, H]:
@@ -44,6 +45,9 @@ def pmc_counters(kernel, N, V, W, H):
         out = {"traffic": k.get("hbm_bytes_per_launch"), "duration_ns": k.get("duration_ns")}
         if "SQ_INSTS_VALU" in k and k.get("duration_ns"):
             out["valu_issue_frac"] = round(4.0 * k["SQ_INSTS_VALU"] / (1024.0 * k["duration_ns"] * 2.4), 4)
+        if "SQ_LDS_IDX_ACTIVE" in k and k.get("duration_ns"):
+            # LDS-array cycles summed over the 256 CUs / (256 x cycles of the dispatch)
+            out["lds_active_frac"] = round(k["SQ_LDS_IDX_ACTIVE"] / (256.0 * k["duration_ns"] * 2.4), 4)
         return out
     except Exception:
         return {}
@@ -478,7 +482,12 @@ def main():
             if pmc.get("valu_issue_frac") is not None:
                 roof["valu_issue_frac"] = pmc["valu_issue_frac"]
                 ft = roof.get("frac_traffic") or 0.0
-                roof["limiter"] = "hbm" if ft > 0.6 else "valu-issue" if pmc["valu_issue_frac"] > 0.5 else "latency/occupancy (VALU + LDS, neither saturated)"
+                lf = pmc.get("lds_active_frac") or 0.0
+                if lf:
+                    roof["lds_active_frac"] = lf
+                vf = pmc["valu_issue_frac"]
+                roof["limiter"] = ("hbm" if ft > 0.6 else "lds + valu-issue" if (lf > 0.55 and vf > 0.45) else "valu-issue" if vf > 0.5
+                                   else "lds" if lf > 0.55 else "latency/occupancy (VALU + LDS, neither saturated)")
         if args.profile_all:
             tot = sum(v[1] for v in prof.values())
             for k, (c, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1]):

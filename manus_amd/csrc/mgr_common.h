@@ -410,7 +410,7 @@ __device__ __forceinline__ bool mgr_quad_bbox(unsigned long long am, int& x0, in
 // (v_pk_mul_f32 / v_pk_fma_f32: two lanes of fp32 per VGPR pair).  The survivors of one wave's
 // 64-entry batch are therefore written to LDS two by two, field-interleaved, so that one
 // ds_read_b128 returns (x_a, x_b, y_a, y_b) etc. already in register-pair order:
-//   [0] x_a x_b y_a y_b   [4] A_a A_b B_a B_b   [8] C_a C_b o_a o_b   [12] r_a r_b g_a g_b
+//   [0] x_a x_b y_a y_b   [4] A_a A_b B_a B_b   [8] C_a C_b o_a o_b   [12] r_a r_b g_a g_b (forward: r_a g_a r_b g_b)
 //   [16] b_a b_b pos_a pos_b
 // A, B, C are the conic pre-scaled so that  log2(G) = A dx^2 + B dx dy + C dy^2
 // (A = -0.5 log2e conic.x, B = -log2e conic.y, C = -0.5 log2e conic.z): the exponent feeds v_exp_f32
@@ -422,6 +422,9 @@ typedef float mgr_v2f __attribute__((ext_vector_type(2)));
 #define MGR_LOG2E 1.44269504088896341f
 #define MGR_LN2 0.69314718055994531f
 
+// RG_PER_ENTRY (forward blend): [12] r_a g_a r_b g_b -- (r, g) of one entry is a register pair, the colour sum is a
+// packed fma with the entry's weight; otherwise (backward) [12] r_a r_b g_a g_b like every other field.
+template <bool RG_PER_ENTRY = false>
 __device__ __forceinline__ void mgr_pair_store(float* pb, int half, float x, float y, float ca, float cb, float cc,
                                                float op, float r, float g, float b, uint32_t pos) {
     pb[0 + half] = x;
@@ -430,16 +433,21 @@ __device__ __forceinline__ void mgr_pair_store(float* pb, int half, float x, flo
     pb[6 + half] = (-MGR_LOG2E) * cb;
     pb[8 + half] = (-0.5f * MGR_LOG2E) * cc;
     pb[10 + half] = op;
-    pb[12 + half] = r;
-    pb[14 + half] = g;
+    pb[RG_PER_ENTRY ? 12 + 2 * half : 12 + half] = r;
+    pb[RG_PER_ENTRY ? 13 + 2 * half : 14 + half] = g;
     pb[16 + half] = b;
     pb[18 + half] = __uint_as_float(pos);
 }
 
 // the second slot of an odd pair: opacity 0 -> alpha 0 -> never valid
+template <bool RG_PER_ENTRY = false>
 __device__ __forceinline__ void mgr_pair_pad(float* pb) {
 #pragma unroll
-    for (int f = 0; f < 10; ++f) pb[2 * f + 1] = 0.0f;
+    for (int f = 0; f < 10; ++f) {
+        if (RG_PER_ENTRY && (f == 6 || f == 7)) continue;
+        pb[2 * f + 1] = 0.0f;
+    }
+    if (RG_PER_ENTRY) { pb[14] = 0.0f; pb[15] = 0.0f; }
 }
 
 // alpha of two entries at one pixel; pw = log2 of the Gaussian falloff (valid entries have pw <= 0).

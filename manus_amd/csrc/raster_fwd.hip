@@ -1634,7 +1634,8 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, 
         // them ended the kernel.  Long lists draw their ticket when they are done.
         const bool early_ticket = nlist < 2048u;
         if (tid == 0 && early_ticket) s_next = atomicAdd(&hdr->queue_head2, 1u);
-        float Tr = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
+        float Tr = 1.0f, C2 = 0.f;
+        mgr_v2f C01 = {0.f, 0.f};   // (red, green) prefix colour
         uint32_t last = 0;
 #ifdef MGR_STATS
         uint32_t stop_pos = 0;
@@ -1675,9 +1676,9 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, 
             if (alive) {
                 const int rank = __popcll(m & lt);
                 float* pb = slab + (rank >> 1) * MGR_PAIR_FLOATS;
-                mgr_pair_store(pb, rank & 1, rec.a.x, rec.a.y, rec.a.z, rec.a.w, rec.b.x, rec.b.y, rec.b.z, rec.b.w, rec.c,
+                mgr_pair_store<true>(pb, rank & 1, rec.a.x, rec.a.y, rec.a.z, rec.a.w, rec.b.x, rec.b.y, rec.b.z, rec.b.w, rec.c,
                                off + (uint32_t)lane + 1u);  // 1-based list position
-                if ((cnt & 1) && rank == cnt - 1) mgr_pair_pad(pb);
+                if ((cnt & 1) && rank == cnt - 1) mgr_pair_pad<true>(pb);
             }
             // issue the gathers of the following batches; they complete during the blend below
             {
@@ -1697,7 +1698,7 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, 
 #endif
             for (int p = 0; p < npair; ++p) {
                 const float4* pp = (const float4*)(slab + p * MGR_PAIR_FLOATS);
-                const float4 R0 = pp[0], R1 = pp[1], R2 = pp[2], R3 = pp[3], R4 = pp[4];
+                const float4 R0 = pp[0], R1 = pp[1], R2 = pp[2], R3 = pp[3], R4 = pp[4];   // (five ds_read_b128 with the (r, g)-per-entry layout)
                 mgr_v2f dx, dy, G, al;
                 bool va, vb;
                 mgr_pair_alpha(R0, R1, R2, fpx2, fpy2, dx, dy, G, al, va, vb);
@@ -1711,8 +1712,7 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, 
                     const float testT = Tr * (1.0f - a);
                     const bool stop = testT < 0.0001f;  // a == 0 leaves testT = Tr >= 1e-4
                     const float w = stop ? 0.0f : a * Tr;
-                    C0 += R3.x * w;
-                    C1 += R3.z * w;
+                    C01 += mgr_v2f{R3.x, R3.y} * w;
                     C2 += R4.x * w;
                     Tr = stop ? Tr : testT;
                     last = w > 0.0f ? __float_as_uint(R4.z) : last;
@@ -1726,8 +1726,7 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, 
                     const float testT = Tr * (1.0f - a);
                     const bool stop = testT < 0.0001f;
                     const float w = stop ? 0.0f : a * Tr;
-                    C0 += R3.y * w;
-                    C1 += R3.w * w;
+                    C01 += mgr_v2f{R3.z, R3.w} * w;
                     C2 += R4.y * w;
                     Tr = stop ? Tr : testT;
                     last = w > 0.0f ? __float_as_uint(R4.w) : last;
@@ -1747,7 +1746,7 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, 
             // backward pass process every MGR_CHUNK-entry chunk of the list independently
             const uint32_t nextpos = off + 64u;
             if ((nextpos % MGR_CHUNK) == 0 && nextpos < nlist)
-                ckpt[(size_t)(ck0 + nextpos / MGR_CHUNK - 1) * 256 + pslot] = make_float4(C0, C1, C2, Tr);
+                ckpt[(size_t)(ck0 + nextpos / MGR_CHUNK - 1) * 256 + pslot] = make_float4(C01.x, C01.y, C2, Tr);
             FP(3);
         }
         FP(3);
@@ -1758,8 +1757,8 @@ __global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, 
             ((uint32_t*)final_T)[(size_t)v * P + pix] = stop_pos;  // list position where this pixel saturated (0 = never)
 #endif
             float* o = out_color + (size_t)v * 3 * P + pix;
-            o[0] = C0 + Tr * bg0;
-            o[P] = C1 + Tr * bg1;
+            o[0] = C01.x + Tr * bg0;
+            o[P] = C01.y + Tr * bg1;
             o[2 * P] = C2 + Tr * bg2;
         }
         // list depth each quadrant consumed; the tile's maximum drives the backward pass
