@@ -429,6 +429,25 @@ int mgr_contact_dist(int N1, const float* pt1, int N2, const float* pt2, float* 
                      void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Skin-weight initialisation from the MANO rest mesh (model-initialisation side of the
+ * dataloader): the device half of init_mano_weights (src/utils/train_utils.py:48-89) as called by
+ * Dataset.build_voxel_grid / Dataset.sample_gaussians_on_bones (src/datasets/brics_dynamic.py:69-144).
+ *
+ * mgr_knn_mean_rows: for each of the n points (n,3) its k nearest of the m reference points (m,3) by squared Euclidean
+ *   distance (replaces torch.cdist(points, mano_verts).topk(k, largest=False), train_utils.py:70-72; ties keep the lower
+ *   index), out (n,C) = mean of rows[idx] (m,C) added nearest first in fp32 (np.mean(init_weights[indices], axis=1),
+ *   :73), out_idx (n,k) int32 the indices (nearest first; -1 beyond m).  Either output may be NULL.  1 <= k <= 32.
+ * mgr_mesh_sdf: signed distance (n,) of the points to the triangle mesh verts (nv,3) / faces (nf,3) int32, positive
+ *   inside (replaces pysdf.SDF(verts, faces)(points), train_utils.py:55-58; pysdf is an external package that is not in
+ *   this image: parity unpinned).  |distance| is the exact point-triangle minimum; the sign comes from the generalised
+ *   winding number (|sum of solid angles| / 4 pi > 1/2), also written to out_winding (n,) when not NULL.
+ * ------------------------------------------------------------------------ */
+int mgr_knn_mean_rows(int n, const float* points, int m, const float* refs, const float* rows, int C, int k, float* out,
+                      int32_t* out_idx, void* stream);
+int mgr_mesh_sdf(int n, const float* points, int nv, const float* verts, int nf, const int32_t* faces, float* out_sdf,
+                 float* out_winding, void* stream);
+
+/* ------------------------------------------------------------------------
  * Measurement aid: when enabled, every kernel launched by this library is
  * bracketed by HIP events recorded on the caller's stream.
  * mgr_profile_report synchronises the stream, writes one line per kernel

@@ -80,6 +80,8 @@ SIGNATURES = {
     "mgr_isotropic_reg": (c_int, [c_int, c_vp, c_f32, c_f32, c_vp, c_int, c_vp, c_vp, c_sz, c_vp]),
     "mgr_contact_workspace_bytes": (c_sz, [c_int, c_int]),
     "mgr_contact_dist": (c_int, [c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "mgr_knn_mean_rows": (c_int, [c_int, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp]),
+    "mgr_mesh_sdf": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp]),
     "mgr_profile_enable": (c_int, [c_int]),
     "mgr_profile_filter": (c_int, [ctypes.c_char_p]),
     "mgr_profile_report": (c_int, [ctypes.c_char_p, c_sz, c_vp]),

@@ -1,0 +1,205 @@
+// Skin-weight initialisation from the MANO rest mesh for gfx950 (the model-initialisation side of
+// the dataloader): what Dataset.build_voxel_grid and Dataset.sample_gaussians_on_bones compute through
+// init_mano_weights (/root/reference/src/datasets/brics_dynamic.py:69-144, /root/reference/src/utils/train_utils.py:48-89):
+//
+//   k_knn_mean_rows   for every query point the k nearest mesh vertices (torch.cdist + topk(largest=False)) and the mean
+//                     of their weight rows, summed nearest first in fp32 like np.mean over the gathered (n, k, C) block;
+//   k_mesh_sdf        the signed distance of every query point to the triangle mesh (the reference: pysdf.SDF, positive
+//                     inside): exact point-triangle distance, sign from the generalised winding number
+//                     sum_f Omega_f / 4 pi > 1/2 (Van Oosterom-Strackee solid angles) -- well defined for MANO's open
+//                     wrist (16 boundary edges), where a ray-parity count depends on the ray.
+//
+// Both are brute force over the mesh (778 vertices, 1538 faces), the mesh streamed through LDS once per workgroup, one
+// query per thread: 3.2 M grid points (196 x 142 x 116, the default grid) x 1538 faces = 4.9 G point-triangle tests.
+// Run once per training run; nothing here is on the per-step path.
+#include "mgr_common.h"
+
+#define MS_T 256
+#define MS_KMAX 32
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k nearest rows.  The running list is kept sorted (nearest first) in registers / scratch; a candidate enters only when it
+// beats the current k-th distance (strictly: among equal distances the lower index stays, the order torch.topk yields
+// for exact ties is unspecified).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(MS_T) void k_knn_mean_rows(int n, const float* __restrict__ pts, int m,
+                                                        const float* __restrict__ refs, const float* __restrict__ rows,
+                                                        int C, int k_rt, float* __restrict__ out,
+                                                        int32_t* __restrict__ out_idx) {
+    __shared__ float4 s_ref[MS_T];
+    const int tid = threadIdx.x, i = blockIdx.x * MS_T + tid;
+    const int k = K > 0 ? K : k_rt;
+    float px = 0.f, py = 0.f, pz = 0.f;
+    if (i < n) { px = pts[3 * (size_t)i]; py = pts[3 * (size_t)i + 1]; pz = pts[3 * (size_t)i + 2]; }
+    float bd[K > 0 ? K : MS_KMAX];
+    int bi[K > 0 ? K : MS_KMAX];
+#pragma unroll
+    for (int j = 0; j < (K > 0 ? K : MS_KMAX); ++j) { bd[j] = 3.0e38f; bi[j] = 0; }
+    for (int j0 = 0; j0 < m; j0 += MS_T) {
+        const int cnt = min(MS_T, m - j0);
+        __syncthreads();
+        if (tid < cnt) {
+            const float* r = refs + 3 * (size_t)(j0 + tid);
+            s_ref[tid] = make_float4(r[0], r[1], r[2], 0.f);
+        }
+        __syncthreads();
+        for (int t = 0; t < cnt; ++t) {
+            const float4 q = s_ref[t];
+            const float dx = px - q.x, dy = py - q.y, dz = pz - q.z;
+            float d = dx * dx + dy * dy + dz * dz;
+            if (d < bd[k - 1]) {
+                int id = j0 + t;
+                if (K > 0) {   // fully unrolled compare-exchange chain: everything stays in registers
+#pragma unroll
+                    for (int j = 0; j < K; ++j) {
+                        if (d < bd[j]) {
+                            const float td = bd[j]; const int ti = bi[j];
+                            bd[j] = d; bi[j] = id; d = td; id = ti;
+                        }
+                    }
+                } else {
+                    int j = k - 1;
+                    while (j > 0 && bd[j - 1] > d) { bd[j] = bd[j - 1]; bi[j] = bi[j - 1]; --j; }
+                    bd[j] = d; bi[j] = id;
+                }
+            }
+        }
+    }
+    if (i >= n) return;
+    const int kk = min(k, m);
+    if (out_idx)
+        for (int j = 0; j < k; ++j) out_idx[(size_t)i * k + j] = j < kk ? bi[j] : -1;
+    if (out) {
+        const float inv = 1.0f / (float)k;
+        for (int c = 0; c < C; ++c) {
+            float s = 0.f;
+            for (int j = 0; j < kk; ++j) s += rows[(size_t)bi[j] * C + c];
+            out[(size_t)i * C + c] = s * inv;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// signed distance to a triangle mesh
+// ---------------------------------------------------------------------------------------------------------------------
+struct MsTri {
+    float ax, ay, az, bx, by, bz, cx, cy, cz;
+};
+
+// squared distance from p to triangle (a, b, c): the closest point by the Voronoi regions of the triangle's features
+// (Ericson, Real-Time Collision Detection 5.1.5)
+__device__ __forceinline__ float ms_tri_dist2(float px, float py, float pz, const MsTri& t) {
+    const float abx = t.bx - t.ax, aby = t.by - t.ay, abz = t.bz - t.az;
+    const float acx = t.cx - t.ax, acy = t.cy - t.ay, acz = t.cz - t.az;
+    const float apx = px - t.ax, apy = py - t.ay, apz = pz - t.az;
+    const float d1 = abx * apx + aby * apy + abz * apz, d2 = acx * apx + acy * apy + acz * apz;
+    float qx, qy, qz;
+    if (d1 <= 0.f && d2 <= 0.f) { qx = t.ax; qy = t.ay; qz = t.az; }
+    else {
+        const float bpx = px - t.bx, bpy = py - t.by, bpz = pz - t.bz;
+        const float d3 = abx * bpx + aby * bpy + abz * bpz, d4 = acx * bpx + acy * bpy + acz * bpz;
+        if (d3 >= 0.f && d4 <= d3) { qx = t.bx; qy = t.by; qz = t.bz; }
+        else {
+            const float vc = d1 * d4 - d3 * d2;
+            if (vc <= 0.f && d1 >= 0.f && d3 <= 0.f) {
+                const float v = d1 / (d1 - d3);
+                qx = t.ax + v * abx; qy = t.ay + v * aby; qz = t.az + v * abz;
+            } else {
+                const float cpx = px - t.cx, cpy = py - t.cy, cpz = pz - t.cz;
+                const float d5 = abx * cpx + aby * cpy + abz * cpz, d6 = acx * cpx + acy * cpy + acz * cpz;
+                if (d6 >= 0.f && d5 <= d6) { qx = t.cx; qy = t.cy; qz = t.cz; }
+                else {
+                    const float vb = d5 * d2 - d1 * d6;
+                    if (vb <= 0.f && d2 >= 0.f && d6 <= 0.f) {
+                        const float w = d2 / (d2 - d6);
+                        qx = t.ax + w * acx; qy = t.ay + w * acy; qz = t.az + w * acz;
+                    } else {
+                        const float va = d3 * d6 - d5 * d4;
+                        if (va <= 0.f && (d4 - d3) >= 0.f && (d5 - d6) >= 0.f) {
+                            const float w = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+                            qx = t.bx + w * (t.cx - t.bx); qy = t.by + w * (t.cy - t.by); qz = t.bz + w * (t.cz - t.bz);
+                        } else {
+                            const float den = 1.0f / (va + vb + vc);
+                            const float v = vb * den, w = vc * den;
+                            qx = t.ax + abx * v + acx * w; qy = t.ay + aby * v + acy * w; qz = t.az + abz * v + acz * w;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    const float ex = px - qx, ey = py - qy, ez = pz - qz;
+    return ex * ex + ey * ey + ez * ez;
+}
+
+// solid angle of the triangle seen from p (signed by the orientation), Van Oosterom & Strackee 1983
+__device__ __forceinline__ float ms_solid_angle(float px, float py, float pz, const MsTri& t) {
+    const float ax = t.ax - px, ay = t.ay - py, az = t.az - pz;
+    const float bx = t.bx - px, by = t.by - py, bz = t.bz - pz;
+    const float cx = t.cx - px, cy = t.cy - py, cz = t.cz - pz;
+    const float la = sqrtf(ax * ax + ay * ay + az * az), lb = sqrtf(bx * bx + by * by + bz * bz),
+                lc = sqrtf(cx * cx + cy * cy + cz * cz);
+    const float det = ax * (by * cz - bz * cy) - ay * (bx * cz - bz * cx) + az * (bx * cy - by * cx);
+    const float den = la * lb * lc + (ax * bx + ay * by + az * bz) * lc + (bx * cx + by * cy + bz * cz) * la +
+                      (cx * ax + cy * ay + cz * az) * lb;
+    return 2.0f * atan2f(det, den);
+}
+
+__global__ __launch_bounds__(MS_T) void k_mesh_sdf(int n, const float* __restrict__ pts, int nf,
+                                                   const float* __restrict__ verts, const int32_t* __restrict__ faces,
+                                                   float* __restrict__ out_sdf, float* __restrict__ out_wind) {
+    __shared__ MsTri s_tri[MS_T];
+    const int tid = threadIdx.x, i = blockIdx.x * MS_T + tid;
+    float px = 0.f, py = 0.f, pz = 0.f;
+    if (i < n) { px = pts[3 * (size_t)i]; py = pts[3 * (size_t)i + 1]; pz = pts[3 * (size_t)i + 2]; }
+    float best = 3.0e38f, omega = 0.f;
+    for (int f0 = 0; f0 < nf; f0 += MS_T) {
+        const int cnt = min(MS_T, nf - f0);
+        __syncthreads();
+        if (tid < cnt) {
+            const int32_t* f = faces + 3 * (size_t)(f0 + tid);
+            const float *a = verts + 3 * (size_t)f[0], *b = verts + 3 * (size_t)f[1], *c = verts + 3 * (size_t)f[2];
+            s_tri[tid] = MsTri{a[0], a[1], a[2], b[0], b[1], b[2], c[0], c[1], c[2]};
+        }
+        __syncthreads();
+        for (int t = 0; t < cnt; ++t) {
+            const MsTri tr = s_tri[t];
+            best = fminf(best, ms_tri_dist2(px, py, pz, tr));
+            omega += ms_solid_angle(px, py, pz, tr);
+        }
+    }
+    if (i >= n) return;
+    const float w = omega * (1.0f / 12.566370614359172f);
+    const float d = sqrtf(best);
+    out_sdf[i] = fabsf(w) > 0.5f ? d : -d;   // positive inside, like pysdf
+    if (out_wind) out_wind[i] = w;
+}
+
+extern "C" int mgr_knn_mean_rows(int n, const float* points, int m, const float* refs, const float* rows, int C, int k,
+                                 float* out, int32_t* out_idx, void* stream_) {
+    if (n < 0 || m < 0 || k < 1 || k > MS_KMAX || (out && C < 1)) return mgr_fail(MGR_EINVAL, "mgr_knn_mean_rows: bad sizes (1 <= k <= 32)");
+    if (n == 0) return MGR_OK;
+    if (!points || (m > 0 && !refs) || (out && !rows) || (!out && !out_idx)) return mgr_fail(MGR_EINVAL, "mgr_knn_mean_rows: null pointer");
+    hipStream_t stream = (hipStream_t)stream_;
+    const dim3 grid((n + MS_T - 1) / MS_T), block(MS_T);
+    MGR_PROF("k_knn_mean_rows", stream);
+    if (k == 4) hipLaunchKernelGGL(k_knn_mean_rows<4>, grid, block, 0, stream, n, points, m, refs, rows, C, k, out, out_idx);
+    else if (k == 1) hipLaunchKernelGGL(k_knn_mean_rows<1>, grid, block, 0, stream, n, points, m, refs, rows, C, k, out, out_idx);
+    else hipLaunchKernelGGL(k_knn_mean_rows<0>, grid, block, 0, stream, n, points, m, refs, rows, C, k, out, out_idx);
+    MGR_LAUNCH_CHECK("k_knn_mean_rows", stream, 0);
+    return MGR_OK;
+}
+
+extern "C" int mgr_mesh_sdf(int n, const float* points, int nv, const float* verts, int nf, const int32_t* faces,
+                            float* out_sdf, float* out_winding, void* stream_) {
+    if (n < 0 || nv < 0 || nf < 0) return mgr_fail(MGR_EINVAL, "mgr_mesh_sdf: bad sizes");
+    if (n == 0) return MGR_OK;
+    if (!points || !out_sdf || (nf > 0 && (!verts || !faces))) return mgr_fail(MGR_EINVAL, "mgr_mesh_sdf: null pointer");
+    hipStream_t stream = (hipStream_t)stream_;
+    MGR_PROF("k_mesh_sdf", stream);
+    hipLaunchKernelGGL(k_mesh_sdf, dim3((n + MS_T - 1) / MS_T), dim3(MS_T), 0, stream, n, points, nf, verts, faces, out_sdf,
+                       out_winding);
+    MGR_LAUNCH_CHECK("k_mesh_sdf", stream, 0);
+    return MGR_OK;
+}

@@ -415,6 +415,35 @@ class SequenceDataset(torch.utils.data.Dataset):
                 "scaling_modifier": 1.0, "bg_color": to_tensor(self.get_bg_color()), "bones_rest": to_tensor(rest),
                 "bones_posed": to_tensor(posed), "pose_latent": md["pose_latent"]}
 
+    # -- model initialisation (brics_dynamic.py:69-144) -------------------------------------------------------
+    def _first_rest(self):
+        action, fno = self.index_list[0][0], self.index_list[0][1]
+        return to_tensor(Bones(**self.metadata_dict[action][str(fno)]["bones_rest"].__dict__))
+
+    def sample_gaussians_on_bones(self, sample_size, mano_weights=False, init_type=None, generator=None, device=None):
+        """(points, point colours, MANO skin weights or None): `sample_size` Gaussians per bone + half as many per joint
+        around the first frame's rest skeleton (train_utils.py:104-139; the draws come from `generator`, not from the
+        reference's global RNG stream), their weights from the nearest MANO vertices (`mano_init.init_mano_weights`; GPU).
+        The reference's .ply dumps are left to the caller."""
+        from . import mano_init, synthetic as S
+        b = self._first_rest()
+        gen = generator or torch.Generator().manual_seed(0)
+        points = S.sample_on_bones(b.heads, b.tails, b.transforms, sample_size, gen)
+        colors = torch.rand(points.shape, generator=gen)
+        weights = None
+        if mano_weights:
+            if init_type not in ("mano_init_voxel", "mano_init_points"):
+                raise ValueError("init_type must be 'mano_init_voxel' or 'mano_init_points'")
+            w, _ = mano_init.init_mano_weights(points, self.mano_data, filter_grid=init_type == "mano_init_voxel", device=device)
+            weights = to_tensor(w)
+        return points, colors, weights
+
+    def build_voxel_grid(self, grid_boundary=(-1, 1), res=128, ratio=(1, 1, 1), offset=(0, 0, 0), device=None):
+        """(scale, center, grid_points, weights, mask) of the skin-weight voxel grid around the first frame's rest
+        skeleton (brics_dynamic.py:99-144): `mano_init.build_voxel_grid` on this capture's `mano_rest` group."""
+        from . import mano_init
+        return mano_init.build_voxel_grid(self._first_rest(), self.mano_data, grid_boundary, res, ratio, offset, device)
+
     # -- hand-off to the engine --------------------------------------------------------------------------------
     def view_batch(self, indices, device="cpu"):
         """Items -> what `engine.HipViewCompute` consumes for one step: targets (V,3,H,W), masks (V,H,W), the camera

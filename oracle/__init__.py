@@ -7,6 +7,9 @@ when its HIP extension is missing.
 * torch_ref.py      — pure-PyTorch restatement of the reference's LBS / covariance
                       / SH / camera / FK code (pinned by tests/golden/*.npz which
                       were produced by importing the reference).
+* mesh_ref.py       — float64 numpy restatement of init_mano_weights (pinned by
+                      tests/golden/mano_init.npz) and of the pysdf signed distance
+                      it calls (PARITY UNPINNED: pysdf is not in this image).
 * raster_oracle.c   — scalar C restatement of the external rasterizer + kNN
                       (PARITY UNPINNED upstream: no reference tests or vectors
                       exist for that boundary; see raster_oracle_impl.h).

@@ -825,11 +825,50 @@ def make_testdataset_golden(mods):
     return out
 
 
+def make_mano_init_golden(mods):
+    """src/utils/train_utils.py::init_mano_weights (48-89) with filter_grid=False (the filter needs pysdf, which is not in
+    this image) and src/utils/extra.py::create_skinning_grid, on the reference's own data/mano/mano_rest.pkl, committed as
+    tests/golden/mano_rest.npz (verts, faces, weights: data).  trimesh / matplotlib are stubs: the .ply dumps and the
+    colour map inside init_mano_weights are replaced by no-ops (they do not touch the returned weights)."""
+    import tempfile
+    import joblib
+    import src.utils.train_utils as tu
+    import src.utils.extra as extra
+    md = joblib.load(os.path.join(REF, "data/mano/mano_rest.pkl"))
+    verts, faces, weights = (np.asarray(md["vert"], np.float32), np.asarray(md["faces"], np.int32),
+                             np.asarray(md["weights"], np.float32))
+    np.savez_compressed(os.path.join(OUT, "mano_rest.npz"), verts=verts, faces=faces, weights=weights)
+    tu.dump_points = lambda *a, **k: None
+    tu.visualize_skin_weights = lambda w: None
+    data = {"verts": verts, "weights": weights, "face": faces}
+    g = np.random.default_rng(7)
+    lo, hi = verts.min(0) - 0.03, verts.max(0) + 0.03
+    pts = torch.tensor(g.uniform(lo, hi, size=(2500, 3)).astype(np.float32))
+    out = {"points": pts.numpy()}
+    cwd = os.getcwd()
+    os.chdir(tempfile.mkdtemp())
+    try:
+        for k in (4, 20):
+            w, mask = tu.init_mano_weights(pts, data, neighbors=k, filter_grid=False)
+            assert mask is None
+            out["weights_k%d" % k] = np.asarray(w)
+            # the neighbour sets themselves (same calls as train_utils.py:70-72), to tell near-ties from errors
+            d = torch.cdist(pts, torch.tensor(verts))
+            out["idx_k%d" % k] = d.topk(k, largest=False)[1].numpy().astype(np.int32)
+    finally:
+        os.chdir(cwd)
+    out["grid_3_4_5"] = extra.create_skinning_grid(3, 4, 5).numpy()
+    return out
+
+
 def main():
     mods = _import_reference()
     torch.manual_seed(0)
     if "--dataset" in sys.argv:    # round 2: the sequence reader (SURVEY 8 f4)
         np.savez_compressed(os.path.join(OUT, "dataset.npz"), **make_dataset_golden(mods))
+        return
+    if "--mano" in sys.argv:    # round 3: skin-weight initialisation from the MANO rest mesh
+        np.savez_compressed(os.path.join(OUT, "mano_init.npz"), **make_mano_init_golden(mods))
         return
     if "--testdataset" in sys.argv:    # round 3: evaluation trajectories (SURVEY 8 f4)
         np.savez_compressed(os.path.join(OUT, "testdataset.npz"), **make_testdataset_golden(mods))

@@ -1,0 +1,148 @@
+"""GPU: skin-weight initialisation from the MANO rest mesh (csrc/mesh.hip, manus_amd/mano_init.py) against the reference's own
+init_mano_weights (tests/golden/mano_init.npz, generator tests/golden/make_golden.py --mano) and the float64 restatement
+oracle/mesh_ref.py.  The mesh is the reference's data/mano/mano_rest.pkl, committed as tests/golden/mano_rest.npz."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def mano(golden_dir):
+    m = np.load(os.path.join(golden_dir, "mano_rest.npz"))
+    return {"verts": m["verts"], "weights": m["weights"], "face": m["faces"]}
+
+
+@pytest.mark.parametrize("k", [4, 20])
+def test_nearest_vertex_weights_equal_the_reference(golden_dir, mano, k):
+    from manus_amd import mano_init as MI
+    from oracle import mesh_ref as R
+    g = np.load(os.path.join(golden_dir, "mano_init.npz"))
+    w, mask = MI.init_mano_weights(g["points"], mano, neighbors=k, filter_grid=False, device=DEV)
+    assert mask is None and w.dtype == np.float32 and w.shape == (len(g["points"]), 20)
+    ref = g["weights_k%d" % k]
+    off = np.abs(w - ref).max(1) > 2e-6
+    # a row may differ only where the k-th and (k+1)-th nearest vertices are within fp32 rounding of each other
+    # (torch.cdist's |x|^2 + |y|^2 - 2 x.y loses the order there, the kernel's exact differences do not)
+    _, d2 = R.knn_indices(g["points"], mano["verts"], k)
+    near_tie = (d2[:, k] - d2[:, k - 1]) < 1e-5 * d2[:, k]
+    assert not (off & ~near_tie).any(), int((off & ~near_tie).sum())
+    assert off.mean() < 0.01
+    pts = torch.tensor(g["points"], device=DEV)
+    _, idx = MI.knn_mean_rows(pts, torch.tensor(mano["verts"], device=DEV), torch.zeros((778, 1), device=DEV), k, want_idx=True)
+    same = (np.sort(idx.cpu().numpy(), 1) == np.sort(g["idx_k%d" % k], 1)).all(1)
+    assert not (~same & ~near_tie).any()
+    exact, _ = R.knn_indices(g["points"][:300], mano["verts"], k)
+    assert (idx.cpu().numpy()[:300] == exact)[~near_tie[:300]].all()          # nearest first
+
+
+def test_knn_edge_cases():
+    from manus_amd import mano_init as MI
+    from manus_amd._lib import ManusHipError
+    refs = torch.tensor([[0.0, 0, 0], [1, 0, 0], [1, 0, 0], [5, 0, 0]], device=DEV)
+    rows = torch.tensor([[1.0, 0], [0, 1], [0, 3], [8, 8]], device=DEV)
+    out, idx = MI.knn_mean_rows(torch.tensor([[0.9, 0, 0]], device=DEV), refs, rows, 2, want_idx=True)
+    assert idx.cpu().tolist() == [[1, 2]] and out.cpu().tolist() == [[0.0, 2.0]]     # equal distances: the lower index first
+    out, idx = MI.knn_mean_rows(torch.tensor([[0.0, 0, 0]], device=DEV), refs[:2], rows[:2], 4, want_idx=True)
+    assert idx.cpu().tolist() == [[0, 1, -1, -1]] and out.cpu().tolist() == [[0.25, 0.25]]   # fewer references than k
+    assert MI.knn_mean_rows(torch.zeros((0, 3), device=DEV), refs, rows, 4).shape == (0, 2)
+    with pytest.raises(ManusHipError):
+        MI.knn_mean_rows(torch.zeros((1, 3), device=DEV), refs, rows, 33)
+    with pytest.raises(ManusHipError):
+        MI.knn_mean_rows(torch.zeros((1, 3)), refs.cpu(), rows.cpu(), 4)
+
+
+def test_signed_distance_of_a_cube_is_analytic():
+    from manus_amd import mano_init as MI
+    V = torch.tensor([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], [0, 0, 1], [1, 0, 1], [1, 1, 1], [0, 1, 1]], dtype=torch.float32, device=DEV)
+    F = torch.tensor([[0, 2, 1], [0, 3, 2], [4, 5, 6], [4, 6, 7], [0, 1, 5], [0, 5, 4], [2, 3, 7], [2, 7, 6], [1, 2, 6], [1, 6, 5],
+                      [0, 4, 7], [0, 7, 3]], device=DEV)
+    P = torch.tensor([[0.5, 0.5, 0.5], [0.5, 0.5, 0.9], [1.5, 0.5, 0.5], [2, 2, 2], [0.2, 0.5, 0.5], [-1, -1, 0.5]], device=DEV)
+    sdf, wind = MI.mesh_sdf(P, V, F, want_winding=True)
+    np.testing.assert_allclose(sdf.cpu().numpy(), [0.5, 0.1, -0.5, -np.sqrt(3.0), 0.2, -np.sqrt(2.0)], atol=1e-6)
+    np.testing.assert_allclose(np.abs(wind.cpu().numpy()), [1, 1, 0, 0, 1, 0], atol=1e-5)
+    sdf_flipped = MI.mesh_sdf(P, V, F[:, [0, 2, 1]])                  # the orientation of the faces does not matter
+    np.testing.assert_allclose(sdf_flipped.cpu().numpy(), sdf.cpu().numpy(), atol=1e-6)
+
+
+def test_signed_distance_to_the_mano_mesh_equals_the_oracle(golden_dir, mano):
+    from manus_amd import mano_init as MI
+    from oracle import mesh_ref as R
+    g = np.load(os.path.join(golden_dir, "mano_init.npz"))
+    pts = g["points"][:500]
+    sdf, wind = MI.mesh_sdf(torch.tensor(pts, device=DEV), torch.tensor(mano["verts"], device=DEV),
+                            torch.tensor(mano["face"].astype(np.int64), device=DEV), want_winding=True)
+    ref, rw = R.mesh_sdf(pts, mano["verts"], mano["face"])
+    np.testing.assert_allclose(np.abs(sdf.cpu().numpy()), np.abs(ref), atol=2e-6)
+    np.testing.assert_allclose(wind.cpu().numpy(), rw, atol=2e-4)
+    clear = np.abs(np.abs(rw) - 0.5) > 1e-3
+    assert (np.sign(sdf.cpu().numpy()) == np.sign(ref))[clear].all()
+    assert 0.02 < (ref > 0).mean() < 0.6                              # the sample holds points on both sides
+
+
+def test_init_with_the_outside_filter_follows_the_restated_reference(golden_dir, mano):
+    from manus_amd import mano_init as MI
+    from oracle import mesh_ref as R
+    g = np.load(os.path.join(golden_dir, "mano_init.npz"))
+    pts = g["points"][:400]
+    w, mask = MI.init_mano_weights(pts, mano, neighbors=4, filter_grid=True, device=DEV)
+    rw, rmask = R.init_mano_weights(pts, mano, neighbors=4, filter_grid=True)
+    assert w.dtype == np.float64 and w.shape == (400, 21) and mask.dtype == bool     # the reference's dtypes
+    sdf, _ = R.mesh_sdf(pts, mano["verts"], mano["face"])
+    clear = np.abs(sdf + 0.02) > 1e-5
+    assert (mask == rmask)[clear].all()
+    np.testing.assert_allclose(w[clear], rw[clear], atol=2e-6)
+    np.testing.assert_allclose(w.sum(-1), 1.0, atol=1e-12)
+    out = sdf < -0.02
+    assert out.any() and (w[out & clear, -1] == 1).all() and (w[~out & clear, -1] == 0).all()
+
+
+def test_voxel_grid_feeds_the_skin_weight_kernel(golden_dir, mano):
+    """Dataset.build_voxel_grid's arithmetic (brics_dynamic.py:99-144) on the novel-pose rest skeleton, then the grid through
+    `ops.skin_weights` (a2): at the voxel centres the trilinear lookup returns the voxel's own row."""
+    from manus_amd import dataset as D, mano_init as MI, ops
+    ind = os.path.join(golden_dir, "eval_inputs")
+    ds = D.TestDataset(dict(cam_path=os.path.join(ind, "camera_path.npz"), cano_cam_path=os.path.join(ind, "cano_camera.npz"),
+                            metadata_path=os.path.join(ind, "novel_pose.npz")))
+    b = ds.bones_rest
+    # the MANO rest mesh lives in its own frame: move it onto this skeleton's extent so that part of the grid is inside
+    kp = torch.cat([b.heads[:1], b.tails]).numpy()
+    v = mano["verts"]
+    v2 = (v - v.mean(0)) * (np.linalg.norm(kp.max(0) - kp.min(0)) / np.linalg.norm(v.max(0) - v.min(0))) + (kp.max(0) + kp.min(0)) / 2
+    data = dict(mano, verts=v2.astype(np.float32))
+    scale, center, gp, w, mask = MI.build_voxel_grid(b, data, res=24, ratio=(1.1, 0.9, 0.65), offset=(0.0, 0.0, 0.0), device=DEV)
+    d, h, wd = int(24 / 0.65), int(24 / 0.9), int(24 / 1.1)
+    assert gp.shape == (d, h, wd, 3) and w.shape == (d, h, wd, 21) and mask.shape == (d, h, wd) and scale.shape == (1, 3)
+    assert w.dtype == torch.float32 and torch.allclose(w.sum(-1), torch.ones(()), atol=1e-6)
+    assert 0.01 < float(mask.float().mean()) < 0.9
+    np.testing.assert_allclose(center.numpy(), (kp.max(0) + kp.min(0)) / 2, atol=1e-7)
+    np.testing.assert_allclose(gp[0, 0, 0].numpy(), center.numpy() - scale.numpy()[0], atol=1e-6)       # lattice corner (-1,-1,-1)
+    np.testing.assert_allclose(gp[-1, -1, -1].numpy(), center.numpy() + scale.numpy()[0], atol=1e-6)
+    q = gp[2:-2:3, 2:-2:3, 2:-2:3].reshape(-1, 3).to(DEV)
+    got = ops.skin_weights(q, w.to(DEV), center.to(DEV), scale.to(DEV))
+    want = w[2:-2:3, 2:-2:3, 2:-2:3].reshape(-1, 21).to(DEV)
+    assert float((got - want).abs().max()) < 2e-4
+
+
+def test_dataset_methods_delegate(golden_dir, tmp_path, mano):
+    import shutil
+    from manus_amd import dataset as D
+    for f in os.listdir(os.path.join(golden_dir, "seq")):
+        shutil.copy(os.path.join(golden_dir, "seq", f), tmp_path / f)
+    cfg = dict(resize_factor=1.0, bg_color="white", subject="s1", width=64, height=48, rand_views_per_timestep=-1, n_bones=20,
+               num_time_steps=-1, split_ratio=1.0, sequences=["grasp_2"], split_by_action=False)
+    ds = D.SequenceDataset(str(tmp_path), cfg, "train")
+    ds.mano_data = mano                                         # (the synthetic capture's mano_rest group holds no faces)
+    pts, cols, w = ds.sample_gaussians_on_bones(40, mano_weights=True, init_type="mano_init_points", device=DEV)
+    assert pts.shape == (20 * 40 + 20 * 20, 3) and cols.shape == pts.shape and w.shape == (pts.shape[0], 20)
+    assert torch.allclose(w.sum(-1), torch.ones(()), atol=1e-5)
+    _, _, w2 = ds.sample_gaussians_on_bones(40, mano_weights=True, init_type="mano_init_voxel", device=DEV)
+    assert w2.shape == (pts.shape[0], 21)
+    with pytest.raises(ValueError):
+        ds.sample_gaussians_on_bones(4, mano_weights=True, init_type="other")
+    scale, center, gp, gw, mask = ds.build_voxel_grid(res=12, ratio=(1.0, 1.0, 1.0), device=DEV)
+    assert gw.shape == (12, 12, 12, 21) and gp.shape == (12, 12, 12, 3)
