@@ -294,14 +294,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(local_rank)                     # before the process group: RCCL binds its communicator to the current device
+    dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # "nccl" is RCCL on ROCm; MANUS_BENCH_BACKEND=gloo lets the N>1 path be exercised on a
         # single-GPU box (all ranks then share device 0)
         dist.init_process_group(os.environ.get("MANUS_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
-    local_rank = local_rank % max(1, torch.cuda.device_count())
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
 
     from manus_amd import _lib, rasterizer
     from manus_amd.engine import HipViewCompute, ViewShardedStep
