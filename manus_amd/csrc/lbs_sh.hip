@@ -183,6 +183,43 @@ __global__ __launch_bounds__(256) void k_skin_fwd24(int N, const float* __restri
         if (b < B) out_w[(size_t)i * B + b] = acc[b] / sum;
 }
 
+// Eight lanes per Gaussian, one per corner: a lane fetches its corner's 96-byte row (six float4 of one or two cache lines),
+// weights it, and the eight rows are summed with a transposing DPP reduction that leaves channel (8 m + k) in lane k.
+// k_skin_fwd24 above keeps all 48 loads of a Gaussian in one thread: 190 VGPRs, two waves per SIMD, 1.5 resident on
+// average over the launch -- the gather is latency-bound (VALU 0.08, HBM 0.43 of peak by the counters) and wants waves
+// in flight, not loads per wave.  Here a wave holds 8 Gaussians and ~50 VGPRs.  The sum over the corners is a tree instead
+// of a chain (last-bit differences against the one-thread kernel).
+__global__ __launch_bounds__(256) void k_skin_fwd24x8(int N, const float* __restrict__ xyz,
+                                                      const float4* __restrict__ grid, int D, int H, int W,
+                                                      int B, const float* __restrict__ center,
+                                                      const float* __restrict__ scale,
+                                                      float* __restrict__ out_w) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int i = min(t >> 3, N - 1), k = t & 7;   // (the tail group recomputes the last Gaussian: lanes stay convergent for the DPP sums)
+    const TriSetup s = tri_setup(xyz, i, center, scale, D, H, W);
+    const float wx = (k & 1) ? s.fx : 1.0f - s.fx, wy = (k & 2) ? s.fy : 1.0f - s.fy, wz = (k & 4) ? s.fz : 1.0f - s.fz;
+    const int x = s.x0 + (k & 1), y = s.y0 + ((k >> 1) & 1), z = s.z0 + (k >> 2);
+    const bool inb = x >= 0 && x < W && y >= 0 && y < H && z >= 0 && z < D;
+    const int xc = min(max(x, 0), W - 1), yc = min(max(y, 0), H - 1), zc = min(max(z, 0), D - 1);
+    const float wk = inb ? (wx * wy) * wz : 0.f;
+    const float4* p = grid + (((size_t)zc * H + yc) * W + xc) * (SKIN_BP / 4);
+    float v[SKIN_BP];
+#pragma unroll
+    for (int q = 0; q < SKIN_BP / 4; ++q) {
+        const float4 c = p[q];
+        v[4 * q + 0] = wk * c.x; v[4 * q + 1] = wk * c.y; v[4 * q + 2] = wk * c.z; v[4 * q + 3] = wk * c.w;
+    }
+    float tot[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) tot[m] = grp8_reduce_scatter(v + 8 * m, k);   // lane k: channel 8 m + k summed over the corners
+    const float sum = grp_sum<8>((tot[0] + tot[1]) + tot[2]);                  // pad channels are zero
+    if ((t >> 3) < N) {
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+            if (8 * m + k < B) out_w[(size_t)i * B + 8 * m + k] = tot[m] / sum;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_skin_bwd24(int N, const float* __restrict__ xyz,
                                                     const float4* __restrict__ grid, int D, int H, int W,
                                                     int B, const float* __restrict__ center,
@@ -246,6 +283,9 @@ __global__ __launch_bounds__(256) void k_skin_bwd24(int N, const float* __restri
     dL_dxyz[3 * i + 2] = (accumulate ? dL_dxyz[3 * i + 2] : 0.f) + (gzP - dot * gzQ) * invS * (0.5f * (float)(D - 1)) / scale[2];
 }
 
+// (An eight-lanes-per-Gaussian version of this kernel, like k_skin_fwd24x8, was measured and is slower: 0.046 against
+// 0.032 ms.  The backward runs on the active list only -- 130 k threads = two waves per SIMD, all resident at once with 48
+// loads each in flight -- and already moves 0.58 of the HBM peak in 96-byte rows; there is no occupancy to win.)
 // ---------------------------------------------------------------------------
 // LBS of means and covariances
 // ---------------------------------------------------------------------------
@@ -556,8 +596,16 @@ extern "C" int mgr_skin_weights_fwd(int N, const float* xyz, const float* grid, 
     hipStream_t stream = (hipStream_t)stream_;
     if (grid_stride != B && grid_stride != SKIN_BP) return mgr_fail(MGR_EINVAL, "mgr_skin_weights_fwd: grid_stride must be B or 24");
     if (grid_stride == SKIN_BP && B <= SKIN_BP && ((uintptr_t)grid & 15) == 0) {
-        { MGR_PROF("k_skin_fwd24", stream); hipLaunchKernelGGL(k_skin_fwd24, dim3((N + 255) / 256), dim3(256), 0, stream, N, xyz, (const float4*)grid, D, H, W, B,
-                           center3, scale3, out_w); }
+        static const bool one_thread = getenv("MGR_SKIN_FWD") && !strcmp(getenv("MGR_SKIN_FWD"), "thread");   // (A/B switch)
+        if (one_thread) {
+            MGR_PROF("k_skin_fwd24", stream);
+            hipLaunchKernelGGL(k_skin_fwd24, dim3((N + 255) / 256), dim3(256), 0, stream, N, xyz, (const float4*)grid, D, H, W, B,
+                               center3, scale3, out_w);
+        } else {
+            MGR_PROF("k_skin_fwd24x8", stream);
+            hipLaunchKernelGGL(k_skin_fwd24x8, dim3((unsigned)(((size_t)N * 8 + 255) / 256)), dim3(256), 0, stream, N, xyz,
+                               (const float4*)grid, D, H, W, B, center3, scale3, out_w);
+        }
         MGR_LAUNCH_CHECK("k_skin_fwd24", stream, 0);
         return MGR_OK;
     }

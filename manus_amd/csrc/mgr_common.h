@@ -403,6 +403,26 @@ __device__ __forceinline__ bool mgr_quad_bbox(unsigned long long am, int& x0, in
     return true;
 }
 
+// sums over aligned groups of G = 2, 4, 8 lanes (DPP quad permutes + row_half_mirror)
+template <int G>
+__device__ __forceinline__ float grp_sum(float x) {  // all lanes of the group receive the total
+    if (G >= 2) x += mgr_dpp<0xb1>(x);   // quad_perm [1,0,3,2]
+    if (G >= 4) x += mgr_dpp<0x4e>(x);   // quad_perm [2,3,0,1]
+    if (G >= 8) x += mgr_dpp<0x141>(x);  // row_half_mirror
+    return x;
+}
+
+// 8 values per lane, 8 lanes per group -> lane k of the group returns the group total of x[k]
+__device__ __forceinline__ float grp8_reduce_scatter(const float x[8], int vl) {
+    const bool b2 = (vl & 4) != 0, b1 = (vl & 2) != 0, b0 = (vl & 1) != 0;
+    float y[4], z[2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) y[k] = (b2 ? x[k + 4] : x[k]) + mgr_dpp<0x141>(b2 ? x[k] : x[k + 4]);  // partner 7 - j
+#pragma unroll
+    for (int k = 0; k < 2; ++k) z[k] = (b1 ? y[k + 2] : y[k]) + mgr_dpp<0x4e>(b1 ? y[k] : y[k + 2]);   // partner j ^ 2
+    return (b0 ? z[1] : z[0]) + mgr_dpp<0xb1>(b0 ? z[0] : z[1]);                                        // partner j ^ 1
+}
+
 // ---------------------------------------------------------------------------
 // Pair-packed staging for the blend kernels.
 //
