@@ -449,8 +449,10 @@ __device__ __forceinline__ void grp_store8(const float x[8], int vl, bool ok, fl
 #ifndef IB_THREADS
 #define IB_THREADS 256
 #endif
+// waves per SIMD of k_inst_bwd: at 3 (168 VGPRs) the kernel spills 57 registers, at 2 (256) none -- 0.158 -> 0.127 ms at eight
+// views (4: 0.225); re-measured late in round 3, the round-2 setting was 3
 #ifndef MGR_IB_WAVES
-#define MGR_IB_WAVES 3
+#define MGR_IB_WAVES 2
 #endif
 #ifndef IG_ROUNDS
 #define IG_ROUNDS 8

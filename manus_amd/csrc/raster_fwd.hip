@@ -1080,6 +1080,9 @@ __global__ __launch_bounds__(1024) void k_dbin_scatter(int N, const int32_t* __r
 // segment: whole buckets, about DB_CHUNK keys, every bucket in exactly one item.  One LDS sort when that is at most
 // SORT_LDS_KEYS keys; bucket by bucket otherwise; a single bucket beyond SORT_LDS_KEYS (all Gaussians in one depth
 // plane) falls back to the in-place bitonic network in global memory.
+#ifndef DBS_WAVES_EU
+#define DBS_WAVES_EU 4
+#endif
 #define DB_CHUNK 2048        // (1024 when there are few instances in all: more, shorter items)
 __device__ __forceinline__ uint32_t db_lower_bound(const uint32_t* __restrict__ st, uint32_t key) {
     uint32_t lo = 0, hi = MGR_DB_BUCKETS;   // first bucket b in [0, MGR_DB_BUCKETS] with st[b] >= key (st is non-decreasing)
@@ -1089,7 +1092,7 @@ __device__ __forceinline__ uint32_t db_lower_bound(const uint32_t* __restrict__ 
     }
     return lo;
 }
-__global__ __launch_bounds__(RS_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_dbin_sort(
+__global__ __launch_bounds__(RS_THREADS) __attribute__((amdgpu_waves_per_eu(DBS_WAVES_EU, DBS_WAVES_EU))) void k_dbin_sort(
     int N, int chunk, int chunks_per_view, int n_items, const uint32_t* __restrict__ db_start, const uint32_t* __restrict__ db_nvis,
     unsigned long long* __restrict__ db_keys, uint32_t* __restrict__ db_order) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
