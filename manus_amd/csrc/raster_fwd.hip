@@ -1558,7 +1558,14 @@ extern "C" int mgr_debug_fprof(unsigned long long* dst) {
 #else
 #define FP(k)
 #endif
-__global__ __launch_bounds__(256) void k_blend_fwd(int N, int W, int H, int gx, int gy, int VT,
+// (occupancy of the forward blend: 78 VGPRs = six waves per SIMD as compiled; forced to five or four the kernel and the step
+// time stay within the run-to-run noise, 0.369-0.377 ms / 598-607 iters/s on one box)
+#ifdef FWD_WAVES_EU
+#define FWD_OCC __attribute__((amdgpu_waves_per_eu(FWD_WAVES_EU, FWD_WAVES_EU)))
+#else
+#define FWD_OCC
+#endif
+__global__ __launch_bounds__(256) FWD_OCC void k_blend_fwd(int N, int W, int H, int gx, int gy, int VT,
                                                    const float* __restrict__ bg,
                                                    const uint32_t* __restrict__ tile_start,
                                                    const uint32_t* __restrict__ tile_queue,
