@@ -1350,23 +1350,33 @@ __device__ unsigned long long g_binprof[8 * 4096];
 // waves meet at one workgroup barrier per batch.
 #define BIN_SC_THREADS 128
 #define BIN_SC_FIXED_BYTES (2 * 64 * sizeof(BinRec) + 2 * BIN_PAIR_CAP * 4 + 2 * 64 * 4 + 16)
-template <bool SMALL>
+// MASKS = tiles the per-tile lane masks cover: BIN_MID_TILES (30 KB of LDS, five workgroups per CU -- the boxes of the
+// hand scene hold 960-1470 tiles, tools/instr/tile_bbox.py), BIN_SMALL_TILES (36 KB, four per CU) or 0 (no masks: any box).
+#define BIN_MID_TILES 1536
+__device__ __forceinline__ bool bin_sc_mine(ushort4 box, int masks) {
+    const uint32_t tb = (uint32_t)box.z * (uint32_t)box.w;
+    if (tb == 0u) return false;
+    const int tier = tb <= (uint32_t)BIN_MID_TILES ? BIN_MID_TILES : (tb <= (uint32_t)BIN_SMALL_TILES ? BIN_SMALL_TILES : 0);
+    return tier == masks;
+}
+template <int MASKS>
 __global__ __launch_bounds__(BIN_SC_THREADS) void k_bin_scatter(int N, int T, int nblk, int bb, const uint32_t* __restrict__ db_nvis,
                                                                 const ushort4* __restrict__ db_bbox,
                                                                 const uint32_t* __restrict__ db_order,
                                                                 const uint4* __restrict__ db_rec,
                                                                 const uint32_t* __restrict__ bin_mat,
                                                                 uint32_t* __restrict__ sorted_gid, uint32_t cap) {
+    constexpr bool SMALL = MASKS > 0;
     extern __shared__ __attribute__((aligned(16))) uint32_t s_mem[];
     BinRec* s_rec = (BinRec*)s_mem;                                     // [2][64] staged instances (by-instance route)
     unsigned long long* s_mask = (unsigned long long*)(s_mem + 2 * 64 * (sizeof(BinRec) / 4));   // SMALL: lane mask per tile
-    uint32_t* s_pairs = (uint32_t*)(s_mask + (SMALL ? BIN_SMALL_TILES : 0));                      // [2][CAP] pairs: tile | lane << 16
+    uint32_t* s_pairs = (uint32_t*)(s_mask + MASKS);                      // [2][CAP] pairs: tile | lane << 16
     uint32_t* s_gid = s_pairs + 2 * BIN_PAIR_CAP;                       // [2][64] Gaussians of the batch
     uint32_t* s_info = s_gid + 2 * 64;                                  // [2] pairs of the batch, or ~0: by-instance route
     uint32_t* s_cur = s_info + 4;                                       // cursors of the box's tiles (absolute list slots)
     const int v = blockIdx.y, b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const ushort4 box = db_bbox[v];
-    if (!bin_mine(box, SMALL)) return;
+    if (!bin_sc_mine(box, MASKS)) return;
     const uint32_t nvis = db_nvis[v], p0 = (uint32_t)b * (uint32_t)bb;
     if (p0 >= nvis) return;
     const uint32_t p1 = min(p0 + (uint32_t)bb, nvis);
@@ -1939,7 +1949,7 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
         MGR_HIP(hipFuncSetAttribute((const void*)k_dbin_sort, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     SORT_LDS_KEYS * 8 + RS_WAVES * 256 * 4 + 256));
         MGR_HIP(hipFuncSetAttribute((const void*)k_bin_count<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
-        MGR_HIP(hipFuncSetAttribute((const void*)k_bin_scatter<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+        MGR_HIP(hipFuncSetAttribute((const void*)k_bin_scatter<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
         attr_set[device].store(true, std::memory_order_release);
     }
 
@@ -2026,11 +2036,15 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
         { MGR_PROF("k_bin_scan", stream); hipLaunchKernelGGL(k_bin_scan, dim3((T + BSCAN_COLS - 1) / BSCAN_COLS, V), dim3(BSCAN_COLS * BSCAN_SEGS), 0, stream, gx, T, nblk, bb, (const uint32_t*)db_nvis,
                            (const ushort4*)db_bbox, (const uint32_t*)tile_start, bin_mat); }
         { MGR_PROF("k_bin_scatter", stream);
-          hipLaunchKernelGGL((k_bin_scatter<true>), grid_b, dim3(BIN_SC_THREADS), (size_t)BIN_SMALL_TILES * 12 + rec_bytes, stream, N, T, nblk, bb,
+          hipLaunchKernelGGL((k_bin_scatter<BIN_MID_TILES>), grid_b, dim3(BIN_SC_THREADS), (size_t)BIN_MID_TILES * 12 + rec_bytes, stream, N, T, nblk, bb,
                              (const uint32_t*)db_nvis, (const ushort4*)db_bbox, (const uint32_t*)db_order, (const uint4*)db_rec, (const uint32_t*)bin_mat,
                              (uint32_t*)(ws + L.sorted_gid), (uint32_t)cap);
+          if (T > BIN_MID_TILES)
+              hipLaunchKernelGGL((k_bin_scatter<BIN_SMALL_TILES>), grid_b, dim3(BIN_SC_THREADS), (size_t)BIN_SMALL_TILES * 12 + rec_bytes, stream, N, T, nblk, bb,
+                                 (const uint32_t*)db_nvis, (const ushort4*)db_bbox, (const uint32_t*)db_order, (const uint4*)db_rec, (const uint32_t*)bin_mat,
+                                 (uint32_t*)(ws + L.sorted_gid), (uint32_t)cap);
           if (big_possible)
-              hipLaunchKernelGGL((k_bin_scatter<false>), grid_b, dim3(BIN_SC_THREADS), (size_t)T * 4 + rec_bytes, stream, N, T, nblk, bb,
+              hipLaunchKernelGGL((k_bin_scatter<0>), grid_b, dim3(BIN_SC_THREADS), (size_t)T * 4 + rec_bytes, stream, N, T, nblk, bb,
                                  (const uint32_t*)db_nvis, (const ushort4*)db_bbox, (const uint32_t*)db_order, (const uint4*)db_rec, (const uint32_t*)bin_mat,
                                  (uint32_t*)(ws + L.sorted_gid), (uint32_t)cap); }
         MGR_LAUNCH_CHECK("k_bin_scatter", stream, debug);
