@@ -116,3 +116,44 @@ def test_project_points_vs_golden(golden_dir):
     got = ops.project_points(torch.tensor(d["pp_points"], device=DEV), torch.tensor(d["pp_K"], device=DEV),
                              torch.tensor(d["pp_E"], device=DEV)).cpu().numpy()
     np.testing.assert_allclose(got, d["pp_out"], rtol=1e-5, atol=1e-3)
+
+
+_SKIN_EDGE = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+from manus_amd import ops
+torch.manual_seed(0)
+D, H, W, B = 7, 9, 11, 21
+grid = torch.rand((D, H, W, B), device="cuda:0") ** 3
+c = torch.tensor([0.01, -0.02, 0.03], device="cuda:0"); s = torch.tensor([[0.5, 0.4, 0.3]], device="cuda:0")
+out = {}
+for N in (1, 2, 7, 9, 63, 255, 257, 1000):
+    xyz = (torch.rand((N, 3), device="cuda:0") * 2.4 - 1.2) * s + c      # some points outside the grid
+    out[N] = ops.skin_weights(xyz, grid, c, s).cpu()
+torch.save(out, sys.argv[2])
+"""
+
+
+def test_skin_forward_lane_split_equals_one_thread_kernel(tmp_path):
+    """k_skin_fwd24x8 (eight lanes per Gaussian, the default) against k_skin_fwd24 (MGR_SKIN_FWD=thread; the switch is read
+    once per process, hence two processes): ragged sizes, points outside the grid (same NaN rows), last-bit differences only."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for mode in ("x8", "thread"):
+        env = dict(os.environ)
+        env.pop("MGR_SKIN_FWD", None)
+        if mode == "thread":
+            env["MGR_SKIN_FWD"] = "thread"
+        out = str(tmp_path / (mode + ".pt"))
+        subprocess.run([sys.executable, "-c", _SKIN_EDGE, root, out], check=True, env=env, timeout=300)
+        res[mode] = torch.load(out)
+    for n, a in res["x8"].items():
+        b = res["thread"][n]
+        assert a.shape == b.shape == (n, 21)
+        fin = torch.isfinite(b)
+        assert torch.equal(torch.isfinite(a), fin)
+        assert fin.any() and float((a[fin] - b[fin]).abs().max()) < 1e-6
+        assert float((a[fin.all(1)].sum(1) - 1).abs().max()) < 1e-5
