@@ -594,13 +594,16 @@ class TestDataset(torch.utils.data.Dataset):
         return out
 
 
-def hand_scene_from_batch(batch, bones_rest, n_gaussians, grid_res=32, seed=0, device="cuda:0", sigma_range=(2e-3, 6e-3)):
+def hand_scene_from_batch(batch, bones_rest, n_gaussians, grid_res=32, seed=0, device="cuda:0", sigma_range=(2e-3, 6e-3),
+                          voxel_grid=None):
     """The scene dict `engine.HipViewCompute` / `engine.Trainer` consume, from one `SequenceDataset.view_batch` and the
     capture's rest skeleton (`ds[i]["bones_rest"]`): Gaussians initialised on the bones like `sample_gaussians_on_bones_func`
     (train_utils.py:104-139), a skin-weight voxel grid with `build_voxel_grid`'s geometry (brics_dynamic.py:99-144; the
     weights themselves are the synthetic softmax of `synthetic.make_skin_grid`, MANO's nearest-vertex weights are not
     built here), the per-view bone transforms posed @ inv(rest) + identity (hand_dynamic.py:93-102), the dataset's own
-    targets, masks, cameras and keypoints.  Returns (scene, targets (V,3,H,W))."""
+    targets, masks, cameras and keypoints.  `voxel_grid` = the tuple `build_voxel_grid` returns (scale, center, grid points,
+    weights (D,H,W,21), mask): the MANO-initialised grid takes the place of the synthetic one, like hand_dynamic.py:43-58 hands
+    it to the model.  Returns (scene, targets (V,3,H,W))."""
     import math
     from . import synthetic as S
     gen = torch.Generator().manual_seed(seed)
@@ -609,7 +612,11 @@ def hand_scene_from_batch(batch, bones_rest, n_gaussians, grid_res=32, seed=0, d
     per = max(2, int(math.ceil(n_gaussians / 30.0)))
     xyz = S.sample_on_bones(heads, tails, rest.numpy(), per, gen)
     xyz = xyz[torch.randperm(xyz.shape[0], generator=gen)[:n_gaussians]]
-    dims, center, scale = S.grid_geometry(heads, tails, res=grid_res)
+    if voxel_grid is not None:
+        g_scale, g_center, _, g_weights, _ = voxel_grid
+        dims, center, scale = tuple(g_weights.shape[:3]), g_center.reshape(3).numpy(), g_scale.reshape(3).numpy()
+    else:
+        dims, center, scale = S.grid_geometry(heads, tails, res=grid_res)
     lo, hi = torch.tensor(center - 0.95 * scale), torch.tensor(center + 0.95 * scale)
     xyz = torch.max(torch.min(xyz, hi), lo).float()
     N = xyz.shape[0]
@@ -623,7 +630,8 @@ def hand_scene_from_batch(batch, bones_rest, n_gaussians, grid_res=32, seed=0, d
     has_img = "targets" in batch
     H, W = batch["targets"].shape[-2:] if has_img else (batch["height"], batch["width"])
     scene = dict(params={k: v.to(device) for k, v in params.items()}, N=N, n_hand=N, kind="hand", grid_dims=dims,
-                 grid=S.make_skin_grid(heads, tails, dims, center, scale, device=device),
+                 grid=(voxel_grid[3].to(device).contiguous() if voxel_grid is not None
+                       else S.make_skin_grid(heads, tails, dims, center, scale, device=device)),
                  grid_center=torch.as_tensor(center).to(device), grid_scale=torch.as_tensor(scale).to(device),
                  rest=rest.to(device), posed=posed.to(device), transforms=tf.to(device), cameras=cams,
                  bg=torch.ones(3, device=device), width=int(W), height=int(H), heads=heads, tails=tails,

@@ -146,3 +146,30 @@ def test_dataset_methods_delegate(golden_dir, tmp_path, mano):
         ds.sample_gaussians_on_bones(4, mano_weights=True, init_type="other")
     scale, center, gp, gw, mask = ds.build_voxel_grid(res=12, ratio=(1.0, 1.0, 1.0), device=DEV)
     assert gw.shape == (12, 12, 12, 21) and gp.shape == (12, 12, 12, 3)
+
+
+def test_mano_grid_drives_the_renderer(golden_dir, mano):
+    """hand_dynamic.py:43-58 end to end: Dataset.build_voxel_grid's MANO-initialised skin-weight grid -> the scene -> both kernel
+    routes of the renderer on an evaluation trajectory (the skin weights are then sparse: at most a few bones per Gaussian)."""
+    from manus_amd import dataset as D, mano_init as MI
+    from manus_amd.engine import HipViewCompute
+    from manus_amd.synthetic import camera_table
+    ind = os.path.join(golden_dir, "eval_inputs")
+    ds = D.TestDataset(dict(cam_path=os.path.join(ind, "camera_path.npz"), cano_cam_path=os.path.join(ind, "cano_camera.npz"),
+                            metadata_path=os.path.join(ind, "novel_pose.npz"), frame_sample_rate=4))
+    b = ds.bones_rest
+    kp = torch.cat([b.heads[:1], b.tails]).numpy()
+    v = mano["verts"]
+    v2 = (v - v.mean(0)) * (np.linalg.norm(kp.max(0) - kp.min(0)) / np.linalg.norm(v.max(0) - v.min(0))) + (kp.max(0) + kp.min(0)) / 2
+    grid = MI.build_voxel_grid(b, dict(mano, verts=v2.astype(np.float32)), res=32, ratio=(1.1, 0.9, 0.65), device=DEV)
+    batch = ds.view_batch([0, 2])
+    scene, _ = D.hand_scene_from_batch(batch, b, 8000, seed=3, device=DEV, voxel_grid=grid)
+    assert tuple(scene["grid"].shape) == tuple(grid[3].shape) and scene["grid_dims"] == tuple(grid[3].shape[:3])
+    ct = camera_table(scene["cameras"], DEV)
+    blank = torch.zeros((2, 3, 1080, 1080), device=DEV)
+    with torch.no_grad():
+        im_m, rad_m, _ = HipViewCompute(scene, blank, ct, fused=False).forward_views([0, 1])
+        im_f, rad_f = HipViewCompute(scene, blank, ct, fused=True).forward_views_fused([0, 1])
+    assert torch.equal(rad_m, rad_f) and torch.isfinite(im_f).all()
+    assert float((im_m - im_f).abs().max()) < 5e-3
+    assert int((rad_f > 0).sum()) > 1000
