@@ -71,7 +71,8 @@ struct MgrHeader {            // first 256 bytes of the workspace
     uint32_t queue_small;     // queue index of the first tile with fewer than 2048 pairs
     uint32_t queue_head3;     // cursor of the small-tile sort
     uint32_t n_active;        // Gaussians with a non-zero pair gradient in the current view group (fused backward)
-    uint32_t pad[5];
+    uint32_t queue_len_i;     // length of the view-interleaved queue of the forward blend (with holes), 0 = not built
+    uint32_t pad[4];
     uint32_t cls_count[34];   // tiles per size class (class = bit length of the pair count, 0 = empty)
     uint32_t cls_cursor[34];  // running cursors of the queue scatter
     uint32_t queue_giant;     // queue index of the first tile with fewer than 16384 pairs
@@ -82,6 +83,9 @@ struct MgrHeader {            // first 256 bytes of the workspace
     // after the other (~11 ns each on this chip, device-wide: 79 000 tickets on one counter were measured to take
     // 0.9 ms), so a queue that hands out tens of thousands of wave-sized items is spread over MGR_NCTR addresses
     uint32_t qctr[16 * 64];
+    // the same for the forward blend, whose work units are (tile, 8x8 quadrant) = one wave each; k_tile_scan_b presets
+    // them so that the first ticket of every counter lies behind the units the waves start on statically
+    uint32_t qctr_f[16 * 64];
 };
 #define MGR_NCTR 16
 
@@ -98,8 +102,8 @@ struct __attribute__((aligned(16))) MgrGRec {
 #define MGR_CHUNK 64         // list entries per backward work item / forward checkpoint interval (one batch of the blend waves)
 
 struct MgrLayout {
-    size_t header, scan_part, grec, depth, rect, alive, pair_off, tile_count, tile_start, tile_cursor, tile_done,
-        tile_queue, tile_qrec, chunk_start, items, ckpt, keys, keys2, groups, sorted_gid, final_T, n_contrib, pair_tag, pair_grad, inst_grad, inst_tag,
+    size_t header, scan_part, grec, depth, rect, alive, pair_off, tile_count, tile_start, tile_cursor, tile_done, tile_qdone,
+        tile_queue, tile_qrec, tile_qrec_i, chunk_start, items, ckpt, keys, keys2, groups, sorted_gid, final_T, n_contrib, pair_tag, pair_grad, inst_grad, inst_tag,
         db_count, db_cursor, db_start, db_nvis, db_bbox, db_keys, db_order, db_rec, bin_mat, total;
 };
 
@@ -130,8 +134,10 @@ static inline MgrLayout mgr_layout(int V, int N, int W, int H, int64_t cap) {
     L.tile_start = o;  o += mgr_align((VT + 1) * 4);
     L.tile_cursor = o; o += mgr_align(VT * 4);
     L.tile_done = o;   o += mgr_align(VT * 4);
+    L.tile_qdone = o;  o += mgr_align(VT * 16);       // list depth each 8x8 quadrant of a tile consumed in the forward blend
     L.tile_queue = o;  o += mgr_align(VT * 4);
     L.tile_qrec = o;   o += mgr_align(VT * 16);       // queue records of the forward blend: (tile, list offset, list length, first checkpoint)
+    L.tile_qrec_i = o; o += mgr_align((VT + 64) * 16); // the same, interleaved by view: position p holds a tile of view p % V (or a hole)
     L.chunk_start = o; o += mgr_align((VT + 1) * 4);
     L.items = o;       o += mgr_align((c / MGR_CHUNK + VT + 1) * 32);   // 32-byte record per (tile, chunk) work item of the backward blend
     L.ckpt = o;        o += mgr_align((c / MGR_CHUNK + 1) * 256 * 16);  // float4 per pixel per checkpoint
@@ -476,9 +482,8 @@ __device__ __forceinline__ void mgr_pair_pad(float* pb) {
 // written with explicit fused multiply-adds and contraction is off: left to the compiler, dx*t + u*dy may become
 // fma(dx, t, u*dy) in one kernel and fma(u, dy, dx*t) in another (observed: the debug kernel and the blend disagreed
 // on a pair whose alpha equals 1/255 to eight digits).
-__device__ __forceinline__ void mgr_pair_alpha(const float4 R0, const float4 R1, const float4 R2, mgr_v2f fpx2,
-                                               mgr_v2f fpy2, mgr_v2f& dx, mgr_v2f& dy, mgr_v2f& G, mgr_v2f& al,
-                                               bool& va, bool& vb, mgr_v2f* pw_out = nullptr) {
+__device__ __forceinline__ void mgr_pair_alpha_core(const float4 R0, const float4 R1, const float4 R2, mgr_v2f fpx2,
+                                                    mgr_v2f fpy2, mgr_v2f& dx, mgr_v2f& dy, mgr_v2f& G, mgr_v2f& al, mgr_v2f& pw) {
 #pragma clang fp contract(off)
     const mgr_v2f x2 = {R0.x, R0.y}, y2 = {R0.z, R0.w}, A2 = {R1.x, R1.y}, B2 = {R1.z, R1.w}, C2 = {R2.x, R2.y},
                   o2 = {R2.z, R2.w};
@@ -487,16 +492,34 @@ __device__ __forceinline__ void mgr_pair_alpha(const float4 R0, const float4 R1,
     mgr_v2f t = A2 * dx;
     t = __builtin_elementwise_fma(B2, dy, t);
     const mgr_v2f u = C2 * dy;
-    const mgr_v2f pw = __builtin_elementwise_fma(dx, t, u * dy);
+    pw = __builtin_elementwise_fma(dx, t, u * dy);
     // min(2^pw, 1) = 2^min(pw, 0) bit for bit; written as a clamp to [0, 1] it is the `clamp` bit of v_exp_f32 (no v_min)
     G.x = __builtin_fminf(__builtin_fmaxf(__builtin_amdgcn_exp2f(pw.x), 0.0f), 1.0f);
     G.y = __builtin_fminf(__builtin_fmaxf(__builtin_amdgcn_exp2f(pw.y), 0.0f), 1.0f);
     al = o2 * G;
     al.x = fminf(0.99f, al.x);
     al.y = fminf(0.99f, al.y);
-    va = pw.x <= 0.0f && al.x >= 1.0f / 255.0f;
-    vb = pw.y <= 0.0f && al.y >= 1.0f / 255.0f;
+}
+// the keep / skip rule of one entry, given its exponent and clamped alpha (one expression for every kernel)
+#define MGR_ALPHA_KEPT(pw_, al_) ((pw_) <= 0.0f && (al_) >= 1.0f / 255.0f)
+
+__device__ __forceinline__ void mgr_pair_alpha(const float4 R0, const float4 R1, const float4 R2, mgr_v2f fpx2,
+                                               mgr_v2f fpy2, mgr_v2f& dx, mgr_v2f& dy, mgr_v2f& G, mgr_v2f& al,
+                                               bool& va, bool& vb, mgr_v2f* pw_out = nullptr) {
+    mgr_v2f pw;
+    mgr_pair_alpha_core(R0, R1, R2, fpx2, fpy2, dx, dy, G, al, pw);
+    va = MGR_ALPHA_KEPT(pw.x, al.x);
+    vb = MGR_ALPHA_KEPT(pw.y, al.y);
     if (pw_out) *pw_out = pw;
+}
+
+// the same with the decisions as lane masks in scalar registers
+__device__ __forceinline__ void mgr_pair_alpha_masks(const float4 R0, const float4 R1, const float4 R2, mgr_v2f fpx2,
+                                                     mgr_v2f fpy2, mgr_v2f& al, unsigned long long& ma, unsigned long long& mb) {
+    mgr_v2f dx, dy, G, pw;
+    mgr_pair_alpha_core(R0, R1, R2, fpx2, fpy2, dx, dy, G, al, pw);
+    ma = __builtin_amdgcn_ballot_w64(pw.x <= 0.0f) & __builtin_amdgcn_ballot_w64(al.x >= 1.0f / 255.0f);
+    mb = __builtin_amdgcn_ballot_w64(pw.y <= 0.0f) & __builtin_amdgcn_ballot_w64(al.y >= 1.0f / 255.0f);
 }
 
 // natural exponential through v_exp_f32 (arguments here lie in [-12, 0])

@@ -449,7 +449,8 @@ __global__ __launch_bounds__(1024) void k_tile_scan_b(int VT, int nblk, uint32_t
         hdr->split_head = 0;
         hdr->group_head = 0;
         hdr->queue_head = 0;
-        hdr->queue_head2 = MGR_FWD_GRID;   // k_blend_fwd: workgroup b starts with queue entry b
+        hdr->queue_head2 = MGR_FWD_GRID;   // k_blend_fwd (workgroup version): workgroup b starts with queue entry b
+        for (int c = 0; c < MGR_NCTR; ++c) hdr->qctr_f[c * 64] = MGR_FWD_GRID / MGR_NCTR;   // wave-granular version: its tickets start behind the grid too
         hdr->queue_head3 = s_cbase[11];
     }
 }
@@ -1564,7 +1565,13 @@ __device__ unsigned long long g_fprof[8];
 extern "C" int mgr_debug_fprof(unsigned long long* dst) {
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_fprof), sizeof(unsigned long long) * 8);
 }
-#define FP(k) { const long long now_ = wall_clock64(); facc_[k] += now_ - ftp_; ftp_ = now_; }
+#ifndef FWD_PROF_MIN
+#define FWD_PROF_MIN 0u
+#endif
+#ifndef FWD_PROF_MAX
+#define FWD_PROF_MAX 0xFFFFFFFFu
+#endif
+#define FP(k) { const long long now_ = wall_clock64(); if (fp_on_) facc_[k] += now_ - ftp_; ftp_ = now_; }
 #else
 #define FP(k)
 #endif
@@ -1606,6 +1613,7 @@ __global__ __launch_bounds__(256) FWD_OCC void k_blend_fwd(int N, int W, int H, 
 #endif
 #ifdef FWD_PROF
     long long facc_[6] = {0, 0, 0, 0, 0, 0}, ftp_ = wall_clock64(), fnt_ = 0;
+    bool fp_on_ = true;   // -DFWD_PROF_MIN / -DFWD_PROF_MAX: only tiles with a list length in [MIN, MAX)
 #endif
     // the first tile of a workgroup is its own index (the tile scan starts the queue cursor at the grid size): 2048
     // workgroups drawing their first ticket from one counter at the same moment are served one after the other
@@ -1679,7 +1687,8 @@ __global__ __launch_bounds__(256) FWD_OCC void k_blend_fwd(int N, int W, int H, 
             rec.c = r->b;
         }
 #ifdef FWD_PROF
-        ++fnt_;
+        fp_on_ = nlist >= FWD_PROF_MIN && nlist < FWD_PROF_MAX;
+        if (fp_on_) ++fnt_;
         if (rec.c == 12345.678f) break;   // (forces the first records to be here before the clock is read)
 #endif
         FP(0);
@@ -1875,6 +1884,503 @@ __global__ __launch_bounds__(256) FWD_OCC void k_blend_fwd(int N, int W, int H, 
         g_tl[blockIdx.x * 4 + 3] = ntl;
     }
 #endif
+}
+
+// ---------------------------------------------------------------------------
+// K5, wave-granular: the same walk, but nothing in the kernel waits at a workgroup barrier.  -DFWD_PROF on the workgroup
+// version above showed why: per tile of fewer than 1024 list entries (63 % of the tiles of the bench scene) a wave spent
+// 15.5 us walking and 33 us around it -- two workgroup barriers that drain the image stores and wait for thread 0's two
+// returning atomics (queue ticket, backward-item base: both on one address each, served one after the other device-wide),
+// the slowest of the four quadrants, the dependent prologue loads.
+//
+// A first version handed (tile, quadrant) units to any wave of the device: no waiting at all, and slower (0.393 against
+// 0.374 ms) -- the four quadrants of a tile gather the same Gaussian records, and on four CUs of four XCDs each of them pulls
+// the lines from memory itself (the counters of the workgroup version: 74 % of the gathers hit the L1 of the CU the four
+// waves share, the L2 serves only 27 % of the rest).  So the tile stays on ONE workgroup, but its waves are not tied to a
+// quadrant:
+//  * a workgroup walks a SEQUENCE of tiles (step 0 = its own index in the queue, later steps = tickets of MgrQueue);
+//  * a wave that is free takes the next unclaimed quadrant of that sequence with one LDS atomic (claim c = step 4 c / 4,
+//    quadrant c % 4): a wave whose quadrant ends early goes on to the next tile, the slowest quadrant delays nobody;
+//  * the wave that claims quadrant 0 of step s draws the ticket of step s + 1, reads the answer after its first batch and
+//    publishes the tile's queue record in an LDS slot; whoever claims a quadrant of step s + 1 finds it there;
+//  * the epilogue is stores only: image, n_contrib, and the list depth the quadrant consumed (tile_qdone);
+//  * the backward's work items, which the workgroup version appended behind a same-address atomic per tile, are built by
+//    k_fwd_items after the blend from the four depths of every tile.
+// ---------------------------------------------------------------------------
+#ifdef MGR_TIMELINE
+// -DMGR_TIMELINE: one record per (tile, quadrant) unit of k_blend_fwd_w: start, end (wall_clock64), list length | quadrant << 28,
+// depth consumed; mgr_debug_timeline_w copies them out (tools/instr/timeline_w.py)
+__device__ unsigned long long g_tlw[65536 * 4];
+__device__ unsigned int g_tlw_n;
+extern "C" int mgr_debug_timeline_w(void* dst, unsigned int* n) {
+    hipError_t e = hipMemcpyFromSymbol(n, HIP_SYMBOL(g_tlw_n), 4);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_tlw), sizeof(unsigned long long) * 65536 * 4);
+    const unsigned int z = 0;
+    if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_tlw_n), &z, 4);
+    return (int)e;
+}
+#endif
+#define MGR_HOLE 0xFFFFFFFEu
+// EXPERIMENT (MGR_FWD_ILV=1): the queue of the forward blend re-arranged so that position p holds a tile of view p % V,
+// each view's tiles in their queue order.  With V = 8 and the interleaved counters of MgrQueue (counter c hands out the
+// positions c, c + 16, ...; a workgroup's home counter is its index mod 16) the workgroups of XCD x -- every eighth
+// workgroup -- then blend the tiles of view x while that view has any: one view's Gaussian records per L2.
+__global__ __launch_bounds__(1024) void k_queue_interleave(int V, int T, const uint4* __restrict__ tile_qrec, uint4* __restrict__ out, MgrHeader* hdr) {
+    __shared__ uint32_t s_cnt[64], s_scan[32];
+    const int tid = threadIdx.x;
+    const uint32_t n = hdr->queue_len;
+    if (tid < 64) s_cnt[tid] = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += 1024u) {
+        const uint32_t i = base + (uint32_t)tid;
+        uint4 r = make_uint4(0, 0, 0, 0);
+        int v = -1;
+        if (i < n) { r = tile_qrec[i]; v = (int)(r.x / (uint32_t)T); }
+        for (int w = 0; w < V; ++w) {
+            uint32_t tot;
+            const uint32_t rk = block_excl_scan(v == w ? 1u : 0u, s_scan, tot);
+            if (v == w) out[(size_t)(s_cnt[w] + rk) * V + w] = r;
+            __syncthreads();
+            if (tid == 0) s_cnt[w] += tot;
+            __syncthreads();
+        }
+    }
+    uint32_t mx = 0;
+    for (int w = 0; w < V; ++w) mx = max(mx, s_cnt[w]);
+    for (int w = 0; w < V; ++w)
+        for (uint32_t k = s_cnt[w] + (uint32_t)tid; k < mx; k += 1024u) out[(size_t)k * V + w] = make_uint4(MGR_HOLE, 0u, 0u, 0u);
+    if (tid == 0) hdr->queue_len_i = mx * (uint32_t)V;
+}
+
+#ifndef FWD_PIPE
+#define FWD_PIPE 0
+#endif
+#ifndef FWD_WARM
+#define FWD_WARM 0   // > 0: batches with at most this many survivors touch the records three batches ahead
+#endif
+// per-lane select by a lane mask held in scalar registers (v_cndmask with an SGPR-pair condition)
+__device__ __forceinline__ float mgr_sel(unsigned long long m, float a, float b) {
+    float r;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+    return r;
+}
+__device__ __forceinline__ uint32_t mgr_selu(unsigned long long m, uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+    return r;
+}
+#define FWD_SLOTS 64   // LDS ring of published steps; a reader spins on its slot from the moment it claims, so it cannot be lapped
+__global__ __launch_bounds__(256) FWD_OCC void k_blend_fwd_w(int N, int W, int H, int gx, int gy, int VT,
+                                                     const float* __restrict__ bg,
+                                                     const uint32_t* __restrict__ tile_queue,
+                                                     const uint4* __restrict__ tile_qrec,
+                                                     const uint32_t* __restrict__ sorted_gid,
+                                                     const MgrGRec* __restrict__ grec,
+                                                     float* __restrict__ out_color,
+                                                     uint32_t* __restrict__ n_contrib,
+                                                     uint32_t* __restrict__ tile_done,
+                                                     uint32_t* __restrict__ tile_qdone,
+                                                     float4* __restrict__ ckpt, MgrHeader* hdr, int ilv) {
+    __shared__ __align__(16) float s_pair[4][32][MGR_PAIR_FLOATS];
+    __shared__ __align__(16) uint4 s_qrec[FWD_SLOTS];     // queue record of a published step
+    __shared__ uint32_t s_step[FWD_SLOTS];                // which step the slot holds (published last: the flag the readers poll)
+    __shared__ uint32_t s_claim;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int T = gx * gy;
+    const uint32_t n_busy = hdr->queue_len;           // non-empty tiles (the empty ones follow them in tile_queue)
+    const uint32_t n_queue = ilv ? hdr->queue_len_i : n_busy;   // positions of the blend's queue (tile_qrec as passed)
+    const size_t P = (size_t)W * H;
+    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    float* const slab = &s_pair[wave][0][0];
+#ifdef KO_GATHER
+    const uint32_t gid_max = 4095u;
+#else
+    const uint32_t gid_max = (uint32_t)(N > 0 ? N - 1 : 0);
+#endif
+
+    if (blockIdx.x == 0 && tid < 34) {  // consumed by the tile scan: zero for the next forward (no per-call memset)
+        hdr->cls_count[tid] = 0;
+        hdr->cls_cursor[tid] = 0;
+    }
+    if (tid < FWD_SLOTS) s_step[tid] = 0xFFFFFFFFu;
+    if (tid == 0) s_claim = 0;
+    __syncthreads();   // (the only workgroup barrier of the kernel)
+#ifdef FWD_PROF
+    long long facc_[6] = {0, 0, 0, 0, 0, 0}, ftp_ = wall_clock64(), fnt_ = 0;
+    bool fp_on_ = true;
+#endif
+    MgrQueue queue;
+    queue.init(hdr->qctr_f, n_queue, (int)blockIdx.x);
+    const uint32_t END = 0xFFFFFFFFu;
+    // A wave in a short list claims its NEXT quadrant when it starts (c_next) and, once the step's record is published,
+    // fetches that tile's first list indices during the current walk: the next unit then starts one dependent round trip
+    // (the Gaussian records) after this one instead of two.  Long lists claim when they end (an early claim would hold a
+    // quadrant of the next tile back for as long as this walk takes).
+    uint32_t c_next = END;
+    bool have_gid = false;
+    uint32_t pf_g0 = 0, pf_g1 = 0;
+    auto claim = [&]() -> uint32_t {
+        uint32_t c = 0;
+        if (lane == 0) c = atomicAdd(&s_claim, 1u);
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+    };
+    auto slot_read = [&](uint32_t st) -> uint4 {
+        uint4 q = s_qrec[st % FWD_SLOTS];
+        q.x = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.x);
+        q.y = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.y);
+        q.z = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.z);
+        q.w = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.w);
+        return q;
+    };
+    while (true) {
+        // ---- the next quadrant of the workgroup's tile sequence ----
+        const uint32_t c = c_next != END ? c_next : claim();
+        c_next = END;
+        const uint32_t step = c >> 2, quad = c & 3u;
+        uint4 qrec;
+        if (step == 0) {   // the first tile of a workgroup is its own index (k_tile_scan_b starts the counters behind the grid)
+            qrec = blockIdx.x < n_queue ? tile_qrec[blockIdx.x] : make_uint4(END, 0u, 0u, 0u);
+        } else {
+            while (__hip_atomic_load(&s_step[step % FWD_SLOTS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != step) __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            qrec = slot_read(step);
+        }
+        if (qrec.x == END) break;
+        const bool got_gid = have_gid;
+        have_gid = false;
+        // quadrant 0 of a step provides the next step: ticket now, answer + queue record after the first batch
+        const bool provider = quad == 0u;
+        uint32_t raw = 0;
+        if (provider) raw = queue.issue(lane);
+        bool provided = !provider;
+
+        const bool hole = qrec.x == MGR_HOLE;   // (interleaved queue: a position its view has no tile for; still provides the next step)
+        const uint32_t vt = hole ? 0u : qrec.x;
+        const int v = (int)(vt / (uint32_t)T), t = (int)(vt % (uint32_t)T);
+        const int bx = t % gx, by = t / gx;
+        const uint32_t start = qrec.y, nlist = qrec.z;
+        const int px = bx * 16 + (int)(quad & 1u) * 8 + (lane & 7);
+        const int py = by * 16 + (int)(quad >> 1) * 8 + (lane >> 3);
+        const bool inside = px < W && py < H && !hole;
+        const mgr_v2f fpx2 = {(float)px, (float)px}, fpy2 = {(float)py, (float)py};
+        const float qx0 = (float)(bx * 16 + (int)(quad & 1u) * 8), qy0 = (float)(by * 16 + (int)(quad >> 1) * 8);
+        const uint32_t ck0 = qrec.w;  // checkpoint c (c >= 1) of this tile lives at ck0 + c - 1
+        const int pslot = (int)(quad << 6) | lane;  // pixel slot inside a checkpoint (same mapping in backward)
+        // the kernel ends when the deepest lists end: long lists issue at raised priority, the rest fill the gaps
+        if (nlist >= 8192u) __builtin_amdgcn_s_setprio(3);
+        else if (nlist >= 2048u) __builtin_amdgcn_s_setprio(2);
+        else if (nlist >= 512u) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+        float Tr = 1.0f, C2 = 0.f;
+        mgr_v2f C01 = {0.f, 0.f};   // (red, green) prefix colour
+        uint32_t last = 0;
+        const unsigned long long exec_m = __builtin_amdgcn_ballot_w64(true);
+        unsigned long long done_m = __builtin_amdgcn_ballot_w64(!inside);   // pixels whose walk has ended (lane mask, scalar)
+        const MgrGRec* const gv = grec + (size_t)v * N;
+
+        // software pipeline: rec = record of batch k, gid_n = index of batch k+1.  All pipeline loads are unconditional
+        // (indices clamped into the list): a predicated load makes hipcc drain the whole memory queue every batch.
+        FwdRec rec;
+        uint32_t gid_n;
+#if FWD_WARM
+        // Deep in a long list few entries survive the box test (3.4 pair steps per 64-entry batch behind position 2048 of
+        // the bench scene): a batch is over long before the gather issued during it returns, and the walk proceeds at one
+        // memory latency per batch.  There the records of the batch three ahead are touched by a load nobody waits for, so
+        // that the real gather finds them in the L2.
+        // (Loads return in order: the touch is issued behind the batch's real gather and its value is "used" three batches
+        // later, so that the compiler's s_waitcnt for the next batch's records leaves it outstanding.)
+        uint32_t gid_2, gid_3, warm_1 = 0, warm_2 = 0, warm_3 = 0, warm_acc = 0;
+#endif
+        const uint32_t* const sg = sorted_gid + start;
+        const uint32_t lastidx = (nlist ? nlist : 1u) - 1u;   // (a list clipped to nothing by the pair capacity: no walk, indices clamped)
+        {
+            const uint32_t g0 = min(got_gid ? pf_g0 : sg[min((uint32_t)lane, lastidx)], gid_max);
+            gid_n = got_gid ? pf_g1 : sg[min(64u + lane, lastidx)];
+#if FWD_WARM
+            gid_2 = sg[min(128u + lane, lastidx)];
+            gid_3 = sg[min(192u + lane, lastidx)];
+#endif
+            const MgrGRec* r = gv + g0;
+            rec.a = *(const float4*)r;
+            rec.b = *((const float4*)r + 1);
+            
+#ifdef KO_RECC
+                rec.c = 0.5f;
+#else
+                rec.c = r->b;
+#endif
+
+        }
+        const bool early = nlist < 2048u;
+        if (early) c_next = claim();
+        bool pf_tried = !early;
+        // the claimed next unit: its queue record if the step is published by now, and its first list indices
+        auto prefetch_next = [&]() {
+            pf_tried = true;
+            const uint32_t ns = c_next >> 2;
+            uint4 q;   // (read again from the slot when the unit starts: fewer scalars live across the walk)
+            if (ns == 0) {
+                if (blockIdx.x >= n_queue) return;
+                q = tile_qrec[blockIdx.x];
+            } else {
+                if (__hip_atomic_load(&s_step[ns % FWD_SLOTS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != ns) return;
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                q = slot_read(ns);
+            }
+            if (q.x == END || q.x == MGR_HOLE) return;
+            const uint32_t nl1 = (q.z ? q.z : 1u) - 1u;
+            pf_g0 = sorted_gid[q.y + min((uint32_t)lane, nl1)];
+            pf_g1 = sorted_gid[q.y + min(64u + lane, nl1)];
+            have_gid = true;
+        };
+#ifdef FWD_PROF
+        fp_on_ = nlist >= FWD_PROF_MIN && nlist < FWD_PROF_MAX;
+        if (fp_on_) ++fnt_;
+        if (rec.c == 12345.678f) break;   // (forces the first records to be here before the clock is read)
+#endif
+        FP(0);
+        for (uint32_t off = 0; off < nlist; off += 64) {
+            // bounding box of this quadrant's pixels that are still accumulating
+            int bx0, by0, bx1, by1;
+            if (!mgr_quad_bbox(~done_m & exec_m, bx0, by0, bx1, by1)) break;
+            bool alive = false;
+            if (off + lane < nlist)
+                alive = !mgr_box_dead(rec.a.x, rec.a.y, rec.a.z, rec.a.w, rec.b.x, mgr_qmax(rec.b.y), qx0 + (float)bx0,
+                                      qy0 + (float)by0, qx0 + (float)bx1, qy0 + (float)by1);
+            const unsigned long long m = __ballot(alive);
+            const int cnt = __popcll(m);
+            if (alive) {
+                const int rank = __popcll(m & lt);
+                float* pb = slab + (rank >> 1) * MGR_PAIR_FLOATS;
+                mgr_pair_store<true>(pb, rank & 1, rec.a.x, rec.a.y, rec.a.z, rec.a.w, rec.b.x, rec.b.y, rec.b.z, rec.b.w, rec.c,
+                               off + (uint32_t)lane + 1u);  // 1-based list position
+                if ((cnt & 1) && rank == cnt - 1) mgr_pair_pad<true>(pb);
+            }
+            // issue the gathers of the following batches; they complete during the blend below
+            {
+                const MgrGRec* r = gv + min(gid_n, gid_max);
+                rec.a = *(const float4*)r;
+                rec.b = *((const float4*)r + 1);
+                
+#ifdef KO_RECC
+                rec.c = 0.5f;
+#else
+                rec.c = r->b;
+#endif
+
+#if FWD_WARM
+                const uint32_t gw = min(cnt <= FWD_WARM ? gid_3 : gid_2, gid_max);   // (dense batches: a line the next gather fetches anyway)
+                gid_n = gid_2;
+                gid_2 = gid_3;
+                gid_3 = sg[min(off + 256u + lane, lastidx)];
+                warm_acc ^= warm_3;
+                warm_3 = warm_2;
+                warm_2 = warm_1;
+                warm_1 = *(const uint32_t*)(gv + gw);   // (the youngest load of the batch)
+#else
+                gid_n = sg[min(off + 128u + lane, lastidx)];
+#endif
+            }
+            if (provided && !pf_tried) prefetch_next();
+            if (!provided) {   // the ticket drawn at the start of the unit is back by now: publish the next step
+                const uint32_t nxt = queue.resolve(raw, lane);
+                uint4 nrec = make_uint4(END, 0u, 0u, 0u);
+                if (nxt != END) nrec = tile_qrec[nxt];
+                if (lane == 0) {
+                    s_qrec[(step + 1u) % FWD_SLOTS] = nrec;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __hip_atomic_store(&s_step[(step + 1u) % FWD_SLOTS], step + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                provided = true;
+            }
+            const int npair = (cnt + 1) >> 1;
+            FP(1);
+#if FWD_PIPE
+            // the pair records of step p + 1 are read from LDS while step p is computed (FWD_PIPE = 1: the three the alpha
+            // needs; 2: all five)
+            float4 N0, N1, N2;
+            { const float4* pp = (const float4*)slab; N0 = pp[0]; N1 = pp[1]; N2 = pp[2]; }
+#if FWD_PIPE > 1
+            float4 N3, N4;
+            { const float4* pp = (const float4*)slab; N3 = pp[3]; N4 = pp[4]; }
+#endif
+#endif
+            for (int p = 0; p < npair; ++p) {
+                const float4* pp = (const float4*)(slab + p * MGR_PAIR_FLOATS);
+#if FWD_PIPE
+                const float4 R0 = N0, R1 = N1, R2 = N2;
+#if FWD_PIPE > 1
+                const float4 R3 = N3, R4 = N4;
+#else
+                const float4 R3 = pp[3], R4 = pp[4];
+#endif
+                {
+                    const float4* pn = (const float4*)(slab + min(p + 1, 31) * MGR_PAIR_FLOATS);
+                    N0 = pn[0]; N1 = pn[1]; N2 = pn[2];
+#if FWD_PIPE > 1
+                    N3 = pn[3]; N4 = pn[4];
+#endif
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#else
+                const float4 R0 = pp[0], R1 = pp[1], R2 = pp[2], R3 = pp[3], R4 = pp[4];   // (five ds_read_b128 with the (r, g)-per-entry layout)
+#endif
+                mgr_v2f al;
+                unsigned long long ma, mb;
+                mgr_pair_alpha_masks(R0, R1, R2, fpx2, fpy2, al, ma, mb);
+                // Per entry: a = alpha if kept and the pixel still accumulates, else 0; the walk of a pixel ends where
+                // T (1 - a) < 1e-4 (that entry contributes nothing).  The lane masks of the decisions live in scalar registers:
+                // "contributes" = kept & not ended & not ending here is formed there, one select per use.
+                {   // entry a
+                    const unsigned long long keep = ma & ~done_m;
+                    const float a = mgr_sel(keep, al.x, 0.0f);
+                    const float testT = Tr * (1.0f - a);
+                    const unsigned long long stop = __builtin_amdgcn_ballot_w64(testT < 0.0001f);  // a == 0 leaves testT = Tr >= 1e-4
+                    const unsigned long long contrib = keep & ~stop;
+                    const float w = mgr_sel(contrib, a * Tr, 0.0f);
+                    C01 += mgr_v2f{R3.x, R3.y} * w;
+                    C2 += R4.x * w;
+                    Tr = mgr_sel(stop, Tr, testT);
+                    last = mgr_selu(contrib, __float_as_uint(R4.z), last);
+                    done_m |= stop;
+                }
+                {   // entry b
+                    const unsigned long long keep = mb & ~done_m;
+                    const float a = mgr_sel(keep, al.y, 0.0f);
+                    const float testT = Tr * (1.0f - a);
+                    const unsigned long long stop = __builtin_amdgcn_ballot_w64(testT < 0.0001f);
+                    const unsigned long long contrib = keep & ~stop;
+                    const float w = mgr_sel(contrib, a * Tr, 0.0f);
+                    C01 += mgr_v2f{R3.z, R3.w} * w;
+                    C2 += R4.y * w;
+                    Tr = mgr_sel(stop, Tr, testT);
+                    last = mgr_selu(contrib, __float_as_uint(R4.w), last);
+                    done_m |= stop;
+                }
+                if ((~done_m & exec_m) == 0ull) break;
+            }
+            FP(2);
+            // pixel state in front of the next chunk (prefix colour + transmittance): lets the
+            // backward pass process every MGR_CHUNK-entry chunk of the list independently
+            const uint32_t nextpos = off + 64u;
+            if ((nextpos % MGR_CHUNK) == 0 && nextpos < nlist)
+                ckpt[(size_t)(ck0 + nextpos / MGR_CHUNK - 1) * 256 + pslot] = make_float4(C01.x, C01.y, C2, Tr);
+            FP(3);
+        }
+        FP(3);
+        if (!provided) {   // (the walk ended before its first batch: all pixels outside the image, or an empty list)
+            const uint32_t nxt = queue.resolve(raw, lane);
+            uint4 nrec = make_uint4(END, 0u, 0u, 0u);
+            if (nxt != END) nrec = tile_qrec[nxt];
+            if (lane == 0) {
+                s_qrec[(step + 1u) % FWD_SLOTS] = nrec;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __hip_atomic_store(&s_step[(step + 1u) % FWD_SLOTS], step + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        if (!pf_tried) prefetch_next();
+        if (inside) {
+            const size_t pix = (size_t)py * W + px;
+            n_contrib[(size_t)v * P + pix] = last;  // (the final transmittance is not needed by the chunk-parallel backward)
+            float* o = out_color + (size_t)v * 3 * P + pix;
+            o[0] = C01.x + Tr * bg0;
+            o[P] = C01.y + Tr * bg1;
+            o[2 * P] = C2 + Tr * bg2;
+        }
+        // list depth this quadrant consumed; the tile's maximum drives the backward pass (k_fwd_items)
+        uint32_t mx = last;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
+        if (lane == 0 && !hole) tile_qdone[(size_t)vt * 4 + quad] = mx;
+#if FWD_WARM
+        asm volatile("" :: "v"(warm_acc ^ warm_1 ^ warm_2 ^ warm_3));
+#endif
+#ifdef MGR_TIMELINE
+        if (lane == 0) {
+            const unsigned int k = atomicAdd(&g_tlw_n, 1u);
+            if (k < 65536u) {
+                g_tlw[k * 4 + 0] = tlw0; g_tlw[k * 4 + 1] = wall_clock64();
+                g_tlw[k * 4 + 2] = nlist | ((unsigned long long)quad << 28) | ((unsigned long long)blockIdx.x << 32); g_tlw[k * 4 + 3] = mx;
+            }
+        }
+#endif
+        FP(5);
+    }
+    __builtin_amdgcn_s_setprio(0);
+#ifdef FWD_PROF
+    if (lane == 0) {
+        for (int k = 0; k < 6; ++k) atomicAdd(&g_fprof[k], (unsigned long long)facc_[k]);
+        atomicAdd(&g_fprof[6], (unsigned long long)fnt_);
+        atomicAdd(&g_fprof[7], 1ull);
+    }
+#endif
+    // empty tiles: background only (no per-pixel state: the backward has no work item that reads it)
+    for (uint32_t q = n_busy + blockIdx.x; q < (uint32_t)VT; q += gridDim.x) {
+        const uint32_t vt = tile_queue[q];
+        const int v = (int)(vt / (uint32_t)T), t = (int)(vt % (uint32_t)T);
+        const int px = (t % gx) * 16 + (tid & 15), py = (t / gx) * 16 + (tid >> 4);
+        if (px < W && py < H) {
+            const size_t pix = (size_t)py * W + px;
+            float* o = out_color + (size_t)v * 3 * P + pix;
+            o[0] = bg0;
+            o[P] = bg1;
+            o[2 * P] = bg2;
+        }
+        if (tid == 0) tile_done[vt] = 0;
+    }
+}
+
+// The backward blend's work items, built after the wave-granular forward blend: one 32-byte record per (tile, 64-entry
+// chunk the tile consumed) = (tile, chunk, list offset of the chunk's first entry, checkpoint in front of the chunk | list
+// depth consumed by each quadrant).  One thread per queue entry; a block reserves its range with one atomic and writes it
+// with all its threads (record i belongs to the tile found by a search of the block's scan).  Also leaves the tile's depth
+// in tile_done (the scheduling hint of the next forward).
+__global__ __launch_bounds__(256) void k_fwd_items(const uint4* __restrict__ tile_qrec, const uint32_t* __restrict__ tile_qdone,
+                                                   uint32_t* __restrict__ tile_done, uint4* __restrict__ items, MgrHeader* hdr, int ilv) {
+    __shared__ uint32_t s_scan[8];
+    __shared__ uint32_t s_base;
+    __shared__ uint32_t s_run[257];
+    __shared__ uint4 s_qr[256], s_qd[256];
+    const int tid = threadIdx.x;
+    const uint32_t n_busy = ilv ? hdr->queue_len_i : hdr->queue_len;
+    const uint32_t nb = (n_busy + 255u) / 256u;
+    if (blockIdx.x >= nb) return;
+    // strided over the queue (which is ordered by depth): every block gets its share of the deep tiles
+    const uint32_t q = (uint32_t)tid * nb + blockIdx.x;
+    uint4 qr = make_uint4(0, 0, 0, 0), qd = make_uint4(0, 0, 0, 0);
+    uint32_t nch = 0;
+    if (q < n_busy && tile_qrec[q].x != MGR_HOLE) {
+        qr = tile_qrec[q];
+        qd = *(const uint4*)(tile_qdone + (size_t)qr.x * 4);
+        const uint32_t tmax = max(max(qd.x, qd.y), max(qd.z, qd.w));
+        tile_done[qr.x] = tmax;
+        nch = (tmax + MGR_CHUNK - 1) / MGR_CHUNK;
+    }
+    uint32_t total;
+    const uint32_t run = block_excl_scan(nch, s_scan, total);
+    s_run[tid] = run;
+    s_qr[tid] = qr;
+    s_qd[tid] = qd;
+    if (tid == 0) {
+        s_run[256] = total;
+        s_base = total ? atomicAdd(&hdr->n_items, total) : 0u;
+    }
+    __syncthreads();
+    const uint32_t base = s_base;
+    for (uint32_t i = (uint32_t)tid; i < total; i += 256u) {   // consecutive threads write consecutive records
+        int lo = 0, hi = 256;   // the last tile whose first record is at or in front of i
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (s_run[mid] <= i) lo = mid; else hi = mid;
+        }
+        const uint32_t c = i - s_run[lo];
+        const uint4 r = s_qr[lo];
+        items[2 * (size_t)(base + i)] = make_uint4(r.x, c, r.y + c * MGR_CHUNK, r.w + (c > 0 ? c - 1 : 0));
+        items[2 * (size_t)(base + i) + 1] = s_qd[lo];
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -2083,6 +2589,21 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
     }
     }   // do_bin
     if (!do_blend) return MGR_OK;
+    static const bool fwd_wg = getenv("MGR_FWD") && strcmp(getenv("MGR_FWD"), "wg") == 0;   // the workgroup-per-tile version (A/B)
+    if (!fwd_wg) {
+        static const bool fwd_ilv = getenv("MGR_FWD_ILV") && atoi(getenv("MGR_FWD_ILV")) != 0;
+        const int ilv = (fwd_ilv && V <= 64) ? 1 : 0;
+        const uint4* qrec_p = (const uint4*)(ws + (ilv ? L.tile_qrec_i : L.tile_qrec));
+        if (ilv) { MGR_PROF("k_queue_interleave", stream); hipLaunchKernelGGL(k_queue_interleave, dim3(1), dim3(1024), 0, stream, V, T, (const uint4*)(ws + L.tile_qrec), (uint4*)(ws + L.tile_qrec_i), hdr); }
+        { MGR_PROF("k_blend_fwd", stream); hipLaunchKernelGGL(k_blend_fwd_w, dim3(MGR_FWD_GRID), dim3(256), 0, stream, N, W, H, gx, gy, VT, bg,
+                           (const uint32_t*)(ws + L.tile_queue), qrec_p, (const uint32_t*)(ws + L.sorted_gid), (const MgrGRec*)(ws + L.grec), out_color,
+                           (uint32_t*)(ws + L.n_contrib), (uint32_t*)(ws + L.tile_done), (uint32_t*)(ws + L.tile_qdone),
+                           (float4*)(ws + L.ckpt), hdr, ilv); }
+        { MGR_PROF("k_fwd_items", stream); hipLaunchKernelGGL(k_fwd_items, dim3((VT + 64 + 255) / 256), dim3(256), 0, stream, qrec_p,
+                           (const uint32_t*)(ws + L.tile_qdone), (uint32_t*)(ws + L.tile_done), (uint4*)(ws + L.items), hdr, ilv); }
+        MGR_LAUNCH_CHECK("k_blend_fwd", stream, debug);
+        return MGR_OK;
+    }
     { MGR_PROF("k_blend_fwd", stream); hipLaunchKernelGGL(k_blend_fwd, dim3(MGR_FWD_GRID), dim3(256), 0, stream, N, W, H, gx, gy, VT, bg, tile_start,
                        (const uint32_t*)(ws + L.tile_queue), (const uint4*)(ws + L.tile_qrec), (const uint32_t*)(ws + L.sorted_gid), (const MgrGRec*)(ws + L.grec), out_color,
                        (float*)(ws + L.final_T), (uint32_t*)(ws + L.n_contrib),
