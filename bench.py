@@ -132,8 +132,7 @@ def cpu_baseline_and_parity(scene_cpu, cams, targets_cpu, gpu, sample_views=2, n
     the sampled views, grec (K,N,12), depth (K,N), radii (K,N) as numpy / cpu tensors."""
     from oracle import BlendOracle, RasterOracle
     from oracle import torch_ref as tr
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from fused_oracle import align_threshold_decisions, kernel_last_gaussian   # (the -m gpu tests assert the same comparison)
+    from tools.parity import align_threshold_decisions, kernel_last_gaussian   # (the -m gpu tests assert the same comparison)
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
@@ -198,7 +197,7 @@ def cpu_baseline_and_parity(scene_cpu, cams, targets_cpu, gpu, sample_views=2, n
                          np.ones(3, np.float32))
         ii = par["identical_inputs"]
         # pairs within rounding of the alpha / transmittance thresholds take the side the KERNELS took (their own device
-        # function is asked: tests/fused_oracle.py); what remains is arithmetic
+        # function is asked: tools/parity.py); what remains is arithmetic
         amb, fl, sfl, svi = align_threshold_decisions(bo, r, r[:, 6:9], np.ones(3, np.float32), W,
                                                       kernel_last_gaussian(k, K, N, W, H, gpu["n_contrib"][k]))
         ii["pairs_within_2e-4_of_alpha_threshold"] += amb

@@ -448,6 +448,29 @@ int mgr_mesh_sdf(int n, const float* points, int nv, const float* verts, int nf,
                  float* out_winding, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Row-compacted gradient exchange of the view-sharded step (no reference counterpart: the reference trains
+ * on one GPU, /root/reference/main.py:84-87).  The step buffer `flat` holds nseg segments of N rows (segment k: widths[k]
+ * floats per row, first float at offs[k]), the visibility counts (N floats at vis_off) and (loss, overflow) at tail_off.
+ * Between two SUM all-reduces issued by the host (torch.distributed / RCCL):
+ *   mgr_exchange_mask    small[0:N] = 1 where the row may be non-zero -- from the rows themselves, or (active_list /
+ *                        active_count: device pointers of mgr_views_active_list) from the fused backward's list of the
+ *                        Gaussians that received a gradient --, small[N:2N] = the visibility counts as bytes
+ *   mgr_exchange_index   idx = the rows with mask != 0 in ascending order, *count (device) their number
+ *   mgr_exchange_pack    buf = [segment 0 rows (n x widths[0]) | segment 1 rows | ... | loss, overflow]
+ *   mgr_exchange_unpack  the inverse into `flat` (rows outside idx untouched) and, when small_vis is given, the visibility
+ *                        counts back as floats
+ * ------------------------------------------------------------------------ */
+int mgr_exchange_mask(int N, const float* flat, int nseg, const int64_t* offs, const int* widths, int64_t vis_off,
+                      const uint32_t* active_list, const uint32_t* active_count, uint8_t* small, void* stream);
+size_t mgr_exchange_index_workspace_bytes(int N);
+int mgr_exchange_index(int N, const uint8_t* mask, uint32_t* idx, uint32_t* count, void* workspace, size_t workspace_bytes,
+                       void* stream);
+int mgr_exchange_pack(int N, int n, const uint32_t* idx, const float* flat, int nseg, const int64_t* offs, const int* widths,
+                      int64_t tail_off, float* buf, void* stream);
+int mgr_exchange_unpack(int N, int n, const uint32_t* idx, float* flat, int nseg, const int64_t* offs, const int* widths,
+                        int64_t tail_off, const float* buf, const uint8_t* small_vis, int64_t vis_off, void* stream);
+
+/* ------------------------------------------------------------------------
  * Measurement aid: when enabled, every kernel launched by this library is
  * bracketed by HIP events recorded on the caller's stream.
  * mgr_profile_report synchronises the stream, writes one line per kernel

@@ -57,6 +57,12 @@ SIGNATURES = {
     "mgr_keypoint_far_mask": (c_int, [c_int, c_vp, c_int, c_vp, c_f32, c_vp, c_vp]),
     "mgr_knn3_workspace_bytes": (c_sz, [c_int]),
     "mgr_knn3_mean_dist2": (c_int, [c_int, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "mgr_exchange_mask": (c_int, [c_int, c_vp, c_int, ctypes.POINTER(c_i64), ctypes.POINTER(c_int), c_i64, c_vp, c_vp, c_vp, c_vp]),
+    "mgr_exchange_index_workspace_bytes": (c_sz, [c_int]),
+    "mgr_exchange_index": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "mgr_exchange_pack": (c_int, [c_int, c_int, c_vp, c_vp, c_int, ctypes.POINTER(c_i64), ctypes.POINTER(c_int), c_i64, c_vp, c_vp]),
+    "mgr_exchange_unpack": (c_int, [c_int, c_int, c_vp, c_vp, c_int, ctypes.POINTER(c_i64), ctypes.POINTER(c_int), c_i64, c_vp, c_vp,
+                                    c_i64, c_vp]),
     "mgr_l1_loss_grad": (c_int, [c_i64, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp]),
     "mgr_image_loss_workspace_bytes": (c_sz, [c_int, c_int, c_int]),
     "mgr_image_loss": (c_int, [c_int, c_int, c_int, c_vp, c_vp, c_f32, c_f32, c_f32, c_f32, c_vp, c_vp, c_vp, c_sz, c_vp]),

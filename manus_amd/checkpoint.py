@@ -47,6 +47,19 @@ def remove_nans_from_checkpoint(checkpoint):
     for key in list(sd.keys()):
         sd[key] = sd[key][keep]
     checkpoint.setdefault("extra_params", {})["num_gaussians"] = sd["model._xyz"].shape[0]
+    # the optimizer state `save_checkpoint(optimizer=...)` adds is per row too: drop the same rows, so that a resume
+    # does not fail (later, in load_state_dict) on a row count that no longer matches the leaves
+    opt = checkpoint.get("manus_amd_optimizer")
+    if isinstance(opt, dict) and bool(nan_mask.any()):
+        def rows(v):
+            if torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == n:
+                return v[keep.to(v.device)]
+            if isinstance(v, dict):
+                return {k: rows(x) for k, x in v.items()}
+            if isinstance(v, (list, tuple)):
+                return type(v)(rows(x) for x in v)
+            return v
+        checkpoint["manus_amd_optimizer"] = rows(opt)
     return checkpoint
 
 
@@ -58,9 +71,10 @@ def load_checkpoint(ckpt_path, device=torch.device("cpu"), allow_pickle=False, r
     trained themselves).  Here that is opt-in: allow_pickle=True -- a file the safe loader rejects is exactly the one that
     can execute code while loading.  return_checkpoint=True also returns the whole dict (optimizer state written by
     `save_checkpoint(optimizer=...)` sits under "manus_amd_optimizer")."""
+    import pickle
     try:
         ckpt = torch.load(ckpt_path, map_location=device, weights_only=True)
-    except Exception as e:
+    except pickle.UnpicklingError as e:     # (a missing or corrupt file raises something else and is not re-labelled)
         if not allow_pickle:
             raise RuntimeError("%s holds pickled objects the safe loader refuses (%s); pass allow_pickle=True if you trust "
                                "the file" % (ckpt_path, e)) from e
@@ -74,8 +88,8 @@ def load_checkpoint(ckpt_path, device=torch.device("cpu"), allow_pickle=False, r
     return weights, ckpt.get("extra_params", {})
 
 
-def get_num_gaussians_from_checkpoint(ckpt_path):
-    return load_checkpoint(ckpt_path)[1]["num_gaussians"]
+def get_num_gaussians_from_checkpoint(ckpt_path, allow_pickle=False):
+    return load_checkpoint(ckpt_path, allow_pickle=allow_pickle)[1]["num_gaussians"]
 
 
 def save_checkpoint(ckpt_dir, params, epoch, step, loss, grid=None, mano_weights=None, extra_state=None, optimizer=None):

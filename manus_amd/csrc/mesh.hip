@@ -67,15 +67,18 @@ __global__ __launch_bounds__(MS_T) void k_knn_mean_rows(int n, const float* __re
         }
     }
     if (i >= n) return;
+    // a query with a non-finite coordinate has no nearest row (no distance beats the sentinel): NaN / -1 like torch.cdist +
+    // topk + mean propagate it, not rows[0] k times; with fewer than k rows the mean is over the rows there are
     const int kk = min(k, m);
+    const bool finite = px - px == 0.f && py - py == 0.f && pz - pz == 0.f;
     if (out_idx)
-        for (int j = 0; j < k; ++j) out_idx[(size_t)i * k + j] = j < kk ? bi[j] : -1;
+        for (int j = 0; j < k; ++j) out_idx[(size_t)i * k + j] = (finite && j < kk) ? bi[j] : -1;
     if (out) {
-        const float inv = 1.0f / (float)k;
+        const float inv = 1.0f / (float)(kk > 0 ? kk : 1);
         for (int c = 0; c < C; ++c) {
             float s = 0.f;
             for (int j = 0; j < kk; ++j) s += rows[(size_t)bi[j] * C + c];
-            out[(size_t)i * C + c] = s * inv;
+            out[(size_t)i * C + c] = finite ? s * inv : __builtin_nanf("");
         }
     }
 }

@@ -71,10 +71,9 @@ struct MgrHeader {            // first 256 bytes of the workspace
     uint32_t queue_small;     // queue index of the first tile with fewer than 2048 pairs
     uint32_t queue_head3;     // cursor of the small-tile sort
     uint32_t n_active;        // Gaussians with a non-zero pair gradient in the current view group (fused backward)
-    uint32_t queue_len_i;     // length of the view-interleaved queue of the forward blend (with holes), 0 = not built
+    uint32_t queue_len_i;     // length of the view-interleaved queue of the forward blend (tile_qrec, with holes)
     uint32_t pad[4];
-    uint32_t cls_count[34];   // tiles per size class (class = bit length of the pair count, 0 = empty)
-    uint32_t cls_cursor[34];  // running cursors of the queue scatter
+    uint32_t spare[68];       // (the size-class counters of the tile scan lived here: it now derives them from per-block histograms)
     uint32_t queue_giant;     // queue index of the first tile with fewer than 16384 pairs
     uint32_t n_groups;        // depth groups produced by k_tile_split for the giant tiles
     uint32_t split_head, group_head;
@@ -102,8 +101,8 @@ struct __attribute__((aligned(16))) MgrGRec {
 #define MGR_CHUNK 64         // list entries per backward work item / forward checkpoint interval (one batch of the blend waves)
 
 struct MgrLayout {
-    size_t header, scan_part, grec, depth, rect, alive, pair_off, tile_count, tile_start, tile_cursor, tile_done, tile_qdone,
-        tile_queue, tile_qrec, tile_qrec_i, chunk_start, items, ckpt, keys, keys2, groups, sorted_gid, final_T, n_contrib, pair_tag, pair_grad, inst_grad, inst_tag,
+    size_t header, scan_part, scan_cls, grec, depth, rect, alive, pair_off, tile_count, tile_start, tile_cursor, tile_done, tile_qdone,
+        tile_queue, tile_qrec, chunk_start, items, ckpt, keys, keys2, groups, sorted_gid, final_T, n_contrib, pair_tag, pair_grad, inst_grad, inst_tag,
         db_count, db_cursor, db_start, db_nvis, db_bbox, db_keys, db_order, db_rec, bin_mat, total;
 };
 
@@ -124,7 +123,9 @@ static inline MgrLayout mgr_layout(int V, int N, int W, int H, int64_t cap) {
     size_t c = (size_t)(cap > 0 ? cap : 1);
     size_t o = 0;
     L.header = o;      o += mgr_align(sizeof(MgrHeader));
-    L.scan_part = o;   o += mgr_align(((VT + 1023) / 1024 + 1) * 8);  // per-block (pairs, chunks) sums of the tile scan
+    const size_t scan_blocks = (size_t)V * ((gx * gy + 1023) / 1024);      // the tile scan runs blocks of up to 1024 tiles of one view
+    L.scan_part = o;   o += mgr_align((scan_blocks + 1) * 8);         // per-block (pairs, chunks) sums of the tile scan
+    L.scan_cls = o;    o += mgr_align(scan_blocks * 34 * 4);          // per-block histogram of its tiles over the size classes
     L.grec = o;        o += mgr_align(VN * sizeof(MgrGRec));
     L.depth = o;       o += mgr_align(VN * 4);
     L.rect = o;        o += mgr_align(VN * 8);       // 4 x uint16
@@ -136,8 +137,7 @@ static inline MgrLayout mgr_layout(int V, int N, int W, int H, int64_t cap) {
     L.tile_done = o;   o += mgr_align(VT * 4);
     L.tile_qdone = o;  o += mgr_align(VT * 16);       // list depth each 8x8 quadrant of a tile consumed in the forward blend
     L.tile_queue = o;  o += mgr_align(VT * 4);
-    L.tile_qrec = o;   o += mgr_align(VT * 16);       // queue records of the forward blend: (tile, list offset, list length, first checkpoint)
-    L.tile_qrec_i = o; o += mgr_align((VT + 64) * 16); // the same, interleaved by view: position p holds a tile of view p % V (or a hole)
+    L.tile_qrec = o;   o += mgr_align(VT * 16);       // queue of the forward blend, interleaved by view: position p = (tile, list offset, list length, first checkpoint) of a tile of view p % V, or a hole
     L.chunk_start = o; o += mgr_align((VT + 1) * 4);
     L.items = o;       o += mgr_align((c / MGR_CHUNK + VT + 1) * 32);   // 32-byte record per (tile, chunk) work item of the backward blend
     L.ckpt = o;        o += mgr_align((c / MGR_CHUNK + 1) * 256 * 16);  // float4 per pixel per checkpoint

@@ -146,11 +146,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BWD_WAVES, 
         const uint32_t gid = sorted_gid[recA.z + (uint32_t)min(lane, cnt - 1)];
         float4 ra, rb, rcz;   // (x, y, conic A, B | conic C, opacity, colour r, g | colour b, slot base, rect width, -)
         {
-#ifdef KO_GATHER
-            const MgrGRec* r = gv + (gid & 4095u);
-#else
             const MgrGRec* r = gv + gid;
-#endif
             ra = *(const float4*)r;
             rb = *((const float4*)r + 1);
             rcz = *((const float4*)r + 2);

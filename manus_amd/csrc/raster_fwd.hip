@@ -346,9 +346,6 @@ __global__ __launch_bounds__(PRE_THREADS) void k_inst_fwd(
 // K2: exclusive scan of the V*T tile counts -> tile_start; queue of non-empty
 // tiles ordered by descending size class (largest first = LPT scheduling)
 // ---------------------------------------------------------------------------
-// Phase A: per-block sums of (pairs, checkpoint chunks) over 1024 tiles, and the global
-// histogram of size classes.
-//
 // Queue key.  The forward blend takes the tiles largest first (LPT), and what a tile costs is the list depth its pixels
 // consume, not the list's length: the per-tile timeline (-DMGR_TIMELINE=2) showed lists of 4 000-8 000 entries that saturate
 // after 300-900 (30-90 us) at the head of the queue while never-saturating lists of 3 000-4 000 entries (120 us) started at
@@ -361,29 +358,46 @@ __device__ __forceinline__ uint32_t mgr_queue_key(uint32_t count, uint32_t prev_
     return (use_hint && count && prev_done) ? min(count, prev_done) : count;
 }
 
-__global__ __launch_bounds__(1024) void k_tile_scan_a(int VT, const uint32_t* __restrict__ tile_count,
+#define MGR_HOLE 0xFFFFFFFEu   // a position of the view-interleaved queue its view has no tile for
+#define MGR_NCLS 34
+
+// Phase A: one block = up to 1024 tiles of ONE view (grid = V x ceil(T / 1024), view-major like the tile index, so the
+// block sums are in tile order).  Per block: the sums of pairs and checkpoints and the histogram of its tiles over the size
+// classes -- written, not accumulated: phase B re-derives every base from these few numbers, so the queues need neither
+// global atomics nor counters that somebody has to clear.
+__global__ __launch_bounds__(1024) void k_tile_scan_a(int T, int nbT, const uint32_t* __restrict__ tile_count,
                                                       const uint32_t* __restrict__ tile_done, int use_hint,
-                                                      uint2* __restrict__ part, MgrHeader* hdr) {
+                                                      uint2* __restrict__ part, uint32_t* __restrict__ blk_cls) {
     __shared__ uint32_t s_scan[32];
-    __shared__ uint32_t s_cls[34];
-    const int tid = threadIdx.x, k = blockIdx.x * 1024 + tid;
-    if (tid < 34) s_cls[tid] = 0;
+    __shared__ uint32_t s_cls[MGR_NCLS];
+    const int tid = threadIdx.x, v = blockIdx.x / nbT, t = (blockIdx.x % nbT) * 1024 + tid;
+    const bool valid = t < T;
+    const size_t k = (size_t)v * T + t;
+    if (tid < MGR_NCLS) s_cls[tid] = 0;
     __syncthreads();
-    const uint32_t c = k < VT ? tile_count[k] : 0u;
-    const uint32_t key = mgr_queue_key(c, k < VT ? tile_done[k] : 0u, use_hint);
-    if (k < VT) atomicAdd(&s_cls[key ? 32 - __clz(key) : 0], 1u);
+    const uint32_t c = valid ? tile_count[k] : 0u;
+    const uint32_t key = mgr_queue_key(c, valid ? tile_done[k] : 0u, use_hint);
+    if (valid) atomicAdd(&s_cls[key ? 32 - __clz(key) : 0], 1u);
     uint32_t total, ctotal;
     (void)block_excl_scan(c, s_scan, total);
     (void)block_excl_scan(c ? (c - 1) / MGR_CHUNK : 0u, s_scan, ctotal);
     if (tid == 0) part[blockIdx.x] = make_uint2(total, ctotal);
-    if (tid < 34 && s_cls[tid]) atomicAdd(&hdr->cls_count[tid], s_cls[tid]);
+    if (tid < MGR_NCLS) blk_cls[(size_t)blockIdx.x * MGR_NCLS + tid] = s_cls[tid];
 }
 
-// Phase B: every block re-derives its base from the (few) block sums, writes tile_start /
-// chunk_start, and scatters its tiles into the size-ordered queue (largest class first, empty
-// tiles last; order inside a class is arbitrary).
-__global__ __launch_bounds__(1024) void k_tile_scan_b(int VT, int nblk, uint32_t* __restrict__ tile_count,
-                                                      const uint2* __restrict__ part,
+// Phase B: every block re-derives its bases from the block sums and block histograms, writes tile_start / chunk_start,
+// and places its tiles in two queues:
+//  * tile_queue -- all tiles of all views by descending size class, empty tiles last (the per-tile sort route cuts it
+//    at class boundaries; the forward blend background-fills its empty tail);
+//  * tile_qrec -- the forward blend's queue, INTERLEAVED BY VIEW: position p holds the (p / V)-th deepest tile of view
+//    p % V as a self-contained record (tile, list offset, list length, first checkpoint), or a hole when that view has
+//    fewer tiles.  MgrQueue's counter c hands out the positions c, c + 16, ... and a workgroup's home counter is its index
+//    mod 16, so with 8 views the workgroups of XCD x -- every eighth -- blend the tiles of view x while it has any: each L2
+//    holds ONE view's Gaussian records (measured: 27 % of the blend's gathers that miss the L1 hit the L2 with views
+//    mixed over the XCDs; k_blend_fwd 0.367 -> 0.325 ms with this order).  A scheduling matter only.
+// Order inside a (view, class) is by block, then arbitrary inside a block.
+__global__ __launch_bounds__(1024) void k_tile_scan_b(int V, int T, int nbT, uint32_t* __restrict__ tile_count,
+                                                      const uint2* __restrict__ part, const uint32_t* __restrict__ blk_cls,
                                                       uint32_t* __restrict__ tile_start,
                                                       uint32_t* __restrict__ tile_cursor,
                                                       uint32_t* __restrict__ tile_queue, uint4* __restrict__ tile_qrec,
@@ -391,67 +405,89 @@ __global__ __launch_bounds__(1024) void k_tile_scan_b(int VT, int nblk, uint32_t
                                                       uint32_t* __restrict__ chunk_start, MgrHeader* hdr,
                                                       uint32_t cap) {
     __shared__ uint32_t s_scan[32];
-    __shared__ uint32_t s_cbase[34], s_lc[34], s_gb[34];
-    __shared__ uint32_t s_base[2], s_tot[2];
-    const int tid = threadIdx.x, k = blockIdx.x * 1024 + tid;
-    if (tid < 34) s_lc[tid] = 0;
-    if (tid == 0) {
+    __shared__ uint32_t s_gtot[MGR_NCLS], s_gpre[MGR_NCLS], s_vtot[MGR_NCLS], s_vpre[MGR_NCLS];   // tiles per class: all / in front of this block, of all views / of this view
+    __shared__ uint32_t s_gbase[MGR_NCLS], s_vbase[MGR_NCLS], s_lc[MGR_NCLS];
+    __shared__ uint32_t s_base[2], s_tot[2], s_maxnb, s_nbv;
+    const int tid = threadIdx.x, nblk = V * nbT, b = blockIdx.x, v = b / nbT, t = (b % nbT) * 1024 + tid;
+    const bool valid = t < T;
+    const size_t k = (size_t)v * T + t;
+    if (tid < MGR_NCLS) {   // thread c: class c over the blocks
+        uint32_t gt = 0, gp = 0, vt = 0, vp = 0;
+        for (int j = 0; j < nblk; ++j) {
+            const uint32_t x = blk_cls[(size_t)j * MGR_NCLS + tid];
+            gt += x;
+            if (j < b) gp += x;
+            if (j / nbT == v) { vt += x; if (j < b) vp += x; }
+        }
+        s_gtot[tid] = gt; s_gpre[tid] = gp; s_vtot[tid] = vt; s_vpre[tid] = vp;
+        s_lc[tid] = 0;
+    }
+    if (tid == 64) {
         uint32_t r = 0, rc = 0, b0 = 0, b1 = 0;
         for (int j = 0; j < nblk; ++j) {
-            if (j == (int)blockIdx.x) { b0 = r; b1 = rc; }
+            if (j == b) { b0 = r; b1 = rc; }
             r += part[j].x;
             rc += part[j].y;
         }
         s_base[0] = b0; s_base[1] = b1; s_tot[0] = r; s_tot[1] = rc;
-        uint32_t q = 0;  // descending class order
-        for (int c = 33; c >= 0; --c) {
-            s_cbase[c] = q;
-            q += hdr->cls_count[c];
-        }
+        s_maxnb = 0;
     }
     __syncthreads();
-    const uint32_t c = k < VT ? tile_count[k] : 0u;
-    if (k < VT) tile_count[k] = 0;  // consumed: left zero for the next forward (no per-call memset of V*T counters)
+    // non-empty tiles per view (threads 128 ..: one view each, strided) -> the longest view sets the interleaved queue's length
+    for (int w = tid - 128; w >= 0 && w < V; w += 896) {
+        uint32_t nb = 0;
+        for (int j = w * nbT; j < (w + 1) * nbT; ++j)
+            for (int c = 1; c < MGR_NCLS; ++c) nb += blk_cls[(size_t)j * MGR_NCLS + c];
+        atomicMax(&s_maxnb, nb);
+    }
+    if (tid == 0) {
+        uint32_t q = 0, qv = 0;  // descending class order; class 0 (empty tiles) last in the global queue
+        for (int c = MGR_NCLS - 1; c >= 0; --c) {
+            s_gbase[c] = q;
+            q += s_gtot[c];
+            s_vbase[c] = qv;
+            if (c > 0) qv += s_vtot[c];
+        }
+        s_nbv = qv;
+    }
+    __syncthreads();
+    const uint32_t c = valid ? tile_count[k] : 0u;
+    if (valid) tile_count[k] = 0;  // consumed: left zero for the next forward (no per-call memset of V*T counters)
     uint32_t total, ctotal;
     const uint32_t run = block_excl_scan(c, s_scan, total);
     const uint32_t crun = block_excl_scan(c ? (c - 1) / MGR_CHUNK : 0u, s_scan, ctotal);
-    // queue slot = class base + this block's base inside the class (ONE global atomic per
-    // (block, class)) + rank inside the block (LDS atomic)
-    const uint32_t key = mgr_queue_key(c, k < VT ? tile_done[k] : 0u, use_hint);
+    const uint32_t key = mgr_queue_key(c, valid ? tile_done[k] : 0u, use_hint);
     const int cls = key ? 32 - __clz(key) : 0;
-    uint32_t rank = 0;
-    if (k < VT) {
+    if (valid) {
         tile_start[k] = s_base[0] + run;
         chunk_start[k] = s_base[1] + crun;
         tile_cursor[k] = 0;
-        rank = atomicAdd(&s_lc[cls], 1u);
+        const uint32_t rank = atomicAdd(&s_lc[cls], 1u);
+        tile_queue[s_gbase[cls] + s_gpre[cls] + rank] = (uint32_t)k;
+        if (cls > 0) {
+            const uint32_t st = min(s_base[0] + run, cap), en = min(s_base[0] + run + c, cap);
+            tile_qrec[(size_t)(s_vbase[cls] + s_vpre[cls] + rank) * V + v] = make_uint4((uint32_t)k, st, en - st, s_base[1] + crun);
+        }
     }
-    __syncthreads();
-    if (tid < 34) s_gb[tid] = s_lc[tid] ? atomicAdd(&hdr->cls_cursor[tid], s_lc[tid]) : 0u;
-    __syncthreads();
-    if (k < VT) {
-        const uint32_t qslot = s_cbase[cls] + s_gb[cls] + rank;
-        tile_queue[qslot] = (uint32_t)k;
-        // what the forward blend needs to start on the tile, in one load: (tile, list offset, list length, first checkpoint)
-        const uint32_t st = min(s_base[0] + run, cap), en = min(s_base[0] + run + c, cap);
-        tile_qrec[qslot] = make_uint4((uint32_t)k, st, en - st, s_base[1] + crun);
-    }
-    if (blockIdx.x == 0 && tid == 0) {
-        tile_start[VT] = s_tot[0];
-        chunk_start[VT] = s_tot[1];
+    // holes behind this view's last tile (its blocks share them out)
+    for (uint32_t r = s_nbv + (uint32_t)(b % nbT) * 1024u + (uint32_t)tid; r < s_maxnb; r += (uint32_t)nbT * 1024u)
+        tile_qrec[(size_t)r * V + v] = make_uint4(MGR_HOLE, 0u, 0u, 0u);
+    if (b == 0 && tid == 0) {
+        tile_start[(size_t)V * T] = s_tot[0];
+        chunk_start[(size_t)V * T] = s_tot[1];
         hdr->overflow = (s_tot[0] > cap || hdr->total_pairs > cap) ? 1u : 0u;
         hdr->n_items = 0;
         hdr->item_head = 0;
-        hdr->queue_len = s_cbase[0];  // class 0 (empty tiles) starts after all non-empty ones
-        hdr->queue_small = s_cbase[11]; // classes <= 11: fewer than 2048 pairs
-        hdr->queue_giant = s_cbase[13]; // classes >= 14: at least 8192 pairs (split into depth groups before sorting)
+        hdr->queue_len = s_gbase[0];     // class 0 (empty tiles) starts after all non-empty ones
+        hdr->queue_len_i = s_maxnb * (uint32_t)V;
+        hdr->queue_small = s_gbase[11];  // classes <= 11: fewer than 2048 pairs
+        hdr->queue_giant = s_gbase[13];  // classes >= 14: at least 8192 pairs (split into depth groups before sorting)
         hdr->n_groups = 0;
         hdr->split_head = 0;
         hdr->group_head = 0;
         hdr->queue_head = 0;
-        hdr->queue_head2 = MGR_FWD_GRID;   // k_blend_fwd (workgroup version): workgroup b starts with queue entry b
-        for (int c = 0; c < MGR_NCTR; ++c) hdr->qctr_f[c * 64] = MGR_FWD_GRID / MGR_NCTR;   // wave-granular version: its tickets start behind the grid too
-        hdr->queue_head3 = s_cbase[11];
+        hdr->queue_head3 = s_gbase[11];
+        for (int cc = 0; cc < MGR_NCTR; ++cc) hdr->qctr_f[cc * 64] = MGR_FWD_GRID / MGR_NCTR;   // k_blend_fwd: workgroup w starts with queue position w, the tickets behind the grid
     }
 }
 
@@ -1530,19 +1566,6 @@ __global__ __launch_bounds__(BIN_SC_THREADS) void k_bin_scatter(int N, int T, in
 #endif
 }
 
-// ---------------------------------------------------------------------------
-// K5: front-to-back alpha compositing, one 16x16 tile at a time per 256-thread workgroup.
-//  * persistent workgroups: non-empty tiles are pulled from the size-ordered queue (largest
-//    first), then the empty tiles are background-filled with a static stride;
-//  * wave w owns the 8x8 pixel quadrant (w&1, w>>1) and walks the tile's list on its own, 64
-//    entries per batch, with no workgroup barrier inside a tile: each lane fetches one entry
-//    (index two batches ahead, record one batch ahead of the blend), tests it against the
-//    bounding box of the quadrant's still-active pixels (mgr_box_dead) and the survivors are
-//    compacted pairwise into the wave's LDS slab (mgr_pair_store);
-//  * the blend loop then takes two entries per step with packed fp32 math; only the short
-//    transmittance update is sequential;
-//  * every MGR_CHUNK entries the per-pixel prefix state is checkpointed for the backward pass.
-// ---------------------------------------------------------------------------
 struct FwdRec {
     float4 a, b;
     float c;
@@ -1582,310 +1605,6 @@ extern "C" int mgr_debug_fprof(unsigned long long* dst) {
 #else
 #define FWD_OCC
 #endif
-__global__ __launch_bounds__(256) FWD_OCC void k_blend_fwd(int N, int W, int H, int gx, int gy, int VT,
-                                                   const float* __restrict__ bg,
-                                                   const uint32_t* __restrict__ tile_start,
-                                                   const uint32_t* __restrict__ tile_queue,
-                                                   const uint4* __restrict__ tile_qrec,
-                                                   const uint32_t* __restrict__ sorted_gid,
-                                                   const MgrGRec* __restrict__ grec,
-                                                   float* __restrict__ out_color,
-                                                   float* __restrict__ final_T,
-                                                   uint32_t* __restrict__ n_contrib,
-                                                   uint32_t* __restrict__ tile_done,
-                                                   const uint32_t* __restrict__ chunk_start,
-                                                   float4* __restrict__ ckpt,
-                                                   uint4* __restrict__ items, MgrHeader* hdr,
-                                                   uint32_t cap) {
-    __shared__ __align__(16) float s_pair[4][32][MGR_PAIR_FLOATS];
-    __shared__ uint32_t s_qmx[4], s_next, s_ibase;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int T = gx * gy;
-    const uint32_t n_busy = hdr->queue_len;
-    const size_t P = (size_t)W * H;
-    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
-    const int pslot = (wave << 6) | lane;  // pixel slot inside a checkpoint (same mapping in backward)
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    float* const slab = &s_pair[wave][0][0];
-
-#ifdef MGR_TIMELINE
-    unsigned long long tl0 = wall_clock64(), ntl = 0;
-#endif
-#ifdef FWD_PROF
-    long long facc_[6] = {0, 0, 0, 0, 0, 0}, ftp_ = wall_clock64(), fnt_ = 0;
-    bool fp_on_ = true;   // -DFWD_PROF_MIN / -DFWD_PROF_MAX: only tiles with a list length in [MIN, MAX)
-#endif
-    // the first tile of a workgroup is its own index (the tile scan starts the queue cursor at the grid size): 2048
-    // workgroups drawing their first ticket from one counter at the same moment are served one after the other
-    if (tid == 0) s_next = blockIdx.x;
-    if (blockIdx.x == 0 && tid < 34) {  // consumed by the tile scan: zero for the next forward (no per-call memset)
-        hdr->cls_count[tid] = 0;
-        hdr->cls_cursor[tid] = 0;
-    }
-    __syncthreads();
-    // Tile prologue pipeline.  A tile used to start with four dependent round trips (queue entry -> list bounds -> list
-    // indices -> Gaussian records: 7 us of a mean 52 us per tile, -DFWD_PROF).  The queue now holds self-contained records
-    // (tile, list offset, list length, first checkpoint: one scalar load), and when the next ticket is known before the
-    // tile ends (short lists draw it early) the next tile's record and its first two batches of list indices are fetched
-    // in the epilogue, while thread 0 waits for its atomics: only the Gaussian records remain at the top of the loop.
-    uint32_t item = s_next;
-    const uint32_t last_q = (n_busy ? n_busy : 1u) - 1u;
-    uint4 qrec = tile_qrec[min(item, last_q)];
-    bool have_gid = false;
-    uint32_t pf_g0 = 0, pf_g1 = 0;
-    while (item < n_busy) {
-#ifdef MGR_TIMELINE
-        ++ntl;
-        const unsigned long long tl_tile0 = wall_clock64();
-#endif
-        const uint32_t vt = qrec.x;
-        const int v = (int)(vt / (uint32_t)T), t = (int)(vt % (uint32_t)T);
-        const int bx = t % gx, by = t / gx;
-        const uint32_t start = qrec.y, nlist = qrec.z;
-        const int px = bx * 16 + (wave & 1) * 8 + (lane & 7);
-        const int py = by * 16 + (wave >> 1) * 8 + (lane >> 3);
-        const bool inside = px < W && py < H;
-        const mgr_v2f fpx2 = {(float)px, (float)px}, fpy2 = {(float)py, (float)py};
-        const float qx0 = (float)(bx * 16 + (wave & 1) * 8), qy0 = (float)(by * 16 + (wave >> 1) * 8);
-        const uint32_t ck0 = qrec.w;  // checkpoint c (c >= 1) of this tile lives at ck0 + c - 1
-        // The kernel ends when the deepest tiles end, and their waves share a SIMD with up to five
-        // waves of ordinary tiles: long lists issue at raised priority, the rest fill the gaps.
-        // (graded by list length; measured: 0.369 ms with one threshold at 4096, 0.361 ms graded)
-        if (nlist >= 8192u) __builtin_amdgcn_s_setprio(3);
-        else if (nlist >= 2048u) __builtin_amdgcn_s_setprio(2);
-        else if (nlist >= 512u) __builtin_amdgcn_s_setprio(1);
-        else __builtin_amdgcn_s_setprio(0);
-        __syncthreads();                       // everyone has read s_next
-        // The next ticket is drawn early (its latency hidden behind this tile) only for short lists.  Behind a long
-        // list an early ticket reserves one of the NEXT largest tiles for as long as this one takes: measured with the
-        // per-tile timeline, half of the tiles of more than 4096 pairs started 50-150 us late that way and one of
-        // them ended the kernel.  Long lists draw their ticket when they are done.
-        const bool early_ticket = nlist < 2048u;
-        if (tid == 0 && early_ticket) s_next = atomicAdd(&hdr->queue_head2, 1u);
-        float Tr = 1.0f, C2 = 0.f;
-        mgr_v2f C01 = {0.f, 0.f};   // (red, green) prefix colour
-        uint32_t last = 0;
-#ifdef MGR_STATS
-        uint32_t stop_pos = 0;
-#endif
-        bool done = !inside;
-        const MgrGRec* const gv = grec + (size_t)v * N;
-
-        // software pipeline: rec = record of batch k, gid_n = index of batch k+1.  All pipeline
-        // loads are unconditional (indices clamped into the list): a predicated load makes hipcc
-        // drain the whole memory queue (s_waitcnt vmcnt(0)) every batch.
-        FwdRec rec;
-        uint32_t gid_n;
-        const uint32_t* const sg = sorted_gid + start;
-        const uint32_t lastidx = nlist - 1u;
-        {
-            const uint32_t g0 = have_gid ? pf_g0 : sg[min((uint32_t)lane, lastidx)];
-            gid_n = have_gid ? pf_g1 : sg[min(64u + lane, lastidx)];
-            const MgrGRec* r = gv + g0;
-            rec.a = *(const float4*)r;
-            rec.b = *((const float4*)r + 1);
-            rec.c = r->b;
-        }
-#ifdef FWD_PROF
-        fp_on_ = nlist >= FWD_PROF_MIN && nlist < FWD_PROF_MAX;
-        if (fp_on_) ++fnt_;
-        if (rec.c == 12345.678f) break;   // (forces the first records to be here before the clock is read)
-#endif
-        FP(0);
-        for (uint32_t off = 0; off < nlist; off += 64) {
-            // bounding box of this quadrant's pixels that are still accumulating
-            int bx0, by0, bx1, by1;
-            if (!mgr_quad_bbox(__ballot(!done), bx0, by0, bx1, by1)) break;
-            bool alive = false;
-            if (off + lane < nlist)
-                alive = !mgr_box_dead(rec.a.x, rec.a.y, rec.a.z, rec.a.w, rec.b.x, mgr_qmax(rec.b.y), qx0 + (float)bx0,
-                                      qy0 + (float)by0, qx0 + (float)bx1, qy0 + (float)by1);
-            const unsigned long long m = __ballot(alive);
-            const int cnt = __popcll(m);
-            if (alive) {
-                const int rank = __popcll(m & lt);
-                float* pb = slab + (rank >> 1) * MGR_PAIR_FLOATS;
-                mgr_pair_store<true>(pb, rank & 1, rec.a.x, rec.a.y, rec.a.z, rec.a.w, rec.b.x, rec.b.y, rec.b.z, rec.b.w, rec.c,
-                               off + (uint32_t)lane + 1u);  // 1-based list position
-                if ((cnt & 1) && rank == cnt - 1) mgr_pair_pad<true>(pb);
-            }
-            // issue the gathers of the following batches; they complete during the blend below
-            {
-                const MgrGRec* r = gv + gid_n;
-                rec.a = *(const float4*)r;
-                rec.b = *((const float4*)r + 1);
-                rec.c = r->b;
-                gid_n = sg[min(off + 128u + lane, lastidx)];
-            }
-            const int npair = (cnt + 1) >> 1;
-            FP(1);
-#ifdef MGR_STATS
-            const int n_act = __popcll(__ballot(!done));
-            FH(0, n_act, 1);
-            FH(4, n_act, cnt);
-            int steps_ = 0;
-#endif
-            for (int p = 0; p < npair; ++p) {
-                const float4* pp = (const float4*)(slab + p * MGR_PAIR_FLOATS);
-                const float4 R0 = pp[0], R1 = pp[1], R2 = pp[2], R3 = pp[3], R4 = pp[4];   // (five ds_read_b128 with the (r, g)-per-entry layout)
-                mgr_v2f dx, dy, G, al;
-                bool va, vb;
-                mgr_pair_alpha(R0, R1, R2, fpx2, fpy2, dx, dy, G, al, va, vb);
-#ifdef MGR_STATS
-                ++steps_;
-                FH(3, __popcll(__ballot(va && !done)), 1);
-                FH(3, __popcll(__ballot(vb && !done)), 1);
-#endif
-                {   // entry a
-                    const float a = (va && !done) ? al.x : 0.0f;
-                    const float testT = Tr * (1.0f - a);
-                    const bool stop = testT < 0.0001f;  // a == 0 leaves testT = Tr >= 1e-4
-                    const float w = stop ? 0.0f : a * Tr;
-                    C01 += mgr_v2f{R3.x, R3.y} * w;
-                    C2 += R4.x * w;
-                    Tr = stop ? Tr : testT;
-                    last = w > 0.0f ? __float_as_uint(R4.z) : last;
-#ifdef MGR_STATS
-                    if (stop && !done) stop_pos = __float_as_uint(R4.z);
-#endif
-                    done = done || stop;
-                }
-                {   // entry b
-                    const float a = (vb && !done) ? al.y : 0.0f;
-                    const float testT = Tr * (1.0f - a);
-                    const bool stop = testT < 0.0001f;
-                    const float w = stop ? 0.0f : a * Tr;
-                    C01 += mgr_v2f{R3.z, R3.w} * w;
-                    C2 += R4.y * w;
-                    Tr = stop ? Tr : testT;
-                    last = w > 0.0f ? __float_as_uint(R4.w) : last;
-#ifdef MGR_STATS
-                    if (stop && !done) stop_pos = __float_as_uint(R4.w);
-#endif
-                    done = done || stop;
-                }
-                if (__all(done)) break;
-            }
-#ifdef MGR_STATS
-            FH(1, n_act, steps_);
-            if (off >= 2048u) FH(2, n_act, steps_);
-#endif
-            FP(2);
-            // pixel state in front of the next chunk (prefix colour + transmittance): lets the
-            // backward pass process every MGR_CHUNK-entry chunk of the list independently
-            const uint32_t nextpos = off + 64u;
-            if ((nextpos % MGR_CHUNK) == 0 && nextpos < nlist)
-                ckpt[(size_t)(ck0 + nextpos / MGR_CHUNK - 1) * 256 + pslot] = make_float4(C01.x, C01.y, C2, Tr);
-            FP(3);
-        }
-        FP(3);
-        if (inside) {
-            const size_t pix = (size_t)py * W + px;
-            n_contrib[(size_t)v * P + pix] = last;  // (the final transmittance is not needed by the chunk-parallel backward)
-#ifdef MGR_STATS
-            ((uint32_t*)final_T)[(size_t)v * P + pix] = stop_pos;  // list position where this pixel saturated (0 = never)
-#endif
-            float* o = out_color + (size_t)v * 3 * P + pix;
-            o[0] = C01.x + Tr * bg0;
-            o[P] = C01.y + Tr * bg1;
-            o[2 * P] = C2 + Tr * bg2;
-        }
-        // list depth each quadrant consumed; the tile's maximum drives the backward pass
-        uint32_t mx = last;
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
-        if (lane == 0) s_qmx[wave] = mx;
-        FP(5);
-        __syncthreads();
-        FP(4);
-        const uint4 qmx = make_uint4(s_qmx[0], s_qmx[1], s_qmx[2], s_qmx[3]);
-        const uint32_t tmax = max(max(qmx.x, qmx.y), max(qmx.z, qmx.w));
-        const uint32_t nchunks = (tmax + MGR_CHUNK - 1) / MGR_CHUNK;
-        if (tid == 0) {
-            tile_done[vt] = tmax;
-            // both atomics are sent before either answer is waited for
-            uint32_t tk = 0, ib = 0;
-            if (!early_ticket) tk = atomicAdd(&hdr->queue_head2, 1u);
-            // backward work items: one per MGR_CHUNK entries actually consumed by this tile
-            if (nchunks) ib = atomicAdd(&hdr->n_items, nchunks);
-            if (!early_ticket) s_next = tk;
-            s_ibase = ib;
-        }
-        // the next tile's record and first list indices, while thread 0 waits (an early ticket is in s_next since before the
-        // barrier above)
-        uint4 nrec = qrec;
-        have_gid = false;
-        if (early_ticket) {
-            const uint32_t nxt = s_next;
-            nrec = tile_qrec[min(nxt, last_q)];
-            if (nxt < n_busy) {
-                const uint32_t nl1 = nrec.z - 1u;
-                pf_g0 = sorted_gid[nrec.y + min((uint32_t)lane, nl1)];
-                pf_g1 = sorted_gid[nrec.y + min(64u + lane, nl1)];
-                have_gid = true;
-            }
-        }
-        __syncthreads();
-        // 32-byte record per (tile, chunk): (tile, chunk, list offset of the chunk's first entry, checkpoint in front of
-        // the chunk | entries consumed by each quadrant) -- everything the item's prologue needs in one load
-        for (uint32_t c = tid; c < nchunks; c += 256) {
-            items[2 * (size_t)(s_ibase + c)] = make_uint4(vt, c, start + c * MGR_CHUNK, ck0 + (c > 0 ? c - 1 : 0));
-            items[2 * (size_t)(s_ibase + c) + 1] = qmx;
-        }
-#ifdef MGR_TIMELINE
-        if (tid == 0 && item < 8192) {
-            g_tl3[item * 4 + 0] = tl_tile0;
-            g_tl3[item * 4 + 1] = wall_clock64();
-            g_tl3[item * 4 + 2] = nlist;
-            g_tl3[item * 4 + 3] = tmax;
-        }
-        if (MGR_TIMELINE == 2 && ntl == 1 && tid == 0 && blockIdx.x < 2048) {   // (g_tl2 is shared with k_tile_split: -DMGR_TIMELINE=2 selects the blend)
-            g_tl2[blockIdx.x * 4 + 0] = wall_clock64();
-            g_tl2[blockIdx.x * 4 + 1] = nlist;
-            g_tl2[blockIdx.x * 4 + 2] = tmax;
-            g_tl2[blockIdx.x * 4 + 3] = item;
-        }
-#endif
-        item = s_next;
-        qrec = early_ticket ? nrec : tile_qrec[min(item, last_q)];
-        FP(5);
-    }
-#ifdef FWD_PROF
-    if (lane == 0) {
-        for (int k = 0; k < 6; ++k) atomicAdd(&g_fprof[k], (unsigned long long)facc_[k]);
-        atomicAdd(&g_fprof[6], (unsigned long long)fnt_);
-        atomicAdd(&g_fprof[7], 1ull);
-    }
-#endif
-#ifdef MGR_TIMELINE
-    unsigned long long tl1 = wall_clock64();
-#endif
-    // empty tiles: background only.  (Measured: the kernel takes 0.351 ms without this fill, 0.372 with it -- at the end,
-    // as here, or spread over the kernel a few tiles after every blended one: it is the 180 MB, not their timing.)
-    for (uint32_t q = n_busy + blockIdx.x; q < (uint32_t)VT; q += gridDim.x) {
-        const uint32_t vt = tile_queue[q];
-        const int v = (int)(vt / (uint32_t)T), t = (int)(vt % (uint32_t)T);
-        const int px = (t % gx) * 16 + (tid & 15), py = (t / gx) * 16 + (tid >> 4);
-        if (px < W && py < H) {
-            const size_t pix = (size_t)py * W + px;
-            // no per-pixel state for empty tiles: the backward has no work item that reads it
-            float* o = out_color + (size_t)v * 3 * P + pix;
-            o[0] = bg0;
-            o[P] = bg1;
-            o[2 * P] = bg2;
-        }
-        if (tid == 0) tile_done[vt] = 0;
-    }
-#ifdef MGR_TIMELINE
-    if (MGR_TIMELINE == 2 && tid == 0 && blockIdx.x < 2048) {
-        g_tl[blockIdx.x * 4 + 0] = tl0;
-        g_tl[blockIdx.x * 4 + 1] = tl1;
-        g_tl[blockIdx.x * 4 + 2] = wall_clock64();
-        g_tl[blockIdx.x * 4 + 3] = ntl;
-    }
-#endif
-}
-
 // ---------------------------------------------------------------------------
 // K5, wave-granular: the same walk, but nothing in the kernel waits at a workgroup barrier.  -DFWD_PROF on the workgroup
 // version above showed why: per tile of fewer than 1024 list entries (63 % of the tiles of the bench scene) a wave spent
@@ -1908,56 +1627,15 @@ __global__ __launch_bounds__(256) FWD_OCC void k_blend_fwd(int N, int W, int H, 
 //    k_fwd_items after the blend from the four depths of every tile.
 // ---------------------------------------------------------------------------
 #ifdef MGR_TIMELINE
-// -DMGR_TIMELINE: one record per (tile, quadrant) unit of k_blend_fwd_w: start, end (wall_clock64), list length | quadrant << 28,
+// -DMGR_TIMELINE: one record per (tile, quadrant) unit of k_blend_fwd: start, end (wall_clock64), list length | quadrant << 28,
 // depth consumed; mgr_debug_timeline_w copies them out (tools/instr/timeline_w.py)
-__device__ unsigned long long g_tlw[65536 * 4];
-__device__ unsigned int g_tlw_n;
+#define TLW_PER_WAVE 24
+__device__ unsigned long long g_tlw[MGR_FWD_GRID * 4 * TLW_PER_WAVE * 4];   // (a wave's own rows: no atomics in the measured kernel)
 extern "C" int mgr_debug_timeline_w(void* dst, unsigned int* n) {
-    hipError_t e = hipMemcpyFromSymbol(n, HIP_SYMBOL(g_tlw_n), 4);
-    if (e != hipSuccess) return (int)e;
-    e = hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_tlw), sizeof(unsigned long long) * 65536 * 4);
-    const unsigned int z = 0;
-    if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_tlw_n), &z, 4);
+    *n = MGR_FWD_GRID * 4 * TLW_PER_WAVE;
+    hipError_t e = hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_tlw), sizeof(g_tlw));
     return (int)e;
 }
-#endif
-#define MGR_HOLE 0xFFFFFFFEu
-// EXPERIMENT (MGR_FWD_ILV=1): the queue of the forward blend re-arranged so that position p holds a tile of view p % V,
-// each view's tiles in their queue order.  With V = 8 and the interleaved counters of MgrQueue (counter c hands out the
-// positions c, c + 16, ...; a workgroup's home counter is its index mod 16) the workgroups of XCD x -- every eighth
-// workgroup -- then blend the tiles of view x while that view has any: one view's Gaussian records per L2.
-__global__ __launch_bounds__(1024) void k_queue_interleave(int V, int T, const uint4* __restrict__ tile_qrec, uint4* __restrict__ out, MgrHeader* hdr) {
-    __shared__ uint32_t s_cnt[64], s_scan[32];
-    const int tid = threadIdx.x;
-    const uint32_t n = hdr->queue_len;
-    if (tid < 64) s_cnt[tid] = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < n; base += 1024u) {
-        const uint32_t i = base + (uint32_t)tid;
-        uint4 r = make_uint4(0, 0, 0, 0);
-        int v = -1;
-        if (i < n) { r = tile_qrec[i]; v = (int)(r.x / (uint32_t)T); }
-        for (int w = 0; w < V; ++w) {
-            uint32_t tot;
-            const uint32_t rk = block_excl_scan(v == w ? 1u : 0u, s_scan, tot);
-            if (v == w) out[(size_t)(s_cnt[w] + rk) * V + w] = r;
-            __syncthreads();
-            if (tid == 0) s_cnt[w] += tot;
-            __syncthreads();
-        }
-    }
-    uint32_t mx = 0;
-    for (int w = 0; w < V; ++w) mx = max(mx, s_cnt[w]);
-    for (int w = 0; w < V; ++w)
-        for (uint32_t k = s_cnt[w] + (uint32_t)tid; k < mx; k += 1024u) out[(size_t)k * V + w] = make_uint4(MGR_HOLE, 0u, 0u, 0u);
-    if (tid == 0) hdr->queue_len_i = mx * (uint32_t)V;
-}
-
-#ifndef FWD_PIPE
-#define FWD_PIPE 0
-#endif
-#ifndef FWD_WARM
-#define FWD_WARM 0   // > 0: batches with at most this many survivors touch the records three batches ahead
 #endif
 // per-lane select by a lane mask held in scalar registers (v_cndmask with an SGPR-pair condition)
 __device__ __forceinline__ float mgr_sel(unsigned long long m, float a, float b) {
@@ -1971,7 +1649,7 @@ __device__ __forceinline__ uint32_t mgr_selu(unsigned long long m, uint32_t a, u
     return r;
 }
 #define FWD_SLOTS 64   // LDS ring of published steps; a reader spins on its slot from the moment it claims, so it cannot be lapped
-__global__ __launch_bounds__(256) FWD_OCC void k_blend_fwd_w(int N, int W, int H, int gx, int gy, int VT,
+__global__ __launch_bounds__(256) FWD_OCC void k_blend_fwd(int N, int W, int H, int gx, int gy, int VT,
                                                      const float* __restrict__ bg,
                                                      const uint32_t* __restrict__ tile_queue,
                                                      const uint4* __restrict__ tile_qrec,
@@ -1981,7 +1659,7 @@ __global__ __launch_bounds__(256) FWD_OCC void k_blend_fwd_w(int N, int W, int H
                                                      uint32_t* __restrict__ n_contrib,
                                                      uint32_t* __restrict__ tile_done,
                                                      uint32_t* __restrict__ tile_qdone,
-                                                     float4* __restrict__ ckpt, MgrHeader* hdr, int ilv) {
+                                                     float4* __restrict__ ckpt, MgrHeader* hdr) {
     __shared__ __align__(16) float s_pair[4][32][MGR_PAIR_FLOATS];
     __shared__ __align__(16) uint4 s_qrec[FWD_SLOTS];     // queue record of a published step
     __shared__ uint32_t s_step[FWD_SLOTS];                // which step the slot holds (published last: the flag the readers poll)
@@ -1990,27 +1668,23 @@ __global__ __launch_bounds__(256) FWD_OCC void k_blend_fwd_w(int N, int W, int H
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int T = gx * gy;
     const uint32_t n_busy = hdr->queue_len;           // non-empty tiles (the empty ones follow them in tile_queue)
-    const uint32_t n_queue = ilv ? hdr->queue_len_i : n_busy;   // positions of the blend's queue (tile_qrec as passed)
+    const uint32_t n_queue = hdr->queue_len_i;         // positions of the blend's queue (tile_qrec: interleaved by view, with holes)
     const size_t P = (size_t)W * H;
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
     const unsigned long long lt = (1ull << lane) - 1ull;
     float* const slab = &s_pair[wave][0][0];
-#ifdef KO_GATHER
-    const uint32_t gid_max = 4095u;
-#else
     const uint32_t gid_max = (uint32_t)(N > 0 ? N - 1 : 0);
-#endif
 
-    if (blockIdx.x == 0 && tid < 34) {  // consumed by the tile scan: zero for the next forward (no per-call memset)
-        hdr->cls_count[tid] = 0;
-        hdr->cls_cursor[tid] = 0;
-    }
     if (tid < FWD_SLOTS) s_step[tid] = 0xFFFFFFFFu;
     if (tid == 0) s_claim = 0;
     __syncthreads();   // (the only workgroup barrier of the kernel)
 #ifdef FWD_PROF
     long long facc_[6] = {0, 0, 0, 0, 0, 0}, ftp_ = wall_clock64(), fnt_ = 0;
     bool fp_on_ = true;
+#endif
+#ifdef MGR_TIMELINE
+    unsigned int tlw_n = 0;
+    if (lane == 0) for (int k = 0; k < TLW_PER_WAVE; ++k) g_tlw[(((size_t)blockIdx.x * 4 + wave) * TLW_PER_WAVE + k) * 4 + 1] = 0;
 #endif
     MgrQueue queue;
     queue.init(hdr->qctr_f, n_queue, (int)blockIdx.x);
@@ -2085,34 +1759,15 @@ __global__ __launch_bounds__(256) FWD_OCC void k_blend_fwd_w(int N, int W, int H
         // (indices clamped into the list): a predicated load makes hipcc drain the whole memory queue every batch.
         FwdRec rec;
         uint32_t gid_n;
-#if FWD_WARM
-        // Deep in a long list few entries survive the box test (3.4 pair steps per 64-entry batch behind position 2048 of
-        // the bench scene): a batch is over long before the gather issued during it returns, and the walk proceeds at one
-        // memory latency per batch.  There the records of the batch three ahead are touched by a load nobody waits for, so
-        // that the real gather finds them in the L2.
-        // (Loads return in order: the touch is issued behind the batch's real gather and its value is "used" three batches
-        // later, so that the compiler's s_waitcnt for the next batch's records leaves it outstanding.)
-        uint32_t gid_2, gid_3, warm_1 = 0, warm_2 = 0, warm_3 = 0, warm_acc = 0;
-#endif
         const uint32_t* const sg = sorted_gid + start;
         const uint32_t lastidx = (nlist ? nlist : 1u) - 1u;   // (a list clipped to nothing by the pair capacity: no walk, indices clamped)
         {
             const uint32_t g0 = min(got_gid ? pf_g0 : sg[min((uint32_t)lane, lastidx)], gid_max);
             gid_n = got_gid ? pf_g1 : sg[min(64u + lane, lastidx)];
-#if FWD_WARM
-            gid_2 = sg[min(128u + lane, lastidx)];
-            gid_3 = sg[min(192u + lane, lastidx)];
-#endif
             const MgrGRec* r = gv + g0;
             rec.a = *(const float4*)r;
             rec.b = *((const float4*)r + 1);
-            
-#ifdef KO_RECC
-                rec.c = 0.5f;
-#else
-                rec.c = r->b;
-#endif
-
+            rec.c = r->b;
         }
         const bool early = nlist < 2048u;
         if (early) c_next = claim();
@@ -2164,25 +1819,9 @@ __global__ __launch_bounds__(256) FWD_OCC void k_blend_fwd_w(int N, int W, int H
                 const MgrGRec* r = gv + min(gid_n, gid_max);
                 rec.a = *(const float4*)r;
                 rec.b = *((const float4*)r + 1);
-                
-#ifdef KO_RECC
-                rec.c = 0.5f;
-#else
                 rec.c = r->b;
-#endif
 
-#if FWD_WARM
-                const uint32_t gw = min(cnt <= FWD_WARM ? gid_3 : gid_2, gid_max);   // (dense batches: a line the next gather fetches anyway)
-                gid_n = gid_2;
-                gid_2 = gid_3;
-                gid_3 = sg[min(off + 256u + lane, lastidx)];
-                warm_acc ^= warm_3;
-                warm_3 = warm_2;
-                warm_2 = warm_1;
-                warm_1 = *(const uint32_t*)(gv + gw);   // (the youngest load of the batch)
-#else
                 gid_n = sg[min(off + 128u + lane, lastidx)];
-#endif
             }
             if (provided && !pf_tried) prefetch_next();
             if (!provided) {   // the ticket drawn at the start of the unit is back by now: publish the next step
@@ -2198,36 +1837,9 @@ __global__ __launch_bounds__(256) FWD_OCC void k_blend_fwd_w(int N, int W, int H
             }
             const int npair = (cnt + 1) >> 1;
             FP(1);
-#if FWD_PIPE
-            // the pair records of step p + 1 are read from LDS while step p is computed (FWD_PIPE = 1: the three the alpha
-            // needs; 2: all five)
-            float4 N0, N1, N2;
-            { const float4* pp = (const float4*)slab; N0 = pp[0]; N1 = pp[1]; N2 = pp[2]; }
-#if FWD_PIPE > 1
-            float4 N3, N4;
-            { const float4* pp = (const float4*)slab; N3 = pp[3]; N4 = pp[4]; }
-#endif
-#endif
             for (int p = 0; p < npair; ++p) {
                 const float4* pp = (const float4*)(slab + p * MGR_PAIR_FLOATS);
-#if FWD_PIPE
-                const float4 R0 = N0, R1 = N1, R2 = N2;
-#if FWD_PIPE > 1
-                const float4 R3 = N3, R4 = N4;
-#else
-                const float4 R3 = pp[3], R4 = pp[4];
-#endif
-                {
-                    const float4* pn = (const float4*)(slab + min(p + 1, 31) * MGR_PAIR_FLOATS);
-                    N0 = pn[0]; N1 = pn[1]; N2 = pn[2];
-#if FWD_PIPE > 1
-                    N3 = pn[3]; N4 = pn[4];
-#endif
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#else
                 const float4 R0 = pp[0], R1 = pp[1], R2 = pp[2], R3 = pp[3], R4 = pp[4];   // (five ds_read_b128 with the (r, g)-per-entry layout)
-#endif
                 mgr_v2f al;
                 unsigned long long ma, mb;
                 mgr_pair_alpha_masks(R0, R1, R2, fpx2, fpy2, al, ma, mb);
@@ -2295,16 +1907,11 @@ __global__ __launch_bounds__(256) FWD_OCC void k_blend_fwd_w(int N, int W, int H
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
         if (lane == 0 && !hole) tile_qdone[(size_t)vt * 4 + quad] = mx;
-#if FWD_WARM
-        asm volatile("" :: "v"(warm_acc ^ warm_1 ^ warm_2 ^ warm_3));
-#endif
 #ifdef MGR_TIMELINE
-        if (lane == 0) {
-            const unsigned int k = atomicAdd(&g_tlw_n, 1u);
-            if (k < 65536u) {
-                g_tlw[k * 4 + 0] = tlw0; g_tlw[k * 4 + 1] = wall_clock64();
-                g_tlw[k * 4 + 2] = nlist | ((unsigned long long)quad << 28) | ((unsigned long long)blockIdx.x << 32); g_tlw[k * 4 + 3] = mx;
-            }
+        if (lane == 0 && tlw_n < TLW_PER_WAVE) {
+            const size_t k = ((size_t)blockIdx.x * 4 + wave) * TLW_PER_WAVE + tlw_n++;
+            g_tlw[k * 4 + 0] = tlw0; g_tlw[k * 4 + 1] = wall_clock64();
+            g_tlw[k * 4 + 2] = nlist | ((unsigned long long)quad << 28) | ((unsigned long long)blockIdx.x << 32); g_tlw[k * 4 + 3] = mx | (hole ? 1ull << 40 : 0ull);
         }
 #endif
         FP(5);
@@ -2339,13 +1946,13 @@ __global__ __launch_bounds__(256) FWD_OCC void k_blend_fwd_w(int N, int W, int H
 // with all its threads (record i belongs to the tile found by a search of the block's scan).  Also leaves the tile's depth
 // in tile_done (the scheduling hint of the next forward).
 __global__ __launch_bounds__(256) void k_fwd_items(const uint4* __restrict__ tile_qrec, const uint32_t* __restrict__ tile_qdone,
-                                                   uint32_t* __restrict__ tile_done, uint4* __restrict__ items, MgrHeader* hdr, int ilv) {
+                                                   uint32_t* __restrict__ tile_done, uint4* __restrict__ items, MgrHeader* hdr) {
     __shared__ uint32_t s_scan[8];
     __shared__ uint32_t s_base;
     __shared__ uint32_t s_run[257];
     __shared__ uint4 s_qr[256], s_qd[256];
     const int tid = threadIdx.x;
-    const uint32_t n_busy = ilv ? hdr->queue_len_i : hdr->queue_len;
+    const uint32_t n_busy = hdr->queue_len_i;
     const uint32_t nb = (n_busy + 255u) / 256u;
     if (blockIdx.x >= nb) return;
     // strided over the queue (which is ordered by depth): every block gets its share of the deep tiles
@@ -2496,12 +2103,13 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
         MGR_LAUNCH_CHECK("k_preprocess", stream, debug);
     }
     {
-        const int nblk = (VT + 1023) / 1024;
+        const int nbT = (T + 1023) / 1024, nblk = V * nbT;   // blocks of up to 1024 tiles of one view
         uint2* part = (uint2*)(ws + L.scan_part);
+        uint32_t* blk_cls = (uint32_t*)(ws + L.scan_cls);
         const int use_hint = ordered ? 1 : 0;
-        { MGR_PROF("k_tile_scan_a", stream); hipLaunchKernelGGL(k_tile_scan_a, dim3(nblk), dim3(1024), 0, stream, VT, tile_count,
-                           (const uint32_t*)(ws + L.tile_done), use_hint, part, hdr); }
-        { MGR_PROF("k_tile_scan_b", stream); hipLaunchKernelGGL(k_tile_scan_b, dim3(nblk), dim3(1024), 0, stream, VT, nblk, tile_count, part,
+        { MGR_PROF("k_tile_scan_a", stream); hipLaunchKernelGGL(k_tile_scan_a, dim3(nblk), dim3(1024), 0, stream, T, nbT, tile_count,
+                           (const uint32_t*)(ws + L.tile_done), use_hint, part, blk_cls); }
+        { MGR_PROF("k_tile_scan_b", stream); hipLaunchKernelGGL(k_tile_scan_b, dim3(nblk), dim3(1024), 0, stream, V, T, nbT, tile_count, part, (const uint32_t*)blk_cls,
                            tile_start, (uint32_t*)(ws + L.tile_cursor), (uint32_t*)(ws + L.tile_queue), (uint4*)(ws + L.tile_qrec),
                            (const uint32_t*)(ws + L.tile_done), use_hint, (uint32_t*)(ws + L.chunk_start), hdr, (uint32_t)cap); }
     }
@@ -2589,26 +2197,12 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
     }
     }   // do_bin
     if (!do_blend) return MGR_OK;
-    static const bool fwd_wg = getenv("MGR_FWD") && strcmp(getenv("MGR_FWD"), "wg") == 0;   // the workgroup-per-tile version (A/B)
-    if (!fwd_wg) {
-        static const bool fwd_ilv = getenv("MGR_FWD_ILV") && atoi(getenv("MGR_FWD_ILV")) != 0;
-        const int ilv = (fwd_ilv && V <= 64) ? 1 : 0;
-        const uint4* qrec_p = (const uint4*)(ws + (ilv ? L.tile_qrec_i : L.tile_qrec));
-        if (ilv) { MGR_PROF("k_queue_interleave", stream); hipLaunchKernelGGL(k_queue_interleave, dim3(1), dim3(1024), 0, stream, V, T, (const uint4*)(ws + L.tile_qrec), (uint4*)(ws + L.tile_qrec_i), hdr); }
-        { MGR_PROF("k_blend_fwd", stream); hipLaunchKernelGGL(k_blend_fwd_w, dim3(MGR_FWD_GRID), dim3(256), 0, stream, N, W, H, gx, gy, VT, bg,
-                           (const uint32_t*)(ws + L.tile_queue), qrec_p, (const uint32_t*)(ws + L.sorted_gid), (const MgrGRec*)(ws + L.grec), out_color,
-                           (uint32_t*)(ws + L.n_contrib), (uint32_t*)(ws + L.tile_done), (uint32_t*)(ws + L.tile_qdone),
-                           (float4*)(ws + L.ckpt), hdr, ilv); }
-        { MGR_PROF("k_fwd_items", stream); hipLaunchKernelGGL(k_fwd_items, dim3((VT + 64 + 255) / 256), dim3(256), 0, stream, qrec_p,
-                           (const uint32_t*)(ws + L.tile_qdone), (uint32_t*)(ws + L.tile_done), (uint4*)(ws + L.items), hdr, ilv); }
-        MGR_LAUNCH_CHECK("k_blend_fwd", stream, debug);
-        return MGR_OK;
-    }
-    { MGR_PROF("k_blend_fwd", stream); hipLaunchKernelGGL(k_blend_fwd, dim3(MGR_FWD_GRID), dim3(256), 0, stream, N, W, H, gx, gy, VT, bg, tile_start,
+    { MGR_PROF("k_blend_fwd", stream); hipLaunchKernelGGL(k_blend_fwd, dim3(MGR_FWD_GRID), dim3(256), 0, stream, N, W, H, gx, gy, VT, bg,
                        (const uint32_t*)(ws + L.tile_queue), (const uint4*)(ws + L.tile_qrec), (const uint32_t*)(ws + L.sorted_gid), (const MgrGRec*)(ws + L.grec), out_color,
-                       (float*)(ws + L.final_T), (uint32_t*)(ws + L.n_contrib),
-                       (uint32_t*)(ws + L.tile_done), (const uint32_t*)(ws + L.chunk_start),
-                       (float4*)(ws + L.ckpt), (uint4*)(ws + L.items), hdr, (uint32_t)cap); }
+                       (uint32_t*)(ws + L.n_contrib), (uint32_t*)(ws + L.tile_done), (uint32_t*)(ws + L.tile_qdone),
+                       (float4*)(ws + L.ckpt), hdr); }
+    { MGR_PROF("k_fwd_items", stream); hipLaunchKernelGGL(k_fwd_items, dim3((VT + 255) / 256), dim3(256), 0, stream, (const uint4*)(ws + L.tile_qrec),
+                       (const uint32_t*)(ws + L.tile_qdone), (uint32_t*)(ws + L.tile_done), (uint4*)(ws + L.items), hdr); }
     MGR_LAUNCH_CHECK("k_blend_fwd", stream, debug);
     return MGR_OK;
 }

@@ -15,6 +15,7 @@ through the small mapping protocol h5py groups offer (`g[name]`, `g.keys()`, `g.
 synthetic sequences of the tests and for captures converted on a machine that has h5py (`convert_hdf5`).
 Host-side IO only; nothing here is on the per-step path."""
 import json
+import collections
 import os
 import re
 from dataclasses import dataclass
@@ -90,18 +91,28 @@ class TreeStore(_Node):
 
 
 class _LazyArrays:
-    """Mapping view of an NpzFile that loads (and memoises) a member on first access."""
+    """Mapping view of an NpzFile that loads a member on access and keeps the most recently used ones (bounded: a
+    capture file holds thousands of image crops; the small shared members -- K, extr, metadata -- are what repeats)."""
+    MAX_BYTES = 64 << 20
 
     def __init__(self, z):
-        self._z, self._names, self._cache = z, set(z.files), {}
+        self._z, self._names = z, set(z.files)
+        self._cache, self._bytes = collections.OrderedDict(), 0
 
     def __contains__(self, k):
         return k in self._names
 
     def __getitem__(self, k):
         a = self._cache.get(k)
-        if a is None:
-            a = self._cache[k] = self._z[k]
+        if a is not None:
+            self._cache.move_to_end(k)
+            return a
+        a = self._z[k]
+        self._cache[k] = a
+        self._bytes += a.nbytes
+        while self._bytes > self.MAX_BYTES and len(self._cache) > 1:
+            _, old = self._cache.popitem(last=False)
+            self._bytes -= old.nbytes
         return a
 
 
@@ -112,7 +123,26 @@ def write_tree(path, arrays):
         np.savez(f, **arrays)
 
 
+# One open store per action file AND PROCESS (the Dataset opens the file on every __getitem__).  A DataLoader worker is
+# a fork of the process that built the dataset: it must not read through the parent's file descriptor -- zipfile
+# serialises seek + read with a per-process lock only, so two workers on one descriptor race -- hence the cache is keyed
+# by pid and emptied in every forked child; a file rewritten under the same name replaces (and closes) its stale store.
 _STORES = {}
+
+
+def _drop_stores_after_fork():
+    _STORES.clear()     # (the parent's handles stay the parent's: not closed here, just never used by the child)
+
+
+if hasattr(os, "register_at_fork"):
+    os.register_at_fork(after_in_child=_drop_stores_after_fork)
+
+
+def close_sequences():
+    """Close every cached action file of this process."""
+    for _, st in _STORES.values():
+        st.close()
+    _STORES.clear()
 
 
 def open_sequence(path):
@@ -120,11 +150,15 @@ def open_sequence(path):
     with open(path, "rb") as f:
         magic = f.read(4)
     if magic[:2] == b"PK":
-        key = (os.path.abspath(path), os.path.getmtime(path))
-        st = _STORES.get(key)
-        if st is None:
-            st = _STORES[key] = TreeStore(path)     # one store per action file (the Dataset opens it on every __getitem__)
-        return st
+        key = (os.getpid(), os.path.abspath(path))
+        mtime = os.path.getmtime(path)
+        ent = _STORES.get(key)
+        if ent is not None and ent[0] != mtime:     # rewritten since it was opened
+            ent[1].close()
+            ent = None
+        if ent is None:
+            ent = _STORES[key] = (mtime, TreeStore(path))
+        return ent[1]
     try:
         import h5py
     except ImportError as e:

@@ -210,7 +210,7 @@ class ViewShardedStep:
             dist.all_reduce(st[self.padded_g:], op=dist.ReduceOp.SUM, group=self.group)    # 2 N + 2 floats
         elif self.world > 1 or self.force or (self.always_pack and self.compact):
             if self.compact:
-                self._compact_all_reduce(st, fv)
+                self._compact_all_reduce(st, fv, active=getattr(self.compute_fn, "last_active", None))
             else:
                 dist.all_reduce(st, op=dist.ReduceOp.SUM, group=self.group)   # the step's ONE collective
         grads = unpack_grads(st[:n_g], self.shapes, N)
@@ -226,16 +226,62 @@ def _row_mask(fv, N):
     return m.to(torch.uint8)
 
 
-def _compact_all_reduce(self, flat, fv):
+_XCH_SEGS = list(GRAD_LAYOUT) + [("grad2d", 1)]
+
+
+def _compact_all_reduce(self, flat, fv, active=None):
     """Two collectives: (1) one byte-sized SUM all-reduce of [row mask | visibility count] (2 N bytes: the visibility
     count is needed for every Gaussian -- a hidden Gaussian still counts as visible, gaussian.py:335-338 -- but it is
     at most the number of views, so a byte carries it); (2) the SUM all-reduce of the 60 floats (59 gradients + the
-    2D-gradient norm) of the rows that are active on some rank."""
+    2D-gradient norm) of the rows that are active on some rank.
+
+    On the GPU everything around the two collectives is five launches of the library (csrc/exchange.hip): the mask -- from
+    the fused backward's own list of the Gaussians that received a gradient when the compute function hands it over
+    (`active`), otherwise from the rows --, the ordered row list (two launches), one pack, one unpack; the host reads one
+    number, the list's length, which sizes the second collective.  Tensors on the CPU (the gloo tests of the rank logic,
+    where a CPU stand-in computes the gradients) take the same steps in torch."""
     N = self.N
     if self.n_views > 255:
         raise ValueError("compact all-reduce carries the visibility count in one byte: at most 255 views per step (use the dense mode)")
+    live = self.world > 1 or self.force
+    if flat.is_cuda:
+        import ctypes
+        from ._lib import check, lib, ptr, stream
+        L = lib()
+        dev = flat.device
+        nseg = len(_XCH_SEGS)
+        base = flat.data_ptr()
+        offs = (ctypes.c_int64 * nseg)(*[(fv[name].data_ptr() - base) // 4 for name, _ in _XCH_SEGS])
+        widths = (ctypes.c_int * nseg)(*[w for _, w in _XCH_SEGS])
+        vis_off, tail_off = (fv["vis"].data_ptr() - base) // 4, (fv["loss"].data_ptr() - base) // 4
+        sc = getattr(self, "_xch", None)
+        if sc is None or sc["small"].device != dev:
+            sc = self._xch = dict(small=torch.empty(2 * N, dtype=torch.uint8, device=dev), idx=torch.empty(N, dtype=torch.int32, device=dev),
+                                  count=torch.zeros(1, dtype=torch.int32, device=dev),
+                                  ws=torch.empty(L.mgr_exchange_index_workspace_bytes(N), dtype=torch.uint8, device=dev),
+                                  host=torch.zeros(1, dtype=torch.int32).pin_memory(), buf=None)
+        small, idx, count = sc["small"], sc["idx"], sc["count"]
+        lst, cnt = active if active is not None else (None, None)
+        check(L.mgr_exchange_mask(N, ptr(flat), nseg, offs, widths, vis_off, lst, cnt, ptr(small), stream()), "mgr_exchange_mask")
+        if live:
+            dist.all_reduce(small, op=dist.ReduceOp.SUM, group=self.group)
+        check(L.mgr_exchange_index(N, ptr(small), ptr(idx), ptr(count), ptr(sc["ws"]), sc["ws"].numel(), stream()), "mgr_exchange_index")
+        sc["host"].copy_(count, non_blocking=True)
+        torch.cuda.current_stream().synchronize()                            # (host sync: the collective's size)
+        n = int(sc["host"][0])
+        self.last_rows = n
+        need = n * (GRAD_WIDTH + 1) + FLAT_TAIL
+        if sc["buf"] is None or sc["buf"].numel() < need:
+            sc["buf"] = torch.empty(int(need * 1.25) + 64, dtype=torch.float32, device=dev)
+        buf = sc["buf"][:need]
+        check(L.mgr_exchange_pack(N, n, ptr(idx), ptr(flat), nseg, offs, widths, tail_off, ptr(buf), stream()), "mgr_exchange_pack")
+        if live:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+        check(L.mgr_exchange_unpack(N, n, ptr(idx), ptr(flat), nseg, offs, widths, tail_off, ptr(buf), small[N:].data_ptr(), vis_off,
+                                    stream()), "mgr_exchange_unpack")
+        return
     small = torch.cat([_row_mask(fv, N), fv["vis"].to(torch.uint8)])
-    if self.world > 1 or self.force:
+    if live:
         dist.all_reduce(small, op=dist.ReduceOp.SUM, group=self.group)
     fv["vis"].copy_(small[N:])
     idx = torch.nonzero(small[:N], as_tuple=False)[:, 0]                     # (host sync: the collective's size)
@@ -244,16 +290,15 @@ def _compact_all_reduce(self, flat, fv):
     width = GRAD_WIDTH + 1
     buf = torch.empty(n * width + FLAT_TAIL, dtype=torch.float32, device=flat.device)
     o, segs = 0, []
-    for name, w in list(GRAD_LAYOUT) + [("grad2d", 1)]:
+    for name, w in _XCH_SEGS:
         seg = buf[o:o + n * w].view(n, w)
         torch.index_select(fv[name].view(N, w), 0, idx, out=seg)
         segs.append((name, w, seg))
         o += n * w
     buf[o:o + FLAT_TAIL].copy_(flat[-FLAT_TAIL:])   # (loss, overflow: the last two floats of the step buffer)
-    if self.world > 1 or self.force:
+    if live:
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
     for name, w, seg in segs:                                                # rows outside the union are zero everywhere
-        fv[name].zero_()
         fv[name].view(N, w).index_copy_(0, idx, seg)
     flat[-FLAT_TAIL:].copy_(buf[o:o + FLAT_TAIL])
 
@@ -507,13 +552,17 @@ class HipViewCompute:
                                            ptr(d_ls), ptr(d_rot), ptr(d_op), ptr(d_fdc), ptr(d_frest), ptr(d_w), ptr(st_g),
                                            ptr(st_v), ptr(st_r), ptr(ws.buf), ws.nbytes, ws.cap, 0, stream()),
                   "mgr_views_backward")
-            if na and V <= 8:
-                # d xyz += d w . d(trilinear weights)/d xyz (the leaf is used twice: gaussian_utils.py:167-196), for the
-                # Gaussians that received a gradient only (the others' d_w rows are zero): the backward's active list
+            active = None
+            if V <= 8 and N > 0:
+                # the backward's list of the Gaussians that received a gradient (device pointers: list, length)
                 import ctypes
                 lst, cnt = ctypes.c_void_p(), ctypes.c_void_p()
                 check(lib().mgr_views_active_list(ptr(ws.buf), V, N, W, H, ws.cap, ctypes.byref(lst), ctypes.byref(cnt)),
                       "mgr_views_active_list")
+                active = (lst, cnt)
+            if na and V <= 8:
+                # d xyz += d w . d(trilinear weights)/d xyz (the leaf is used twice: gaussian_utils.py:167-196), for the
+                # Gaussians that received a gradient only (the others' d_w rows are zero)
                 check(lib().mgr_skin_weights_bwd_indexed(na, ptr(p["_xyz"]), ptr(sg.data), sg.D, sg.H, sg.W, sg.B, sg.stride,
                                                          ptr(s["grid_center"]), ptr(s["grid_scale"]), ptr(d_w), ptr(d_xyz),
                                                          lst, cnt, N, stream()), "mgr_skin_weights_bwd_indexed")
@@ -525,12 +574,14 @@ class HipViewCompute:
         finally:
             ws.busy = False
         self.last_image, self.last_radii = out, radii
+        self.last_active = active      # (device pointers into the workspace of this step: valid until the next forward on it)
         return dict(grads={"_xyz": d_xyz, "_scaling": d_ls, "_rotation": d_rot, "_opacity": d_op, "_features_dc": d_fdc,
                            "_features_rest": d_frest}, grad2d=st_g, vis=st_v, radii=st_r, loss=loss, overflow=overflow)
 
     def __call__(self, view_ids, scale=1.0):
         if self.fused:
             return self._step_direct(view_ids, scale)
+        self.last_active = None
         for v in self.params.values():
             v.grad = None
         img, radii, means2D = self.forward_views(view_ids)
@@ -553,20 +604,24 @@ class HipViewCompute:
         T = ((W + 15) // 16) * ((H + 15) // 16)
         N = self.params["_xyz"].shape[0]
         out = []
-        keep = self.sync_check
-        self.sync_check = True
-        try:
-            with torch.no_grad():
-                for k in range(0, len(ids), group):
-                    part = ids[k:k + group]
+        from ._lib import ManusHipError
+        ctx = self.rz.context(self.device)
+        with torch.no_grad():
+            for k in range(0, len(ids), group):
+                part = ids[k:k + group]
+                for attempt in range(4):
                     self.forward_views_fused(part)
-                    ws = self.rz.context(self.device).last_ws
-                    arr = (ctypes.c_size_t * 32)()
-                    lib().mgr_raster_layout(len(part), N, W, H, ws.cap, arr, 32)
-                    ts = ws.buf[int(arr[7]): int(arr[7]) + 4 * (len(part) * T + 1)].view(torch.int32)[::T].cpu().tolist()
-                    out += [int(b - a) for a, b in zip(ts[:-1], ts[1:])]
-        finally:
-            self.sync_check = keep
+                    try:    # (the autograd node's forward follows the device's sync policy: whatever that is, the tile offsets
+                        ctx.check_overflow()    # read below come from a forward that did not overflow its pair capacity)
+                        break
+                    except ManusHipError:
+                        if attempt == 3:
+                            raise
+                ws = ctx.last_ws
+                arr = (ctypes.c_size_t * 32)()
+                lib().mgr_raster_layout(len(part), N, W, H, ws.cap, arr, 32)
+                ts = ws.buf[int(arr[7]): int(arr[7]) + 4 * (len(part) * T + 1)].view(torch.int32)[::T].cpu().tolist()
+                out += [int(b - a) for a, b in zip(ts[:-1], ts[1:])]
         return out
 
     # -- inputs of the pruning tests (on_after_backward) ---------------------------------------------

@@ -75,7 +75,9 @@ def mesh_sdf(points, verts, faces, want_winding=False):
 def init_mano_weights(points, data, neighbors=20, filter_grid=True, device=None):
     """train_utils.py:48-89.  `data`: {"verts" (778,3), "weights" (778,16), "face" (1538,3)}.  Returns (weights, mask) as
     numpy: weights (n, 20) float32, or (n, 21) float64 with the background channel when `filter_grid` (mask = points not
-    farther than 2 cm outside the mesh; None otherwise) -- the reference's dtypes."""
+    farther than 2 cm outside the mesh; None otherwise) -- the reference's dtypes.  The mean over the k rows is formed in
+    fp32 on the device and cast; the reference averages in the dtype of the MANO weights (float32 in `mano_rest.pkl`; with
+    float64 weights its last bits would differ from this by fp32 rounding, ~6e-8 relative)."""
     dev = _dev(device)
     verts = torch.as_tensor(np.asarray(data["verts"]), dtype=torch.float32, device=dev)
     init_weights = np.asarray(data["weights"])[..., MANO_TO_OURS]

@@ -1,4 +1,4 @@
-"""Shared by the GPU parity tests and bench.py: the fused path (mgr_views_forward / mgr_views_backward) against the
+"""Shared by the GPU parity tests (the helpers bench.py also needs live in tools/parity.py): the fused path (mgr_views_forward / mgr_views_backward) against the
 ORACLE on identical blend inputs, with the alpha-threshold flips accounted for.
 
 The fused kernels never materialise the rasterizer's inputs, so the comparison is closed around the blend: the
@@ -23,89 +23,8 @@ import torch
 
 from util import max_rel_err, psnr
 
-FLIP_EPS = 2e-4
-DEV = "cuda:0"
-
-
-def layout(V, N, W, H, cap):
-    from manus_amd._lib import lib
-    arr = (ctypes.c_size_t * 32)()
-    n = lib().mgr_raster_layout(V, N, W, H, cap, arr, 32)
-    names = ["header", "grec", "depth", "rect", "alive", "pair_off", "tile_count", "tile_start", "tile_cursor", "tile_done",
-             "tile_queue", "chunk_start", "items", "ckpt", "keys", "sorted_gid", "final_T", "n_contrib", "pair_tag",
-             "pair_grad", "total", "inst_grad", "inst_tag", "db_nvis", "db_bbox", "db_order"]
-    assert n == len(names)
-    return dict(zip(names, [int(x) for x in arr[:n]]))
-
-
-def fused_records(ws, V, N, W, H):
-    """(grec (V,N,12), depth (V,N), gathered blend sums (N,G,12)) of the last forward / backward on workspace `ws`."""
-    L = layout(V, N, W, H, ws.cap)
-    P = W * H
-    ncontrib = ws.buf[L["n_contrib"]: L["n_contrib"] + V * P * 4].view(torch.int32).reshape(V, H, W).cpu().numpy()
-    grec = ws.buf[L["grec"]: L["grec"] + V * N * 48].view(torch.float32).reshape(V, N, 12).cpu().numpy()
-    depth = ws.buf[L["depth"]: L["depth"] + V * N * 4].view(torch.float32).reshape(V, N).cpu().numpy()
-    G = 1 if V <= 1 else 2 if V <= 2 else 4 if V <= 4 else 8
-    iacc = ws.buf[L["inst_grad"]: L["inst_grad"] + N * G * 48].view(torch.float32).reshape(N, G, 12).cpu().numpy()
-    return grec, depth, iacc, ncontrib
-
-
-def device_alpha_decisions(rec6, px, py, device=DEV):
-    """The blend kernels' own alpha / validity for (record, pixel) pairs (mgr_debug_pair_alpha)."""
-    from manus_amd._lib import check, lib, ptr, stream
-    n = int(len(px))
-    if n == 0:
-        return np.zeros(0, np.float32), np.zeros(0, np.int32)
-    r = torch.as_tensor(np.ascontiguousarray(rec6, np.float32), device=device)
-    x = torch.as_tensor(np.ascontiguousarray(px, np.int32), device=device)
-    y = torch.as_tensor(np.ascontiguousarray(py, np.int32), device=device)
-    al = torch.empty(n, dtype=torch.float32, device=device)
-    va = torch.empty(n, dtype=torch.int32, device=device)
-    check(lib().mgr_debug_pair_alpha(n, ptr(r), ptr(x), ptr(y), ptr(al), ptr(va), stream()), "mgr_debug_pair_alpha")
-    return al.cpu().numpy(), va.cpu().numpy()
-
-
-def kernel_last_gaussian(view, V, N, W, H, ncontrib_v):
-    """(H,W) int32: the Gaussian each pixel's walk ended on in the kernels (-1: no contributor), from the per-pixel list
-    position the forward saved (n_contrib, 1-based into the kernels' tile list -- the oracle's list minus the provably
-    null pairs, so positions differ but Gaussians do not) and the tile lists (mgr_raster_debug_binning_sync)."""
-    from manus_amd import rasterizer as rz
-    from manus_amd._lib import lib, ptr, stream
-    ws = rz.context().last_ws
-    gx, gy = (W + 15) // 16, (H + 15) // 16
-    ranges = np.zeros((gx * gy, 2), np.int32)
-    npairs, ovf = ctypes.c_int64(0), ctypes.c_int32(0)
-    lib().mgr_raster_status_sync(ptr(ws.buf), ctypes.byref(npairs), ctypes.byref(ovf), stream())
-    pl = np.zeros((max(int(npairs.value), 1),), np.int32)
-    rc = lib().mgr_raster_debug_binning_sync(ptr(ws.buf), V, N, W, H, ws.cap, view, ranges.ctypes.data_as(ctypes.c_void_p),
-                                             pl.ctypes.data_as(ctypes.c_void_p), pl.shape[0], stream())
-    assert rc == 0
-    ys, xs = np.mgrid[0:H, 0:W]
-    tile = (ys // 16) * gx + xs // 16
-    start, size = ranges[tile, 0].astype(np.int64), (ranges[tile, 1] - ranges[tile, 0]).astype(np.int64)
-    last = np.where(size > 0, ncontrib_v.astype(np.int64), 0)     # (nothing is written under empty tiles)
-    assert (last <= size).all()
-    return np.where(last > 0, pl[np.clip(start + last - 1, 0, pl.shape[0] - 1)], -1).astype(np.int32)
-
-
-def align_threshold_decisions(bo, rec, colors, bg, W, kernel_last=None, device=DEV):
-    """Force the oracle `bo` to the kernels' outcome of the alpha >= 1/255 test on the pairs where the two disagree, and
-    -- with kernel_last (H,W), the Gaussian every pixel's walk ended on in the kernels -- to the kernels' end of the
-    walk (the second threshold, T (1 - alpha) < 1e-4).  rec (N,12): the kernels' per-Gaussian records of this view.
-    Returns (ambiguous pairs, alpha flips, stop flips, stop flips that were NOT within rounding of the threshold)."""
-    pix, gid, al = bo.ambiguous_pairs(FLIP_EPS)
-    flips = np.zeros(0, bool)
-    dev_valid = np.zeros(0, np.int32)
-    if len(pix):
-        dev_alpha, dev_valid = device_alpha_decisions(rec[gid][:, :6], pix % W, pix // W, device)
-        ora_keep = (al >= np.float32(1.0) / np.float32(255.0)).astype(np.int32)
-        flips = dev_valid != ora_keep
-        assert np.abs(dev_alpha - al).max() < 1e-6, "device and oracle alpha differ by more than rounding on identical inputs"
-    need_stop = kernel_last is not None
-    sf = sv = 0
-    if flips.any() or need_stop:
-        sf, sv = bo.reblend(pix[flips], gid[flips], dev_valid[flips], colors, bg, forced_last=kernel_last if need_stop else None)
-    return int(len(pix)), int(flips.sum()), sf, sv
+from tools.parity import (DEV, FLIP_EPS, align_threshold_decisions, device_alpha_decisions, fused_records,  # noqa: F401
+                          kernel_last_gaussian, layout)
 
 
 def run_fused_vs_oracle(kind, views, n, W, H, seed, grid_res=24, cam_radius=0.5, sigma_range=(2e-3, 8e-3), account_flips=True,

@@ -48,7 +48,9 @@ def test_knn_edge_cases():
     out, idx = MI.knn_mean_rows(torch.tensor([[0.9, 0, 0]], device=DEV), refs, rows, 2, want_idx=True)
     assert idx.cpu().tolist() == [[1, 2]] and out.cpu().tolist() == [[0.0, 2.0]]     # equal distances: the lower index first
     out, idx = MI.knn_mean_rows(torch.tensor([[0.0, 0, 0]], device=DEV), refs[:2], rows[:2], 4, want_idx=True)
-    assert idx.cpu().tolist() == [[0, 1, -1, -1]] and out.cpu().tolist() == [[0.25, 0.25]]   # fewer references than k
+    assert idx.cpu().tolist() == [[0, 1, -1, -1]] and out.cpu().tolist() == [[0.5, 0.5]]     # fewer references than k: the mean of those there are
+    out, idx = MI.knn_mean_rows(torch.tensor([[float("nan"), 0, 0], [0.9, 0, 0]], device=DEV), refs, rows, 2, want_idx=True)
+    assert idx.cpu().tolist() == [[-1, -1], [1, 2]] and bool(torch.isnan(out[0]).all()) and out[1].cpu().tolist() == [0.0, 2.0]   # a non-finite query has no neighbours
     assert MI.knn_mean_rows(torch.zeros((0, 3), device=DEV), refs, rows, 4).shape == (0, 2)
     with pytest.raises(ManusHipError):
         MI.knn_mean_rows(torch.zeros((1, 3), device=DEV), refs, rows, 33)

@@ -161,7 +161,8 @@ def test_product_never_imports_the_oracle():
         for f in files:
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
-                assert "oracle" not in re.sub(r"#.*", "", src), f
+                code = re.sub(r"#.*", "", src)
+                assert "oracle" not in code and "tools.parity" not in code and "import tools" not in code, f
 
 
 # ---------------------------------------------------------------------------
@@ -355,6 +356,25 @@ def test_checkpoint_loader_refuses_pickled_objects_unless_asked(tmp_path):
         ck.load_checkpoint(path)
     w, e = ck.load_checkpoint(path, allow_pickle=True)
     assert e["num_gaussians"] == 4 and w["_xyz"].shape == (4, 3)
+    assert ck.get_num_gaussians_from_checkpoint(path, allow_pickle=True) == 4
+    # a missing file is a missing file, not advice to unpickle
+    with pytest.raises(FileNotFoundError):
+        ck.load_checkpoint(str(tmp_path / "absent.ckpt"))
+
+
+def test_nan_rows_leave_the_optimizer_state_of_a_checkpoint_too(tmp_path):
+    from manus_amd import checkpoint as ck
+    n = 5
+    sd = {"model." + k: torch.rand((n,) + s) for k, s in (("_xyz", (3,)), ("_features_dc", (1, 3)), ("_features_rest", (15, 3)),
+                                                          ("_scaling", (3,)), ("_rotation", (4,)), ("_opacity", (1,)))}
+    sd["model._scaling"][2, 1] = float("nan")
+    opt = {"exp_avg": {"_xyz": torch.arange(n * 3, dtype=torch.float32).reshape(n, 3)}, "steps": [3, 3], "denom": torch.arange(n, dtype=torch.float32)}
+    path = str(tmp_path / "epoch=000-step=1-loss=0.5.ckpt")
+    torch.save({"epoch": 0, "global_step": 1, "state_dict": sd, "extra_params": {"num_gaussians": n}, "manus_amd_optimizer": opt}, path)
+    w, e, full = ck.load_checkpoint(path, return_checkpoint=True)
+    assert e["num_gaussians"] == 4 and w["_xyz"].shape[0] == 4
+    o = full["manus_amd_optimizer"]
+    assert o["exp_avg"]["_xyz"].shape == (4, 3) and o["denom"].tolist() == [0.0, 1.0, 3.0, 4.0] and o["steps"] == [3, 3]
 
 
 def test_sequence_container_is_read_lazily_and_opened_once(golden_dir, tmp_path):
@@ -363,7 +383,24 @@ def test_sequence_container_is_read_lazily_and_opened_once(golden_dir, tmp_path)
     p = str(tmp_path / "grasp_2.npz")
     shutil.copy(os.path.join(golden_dir, "seq", "grasp_2.npz"), p)
     a, b = D.open_sequence(p), D.open_sequence(p)
-    assert a is b                                             # one store per action file
+    assert a is b                                             # one store per action file (and process)
     assert len(a._a._cache) == 0                              # nothing decompressed yet
     _ = a["frames"]["8"]["metadata"]["rest_matrixs"][:]
     assert list(a._a._cache) == ["frames/8/metadata/rest_matrixs"]
+    # a forked child (a DataLoader worker) opens its own descriptor instead of sharing the parent's
+    r, w = os.pipe()
+    pid = os.fork()
+    if pid == 0:
+        try:
+            c = D.open_sequence(p)
+            ok = (c is not a) and c._z.fid is not a._z.fid and len(D._STORES) == 1
+            os.write(w, b"1" if ok else b"0")
+        finally:
+            os._exit(0)
+    os.waitpid(pid, 0)
+    assert os.read(r, 1) == b"1"
+    # a file rewritten under the same name replaces its stale store
+    os.utime(p, (1, 1))
+    assert D.open_sequence(p) is not a
+    D.close_sequences()
+    assert not D._STORES
