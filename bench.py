@@ -25,8 +25,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
-DOMINANT = "k_blend_bwd"
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc.json")  # rocprofv3 --pmc passes of this same command (tools/measure_round.sh)
+PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc.json")  # rocprofv3 --pmc passes of this same command (tools/measure_round.sh)
 REPEATS = 5   # the --steps loop is timed this many times; the median goes into the line, min / max beside it
 
 
@@ -42,7 +41,8 @@ def pmc_counters(kernel, N, V, W, H):
         if d.get("workload") != [N, V, W, H]:
             return {}
         k = d["kernels"][kernel]
-        out = {"traffic": k.get("hbm_bytes_per_launch"), "duration_ns": k.get("duration_ns")}
+        out = {"traffic": k.get("hbm_bytes_per_launch"), "duration_ns": k.get("duration_ns"),
+               "step_hbm_bytes": d.get("step_hbm_bytes"), "step_kernel_ns": d.get("step_kernel_ns")}
         if "SQ_INSTS_VALU" in k and k.get("duration_ns"):
             out["valu_issue_frac"] = round(4.0 * k["SQ_INSTS_VALU"] / (1024.0 * k["duration_ns"] * 2.4), 4)
         if "SQ_LDS_IDX_ACTIVE" in k and k.get("duration_ns"):
@@ -409,6 +409,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # The dominant kernel is the one THIS run spends most of its time in (k_blend_bwd with eight views on the GPU, the
+    # forward blend with one or two): three untimed steps with HIP events around every library kernel decide it, so that
+    # every line -- also the one-view-per-GPU shares of a multi-GPU run -- carries the roofline of its own dominant kernel.
+    _lib.profile_enable(True, only=None)
+    for _ in range(3):
+        step.step()
+    pre = _lib.profile_report()
+    _lib.profile_enable(False)
+    pre.pop("k_image_loss_list", None)      # (runs on the side stream next to the forward blend: its bracket spans the overlap)
+    DOMINANT = max(pre, key=lambda k_: pre[k_][1]) if pre else "k_blend_bwd"
+    if world > 1:   # every rank brackets the same kernel (rank 0's choice)
+        names = sorted(pre) if pre else ["k_blend_bwd"]
+        pick = torch.tensor([names.index(DOMINANT)], device=dev)
+        dist.broadcast(pick, src=0)
+        DOMINANT = names[int(pick.item())] if int(pick.item()) < len(names) else DOMINANT
     # HIP events on the kernel's own stream: around the dominant kernel only (the roofline's duration), around every
     # library kernel with --profile-all (26 bracketed launches per step cost ~0.1 ms of the step).
     # The loop of exactly --steps steps (barrier + synchronize on both sides, MAX over the ranks) is timed REPEATS times:
@@ -454,7 +469,7 @@ def main():
         roof = None
         if dom:
             avg_ms = dom[1] / dom[0]
-            kb = kernel_algorithmic_bytes(DOMINANT, N, V_local, R_view, P_px)
+            kb = kernel_algorithmic_bytes(DOMINANT, N, V_local, R_view, P_px) or 0
             ach = kb / (avg_ms * 1e-3) / 1e9
             pmc = pmc_counters(DOMINANT, N, V_local, W, H) if world == 1 else {}
             # the committed counter passes describe THIS kernel only if their dispatch took as long as it does now
@@ -469,6 +484,15 @@ def main():
                             "`limiter` says what the counters say bounds the kernel"}
             if pmc.get("stale"):
                 roof["traffic_stale"] = True    # counters on file are of an older build of the kernel: not reused
+            if pmc.get("step_hbm_bytes") and pmc.get("step_kernel_ns"):
+                # HBM bytes of ALL kernels of one step by the counters (the sum over the kernels of their mean per launch x
+                # their launches per step) over this run's step time -- what the step as a whole moves, next to the
+                # algorithmic figure above; only when the counter pass's kernels took as long as this run's step
+                step_ms = 1e3 * dt / args.steps
+                if abs(pmc["step_kernel_ns"] * 1e-6 - step_ms) < 0.08 * step_ms:
+                    roof["step_traffic_bytes"] = int(pmc["step_hbm_bytes"])
+                    roof["step_traffic_GBps"] = round(pmc["step_hbm_bytes"] / (step_ms * 1e-3) / 1e9, 1)
+                    roof["step_traffic_frac"] = round(pmc["step_hbm_bytes"] / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
             # The SURVEY 8(d) figure counts every rectangle pair (R = num_rendered); exact null-pair culling and early
             # termination mean most of them are never read.  What the kernel really touches: 112 B per list entry
             # consumed + 20 B per pixel.

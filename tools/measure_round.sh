@@ -3,7 +3,7 @@
 # (separate passes, never combined with API traces), the bench itself (with the CPU oracle leg).
 # Usage: tools/measure_round.sh TAG [ROUND]      (outputs under gpurun_out/, summaries copied to profiles/)
 TAG=${1:-x}
-RND=${2:-r03}
+RND=${2:-r04}
 ROOT=$(pwd)
 export TMPDIR=/tmp
 mkdir -p profiles gpurun_out

@@ -1,7 +1,7 @@
 #!/bin/bash
 # The other workloads of BASELINE.json through the same bench.py (not headline lines): 1 / 2 / 4 views per GPU of the hand
 # scene, the 500 k composite with 7 views, the 100 k object with one view.  Usage: tools/other_configs.sh [ROUND]
-RND=${1:-r03}
+RND=${1:-r04}
 OUT=profiles/${RND}_other_configs
 mkdir -p $OUT
 run() { name=$1; shift; python bench.py --steps 50 --warmup 5 --no-cpu-baseline "$@" > $OUT/$name.json 2>/dev/null

@@ -46,7 +46,11 @@ def main():
         wl = None
         if "--workload" in sys.argv:
             wl = [int(x) for x in sys.argv[sys.argv.index("--workload") + 1].split(",")]
-        json.dump({"workload": wl, "source": "rocprofv3 --pmc passes of `python bench.py --steps 4 --warmup 2 --no-cpu-baseline` "
+        # one step: every kernel's mean per launch x its launches per step (the dominant backward blend runs once per step)
+        steps = max(1, res.get("k_blend_bwd", {}).get("launches", 1))
+        step_bytes = sum(d.get("hbm_bytes_per_launch", 0.0) * d["launches"] / steps for d in res.values())
+        step_ns = sum(d.get("duration_ns", 0.0) * d["launches"] / steps for d in res.values())
+        json.dump({"workload": wl, "step_hbm_bytes": step_bytes, "step_kernel_ns": step_ns, "source": "rocprofv3 --pmc passes of `python bench.py --steps 4 --warmup 2 --no-cpu-baseline` "
                    "(tools/pmc_collect.sh: one pass per counter group, never combined with API traces), mean per launch, "
                    "summed over XCDs / SEs; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) KB (gfx950 FETCH_SIZE correction, "
                    "MI355X_MICROARCH.md HBM section; gather widths uncalibrated)",
