@@ -38,6 +38,7 @@ def lib():
         _LIB = ctypes.CDLL(build())
         for sfx in ("_f32", "_f64"):
             getattr(_LIB, "orc_forward" + sfx).restype = ctypes.c_void_p
+            getattr(_LIB, "orc_forward_ex" + sfx).restype = ctypes.c_void_p
             getattr(_LIB, "orc_forward_geom" + sfx).restype = ctypes.c_void_p
             getattr(_LIB, "orc_backward_geom" + sfx).restype = None
             getattr(_LIB, "orc_num_rendered" + sfx).restype = ctypes.c_long
@@ -61,7 +62,7 @@ class RasterOracle:
     i.e. column-major math matrices; cam_utils.py:58-63)."""
 
     def __init__(self, W, H, tanfovx, tanfovy, view, proj, means3D, cov3D, colors, opacity, bg,
-                 dtype=np.float32):
+                 dtype=np.float32, blend=True):
         self.dt = np.dtype(dtype)
         self.sfx = "_f32" if self.dt == np.float32 else "_f64"
         self.c_real = ctypes.c_float if self.dt == np.float32 else ctypes.c_double
@@ -75,10 +76,11 @@ class RasterOracle:
         opacity, bg = c(opacity, (self.N,)), c(bg, (3,))
         self.color = np.zeros((3, self.H, self.W), dtype=self.dt)
         self.radii = np.zeros((self.N,), dtype=np.int32)
-        self._h = getattr(L, "orc_forward" + self.sfx)(
+        # blend=False: the per-Gaussian preprocess only (radii, geom(), num_rendered; no image, no backward)
+        self._h = getattr(L, "orc_forward_ex" + self.sfx)(
             ctypes.c_int(self.W), ctypes.c_int(self.H), self.c_real(tanfovx), self.c_real(tanfovy),
             _p(view), _p(proj), ctypes.c_int(self.N), _p(means3D), _p(cov3D), _p(colors), _p(opacity),
-            _p(bg), _p(self.color), _p(self.radii))
+            _p(bg), _p(self.color), _p(self.radii), ctypes.c_int(1 if blend else 0))
         self._h = ctypes.c_void_p(self._h)
         self.num_rendered = int(getattr(L, "orc_num_rendered" + self.sfx)(self._h))
 

@@ -223,11 +223,12 @@ static void FN(orc_blend_forward)(FN(OrcState) * s, const REAL* colors, const RE
         }
 }
 
-/* Forward.  out_color is CHW (3,H,W); radii int32 (N). */
-FN(OrcState) * FN(orc_forward)(int W, int H, REAL tanfovx, REAL tanfovy, const REAL* view,
+/* Forward.  out_color is CHW (3,H,W); radii int32 (N).  do_blend = 0 stops after K1 (the per-Gaussian preprocess: radii,
+ * depth, pixel centres, conics, tile rectangles, num_rendered): what a test of the integer state at full size needs. */
+FN(OrcState) * FN(orc_forward_ex)(int W, int H, REAL tanfovx, REAL tanfovy, const REAL* view,
                                const REAL* proj, int N, const REAL* means3D, const REAL* cov3D,
                                const REAL* colors, const REAL* opacity, const REAL* bg,
-                               REAL* out_color, int* radii_out) {
+                               REAL* out_color, int* radii_out, int do_blend) {
     FN(OrcState)* s = (FN(OrcState)*)calloc(1, sizeof(FN(OrcState)));
     s->W = W; s->H = H; s->N = N;
     s->gx = (W + 15) / 16; s->gy = (H + 15) / 16;
@@ -291,11 +292,20 @@ FN(OrcState) * FN(orc_forward)(int W, int H, REAL tanfovx, REAL tanfovy, const R
         s->rect[4 * i] = x0; s->rect[4 * i + 1] = y0; s->rect[4 * i + 2] = x1; s->rect[4 * i + 3] = y1;
         total += s->tiles_touched[i];
     }
-    (void)total;
     if (radii_out) memcpy(radii_out, s->radii, (size_t)N * sizeof(int));
-
+    if (!do_blend) {
+        s->num_rendered = total;
+        return s;
+    }
     FN(orc_bin_and_blend)(s, colors, bg, out_color);
     return s;
+}
+
+FN(OrcState) * FN(orc_forward)(int W, int H, REAL tanfovx, REAL tanfovy, const REAL* view,
+                               const REAL* proj, int N, const REAL* means3D, const REAL* cov3D,
+                               const REAL* colors, const REAL* opacity, const REAL* bg,
+                               REAL* out_color, int* radii_out) {
+    return FN(orc_forward_ex)(W, H, tanfovx, tanfovy, view, proj, N, means3D, cov3D, colors, opacity, bg, out_color, radii_out, 1);
 }
 
 /* Forward from given 2D state: the blend (K2-K6) of SURVEY.md Appendix A on per-Gaussian screen-space inputs

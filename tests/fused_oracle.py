@@ -27,10 +27,39 @@ from tools.parity import (DEV, FLIP_EPS, align_threshold_decisions, device_alpha
                           kernel_last_gaussian, layout)
 
 
+def _contributors_at(bo, rec, pix, W):
+    """Gaussians that can contribute at the given pixels (a superset: the early stop is ignored): the entries of the
+    pixel's tile list whose alpha there reaches 1/255 (within 0.1 %)."""
+    pl, rg = bo.binning()
+    gx = (W + 15) // 16
+    out = set()
+    for p in np.unique(np.asarray(pix)):
+        px, py = int(p) % W, int(p) // W
+        t = (py // 16) * gx + px // 16
+        g = pl[rg[t, 0]:rg[t, 1]]
+        r = rec[g].astype(np.float64)
+        dx, dy = r[:, 0] - px, r[:, 1] - py
+        power = -0.5 * (r[:, 2] * dx * dx + r[:, 4] * dy * dy) - r[:, 3] * dx * dy
+        alpha = np.minimum(0.99, r[:, 5] * np.exp(np.minimum(power, 0.0)))
+        out.update(int(x) for x in g[(power <= 1e-6) & (alpha >= (1.0 - 1e-3) / 255.0)])
+    return out
+
+
+def _ulps(a, b):
+    """Distance in units of the last place between two float32 arrays of equal sign."""
+    ia, ib = a.astype(np.float32).view(np.int32).astype(np.int64), b.astype(np.float32).view(np.int32).astype(np.int64)
+    return np.abs(ia - ib)
+
+
 def run_fused_vs_oracle(kind, views, n, W, H, seed, grid_res=24, cam_radius=0.5, sigma_range=(2e-3, 8e-3), account_flips=True,
-                        device=DEV, n_cameras=None, g_scale=1.0):
+                        device=DEV, n_cameras=None, g_scale=1.0, own_projection=False):
     """One fused forward + backward of `views` views against the oracle on identical blend inputs.  Returns a dict of
-    measured deviations; asserts nothing except exact integer state (visibility counts, radii)."""
+    measured deviations; asserts nothing except exact integer state (visibility counts, radii).
+
+    own_projection=True also runs the ORACLE'S OWN per-Gaussian preprocess (RasterOracle(blend=False) on the torch chain's
+    posed means / covariances: an fp32 chain independent of the kernels') and reports, per view, how its integer state
+    compares with the kernels': the Gaussians whose radius or tile rectangle differs (listed, with both values), the pair
+    counts of both sides, and the depth keys' distance in units of the last place."""
     from manus_amd import rasterizer as rz
     from manus_amd.engine import HipViewCompute
     from manus_amd.synthetic import camera_table, make_scene
@@ -59,11 +88,29 @@ def run_fused_vs_oracle(kind, views, n, W, H, seed, grid_res=24, cam_radius=0.5,
     res = dict(ambiguous=0, flips=0, stop_flips=0, stop_violations=0, img_max=0.0, img_mean=0.0, img_frac_2e6=0.0, dpsnr=0.0, sums9=0.0, proj_pix=0.0, proj_conic=0.0,
                proj_col=0.0)
     bos, bws = [], []
+    touched = set()      # Gaussians that contribute at a pixel where a threshold decision was (or could be) flipped
     for v in ids:
         bo = BlendOracle(W, H, grec[v][:, 0:2], depth[v], grec[v][:, 2:5], grec[v][:, 5], radii[v], grec[v][:, 6:9], bg)
+        # The pixels where the kernels decide a threshold differently from the oracle (alpha >= 1/255 on a pair within rounding
+        # of it; the end of a pixel's walk), found on the un-forced oracle whether or not the decisions are then aligned:
+        # a flipped decision changes the gradient of everything composited at its pixel, and nothing else.
+        klast = kernel_last_gaussian(v, views, n, W, H, kernel_last[v])
+        apix, agid, aal = bo.ambiguous_pairs(FLIP_EPS)
+        fpix = np.zeros(0, np.int64)
+        if len(apix):
+            _, dvalid = device_alpha_decisions(grec[v][agid][:, :6], apix % W, apix // W, device)
+            fpix = apix[dvalid != (aal >= np.float32(1.0) / np.float32(255.0)).astype(np.int32)].astype(np.int64)
+        _, onc = bo.image_state()
+        pl, rg = bo.binning()
+        gx_ = (W + 15) // 16
+        ys_, xs_ = np.mgrid[0:H, 0:W]
+        tl = (ys_ // 16) * gx_ + xs_ // 16
+        olast = np.where(onc > 0, pl[np.clip(rg[tl, 0].astype(np.int64) + onc - 1, 0, max(len(pl) - 1, 0))] if len(pl) else -1, -1)
+        spix = np.nonzero((olast != klast).reshape(-1))[0]
+        touched |= _contributors_at(bo, grec[v], np.concatenate([fpix, spix]), W)
+        res["decision_pixels"] = res.get("decision_pixels", 0) + int(len(np.unique(np.concatenate([fpix, spix]))))
         if account_flips:
-            a, f, sf, sv = align_threshold_decisions(bo, grec[v], grec[v][:, 6:9], bg, W,
-                                                     kernel_last_gaussian(v, views, n, W, H, kernel_last[v]), device)
+            a, f, sf, sv = align_threshold_decisions(bo, grec[v], grec[v][:, 6:9], bg, W, klast, device)
             res["ambiguous"] += a
             res["flips"] += f
             res["stop_flips"] += sf
@@ -99,6 +146,27 @@ def run_fused_vs_oracle(kind, views, n, W, H, seed, grid_res=24, cam_radius=0.5,
                                     torch.tensor(np.asarray(c["world_view_transform"], np.float32)),
                                     torch.tensor(np.asarray(c["full_proj_transform"], np.float32)))
         visible = radii[v] > 0
+        if own_projection:
+            from oracle import RasterOracle
+            ro = RasterOracle(W, H, math.tan(c["fovx"] / 2), math.tan(c["fovy"] / 2),
+                              np.asarray(c["world_view_transform"], np.float32).reshape(-1),
+                              np.asarray(c["full_proj_transform"], np.float32).reshape(-1),
+                              o["posed_xyz"].detach().numpy(), o["posed_cov"].detach().numpy(), o["colors"].detach().numpy(),
+                              o["opacity"].detach().numpy()[:, 0], bg, blend=False)
+            geo = ro.geom()
+            kgeo = bos[v].geom()     # the kernels' state through the oracle's rectangle rule (what the identical-inputs blend used)
+            dr = np.nonzero(ro.radii != radii[v])[0]
+            drect = np.nonzero((geo["rect"] != kgeo["rect"]).any(1) & (ro.radii == radii[v]))[0]
+            both = (ro.radii > 0) & visible
+            own = res.setdefault("own", [])
+            own.append(dict(view=v, radius_differs=[(int(i), int(radii[v][i]), int(ro.radii[i])) for i in dr[:64]], n_radius_differs=int(len(dr)),
+                            max_radius_delta=int(np.abs(ro.radii[dr] - radii[v][dr]).max()) if len(dr) else 0,
+                            n_rect_differs=int(len(drect)), pairs_kernels=int(bos[v].num_rendered), pairs_oracle=int(ro.num_rendered),
+                            pairs_delta_explained=int((geo["tiles_touched"].astype(np.int64) - kgeo["tiles_touched"].astype(np.int64))[np.union1d(dr, drect)].sum()),
+                            depth_max_ulps=int(_ulps(geo["depth"][both], depth[v][both]).max()) if both.any() else 0,
+                            depth_bit_equal=float(np.mean(geo["depth"][both].view(np.int32) == depth[v][both].view(np.int32))) if both.any() else 1.0,
+                            xy_max=float(np.abs(geo["xy"][both] - r[both, 0:2]).max()) if both.any() else 0.0))
+            ro.close()
         pix = ((ndc.detach().numpy() + 1.0) * np.array([W, H]) - 1.0) * 0.5
         res["proj_pix"] = max(res["proj_pix"], float(np.abs(pix[visible] - r[visible, 0:2]).max()))
         res["proj_conic"] = max(res["proj_conic"], max_rel_err(conic.detach().numpy()[visible], r[visible, 2:5]))
@@ -112,10 +180,18 @@ def run_fused_vs_oracle(kind, views, n, W, H, seed, grid_res=24, cam_radius=0.5,
         vis_cnt += visible
     chain.backward()
     res["grads"], res["rows_over_2e5"] = {}, {}
+    dev_rows = set()
     for k in P:
         a, b = out["grads"][k].cpu().numpy().reshape(P[k].shape).astype(np.float64), P[k].grad.numpy().astype(np.float64)
         res["grads"][k] = max_rel_err(a, b)
-        res["rows_over_2e5"][k] = float(np.mean(np.abs(a - b).reshape(a.shape[0], -1).max(1) > 2e-5 * np.abs(b).max()))
+        over = np.abs(a - b).reshape(a.shape[0], -1).max(1) > 2e-5 * np.abs(b).max()
+        res["rows_over_2e5"][k] = float(np.mean(over))
+        dev_rows.update(int(i) for i in np.nonzero(over)[0])
+    # every leaf row that deviates belongs to a Gaussian that contributes at a pixel holding a pair within rounding of the
+    # alpha threshold (a flipped pair changes the gradient of everything composited at its pixel)
+    res["dev_rows"] = len(dev_rows)
+    res["dev_rows_unexplained"] = sorted(dev_rows - touched)[:32]
+    res["n_touched"] = len(touched)
     res["grad2d"] = max_rel_err(out["grad2d"].cpu().numpy(), g2)
     np.testing.assert_array_equal(out["vis"].cpu().numpy(), vis_cnt)
     np.testing.assert_array_equal(out["radii"].cpu().numpy(), radii.max(0))
@@ -135,4 +211,5 @@ def assert_north_star(res, tag=""):
     for k, e in res["grads"].items():
         assert e < 1e-4, (tag, k, res)
     assert res["grad2d"] < 1e-4, (tag, res)
-    assert res["proj_pix"] < 2.1e-5 * res["width"] and res["proj_conic"] < 1e-4 and res["proj_col"] < 2e-5, (tag, res)
+    # pixel centres of two independent fp32 chains: 2e-4 px measured at 1920 x 1080 (coordinates up to 2e3: 1-2 units of the last place)
+    assert res["proj_pix"] < 1.1e-6 * res["width"] and res["proj_conic"] < 1e-4 and res["proj_col"] < 2e-5, (tag, res)
