@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BWD_WAVES, 
     long long acc_[6] = {0, 0, 0, 0, 0, 0}, tp_ = wall_clock64(), nit_ = 0;
 #endif
 
-    MgrQueue queue;
+    MgrQueue queue;   // (blocked counters -- the chunks of a tile to one XCD -- measured: 0.426 against 0.422 ms, no gain)
     queue.init(hdr->qctr, n_items, (int)blockIdx.x);
     uint32_t item = queue.resolve(queue.issue(lane), lane);
     while (item != 0xFFFFFFFFu) {
