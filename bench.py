@@ -285,6 +285,8 @@ def main():
     ap.add_argument("--dense-loss-scan", action="store_true",
                     help="image loss without the rasterizer's tile occupancy: compares rendered and target image everywhere "
                          "to find the spans that need work (the default settles spans under empty tiles from the target alone)")
+    ap.add_argument("--no-depth-cut", action="store_true",
+                    help="bin every pair every step (no use of the previous forward's per-tile saturation depth)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (cpu_baseline and parity)")
     ap.add_argument("--parity-views", type=int, default=2, help="views of the step run through the CPU oracle")
     ap.add_argument("--profile-all", action="store_true", help="print a per-kernel HIP-event breakdown to stderr")
@@ -320,7 +322,8 @@ def main():
         targets = hp.forward_views_fused(list(range(V)))[0].contiguous()
         del hp
     rasterizer.context(dev).clear()
-    compute = HipViewCompute(scene, targets, ct, loss=args.loss, sh_storage=args.sh_storage, sparse_loss=not args.dense_loss_scan)
+    compute = HipViewCompute(scene, targets, ct, loss=args.loss, sh_storage=args.sh_storage, sparse_loss=not args.dense_loss_scan,
+                             depth_cut=not args.no_depth_cut)
     shapes = {k: v.shape for k, v in compute.params.items()}
     sharded = args.sharded_adam and args.optimizer and world > 1
     # N > 1: the views go to the ranks by measured cost (pairs per view from one forward of every view -- deterministic,
@@ -385,6 +388,14 @@ def main():
 
         def step_with_adam():
             o = base_step()
+            if compute.depth_cut and not rasterizer.context(dev).sync_every_forward:
+                # the model moves under the depth-cut hints: wait for the forward's fence (the backward queued behind it
+                # keeps the GPU busy) and run the step again if it was flagged -- what engine.Trainer does every step
+                try:
+                    rasterizer.poll(dev)
+                except RuntimeError:
+                    o = base_step()
+                    rasterizer.poll(dev)
             opt.update_learning_rate(opt.state_step + 1)
             if sharded:
                 opt.step_range(step._store, *step.owned)
@@ -573,6 +584,10 @@ def main():
                                       "detail": "dense 61N floats" if mode == "dense" else
                                                 "rows with a gradient (%s of %d) x 60 floats + 2N bytes" % (step.last_rows, N)}),
                        "optimizer_in_step": bool(args.optimizer), "sh_storage": args.sh_storage,
+                       "depth_cut": ("off" if not compute.depth_cut else
+                                     "per-tile saturation depth of the previous forward of the same views bounds the binning; exact "
+                                     "(flagged and re-run without it when a cut list runs out): %d flagged forwards in this run"
+                                     % rasterizer.context(dev).cut_retries),
                        "loss_span_list": "full comparison of rendered and target image" if args.dense_loss_scan else "tile occupancy of the forward + target background",
                        "nonfinite_grad_values": nonfinite},
             "roofline": roof, "cpu_baseline": cpu, "parity": parity,

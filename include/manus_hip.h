@@ -79,7 +79,9 @@ enum {
     MGR_EINVAL = -1,   /* bad argument */
     MGR_ENOMEM = -2,   /* workspace too small (see mgr_raster_workspace_bytes) */
     MGR_EHIP = -3,     /* a HIP call failed; text in mgr_last_error() */
-    MGR_EOVERFLOW = -4 /* pair capacity exceeded (reported by mgr_raster_status_sync) */
+    MGR_EOVERFLOW = -4, /* pair capacity exceeded (reported by mgr_raster_status_sync) */
+    MGR_ECUT = -6       /* a forward run with the depth cut (debug bit 8) met a scene its hints no longer fit: its image is
+                           incomplete; run it again without the bit (reported by mgr_raster_status_sync) */
 };
 
 int mgr_version(void);
@@ -110,7 +112,15 @@ size_t mgr_raster_workspace_bytes(int V, int N, int W, int H, int64_t pair_capac
  * final, out_color is not written); 4 = the blend only, after a call with bit 2 on the same workspace and arguments.
  * Bits 2 / 4 let a caller put work that needs the tile lists but not the image next to the blend (the image loss's
  * span list, mgr_image_loss_tiles_list).  The tile lists come from the depth-ordered binning; MGR_BINNING=sorted in
- * the environment selects the per-tile sorts instead (identical lists). */
+ * the environment selects the per-tile sorts instead (identical lists).
+ * 8 (mgr_views_forward only) = depth cut.  Every forward leaves, per tile whose pixels all saturated, the depth in front
+ * of which they had all stopped plus a margin; with bit 8 the next forward on the same workspace leaves the instances
+ * behind that depth out of the tile's list (they lie behind every pixel's stop: image, n_contrib and gradients are bit
+ * for bit those of the full lists, but the binning handles a fraction of the pairs).  Only valid when that previous
+ * forward rendered the SAME views (camera + pose) of a model that has moved little since; if a cut list runs out under
+ * a pixel that has not saturated the forward raises the overflow word's bit 1 (mgr_raster_status_sync: MGR_ECUT) and
+ * the caller runs it again without bit 8.  Pass the bit to both calls of a forward split with bits 2 / 4.  No
+ * counterpart upstream (the reference renders one view per step and re-bins everything). */
 int mgr_raster_forward(int V, int N, int W, int H, const float* cams, const float* bg,
                        const float* means3D, int64_t stride_means3D, const float* cov3D,
                        int64_t stride_cov3D, const float* colors, int64_t stride_colors,

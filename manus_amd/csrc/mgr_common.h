@@ -87,6 +87,9 @@ struct MgrHeader {            // first 256 bytes of the workspace
     uint32_t qctr_f[16 * 64];
 };
 #define MGR_NCTR 16
+// bits of MgrHeader::overflow
+#define MGR_OVF_PAIRS 1u   // the pair capacity was exceeded: lists clipped, image and gradients incomplete
+#define MGR_OVF_CUT 2u     // a tile whose list was cut short by the depth cut ran out of entries with a pixel still unsaturated
 
 // 48-byte per-(view,Gaussian) record gathered by the blend kernels
 struct __attribute__((aligned(16))) MgrGRec {
@@ -102,7 +105,7 @@ struct __attribute__((aligned(16))) MgrGRec {
 
 struct MgrLayout {
     size_t header, scan_part, scan_cls, grec, depth, rect, alive, pair_off, tile_count, tile_start, tile_cursor, tile_done, tile_qdone,
-        tile_queue, tile_qrec, chunk_start, items, ckpt, keys, keys2, groups, sorted_gid, final_T, n_contrib, pair_tag, pair_grad, inst_grad, inst_tag,
+        tile_zcut, tile_zused, tile_qend, tile_queue, tile_qrec, chunk_start, items, ckpt, keys, keys2, groups, sorted_gid, final_T, n_contrib, pair_tag, pair_grad, inst_grad, inst_tag,
         db_count, db_cursor, db_start, db_nvis, db_bbox, db_keys, db_order, db_rec, bin_mat, total;
 };
 
@@ -136,6 +139,13 @@ static inline MgrLayout mgr_layout(int V, int N, int W, int H, int64_t cap) {
     L.tile_cursor = o; o += mgr_align(VT * 4);
     L.tile_done = o;   o += mgr_align(VT * 4);
     L.tile_qdone = o;  o += mgr_align(VT * 16);       // list depth each 8x8 quadrant of a tile consumed in the forward blend
+    // depth cut (mgr_views_forward, debug bit 8): per tile the complement of the float bits of the depth beyond which the
+    // NEXT forward may leave instances out of the tile's list (0 = no cut), written by k_fwd_items from how deep THIS
+    // forward's walk went; the value a forward applied (k_tile_scan_b moves it there); the list position at which the
+    // tile's last quadrant saturated (0xFFFFFFFF: some pixel never did)
+    L.tile_zcut = o;   o += mgr_align(VT * 4);
+    L.tile_zused = o;  o += mgr_align(VT * 4);
+    L.tile_qend = o;   o += mgr_align(VT * 4);
     L.tile_queue = o;  o += mgr_align(VT * 4);
     L.tile_qrec = o;   o += mgr_align(VT * 16);       // queue of the forward blend, interleaved by view: position p = (tile, list offset, list length, first checkpoint) of a tile of view p % V, or a hole
     L.chunk_start = o; o += mgr_align((VT + 1) * 4);

@@ -152,12 +152,12 @@ __device__ __forceinline__ void pre_tail(int N, int gx, int gy, int v, int i, co
                                          MgrGRec* __restrict__ grec, float* __restrict__ depth,
                                          ushort4* __restrict__ rect, unsigned long long* __restrict__ alive,
                                          uint32_t* __restrict__ pair_off, uint32_t* __restrict__ tile_count,
-                                         int32_t* __restrict__ radii, MgrHeader* hdr) {
+                                         int32_t* __restrict__ radii, MgrHeader* hdr, const uint32_t* __restrict__ zcut_v = nullptr) {
     const int tid = threadIdx.x, T = gx * gy;
     const int radius = po.radius, x0 = po.x0, y0 = po.y0, x1 = po.x1, y1 = po.y1;
     const uint32_t tiles = (uint32_t)((x1 - x0) * (y1 - y0));
     unsigned long long amask = ~0ull;
-    if (radius > 0) {
+    if (radius > 0 && !(zcut_v && tiles <= 64)) {
         const bool small = tiles <= 64;
         const MgrCull cull = mgr_cull_init(po.px, po.py, po.ca, po.cb, po.cc, mgr_qmax(op_i));
         if (small) amask = 0ull;
@@ -172,6 +172,48 @@ __device__ __forceinline__ void pre_tail(int N, int gx, int gy, int v, int i, co
                 }
                 if (lds_hist) atomicAdd(&s_hist[y * gx + x], 1u);
                 else atomicAdd(&tile_count[(size_t)v * T + y * gx + x], 1u);
+            }
+        }
+    } else if (radius > 0) {
+        // Depth cut (zcut_v: this view's row of tile_zcut).  A tile whose every pixel saturated in front of depth zc in the
+        // previous forward of this view leaves out the instances behind zc -- they sit behind the stop of every pixel
+        // unless the scene changed, which the blend detects (MGR_OVF_CUT) and the caller answers by a forward without the
+        // cut.  Stored value = ~(float bits of zc), 0 = no cut; depths are positive, so their bits order like the floats.
+        // Two passes, so that the table lookups do not sit one behind the other in the cull loop: the null-tile test
+        // first (arithmetic only), then the surviving tiles four at a time.  (Rectangles of more than 64 tiles have no mask
+        // and are never cut.)
+        const MgrCull cull = mgr_cull_init(po.px, po.py, po.ca, po.cb, po.cc, mgr_qmax(op_i));
+        unsigned long long m = 0ull;
+        int k = 0;
+        for (int y = y0; y < y1; ++y) {
+            float dy_lo, dy_hi, dxo;
+            mgr_cull_row(cull, 16.0f * y, 16.0f * y + 15.0f, dy_lo, dy_hi, dxo);
+            for (int x = x0; x < x1; ++x, ++k)
+                if (!mgr_cull_dead(cull, dy_lo, dy_hi, dxo, 16.0f * x, 16.0f * x + 15.0f)) m |= 1ull << k;
+        }
+        const uint32_t zbits = __float_as_uint(po.zv);
+        const int w = x1 - x0;
+        const float rw = 1.0f / (float)w;
+        amask = 0ull;
+        while (m) {
+            int kk[4], tt[4];
+            uint32_t zc[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                kk[j] = m ? __builtin_ctzll(m) : -1;
+                m &= m - 1ull;                                        // (0 stays 0)
+                const int ky = (int)(((float)max(kk[j], 0) + 0.5f) * rw);   // k / w, exact for k < 64
+                tt[j] = (y0 + ky) * gx + x0 + (max(kk[j], 0) - ky * w);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) zc[j] = zcut_v[tt[j]];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (kk[j] >= 0 && zbits <= ~zc[j]) {
+                    amask |= 1ull << kk[j];
+                    if (lds_hist) atomicAdd(&s_hist[tt[j]], 1u);
+                    else atomicAdd(&tile_count[(size_t)v * T + tt[j]], 1u);
+                }
             }
         }
     }
@@ -265,7 +307,7 @@ __global__ __launch_bounds__(PRE_THREADS) void k_inst_fwd(
     const float* __restrict__ skin_w, const float* __restrict__ transforms, MgrGRec* __restrict__ grec,
     float* __restrict__ depth, ushort4* __restrict__ rect, unsigned long long* __restrict__ alive,
     uint32_t* __restrict__ pair_off, uint32_t* __restrict__ tile_count, int32_t* __restrict__ radii,
-    MgrHeader* hdr, int lds_hist, int V) {
+    MgrHeader* hdr, int lds_hist, int V, const uint32_t* __restrict__ tile_zcut) {
     extern __shared__ uint32_t s_mem[];
     uint32_t* s_scan = s_mem;
     uint32_t* s_hist = s_mem + 32;
@@ -339,7 +381,7 @@ __global__ __launch_bounds__(PRE_THREADS) void k_inst_fwd(
         }
     }
     pre_tail(N, gx, gy, v, i, po, op_i, col, s_scan, s_hist, lds_hist, grec, depth, rect, alive, pair_off, tile_count,
-             radii, hdr);
+             radii, hdr, tile_zcut ? tile_zcut + (size_t)v * T : nullptr);
 }
 
 // ---------------------------------------------------------------------------
@@ -403,7 +445,9 @@ __global__ __launch_bounds__(1024) void k_tile_scan_b(int V, int T, int nbT, uin
                                                       uint32_t* __restrict__ tile_queue, uint4* __restrict__ tile_qrec,
                                                       const uint32_t* __restrict__ tile_done, int use_hint,
                                                       uint32_t* __restrict__ chunk_start, MgrHeader* hdr,
-                                                      uint32_t cap) {
+                                                      uint32_t cap, uint32_t* __restrict__ tile_zcut,
+                                                      uint32_t* __restrict__ tile_zused, uint32_t* __restrict__ tile_qend,
+                                                      int use_cut) {
     __shared__ uint32_t s_scan[32];
     __shared__ uint32_t s_gtot[MGR_NCLS], s_gpre[MGR_NCLS], s_vtot[MGR_NCLS], s_vpre[MGR_NCLS];   // tiles per class: all / in front of this block, of all views / of this view
     __shared__ uint32_t s_gbase[MGR_NCLS], s_vbase[MGR_NCLS], s_lc[MGR_NCLS];
@@ -462,6 +506,11 @@ __global__ __launch_bounds__(1024) void k_tile_scan_b(int V, int T, int nbT, uin
         tile_start[k] = s_base[0] + run;
         chunk_start[k] = s_base[1] + crun;
         tile_cursor[k] = 0;
+        // depth cut: what this forward applied to the tile moves to tile_zused (the blend's check, k_fwd_items), the hint
+        // itself is consumed -- k_fwd_items writes the next one for the tiles that have a list
+        tile_zused[k] = use_cut ? tile_zcut[k] : 0u;
+        tile_zcut[k] = 0u;
+        tile_qend[k] = 0u;
         const uint32_t rank = atomicAdd(&s_lc[cls], 1u);
         tile_queue[s_gbase[cls] + s_gpre[cls] + rank] = (uint32_t)k;
         if (cls > 0) {
@@ -475,7 +524,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan_b(int V, int T, int nbT, uin
     if (b == 0 && tid == 0) {
         tile_start[(size_t)V * T] = s_tot[0];
         chunk_start[(size_t)V * T] = s_tot[1];
-        hdr->overflow = (s_tot[0] > cap || hdr->total_pairs > cap) ? 1u : 0u;
+        hdr->overflow = (s_tot[0] > cap || hdr->total_pairs > cap) ? MGR_OVF_PAIRS : 0u;
         hdr->n_items = 0;
         hdr->item_head = 0;
         hdr->queue_len = s_gbase[0];     // class 0 (empty tiles) starts after all non-empty ones
@@ -1659,7 +1708,8 @@ __global__ __launch_bounds__(256) FWD_OCC void k_blend_fwd(int N, int W, int H, 
                                                      uint32_t* __restrict__ n_contrib,
                                                      uint32_t* __restrict__ tile_done,
                                                      uint32_t* __restrict__ tile_qdone,
-                                                     float4* __restrict__ ckpt, MgrHeader* hdr) {
+                                                     float4* __restrict__ ckpt, MgrHeader* hdr,
+                                                     const uint32_t* __restrict__ tile_zused, uint32_t* __restrict__ tile_qend) {
     __shared__ __align__(16) float s_pair[4][32][MGR_PAIR_FLOATS];
     __shared__ __align__(16) uint4 s_qrec[FWD_SLOTS];     // queue record of a published step
     __shared__ uint32_t s_step[FWD_SLOTS];                // which step the slot holds (published last: the flag the readers poll)
@@ -1797,7 +1847,8 @@ __global__ __launch_bounds__(256) FWD_OCC void k_blend_fwd(int N, int W, int H, 
         if (rec.c == 12345.678f) break;   // (forces the first records to be here before the clock is read)
 #endif
         FP(0);
-        for (uint32_t off = 0; off < nlist; off += 64) {
+        uint32_t off = 0;
+        for (; off < nlist; off += 64) {
             // bounding box of this quadrant's pixels that are still accumulating
             int bx0, by0, bx1, by1;
             if (!mgr_quad_bbox(~done_m & exec_m, bx0, by0, bx1, by1)) break;
@@ -1906,7 +1957,15 @@ __global__ __launch_bounds__(256) FWD_OCC void k_blend_fwd(int N, int W, int H, 
         uint32_t mx = last;
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
-        if (lane == 0 && !hole) tile_qdone[(size_t)vt * 4 + quad] = mx;
+        if (lane == 0 && !hole) {
+            tile_qdone[(size_t)vt * 4 + quad] = mx;
+            // depth cut: the list position in front of which every pixel of the quadrant had stopped (a whole number of
+            // batches; the tile's maximum becomes the next forward's hint), or "never" -- and if the list ran out under an
+            // unsaturated pixel while this forward had cut it short, the image may lack contributions: raise the flag
+            const bool unsat = (~done_m & exec_m) != 0ull;
+            atomicMax(&tile_qend[vt], unsat ? 0xFFFFFFFFu : min(off, nlist));
+            if (unsat && tile_zused[vt] != 0u) atomicOr(&hdr->overflow, MGR_OVF_CUT);
+        }
 #ifdef MGR_TIMELINE
         if (lane == 0 && tlw_n < TLW_PER_WAVE) {
             const size_t k = ((size_t)blockIdx.x * 4 + wave) * TLW_PER_WAVE + tlw_n++;
@@ -1945,8 +2004,26 @@ __global__ __launch_bounds__(256) FWD_OCC void k_blend_fwd(int N, int W, int H, 
 // depth consumed by each quadrant).  One thread per queue entry; a block reserves its range with one atomic and writes it
 // with all its threads (record i belongs to the tile found by a search of the block's scan).  Also leaves the tile's depth
 // in tile_done (the scheduling hint of the next forward).
+//
+// Depth cut: the same thread leaves the tile's hint for the NEXT forward in tile_zcut.  A tile whose every pixel had stopped
+// by list position e (tile_qend) needs its entries up to e only; the hint keeps everything up to the depth
+//   zc = max(z_e + MGR_CUT_RANGE (z_e - z_0) + MGR_CUT_REL z_e,  z of entry e + 63)
+// (z_0, z_e: depth of the first entry and of entry e - 1) and lets the next forward drop what lies behind: a margin in
+// depth and in entries for whatever moved in between.  (The bench scene packs ~270 list entries per millimetre of depth
+// into its deep tiles: with 1/4 of the range and z / 500 the cut kept 56 % of the saturating tiles' pairs where the walks
+// end after 18 %; tools/instr/cut_stats.py.)  A list already cut that ends inside that margin keeps at least its
+// cut; an uncut one that does is needed whole.  Unsaturated tiles (silhouette, thin parts) get no hint.
+#ifndef MGR_CUT_RANGE
+#define MGR_CUT_RANGE 0.0625f
+#endif
+#ifndef MGR_CUT_REL
+#define MGR_CUT_REL 2.0e-4f
+#endif
 __global__ __launch_bounds__(256) void k_fwd_items(const uint4* __restrict__ tile_qrec, const uint32_t* __restrict__ tile_qdone,
-                                                   uint32_t* __restrict__ tile_done, uint4* __restrict__ items, MgrHeader* hdr) {
+                                                   uint32_t* __restrict__ tile_done, uint4* __restrict__ items, MgrHeader* hdr,
+                                                   int N, int T, const uint32_t* __restrict__ sorted_gid, const float* __restrict__ depth,
+                                                   const uint32_t* __restrict__ tile_zused, const uint32_t* __restrict__ tile_qend,
+                                                   uint32_t* __restrict__ tile_zcut) {
     __shared__ uint32_t s_scan[8];
     __shared__ uint32_t s_base;
     __shared__ uint32_t s_run[257];
@@ -1965,6 +2042,18 @@ __global__ __launch_bounds__(256) void k_fwd_items(const uint4* __restrict__ til
         const uint32_t tmax = max(max(qd.x, qd.y), max(qd.z, qd.w));
         tile_done[qr.x] = tmax;
         nch = (tmax + MGR_CHUNK - 1) / MGR_CHUNK;
+        const uint32_t e = tile_qend[qr.x], nl = qr.z, used = tile_zused[qr.x];
+        uint32_t hint = 0u;
+        if (e != 0xFFFFFFFFu && e > 0u && e <= nl && (e + 64u <= nl || used != 0u)) {
+            const uint32_t* sg = sorted_gid + qr.y;
+            const float* dv = depth + (size_t)(qr.x / (uint32_t)T) * N;
+            const uint32_t g0 = sg[0], ge = sg[e - 1u], gm = sg[min(e + 63u, nl - 1u)];
+            const float z0 = dv[g0], ze = dv[ge], zm = dv[gm];
+            float zc = ze + MGR_CUT_RANGE * (ze - z0) + MGR_CUT_REL * ze;
+            zc = fmaxf(zc, e + 64u <= nl ? zm : __uint_as_float(~used));
+            hint = ~__float_as_uint(zc);
+        }
+        tile_zcut[qr.x] = hint;
     }
     uint32_t total;
     const uint32_t run = block_excl_scan(nch, s_scan, total);
@@ -2026,7 +2115,8 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
     hipStream_t stream = (hipStream_t)stream_;
     // debug bit 0: synchronise and check after every kernel; bit 1: stop before the blend (instance kernels and binning
     // only); bit 2: the blend only (after a call with bit 1 on the same workspace and arguments)
-    const bool do_bin = !(debug & 4), do_blend = !(debug & 2);
+    // bit 3 (8): depth cut -- apply the hints the previous forward on this workspace left in tile_zcut (fused path only)
+    const bool do_bin = !(debug & 4), do_blend = !(debug & 2), use_cut = (debug & 8) && canon != nullptr;
     debug &= 1;
     if (V <= 0 || N < 0 || W <= 0 || H <= 0 || cap < 0 || cap > 0xFFFFFFF0ll)
         return mgr_fail(MGR_EINVAL, "mgr_raster_forward: bad sizes");
@@ -2088,7 +2178,8 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
                        gx, gy, cams, canon->xyz, canon->log_scale, canon->rot, canon->op_logit, canon->f_dc,            \
                        canon->f_rest, canon->skin_w, canon->transforms, (MgrGRec*)(ws + L.grec),                        \
                        (float*)(ws + L.depth), (ushort4*)(ws + L.rect), (unsigned long long*)(ws + L.alive),            \
-                       (uint32_t*)(ws + L.pair_off), tile_count, radii, hdr, lds_hist, V)
+                       (uint32_t*)(ws + L.pair_off), tile_count, radii, hdr, lds_hist, V,                                  \
+                       use_cut ? (const uint32_t*)(ws + L.tile_zcut) : (const uint32_t*)nullptr)
             if (mixed && canon->sh_half) MGR_IF_LAUNCH(true, true);
             else if (mixed) MGR_IF_LAUNCH(true, false);
             else if (canon->sh_half) MGR_IF_LAUNCH(false, true);
@@ -2111,7 +2202,8 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
                            (const uint32_t*)(ws + L.tile_done), use_hint, part, blk_cls); }
         { MGR_PROF("k_tile_scan_b", stream); hipLaunchKernelGGL(k_tile_scan_b, dim3(nblk), dim3(1024), 0, stream, V, T, nbT, tile_count, part, (const uint32_t*)blk_cls,
                            tile_start, (uint32_t*)(ws + L.tile_cursor), (uint32_t*)(ws + L.tile_queue), (uint4*)(ws + L.tile_qrec),
-                           (const uint32_t*)(ws + L.tile_done), use_hint, (uint32_t*)(ws + L.chunk_start), hdr, (uint32_t)cap); }
+                           (const uint32_t*)(ws + L.tile_done), use_hint, (uint32_t*)(ws + L.chunk_start), hdr, (uint32_t)cap,
+                           (uint32_t*)(ws + L.tile_zcut), (uint32_t*)(ws + L.tile_zused), (uint32_t*)(ws + L.tile_qend), use_cut ? 1 : 0); }
     }
     MGR_LAUNCH_CHECK("k_tile_scan", stream, debug);
     if (N > 0 && ordered) {
@@ -2200,9 +2292,11 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
     { MGR_PROF("k_blend_fwd", stream); hipLaunchKernelGGL(k_blend_fwd, dim3(MGR_FWD_GRID), dim3(256), 0, stream, N, W, H, gx, gy, VT, bg,
                        (const uint32_t*)(ws + L.tile_queue), (const uint4*)(ws + L.tile_qrec), (const uint32_t*)(ws + L.sorted_gid), (const MgrGRec*)(ws + L.grec), out_color,
                        (uint32_t*)(ws + L.n_contrib), (uint32_t*)(ws + L.tile_done), (uint32_t*)(ws + L.tile_qdone),
-                       (float4*)(ws + L.ckpt), hdr); }
+                       (float4*)(ws + L.ckpt), hdr, (const uint32_t*)(ws + L.tile_zused), (uint32_t*)(ws + L.tile_qend)); }
     { MGR_PROF("k_fwd_items", stream); hipLaunchKernelGGL(k_fwd_items, dim3((VT + 255) / 256), dim3(256), 0, stream, (const uint4*)(ws + L.tile_qrec),
-                       (const uint32_t*)(ws + L.tile_qdone), (uint32_t*)(ws + L.tile_done), (uint4*)(ws + L.items), hdr); }
+                       (const uint32_t*)(ws + L.tile_qdone), (uint32_t*)(ws + L.tile_done), (uint4*)(ws + L.items), hdr,
+                       N, T, (const uint32_t*)(ws + L.sorted_gid), (const float*)(ws + L.depth), (const uint32_t*)(ws + L.tile_zused),
+                       (const uint32_t*)(ws + L.tile_qend), (uint32_t*)(ws + L.tile_zcut)); }
     MGR_LAUNCH_CHECK("k_blend_fwd", stream, debug);
     return MGR_OK;
 }
@@ -2244,7 +2338,7 @@ extern "C" int mgr_raster_layout(int V, int N, int W, int H, int64_t cap, size_t
     const size_t v[] = {L.header, L.grec, L.depth, L.rect, L.alive, L.pair_off, L.tile_count, L.tile_start,
                         L.tile_cursor, L.tile_done, L.tile_queue, L.chunk_start, L.items, L.ckpt, L.keys,
                         L.sorted_gid, L.final_T, L.n_contrib, L.pair_tag, L.pair_grad, L.total, L.inst_grad, L.inst_tag,
-                        L.db_nvis, L.db_bbox, L.db_order};
+                        L.db_nvis, L.db_bbox, L.db_order, L.tile_zcut, L.tile_zused, L.tile_qend};
     const int n = (int)(sizeof(v) / sizeof(v[0]));
     for (int i = 0; i < n && i < n_out; ++i) out[i] = v[i];
     return n;
@@ -2286,7 +2380,8 @@ extern "C" int mgr_raster_status_sync(const void* workspace, int64_t* num_pairs,
     MGR_HIP(hipStreamSynchronize(stream));
     if (num_pairs) *num_pairs = h[0];
     if (overflow) *overflow = (int32_t)h[1];
-    if (h[1]) return mgr_fail(MGR_EOVERFLOW, "pair capacity exceeded");
+    if (h[1] & MGR_OVF_PAIRS) return mgr_fail(MGR_EOVERFLOW, "pair capacity exceeded");
+    if (h[1] & MGR_OVF_CUT) return mgr_fail(MGR_ECUT, "depth cut violated: run the forward again without debug bit 8");
     return MGR_OK;
 }
 

@@ -317,8 +317,18 @@ class HipViewCompute:
     the modular operators under autograd (the reference-shaped path)."""
 
     def __init__(self, scene, targets, cam_table, loss_weight=1.0, fused=True, loss="l1", w_rgb=0.8, w_ssim=0.2,
-                 sh_storage="fp32", sparse_loss=True, overlap_loss=True):
+                 sh_storage="fp32", sparse_loss=True, overlap_loss=True, depth_cut=True, max_cut_hints=1024):
         from . import fused as fused_mod, ops, rasterizer
+        # depth_cut (fused step only): every forward leaves, per tile whose pixels all saturated, the depth in front of
+        # which they had stopped (+ a margin); the next forward of the SAME views leaves the instances behind it out of
+        # that tile's list -- the binning kernels then handle a fraction of the pairs, the image and the gradients stay
+        # bit for bit those of the full lists (a cut list that runs out under an unsaturated pixel is flagged like a
+        # pair-capacity overflow and the step is run again without the cut).  The hints live in the workspace; when the
+        # view set changes they are parked per view set (max_cut_hints sets of 4 bytes per tile and view) and brought
+        # back when it returns -- a training run revisits its (frame, camera) pairs every epoch.  MANUS_DEPTH_CUT=0 in
+        # the environment switches it off for A/B runs.
+        self.depth_cut = bool(depth_cut) and os.environ.get("MANUS_DEPTH_CUT", "1") != "0"
+        self._cut_store, self._cut_max, self._cut_gen, self._cut_bit = {}, int(max_cut_hints), 0, 0
         # sparse_loss: the fused step hands the forward's tile-list offsets to the image loss, which then settles the
         # spans under empty tiles from the target alone (exact: the rasterizer writes the background colour there) and
         # leaves their gradient unwritten (the backward never reads it).  False: the loss reads both images everywhere.
@@ -367,6 +377,8 @@ class HipViewCompute:
             self.n_art = self.params["_xyz"].shape[0]
         self.grad_arena = None
         self._sh_dirty = True
+        self._cut_gen += 1          # rows were added / removed: the hints of the old model are dropped
+        self._cut_store.clear()
 
     def mark_params_changed(self):
         """The leaves were updated in place (optimizer step): derived storage copies are stale."""
@@ -452,7 +464,7 @@ class HipViewCompute:
         sums, g = self.ops.image_loss_grad(img, tgt, self.w_rgb, self.w_ssim, k, const, bg=bg, tile_start_ptr=ts)
         return sums[2], g
 
-    def _tile_start_ptr(self, ws, V, N, W, H):
+    def _layout(self, ws, V, N, W, H):
         key = (V, N, W, H, ws.cap)
         off = self._ts_off.get(key)
         if off is None:
@@ -460,8 +472,38 @@ class HipViewCompute:
             from ._lib import lib
             arr = (ctypes.c_size_t * 32)()
             lib().mgr_raster_layout(V, N, W, H, ws.cap, arr, 32)
-            off = self._ts_off[key] = int(arr[7])
-        return ws.buf.data_ptr() + off
+            off = self._ts_off[key] = [int(x) for x in arr]
+        return off
+
+    def _tile_start_ptr(self, ws, V, N, W, H):
+        return ws.buf.data_ptr() + self._layout(ws, V, N, W, H)[7]
+
+    def _cut_flag(self, ws, view_ids, V, N, W, H):
+        """debug bit 8 of mgr_views_forward for this forward on `ws`: set when the workspace holds the depth-cut hints of
+        exactly these views (left by the previous forward, or parked earlier and brought back here) and the last forward
+        with them was not flagged."""
+        if not self.depth_cut or not self.rz.context(self.device).fenced(self.sync_check):
+            return 0      # (with a host sync per forward the split forward would need a second one after the blend: not worth it)
+        key = (id(self), self._cut_gen, tuple(view_ids))
+        prev = ws.prev_hint_key
+        ws.hint_key = key
+        if prev != key:
+            T = ((W + 15) // 16) * ((H + 15) // 16)
+            off = self._layout(ws, V, N, W, H)[26]
+            region = ws.buf[off: off + 4 * V * T]
+            if prev is not None and prev[:2] == key[:2]:      # park the hints of the views rendered last
+                while len(self._cut_store) >= self._cut_max:
+                    self._cut_store.pop(next(iter(self._cut_store)))
+                self._cut_store[prev] = region.clone()
+            saved = self._cut_store.pop(key, None)
+            if saved is not None and saved.numel() == region.numel():
+                region.copy_(saved)
+            else:
+                region.zero_()                                              # no hints for these views yet
+        if ws.cut_block:                  # the previous forward was flagged: this one rebuilds the hints from full lists
+            ws.cut_block = False
+            return 0
+        return 8
 
     # -- fused path, direct C-ABI calls ------------------------------------------------------------
     def _step_direct(self, view_ids, scale, g_img=None):
@@ -506,14 +548,18 @@ class HipViewCompute:
         def fwd(ws, phase):
             check(lib().mgr_views_forward(V, N, B, na, sh_half, W, H, ptr(cams), ptr(bg), ptr(p["_xyz"]), ptr(p["_scaling"]),
                                           ptr(p["_rotation"]), ptr(op), ptr(p["_features_dc"]), ptr(f_rest),
-                                          ptr(w), ptr(T), ptr(out), ptr(radii), ptr(ws.buf), ws.nbytes, ws.cap, phase,
-                                          stream()), "mgr_views_forward")
+                                          ptr(w), ptr(T), ptr(out), ptr(radii), ptr(ws.buf), ws.nbytes, ws.cap,
+                                          phase | self._cut_bit, stream()), "mgr_views_forward")
 
         def launch(ws):
+            self._cut_bit = self._cut_flag(ws, view_ids, V, N, W, H)
             fwd(ws, 2 if overlap else 0)
 
-        ws, _ = self.rz.context(dev).forward(V, N, W, H, launch, sync_check=self.sync_check)
+        ctx = self.rz.context(dev)
+        ws, _ = ctx.forward(V, N, W, H, launch, sync_check=self.sync_check, defer_fence=True)
         try:
+            if not overlap and ctx.fenced(self.sync_check):
+                ctx.fence(ws)
             if overlap:
                 import ctypes
                 tgt = sel["targets"]
@@ -529,6 +575,8 @@ class HipViewCompute:
                     check(lib().mgr_image_loss_tiles_list(V, H, W, ptr(tgt), ptr(bg), ctypes.c_void_p(self._tile_start_ptr(ws, V, N, W, H)),
                                                           ptr(lws), nbytes, stream()), "mgr_image_loss_tiles_list")
                 fwd(ws, 4)                                  # the blend, next to the list
+                if ctx.fenced(self.sync_check):
+                    ctx.fence(ws)                           # (after the blend: it is the blend that raises the depth-cut flag)
                 cur.wait_stream(self._side)
                 lws.record_stream(self._side)
                 per_view = out[0].numel()

@@ -50,6 +50,10 @@ class RasterWorkspace:
         # zero-filled once: pair tags start at 0 = "never written"
         self.buf = torch.zeros(self.nbytes, dtype=torch.uint8, device=device)
         self.busy = False
+        # depth cut (mgr_views_forward, debug bit 8): whose views the per-tile hints in this workspace describe (set by
+        # the caller that opts in), and "the last forward with the cut was flagged: run the next one without it"
+        self.hint_key = self.prev_hint_key = None
+        self.cut_block = False
 
 
 def default_pair_capacity(V, N):
@@ -72,6 +76,7 @@ class RasterContext:
         self._fences = []        # (workspace, pinned int32[2], event) per unsynchronised forward, oldest first
         self._free_pinned = []
         self._evicted_overflow = False   # an overflow seen while retiring old fences: raised by the next poll()
+        self.cut_retries = 0             # forwards flagged MGR_OVF_CUT (each is answered by a forward without the depth cut)
 
     # -- pool ---------------------------------------------------------------------------------
     def acquire(self, V, N, W, H, min_cap):
@@ -98,19 +103,25 @@ class RasterContext:
         self.cap_hint[key] = max(self.cap_hint.get(key, 0), int(npairs * 1.25) + 4096)
 
     # -- forward driver -------------------------------------------------------------------------
-    def forward(self, V, N, W, H, launch, sync_check=True):
+    def forward(self, V, N, W, H, launch, sync_check=True, defer_fence=False):
         """Run `launch(ws)` (which enqueues one forward on the current stream) with a workspace large enough for
         the pairs it produces.  sync policy True: read the pair count back (one host sync, like upstream) and
         retry with a larger workspace on overflow; False: no host sync, an overflow fence is recorded instead
-        (`poll()` / `check_overflow()`).  Returns (workspace, pair count or None)."""
+        (`poll()` / `check_overflow()`).  Returns (workspace, pair count or None).  defer_fence: the caller records the
+        fence itself (`fence(ws)`) once everything that can raise a flag is queued -- a forward split at the blend raises
+        the depth-cut flag in its second half."""
         key = (V, N, W, H)
         cap = max(self.cap_hint.get(key, 0), default_pair_capacity(V, N))
         while True:
             ws = self.acquire(V, N, W, H, cap)
+            # whoever launches may claim the depth-cut hints of the forward before (prev_hint_key) and name the views of
+            # this one; a launch that does neither leaves hints nobody may use
+            ws.prev_hint_key, ws.hint_key = ws.hint_key, None
             launch(ws)
             self.last_ws = ws
             if not (sync_check and self.sync_every_forward):
-                self._fence(ws)
+                if not defer_fence:
+                    self._fence(ws)
                 return ws, None
             import ctypes
             npairs, ovf = ctypes.c_int64(0), ctypes.c_int32(0)
@@ -118,12 +129,24 @@ class RasterContext:
             if rc == 0:
                 self._learn(key, npairs.value)
                 return ws, int(npairs.value)
+            if rc == -6 and not (ovf.value & 1):   # MGR_ECUT: the depth-cut hints no longer fit; same workspace, no cut
+                ws.cut_block = True
+                self.cut_retries += 1
+                ws.busy = False
+                continue
             if rc != -4:
                 check(rc, "mgr_raster_status_sync")
             ws.busy = False  # overflow: retry with room for the observed count
             cap = int(npairs.value * 1.5) + 4096
 
     # -- overflow fences ------------------------------------------------------------------------
+    def fence(self, ws):
+        self._fence(ws)
+
+    def fenced(self, sync_check=True):
+        """True when forwards run without a host synchronisation (fences instead)."""
+        return not (sync_check and self.sync_every_forward)
+
     def _fence(self, ws):
         """Asynchronous copy of (pair count, overflow flag) to pinned host memory + an event right behind it: the
         host can later wait for THIS forward only, while the kernels queued after it keep the GPU busy."""
@@ -142,6 +165,9 @@ class RasterContext:
         npairs, ovf = int(pinned[0].item()) & 0xFFFFFFFF, int(pinned[1].item())
         self._free_pinned.append(pinned)
         self._learn(ws.key, npairs)
+        if ovf & 2:     # MGR_OVF_CUT: the caller re-runs the step; that forward must not use the hints
+            ws.cut_block = True
+            self.cut_retries += 1
         return npairs, ovf
 
     def poll(self):
@@ -154,7 +180,8 @@ class RasterContext:
             npairs, ovf = self._resolve(self._fences.pop(0))
             last, bad = npairs, bad or bool(ovf)
         if bad:
-            raise _lib.ManusHipError("rasterizer pair capacity exceeded (retry: the capacity hint was enlarged)")
+            raise _lib.ManusHipError("rasterizer forward incomplete: pair capacity exceeded or depth-cut hints outdated "
+                                     "(retry: the capacity hint was enlarged / the next forward runs without the cut)")
         return last
 
     def check_overflow(self):
@@ -168,6 +195,9 @@ class RasterContext:
         npairs, ovf = ctypes.c_int64(0), ctypes.c_int32(0)
         rc = lib().mgr_raster_status_sync(ptr(ws.buf), ctypes.byref(npairs), ctypes.byref(ovf), stream())
         self._learn(ws.key, npairs.value)
+        if rc == -6:
+            ws.cut_block = True
+            self.cut_retries += 1
         if rc != 0:
             check(rc, "rasterizer overflow check (retry: capacity hint was enlarged)")
         return int(npairs.value)

@@ -1,0 +1,184 @@
+"""GPU: the depth cut of the fused step (mgr_views_forward, debug bit 8; include/manus_hip.h).
+
+A forward leaves, per tile whose pixels all saturated, the depth in front of which they had stopped; the next forward of the
+same views drops the instances behind it from that tile's list.  What must hold:
+  * image, radii, loss and every leaf gradient are BIT FOR BIT those of the step without the cut, while the binning handles
+    fewer pairs;
+  * hints that no longer fit the scene (here: every opacity lowered, so that the walks go deeper) are detected -- the step is
+    flagged like a pair-capacity overflow -- and the re-run without the cut is exact again, as is the step after it;
+  * view sets that alternate keep their own hints;
+  * a Trainer with the cut follows the trajectory of one without it, through the optimizer steps that move the model under
+    the hints, a densification and an opacity reset.
+There is no reference counterpart (upstream re-bins everything every step); the parity bar is equality with our own
+uncut step, which the other GPU tests tie to the oracle."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+LEAVES = ("_xyz", "_scaling", "_rotation", "_opacity", "_features_dc", "_features_rest")
+
+
+def _scene(V=4, n=40000, W=256, H=192, seed=3):
+    from manus_amd.synthetic import camera_table, make_scene
+    # opaque, fairly large Gaussians on the hand, seen from close: the interior tiles saturate, the silhouette does not
+    sc = make_scene(n_gaussians=n, kind="hand", seed=seed, grid_res=32, n_cameras=V, width=W, height=H, cam_radius=0.45,
+                    sigma_range=(2e-3, 5e-3), device=DEV)
+    sc["params"]["_opacity"] = sc["params"]["_opacity"] + 2.0
+    g = torch.Generator().manual_seed(seed + 100)
+    targets = torch.rand((V, 3, H, W), generator=g).to(DEV)
+    return sc, targets, camera_table(sc["cameras"], DEV)
+
+
+def _compute(sc, targets, ct, cut):
+    from manus_amd.engine import HipViewCompute
+    return HipViewCompute(sc, targets, ct, loss="l1+ssim", depth_cut=cut)
+
+
+def _surviving_pairs(compute, V, N, W, H):
+    """Pairs the binning of the most recent forward put into the tile lists."""
+    from manus_amd import rasterizer
+    ws = rasterizer.context(DEV).last_ws
+    off = compute._layout(ws, V, N, W, H)
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    return int(ws.buf[off[7] + 4 * V * T: off[7] + 4 * V * T + 4].view(torch.int32).item())
+
+
+def _same(a, b):
+    assert torch.equal(a["loss"], b["loss"]), (float(a["loss"]), float(b["loss"]))
+    assert torch.equal(a["radii"], b["radii"])
+    for k in LEAVES:
+        assert torch.equal(a["grads"][k], b["grads"][k]), k
+    assert torch.equal(a["grad2d"], b["grad2d"]) and torch.equal(a["vis"], b["vis"])
+
+
+@pytest.fixture
+def fenced():
+    from manus_amd import rasterizer
+    ctx = rasterizer.context(DEV)
+    ctx.clear()
+    ctx.cut_retries = 0
+    rasterizer.set_sync_policy(True)
+    yield ctx
+    rasterizer.set_sync_policy(True)
+    ctx.clear()
+
+
+def _warm(compute, views):
+    """One step with host syncs (learns the pair capacity), then the fenced mode the cut needs."""
+    from manus_amd import rasterizer
+    compute(views)
+    rasterizer.check_overflow(DEV)
+    rasterizer.set_sync_policy(False, DEV)
+
+
+def test_cut_step_equals_the_full_step_and_bins_fewer_pairs(fenced):
+    from manus_amd import rasterizer
+    V, W, H = 4, 256, 192
+    sc, targets, ct = _scene(V=V, W=W, H=H)
+    N = sc["params"]["_xyz"].shape[0]
+    views = list(range(V))
+    ref = _compute(sc, targets, ct, cut=False)
+    _warm(ref, views)
+    want = ref(views)
+    img_want = ref.last_image.clone()
+    full = _surviving_pairs(ref, V, N, W, H)
+    rasterizer.check_overflow(DEV)
+
+    rasterizer.set_sync_policy(True, DEV)
+    cmp_ = _compute(sc, targets, ct, cut=True)
+    _warm(cmp_, views)
+    first = cmp_(views)                       # fenced, no hints of these views under this key yet: full lists
+    assert _surviving_pairs(cmp_, V, N, W, H) == full
+    _same(first, want)
+    for _ in range(3):                        # hints of the step before: cut lists, same results, and stable
+        got = cmp_(views)
+        cut = _surviving_pairs(cmp_, V, N, W, H)
+        _same(got, want)
+        assert torch.equal(cmp_.last_image, img_want)
+    assert rasterizer.check_overflow(DEV) > 0           # (returns the rectangle pair count; raises if a step was flagged)
+    assert fenced.cut_retries == 0
+    print("pairs in the lists: %d full, %d with the cut (%.2f)" % (full, cut, cut / full))
+    assert cut < 0.8 * full, (cut, full)
+
+
+def test_outdated_hints_are_flagged_and_the_rerun_is_exact(fenced):
+    from manus_amd import rasterizer
+    from manus_amd._lib import ManusHipError
+    V, W, H = 2, 256, 192
+    sc, targets, ct = _scene(V=V, W=W, H=H, seed=5)
+    views = list(range(V))
+    # the model the hints will be outdated for: every Gaussian far more transparent -> the walks need entries the cut removed
+    sc2 = dict(sc)
+    sc2["params"] = {k: (v - 4.0 if k == "_opacity" else v).detach().clone() for k, v in sc["params"].items()}
+    ref = _compute(sc2, targets, ct, cut=False)
+    _warm(ref, views)
+    want = ref(views)
+    rasterizer.check_overflow(DEV)
+    rasterizer.set_sync_policy(True, DEV)
+    cmp_ = _compute(sc, targets, ct, cut=True)
+    _warm(cmp_, views)
+    cmp_(views)
+    cmp_(views)
+    rasterizer.poll(DEV)
+    with torch.no_grad():
+        cmp_.params["_opacity"].sub_(4.0)      # the model changes under the hints
+    cmp_(views)                                # cut lists against the new model
+    with pytest.raises(ManusHipError):
+        rasterizer.poll(DEV)
+    assert fenced.cut_retries == 1
+    again = cmp_(views)                        # the re-run: no cut, fresh hints
+    rasterizer.poll(DEV)
+    _same(again, want)
+    nxt = cmp_(views)                          # and the step after it, on the fresh hints
+    rasterizer.poll(DEV)
+    _same(nxt, want)
+    assert fenced.cut_retries == 1
+
+
+def test_alternating_view_sets_keep_their_hints(fenced):
+    from manus_amd import rasterizer
+    V, W, H = 4, 256, 192
+    sc, targets, ct = _scene(V=V, W=W, H=H, seed=7)
+    N = sc["params"]["_xyz"].shape[0]
+    a, b = [0, 1], [2, 3]
+    ref = _compute(sc, targets, ct, cut=False)
+    _warm(ref, a)
+    want_a, want_b = ref(a), ref(b)
+    full_b = _surviving_pairs(ref, 2, N, W, H)
+    rasterizer.check_overflow(DEV)
+    rasterizer.set_sync_policy(True, DEV)
+    cmp_ = _compute(sc, targets, ct, cut=True)
+    _warm(cmp_, a)
+    for rnd in range(3):
+        _same(cmp_(a), want_a)
+        _same(cmp_(b), want_b)
+        pairs_b = _surviving_pairs(cmp_, 2, N, W, H)
+        assert (pairs_b == full_b) if rnd == 0 else (pairs_b < full_b), (rnd, pairs_b, full_b)
+    rasterizer.check_overflow(DEV)
+    assert fenced.cut_retries == 0
+
+
+def test_trainer_with_the_cut_follows_the_trainer_without(fenced):
+    from manus_amd.engine import Trainer
+    V, W, H = 3, 192, 128
+    out = {}
+    for cut in (False, True):
+        fenced.clear()
+        torch.manual_seed(0)
+        sc, targets, ct = _scene(V=V, n=12000, W=W, H=H, seed=11)
+        compute = _compute(sc, targets, ct, cut=cut)
+        opts = dict(densify_from_step=4, densification_interval=6, densify_until_step=1000, opacity_reset_interval=9,
+                    percent_dense=0.01, densify_grad_threshold=5e-5)
+        tr = Trainer(compute, V, extent=0.3, opts=opts, spatial_lr_scale=0.05, bg_white=False)
+        losses = []
+        for _ in range(14):
+            torch.manual_seed(100 + tr.global_step)          # the split noise of a densification
+            losses.append(float(tr.train_step()["loss"]))
+        out[cut] = (losses, tr.opt.N, {k: v.detach().clone() for k, v in tr.compute.params.items()}, tr.retries,
+                    fenced.cut_retries)
+    (l0, n0, p0, _, _), (l1, n1, p1, retries, flagged) = out[False], out[True]
+    print("losses", [round(x, 5) for x in l1], "N", n1, "re-run steps", retries, "flagged forwards", flagged)
+    assert n0 == n1 and l0 == l1
+    for k in LEAVES:
+        assert torch.equal(p0[k], p1[k]), k
