@@ -104,7 +104,7 @@ struct __attribute__((aligned(16))) MgrGRec {
 #define MGR_CHUNK 64         // list entries per backward work item / forward checkpoint interval (one batch of the blend waves)
 
 struct MgrLayout {
-    size_t header, scan_part, scan_cls, grec, depth, rect, alive, pair_off, tile_count, tile_start, tile_cursor, tile_done, tile_qdone,
+    size_t header, scan_part, scan_cls, scan_box, grec, depth, rect, alive, pair_off, tile_count, tile_start, tile_cursor, tile_done, tile_qdone,
         tile_zcut, tile_zused, tile_qend, tile_queue, tile_qrec, chunk_start, items, ckpt, keys, keys2, groups, sorted_gid, final_T, n_contrib, pair_tag, pair_grad, inst_grad, inst_tag,
         db_count, db_cursor, db_start, db_nvis, db_bbox, db_keys, db_order, db_rec, bin_mat, total;
 };
@@ -129,6 +129,7 @@ static inline MgrLayout mgr_layout(int V, int N, int W, int H, int64_t cap) {
     const size_t scan_blocks = (size_t)V * ((gx * gy + 1023) / 1024);      // the tile scan runs blocks of up to 1024 tiles of one view
     L.scan_part = o;   o += mgr_align((scan_blocks + 1) * 8);         // per-block (pairs, chunks) sums of the tile scan
     L.scan_cls = o;    o += mgr_align(scan_blocks * 34 * 4);          // per-block histogram of its tiles over the size classes
+    L.scan_box = o;    o += mgr_align(scan_blocks * 16);              // per-block bounding box of its non-empty tiles (x0, y0, x1, y1)
     L.grec = o;        o += mgr_align(VN * sizeof(MgrGRec));
     L.depth = o;       o += mgr_align(VN * 4);
     L.rect = o;        o += mgr_align(VN * 8);       // 4 x uint16
@@ -372,7 +373,12 @@ struct MgrCull {
     bool pd;
 };
 
+// (No fma contraction in the three functions below: the test is conservative either way, but its outcome for a tile at the
+// threshold must not depend on the loop it was inlined into -- the per-instance kernel has two forms of its cull loop, and a
+// null pair listed by one and not by the other shifts the list positions behind it, hence the backward's chunk boundaries
+// and its rounding.)
 __device__ __forceinline__ MgrCull mgr_cull_init(float cx, float cy, float A, float B, float C, float qmax) {
+#pragma clang fp contract(off)
     MgrCull c;
     c.cx = cx; c.cy = cy; c.A = A; c.B = B; c.C = C;
     c.pd = A > 0.0f && C > 0.0f && A * C - B * B > 0.0f;
@@ -384,12 +390,14 @@ __device__ __forceinline__ MgrCull mgr_cull_init(float cx, float cy, float A, fl
 
 // row part: dy range of the box and the x of the row-constrained minimum
 __device__ __forceinline__ void mgr_cull_row(const MgrCull& c, float y0, float y1, float& dy_lo, float& dy_hi, float& dxo) {
+#pragma clang fp contract(off)
     dy_lo = y0 - c.cy;
     dy_hi = y1 - c.cy;
     dxo = c.nBiA * __builtin_amdgcn_fmed3f(0.0f, dy_lo, dy_hi);
 }
 
 __device__ __forceinline__ bool mgr_cull_dead(const MgrCull& c, float dy_lo, float dy_hi, float dxo, float x0, float x1) {
+#pragma clang fp contract(off)
     const float dxe = __builtin_amdgcn_fmed3f(dxo, x0 - c.cx, x1 - c.cx);
     const float dye = __builtin_amdgcn_fmed3f(c.nBiC * dxe, dy_lo, dy_hi);
     const float t0 = c.A * dxe * dxe, t1 = 2.0f * c.B * dxe * dye, t2 = c.C * dye * dye;

@@ -143,6 +143,16 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t val, uint32_t* s_wa
 #define PRE_THREADS 512
 #define EMIT_THREADS 1024
 
+__device__ __forceinline__ uint32_t db_bucket(float z) {
+    const uint32_t b = __float_as_uint(z) >> 13, b0 = 0x3E4CCCCDu >> 13;   // 0.2f
+    return b > b0 ? min(b - b0, (uint32_t)MGR_DB_BUCKETS - 1u) : 0u;
+}
+// an instance takes part when it has at least one non-null tile
+__device__ __forceinline__ bool db_takes_part(int radius, ushort4 rc, unsigned long long am) {
+    const uint32_t tiles = (uint32_t)((rc.z - rc.x) * (rc.w - rc.y));
+    return radius > 0 && tiles > 0u && (tiles > 64u || am != 0ull);
+}
+
 // Shared tail of the per-instance forward kernels: per-tile histogram over the NON-NULL tiles of
 // the rectangle (exact culling, mgr_box_dead; the mask is stored so that k_emit makes the
 // identical decision; rectangles of more than 64 tiles are not culled), pair-slot offsets
@@ -400,6 +410,133 @@ __device__ __forceinline__ uint32_t mgr_queue_key(uint32_t count, uint32_t prev_
     return (use_hint && count && prev_done) ? min(count, prev_done) : count;
 }
 
+#define DB_PER 8   // instances per thread of the bucket scatter (one LDS histogram flush per 8192 instances)
+// The depth-bucket kernels ride in other launches where they can: the count (8192 instances of one view per workgroup)
+// behind the workgroups of tile-scan phase A, the bucket scan (one workgroup per view) behind those of phase B -- each
+// depends on the launch before only, and as launches of their own they cost 20 + 15 us for a few microseconds of work.
+// (Counting the buckets with global atomics from the per-instance kernel instead was measured: the hand's instances fall
+// into ~200 buckets per view and k_inst_fwd went from 0.17 to 0.36 ms.)
+__device__ __forceinline__ void dbin_count_block(int bx, int v, int N, const int32_t* __restrict__ radii,
+                                                 const float* __restrict__ depth, const ushort4* __restrict__ rect,
+                                                 const unsigned long long* __restrict__ alive, uint32_t* __restrict__ db_count,
+                                                 uint32_t* s_hist /*MGR_DB_BUCKETS*/) {
+    const int tid = threadIdx.x;
+    for (int k = tid; k < MGR_DB_BUCKETS; k += 1024) s_hist[k] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < DB_PER; ++r) {
+        const int i = (bx * DB_PER + r) * 1024 + tid;
+        if (i < N) {
+            const size_t vi = (size_t)v * N + i;
+            if (db_takes_part(radii[vi], rect[vi], alive[vi])) atomicAdd(&s_hist[db_bucket(depth[vi])], 1u);
+        }
+    }
+    __syncthreads();
+    for (int k = tid; k < MGR_DB_BUCKETS; k += 1024) {
+        const uint32_t c = s_hist[k];
+        if (c) atomicAdd(&db_count[(size_t)v * MGR_DB_BUCKETS + k], c);
+    }
+}
+
+// One workgroup per view (extra workgroups of the k_tile_scan_b launch): bucket offsets inside the view's segment, the
+// number of participating instances (the counters are consumed: left zero for the next forward), and the bounding box of the
+// view's non-empty tiles (from the boxes phase A left per block of tiles).
+__device__ __forceinline__ void dbin_scan_block(int v, int nbT, const uint4* __restrict__ blk_box,
+                                                uint32_t* __restrict__ db_count, uint32_t* __restrict__ db_cursor,
+                                                uint32_t* __restrict__ db_start, uint32_t* __restrict__ db_nvis,
+                                                ushort4* __restrict__ db_bbox, uint32_t* s_scan /*32*/, uint32_t* s_box /*4*/) {
+    const int tid = threadIdx.x;
+    if (tid == 0) { s_box[0] = 0xFFFFu; s_box[1] = 0xFFFFu; s_box[2] = 0u; s_box[3] = 0u; }
+    constexpr int PER = MGR_DB_BUCKETS / 1024;
+    uint32_t c[PER], sum = 0;
+    uint32_t* cnt = db_count + (size_t)v * MGR_DB_BUCKETS + tid * PER;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) { c[k] = cnt[k]; sum += c[k]; cnt[k] = 0; }
+    uint32_t total;
+    uint32_t run = block_excl_scan(sum, s_scan, total);   // (contains the barrier that publishes s_box)
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        db_start[(size_t)v * (MGR_DB_BUCKETS + 1) + tid * PER + k] = run;
+        db_cursor[(size_t)v * MGR_DB_BUCKETS + tid * PER + k] = 0;
+        run += c[k];
+    }
+    uint32_t x0 = 0xFFFFu, y0 = 0xFFFFu, x1 = 0u, y1 = 0u;
+    if (tid < nbT) {
+        const uint4 bb = blk_box[(size_t)v * nbT + tid];
+        x0 = bb.x; y0 = bb.y; x1 = bb.z; y1 = bb.w;
+    }
+    if (x1 > 0u) { atomicMin(&s_box[0], x0); atomicMin(&s_box[1], y0); atomicMax(&s_box[2], x1); atomicMax(&s_box[3], y1); }
+    __syncthreads();
+    if (tid == 0) {
+        db_start[(size_t)v * (MGR_DB_BUCKETS + 1) + MGR_DB_BUCKETS] = total;
+        db_nvis[v] = total;
+        const bool any = s_box[2] > 0u;   // box = (x0, y0, width, height); empty view: 0 x 0
+        db_bbox[v] = any ? make_ushort4((unsigned short)s_box[0], (unsigned short)s_box[1], (unsigned short)(s_box[2] - s_box[0]),
+                                        (unsigned short)(s_box[3] - s_box[1]))
+                         : make_ushort4(0, 0, 0, 0);
+    }
+}
+
+// 8192 instances of one view per workgroup (extra workgroups of the k_tile_scan_b launch): keys into their depth buckets.
+__device__ __forceinline__ void dbin_scatter_block(int bx, int v, int N, const int32_t* __restrict__ radii,
+                                                   const float* __restrict__ depth, const ushort4* __restrict__ rect,
+                                                   const unsigned long long* __restrict__ alive,
+                                                   const uint32_t* __restrict__ db_start, uint32_t* __restrict__ db_cursor,
+                                                   unsigned long long* __restrict__ db_keys, uint32_t* s_hist /*MGR_DB_BUCKETS*/) {
+    const int tid = threadIdx.x;
+    for (int k = tid; k < MGR_DB_BUCKETS; k += 1024) s_hist[k] = 0;
+    __syncthreads();
+    float z[DB_PER];
+    uint32_t on = 0;
+#pragma unroll
+    for (int r = 0; r < DB_PER; ++r) {
+        const int i = (bx * DB_PER + r) * 1024 + tid;
+        z[r] = 0.f;
+        if (i < N) {
+            const size_t vi = (size_t)v * N + i;
+            z[r] = depth[vi];
+            if (db_takes_part(radii[vi], rect[vi], alive[vi])) {
+                on |= 1u << r;
+                atomicAdd(&s_hist[db_bucket(z[r])], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (int k = tid; k < MGR_DB_BUCKETS; k += 1024) {
+        const uint32_t c = s_hist[k];
+        if (c) s_hist[k] = db_start[(size_t)v * (MGR_DB_BUCKETS + 1) + k] + atomicAdd(&db_cursor[(size_t)v * MGR_DB_BUCKETS + k], c);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < DB_PER; ++r) {
+        if ((on >> r) & 1u) {
+            const int i = (bx * DB_PER + r) * 1024 + tid;
+            const uint32_t pos = atomicAdd(&s_hist[db_bucket(z[r])], 1u);
+            db_keys[(size_t)v * N + pos] = ((unsigned long long)__float_as_uint(z[r]) << 32) | (unsigned)i;
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_dbin_scatter(int N, const int32_t* __restrict__ radii,
+                                                       const float* __restrict__ depth, const ushort4* __restrict__ rect,
+                                                       const unsigned long long* __restrict__ alive,
+                                                       const uint32_t* __restrict__ db_start, uint32_t* __restrict__ db_cursor,
+                                                       unsigned long long* __restrict__ db_keys) {
+    __shared__ uint32_t s_hist[MGR_DB_BUCKETS];
+    dbin_scatter_block((int)blockIdx.x, (int)blockIdx.y, N, radii, depth, rect, alive, db_start, db_cursor, db_keys, s_hist);
+}
+
+struct DbinArgs {   // depth-bucket side of the two tile-scan launches (ordered binning); db_count == nullptr: none
+    int N, n_bx;
+    const int32_t* radii;
+    const float* depth;
+    const ushort4* rect;
+    const unsigned long long* alive;
+    uint32_t *db_count, *db_cursor, *db_start, *db_nvis;
+    ushort4* db_bbox;
+    unsigned long long* db_keys;
+};
+
 #define MGR_HOLE 0xFFFFFFFEu   // a position of the view-interleaved queue its view has no tile for
 #define MGR_NCLS 34
 
@@ -409,10 +546,19 @@ __device__ __forceinline__ uint32_t mgr_queue_key(uint32_t count, uint32_t prev_
 // global atomics nor counters that somebody has to clear.
 __global__ __launch_bounds__(1024) void k_tile_scan_a(int T, int nbT, const uint32_t* __restrict__ tile_count,
                                                       const uint32_t* __restrict__ tile_done, int use_hint,
-                                                      uint2* __restrict__ part, uint32_t* __restrict__ blk_cls) {
+                                                      uint2* __restrict__ part, uint32_t* __restrict__ blk_cls,
+                                                      uint4* __restrict__ blk_box, int gx, int n_scan_blocks, DbinArgs db) {
+    __shared__ uint32_t s_dbh[MGR_DB_BUCKETS];
+    if ((int)blockIdx.x >= n_scan_blocks) {   // the workgroups behind the scan's: depth buckets of 8192 instances of one view
+        const int b2 = (int)blockIdx.x - n_scan_blocks;
+        dbin_count_block(b2 % db.n_bx, b2 / db.n_bx, db.N, db.radii, db.depth, db.rect, db.alive, db.db_count, s_dbh);
+        return;
+    }
     __shared__ uint32_t s_scan[32];
     __shared__ uint32_t s_cls[MGR_NCLS];
+    __shared__ uint32_t s_bb[4];
     const int tid = threadIdx.x, v = blockIdx.x / nbT, t = (blockIdx.x % nbT) * 1024 + tid;
+    if (tid == 0) { s_bb[0] = 0xFFFFu; s_bb[1] = 0xFFFFu; s_bb[2] = 0u; s_bb[3] = 0u; }
     const bool valid = t < T;
     const size_t k = (size_t)v * T + t;
     if (tid < MGR_NCLS) s_cls[tid] = 0;
@@ -420,11 +566,16 @@ __global__ __launch_bounds__(1024) void k_tile_scan_a(int T, int nbT, const uint
     const uint32_t c = valid ? tile_count[k] : 0u;
     const uint32_t key = mgr_queue_key(c, valid ? tile_done[k] : 0u, use_hint);
     if (valid) atomicAdd(&s_cls[key ? 32 - __clz(key) : 0], 1u);
+    if (c) {   // bounding box of the block's non-empty tiles (one wave-level step, then four LDS atomics per wave)
+        const uint32_t y = (uint32_t)t / (uint32_t)gx, x = (uint32_t)t - y * (uint32_t)gx;
+        atomicMin(&s_bb[0], x); atomicMin(&s_bb[1], y); atomicMax(&s_bb[2], x + 1u); atomicMax(&s_bb[3], y + 1u);
+    }
     uint32_t total, ctotal;
     (void)block_excl_scan(c, s_scan, total);
     (void)block_excl_scan(c ? (c - 1) / MGR_CHUNK : 0u, s_scan, ctotal);
     if (tid == 0) part[blockIdx.x] = make_uint2(total, ctotal);
     if (tid < MGR_NCLS) blk_cls[(size_t)blockIdx.x * MGR_NCLS + tid] = s_cls[tid];
+    if (tid == 0) blk_box[blockIdx.x] = make_uint4(s_bb[0], s_bb[1], s_bb[2], s_bb[3]);   // (behind the scans' barriers)
 }
 
 // Phase B: every block re-derives its bases from the block sums and block histograms, writes tile_start / chunk_start,
@@ -447,8 +598,14 @@ __global__ __launch_bounds__(1024) void k_tile_scan_b(int V, int T, int nbT, uin
                                                       uint32_t* __restrict__ chunk_start, MgrHeader* hdr,
                                                       uint32_t cap, uint32_t* __restrict__ tile_zcut,
                                                       uint32_t* __restrict__ tile_zused, uint32_t* __restrict__ tile_qend,
-                                                      int use_cut) {
+                                                      int use_cut, const uint4* __restrict__ blk_box, DbinArgs db) {
     __shared__ uint32_t s_scan[32];
+    if ((int)blockIdx.x >= V * nbT) {   // the workgroups behind the scan's: one per view, depth-bucket offsets + tile box
+        __shared__ uint32_t s_box[4];
+        dbin_scan_block((int)blockIdx.x - V * nbT, nbT, blk_box, db.db_count, db.db_cursor, db.db_start, db.db_nvis, db.db_bbox,
+                        s_scan, s_box);
+        return;
+    }
     __shared__ uint32_t s_gtot[MGR_NCLS], s_gpre[MGR_NCLS], s_vtot[MGR_NCLS], s_vpre[MGR_NCLS];   // tiles per class: all / in front of this block, of all views / of this view
     __shared__ uint32_t s_gbase[MGR_NCLS], s_vbase[MGR_NCLS], s_lc[MGR_NCLS];
     __shared__ uint32_t s_base[2], s_tot[2], s_maxnb, s_nbv;
@@ -508,8 +665,12 @@ __global__ __launch_bounds__(1024) void k_tile_scan_b(int V, int T, int nbT, uin
         tile_cursor[k] = 0;
         // depth cut: what this forward applied to the tile moves to tile_zused (the blend's check, k_fwd_items), the hint
         // itself is consumed -- k_fwd_items writes the next one for the tiles that have a list
-        tile_zused[k] = use_cut ? tile_zcut[k] : 0u;
+        const uint32_t zu = use_cut ? tile_zcut[k] : 0u;
+        tile_zused[k] = zu;
         tile_zcut[k] = 0u;
+        // a tile that had a hint saturated in the forward that left it; if nothing at all is listed for it now, the cut may
+        // have taken everything the tile should show and no walk will ever notice: flag it here
+        if (zu != 0u && c == 0u) atomicOr(&hdr->overflow, MGR_OVF_CUT);
         tile_qend[k] = 0u;
         const uint32_t rank = atomicAdd(&s_lc[cls], 1u);
         tile_queue[s_gbase[cls] + s_gpre[cls] + rank] = (uint32_t)k;
@@ -524,7 +685,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan_b(int V, int T, int nbT, uin
     if (b == 0 && tid == 0) {
         tile_start[(size_t)V * T] = s_tot[0];
         chunk_start[(size_t)V * T] = s_tot[1];
-        hdr->overflow = (s_tot[0] > cap || hdr->total_pairs > cap) ? MGR_OVF_PAIRS : 0u;
+        if (s_tot[0] > cap || hdr->total_pairs > cap) atomicOr(&hdr->overflow, MGR_OVF_PAIRS);   // (zeroed when the forward started)
         hdr->n_items = 0;
         hdr->item_head = 0;
         hdr->queue_len = s_gbase[0];     // class 0 (empty tiles) starts after all non-empty ones
@@ -1026,7 +1187,8 @@ __global__ __launch_bounds__(256) void k_tile_sort_small(
 // Every tile list must come out in (depth, Gaussian index) order.  The per-tile sorts order ~R = 5.4 N
 // pairs per view; here the N instances of a view are sorted ONCE by (depth, index) and the pairs are then
 // *generated in that order*, so that no list needs sorting:
-//   1. k_dbin_count / k_dbin_scan / k_dbin_scatter: instances -> 8192 monotone depth buckets per view
+//   1. depth buckets: instances -> 8192 monotone depth buckets per view (counted by the per-instance forward kernel, scanned
+//      and scattered by extra workgroups of the two tile-scan launches: pre_tail, dbin_scan_block, dbin_scatter_block)
 //      (float bits of z >> 13: 1024 buckets per octave above the 0.2 cull plane);
 //   2. k_dbin_sort: LDS radix sorts (lds_sort_emit) of runs of whole buckets, about DB_CHUNK keys each -> db_order;
 //   3. k_bin_count: per block of MGR_BIN_BLOCK depth-consecutive instances, the pairs per tile (LDS
@@ -1039,129 +1201,6 @@ __global__ __launch_bounds__(256) void k_tile_sort_small(
 //      of at most 16 tiles share a step (16 lanes each, their LDS adds issued one instance after the other).
 // The result is bit-identical to the sorted route (unique keys: there is one correct order).
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t db_bucket(float z) {
-    const uint32_t b = __float_as_uint(z) >> 13, b0 = 0x3E4CCCCDu >> 13;   // 0.2f
-    return b > b0 ? min(b - b0, (uint32_t)MGR_DB_BUCKETS - 1u) : 0u;
-}
-// an instance takes part when it has at least one non-null tile
-__device__ __forceinline__ bool db_takes_part(int radius, ushort4 rc, unsigned long long am) {
-    const uint32_t tiles = (uint32_t)((rc.z - rc.x) * (rc.w - rc.y));
-    return radius > 0 && tiles > 0u && (tiles > 64u || am != 0ull);
-}
-
-#define DB_PER 8   // instances per thread of the bucket count / scatter kernels (one LDS histogram flush per 8192 instances)
-__global__ __launch_bounds__(1024) void k_dbin_count(int N, const int32_t* __restrict__ radii,
-                                                     const float* __restrict__ depth, const ushort4* __restrict__ rect,
-                                                     const unsigned long long* __restrict__ alive,
-                                                     uint32_t* __restrict__ db_count) {
-    __shared__ uint32_t s_hist[MGR_DB_BUCKETS];
-    const int v = blockIdx.y, tid = threadIdx.x;
-    for (int k = tid; k < MGR_DB_BUCKETS; k += 1024) s_hist[k] = 0;
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < DB_PER; ++r) {
-        const int i = (blockIdx.x * DB_PER + r) * 1024 + tid;
-        if (i < N) {
-            const size_t vi = (size_t)v * N + i;
-            if (db_takes_part(radii[vi], rect[vi], alive[vi])) atomicAdd(&s_hist[db_bucket(depth[vi])], 1u);
-        }
-    }
-    __syncthreads();
-    for (int k = tid; k < MGR_DB_BUCKETS; k += 1024) {
-        const uint32_t c = s_hist[k];
-        if (c) atomicAdd(&db_count[(size_t)v * MGR_DB_BUCKETS + k], c);
-    }
-}
-
-// one workgroup per view: bucket offsets inside the view's segment, the number of participating instances (the
-// counters are consumed: left zero for the next forward), and the bounding box of the view's non-empty tiles
-__global__ __launch_bounds__(1024) void k_dbin_scan(int gx, int T, const uint32_t* __restrict__ tile_start,
-                                                    uint32_t* __restrict__ db_count, uint32_t* __restrict__ db_cursor,
-                                                    uint32_t* __restrict__ db_start, uint32_t* __restrict__ db_nvis,
-                                                    ushort4* __restrict__ db_bbox) {
-    __shared__ uint32_t s_scan[32];
-    __shared__ uint32_t s_box[4];
-    const int v = blockIdx.x, tid = threadIdx.x;
-    if (tid == 0) { s_box[0] = 0xFFFFu; s_box[1] = 0xFFFFu; s_box[2] = 0u; s_box[3] = 0u; }
-    constexpr int PER = MGR_DB_BUCKETS / 1024;
-    uint32_t c[PER], sum = 0;
-    uint32_t* cnt = db_count + (size_t)v * MGR_DB_BUCKETS + tid * PER;
-#pragma unroll
-    for (int k = 0; k < PER; ++k) { c[k] = cnt[k]; sum += c[k]; cnt[k] = 0; }
-    uint32_t total;
-    uint32_t run = block_excl_scan(sum, s_scan, total);   // (contains the barrier that publishes s_box)
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        db_start[(size_t)v * (MGR_DB_BUCKETS + 1) + tid * PER + k] = run;
-        db_cursor[(size_t)v * MGR_DB_BUCKETS + tid * PER + k] = 0;
-        run += c[k];
-    }
-    uint32_t x0 = 0xFFFFu, y0 = 0xFFFFu, x1 = 0u, y1 = 0u;
-    for (int t0 = tid * 8; t0 < T; t0 += 8192) {   // eight consecutive tiles per thread: nine loads in flight, one round trip
-        uint32_t ts[9];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) ts[k] = tile_start[(size_t)v * T + min(t0 + k, T)];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int t = t0 + k;
-            if (t < T && ts[k + 1] > ts[k]) {
-                const uint32_t y = (uint32_t)t / (uint32_t)gx, x = (uint32_t)t - y * (uint32_t)gx;
-                x0 = min(x0, x); y0 = min(y0, y); x1 = max(x1, x + 1); y1 = max(y1, y + 1);
-            }
-        }
-    }
-    if (x1 > 0u) { atomicMin(&s_box[0], x0); atomicMin(&s_box[1], y0); atomicMax(&s_box[2], x1); atomicMax(&s_box[3], y1); }
-    __syncthreads();
-    if (tid == 0) {
-        db_start[(size_t)v * (MGR_DB_BUCKETS + 1) + MGR_DB_BUCKETS] = total;
-        db_nvis[v] = total;
-        const bool any = s_box[2] > 0u;   // box = (x0, y0, width, height); empty view: 0 x 0
-        db_bbox[v] = any ? make_ushort4((unsigned short)s_box[0], (unsigned short)s_box[1], (unsigned short)(s_box[2] - s_box[0]),
-                                        (unsigned short)(s_box[3] - s_box[1]))
-                         : make_ushort4(0, 0, 0, 0);
-    }
-}
-
-__global__ __launch_bounds__(1024) void k_dbin_scatter(int N, const int32_t* __restrict__ radii,
-                                                       const float* __restrict__ depth, const ushort4* __restrict__ rect,
-                                                       const unsigned long long* __restrict__ alive,
-                                                       const uint32_t* __restrict__ db_start, uint32_t* __restrict__ db_cursor,
-                                                       unsigned long long* __restrict__ db_keys) {
-    __shared__ uint32_t s_hist[MGR_DB_BUCKETS];
-    const int v = blockIdx.y, tid = threadIdx.x;
-    for (int k = tid; k < MGR_DB_BUCKETS; k += 1024) s_hist[k] = 0;
-    __syncthreads();
-    float z[DB_PER];
-    uint32_t on = 0;
-#pragma unroll
-    for (int r = 0; r < DB_PER; ++r) {
-        const int i = (blockIdx.x * DB_PER + r) * 1024 + tid;
-        z[r] = 0.f;
-        if (i < N) {
-            const size_t vi = (size_t)v * N + i;
-            z[r] = depth[vi];
-            if (db_takes_part(radii[vi], rect[vi], alive[vi])) {
-                on |= 1u << r;
-                atomicAdd(&s_hist[db_bucket(z[r])], 1u);
-            }
-        }
-    }
-    __syncthreads();
-    for (int k = tid; k < MGR_DB_BUCKETS; k += 1024) {
-        const uint32_t c = s_hist[k];
-        if (c) s_hist[k] = db_start[(size_t)v * (MGR_DB_BUCKETS + 1) + k] + atomicAdd(&db_cursor[(size_t)v * MGR_DB_BUCKETS + k], c);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < DB_PER; ++r) {
-        if ((on >> r) & 1u) {
-            const int i = (blockIdx.x * DB_PER + r) * 1024 + tid;
-            const uint32_t pos = atomicAdd(&s_hist[db_bucket(z[r])], 1u);
-            db_keys[(size_t)v * N + pos] = ((unsigned long long)__float_as_uint(z[r]) << 32) | (unsigned)i;
-        }
-    }
-}
-
 // Sort the bucketed keys.  Item (view, c) takes the buckets whose first key lies in [c, c + 1) * DB_CHUNK of the view's
 // segment: whole buckets, about DB_CHUNK keys, every bucket in exactly one item.  One LDS sort when that is at most
 // SORT_LDS_KEYS keys; bucket by bucket otherwise; a single bucket beyond SORT_LDS_KEYS (all Gaussians in one depth
@@ -2198,21 +2237,27 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
         uint2* part = (uint2*)(ws + L.scan_part);
         uint32_t* blk_cls = (uint32_t*)(ws + L.scan_cls);
         const int use_hint = ordered ? 1 : 0;
-        { MGR_PROF("k_tile_scan_a", stream); hipLaunchKernelGGL(k_tile_scan_a, dim3(nblk), dim3(1024), 0, stream, T, nbT, tile_count,
-                           (const uint32_t*)(ws + L.tile_done), use_hint, part, blk_cls); }
-        { MGR_PROF("k_tile_scan_b", stream); hipLaunchKernelGGL(k_tile_scan_b, dim3(nblk), dim3(1024), 0, stream, V, T, nbT, tile_count, part, (const uint32_t*)blk_cls,
+        // ordered binning: the depth-bucket count rides behind the workgroups of scan phase A, the bucket scan behind those
+        // of phase B (dbin_count_block / dbin_scan_block)
+        const bool dbin = ordered && N > 0;
+        const int n_bx = (N + 1024 * DB_PER - 1) / (1024 * DB_PER);
+        uint4* blk_box = (uint4*)(ws + L.scan_box);
+        const DbinArgs dba = {N, n_bx, (const int32_t*)radii, (const float*)(ws + L.depth), (const ushort4*)(ws + L.rect),
+                              (const unsigned long long*)(ws + L.alive), dbin ? (uint32_t*)(ws + L.db_count) : nullptr,
+                              (uint32_t*)(ws + L.db_cursor), (uint32_t*)(ws + L.db_start), (uint32_t*)(ws + L.db_nvis),
+                              (ushort4*)(ws + L.db_bbox), (unsigned long long*)(ws + L.db_keys)};
+        { MGR_PROF("k_tile_scan_a", stream); hipLaunchKernelGGL(k_tile_scan_a, dim3(nblk + (dbin ? n_bx * V : 0)), dim3(1024), 0, stream, T, nbT, tile_count,
+                           (const uint32_t*)(ws + L.tile_done), use_hint, part, blk_cls, blk_box, gx, nblk, dba); }
+        { MGR_PROF("k_tile_scan_b", stream); hipLaunchKernelGGL(k_tile_scan_b, dim3(nblk + (dbin ? V : 0)), dim3(1024), 0, stream, V, T, nbT, tile_count, part, (const uint32_t*)blk_cls,
                            tile_start, (uint32_t*)(ws + L.tile_cursor), (uint32_t*)(ws + L.tile_queue), (uint4*)(ws + L.tile_qrec),
                            (const uint32_t*)(ws + L.tile_done), use_hint, (uint32_t*)(ws + L.chunk_start), hdr, (uint32_t)cap,
-                           (uint32_t*)(ws + L.tile_zcut), (uint32_t*)(ws + L.tile_zused), (uint32_t*)(ws + L.tile_qend), use_cut ? 1 : 0); }
+                           (uint32_t*)(ws + L.tile_zcut), (uint32_t*)(ws + L.tile_zused), (uint32_t*)(ws + L.tile_qend), use_cut ? 1 : 0, (const uint4*)blk_box, dba); }
     }
     MGR_LAUNCH_CHECK("k_tile_scan", stream, debug);
     if (N > 0 && ordered) {
         const int bb = mgr_bin_block(V, N), nblk = (N + bb - 1) / bb;
-        const float* depth = (const float*)(ws + L.depth);
         const ushort4* rect = (const ushort4*)(ws + L.rect);
         const unsigned long long* alive = (const unsigned long long*)(ws + L.alive);
-        uint32_t* db_count = (uint32_t*)(ws + L.db_count);
-        uint32_t* db_cursor = (uint32_t*)(ws + L.db_cursor);
         uint32_t* db_start = (uint32_t*)(ws + L.db_start);
         uint32_t* db_nvis = (uint32_t*)(ws + L.db_nvis);
         unsigned long long* db_keys = (unsigned long long*)(ws + L.db_keys);
@@ -2223,11 +2268,8 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
         const dim3 grid_n((N + 1024 * DB_PER - 1) / (1024 * DB_PER), V), grid_b(nblk, V);
         const int chunk = bb == MGR_BIN_BLOCK ? DB_CHUNK : 1024, chunks = (N + chunk - 1) / chunk;
         const size_t rec_bytes = BIN_SC_FIXED_BYTES;
-        { MGR_PROF("k_dbin_count", stream); hipLaunchKernelGGL(k_dbin_count, grid_n, dim3(1024), 0, stream, N, (const int32_t*)radii, depth, rect, alive, db_count); }
-        { MGR_PROF("k_dbin_scan", stream); hipLaunchKernelGGL(k_dbin_scan, dim3(V), dim3(1024), 0, stream, gx, T, (const uint32_t*)tile_start, db_count, db_cursor,
-                           db_start, db_nvis, db_bbox); }
-        { MGR_PROF("k_dbin_scatter", stream); hipLaunchKernelGGL(k_dbin_scatter, grid_n, dim3(1024), 0, stream, N, (const int32_t*)radii, depth, rect, alive,
-                           (const uint32_t*)db_start, db_cursor, db_keys); }
+        { MGR_PROF("k_dbin_scatter", stream); hipLaunchKernelGGL(k_dbin_scatter, grid_n, dim3(1024), 0, stream, N, (const int32_t*)radii, (const float*)(ws + L.depth), rect, alive,
+                           (const uint32_t*)db_start, (uint32_t*)(ws + L.db_cursor), db_keys); }
         { MGR_PROF("k_dbin_sort", stream); hipLaunchKernelGGL(k_dbin_sort, dim3(1024), dim3(RS_THREADS), SORT_LDS_KEYS * 8 + RS_WAVES * 256 * 4 + 256, stream,
                            N, chunk, chunks, V * chunks, (const uint32_t*)db_start, (const uint32_t*)db_nvis, db_keys, db_order); }
         MGR_LAUNCH_CHECK("k_dbin_sort", stream, debug);

@@ -179,6 +179,7 @@ def test_trainer_with_the_cut_follows_the_trainer_without(fenced):
                     fenced.cut_retries)
     (l0, n0, p0, _, _), (l1, n1, p1, retries, flagged) = out[False], out[True]
     print("losses", [round(x, 5) for x in l1], "N", n1, "re-run steps", retries, "flagged forwards", flagged)
-    assert n0 == n1 and l0 == l1
-    for k in LEAVES:
-        assert torch.equal(p0[k], p1[k]), k
+    assert n0 == n1 and l0 == l1, (n0, n1, [(i, a, b) for i, (a, b) in enumerate(zip(l0, l1)) if a != b][:3], out[False][3:])
+    for k in LEAVES:      # bit patterns: a Gaussian that left the skin-weight grid carries NaN (like the reference), NaN != NaN
+        d = p0[k].view(torch.int32) != p1[k].view(torch.int32)
+        assert not bool(d.any()), (k, int(d.sum()), p0[k][d][:4], p1[k][d][:4])

@@ -17,7 +17,7 @@ def layout(V, N, W, H, cap):
     n = lib().mgr_raster_layout(V, N, W, H, cap, arr, 32)
     names = ["header", "grec", "depth", "rect", "alive", "pair_off", "tile_count", "tile_start", "tile_cursor", "tile_done",
              "tile_queue", "chunk_start", "items", "ckpt", "keys", "sorted_gid", "final_T", "n_contrib", "pair_tag",
-             "pair_grad", "total", "inst_grad", "inst_tag", "db_nvis", "db_bbox", "db_order"]
+             "pair_grad", "total", "inst_grad", "inst_tag", "db_nvis", "db_bbox", "db_order", "tile_zcut", "tile_zused", "tile_qend"]
     assert n == len(names)
     return dict(zip(names, [int(x) for x in arr[:n]]))
 
