@@ -80,8 +80,10 @@ enum {
     MGR_ENOMEM = -2,   /* workspace too small (see mgr_raster_workspace_bytes) */
     MGR_EHIP = -3,     /* a HIP call failed; text in mgr_last_error() */
     MGR_EOVERFLOW = -4, /* pair capacity exceeded (reported by mgr_raster_status_sync) */
-    MGR_ECUT = -6       /* a forward run with the depth cut (debug bit 8) met a scene its hints no longer fit: its image is
+    MGR_ECUT = -6,      /* a forward run with the depth cut (debug bit 8) met a scene its hints no longer fit: its image is
                            incomplete; run it again without the bit (reported by mgr_raster_status_sync) */
+    MGR_ETIER = -7      /* a forward told to skip binning launches (debug bits 16 / 32) had a view that needed one: its image
+                           is incomplete; run it again without the bits */
 };
 
 int mgr_version(void);
@@ -120,7 +122,11 @@ size_t mgr_raster_workspace_bytes(int V, int N, int W, int H, int64_t pair_capac
  * forward rendered the SAME views (camera + pose) of a model that has moved little since; if a cut list runs out under
  * a pixel that has not saturated the forward raises the overflow word's bit 1 (mgr_raster_status_sync: MGR_ECUT) and
  * the caller runs it again without bit 8.  Pass the bit to both calls of a forward split with bits 2 / 4.  No
- * counterpart upstream (the reference renders one view per step and re-bins everything). */
+ * counterpart upstream (the reference renders one view per step and re-bins everything).
+ * 16 / 32 = skip the binning launches that only serve views whose box of non-empty tiles has more than 2048 / has
+ * 1537..2048 tiles (they hold more LDS per workgroup; three launches of ~6 us each that do nothing for smaller boxes).
+ * mgr_raster_status_tiers_sync reports which of them a forward needed (bit 0 / bit 1); pass the bits for the tiers the
+ * previous forward did not need.  A view that needs a skipped launch raises the overflow word's bit 2 (MGR_ETIER). */
 int mgr_raster_forward(int V, int N, int W, int H, const float* cams, const float* bg,
                        const float* means3D, int64_t stride_means3D, const float* cov3D,
                        int64_t stride_cov3D, const float* colors, int64_t stride_colors,
@@ -199,6 +205,10 @@ int mgr_raster_layout(int V, int N, int W, int H, int64_t pair_capacity, size_t*
 /* Blocking read-back of the workspace header after a forward: total number of
  * (Gaussian, tile) pairs (`num_rendered`, summed over views) and the overflow
  * flag.  Returns MGR_EOVERFLOW when the flag is set. */
+/* mgr_raster_status_sync plus `tiers` (see debug bits 16 / 32 of the forward): bit 0 = a view's tile box had more than
+ * 2048 tiles, bit 1 = one had 1537..2048. */
+int mgr_raster_status_tiers_sync(const void* workspace, int64_t* num_pairs, int32_t* overflow, int32_t* tiers,
+                                 void* stream);
 int mgr_raster_status_sync(const void* workspace, int64_t* num_pairs, int32_t* overflow,
                            void* stream);
 

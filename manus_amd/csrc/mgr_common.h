@@ -60,8 +60,8 @@ struct MgrProfScope {
 // workspace layout of the rasterizer (shared by forward and backward)
 // ---------------------------------------------------------------------------
 struct MgrHeader {            // first 256 bytes of the workspace
-    uint32_t total_pairs;     // sum of tiles_touched over all views (may exceed capacity)
-    uint32_t overflow;        // 1 if total_pairs > capacity
+    uint32_t total_pairs;     // sum of tiles_touched over all views (may exceed capacity); published by k_tile_scan_b
+    uint32_t overflow;        // MGR_OVF_* bits of the most recent forward (k_tile_scan_b: pairs; k_fwd_items adds the depth-cut flag)
     uint32_t epoch;           // backward call counter (tags valid pair-gradient records)
     uint32_t queue_len;       // number of non-empty tiles in tile_queue
     uint32_t queue_head;      // work-queue cursor (sort)
@@ -72,7 +72,14 @@ struct MgrHeader {            // first 256 bytes of the workspace
     uint32_t queue_head3;     // cursor of the small-tile sort
     uint32_t n_active;        // Gaussians with a non-zero pair gradient in the current view group (fused backward)
     uint32_t queue_len_i;     // length of the view-interleaved queue of the forward blend (tile_qrec, with holes)
-    uint32_t pad[4];
+    // accumulators of the forward in flight: pairs counted by the per-instance kernel, depth-cut flags raised by the tile
+    // scan and the blend.  Whoever publishes them (above) leaves them zero for the next forward -- no memset per call.
+    uint32_t acc_pairs, acc_flags;
+    // ordered binning: LDS tiers the views' tile boxes of the most recent forward needed beyond the smallest one
+    // (bit 0: a box of more than 2048 tiles, bit 1: one of 1537..2048) -- a caller may skip the launches of tiers the
+    // previous forward did not need (debug bits 16 / 32); a skipped tier that IS needed raises MGR_OVF_TIER
+    uint32_t tiers;
+    uint32_t pad[1];
     uint32_t spare[68];       // (the size-class counters of the tile scan lived here: it now derives them from per-block histograms)
     uint32_t queue_giant;     // queue index of the first tile with fewer than 16384 pairs
     uint32_t n_groups;        // depth groups produced by k_tile_split for the giant tiles
@@ -90,6 +97,7 @@ struct MgrHeader {            // first 256 bytes of the workspace
 // bits of MgrHeader::overflow
 #define MGR_OVF_PAIRS 1u   // the pair capacity was exceeded: lists clipped, image and gradients incomplete
 #define MGR_OVF_CUT 2u     // a tile whose list was cut short by the depth cut ran out of entries with a pixel still unsaturated
+#define MGR_OVF_TIER 4u    // a view's tile box needed a binning launch the caller had asked to skip (debug bits 16 / 32)
 
 // 48-byte per-(view,Gaussian) record gathered by the blend kernels
 struct __attribute__((aligned(16))) MgrGRec {

@@ -382,7 +382,8 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
     const float4* __restrict__ pair_grad, float* __restrict__ dL_dmeans3D,
     float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dcolors,
     float* __restrict__ dL_dopacity, float* __restrict__ dL_dcov3D, const uint32_t* __restrict__ inst_tag,
-    uint32_t cap, uint32_t epoch) {
+    uint32_t cap, uint32_t epoch, MgrHeader* hdr) {
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < MGR_NCTR) hdr->qctr[threadIdx.x * 64] = 0u;   // (see k_inst_gather)
     const int v = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
@@ -478,6 +479,7 @@ __global__ __launch_bounds__(256) void k_inst_gather(
     __shared__ uint32_t s_list[IPB * IG_ROUNDS];
     __shared__ uint32_t s_cnt, s_base;
     const int tid = threadIdx.x, vl = tid & (G - 1), il = tid / G, lane = tid & 63;
+    if (blockIdx.x == 0 && tid < MGR_NCTR && v_first == 0) hdr->qctr[tid * 64] = 0u;   // the blend's queue is drained: ready for the next backward
     if (tid == 0) s_cnt = 0;
     __syncthreads();
     const bool acc_out = accumulate != 0;
@@ -761,7 +763,8 @@ static int raster_backward_impl(int V, int N, int W, int H, const float* cams, c
     uint32_t epoch = g_epoch.fetch_add(1) + 1;
     if (epoch == 0) epoch = g_epoch.fetch_add(1) + 1;
 
-    MGR_HIP(hipMemsetAsync(hdr->qctr, 0, sizeof(hdr->qctr), stream));   // queue counters of the blend
+    // (the queue counters of the blend are left zero by the kernel that follows it, k_inst_gather / k_preprocess_bwd: no
+    // memset per call)
     { MGR_PROF("k_blend_bwd", stream); hipLaunchKernelGGL(k_blend_bwd, dim3(256 * BWD_WAVES), dim3(256), 0, stream, N, W, H, gx, gy,
                        (const uint32_t*)(ws + L.sorted_gid), (const MgrGRec*)(ws + L.grec), (const uint32_t*)(ws + L.n_contrib),
                        (const float4*)(ws + L.ckpt), (const uint4*)(ws + L.items), hdr, out_color,
@@ -832,7 +835,7 @@ static int raster_backward_impl(int V, int N, int W, int H, const float* cams, c
                        (const ushort4*)(ws + L.rect), (const uint32_t*)(ws + L.pair_off),
                        (const uint32_t*)(ws + L.pair_tag), (const float4*)(ws + L.pair_grad),
                        dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dcov3D,
-                       (const uint32_t*)(ws + L.inst_tag), (uint32_t)cap, epoch); }
+                       (const uint32_t*)(ws + L.inst_tag), (uint32_t)cap, epoch, hdr); }
     MGR_LAUNCH_CHECK("k_preprocess_bwd", stream, debug);
     return MGR_OK;
 }

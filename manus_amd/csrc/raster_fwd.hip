@@ -229,7 +229,7 @@ __device__ __forceinline__ void pre_tail(int N, int gx, int gy, int v, int i, co
     }
     uint32_t block_total;
     const uint32_t local = block_excl_scan(tiles, s_scan, block_total);
-    if (tid == 0) s_scan[20] = block_total ? atomicAdd(&hdr->total_pairs, block_total) : 0u;
+    if (tid == 0) s_scan[20] = block_total ? atomicAdd(&hdr->acc_pairs, block_total) : 0u;
     __syncthreads();
     const uint32_t off = s_scan[20] + local;
     if (i < N) {
@@ -444,7 +444,8 @@ __device__ __forceinline__ void dbin_count_block(int bx, int v, int N, const int
 __device__ __forceinline__ void dbin_scan_block(int v, int nbT, const uint4* __restrict__ blk_box,
                                                 uint32_t* __restrict__ db_count, uint32_t* __restrict__ db_cursor,
                                                 uint32_t* __restrict__ db_start, uint32_t* __restrict__ db_nvis,
-                                                ushort4* __restrict__ db_bbox, uint32_t* s_scan /*32*/, uint32_t* s_box /*4*/) {
+                                                ushort4* __restrict__ db_bbox, uint32_t* s_scan /*32*/, uint32_t* s_box /*4*/,
+                                                MgrHeader* hdr) {
     const int tid = threadIdx.x;
     if (tid == 0) { s_box[0] = 0xFFFFu; s_box[1] = 0xFFFFu; s_box[2] = 0u; s_box[3] = 0u; }
     constexpr int PER = MGR_DB_BUCKETS / 1024;
@@ -474,6 +475,9 @@ __device__ __forceinline__ void dbin_scan_block(int v, int nbT, const uint4* __r
         db_bbox[v] = any ? make_ushort4((unsigned short)s_box[0], (unsigned short)s_box[1], (unsigned short)(s_box[2] - s_box[0]),
                                         (unsigned short)(s_box[3] - s_box[1]))
                          : make_ushort4(0, 0, 0, 0);
+        const uint32_t tb = any ? (s_box[2] - s_box[0]) * (s_box[3] - s_box[1]) : 0u;   // which LDS tier of the bin kernels the view needs
+        if (tb > 2048u) atomicOr(&hdr->tiers, 1u);
+        else if (tb > 1536u) atomicOr(&hdr->tiers, 2u);
     }
 }
 
@@ -547,7 +551,8 @@ struct DbinArgs {   // depth-bucket side of the two tile-scan launches (ordered 
 __global__ __launch_bounds__(1024) void k_tile_scan_a(int T, int nbT, const uint32_t* __restrict__ tile_count,
                                                       const uint32_t* __restrict__ tile_done, int use_hint,
                                                       uint2* __restrict__ part, uint32_t* __restrict__ blk_cls,
-                                                      uint4* __restrict__ blk_box, int gx, int n_scan_blocks, DbinArgs db) {
+                                                      uint4* __restrict__ blk_box, int gx, int n_scan_blocks, DbinArgs db,
+                                                      MgrHeader* hdr) {
     __shared__ uint32_t s_dbh[MGR_DB_BUCKETS];
     if ((int)blockIdx.x >= n_scan_blocks) {   // the workgroups behind the scan's: depth buckets of 8192 instances of one view
         const int b2 = (int)blockIdx.x - n_scan_blocks;
@@ -559,6 +564,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan_a(int T, int nbT, const uint
     __shared__ uint32_t s_bb[4];
     const int tid = threadIdx.x, v = blockIdx.x / nbT, t = (blockIdx.x % nbT) * 1024 + tid;
     if (tid == 0) { s_bb[0] = 0xFFFFu; s_bb[1] = 0xFFFFu; s_bb[2] = 0u; s_bb[3] = 0u; }
+    if (blockIdx.x == 0 && tid == 0) hdr->tiers = 0u;   // (phase B's depth-bucket workgroups set the bits)
     const bool valid = t < T;
     const size_t k = (size_t)v * T + t;
     if (tid < MGR_NCLS) s_cls[tid] = 0;
@@ -603,7 +609,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan_b(int V, int T, int nbT, uin
     if ((int)blockIdx.x >= V * nbT) {   // the workgroups behind the scan's: one per view, depth-bucket offsets + tile box
         __shared__ uint32_t s_box[4];
         dbin_scan_block((int)blockIdx.x - V * nbT, nbT, blk_box, db.db_count, db.db_cursor, db.db_start, db.db_nvis, db.db_bbox,
-                        s_scan, s_box);
+                        s_scan, s_box, hdr);
         return;
     }
     __shared__ uint32_t s_gtot[MGR_NCLS], s_gpre[MGR_NCLS], s_vtot[MGR_NCLS], s_vpre[MGR_NCLS];   // tiles per class: all / in front of this block, of all views / of this view
@@ -670,7 +676,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan_b(int V, int T, int nbT, uin
         tile_zcut[k] = 0u;
         // a tile that had a hint saturated in the forward that left it; if nothing at all is listed for it now, the cut may
         // have taken everything the tile should show and no walk will ever notice: flag it here
-        if (zu != 0u && c == 0u) atomicOr(&hdr->overflow, MGR_OVF_CUT);
+        if (zu != 0u && c == 0u) atomicOr(&hdr->acc_flags, MGR_OVF_CUT);
         tile_qend[k] = 0u;
         const uint32_t rank = atomicAdd(&s_lc[cls], 1u);
         tile_queue[s_gbase[cls] + s_gpre[cls] + rank] = (uint32_t)k;
@@ -685,7 +691,10 @@ __global__ __launch_bounds__(1024) void k_tile_scan_b(int V, int T, int nbT, uin
     if (b == 0 && tid == 0) {
         tile_start[(size_t)V * T] = s_tot[0];
         chunk_start[(size_t)V * T] = s_tot[1];
-        if (s_tot[0] > cap || hdr->total_pairs > cap) atomicOr(&hdr->overflow, MGR_OVF_PAIRS);   // (zeroed when the forward started)
+        const uint32_t rect_pairs = hdr->acc_pairs;   // (the per-instance kernel is done; consumed: zero for the next forward)
+        hdr->acc_pairs = 0u;
+        hdr->total_pairs = rect_pairs;
+        hdr->overflow = (s_tot[0] > cap || rect_pairs > cap) ? MGR_OVF_PAIRS : 0u;
         hdr->n_items = 0;
         hdr->item_head = 0;
         hdr->queue_len = s_gbase[0];     // class 0 (empty tiles) starts after all non-empty ones
@@ -1490,7 +1499,8 @@ __global__ __launch_bounds__(BIN_SC_THREADS) void k_bin_scatter(int N, int T, in
                                                                 const uint32_t* __restrict__ db_order,
                                                                 const uint4* __restrict__ db_rec,
                                                                 const uint32_t* __restrict__ bin_mat,
-                                                                uint32_t* __restrict__ sorted_gid, uint32_t cap) {
+                                                                uint32_t* __restrict__ sorted_gid, uint32_t cap,
+                                                                MgrHeader* hdr, int skipped) {
     constexpr bool SMALL = MASKS > 0;
     extern __shared__ __attribute__((aligned(16))) uint32_t s_mem[];
     BinRec* s_rec = (BinRec*)s_mem;                                     // [2][64] staged instances (by-instance route)
@@ -1501,7 +1511,16 @@ __global__ __launch_bounds__(BIN_SC_THREADS) void k_bin_scatter(int N, int T, in
     uint32_t* s_cur = s_info + 4;                                       // cursors of the box's tiles (absolute list slots)
     const int v = blockIdx.y, b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const ushort4 box = db_bbox[v];
-    if (!bin_sc_mine(box, MASKS)) return;
+    if (!bin_sc_mine(box, MASKS)) {
+        // the instantiation that is always launched checks the tiers the caller skipped (bit 0: boxes of more than
+        // BIN_SMALL_TILES tiles -- k_bin_count<false>, k_bin_scatter<0>; bit 1: k_bin_scatter<BIN_SMALL_TILES>)
+        if (MASKS == BIN_MID_TILES && skipped && b == 0 && tid == 0) {
+            const uint32_t tb = (uint32_t)box.z * (uint32_t)box.w;
+            if ((tb > (uint32_t)BIN_SMALL_TILES && (skipped & 1)) || (tb > (uint32_t)BIN_MID_TILES && tb <= (uint32_t)BIN_SMALL_TILES && (skipped & 2)))
+                atomicOr(&hdr->overflow, MGR_OVF_TIER);
+        }
+        return;
+    }
     const uint32_t nvis = db_nvis[v], p0 = (uint32_t)b * (uint32_t)bb;
     if (p0 >= nvis) return;
     const uint32_t p1 = min(p0 + (uint32_t)bb, nvis);
@@ -2003,7 +2022,7 @@ __global__ __launch_bounds__(256) FWD_OCC void k_blend_fwd(int N, int W, int H, 
             // unsaturated pixel while this forward had cut it short, the image may lack contributions: raise the flag
             const bool unsat = (~done_m & exec_m) != 0ull;
             atomicMax(&tile_qend[vt], unsat ? 0xFFFFFFFFu : min(off, nlist));
-            if (unsat && tile_zused[vt] != 0u) atomicOr(&hdr->overflow, MGR_OVF_CUT);
+            if (unsat && tile_zused[vt] != 0u) atomicOr(&hdr->acc_flags, MGR_OVF_CUT);
         }
 #ifdef MGR_TIMELINE
         if (lane == 0 && tlw_n < TLW_PER_WAVE) {
@@ -2070,6 +2089,10 @@ __global__ __launch_bounds__(256) void k_fwd_items(const uint4* __restrict__ til
     const int tid = threadIdx.x;
     const uint32_t n_busy = hdr->queue_len_i;
     const uint32_t nb = (n_busy + 255u) / 256u;
+    if (blockIdx.x == 0 && tid == 0) {   // the forward's last kernel publishes the depth-cut flags (tile scan + blend) and consumes them
+        const uint32_t f = hdr->acc_flags;
+        if (f) { hdr->overflow |= f; hdr->acc_flags = 0u; }
+    }
     if (blockIdx.x >= nb) return;
     // strided over the queue (which is ordered by depth): every block gets its share of the deep tiles
     const uint32_t q = (uint32_t)tid * nb + blockIdx.x;
@@ -2155,7 +2178,10 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
     // debug bit 0: synchronise and check after every kernel; bit 1: stop before the blend (instance kernels and binning
     // only); bit 2: the blend only (after a call with bit 1 on the same workspace and arguments)
     // bit 3 (8): depth cut -- apply the hints the previous forward on this workspace left in tile_zcut (fused path only)
+    // bits 4 / 5 (16 / 32): skip the binning launches for tile boxes of more than 2048 / of 1537..2048 tiles (the caller saw
+    // in the previous forward's header that no view needed them; a view that does now raises MGR_OVF_TIER)
     const bool do_bin = !(debug & 4), do_blend = !(debug & 2), use_cut = (debug & 8) && canon != nullptr;
+    const int skip_tiers = ((debug & 16) ? 1 : 0) | ((debug & 32) ? 2 : 0);
     debug &= 1;
     if (V <= 0 || N < 0 || W <= 0 || H <= 0 || cap < 0 || cap > 0xFFFFFFF0ll)
         return mgr_fail(MGR_EINVAL, "mgr_raster_forward: bad sizes");
@@ -2202,8 +2228,8 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
     const bool ordered = ordered_env && lds_hist && T <= 65535 && (size_t)T * 4 + BIN_SC_FIXED_BYTES <= 150 * 1024;
     const size_t hist_bytes = lds_hist ? (size_t)T * 4 : 0;
     if (do_bin) {
-    // per-call counters (epoch lives past the first 32 bytes and persists)
-    MGR_HIP(hipMemsetAsync(hdr, 0, 8, stream));
+    // (no per-call memset: the pair and flag accumulators of the header are consumed -- left zero -- by the kernels that
+    // publish them, k_tile_scan_b and k_fwd_items; 7 us per forward as a launch of its own)
     // tile_count and the size-class counters are left zero by the previous forward on this workspace
     // (k_tile_scan_b / k_blend_fwd) and by the zero-filled allocation before the first one
 
@@ -2247,7 +2273,7 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
                               (uint32_t*)(ws + L.db_cursor), (uint32_t*)(ws + L.db_start), (uint32_t*)(ws + L.db_nvis),
                               (ushort4*)(ws + L.db_bbox), (unsigned long long*)(ws + L.db_keys)};
         { MGR_PROF("k_tile_scan_a", stream); hipLaunchKernelGGL(k_tile_scan_a, dim3(nblk + (dbin ? n_bx * V : 0)), dim3(1024), 0, stream, T, nbT, tile_count,
-                           (const uint32_t*)(ws + L.tile_done), use_hint, part, blk_cls, blk_box, gx, nblk, dba); }
+                           (const uint32_t*)(ws + L.tile_done), use_hint, part, blk_cls, blk_box, gx, nblk, dba, hdr); }
         { MGR_PROF("k_tile_scan_b", stream); hipLaunchKernelGGL(k_tile_scan_b, dim3(nblk + (dbin ? V : 0)), dim3(1024), 0, stream, V, T, nbT, tile_count, part, (const uint32_t*)blk_cls,
                            tile_start, (uint32_t*)(ws + L.tile_cursor), (uint32_t*)(ws + L.tile_queue), (uint4*)(ws + L.tile_qrec),
                            (const uint32_t*)(ws + L.tile_done), use_hint, (uint32_t*)(ws + L.chunk_start), hdr, (uint32_t)cap,
@@ -2278,7 +2304,7 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
           const dim3 grid_c = (V % 8 == 0) ? dim3(nblk * V) : grid_b;   // (XCD-aware order, see the kernel)
           hipLaunchKernelGGL((k_bin_count<true>), grid_c, dim3(BCNT_THREADS), (size_t)BIN_SMALL_TILES * 4, stream, N, T, nblk, bb, (const uint32_t*)db_nvis,
                              (const ushort4*)db_bbox, (const uint32_t*)db_order, rect, alive, db_rec, bin_mat, V % 8 == 0 ? 1 : 0);
-          if (big_possible)
+          if (big_possible && !(skip_tiers & 1))
               hipLaunchKernelGGL((k_bin_count<false>), grid_c, dim3(BCNT_THREADS), (size_t)T * 4, stream, N, T, nblk, bb, (const uint32_t*)db_nvis,
                                  (const ushort4*)db_bbox, (const uint32_t*)db_order, rect, alive, db_rec, bin_mat, V % 8 == 0 ? 1 : 0); }
         { MGR_PROF("k_bin_scan", stream); hipLaunchKernelGGL(k_bin_scan, dim3((T + BSCAN_COLS - 1) / BSCAN_COLS, V), dim3(BSCAN_COLS * BSCAN_SEGS), 0, stream, gx, T, nblk, bb, (const uint32_t*)db_nvis,
@@ -2286,15 +2312,15 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
         { MGR_PROF("k_bin_scatter", stream);
           hipLaunchKernelGGL((k_bin_scatter<BIN_MID_TILES>), grid_b, dim3(BIN_SC_THREADS), (size_t)BIN_MID_TILES * 12 + rec_bytes, stream, N, T, nblk, bb,
                              (const uint32_t*)db_nvis, (const ushort4*)db_bbox, (const uint32_t*)db_order, (const uint4*)db_rec, (const uint32_t*)bin_mat,
-                             (uint32_t*)(ws + L.sorted_gid), (uint32_t)cap);
-          if (T > BIN_MID_TILES)
+                             (uint32_t*)(ws + L.sorted_gid), (uint32_t)cap, hdr, skip_tiers);
+          if (T > BIN_MID_TILES && !(skip_tiers & 2))
               hipLaunchKernelGGL((k_bin_scatter<BIN_SMALL_TILES>), grid_b, dim3(BIN_SC_THREADS), (size_t)BIN_SMALL_TILES * 12 + rec_bytes, stream, N, T, nblk, bb,
                                  (const uint32_t*)db_nvis, (const ushort4*)db_bbox, (const uint32_t*)db_order, (const uint4*)db_rec, (const uint32_t*)bin_mat,
-                                 (uint32_t*)(ws + L.sorted_gid), (uint32_t)cap);
-          if (big_possible)
+                                 (uint32_t*)(ws + L.sorted_gid), (uint32_t)cap, hdr, 0);
+          if (big_possible && !(skip_tiers & 1))
               hipLaunchKernelGGL((k_bin_scatter<0>), grid_b, dim3(BIN_SC_THREADS), (size_t)T * 4 + rec_bytes, stream, N, T, nblk, bb,
                                  (const uint32_t*)db_nvis, (const ushort4*)db_bbox, (const uint32_t*)db_order, (const uint4*)db_rec, (const uint32_t*)bin_mat,
-                                 (uint32_t*)(ws + L.sorted_gid), (uint32_t)cap); }
+                                 (uint32_t*)(ws + L.sorted_gid), (uint32_t)cap, hdr, 0); }
         MGR_LAUNCH_CHECK("k_bin_scatter", stream, debug);
     } else if (N > 0) {
         dim3 grid((N + EMIT_THREADS - 1) / EMIT_THREADS, V);
@@ -2424,6 +2450,22 @@ extern "C" int mgr_raster_status_sync(const void* workspace, int64_t* num_pairs,
     if (overflow) *overflow = (int32_t)h[1];
     if (h[1] & MGR_OVF_PAIRS) return mgr_fail(MGR_EOVERFLOW, "pair capacity exceeded");
     if (h[1] & MGR_OVF_CUT) return mgr_fail(MGR_ECUT, "depth cut violated: run the forward again without debug bit 8");
+    if (h[1] & MGR_OVF_TIER) return mgr_fail(MGR_ETIER, "a skipped binning tier was needed: run the forward again without debug bits 16 / 32");
+    return MGR_OK;
+}
+
+extern "C" int mgr_raster_status_tiers_sync(const void* workspace, int64_t* num_pairs, int32_t* overflow, int32_t* tiers,
+                                            void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    uint32_t h[16];
+    MGR_HIP(hipMemcpyAsync(h, workspace, sizeof(h), hipMemcpyDeviceToHost, stream));
+    MGR_HIP(hipStreamSynchronize(stream));
+    if (num_pairs) *num_pairs = h[0];
+    if (overflow) *overflow = (int32_t)h[1];
+    if (tiers) *tiers = (int32_t)h[offsetof(MgrHeader, tiers) / 4];
+    if (h[1] & MGR_OVF_PAIRS) return mgr_fail(MGR_EOVERFLOW, "pair capacity exceeded");
+    if (h[1] & MGR_OVF_CUT) return mgr_fail(MGR_ECUT, "depth cut violated: run the forward again without debug bit 8");
+    if (h[1] & MGR_OVF_TIER) return mgr_fail(MGR_ETIER, "a skipped binning tier was needed: run the forward again without debug bits 16 / 32");
     return MGR_OK;
 }
 

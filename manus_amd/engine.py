@@ -549,7 +549,7 @@ class HipViewCompute:
             check(lib().mgr_views_forward(V, N, B, na, sh_half, W, H, ptr(cams), ptr(bg), ptr(p["_xyz"]), ptr(p["_scaling"]),
                                           ptr(p["_rotation"]), ptr(op), ptr(p["_features_dc"]), ptr(f_rest),
                                           ptr(w), ptr(T), ptr(out), ptr(radii), ptr(ws.buf), ws.nbytes, ws.cap,
-                                          phase | self._cut_bit, stream()), "mgr_views_forward")
+                                          phase | self._cut_bit | ws.skip_bits(), stream()), "mgr_views_forward")
 
         def launch(ws):
             self._cut_bit = self._cut_flag(ws, view_ids, V, N, W, H)

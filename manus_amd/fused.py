@@ -50,7 +50,7 @@ class _RenderViews(torch.autograd.Function):
         def launch(ws):
             check(lib().mgr_views_forward(V, N, B, n_art, sh_half, W, H, ptr(cams), ptr(bg), ptr(xyz), ptr(log_scale), ptr(rot),
                                           ptr(opacity), ptr(f_dc), ptr(f_rest), ptr(skin_w), ptr(transforms),
-                                          ptr(out), ptr(radii), ptr(ws.buf), ws.nbytes, ws.cap, 0, stream()),
+                                          ptr(out), ptr(radii), ptr(ws.buf), ws.nbytes, ws.cap, ws.skip_bits(), stream()),
                   "mgr_views_forward")
 
         ws, _ = _rz.context(dev).forward(V, N, W, H, launch)

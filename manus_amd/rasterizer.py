@@ -54,6 +54,16 @@ class RasterWorkspace:
         # the caller that opts in), and "the last forward with the cut was flagged: run the next one without it"
         self.hint_key = self.prev_hint_key = None
         self.cut_block = False
+        # binning tiers (debug bits 16 / 32 of the forward): which LDS tiers beyond the smallest the most recent forward
+        # whose header was read needed (None: unknown -- launch them all)
+        self.tiers = None
+
+    def skip_bits(self):
+        """debug bits that spare the forward the binning launches its views did not need last time (they are verified on
+        the device: a view that needs a skipped launch flags the forward, which is then run again with all of them)."""
+        if self.tiers is None:
+            return 0
+        return (0 if self.tiers & 1 else 16) | (0 if self.tiers & 2 else 32)
 
 
 def default_pair_capacity(V, N):
@@ -77,6 +87,7 @@ class RasterContext:
         self._free_pinned = []
         self._evicted_overflow = False   # an overflow seen while retiring old fences: raised by the next poll()
         self.cut_retries = 0             # forwards flagged MGR_OVF_CUT (each is answered by a forward without the depth cut)
+        self.tier_retries = 0            # forwards flagged MGR_OVF_TIER (answered by a forward with every binning launch)
 
     # -- pool ---------------------------------------------------------------------------------
     def acquire(self, V, N, W, H, min_cap):
@@ -124,11 +135,16 @@ class RasterContext:
                     self._fence(ws)
                 return ws, None
             import ctypes
-            npairs, ovf = ctypes.c_int64(0), ctypes.c_int32(0)
-            rc = lib().mgr_raster_status_sync(ptr(ws.buf), ctypes.byref(npairs), ctypes.byref(ovf), stream())
+            npairs, ovf, tiers = ctypes.c_int64(0), ctypes.c_int32(0), ctypes.c_int32(0)
+            rc = lib().mgr_raster_status_tiers_sync(ptr(ws.buf), ctypes.byref(npairs), ctypes.byref(ovf), ctypes.byref(tiers), stream())
+            ws.tiers = None if (ovf.value & 4) else int(tiers.value)
             if rc == 0:
                 self._learn(key, npairs.value)
                 return ws, int(npairs.value)
+            if rc == -7 and not (ovf.value & 3):   # MGR_ETIER: a skipped binning launch was needed; same workspace, all launches
+                self.tier_retries += 1
+                ws.busy = False
+                continue
             if rc == -6 and not (ovf.value & 1):   # MGR_ECUT: the depth-cut hints no longer fit; same workspace, no cut
                 ws.cut_block = True
                 self.cut_retries += 1
@@ -153,8 +169,8 @@ class RasterContext:
         while len(self._fences) >= self.MAX_FENCES:
             _, ovf = self._resolve(self._fences.pop(0))
             self._evicted_overflow = self._evicted_overflow or bool(ovf)
-        pinned = self._free_pinned.pop() if self._free_pinned else torch.empty(2, dtype=torch.int32).pin_memory()
-        pinned.copy_(ws.buf[:8].view(torch.int32), non_blocking=True)
+        pinned = self._free_pinned.pop() if self._free_pinned else torch.empty(16, dtype=torch.int32).pin_memory()
+        pinned.copy_(ws.buf[:64].view(torch.int32), non_blocking=True)   # (the header's first 16 words: ..., 14 = binning tiers)
         ev = torch.cuda.Event()
         ev.record()
         self._fences.append((ws, pinned, ev))
@@ -168,6 +184,11 @@ class RasterContext:
         if ovf & 2:     # MGR_OVF_CUT: the caller re-runs the step; that forward must not use the hints
             ws.cut_block = True
             self.cut_retries += 1
+        if ovf & 4:     # MGR_OVF_TIER: ... and with every binning launch
+            ws.tiers = None
+            self.tier_retries += 1
+        else:
+            ws.tiers = int(pinned[14].item())
         return npairs, ovf
 
     def poll(self):
@@ -192,9 +213,12 @@ class RasterContext:
         ws = self.last_ws
         if ws is None:
             return polled
-        npairs, ovf = ctypes.c_int64(0), ctypes.c_int32(0)
-        rc = lib().mgr_raster_status_sync(ptr(ws.buf), ctypes.byref(npairs), ctypes.byref(ovf), stream())
+        npairs, ovf, tiers = ctypes.c_int64(0), ctypes.c_int32(0), ctypes.c_int32(0)
+        rc = lib().mgr_raster_status_tiers_sync(ptr(ws.buf), ctypes.byref(npairs), ctypes.byref(ovf), ctypes.byref(tiers), stream())
         self._learn(ws.key, npairs.value)
+        ws.tiers = None if (ovf.value & 4) else int(tiers.value)
+        if ovf.value & 4:
+            self.tier_retries += 1
         if rc == -6:
             ws.cut_block = True
             self.cut_retries += 1
@@ -255,7 +279,7 @@ def _run_forward(cams, V, N, W, H, bg, means3D, cov3D, colors, opacity, debug, s
     def launch(ws):
         check(lib().mgr_raster_forward(V, N, W, H, ptr(cams), ptr(bg), ptr(means3D), s_m, ptr(cov3D), s_c,
                                        ptr(colors), s_col, ptr(opacity), s_o, ptr(out), ptr(radii),
-                                       ptr(ws.buf), ws.nbytes, ws.cap, int(bool(debug)), stream()),
+                                       ptr(ws.buf), ws.nbytes, ws.cap, int(bool(debug)) | ws.skip_bits(), stream()),
               "mgr_raster_forward")
 
     ws, npairs = context(dev).forward(V, N, W, H, launch, sync_check)

@@ -193,6 +193,36 @@ def test_capacity_overflow_is_detected_and_retried():
     assert rz.check_overflow() == o.num_rendered
 
 
+def test_skipped_binning_tiers_are_verified_and_retried():
+    """debug bits 16 / 32 of the forward (include/manus_hip.h): a forward whose views' tile boxes fit the smallest LDS tier
+    lets the next one skip the launches of the larger tiers; when the next one needs them after all -- the same Gaussians
+    spread over the whole 1080p frame: a box of more than 2048 tiles -- it is flagged (MGR_ETIER) and run again with every
+    launch.  Both forwards must equal a forward on a fresh context, bit for bit, and the large box then keeps its launches."""
+    from manus_amd import rasterizer as rz
+    W, H = 1920, 1080
+    cam = make_camera(W, H)
+    m, c, col, op = random_gaussians(20000, seed=11, spread=0.03, sigma=(0.002, 0.006))
+    g = np.random.default_rng(1).normal(size=(1, 3, H, W)).astype(np.float32)
+    ctx = rz.context()
+    ctx.clear()
+    want_small = _hip([cam], m, c, col, op, grad_img=g)
+    ctx.clear()
+    want_big = _hip([cam], 6.0 * m, c, col, op, grad_img=g)
+    ctx.clear()
+    ctx.tier_retries = 0
+    got_small = _hip([cam], m, c, col, op, grad_img=g)
+    ws = ctx.last_ws
+    assert ws.tiers == 0 and ws.skip_bits() == 48            # box of at most 1536 tiles: neither larger tier needed
+    got_big = _hip([cam], 6.0 * m, c, col, op, grad_img=g)  # skips them, is flagged, runs again
+    assert ctx.tier_retries == 1 and ctx.last_ws.tiers == 1 and ctx.last_ws.skip_bits() == 32
+    again = _hip([cam], 6.0 * m, c, col, op, grad_img=g)
+    assert ctx.tier_retries == 1
+    for k in want_small:
+        assert np.array_equal(got_small[k], want_small[k]), k
+        assert np.array_equal(got_big[k], want_big[k]), k
+        assert np.array_equal(again[k], want_big[k]), k
+
+
 def test_multi_view_batch_equals_single_views_bitwise():
     W, H = 160, 96
     cams = [make_camera(W, H, pos=p) for p in [(0.3, -0.2, -1.5), (-0.8, 0.1, -1.2), (0.1, 0.9, -1.3)]]
