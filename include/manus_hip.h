@@ -205,6 +205,13 @@ int mgr_raster_layout(int V, int N, int W, int H, int64_t pair_capacity, size_t*
 /* Blocking read-back of the workspace header after a forward: total number of
  * (Gaussian, tile) pairs (`num_rendered`, summed over views) and the overflow
  * flag.  Returns MGR_EOVERFLOW when the flag is set. */
+/* Status without a copy: `host_words` points to 4 uint32 of host memory the device can write (hipHostMalloc / pinned
+ * memory); the next forward that runs the blend on `workspace` writes (pair total, overflow word, binning tiers, 1) there
+ * from its last kernel.  An event recorded behind that forward then tells the host when the words are valid -- no
+ * device-to-host copy, no host synchronisation of the stream.  One shot per call; nullptr withdraws a pending mirror.  The
+ * caller zeroes word 3 beforehand and keeps the memory alive until it has read it.  (The reference's rasterizer returns
+ * num_rendered through a blocking read-back, SURVEY App. A.) */
+int mgr_raster_set_status_mirror(const void* workspace, void* host_words);
 /* mgr_raster_status_sync plus `tiers` (see debug bits 16 / 32 of the forward): bit 0 = a view's tile box had more than
  * 2048 tiles, bit 1 = one had 1537..2048. */
 int mgr_raster_status_tiers_sync(const void* workspace, int64_t* num_pairs, int32_t* overflow, int32_t* tiers,

@@ -15,6 +15,7 @@
 //  * no host synchronisation: the pair count stays on the device, capacity
 //    overflow raises a flag in the workspace header.
 #include <atomic>
+#include <mutex>
 
 #include "instance_math.h"
 
@@ -2081,7 +2082,7 @@ __global__ __launch_bounds__(256) void k_fwd_items(const uint4* __restrict__ til
                                                    uint32_t* __restrict__ tile_done, uint4* __restrict__ items, MgrHeader* hdr,
                                                    int N, int T, const uint32_t* __restrict__ sorted_gid, const float* __restrict__ depth,
                                                    const uint32_t* __restrict__ tile_zused, const uint32_t* __restrict__ tile_qend,
-                                                   uint32_t* __restrict__ tile_zcut) {
+                                                   uint32_t* __restrict__ tile_zcut, uint32_t* mirror) {
     __shared__ uint32_t s_scan[8];
     __shared__ uint32_t s_base;
     __shared__ uint32_t s_run[257];
@@ -2091,7 +2092,13 @@ __global__ __launch_bounds__(256) void k_fwd_items(const uint4* __restrict__ til
     const uint32_t nb = (n_busy + 255u) / 256u;
     if (blockIdx.x == 0 && tid == 0) {   // the forward's last kernel publishes the depth-cut flags (tile scan + blend) and consumes them
         const uint32_t f = hdr->acc_flags;
-        if (f) { hdr->overflow |= f; hdr->acc_flags = 0u; }
+        uint32_t ovf = hdr->overflow;
+        if (f) { ovf |= f; hdr->overflow = ovf; hdr->acc_flags = 0u; }
+        if (mirror) {   // the caller's host-mapped status words (mgr_raster_set_status_mirror): no copy, no launch
+            mirror[0] = hdr->total_pairs; mirror[1] = ovf; mirror[2] = hdr->tiers;
+            __threadfence_system();
+            mirror[3] = 1u;
+        }
     }
     if (blockIdx.x >= nb) return;
     // strided over the queue (which is ordered by depth): every block gets its share of the deep tiles
@@ -2166,6 +2173,34 @@ struct MgrSideStream {
 static MgrSideStream& mgr_side_stream(int device) {   // one per (host thread, device): streams and events belong to a device
     static thread_local MgrSideStream s[MGR_MAX_DEVICES];
     return s[device];
+}
+
+// Host-mapped status words per workspace (mgr_raster_set_status_mirror): the forward's last kernel writes (pair total,
+// overflow word, binning tiers, 1) there, so that a caller who does not want to synchronise needs neither a device-to-host
+// copy nor a read-back launch per forward -- an event behind the forward is enough.  One shot: taken by the forward that
+// runs the blend on that workspace.
+static std::mutex g_mirror_mu;
+static struct { const void* ws; uint32_t* dev; } g_mirror[64];
+static uint32_t* mgr_take_status_mirror(const void* workspace) {
+    std::lock_guard<std::mutex> lk(g_mirror_mu);
+    for (auto& m : g_mirror)
+        if (m.ws == workspace) { uint32_t* p = m.dev; m.ws = nullptr; m.dev = nullptr; return p; }
+    return nullptr;
+}
+extern "C" int mgr_raster_set_status_mirror(const void* workspace, void* host_words) {
+    if (!workspace) return mgr_fail(MGR_EINVAL, "mgr_raster_set_status_mirror: null workspace");
+    void* dev = nullptr;
+    if (host_words) MGR_HIP(hipHostGetDevicePointer(&dev, host_words, 0));
+    std::lock_guard<std::mutex> lk(g_mirror_mu);
+    int free_slot = -1;
+    for (int k = 0; k < 64; ++k) {
+        if (g_mirror[k].ws == workspace) { free_slot = k; break; }
+        if (!g_mirror[k].ws && free_slot < 0) free_slot = k;
+    }
+    if (free_slot < 0) return mgr_fail(MGR_EINVAL, "mgr_raster_set_status_mirror: too many workspaces with a pending mirror");
+    g_mirror[free_slot].ws = host_words ? workspace : nullptr;
+    g_mirror[free_slot].dev = (uint32_t*)dev;
+    return MGR_OK;
 }
 
 static int raster_forward_impl(int V, int N, int W, int H, const float* cams, const float* bg,
@@ -2364,7 +2399,7 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
     { MGR_PROF("k_fwd_items", stream); hipLaunchKernelGGL(k_fwd_items, dim3((VT + 255) / 256), dim3(256), 0, stream, (const uint4*)(ws + L.tile_qrec),
                        (const uint32_t*)(ws + L.tile_qdone), (uint32_t*)(ws + L.tile_done), (uint4*)(ws + L.items), hdr,
                        N, T, (const uint32_t*)(ws + L.sorted_gid), (const float*)(ws + L.depth), (const uint32_t*)(ws + L.tile_zused),
-                       (const uint32_t*)(ws + L.tile_qend), (uint32_t*)(ws + L.tile_zcut)); }
+                       (const uint32_t*)(ws + L.tile_qend), (uint32_t*)(ws + L.tile_zcut), mgr_take_status_mirror(workspace)); }
     MGR_LAUNCH_CHECK("k_blend_fwd", stream, debug);
     return MGR_OK;
 }

@@ -522,14 +522,15 @@ def convert_armature_space_to_world_space(md):
     return out
 
 
-def _load_table(path):
-    """A camera-path / skeleton table: the reference's joblib pickle, or the same dict as one `.npz`."""
+def _load_table(path, size=None):
+    """A camera-path / skeleton table: the reference's joblib pickle, the same dict as one `.npz`, or -- cameras only,
+    `size` = (width, height) -- a calibration `.txt` (brics_dynamic.py:513-531; manus_amd/calib.py, parity unpinned)."""
+    if path.endswith(".txt") and size is not None:
+        from .calib import camera_table_from_calibration
+        return camera_table_from_calibration(path, size[0], size[1])
     if path.endswith(".npz"):
         with np.load(path, allow_pickle=False) as z:
             return {k: z[k] for k in z.files}
-    if path.endswith(".txt"):
-        raise NotImplementedError("calibration .txt camera files go through cv2.getOptimalNewCameraMatrix in the reference "
-                                  "(brics_dynamic.py:513-533); OpenCV is absent here -- convert the file to intrs / extrs first")
     import joblib
     return joblib.load(path)
 
@@ -558,7 +559,8 @@ class TestDataset(torch.utils.data.Dataset):
         self.frame_sample_rate, self.test_on_canonical_pose = o["frame_sample_rate"], o["test_on_canonical_pose"]
         self.width, self.height, self.n_bones = o["width"], o["height"], o["n_bones"]
         self.subject_id, self.mode = o["subject"], o["contact_render_type"]
-        cam_data, cano = _load_table(o["cam_path"]), _load_table(o["cano_cam_path"])
+        cam_data = _load_table(o["cam_path"], size=(self.width, self.height) if self.mode == "acc_gt_eval" else None)
+        cano = _load_table(o["cano_cam_path"])
         md = convert_armature_space_to_world_space(_load_table(o["metadata_path"]))
         parts = os.path.normpath(o["metadata_path"]).split(os.sep)
         action = parts[-2] if len(parts) > 1 else ""

@@ -15,6 +15,8 @@ multi-view batched form (V cameras in every launch) used by the training engine.
 """
 from typing import NamedTuple
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -54,6 +56,7 @@ class RasterWorkspace:
         # the caller that opts in), and "the last forward with the cut was flagged: run the next one without it"
         self.hint_key = self.prev_hint_key = None
         self.cut_block = False
+        self.mirror = None
         # binning tiers (debug bits 16 / 32 of the forward): which LDS tiers beyond the smallest the most recent forward
         # whose header was read needed (None: unknown -- launch them all)
         self.tiers = None
@@ -104,6 +107,16 @@ class RasterContext:
 
     def clear(self):
         """Forget pooled workspaces and learnt capacities (e.g. after densification changed N)."""
+        for ws, pinned, ev in self._fences:     # the forwards' last kernels write into the pinned words: wait before recycling
+            ev.synchronize()
+            if pinned is not None:
+                self._free_pinned.append(pinned)
+        for lst in self.pool.values():          # withdraw mirrors that no forward took
+            for ws in lst:
+                if getattr(ws, "mirror", None) is not None:
+                    lib().mgr_raster_set_status_mirror(ptr(ws.buf), None)
+                    self._free_pinned.append(ws.mirror)
+                    ws.mirror = None
         self.pool.clear()
         self.cap_hint.clear()
         self._fences.clear()
@@ -128,9 +141,12 @@ class RasterContext:
             # whoever launches may claim the depth-cut hints of the forward before (prev_hint_key) and name the views of
             # this one; a launch that does neither leaves hints nobody may use
             ws.prev_hint_key, ws.hint_key = ws.hint_key, None
+            fenced = not (sync_check and self.sync_every_forward)
+            if fenced:
+                self._arm_mirror(ws)
             launch(ws)
             self.last_ws = ws
-            if not (sync_check and self.sync_every_forward):
+            if fenced:
                 if not defer_fence:
                     self._fence(ws)
                 return ws, None
@@ -163,23 +179,38 @@ class RasterContext:
         """True when forwards run without a host synchronisation (fences instead)."""
         return not (sync_check and self.sync_every_forward)
 
-    def _fence(self, ws):
-        """Asynchronous copy of (pair count, overflow flag) to pinned host memory + an event right behind it: the
-        host can later wait for THIS forward only, while the kernels queued after it keep the GPU busy."""
+    def _arm_mirror(self, ws):
+        """Before an unsynchronised forward: four pinned words the forward's last kernel writes its status to
+        (mgr_raster_set_status_mirror) -- the fence is then an event only, no device-to-host copy on the stream."""
         while len(self._fences) >= self.MAX_FENCES:
             _, ovf = self._resolve(self._fences.pop(0))
             self._evicted_overflow = self._evicted_overflow or bool(ovf)
-        pinned = self._free_pinned.pop() if self._free_pinned else torch.empty(16, dtype=torch.int32).pin_memory()
-        pinned.copy_(ws.buf[:64].view(torch.int32), non_blocking=True)   # (the header's first 16 words: ..., 14 = binning tiers)
+        pinned = self._free_pinned.pop() if self._free_pinned else torch.zeros(4, dtype=torch.int32).pin_memory()
+        pinned[3] = 0
+        import ctypes
+        rc = lib().mgr_raster_set_status_mirror(ptr(ws.buf), ctypes.c_void_p(pinned.data_ptr()))
+        ws.mirror = pinned if rc == 0 else None      # (not mappable: the fence falls back to a blocking read)
+
+    def _fence(self, ws):
+        """An event right behind the forward: the host can later wait for THIS forward only, while the kernels queued
+        after it keep the GPU busy; the status words arrive through the mirror armed before the launch."""
         ev = torch.cuda.Event()
         ev.record()
-        self._fences.append((ws, pinned, ev))
+        self._fences.append((ws, getattr(ws, "mirror", None), ev))
+        ws.mirror = None
 
     def _resolve(self, fence):
         ws, pinned, ev = fence
         ev.synchronize()
-        npairs, ovf = int(pinned[0].item()) & 0xFFFFFFFF, int(pinned[1].item())
-        self._free_pinned.append(pinned)
+        if pinned is not None and int(pinned[3].item()) == 1:
+            npairs, ovf, tiers_seen = int(pinned[0].item()) & 0xFFFFFFFF, int(pinned[1].item()), int(pinned[2].item())
+        else:   # (a forward that did not run its blend, or no mirror: read the header -- valid if nothing ran on ws since)
+            import ctypes
+            n_, o_, t_ = ctypes.c_int64(0), ctypes.c_int32(0), ctypes.c_int32(0)
+            lib().mgr_raster_status_tiers_sync(ptr(ws.buf), ctypes.byref(n_), ctypes.byref(o_), ctypes.byref(t_), stream())
+            npairs, ovf, tiers_seen = int(n_.value), int(o_.value), int(t_.value)
+        if pinned is not None:
+            self._free_pinned.append(pinned)
         self._learn(ws.key, npairs)
         if ovf & 2:     # MGR_OVF_CUT: the caller re-runs the step; that forward must not use the hints
             ws.cut_block = True
@@ -188,7 +219,7 @@ class RasterContext:
             ws.tiers = None
             self.tier_retries += 1
         else:
-            ws.tiers = int(pinned[14].item())
+            ws.tiers = tiers_seen
         return npairs, ovf
 
     def poll(self):

@@ -158,9 +158,67 @@ def test_armature_to_world_is_a_point_and_frame_map(golden_dir):
     assert md["rest_matrixs"] is not w["rest_matrixs"] and "frame_nums" in w     # input left alone, other columns kept
 
 
-def test_eval_dataset_refuses_calibration_text_files(golden_dir, tmp_path):
-    from manus_amd import dataset as D
+def _calib_rows(n=3):
+    """Rows of a calibration file in the column order of params.py:57-88 (names deliberately unsorted)."""
+    g = np.random.default_rng(3)
+    rows = []
+    for k in range(n):
+        q = g.normal(size=4)
+        q /= np.linalg.norm(q)
+        rows.append([k, 1280, 720, 900.0 + 10 * k, 905.0 + 7 * k, 633.0 + 3 * k, 371.0 - 2 * k, -0.08 + 0.01 * k, 0.03, 1e-3, -5e-4,
+                     "brics-cam%02d" % (n - k), q[0], q[1], q[2], q[3], 0.1 * k, -0.2, 1.5 + 0.1 * k])
+    return rows
+
+
+def test_calibration_file_cameras(golden_dir, tmp_path):
+    """brics_dynamic.py:513-531 (mode "acc_gt_eval" with a calibration .txt): read_params / get_intr / get_extr restate
+    params.py; the optimal new camera matrix restates OpenCV's published algorithm -- PARITY UNPINNED (no OpenCV here, no
+    vectors upstream), so what is checked are its closed forms."""
+    from manus_amd import calib, dataset as D
+    rows = _calib_rows()
+    path = tmp_path / "calib.txt"
+    path.write_text("\n".join(" ".join(str(v) for v in r) for r in rows) + "\n")
+    params = calib.read_params(str(path))
+    assert [str(p["cam_name"]) for p in params] == sorted(r[11] for r in rows)             # np.sort(order="cam_name")
+    intr, dist = calib.get_intr(params[0])
+    src = rows[-1]                                                                          # cam01 sorts first
+    assert (intr[0, 0], intr[1, 1], intr[0, 2], intr[1, 2]) == tuple(src[3:7]) and tuple(dist) == tuple(src[7:11])
+    e = calib.get_extr(params[0])
+    assert e.shape == (3, 4)
+    np.testing.assert_allclose(e[:, :3] @ e[:, :3].T, np.eye(3), atol=1e-12)                # a rotation
+    np.testing.assert_allclose(e[:, 3], src[16:19])
+    # no distortion: undistortion is the identity, both rectangles are the frame, and the centred matrix scales the
+    # focal lengths by the largest of the four centre / border ratios
+    w, h = 1280, 720
+    K = np.array([[900.0, 0, 600.0], [0, 910.0, 380.0], [0, 0, 1]])
+    pts = np.array([[0.0, 0.0], [w, h], [333.0, 77.0]])
+    np.testing.assert_allclose(calib.undistort_points(pts, K, np.zeros(4), K), pts, atol=1e-9)
+    new, roi = calib.optimal_new_camera_matrix(K, np.zeros(4), (w, h), alpha=0.0)
+    cx, cy = (w - 1) / 2, (h - 1) / 2
+    s = max(cx / 600.0, cy / 380.0, cx / (w - 600.0), cy / (h - 380.0))
+    np.testing.assert_allclose([new[0, 0], new[1, 1], new[0, 2], new[1, 2]], [900.0 * s, 910.0 * s, cx, cy], rtol=1e-6)
+    assert roi[0] >= 0 and roi[1] >= 0 and roi[0] + roi[2] <= w and roi[1] + roi[3] <= h
+    # radial + tangential distortion: the fixed-point iteration inverts the forward model
+    d = np.array([-0.12, 0.04, 1.5e-3, -8e-4])
+    xy = np.random.default_rng(0).uniform(-0.45, 0.45, size=(50, 2))
+    r2 = (xy ** 2).sum(-1)
+    rad = 1 + d[0] * r2 + d[1] * r2 ** 2
+    xd = xy[:, 0] * rad + 2 * d[2] * xy[:, 0] * xy[:, 1] + d[3] * (r2 + 2 * xy[:, 0] ** 2)
+    yd = xy[:, 1] * rad + d[2] * (r2 + 2 * xy[:, 1] ** 2) + 2 * d[3] * xy[:, 0] * xy[:, 1]
+    pix = np.stack([xd * K[0, 0] + K[0, 2], yd * K[1, 1] + K[1, 2]], -1)
+    want = np.stack([xy[:, 0] * K[0, 0] + K[0, 2], xy[:, 1] * K[1, 1] + K[1, 2]], -1)
+    np.testing.assert_allclose(calib.undistort_points(pix, K, d, K), want, atol=0.05)       # five iterations: ~1e-2 px
+    np.testing.assert_allclose(calib.undistort_points(pix, K, d, K, iters=40), want, atol=1e-6)
+    # barrel distortion (k1 < 0): the undistorted border bulges outwards, so the inscribed rectangle is the frame's own
+    # corners' hull shrunk -- alpha = 0 must zoom IN relative to the undistorted bounding rectangle (alpha = 1)
+    n0, _ = calib.optimal_new_camera_matrix(K, d, (w, h), alpha=0.0)
+    n1, _ = calib.optimal_new_camera_matrix(K, d, (w, h), alpha=1.0)
+    assert n0[0, 0] > n1[0, 0] and n0[1, 1] > n1[1, 1] and n0[0, 2] == n1[0, 2] == cx
+    # and the dataset takes the file
     ind = os.path.join(golden_dir, "eval_inputs")
-    with pytest.raises(NotImplementedError, match="OpenCV"):
-        D.TestDataset(dict(cam_path=str(tmp_path / "calib.txt"), cano_cam_path=os.path.join(ind, "cano_camera.npz"),
-                           metadata_path=os.path.join(ind, "novel_pose.npz"), contact_render_type="acc_gt_eval"))
+    ds = D.TestDataset(dict(cam_path=str(path), cano_cam_path=os.path.join(ind, "cano_camera.npz"), width=w, height=h,
+                            metadata_path=os.path.join(ind, "novel_pose.npz"), contact_render_type="acc_gt_eval"))
+    assert [i[3] for i in ds.infos] == sorted(r[11] for r in rows)       # the file's camera names label the items (:597)
+    tab = calib.camera_table_from_calibration(str(path), w, h)
+    np.testing.assert_allclose(np.asarray(ds.all_cameras.K)[:, 0, 0], [k[0] for k in tab["intrs"]], rtol=1e-6)
+    assert len(ds) > 0 and "camera" in ds[0]
