@@ -364,6 +364,17 @@ int mgr_image_loss_tiles(int V, int H, int W, const float* pred, const float* ta
  * workspace; the caller orders it after both the list and the blend). */
 int mgr_image_loss_tiles_list(int V, int H, int W, const float* target, const float* bg3, const uint32_t* tile_start,
                               void* workspace, size_t workspace_bytes, void* stream);
+/* The span list without reading the targets.  mgr_image_loss_target_map computes, once per set of target images and
+ * background colour, the column masks the list is derived from (mgr_image_loss_target_map_words(V,H,W) uint32);
+ * mgr_image_loss_tiles_list_mapped then builds the list of mgr_image_loss_tiles_list from those masks and the forward's tile
+ * offsets.  Same list, same sums and gradients; a target image is a constant of its view (the reference reads it from the
+ * dataset every step, src/modules/base.py:323-365). */
+size_t mgr_image_loss_target_map_words(int V, int H, int W);
+int mgr_image_loss_target_map(int V, int H, int W, const float* target, const float* bg3, uint32_t* map, void* stream);
+int mgr_image_loss_tiles_list_mapped(int V, int H, int W, const uint32_t* map, const float* bg3, const uint32_t* tile_start,
+                                     void* workspace, size_t workspace_bytes, int workspace_kept, void* stream);
+/* workspace_kept != 0: the workspace was zero-filled when allocated and has only been used by list / finish pairs since (the
+ * finish pass leaves its list counter zero): the 4-byte memset per call is skipped. */
 int mgr_image_loss_tiles_finish(int V, int H, int W, const float* pred, const float* target, float w_l1, float w_ssim,
                                 float grad_scale, float loss_offset, float* dL_dpred, float* sums, void* workspace,
                                 size_t workspace_bytes, void* stream);

@@ -317,7 +317,11 @@ __global__ __launch_bounds__(ILS_T) void k_image_loss_scan(int H, int W, int gxb
 __global__ __launch_bounds__(ILS_T) void k_image_loss_list(int H, int W, int gxb, const float* __restrict__ target,
                                                            const float* __restrict__ bg, const uint32_t* __restrict__ tile_start,
                                                            float2* __restrict__ partial, uint32_t* __restrict__ work_list,
-                                                           uint32_t* __restrict__ work_count) {
+                                                           uint32_t* __restrict__ work_count, const uint32_t* __restrict__ tmap,
+                                                           uint32_t* __restrict__ tmap_out) {
+    // tmap: the column masks below, computed by an earlier call for the same target and background (tmap_out) -- a target
+    // image is a constant of its view, so a caller that renders the view again hands the masks back instead of having
+    // 24 bytes per pixel of target read per step (mgr_image_loss_target_map / mgr_image_loss_tiles_list_mapped)
     __shared__ uint32_t s_diff[ILS_MAXW / 32];   // bit w: target column w differs from the background in some channel / row
     __shared__ uint32_t s_cand[(ILS_MAXW / IL_W + 32) / 32];   // bit b: every tile under span b is empty
     __shared__ uint32_t s_n, s_base;
@@ -330,9 +334,11 @@ __global__ __launch_bounds__(ILS_T) void k_image_loss_list(int H, int W, int gxb
     const int nwords = (W + 31) / 32;
     const int gxt = (W + 15) / 16, T = gxt * ((H + 15) / 16);
     const uint32_t* trow = tile_start + (size_t)v * T + (size_t)(h0 >> 4) * gxt;   // both rows of the pair lie in this tile row
-    for (int k = tid; k < nwords; k += ILS_T) s_diff[k] = 0;
+    const size_t map_row = ((size_t)v * gridDim.x + blockIdx.x) * (size_t)nwords;
+    for (int k = tid; k < nwords; k += ILS_T) s_diff[k] = tmap ? tmap[map_row + k] : 0u;
     if (tid < (int)(sizeof(s_cand) / 4)) s_cand[tid] = 0;
     __syncthreads();
+    if (tile_start)
     for (int b = tid; b < gxb; b += ILS_T) {
         const int lo = max(b * IL_W - 2 * IL_H1, 0), hi = min(b * IL_W + IL_ND, W);  // [lo, hi)
         const int t0 = lo >> 4, t1 = (hi - 1) >> 4;
@@ -343,7 +349,8 @@ __global__ __launch_bounds__(ILS_T) void k_image_loss_list(int H, int W, int gxb
     const int rows = row1 ? 2 : 1;
     const float b0 = bg[0], b1 = bg[1], b2 = bg[2];
     const bool vec = (W & 3) == 0 && (((uintptr_t)target) & 15) == 0;
-    if (vec) {
+    if (tmap) {
+    } else if (vec) {
         const int n4 = W >> 2;
         for (int q = tid; q < n4; q += ILS_T) {
             uint32_t d = 0;
@@ -364,6 +371,10 @@ __global__ __launch_bounds__(ILS_T) void k_image_loss_list(int H, int W, int gxb
         }
     }
     __syncthreads();
+    if (tmap_out) {
+        for (int k = tid; k < nwords; k += ILS_T) tmap_out[map_row + k] = s_diff[k];
+        if (!tile_start) return;     // (map only)
+    }
     // classify; the listed spans of the row pair take ONE slot range of the global list (one returning atomic per
     // workgroup: thousands of them on a single counter cost more than reading the target)
     uint32_t my_rank[(ILS_MAXW / IL_W + ILS_T) / ILS_T];
@@ -394,9 +405,61 @@ __global__ __launch_bounds__(ILS_T) void k_image_loss_list(int H, int W, int gxb
             work_list[s_base + my_rank[nmine]] = ((uint32_t)v * gridDim.x + blockIdx.x) * (uint32_t)gxb + (uint32_t)b;
 }
 
+// The same classification from precomputed column masks (tmap: what k_image_loss_list leaves in tmap_out): one thread per
+// (row pair, span), ILM_R row pairs per workgroup -- the list kernel above spends its time on one returning atomic per row
+// pair, all on one counter (4320 of them at 8 views of 1080p: 31 us for a few kilobytes of work); here a workgroup
+// collects its listed spans in LDS and takes ONE slot range.
+#define ILM_R 8
+__global__ __launch_bounds__(ILS_T) void k_image_loss_list_mapped(int H, int W, int gxb, int HP, const uint32_t* __restrict__ tmap,
+                                                                  const uint32_t* __restrict__ tile_start,
+                                                                  float2* __restrict__ partial, uint32_t* __restrict__ work_list,
+                                                                  uint32_t* __restrict__ work_count) {
+    __shared__ uint32_t s_n, s_base;
+    const int tid = threadIdx.x, v = blockIdx.y;
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    const int nwords = (W + 31) / 32;
+    const int gxt = (W + 15) / 16, T = gxt * ((H + 15) / 16);
+    const int n_items = ILM_R * gxb;
+    constexpr int PER = (ILM_R * ((ILS_MAXW + IL_W - 1) / IL_W) + ILS_T - 1) / ILS_T;
+    uint32_t my_rank[PER], my_bid[PER];
+    int nmine = 0;
+    for (int it = tid; it < n_items; it += ILS_T, ++nmine) {
+        const int rp = blockIdx.x * ILM_R + it / gxb, b = it % gxb;
+        my_rank[nmine] = 0xFFFFFFFFu;
+        my_bid[nmine] = 0;
+        if (rp >= HP) continue;
+        const int h0 = rp * 2, rows = h0 + 1 < H ? 2 : 1;
+        const uint32_t* trow = tile_start + (size_t)v * T + (size_t)(h0 >> 4) * gxt;
+        const int lo = max(b * IL_W - 2 * IL_H1, 0), hi = min(b * IL_W + IL_ND, W);  // [lo, hi)
+        uint32_t any = trow[((hi - 1) >> 4) + 1] == trow[lo >> 4] ? 0u : 1u;   // some tile under the span holds Gaussians
+        const uint32_t* mrow = tmap + ((size_t)v * HP + rp) * (size_t)nwords;
+        for (int k = lo >> 5; k <= (hi - 1) >> 5 && !any; ++k) {
+            uint32_t m = mrow[k];
+            const int base = k << 5;
+            if (lo > base) m &= ~0u << (lo - base);
+            if (hi < base + 32) m &= ~0u >> (base + 32 - hi);
+            any |= m;
+        }
+        const uint32_t bid = ((uint32_t)v * (uint32_t)HP + (uint32_t)rp) * (uint32_t)gxb + (uint32_t)b;
+        my_bid[nmine] = bid;
+        if (any) my_rank[nmine] = atomicAdd(&s_n, 1u);
+        else {
+            const int wcnt = min((b + 1) * IL_W, W) - b * IL_W;
+            partial[bid] = make_float2(0.f, (float)(wcnt * 3 * rows));
+        }
+    }
+    __syncthreads();
+    if (tid == 0 && s_n) s_base = atomicAdd(work_count, s_n);
+    __syncthreads();
+    for (int k = 0; k < nmine; ++k)
+        if (my_rank[k] != 0xFFFFFFFFu) work_list[s_base + my_rank[k]] = my_bid[k];
+}
+
 // fold the per-workgroup sums: sums[0] = sum |pred - target|, sums[1] = sum of the SSIM map
 __global__ __launch_bounds__(1024) void k_image_loss_fold(int64_t n, const float2* __restrict__ partial,
-                                                          float* __restrict__ sums, float ca, float cb, float cc) {
+                                                          float* __restrict__ sums, float ca, float cb, float cc,
+                                                          uint32_t* __restrict__ work_count) {
     __shared__ double s_a[16], s_b[16];
     double a = 0.0, b = 0.0;
     for (int64_t k = threadIdx.x; k < n; k += 1024) {
@@ -423,6 +486,7 @@ __global__ __launch_bounds__(1024) void k_image_loss_fold(int64_t n, const float
         sums[0] = (float)ta;
         sums[1] = (float)tb;
         sums[2] = (float)((double)ca * ta + (double)cb * tb + (double)cc);  // the caller's loss value, no host-side arithmetic
+        *work_count = 0u;   // the list is consumed: a caller that keeps the workspace builds the next one without a memset
     }
 }
 
@@ -435,10 +499,11 @@ extern "C" size_t mgr_image_loss_workspace_bytes(int V, int H, int W) {
 
 static int image_loss_impl(int V, int H, int W, const float* pred, const float* target, const float* bg3,
                            const uint32_t* tile_start, float w_l1, float w_ssim, float grad_scale, float loss_offset,
-                           float* dL_dpred, float* sums, void* workspace, size_t workspace_bytes, void* stream_, int phase = 0) {
+                           float* dL_dpred, float* sums, void* workspace, size_t workspace_bytes, void* stream_, int phase = 0,
+                           const uint32_t* tmap = nullptr, bool clean = false) {
     // phase 0: everything; 1: the span list only (needs target, bg3, tile_start, workspace); 2: the rest, on a list already built
     if (V <= 0 || H <= 0 || W <= 0) return mgr_fail(MGR_EINVAL, "mgr_image_loss: bad sizes");
-    if (!target || !workspace || (phase != 1 && (!pred || !dL_dpred || !sums))) return mgr_fail(MGR_EINVAL, "mgr_image_loss: null pointer");
+    if ((!target && !(phase == 1 && tmap)) || !workspace || (phase != 1 && (!pred || !dL_dpred || !sums))) return mgr_fail(MGR_EINVAL, "mgr_image_loss: null pointer");
     if (H > 65535 || V > 65535) return mgr_fail(MGR_EINVAL, "mgr_image_loss: H and V must fit a grid dimension");
     if (workspace_bytes < mgr_image_loss_workspace_bytes(V, H, W))
         return mgr_fail(MGR_ENOMEM, "mgr_image_loss: workspace too small");
@@ -458,12 +523,16 @@ static int image_loss_impl(int V, int H, int W, const float* pred, const float* 
     uint32_t* work_list = (uint32_t*)((char*)workspace + (size_t)nb * sizeof(float2));
     uint32_t* work_count = (uint32_t*)((char*)workspace + (size_t)nb * (sizeof(float2) + sizeof(uint32_t)) + 64);
     if (W > ILS_MAXW) return mgr_fail(MGR_EINVAL, "mgr_image_loss: image wider than 16384");
-    if (phase != 2) MGR_HIP(hipMemsetAsync(work_count, 0, 4, stream));
+    if (phase != 2 && !clean) MGR_HIP(hipMemsetAsync(work_count, 0, 4, stream));
     if (phase == 2) {
+    } else if (tile_start && tmap) {
+        MGR_PROF("k_image_loss_list", stream);
+        hipLaunchKernelGGL(k_image_loss_list_mapped, dim3((grid.y + ILM_R - 1) / ILM_R, V), dim3(ILS_T), 0, stream, H, W, (int)grid.x,
+                           (int)grid.y, tmap, tile_start, partial, work_list, work_count);
     } else if (tile_start) {
         MGR_PROF("k_image_loss_list", stream);
         hipLaunchKernelGGL(k_image_loss_list, dim3(grid.y, V), dim3(ILS_T), 0, stream, H, W, (int)grid.x, target, bg3, tile_start,
-                           partial, work_list, work_count);
+                           partial, work_list, work_count, tmap, (uint32_t*)nullptr);
     } else {
         MGR_PROF("k_image_loss_scan", stream);
         hipLaunchKernelGGL(k_image_loss_scan, dim3(grid.y, V), dim3(ILS_T), 0, stream, H, W, (int)grid.x, pred, target, dL_dpred,
@@ -478,7 +547,7 @@ static int image_loss_impl(int V, int H, int W, const float* pred, const float* 
                            (int)grid.x, (int)grid.y);
     }
     hipLaunchKernelGGL(k_image_loss_fold, dim3(1), dim3(1024), 0, stream, il_blocks(V, H, W), (const float2*)workspace,
-                       sums, grad_scale * w_l1, -grad_scale * w_ssim, loss_offset);
+                       sums, grad_scale * w_l1, -grad_scale * w_ssim, loss_offset, work_count);
     MGR_LAUNCH_CHECK("k_image_loss", stream, 0);
     return MGR_OK;
 }
@@ -512,4 +581,31 @@ extern "C" int mgr_image_loss_tiles_finish(int V, int H, int W, const float* pre
                                            size_t workspace_bytes, void* stream_) {
     return image_loss_impl(V, H, W, pred, target, nullptr, nullptr, w_l1, w_ssim, grad_scale, loss_offset, dL_dpred, sums,
                            workspace, workspace_bytes, stream_, 2);
+}
+
+/* The target-vs-background column masks of V target images (what the span list of mgr_image_loss_tiles derives from the
+ * target every call): V x ceil(H / 2) x ceil(W / 32) words.  A target image is a constant of its view: a caller that renders
+ * the same views again computes the masks once and builds the list from them (mgr_image_loss_tiles_list_mapped) without
+ * reading the targets. */
+extern "C" size_t mgr_image_loss_target_map_words(int V, int H, int W) {
+    if (V <= 0 || H <= 0 || W <= 0) return 0;
+    return (size_t)V * ((H + 1) / 2) * ((W + 31) / 32);
+}
+
+extern "C" int mgr_image_loss_target_map(int V, int H, int W, const float* target, const float* bg3, uint32_t* map, void* stream_) {
+    if (V <= 0 || H <= 0 || W <= 0) return mgr_fail(MGR_EINVAL, "mgr_image_loss_target_map: bad sizes");
+    if (!target || !bg3 || !map) return mgr_fail(MGR_EINVAL, "mgr_image_loss_target_map: null pointer");
+    if (H > 65535 || V > 65535 || W > ILS_MAXW) return mgr_fail(MGR_EINVAL, "mgr_image_loss_target_map: image too large");
+    hipLaunchKernelGGL(k_image_loss_list, dim3((H + 1) / 2, V), dim3(ILS_T), 0, (hipStream_t)stream_, H, W, (W + IL_W - 1) / IL_W,
+                       target, bg3, (const uint32_t*)nullptr, (float2*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                       (const uint32_t*)nullptr, map);
+    MGR_LAUNCH_CHECK("k_image_loss_list", (hipStream_t)stream_, 0);
+    return MGR_OK;
+}
+
+extern "C" int mgr_image_loss_tiles_list_mapped(int V, int H, int W, const uint32_t* map, const float* bg3, const uint32_t* tile_start,
+                                                void* workspace, size_t workspace_bytes, int workspace_kept, void* stream_) {
+    if (!map || !bg3 || !tile_start) return mgr_fail(MGR_EINVAL, "mgr_image_loss_tiles_list_mapped: null pointer");
+    return image_loss_impl(V, H, W, nullptr, nullptr, bg3, tile_start, 0.f, 0.f, 0.f, 0.f, nullptr, nullptr, workspace,
+                           workspace_bytes, stream_, 1, map, workspace_kept != 0);
 }

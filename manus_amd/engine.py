@@ -336,6 +336,12 @@ class HipViewCompute:
         # overlap_loss: that span list is built on a second stream while the forward blend runs (MANUS_OVERLAP_LOSS=0
         # in the environment switches it off for A/B runs)
         self.overlap_loss, self._side = bool(overlap_loss) and os.environ.get("MANUS_OVERLAP_LOSS", "1") != "0", None
+        # target_map: the span list is derived from column masks "target differs from the background here", which the list
+        # kernel otherwise recomputes from the full target images every step (0.2 GB at 8 views of 1080p).  A target is a
+        # constant of its view: the masks are computed once per view (1 bit per pixel column and row pair, 130 KB per
+        # 1080p view) and the list is built from them, in-stream, in a few microseconds -- no second stream, no forward
+        # split at the blend.  Same list, same loss and gradients.  MANUS_TARGET_MAP=0 switches it off for A/B runs.
+        self.target_map, self._tmaps, self._lws = os.environ.get("MANUS_TARGET_MAP", "1") != "0", {}, {}
         # sh_storage "fp16" (BASELINE config 5): the fused kernels read an fp16 copy of _features_rest (96 B instead of
         # 180 B per Gaussian and view group); arithmetic, gradients and the optimizer's master copy stay fp32.  The copy
         # is refreshed lazily after the leaves changed (`mark_params_changed`).  The reference has no fp16 mode:
@@ -475,6 +481,25 @@ class HipViewCompute:
             off = self._ts_off[key] = [int(x) for x in arr]
         return off
 
+    def _target_map(self, view_ids, sel, bg):
+        """(V, rows / 2, ceil(W / 32)) int32: the target-vs-background column masks of the views (computed once per view)."""
+        m = sel.get("tmap")
+        if m is None:
+            from ._lib import check, lib, ptr, stream
+            H, W = int(self.s["height"]), int(self.s["width"])
+            per = int(lib().mgr_image_loss_target_map_words(1, H, W))
+            rows = []
+            for k, v in enumerate(view_ids):
+                t = self._tmaps.get(v)
+                if t is None:
+                    t = torch.empty(per, dtype=torch.int32, device=self.device)
+                    check(lib().mgr_image_loss_target_map(1, H, W, ptr(sel["targets"][k]), ptr(bg), ptr(t), stream()),
+                          "mgr_image_loss_target_map")
+                    self._tmaps[v] = t
+                rows.append(t)
+            m = sel["tmap"] = torch.stack(rows).contiguous()
+        return m
+
     def _tile_start_ptr(self, ws, V, N, W, H):
         return ws.buf.data_ptr() + self._layout(ws, V, N, W, H)[7]
 
@@ -543,7 +568,8 @@ class HipViewCompute:
 
         # The span list of the image loss needs the forward's tile offsets but not its image: with overlap_loss it is
         # built on a second stream while the forward blend runs (forward split at the blend, debug bits 1 / 2).
-        overlap = g_img is None and self.loss == "l1+ssim" and self.sparse_loss and self.overlap_loss
+        mapped = g_img is None and self.loss == "l1+ssim" and self.sparse_loss and self.target_map
+        overlap = g_img is None and self.loss == "l1+ssim" and self.sparse_loss and self.overlap_loss and not mapped
 
         def fwd(ws, phase):
             check(lib().mgr_views_forward(V, N, B, na, sh_half, W, H, ptr(cams), ptr(bg), ptr(p["_xyz"]), ptr(p["_scaling"]),
@@ -560,7 +586,25 @@ class HipViewCompute:
         try:
             if not overlap and ctx.fenced(self.sync_check):
                 ctx.fence(ws)
-            if overlap:
+            if mapped:
+                import ctypes
+                tgt = sel["targets"]
+                nbytes = int(lib().mgr_image_loss_workspace_bytes(V, H, W))
+                lws = self._lws.get((V, H, W))      # kept across steps, zero-filled once: list / finish pairs leave it clean
+                if lws is None:
+                    lws = self._lws[(V, H, W)] = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+                g_img = torch.empty_like(out)
+                sums = torch.empty(3, dtype=torch.float32, device=dev)
+                check(lib().mgr_image_loss_tiles_list_mapped(V, H, W, ptr(self._target_map(view_ids, sel, bg)), ptr(bg),
+                                                             ctypes.c_void_p(self._tile_start_ptr(ws, V, N, W, H)),
+                                                             ptr(lws), nbytes, 1, stream()), "mgr_image_loss_tiles_list_mapped")
+                per_view = out[0].numel()
+                k = self.loss_weight * scale / per_view
+                const = self.w_ssim * self.loss_weight * scale * V
+                check(lib().mgr_image_loss_tiles_finish(V, H, W, ptr(out), ptr(tgt), self.w_rgb, self.w_ssim, k, const, ptr(g_img),
+                                                        ptr(sums), ptr(lws), nbytes, stream()), "mgr_image_loss_tiles_finish")
+                loss = sums[2]
+            elif overlap:
                 import ctypes
                 tgt = sel["targets"]
                 nbytes = int(lib().mgr_image_loss_workspace_bytes(V, H, W))

@@ -201,3 +201,68 @@ def test_tile_aware_loss_equals_the_full_comparison():
     frac = float(written.float().mean())
     assert 0.02 < frac < 0.9, frac                      # most of the frame is background and was skipped
     assert written[1, :, 5:9, 440:470].all()            # the target-only foreground was computed (it counts in the loss)
+
+
+def test_span_list_from_target_maps_equals_the_list_from_the_targets():
+    """mgr_image_loss_target_map + mgr_image_loss_tiles_list_mapped (the target's column masks computed once per view) against
+    mgr_image_loss_tiles_list (the masks recomputed from the full targets every call): the same spans listed, the same
+    sums for the unlisted ones, and a training step that is bit for bit the same -- loss included."""
+    import ctypes
+    from manus_amd import rasterizer as rz
+    from manus_amd._lib import check, lib, ptr, stream
+    from manus_amd.engine import HipViewCompute
+    from manus_amd.synthetic import camera_table, make_scene
+    V, W, H, n = 3, 500, 331, 4000      # W not a multiple of 16, 32 or 246; H odd
+    sc = make_scene(n_gaussians=n, kind="hand", seed=9, grid_res=24, n_cameras=V, width=W, height=H, cam_radius=0.9,
+                    sigma_range=(2e-3, 8e-3), device=DEV)
+    ct = camera_table(sc["cameras"], DEV)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    tgt_scene = dict(sc)
+    tgt_scene["params"] = {k: (v + 0.02 * v.abs().mean() * torch.randn(v.shape, generator=g).to(DEV)) for k, v in sc["params"].items()}
+    with torch.no_grad():
+        targets = HipViewCompute(tgt_scene, torch.zeros((V, 3, H, W), device=DEV), ct).forward_views_fused(list(range(V)))[0].contiguous()
+    targets[1, :, 5:9, 440:470] = 0.25          # target foreground where nothing is rendered (empty tiles)
+    targets[2, 1, 330, 499] = 0.5               # ... and in the last column of the last (unpaired) row
+    rz.set_sync_policy(True)
+    res = {}
+    for mapped in (False, True):
+        hc = HipViewCompute(sc, targets, ct, loss="l1+ssim")
+        hc.target_map = mapped
+        out = hc._step_direct(list(range(V)), 1.0 / V)
+        res[mapped] = ({k: v.clone() for k, v in out["grads"].items()}, out["loss"].clone(), hc)
+    for k in res[False][0]:
+        assert torch.equal(res[False][0][k], res[True][0][k]), k
+    assert torch.equal(res[False][1], res[True][1])
+    # the two list builders on the last forward's tile offsets
+    hc = res[True][2]
+    ws = rz.context().last_ws
+    ts_ptr = ctypes.c_void_p(hc._tile_start_ptr(ws, V, n, W, H))
+    nbytes = int(lib().mgr_image_loss_workspace_bytes(V, H, W))
+    nb = V * ((H + 1) // 2) * ((W + 245) // 246)
+    lists = []
+    words = int(lib().mgr_image_loss_target_map_words(V, H, W))
+    assert words == V * ((H + 1) // 2) * ((W + 31) // 32)
+    tmap = torch.empty(words, dtype=torch.int32, device=DEV)
+    check(lib().mgr_image_loss_target_map(V, H, W, ptr(targets), ptr(sc["bg"]), ptr(tmap), stream()), "mgr_image_loss_target_map")
+    assert torch.equal(tmap.view(V, -1), hc._target_map(list(range(V)), hc._select(list(range(V))), sc["bg"]).view(V, -1))
+    for use_map in (False, True):
+        wsb = torch.full((nbytes,), 0xAB, dtype=torch.uint8, device=DEV)
+        if use_map:
+            check(lib().mgr_image_loss_tiles_list_mapped(V, H, W, ptr(tmap), ptr(sc["bg"]), ts_ptr, ptr(wsb), nbytes, 0, stream()), "list_mapped")
+        else:
+            check(lib().mgr_image_loss_tiles_list(V, H, W, ptr(targets), ptr(sc["bg"]), ts_ptr, ptr(wsb), nbytes, stream()), "list")
+        count = int(wsb[nb * 12 + 64: nb * 12 + 68].view(torch.int32).item())
+        work = wsb[nb * 8: nb * 8 + 4 * count].view(torch.int32).sort().values.cpu()
+        partial = wsb[: nb * 8].view(torch.float32).view(nb, 2).cpu()
+        lists.append((count, work, partial))
+    assert lists[0][0] == lists[1][0] and 0 < lists[0][0] < nb
+    assert torch.equal(lists[0][1], lists[1][1])
+    listed = torch.zeros(nb, dtype=torch.bool)
+    listed[lists[0][1].long()] = True
+    assert torch.equal(lists[0][2][~listed], lists[1][2][~listed])     # (the listed spans' sums are written by the finish pass)
+    # the map marks exactly the columns where the target differs from the background in some channel of the row pair
+    diff = (targets != sc["bg"].view(1, 3, 1, 1)).any(1)                                   # (V, H, W)
+    diff = torch.nn.functional.pad(diff, (0, (-W) % 32, 0, H % 2))
+    diff = (diff[:, 0::2] | diff[:, 1::2]).view(V, (H + 1) // 2, -1, 32)
+    want = (diff.long() << torch.arange(32, device=DEV)).sum(-1)
+    assert torch.equal(want, tmap.view(V, (H + 1) // 2, -1).long() & 0xFFFFFFFF)
