@@ -588,7 +588,9 @@ def main():
                                      "per-tile saturation depth of the previous forward of the same views bounds the binning; exact "
                                      "(flagged and re-run without it when a cut list runs out): %d flagged forwards in this run"
                                      % rasterizer.context(dev).cut_retries),
-                       "loss_span_list": "full comparison of rendered and target image" if args.dense_loss_scan else "tile occupancy of the forward + target background",
+                       "loss_span_list": ("full comparison of rendered and target image" if args.dense_loss_scan else
+                                          "tile occupancy of the forward + per-view target-vs-background column masks (computed once per view)"
+                                          if compute.target_map else "tile occupancy of the forward + target background"),
                        "nonfinite_grad_values": nonfinite},
             "roofline": roof, "cpu_baseline": cpu, "parity": parity,
         }

@@ -190,41 +190,29 @@ __device__ __forceinline__ void pre_tail(int N, int gx, int gy, int v, int i, co
         // previous forward of this view leaves out the instances behind zc -- they sit behind the stop of every pixel
         // unless the scene changed, which the blend detects (MGR_OVF_CUT) and the caller answers by a forward without the
         // cut.  Stored value = ~(float bits of zc), 0 = no cut; depths are positive, so their bits order like the floats.
-        // Two passes, so that the table lookups do not sit one behind the other in the cull loop: the null-tile test
-        // first (arithmetic only), then the surviving tiles four at a time.  (Rectangles of more than 64 tiles have no mask
-        // and are never cut.)
+        // The lookup of the next tile is issued before the current one is tested, so that the loop does not wait a memory
+        // round trip per tile.  (Measured: lookups behind the test of their own tile +16 us on k_inst_fwd; two passes -- the
+        // null-tile test, then the survivors' lookups four at a time -- +8 us, 15 % more VALU instructions.  Rectangles of
+        // more than 64 tiles have no mask and are never cut.)
         const MgrCull cull = mgr_cull_init(po.px, po.py, po.ca, po.cb, po.cc, mgr_qmax(op_i));
-        unsigned long long m = 0ull;
+        const uint32_t zbits = __float_as_uint(po.zv);
+        amask = 0ull;
         int k = 0;
+        uint32_t zc = tiles ? zcut_v[y0 * gx + x0] : 0u;      // (the lookup of tile k + 1 is in flight while tile k is tested)
         for (int y = y0; y < y1; ++y) {
             float dy_lo, dy_hi, dxo;
             mgr_cull_row(cull, 16.0f * y, 16.0f * y + 15.0f, dy_lo, dy_hi, dxo);
-            for (int x = x0; x < x1; ++x, ++k)
-                if (!mgr_cull_dead(cull, dy_lo, dy_hi, dxo, 16.0f * x, 16.0f * x + 15.0f)) m |= 1ull << k;
-        }
-        const uint32_t zbits = __float_as_uint(po.zv);
-        const int w = x1 - x0;
-        const float rw = 1.0f / (float)w;
-        amask = 0ull;
-        while (m) {
-            int kk[4], tt[4];
-            uint32_t zc[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                kk[j] = m ? __builtin_ctzll(m) : -1;
-                m &= m - 1ull;                                        // (0 stays 0)
-                const int ky = (int)(((float)max(kk[j], 0) + 0.5f) * rw);   // k / w, exact for k < 64
-                tt[j] = (y0 + ky) * gx + x0 + (max(kk[j], 0) - ky * w);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) zc[j] = zcut_v[tt[j]];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (kk[j] >= 0 && zbits <= ~zc[j]) {
-                    amask |= 1ull << kk[j];
-                    if (lds_hist) atomicAdd(&s_hist[tt[j]], 1u);
-                    else atomicAdd(&tile_count[(size_t)v * T + tt[j]], 1u);
+            for (int x = x0; x < x1; ++x, ++k) {
+                const bool wrap = x + 1 == x1;
+                const int nx = wrap ? x0 : x + 1, ny = wrap ? y + 1 : y;
+                const uint32_t zn = zcut_v[min(ny, y1 - 1) * gx + nx];
+                const bool dead = mgr_cull_dead(cull, dy_lo, dy_hi, dxo, 16.0f * x, 16.0f * x + 15.0f);
+                if (!dead && zbits <= ~zc) {
+                    amask |= 1ull << k;
+                    if (lds_hist) atomicAdd(&s_hist[y * gx + x], 1u);
+                    else atomicAdd(&tile_count[(size_t)v * T + y * gx + x], 1u);
                 }
+                zc = zn;
             }
         }
     }
