@@ -205,6 +205,12 @@ int mgr_raster_layout(int V, int N, int W, int H, int64_t pair_capacity, size_t*
 /* Blocking read-back of the workspace header after a forward: total number of
  * (Gaussian, tile) pairs (`num_rendered`, summed over views) and the overflow
  * flag.  Returns MGR_EOVERFLOW when the flag is set. */
+/* Margins of the depth-cut hints the forwards of this host thread leave (debug bit 8): a tile keeps the entries its walks
+ * used plus max(min_entries, frac_entries x that many), and at least the depth of the last one plus depth_range_frac of the
+ * walked depth range plus depth_rel of that depth.  interior_only: hints only for tiles whose eight neighbours saturated
+ * too (a silhouette tile stops saturating when an edge moves by a fraction of a pixel).  Defaults 0.125, 64, 0.0625, 2e-4, 0.
+ * Wider margins: more pairs binned, fewer forwards flagged MGR_ECUT when the model moves between two forwards of a view. */
+int mgr_raster_set_cut_margin(float frac_entries, int min_entries, float depth_range_frac, float depth_rel, int interior_only);
 /* Status without a copy: `host_words` points to 4 uint32 of host memory the device can write (hipHostMalloc / pinned
  * memory); the next forward that runs the blend on `workspace` writes (pair total, overflow word, binning tiers, 1) there
  * from its last kernel.  An event recorded behind that forward then tells the host when the words are valid -- no

@@ -120,7 +120,10 @@ struct MgrLayout {
 // Depth-ordered binning (raster_fwd.hip, "ordered" route): the instances of a view are sorted by depth once, then
 // scattered to the tile lists in that order, instead of sorting every tile list.
 #define MGR_DB_BUCKETS 8192   // depth buckets per view of the instance sort (1024 per octave of z above the 0.2 cull plane)
-#define MGR_BIN_BLOCK 1024    // depth-consecutive instances per row of the (block, tile) count matrix (at most)
+#ifndef MGR_BIN_BLOCK
+#define MGR_BIN_BLOCK 1024
+#endif
+// MGR_BIN_BLOCK:    // depth-consecutive instances per row of the (block, tile) count matrix (at most)
 // rows of 256 instances when there are few instances in all (one or two views per rank): k_bin_scatter runs one wave per row
 static inline int mgr_bin_block(int V, int N) { return (long long)V * (long long)N >= 500000ll ? MGR_BIN_BLOCK : 256; }
 

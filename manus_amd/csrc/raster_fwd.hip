@@ -2054,23 +2054,31 @@ __global__ __launch_bounds__(256) FWD_OCC void k_blend_fwd(int N, int W, int H, 
 //
 // Depth cut: the same thread leaves the tile's hint for the NEXT forward in tile_zcut.  A tile whose every pixel had stopped
 // by list position e (tile_qend) needs its entries up to e only; the hint keeps everything up to the depth
-//   zc = max(z_e + MGR_CUT_RANGE (z_e - z_0) + MGR_CUT_REL z_e,  z of entry e + 63)
-// (z_0, z_e: depth of the first entry and of entry e - 1) and lets the next forward drop what lies behind: a margin in
-// depth and in entries for whatever moved in between.  (The bench scene packs ~270 list entries per millimetre of depth
+//   zc = max(z_e + range (z_e - z_0) + rel z_e,  z of entry e + max(min_entries, frac e))
+// (z_0, z_e: depth of the first entry and of entry e - 1; the four margins: mgr_raster_set_cut_margin) and lets the next
+// forward drop what lies behind: a margin in depth and in entries for whatever moved in between -- an optimizer step moves
+// every opacity logit by its learning rate, so the walks of a deep tile lengthen by a percent or two of their length per
+// step: the entry margin is proportional to the walk, and the engine widens all four when a forward is flagged.  (The bench scene packs ~270 list entries per millimetre of depth
 // into its deep tiles: with 1/4 of the range and z / 500 the cut kept 56 % of the saturating tiles' pairs where the walks
 // end after 18 %; tools/instr/cut_stats.py.)  A list already cut that ends inside that margin keeps at least its
 // cut; an uncut one that does is needed whole.  Unsaturated tiles (silhouette, thin parts) get no hint.
-#ifndef MGR_CUT_RANGE
-#define MGR_CUT_RANGE 0.0625f
-#endif
-#ifndef MGR_CUT_REL
-#define MGR_CUT_REL 2.0e-4f
-#endif
+// margins of the depth-cut hints (per host thread; see k_fwd_items)
+static thread_local float g_cut_frac = 0.125f, g_cut_range = 0.0625f, g_cut_rel = 2.0e-4f;
+static thread_local int g_cut_min = 64, g_cut_interior = 0;
+extern "C" int mgr_raster_set_cut_margin(float frac_entries, int min_entries, float depth_range_frac, float depth_rel,
+                                         int interior_only) {
+    if (!(frac_entries >= 0.f) || min_entries < 0 || !(depth_range_frac >= 0.f) || !(depth_rel >= 0.f))
+        return mgr_fail(MGR_EINVAL, "mgr_raster_set_cut_margin: margins must be non-negative");
+    g_cut_frac = frac_entries; g_cut_min = min_entries; g_cut_range = depth_range_frac; g_cut_rel = depth_rel;
+    g_cut_interior = interior_only ? 1 : 0;
+    return MGR_OK;
+}
 __global__ __launch_bounds__(256) void k_fwd_items(const uint4* __restrict__ tile_qrec, const uint32_t* __restrict__ tile_qdone,
                                                    uint32_t* __restrict__ tile_done, uint4* __restrict__ items, MgrHeader* hdr,
                                                    int N, int T, const uint32_t* __restrict__ sorted_gid, const float* __restrict__ depth,
                                                    const uint32_t* __restrict__ tile_zused, const uint32_t* __restrict__ tile_qend,
-                                                   uint32_t* __restrict__ tile_zcut, uint32_t* mirror) {
+                                                   uint32_t* __restrict__ tile_zcut, uint32_t* mirror, float cut_frac, uint32_t cut_min,
+                                                   float cut_range, float cut_rel, int gx, int interior_only) {
     __shared__ uint32_t s_scan[8];
     __shared__ uint32_t s_base;
     __shared__ uint32_t s_run[257];
@@ -2101,13 +2109,33 @@ __global__ __launch_bounds__(256) void k_fwd_items(const uint4* __restrict__ til
         nch = (tmax + MGR_CHUNK - 1) / MGR_CHUNK;
         const uint32_t e = tile_qend[qr.x], nl = qr.z, used = tile_zused[qr.x];
         uint32_t hint = 0u;
-        if (e != 0xFFFFFFFFu && e > 0u && e <= nl && (e + 64u <= nl || used != 0u)) {
+        const uint32_t em = e + max(cut_min, (uint32_t)(cut_frac * (float)e));   // entries kept: the walk's + the margin
+        // interior_only: all eight neighbours saturated as well (an empty neighbour shows the background).  A tile at the
+        // silhouette stops saturating when an edge moves by a fraction of a pixel -- no margin helps a pixel that sees
+        // through -- and with the optimizer in the loop some such tile flagged nearly every step (measured: 253 of 255);
+        // the engine asks for it once a forward has been flagged.
+        bool interior = e != 0xFFFFFFFFu && e > 0u;
+        if (interior && interior_only) {
+            const uint32_t t = qr.x % (uint32_t)T, vbase = qr.x - t;
+            const int tx = (int)(t % (uint32_t)gx), ty = (int)(t / (uint32_t)gx), gy = T / gx;
+            for (int dy = -1; dy <= 1; ++dy)
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int x = tx + dx, y = ty + dy;
+                    if ((dx | dy) == 0 || x < 0 || y < 0 || x >= gx || y >= gy) continue;
+                    const uint32_t q2 = tile_qend[vbase + (uint32_t)(y * gx + x)];
+                    interior = interior && q2 != 0xFFFFFFFFu && q2 != 0u;
+                }
+        }
+        if (interior && e <= nl && (em <= nl || used != 0u)) {
             const uint32_t* sg = sorted_gid + qr.y;
             const float* dv = depth + (size_t)(qr.x / (uint32_t)T) * N;
-            const uint32_t g0 = sg[0], ge = sg[e - 1u], gm = sg[min(e + 63u, nl - 1u)];
+            const uint32_t g0 = sg[0], ge = sg[e - 1u], gm = sg[min(em, nl) - 1u];
             const float z0 = dv[g0], ze = dv[ge], zm = dv[gm];
-            float zc = ze + MGR_CUT_RANGE * (ze - z0) + MGR_CUT_REL * ze;
-            zc = fmaxf(zc, e + 64u <= nl ? zm : __uint_as_float(~used));
+            float zc = ze + cut_range * (ze - z0) + cut_rel * ze;
+            // a list already cut that ends inside the margin has no entry to read the margin's depth from: extrapolate it
+            // from the walk's own depth per entry (x 1.5), and never move the cut forward
+            const float zx = fmaxf(__uint_as_float(~used), ze + 1.5f * (float)(em - e) * (ze - z0) / (float)e);
+            zc = fmaxf(zc, em <= nl ? zm : zx);
             hint = ~__float_as_uint(zc);
         }
         tile_zcut[qr.x] = hint;
@@ -2387,7 +2415,8 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
     { MGR_PROF("k_fwd_items", stream); hipLaunchKernelGGL(k_fwd_items, dim3((VT + 255) / 256), dim3(256), 0, stream, (const uint4*)(ws + L.tile_qrec),
                        (const uint32_t*)(ws + L.tile_qdone), (uint32_t*)(ws + L.tile_done), (uint4*)(ws + L.items), hdr,
                        N, T, (const uint32_t*)(ws + L.sorted_gid), (const float*)(ws + L.depth), (const uint32_t*)(ws + L.tile_zused),
-                       (const uint32_t*)(ws + L.tile_qend), (uint32_t*)(ws + L.tile_zcut), mgr_take_status_mirror(workspace)); }
+                       (const uint32_t*)(ws + L.tile_qend), (uint32_t*)(ws + L.tile_zcut), mgr_take_status_mirror(workspace),
+                       g_cut_frac, (uint32_t)g_cut_min, g_cut_range, g_cut_rel, gx, g_cut_interior); }
     MGR_LAUNCH_CHECK("k_blend_fwd", stream, debug);
     return MGR_OK;
 }

@@ -329,6 +329,18 @@ class HipViewCompute:
         # the environment switches it off for A/B runs.
         self.depth_cut = bool(depth_cut) and os.environ.get("MANUS_DEPTH_CUT", "1") != "0"
         self._cut_store, self._cut_max, self._cut_gen, self._cut_bit = {}, int(max_cut_hints), 0, 0
+        # A flagged forward costs a whole step, and with the optimizer in the loop no margin prevents them all: a pixel whose
+        # transmittance ends just under the threshold needs many more entries after the slightest change (measured on the
+        # bench scene with Adam at the reference's learning rates: a flagged forward every ~30 steps at 4x the margins).  So
+        # the cut backs off: a flagged forward doubles the margins (every clean one takes 2 % off again, 1x .. 32x the
+        # library's defaults), restricts the hints to interior tiles, and suspends the cut for `backoff` forwards -- 4, then
+        # 8, ... up to 512; 32 clean forwards in a row halve it again.  A model that stands still between two forwards of its
+        # views (fwd+bwd benchmarks, evaluation sweeps, several losses on one state) keeps the cut on; one that moves every
+        # step ends up trying it every few hundred steps, at a cost below the run-to-run noise.  Hints that have seen more
+        # than `cut_max_age` parameter updates are not used at all (a dataset of thousands of views revisits each once per
+        # epoch: the forward then simply runs uncut and leaves fresh hints).
+        self._cut_scale, self._cut_seen, self.cut_max_age, self._cut_clock, self._cut_born = 1.0, 0, 16, 0, {}
+        self._cut_pause, self._cut_backoff, self._cut_clean = 0, 4, 0
         # sparse_loss: the fused step hands the forward's tile-list offsets to the image loss, which then settles the
         # spans under empty tiles from the target alone (exact: the rasterizer writes the background colour there) and
         # leaves their gradient unwritten (the backward never reads it).  False: the loss reads both images everywhere.
@@ -389,6 +401,7 @@ class HipViewCompute:
     def mark_params_changed(self):
         """The leaves were updated in place (optimizer step): derived storage copies are stale."""
         self._sh_dirty = True
+        self._cut_clock += 1
 
     def _sh_storage(self, f_rest):
         """(pointer source tensor, sh_half flag) for the fused kernels."""
@@ -512,6 +525,17 @@ class HipViewCompute:
         key = (id(self), self._cut_gen, tuple(view_ids))
         prev = ws.prev_hint_key
         ws.hint_key = key
+        from ._lib import lib
+        ctx = self.rz.context(self.device)
+        if ctx.cut_retries != self._cut_seen:          # a forward of ours was flagged since the last launch
+            self._cut_seen, self._cut_scale = ctx.cut_retries, min(32.0, self._cut_scale * 2.0)
+            self._cut_pause, self._cut_backoff, self._cut_clean = self._cut_backoff, min(512, self._cut_backoff * 2), 0
+        else:
+            self._cut_scale = max(1.0, self._cut_scale * 0.98)
+        k = self._cut_scale
+        lib().mgr_raster_set_cut_margin(min(4.0, 0.125 * k), int(64 * k), min(4.0, 0.0625 * k), 2.0e-4 * k, 1 if k > 1.0 else 0)
+        born, self._cut_born[key] = self._cut_born.get(key), self._cut_clock
+        too_old = born is None or self._cut_clock - born > self.cut_max_age
         if prev != key:
             T = ((W + 15) // 16) * ((H + 15) // 16)
             off = self._layout(ws, V, N, W, H)[26]
@@ -528,6 +552,14 @@ class HipViewCompute:
         if ws.cut_block:                  # the previous forward was flagged: this one rebuilds the hints from full lists
             ws.cut_block = False
             return 0
+        if too_old:
+            return 0
+        if self._cut_pause > 0:           # backing off after a flagged forward
+            self._cut_pause -= 1
+            return 0
+        self._cut_clean += 1
+        if self._cut_clean >= 32:
+            self._cut_clean, self._cut_backoff = 0, max(4, self._cut_backoff // 2)
         return 8
 
     # -- fused path, direct C-ABI calls ------------------------------------------------------------
