@@ -1,4 +1,4 @@
-"""Aggregate rocprofv3 counter_collection CSVs: mean counter value per launch for each kernel.
+"""Aggregate rocprofv3 counter_collection CSVs: median counter value per launch for each kernel.
 
 Usage: python tools/pmc_summary.py gpurun_out/pmc_TAG_*  [--json out.json]
 FETCH_SIZE / WRITE_SIZE are reported in KB by rocprofv3; on gfx950 FETCH_SIZE under-reports by 2x
@@ -33,7 +33,9 @@ def main():
             continue
         # (every dispatch of a kernel in the bench process has the same shape: the target images are rendered by one
         # fused launch over all views, bench.py)
-        res[k] = {c: sum(v) / len(v) for c, v in acc[k].items()}
+        # median over the launches: the first two or three steps of the process run with host synchronisation and without the
+        # depth cut (longer lists), the rest is the steady state the bench times
+        res[k] = {c: sorted(v)[len(v) // 2] for c, v in acc[k].items()}
         res[k]["launches"] = max(len(v) for v in acc[k].values())
     cols = sorted({c for k in res for c in res[k] if c != "launches"})
     print("%-22s %8s " % ("kernel", "launches") + " ".join("%16s" % c[:16] for c in cols))
@@ -48,10 +50,11 @@ def main():
             wl = [int(x) for x in sys.argv[sys.argv.index("--workload") + 1].split(",")]
         # one step: every kernel's mean per launch x its launches per step (the dominant backward blend runs once per step)
         steps = max(1, res.get("k_blend_bwd", {}).get("launches", 1))
-        step_bytes = sum(d.get("hbm_bytes_per_launch", 0.0) * d["launches"] / steps for d in res.values())
-        step_ns = sum(d.get("duration_ns", 0.0) * d["launches"] / steps for d in res.values())
+        per_step = lambda d: round(d["launches"] / steps) if d["launches"] * 2 >= steps else 0   # (set-up kernels run a few times per process)
+        step_bytes = sum(d.get("hbm_bytes_per_launch", 0.0) * per_step(d) for d in res.values())
+        step_ns = sum(d.get("duration_ns", 0.0) * per_step(d) for d in res.values())
         json.dump({"workload": wl, "step_hbm_bytes": step_bytes, "step_kernel_ns": step_ns, "source": "rocprofv3 --pmc passes of `python bench.py --steps 4 --warmup 2 --no-cpu-baseline` "
-                   "(tools/pmc_collect.sh: one pass per counter group, never combined with API traces), mean per launch, "
+                   "(tools/pmc_collect.sh: one pass per counter group, never combined with API traces), median per launch, "
                    "summed over XCDs / SEs; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) KB (gfx950 FETCH_SIZE correction, "
                    "MI355X_MICROARCH.md HBM section; gather widths uncalibrated)",
                    "kernels": res}, open(out_json, "w"), indent=1)
