@@ -439,7 +439,9 @@ def main():
     # library kernel with --profile-all (26 bracketed launches per step cost ~0.1 ms of the step).
     # The loop of exactly --steps steps (barrier + synchronize on both sides, MAX over the ranks) is timed REPEATS times:
     # the line carries the median, the spread beside it -- one hiccup in a 40 ms region no longer moves the headline.
-    _lib.profile_enable(True, only=None if args.profile_all else DOMINANT)
+    # (the two events around a launch cost ~6 us of idle GPU each: the dominant kernel is bracketed on every fourth step of
+    # the timed region -- 5 x steps / 4 samples of its duration, all taken inside it)
+    _lib.profile_enable(True, only=None if args.profile_all else DOMINANT, every=1 if args.profile_all else 4)
     dts = []
     for _ in range(REPEATS):
         barrier()
@@ -489,7 +491,7 @@ def main():
                 pmc = {"stale": bool(stale)}
             roof = {"bound": "hbm", "kernel": DOMINANT, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": pmc.get("traffic"),
-                    "avg_kernel_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(kb),
+                    "avg_kernel_ms": round(avg_ms, 4), "kernel_duration_samples": int(dom[0]), "algorithmic_bytes_per_launch": int(kb),
                     "iter_algorithmic_GBps": round(b_iter * args.steps / dt / 1e9, 2),
                     "note": "peak / unit / achieved / frac price the HBM roofline of SURVEY 8(d) (this path has no dense contraction); "
                             "`limiter` says what the counters say bounds the kernel"}

@@ -525,6 +525,9 @@ int mgr_profile_enable(int on);
  * bracketed launch cost a few microseconds of GPU time each: a run that is itself being timed should name the one
  * kernel it needs. */
 int mgr_profile_filter(const char* kernel_name);
+/* Bracket only every n-th launch that passes the filter (n <= 1: every one): the two events around a launch keep the
+ * kernels on either side from following it without a gap (~6 us each on this GPU), so a run that is being timed samples. */
+int mgr_profile_sample_every(int n);
 int mgr_profile_report(char* buf_host, size_t len, void* stream);
 
 #ifdef __cplusplus

@@ -97,13 +97,16 @@ SIGNATURES = {
     "mgr_mesh_sdf": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp]),
     "mgr_profile_enable": (c_int, [c_int]),
     "mgr_profile_filter": (c_int, [ctypes.c_char_p]),
+    "mgr_profile_sample_every": (c_int, [c_int]),
     "mgr_profile_report": (c_int, [ctypes.c_char_p, c_sz, c_vp]),
 }
 
 
-def profile_enable(on, only=None):
-    """HIP events around the library's kernel launches; `only`: just the kernel of that name."""
+def profile_enable(on, only=None, every=1):
+    """HIP events around the library's kernel launches; `only`: just the kernel of that name; `every`: only every n-th
+    of those launches."""
     check(lib().mgr_profile_filter(only.encode() if only else None), "mgr_profile_filter")
+    check(lib().mgr_profile_sample_every(int(every)), "mgr_profile_sample_every")
     check(lib().mgr_profile_enable(int(bool(on))), "mgr_profile_enable")
 
 

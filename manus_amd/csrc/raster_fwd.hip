@@ -53,7 +53,16 @@ void mgr_prof_end(hipStream_t stream) {
 }
 
 static std::string g_prof_filter;
-bool mgr_prof_match(const char* name) { return g_prof_filter.empty() || g_prof_filter == name; }
+static int g_prof_period = 1, g_prof_seen = 0;
+bool mgr_prof_match(const char* name) {
+    if (!(g_prof_filter.empty() || g_prof_filter == name)) return false;
+    return g_prof_period <= 1 || (g_prof_seen++ % g_prof_period) == 0;   // (every n-th matching launch)
+}
+extern "C" int mgr_profile_sample_every(int n) {
+    g_prof_period = n < 1 ? 1 : n;
+    g_prof_seen = 0;
+    return MGR_OK;
+}
 
 extern "C" int mgr_profile_enable(int on) {
     g_mgr_prof_on = on ? 1 : 0;
