@@ -1820,6 +1820,9 @@ __global__ __launch_bounds__(256) FWD_OCC void k_blend_fwd(int N, int W, int H, 
         const uint32_t c = c_next != END ? c_next : claim();
         c_next = END;
         const uint32_t step = c >> 2, quad = c & 3u;
+#ifdef MGR_TIMELINE
+        const unsigned long long tlw0 = wall_clock64();
+#endif
         uint4 qrec;
         if (step == 0) {   // the first tile of a workgroup is its own index (k_tile_scan_b starts the counters behind the grid)
             qrec = blockIdx.x < n_queue ? tile_qrec[blockIdx.x] : make_uint4(END, 0u, 0u, 0u);
@@ -1863,10 +1866,17 @@ __global__ __launch_bounds__(256) FWD_OCC void k_blend_fwd(int N, int W, int H, 
 
         // software pipeline: rec = record of batch k, gid_n = index of batch k+1.  All pipeline loads are unconditional
         // (indices clamped into the list): a predicated load makes hipcc drain the whole memory queue every batch.
+        // Two batches of records in flight (round 4): the per-unit timeline shows the kernel ending with the walks of its
+        // deepest lists -- 10 500 consumed entries at 30 ns each from t = 0 to the last microsecond, the chip four fifths
+        // empty for the last third -- and a walk alone on its SIMD is one HBM round trip per batch when only the next batch
+        // is on its way (its own pair loop is shorter than that once most pixels of the quadrant have stopped).
         FwdRec rec;
         uint32_t gid_n;
         const uint32_t* const sg = sorted_gid + start;
         const uint32_t lastidx = (nlist ? nlist : 1u) - 1u;   // (a list clipped to nothing by the pair capacity: no walk, indices clamped)
+#ifndef FWD_PF1
+        FwdRec rec1;   // records of batch k + 1 (in flight); gid_n then holds the indices of batch k + 2
+#endif
         {
             const uint32_t g0 = min(got_gid ? pf_g0 : sg[min((uint32_t)lane, lastidx)], gid_max);
             gid_n = got_gid ? pf_g1 : sg[min(64u + lane, lastidx)];
@@ -1874,6 +1884,13 @@ __global__ __launch_bounds__(256) FWD_OCC void k_blend_fwd(int N, int W, int H, 
             rec.a = *(const float4*)r;
             rec.b = *((const float4*)r + 1);
             rec.c = r->b;
+#ifndef FWD_PF1
+            const MgrGRec* r1 = gv + min(gid_n, gid_max);
+            gid_n = sg[min(128u + lane, lastidx)];
+            rec1.a = *(const float4*)r1;
+            rec1.b = *((const float4*)r1 + 1);
+            rec1.c = r1->b;
+#endif
         }
         const bool early = nlist < 2048u;
         if (early) c_next = claim();
@@ -1922,6 +1939,7 @@ __global__ __launch_bounds__(256) FWD_OCC void k_blend_fwd(int N, int W, int H, 
                 if ((cnt & 1) && rank == cnt - 1) mgr_pair_pad<true>(pb);
             }
             // issue the gathers of the following batches; they complete during the blend below
+#ifdef FWD_PF1
             {
                 const MgrGRec* r = gv + min(gid_n, gid_max);
                 rec.a = *(const float4*)r;
@@ -1930,6 +1948,16 @@ __global__ __launch_bounds__(256) FWD_OCC void k_blend_fwd(int N, int W, int H, 
 
                 gid_n = sg[min(off + 128u + lane, lastidx)];
             }
+#else
+            FwdRec rec2;
+            {
+                const MgrGRec* r = gv + min(gid_n, gid_max);
+                rec2.a = *(const float4*)r;
+                rec2.b = *((const float4*)r + 1);
+                rec2.c = r->b;
+                gid_n = sg[min(off + 192u + lane, lastidx)];
+            }
+#endif
             if (provided && !pf_tried) prefetch_next();
             if (!provided) {   // the ticket drawn at the start of the unit is back by now: publish the next step
                 const uint32_t nxt = queue.resolve(raw, lane);
@@ -1987,6 +2015,10 @@ __global__ __launch_bounds__(256) FWD_OCC void k_blend_fwd(int N, int W, int H, 
             const uint32_t nextpos = off + 64u;
             if ((nextpos % MGR_CHUNK) == 0 && nextpos < nlist)
                 ckpt[(size_t)(ck0 + nextpos / MGR_CHUNK - 1) * 256 + pslot] = make_float4(C01.x, C01.y, C2, Tr);
+#ifndef FWD_PF1
+            rec = rec1;
+            rec1 = rec2;
+#endif
             FP(3);
         }
         FP(3);
