@@ -1215,7 +1215,10 @@ __global__ __launch_bounds__(256) void k_tile_sort_small(
 #ifndef DBS_WAVES_EU
 #define DBS_WAVES_EU 4
 #endif
-#define DB_CHUNK 2048        // (1024 when there are few instances in all: more, shorter items)
+#ifndef DB_CHUNK
+#define DB_CHUNK 2048
+#endif
+// DB_CHUNK:        // (1024 when there are few instances in all: more, shorter items)
 __device__ __forceinline__ uint32_t db_lower_bound(const uint32_t* __restrict__ st, uint32_t key) {
     uint32_t lo = 0, hi = MGR_DB_BUCKETS;   // first bucket b in [0, MGR_DB_BUCKETS] with st[b] >= key (st is non-decreasing)
     while (lo < hi) {
