@@ -1975,43 +1975,71 @@ __global__ __launch_bounds__(256) FWD_OCC void k_blend_fwd(int N, int W, int H, 
             }
             const int npair = (cnt + 1) >> 1;
             FP(1);
+            // one pair step; true when every pixel of the quadrant has stopped
+            auto pair_step = [&](const float4& R0, const float4& R1, const float4& R2, const float4& R3, const float4& R4) -> bool {
+                    mgr_v2f al;
+                    unsigned long long ma, mb;
+                    mgr_pair_alpha_masks(R0, R1, R2, fpx2, fpy2, al, ma, mb);
+                    // Per entry: a = alpha if kept and the pixel still accumulates, else 0; the walk of a pixel ends where
+                    // T (1 - a) < 1e-4 (that entry contributes nothing).  The lane masks of the decisions live in scalar registers:
+                    // "contributes" = kept & not ended & not ending here is formed there, one select per use.
+                    {   // entry a
+                        const unsigned long long keep = ma & ~done_m;
+                        const float a = mgr_sel(keep, al.x, 0.0f);
+                        const float testT = Tr * (1.0f - a);
+                        const unsigned long long stop = __builtin_amdgcn_ballot_w64(testT < 0.0001f);  // a == 0 leaves testT = Tr >= 1e-4
+                        const unsigned long long contrib = keep & ~stop;
+                        const float w = mgr_sel(contrib, a * Tr, 0.0f);
+                        C01 += mgr_v2f{R3.x, R3.y} * w;
+                        C2 += R4.x * w;
+                        Tr = mgr_sel(stop, Tr, testT);
+                        last = mgr_selu(contrib, __float_as_uint(R4.z), last);
+                        done_m |= stop;
+                    }
+                    {   // entry b
+                        const unsigned long long keep = mb & ~done_m;
+                        const float a = mgr_sel(keep, al.y, 0.0f);
+                        const float testT = Tr * (1.0f - a);
+                        const unsigned long long stop = __builtin_amdgcn_ballot_w64(testT < 0.0001f);
+                        const unsigned long long contrib = keep & ~stop;
+                        const float w = mgr_sel(contrib, a * Tr, 0.0f);
+                        C01 += mgr_v2f{R3.z, R3.w} * w;
+                        C2 += R4.y * w;
+                        Tr = mgr_sel(stop, Tr, testT);
+                        last = mgr_selu(contrib, __float_as_uint(R4.w), last);
+                        done_m |= stop;
+                    }
+                return (~done_m & exec_m) == 0ull;
+            };
+#ifdef FWD_LDS_PIPE1
             for (int p = 0; p < npair; ++p) {
                 const float4* pp = (const float4*)(slab + p * MGR_PAIR_FLOATS);
                 const float4 R0 = pp[0], R1 = pp[1], R2 = pp[2], R3 = pp[3], R4 = pp[4];   // (five ds_read_b128 with the (r, g)-per-entry layout)
-                mgr_v2f al;
-                unsigned long long ma, mb;
-                mgr_pair_alpha_masks(R0, R1, R2, fpx2, fpy2, al, ma, mb);
-                // Per entry: a = alpha if kept and the pixel still accumulates, else 0; the walk of a pixel ends where
-                // T (1 - a) < 1e-4 (that entry contributes nothing).  The lane masks of the decisions live in scalar registers:
-                // "contributes" = kept & not ended & not ending here is formed there, one select per use.
-                {   // entry a
-                    const unsigned long long keep = ma & ~done_m;
-                    const float a = mgr_sel(keep, al.x, 0.0f);
-                    const float testT = Tr * (1.0f - a);
-                    const unsigned long long stop = __builtin_amdgcn_ballot_w64(testT < 0.0001f);  // a == 0 leaves testT = Tr >= 1e-4
-                    const unsigned long long contrib = keep & ~stop;
-                    const float w = mgr_sel(contrib, a * Tr, 0.0f);
-                    C01 += mgr_v2f{R3.x, R3.y} * w;
-                    C2 += R4.x * w;
-                    Tr = mgr_sel(stop, Tr, testT);
-                    last = mgr_selu(contrib, __float_as_uint(R4.z), last);
-                    done_m |= stop;
-                }
-                {   // entry b
-                    const unsigned long long keep = mb & ~done_m;
-                    const float a = mgr_sel(keep, al.y, 0.0f);
-                    const float testT = Tr * (1.0f - a);
-                    const unsigned long long stop = __builtin_amdgcn_ballot_w64(testT < 0.0001f);
-                    const unsigned long long contrib = keep & ~stop;
-                    const float w = mgr_sel(contrib, a * Tr, 0.0f);
-                    C01 += mgr_v2f{R3.z, R3.w} * w;
-                    C2 += R4.y * w;
-                    Tr = mgr_sel(stop, Tr, testT);
-                    last = mgr_selu(contrib, __float_as_uint(R4.w), last);
-                    done_m |= stop;
-                }
-                if ((~done_m & exec_m) == 0ull) break;
+                if (pair_step(R0, R1, R2, R3, R4)) break;
             }
+#else
+            // The three records a pair step needs first (positions and conics) are read one step ahead: a walk that is alone
+            // on its SIMD -- the deepest lists, which the kernel ends with -- otherwise waits an LDS round trip at the top
+            // of every step (12 more VGPRs: 83 -> 95, still five waves per SIMD).  Unrolled by two so that the two sets swap
+            // roles without moves.
+            if (npair > 0) {
+                const float4* pa = (const float4*)slab;
+                float4 A0 = pa[0], A1 = pa[1], A2 = pa[2];
+                for (int p = 0;; p += 2) {
+                    const float4* pb = (const float4*)(slab + min(p + 1, 31) * MGR_PAIR_FLOATS);
+                    const float4 B0 = pb[0], B1 = pb[1], B2 = pb[2];
+                    const float4* pc = (const float4*)(slab + p * MGR_PAIR_FLOATS);
+                    const float4 A3 = pc[3], A4 = pc[4];
+                    __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise sinks the reads to their first use)
+                    if (pair_step(A0, A1, A2, A3, A4) || p + 1 >= npair) break;
+                    const float4* pn = (const float4*)(slab + min(p + 2, 31) * MGR_PAIR_FLOATS);
+                    A0 = pn[0]; A1 = pn[1]; A2 = pn[2];
+                    const float4 B3 = pb[3], B4 = pb[4];
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (pair_step(B0, B1, B2, B3, B4) || p + 2 >= npair) break;
+                }
+            }
+#endif
             FP(2);
             // pixel state in front of the next chunk (prefix colour + transmittance): lets the
             // backward pass process every MGR_CHUNK-entry chunk of the list independently
