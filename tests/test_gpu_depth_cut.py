@@ -183,3 +183,33 @@ def test_trainer_with_the_cut_follows_the_trainer_without(fenced):
     for k in LEAVES:      # bit patterns: a Gaussian that left the skin-weight grid carries NaN (like the reference), NaN != NaN
         d = p0[k].view(torch.int32) != p1[k].view(torch.int32)
         assert not bool(d.any()), (k, int(d.sum()), p0[k][d][:4], p1[k][d][:4])
+
+
+def test_depth_cut_at_the_bench_size(fenced):
+    """BASELINE config 3 at full size (300 000 Gaussians, 8 views of 1920 x 1080, the bench's scene): the step with the
+    depth cut is bit for bit the step without it, no forward is flagged, and the lists hold less than 40 % of the pairs."""
+    from manus_amd import rasterizer
+    from manus_amd.synthetic import camera_table, make_scene
+    V, N, W, H = 8, 300000, 1920, 1080
+    sc = make_scene(n_gaussians=N, kind="hand", seed=0, n_cameras=V, width=W, height=H, device=DEV)
+    ct = camera_table(sc["cameras"], DEV)
+    targets = torch.rand((V, 3, H, W), generator=torch.Generator().manual_seed(9)).to(DEV)
+    views = list(range(V))
+    ref = _compute(sc, targets, ct, cut=False)
+    _warm(ref, views)
+    want = ref(views)
+    img = ref.last_image.clone()
+    full = _surviving_pairs(ref, V, N, W, H)
+    rasterizer.check_overflow(DEV)
+    rasterizer.set_sync_policy(True, DEV)
+    c = _compute(sc, targets, ct, cut=True)
+    _warm(c, views)
+    c(views)
+    for _ in range(2):
+        got = c(views)
+        _same(got, want)
+        assert torch.equal(c.last_image, img)
+    cut = _surviving_pairs(c, V, N, W, H)
+    rasterizer.check_overflow(DEV)
+    print("pairs in the lists at the bench size: %d full, %d with the cut (%.3f)" % (full, cut, cut / full))
+    assert fenced.cut_retries == 0 and cut < 0.4 * full
