@@ -397,6 +397,7 @@ class HipViewCompute:
         self._sh_dirty = True
         self._cut_gen += 1          # rows were added / removed: the hints of the old model are dropped
         self._cut_store.clear()
+        self._cut_born.clear()
 
     def mark_params_changed(self):
         """The leaves were updated in place (optimizer step): derived storage copies are stale."""
