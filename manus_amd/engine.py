@@ -785,7 +785,7 @@ class Trainer:
     over the ranks; max_radii2D is MAX-reduced before it is consumed."""
 
     def __init__(self, compute, n_views, extent, opts=None, spatial_lr_scale=1.0, rank=0, world_size=1, group=None,
-                 bg_white=True, kind=None, compact_allreduce=False, sharded_adam=False, view_weights=None):
+                 bg_white=True, kind=None, compact_allreduce=False, sharded_adam=False, view_weights=None, depth_cut=False):
         # sharded_adam (world_size > 1): reduce-scatter of the gradients -> every rank takes the Adam step on the 1/world
         # of the parameter elements it owns -> all-gather of the parameters.  The same bytes on the wire as the
         # all-reduce (which is a reduce-scatter followed by an all-gather), 1/world of the optimizer work per rank.
@@ -812,6 +812,11 @@ class Trainer:
         self._rz = rasterizer
         if getattr(compute, "fused", False) and hasattr(compute, "sync_check"):
             compute.sync_check = False      # this trainer's forwards are fenced and polled in _run_step (no global policy flip)
+        # depth_cut: a Trainer moves the model every step, and under a moving model the depth cut of the fused forward is a
+        # wash at best (flagged forwards are run twice; measured 567 against 578 iters/s with its back-off): off
+        # unless asked for.  A compute object used without an optimizer (fwd+bwd loops, evaluation sweeps) keeps its own.
+        if hasattr(compute, "depth_cut") and not depth_cut:
+            compute.depth_cut = False
         self._rebuild_step()
 
     def _rebuild_step(self):

@@ -170,7 +170,7 @@ def test_trainer_with_the_cut_follows_the_trainer_without(fenced):
         compute = _compute(sc, targets, ct, cut=cut)
         opts = dict(densify_from_step=4, densification_interval=6, densify_until_step=1000, opacity_reset_interval=9,
                     percent_dense=0.01, densify_grad_threshold=5e-5)
-        tr = Trainer(compute, V, extent=0.3, opts=opts, spatial_lr_scale=0.05, bg_white=False)
+        tr = Trainer(compute, V, extent=0.3, opts=opts, spatial_lr_scale=0.05, bg_white=False, depth_cut=cut)
         losses = []
         for _ in range(14):
             torch.manual_seed(100 + tr.global_step)          # the split noise of a densification
