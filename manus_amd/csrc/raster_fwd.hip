@@ -950,6 +950,7 @@ __device__ __forceinline__ void lds_sort_emit(const unsigned long long* __restri
     }
     if (n <= 2u * RS_THREADS) MGR_RADIX_CASE(2)
     else if (n <= 4u * RS_THREADS) MGR_RADIX_CASE(4)
+    else if (n <= 6u * RS_THREADS) MGR_RADIX_CASE(6)   // (an item of the instance sort is "about 2048 keys": whole buckets, often a few more)
     else if (n <= 8u * RS_THREADS) MGR_RADIX_CASE(8)
     else MGR_RADIX_CASE(16)
 #undef MGR_RADIX_CASE
