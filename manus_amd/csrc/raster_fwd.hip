@@ -562,7 +562,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan_a(int T, int nbT, const uint
     __shared__ uint32_t s_bb[4];
     const int tid = threadIdx.x, v = blockIdx.x / nbT, t = (blockIdx.x % nbT) * 1024 + tid;
     if (tid == 0) { s_bb[0] = 0xFFFFu; s_bb[1] = 0xFFFFu; s_bb[2] = 0u; s_bb[3] = 0u; }
-    if (blockIdx.x == 0 && tid == 0) hdr->tiers = 0u;   // (phase B's depth-bucket workgroups set the bits)
+    if (blockIdx.x == 0 && tid == 0) { hdr->tiers = 0u; hdr->sort_big = 0u; }   // (phase B's depth-bucket workgroups / the sort set them)
     const bool valid = t < T;
     const size_t k = (size_t)v * T + t;
     if (tid < MGR_NCLS) s_cls[tid] = 0;
@@ -1228,12 +1228,24 @@ __device__ __forceinline__ uint32_t db_lower_bound(const uint32_t* __restrict__ 
     }
     return lo;
 }
+// Two launches can share the items by size: the light one (LDS for DBS_LIGHT_KEYS keys: three workgroups per CU instead of
+// two, so the ~530 items of the bench step run in one round instead of two) takes the items of at most that many keys and
+// the full one (SORT_LDS_KEYS) the rest -- or, when the caller skips the full launch (debug bit 128), the light one sorts
+// the few larger items bucket by bucket itself: slower per item (0.25 ms when all items are large), faster in all when they
+// are a handful (with the depth cut the instances that take part halve: 0.051 -> 0.041 ms).  The header counts the large
+// items (sort_big) so that the caller can choose for the next forward; either way every item is sorted by exactly one
+// launch.  lds_keys: capacity of this launch; min_keys: items of at most this many keys belong to the other launch;
+// full_runs: the full launch follows (light launch only).
+#define DBS_LIGHT_KEYS 4096
+template <int LDS_KEYS>   // (a template so that the light instantiation sheds the 16-keys-per-thread case and its spills)
 __global__ __launch_bounds__(RS_THREADS) __attribute__((amdgpu_waves_per_eu(DBS_WAVES_EU, DBS_WAVES_EU))) void k_dbin_sort(
     int N, int chunk, int chunks_per_view, int n_items, const uint32_t* __restrict__ db_start, const uint32_t* __restrict__ db_nvis,
-    unsigned long long* __restrict__ db_keys, uint32_t* __restrict__ db_order) {
+    unsigned long long* __restrict__ db_keys, uint32_t* __restrict__ db_order, uint32_t min_keys, MgrHeader* hdr,
+    int full_runs) {
+    constexpr uint32_t lds_keys = (uint32_t)LDS_KEYS;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     unsigned long long* s_keys = (unsigned long long*)s_raw;
-    uint32_t* s_cnt = (uint32_t*)(s_raw + (size_t)SORT_LDS_KEYS * 8);
+    uint32_t* s_cnt = (uint32_t*)(s_raw + (size_t)lds_keys * 8);
     uint32_t* s_scan = s_cnt + RS_WAVES * 256;
     const int tid = threadIdx.x;
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
@@ -1246,14 +1258,21 @@ __global__ __launch_bounds__(RS_THREADS) __attribute__((amdgpu_waves_per_eu(DBS_
         if (b1 <= b0) continue;
         const uint32_t lo = st[b0], hi = st[b1];
         if (hi == lo) continue;
+        if (hi - lo <= min_keys) continue;                          // the light launch's
+        if (lds_keys < (uint32_t)SORT_LDS_KEYS && hi - lo > lds_keys) {
+            if (threadIdx.x == 0) atomicAdd(&hdr->sort_big, 1u);
+            if (full_runs) continue;     // the full launch's (else: bucket by bucket below)
+        }
+        if (lds_keys == (uint32_t)SORT_LDS_KEYS && min_keys == 0u && hi - lo > (uint32_t)DBS_LIGHT_KEYS && threadIdx.x == 0)
+            atomicAdd(&hdr->sort_big, 1u);   // (the full launch alone: it keeps the count for the caller's next choice)
         unsigned long long* keys = db_keys + (size_t)v * N;
         uint32_t* out = db_order + (size_t)v * N;
-        const uint32_t parts = (hi - lo <= (uint32_t)SORT_LDS_KEYS) ? 1u : b1 - b0;
+        const uint32_t parts = (hi - lo <= lds_keys) ? 1u : b1 - b0;
         for (uint32_t p = 0; p < parts; ++p) {
             const uint32_t a = parts == 1u ? lo : st[b0 + p], n = (parts == 1u ? hi : st[b0 + p + 1]) - a;
             if (n == 0) continue;
             __syncthreads();
-            if (n <= (uint32_t)SORT_LDS_KEYS) {
+            if (n <= lds_keys) {
                 lds_sort_emit(keys + a, n, s_keys, s_cnt, s_scan, tid, out + a);
             } else {
                 uint32_t npad = 1;
@@ -2164,7 +2183,7 @@ __global__ __launch_bounds__(256) void k_fwd_items(const uint4* __restrict__ til
         uint32_t ovf = hdr->overflow;
         if (f) { ovf |= f; hdr->overflow = ovf; hdr->acc_flags = 0u; }
         if (mirror) {   // the caller's host-mapped status words (mgr_raster_set_status_mirror): no copy, no launch
-            mirror[0] = hdr->total_pairs; mirror[1] = ovf; mirror[2] = hdr->tiers;
+            mirror[0] = hdr->total_pairs; mirror[1] = ovf; mirror[2] = hdr->tiers | (min(hdr->sort_big, 0xFFFFu) << 8);
             __threadfence_system();
             mirror[3] = 1u;
         }
@@ -2305,7 +2324,7 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
     // bits 4 / 5 (16 / 32): skip the binning launches for tile boxes of more than 2048 / of 1537..2048 tiles (the caller saw
     // in the previous forward's header that no view needed them; a view that does now raises MGR_OVF_TIER)
     const bool do_bin = !(debug & 4), do_blend = !(debug & 2), use_cut = (debug & 8) && canon != nullptr;
-    const int skip_tiers = ((debug & 16) ? 1 : 0) | ((debug & 32) ? 2 : 0);
+    const int skip_tiers = ((debug & 16) ? 1 : 0) | ((debug & 32) ? 2 : 0) | ((debug & 128) ? 4 : 0) | ((debug & 256) ? 8 : 0);
     debug &= 1;
     if (V <= 0 || N < 0 || W <= 0 || H <= 0 || cap < 0 || cap > 0xFFFFFFF0ll)
         return mgr_fail(MGR_EINVAL, "mgr_raster_forward: bad sizes");
@@ -2338,7 +2357,7 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
         MGR_HIP(hipFuncSetAttribute((const void*)k_inst_fwd<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
         MGR_HIP(hipFuncSetAttribute((const void*)k_inst_fwd<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
         MGR_HIP(hipFuncSetAttribute((const void*)k_inst_fwd<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
-        MGR_HIP(hipFuncSetAttribute((const void*)k_dbin_sort, hipFuncAttributeMaxDynamicSharedMemorySize,
+        MGR_HIP(hipFuncSetAttribute((const void*)k_dbin_sort<SORT_LDS_KEYS>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     SORT_LDS_KEYS * 8 + RS_WAVES * 256 * 4 + 256));
         MGR_HIP(hipFuncSetAttribute((const void*)k_bin_count<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
         MGR_HIP(hipFuncSetAttribute((const void*)k_bin_scatter<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
@@ -2420,8 +2439,16 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
         const size_t rec_bytes = BIN_SC_FIXED_BYTES;
         { MGR_PROF("k_dbin_scatter", stream); hipLaunchKernelGGL(k_dbin_scatter, grid_n, dim3(1024), 0, stream, N, (const int32_t*)radii, (const float*)(ws + L.depth), rect, alive,
                            (const uint32_t*)db_start, (uint32_t*)(ws + L.db_cursor), db_keys); }
-        { MGR_PROF("k_dbin_sort", stream); hipLaunchKernelGGL(k_dbin_sort, dim3(1024), dim3(RS_THREADS), SORT_LDS_KEYS * 8 + RS_WAVES * 256 * 4 + 256, stream,
-                           N, chunk, chunks, V * chunks, (const uint32_t*)db_start, (const uint32_t*)db_nvis, db_keys, db_order); }
+        { MGR_PROF("k_dbin_sort", stream);
+          const bool run_light = !(skip_tiers & 8) || (skip_tiers & 4), run_full = !(skip_tiers & 4);   // (never neither)
+          if (run_light)
+              hipLaunchKernelGGL((k_dbin_sort<DBS_LIGHT_KEYS>), dim3(1024), dim3(RS_THREADS), DBS_LIGHT_KEYS * 8 + RS_WAVES * 256 * 4 + 256, stream,
+                                 N, chunk, chunks, V * chunks, (const uint32_t*)db_start, (const uint32_t*)db_nvis, db_keys, db_order,
+                                 0u, hdr, run_full ? 1 : 0);
+          if (run_full)
+              hipLaunchKernelGGL((k_dbin_sort<SORT_LDS_KEYS>), dim3(1024), dim3(RS_THREADS), SORT_LDS_KEYS * 8 + RS_WAVES * 256 * 4 + 256, stream,
+                                 N, chunk, chunks, V * chunks, (const uint32_t*)db_start, (const uint32_t*)db_nvis, db_keys, db_order,
+                                 run_light ? (uint32_t)DBS_LIGHT_KEYS : 0u, hdr, 0); }
         MGR_LAUNCH_CHECK("k_dbin_sort", stream, debug);
         const bool big_possible = T > BIN_SMALL_TILES;   // a box of more than BIN_SMALL_TILES tiles can only exist then
         { MGR_PROF("k_bin_count", stream);
@@ -2587,7 +2614,10 @@ extern "C" int mgr_raster_status_tiers_sync(const void* workspace, int64_t* num_
     MGR_HIP(hipStreamSynchronize(stream));
     if (num_pairs) *num_pairs = h[0];
     if (overflow) *overflow = (int32_t)h[1];
-    if (tiers) *tiers = (int32_t)h[offsetof(MgrHeader, tiers) / 4];
+    if (tiers) {   // bits 0-1: binning tiers needed; bits 8..: items of the instance sort beyond its light launch (capped at 65535)
+        const uint32_t sb = h[offsetof(MgrHeader, sort_big) / 4];
+        *tiers = (int32_t)(h[offsetof(MgrHeader, tiers) / 4] | ((sb < 0xFFFFu ? sb : 0xFFFFu) << 8));
+    }
     if (h[1] & MGR_OVF_PAIRS) return mgr_fail(MGR_EOVERFLOW, "pair capacity exceeded");
     if (h[1] & MGR_OVF_CUT) return mgr_fail(MGR_ECUT, "depth cut violated: run the forward again without debug bit 8");
     if (h[1] & MGR_OVF_TIER) return mgr_fail(MGR_ETIER, "a skipped binning tier was needed: run the forward again without debug bits 16 / 32");

@@ -44,6 +44,7 @@ class GaussianRasterizationSettings(NamedTuple):
 # ---------------------------------------------------------------------------
 class RasterWorkspace:
     """One opaque byte tensor that links a forward to its backward."""
+    SORT_BIG_MAX = int(os.environ.get("MANUS_SORT_BIG_MAX", "24"))   # large sort items the light launch takes on itself
 
     def __init__(self, device, V, N, W, H, cap):
         self.key = (V, N, W, H)
@@ -66,7 +67,8 @@ class RasterWorkspace:
         the device: a view that needs a skipped launch flags the forward, which is then run again with all of them)."""
         if self.tiers is None:
             return 0
-        return (0 if self.tiers & 1 else 16) | (0 if self.tiers & 2 else 32)
+        # (128: the instance sort's full-size launch pays from a few dozen large items on)
+        return (0 if self.tiers & 1 else 16) | (0 if self.tiers & 2 else 32) | (128 if (self.tiers >> 8) <= RasterWorkspace.SORT_BIG_MAX else 256)
 
 
 def default_pair_capacity(V, N):

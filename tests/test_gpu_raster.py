@@ -11,6 +11,8 @@ import numpy as np
 import pytest
 import torch
 
+from manus_amd.synthetic import look_at_extrinsics
+
 from oracle import RasterOracle
 
 from util import cam_args, cam_table_np, make_camera, max_rel_err, psnr, random_gaussians
@@ -212,15 +214,28 @@ def test_skipped_binning_tiers_are_verified_and_retried():
     ctx.tier_retries = 0
     got_small = _hip([cam], m, c, col, op, grad_img=g)
     ws = ctx.last_ws
-    assert ws.tiers == 0 and ws.skip_bits() == 48            # box of at most 1536 tiles: neither larger tier needed
+    assert ws.tiers == 0 and ws.skip_bits() == 48 + 128      # box of at most 1536 tiles, sort items of at most 4096 keys
     got_big = _hip([cam], 6.0 * m, c, col, op, grad_img=g)  # skips them, is flagged, runs again
-    assert ctx.tier_retries == 1 and ctx.last_ws.tiers == 1 and ctx.last_ws.skip_bits() == 32
+    assert ctx.tier_retries == 1 and (ctx.last_ws.tiers & 0xFF) == 1 and ctx.last_ws.skip_bits() == 32 + 128
     again = _hip([cam], 6.0 * m, c, col, op, grad_img=g)
     assert ctx.tier_retries == 1
     for k in want_small:
         assert np.array_equal(got_small[k], want_small[k]), k
         assert np.array_equal(got_big[k], want_big[k]), k
         assert np.array_equal(again[k], want_big[k]), k
+    # the instance sort (bit 128: its light launch alone): every Gaussian in one depth plane of the camera -> one depth bucket
+    # of 20 000 keys, sorted by the full launch the first time, by the light launch's bucket path once it is skipped
+    E = look_at_extrinsics((0.3, -0.2, -1.5), (0, 0, 0), up=(0, 1, 0))
+    R, tvec = np.asarray(E)[:3, :3], np.asarray(E)[:3, 3]
+    pc = (m.astype(np.float64) @ R.T + tvec)
+    pc[:, 2] = 1.5
+    m_plane = ((pc - tvec) @ R).astype(np.float32)            # same image positions, all at view depth 1.5
+    ctx.clear()
+    want_plane = _hip([cam], m_plane, c, col, op, grad_img=g)        # (no record of the tiers yet: both launches)
+    assert (ctx.last_ws.tiers >> 8) >= 1 and (ctx.last_ws.skip_bits() & 128)     # one large item: the light launch will take it
+    got_plane = _hip([cam], m_plane, c, col, op, grad_img=g)
+    for k in want_plane:
+        assert np.array_equal(got_plane[k], want_plane[k]), k
 
 
 def test_multi_view_batch_equals_single_views_bitwise():
