@@ -127,11 +127,10 @@ size_t mgr_raster_workspace_bytes(int V, int N, int W, int H, int64_t pair_capac
  * 1537..2048 tiles (they hold more LDS per workgroup; three launches of ~6 us each that do nothing for smaller boxes).
  * mgr_raster_status_tiers_sync reports which of them a forward needed (bit 0 / bit 1); pass the bits for the tiers the
  * previous forward did not need.  A view that needs a skipped launch raises the overflow word's bit 2 (MGR_ETIER).
- * 128 = skip the instance sort's full-size launch: its light launch (LDS for 4096 keys, more workgroups per CU) then also
- * sorts the items of more than 4096 keys, bucket by bucket -- the better choice when those are a handful (bits 8.. of
- * `tiers` count them; not a correctness matter, nothing to verify).  256 = skip the light launch instead: the full one
- * sorts every item (the better choice when most items are large: an item costs ~20 us of bucket searches in each launch
- * that looks at it). */
+ * 128 = skip the instance sort's full-size launch: its light launch (LDS for 4096 keys, more workgroups per CU) sorts every
+ * item, the ones of more than 4096 keys bucket by bucket -- the better choice unless an item holds a single bucket of more
+ * than 4096 keys (bits 8.. of `tiers` count those; not a correctness matter, nothing to verify).  256 = skip the light
+ * launch instead: the full one sorts every item.  Neither bit: both launches, each item sorted by exactly one of them. */
 int mgr_raster_forward(int V, int N, int W, int H, const float* cams, const float* bg,
                        const float* means3D, int64_t stride_means3D, const float* cov3D,
                        int64_t stride_cov3D, const float* colors, int64_t stride_colors,
@@ -224,7 +223,7 @@ int mgr_raster_set_cut_margin(float frac_entries, int min_entries, float depth_r
  * num_rendered through a blocking read-back, SURVEY App. A.) */
 int mgr_raster_set_status_mirror(const void* workspace, void* host_words);
 /* mgr_raster_status_sync plus `tiers` (see debug bits 16 / 32 / 128 of the forward): bit 0 = a view's tile box had more than
- * 2048 tiles, bit 1 = one had 1537..2048, bits 8.. = items of the instance sort with more than 4096 keys. */
+ * 2048 tiles, bit 1 = one had 1537..2048, bits 8.. = items of the instance sort that hold a single depth bucket of more than 4096 keys. */
 int mgr_raster_status_tiers_sync(const void* workspace, int64_t* num_pairs, int32_t* overflow, int32_t* tiers,
                                  void* stream);
 int mgr_raster_status_sync(const void* workspace, int64_t* num_pairs, int32_t* overflow,

@@ -79,7 +79,7 @@ struct MgrHeader {            // first 256 bytes of the workspace
     // (bit 0: a box of more than 2048 tiles, bit 1: one of 1537..2048) -- a caller may skip the launches of tiers the
     // previous forward did not need (debug bits 16 / 32); a skipped tier that IS needed raises MGR_OVF_TIER
     uint32_t tiers;
-    uint32_t sort_big;        // items of the instance sort with more than DBS_LIGHT_KEYS keys (reported in bits 8.. of the tiers word)
+    uint32_t sort_big;        // items of the instance sort holding a single bucket of more than DBS_LIGHT_KEYS keys (bits 8.. of the reported tiers word)
     uint32_t spare[68];       // (the size-class counters of the tile scan lived here: it now derives them from per-block histograms)
     uint32_t queue_giant;     // queue index of the first tile with fewer than 16384 pairs
     uint32_t n_groups;        // depth groups produced by k_tile_split for the giant tiles

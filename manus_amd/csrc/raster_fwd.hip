@@ -1230,11 +1230,12 @@ __device__ __forceinline__ uint32_t db_lower_bound(const uint32_t* __restrict__ 
 }
 // Two launches can share the items by size: the light one (LDS for DBS_LIGHT_KEYS keys: three workgroups per CU instead of
 // two, so the ~530 items of the bench step run in one round instead of two) takes the items of at most that many keys and
-// the full one (SORT_LDS_KEYS) the rest -- or, when the caller skips the full launch (debug bit 128), the light one sorts
-// the few larger items bucket by bucket itself: slower per item (0.25 ms when all items are large), faster in all when they
-// are a handful (with the depth cut the instances that take part halve: 0.051 -> 0.041 ms).  The header counts the large
-// items (sort_big) so that the caller can choose for the next forward; either way every item is sorted by exactly one
-// launch.  lds_keys: capacity of this launch; min_keys: items of at most this many keys belong to the other launch;
+// larger ones bucket by bucket, all but those with a single bucket beyond its LDS -- those (a dense depth slice: typical
+// with one view and rows of 1024 keys) are the full launch's (SORT_LDS_KEYS), or, when the caller skips the full launch
+// (debug bit 128), go through the light one's global-memory fallback.  The header counts them (sort_big) so that the caller
+// can choose for the next forward: none -> the light launch alone (with the depth cut the instances that take part halve:
+// 0.051 -> 0.044 ms at eight views), some -> the full launch alone (one view: 0.039 ms; the light one alone took 0.093 there);
+// either way every item is sorted by exactly one launch.  lds_keys: capacity of this launch; min_keys: items of at most this many keys belong to the other launch;
 // full_runs: the full launch follows (light launch only).
 #define DBS_LIGHT_KEYS 4096
 template <int LDS_KEYS>   // (a template so that the light instantiation sheds the 16-keys-per-thread case and its spills)
@@ -1259,12 +1260,21 @@ __global__ __launch_bounds__(RS_THREADS) __attribute__((amdgpu_waves_per_eu(DBS_
         const uint32_t lo = st[b0], hi = st[b1];
         if (hi == lo) continue;
         if (hi - lo <= min_keys) continue;                          // the light launch's
-        if (lds_keys < (uint32_t)SORT_LDS_KEYS && hi - lo > lds_keys) {
-            if (threadIdx.x == 0) atomicAdd(&hdr->sort_big, 1u);
-            if (full_runs) continue;     // the full launch's (else: bucket by bucket below)
+        if (hi - lo > (uint32_t)DBS_LIGHT_KEYS) {
+            // an item beyond the light launch's LDS: the light launch still takes it, bucket by bucket, unless one of its
+            // buckets alone is beyond it (that one would go through the bitonic network in global memory: ~90 us) -- such
+            // items are the full launch's, and they are what the header counts for the caller's next choice
+            uint32_t big = 0;
+            for (uint32_t p = (uint32_t)tid; p < b1 - b0; p += (uint32_t)RS_THREADS) big |= (st[b0 + p + 1] - st[b0 + p] > (uint32_t)DBS_LIGHT_KEYS) ? 1u : 0u;
+            const bool huge = __syncthreads_or((int)big) != 0;
+            if (lds_keys < (uint32_t)SORT_LDS_KEYS) {
+                if (huge && tid == 0) atomicAdd(&hdr->sort_big, 1u);
+                if (huge && full_runs) continue;
+            } else {
+                if (huge && min_keys == 0u && tid == 0) atomicAdd(&hdr->sort_big, 1u);   // (the full launch alone keeps the count)
+                if (!huge && min_keys != 0u) continue;
+            }
         }
-        if (lds_keys == (uint32_t)SORT_LDS_KEYS && min_keys == 0u && hi - lo > (uint32_t)DBS_LIGHT_KEYS && threadIdx.x == 0)
-            atomicAdd(&hdr->sort_big, 1u);   // (the full launch alone: it keeps the count for the caller's next choice)
         unsigned long long* keys = db_keys + (size_t)v * N;
         uint32_t* out = db_order + (size_t)v * N;
         const uint32_t parts = (hi - lo <= lds_keys) ? 1u : b1 - b0;

@@ -44,7 +44,10 @@ class GaussianRasterizationSettings(NamedTuple):
 # ---------------------------------------------------------------------------
 class RasterWorkspace:
     """One opaque byte tensor that links a forward to its backward."""
-    SORT_BIG_MAX = int(os.environ.get("MANUS_SORT_BIG_MAX", "24"))   # large sort items the light launch takes on itself
+    # sort items with a single depth bucket beyond the light launch's LDS that the light launch may take on itself: none --
+    # such a bucket goes through its global-memory fallback, ~90 us, which with one view on the GPU is the whole kernel
+    # (measured: 0.039 -> 0.093 ms)
+    SORT_BIG_MAX = int(os.environ.get("MANUS_SORT_BIG_MAX", "0"))
 
     def __init__(self, device, V, N, W, H, cap):
         self.key = (V, N, W, H)
@@ -67,7 +70,7 @@ class RasterWorkspace:
         the device: a view that needs a skipped launch flags the forward, which is then run again with all of them)."""
         if self.tiers is None:
             return 0
-        # (128: the instance sort's full-size launch pays from a few dozen large items on)
+        # (128 / 256: the instance sort's light launch alone, or its full-size launch alone)
         return (0 if self.tiers & 1 else 16) | (0 if self.tiers & 2 else 32) | (128 if (self.tiers >> 8) <= RasterWorkspace.SORT_BIG_MAX else 256)
 
 
