@@ -1238,6 +1238,12 @@ __device__ __forceinline__ uint32_t db_lower_bound(const uint32_t* __restrict__ 
 // either way every item is sorted by exactly one launch.  lds_keys: capacity of this launch; min_keys: items of at most this many keys belong to the other launch;
 // full_runs: the full launch follows (light launch only).
 #define DBS_LIGHT_KEYS 4096
+#ifdef DBS_PROF   // tools/instr/dbsprof.py: per-item times of k_dbin_sort (wall_clock64, thread 0)
+__device__ unsigned long long g_dbsprof[16];
+extern "C" int mgr_debug_dbsprof(unsigned long long* dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_dbsprof), sizeof(unsigned long long) * 16);
+}
+#endif
 template <int LDS_KEYS>   // (a template so that the light instantiation sheds the 16-keys-per-thread case and its spills)
 __global__ __launch_bounds__(RS_THREADS) __attribute__((amdgpu_waves_per_eu(DBS_WAVES_EU, DBS_WAVES_EU))) void k_dbin_sort(
     int N, int chunk, int chunks_per_view, int n_items, const uint32_t* __restrict__ db_start, const uint32_t* __restrict__ db_nvis,
@@ -1249,7 +1255,13 @@ __global__ __launch_bounds__(RS_THREADS) __attribute__((amdgpu_waves_per_eu(DBS_
     uint32_t* s_cnt = (uint32_t*)(s_raw + (size_t)lds_keys * 8);
     uint32_t* s_scan = s_cnt + RS_WAVES * 256;
     const int tid = threadIdx.x;
+#ifdef DBS_PROF
+    const long long t_start = wall_clock64();
+#endif
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+#ifdef DBS_PROF
+        const long long t0 = wall_clock64();
+#endif
         const int v = item % (n_items / chunks_per_view), ch = item / (n_items / chunks_per_view);   // view-minor: neighbours differ in view
         const uint32_t nvis = db_nvis[v];
         if ((uint32_t)ch * (uint32_t)chunk >= nvis) continue;
@@ -1278,6 +1290,9 @@ __global__ __launch_bounds__(RS_THREADS) __attribute__((amdgpu_waves_per_eu(DBS_
         unsigned long long* keys = db_keys + (size_t)v * N;
         uint32_t* out = db_order + (size_t)v * N;
         const uint32_t parts = (hi - lo <= lds_keys) ? 1u : b1 - b0;
+#ifdef DBS_PROF
+        const long long t1 = wall_clock64();
+#endif
         for (uint32_t p = 0; p < parts; ++p) {
             const uint32_t a = parts == 1u ? lo : st[b0 + p], n = (parts == 1u ? hi : st[b0 + p + 1]) - a;
             if (n == 0) continue;
@@ -1291,6 +1306,21 @@ __global__ __launch_bounds__(RS_THREADS) __attribute__((amdgpu_waves_per_eu(DBS_
                 for (uint32_t t = tid; t < n; t += RS_THREADS) out[a + t] = (uint32_t)keys[a + t];
             }
         }
+#ifdef DBS_PROF
+        if (tid == 0) {
+            const long long t2 = wall_clock64();
+            atomicAdd(&g_dbsprof[0], (unsigned long long)(t1 - t0));      // prologue (item bounds)
+            atomicAdd(&g_dbsprof[1], (unsigned long long)(t2 - t1));      // loads + sorts + output
+            atomicAdd(&g_dbsprof[2], 1ull);                                // items
+            atomicAdd(&g_dbsprof[3], (unsigned long long)(hi - lo));      // keys
+            atomicAdd(&g_dbsprof[4], (unsigned long long)parts);
+            atomicMax(&g_dbsprof[5], (unsigned long long)(t2 - t0));      // slowest item
+            atomicMax(&g_dbsprof[6], (unsigned long long)(hi - lo));      // largest item
+            atomicMax(&g_dbsprof[7], (unsigned long long)(t2 - t_start)); // latest end since the workgroup's start
+            const uint32_t nk = hi - lo;
+            atomicAdd(&g_dbsprof[nk <= 1024u ? 8 : nk <= 2048u ? 9 : nk <= 3072u ? 10 : nk <= 4096u ? 11 : 12], 1ull);
+        }
+#endif
     }
 }
 
