@@ -48,6 +48,7 @@ SIGNATURES = {
                                      c_vp, c_int, c_vp]),
     "mgr_skin_weights_bwd_indexed": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp,
                                              c_vp, c_vp, c_vp, c_int, c_vp]),
+    "mgr_views_backward_run_lists": (c_int, [c_int]),
     "mgr_views_active_list": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_i64, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp)]),
     "mgr_lbs_cov_fwd": (c_int, [c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "mgr_lbs_cov_bwd": (c_int, [c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,

@@ -80,7 +80,10 @@ struct MgrHeader {            // first 256 bytes of the workspace
     // previous forward did not need (debug bits 16 / 32); a skipped tier that IS needed raises MGR_OVF_TIER
     uint32_t tiers;
     uint32_t sort_big;        // items of the instance sort holding a single bucket of more than DBS_LIGHT_KEYS keys (bits 8.. of the reported tiers word)
-    uint32_t spare[68];       // (the size-class counters of the tile scan lived here: it now derives them from per-block histograms)
+    // fused backward, 5..8 views per group: the active Gaussians by the number of their views that hold pair records, rounded up
+    // to 8 / 4 / 2 lanes -- k_inst_bwd_runs gives a Gaussian that many lanes instead of eight (k_inst_gather counts and lists them)
+    uint32_t n_runs[4];       // (three classes; the fourth word is spare)
+    uint32_t spare[64];       // (the size-class counters of the tile scan lived here: it now derives them from per-block histograms)
     uint32_t queue_giant;     // queue index of the first tile with fewer than 16384 pairs
     uint32_t n_groups;        // depth groups produced by k_tile_split for the giant tiles
     uint32_t split_head, group_head;

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BWD_WAVES, 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int T = gx * gy;
     const uint32_t n_items = hdr->n_items;
-    if (blockIdx.x == 0 && tid == 0) hdr->n_active = 0;  // for the gather that follows (first view group)
+    if (blockIdx.x == 0 && tid < 4) (tid == 3 ? hdr->n_active : hdr->n_runs[tid]) = 0;  // for the gather that follows (first view group)
     const size_t P = (size_t)W * H;
     const unsigned long long lt = (1ull << lane) - 1ull;
     float* const slab = &s_pair[wave][0][0];
@@ -428,6 +428,47 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
 //   * nothing is staged through global memory between the phases.
 // `accumulate` adds to the outputs instead of writing them (view groups beyond the first).
 // ---------------------------------------------------------------------------
+// Every lane of a group of G < 8 holds the same eight totals t[0..7]: lane r stores the 8 / G consecutive ones from r * 8 / G
+// with one vector store (dst is only dword-aligned) -- not lane 0 all eight one after the other: with runs of 4 / 2 / 1 lanes
+// (k_inst_bwd_runs) that was 8 store instructions of 16 / 32 / 64 scattered dwords per block of eight values.
+typedef float mgr_f2u __attribute__((ext_vector_type(2), aligned(4)));
+template <int G>
+__device__ __forceinline__ void grp_store_span(const float t[8], int vl, bool ok, float* __restrict__ dst, int n, bool accumulate) {
+    constexpr int PER = 8 / G;
+    float mine[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        mine[j] = t[j];
+#pragma unroll
+        for (int r = 1; r < G; ++r) mine[j] = vl == r ? t[r * PER + j] : mine[j];
+    }
+    const int e0 = vl * PER;
+    if (!ok || e0 >= n) return;
+    float* d = dst + e0;
+    if (e0 + PER <= n) {
+        if (PER == 2) {
+            mgr_f2u v = {mine[0], mine[1]};
+            if (accumulate) v += *(const mgr_f2u*)d;
+            *(mgr_f2u*)d = v;
+        } else if (PER == 4) {
+            mgr_f4u v = {mine[0], mine[1], mine[2], mine[3]};
+            if (accumulate) v += *(const mgr_f4u*)d;
+            *(mgr_f4u*)d = v;
+        } else {
+#pragma unroll
+            for (int h = 0; h < PER / 4; ++h) {
+                mgr_f4u v = {mine[4 * h], mine[4 * h + 1], mine[4 * h + 2], mine[4 * h + 3]};
+                if (accumulate) v += *(const mgr_f4u*)(d + 4 * h);
+                *(mgr_f4u*)(d + 4 * h) = v;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < PER; ++j)
+            if (e0 + j < n) d[j] = accumulate ? d[j] + mine[j] : mine[j];
+    }
+}
+
 // Sum x[0..7] over the group and store them at dst[0..n) (n <= 8).
 template <int G>
 __device__ __forceinline__ void grp_store8(const float x[8], int vl, bool ok, float* __restrict__ dst, int n,
@@ -439,11 +480,7 @@ __device__ __forceinline__ void grp_store8(const float x[8], int vl, bool ok, fl
         float t[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) t[k] = grp_sum<G>(x[k]);
-        if (ok && vl == 0) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if (k < n) dst[k] = accumulate ? dst[k] + t[k] : t[k];
-        }
+        grp_store_span<G>(t, vl, ok, dst, n, accumulate);
     }
 }
 
@@ -474,13 +511,22 @@ __global__ __launch_bounds__(256) void k_inst_gather(
     uint32_t* __restrict__ active_list, MgrHeader* hdr, float* __restrict__ d_xyz, float* __restrict__ d_ls,
     float* __restrict__ d_rot, float* __restrict__ d_op, float* __restrict__ d_fdc, float* __restrict__ d_frest,
     float* __restrict__ d_w, float* __restrict__ st_grad2d, float* __restrict__ st_vis,
-    int32_t* __restrict__ st_radii) {
+    int32_t* __restrict__ st_radii, uint32_t* __restrict__ run_list) {
     constexpr int IPB = 256 / G;
     __shared__ uint32_t s_list[IPB * IG_ROUNDS];
     __shared__ uint32_t s_cnt, s_base;
+    // run_list (G = 8 only): besides the active list, the active Gaussians by lane class -- entry = Gaussian | view mask << 24,
+    // the mask of the views whose record sums are non-zero; class c = 0 / 1 / 2 holds the Gaussians with 5..8 / 3..4 / 1..2
+    // such views = runs of 8 / 4 / 2 lanes of k_inst_bwd_runs.  (Single-lane runs for the Gaussians with one view were
+    // measured: 0.105 against 0.099 ms -- 64 Gaussians per wave make every load and store of a row 64 cache lines wide.)
+    constexpr int RL = G == 8 ? IPB * IG_ROUNDS : 1;
+    __shared__ uint32_t s_rl[3][RL];
+    __shared__ uint32_t s_rc[3], s_rb[3];
+    const bool runs = G == 8 && run_list != nullptr;
     const int tid = threadIdx.x, vl = tid & (G - 1), il = tid / G, lane = tid & 63;
     if (blockIdx.x == 0 && tid < MGR_NCTR && v_first == 0) hdr->qctr[tid * 64] = 0u;   // the blend's queue is drained: ready for the next backward
     if (tid == 0) s_cnt = 0;
+    if (tid < 3) s_rc[tid] = 0;
     __syncthreads();
     const bool acc_out = accumulate != 0;
 #pragma unroll 1
@@ -513,7 +559,14 @@ __global__ __launch_bounds__(256) void k_inst_gather(
         if (G >= 2) maxrad = max(maxrad, __builtin_amdgcn_update_dpp(0, maxrad, 0xb1, 0xf, 0xf, false));
         if (G >= 4) maxrad = max(maxrad, __builtin_amdgcn_update_dpp(0, maxrad, 0x4e, 0xf, 0xf, false));
         if (G >= 8) maxrad = max(maxrad, __builtin_amdgcn_update_dpp(0, maxrad, 0x141, 0xf, 0xf, false));
-        if (ok && grp_any) {  // phase 2 reads these back, lane for lane
+        if (runs) {
+            const uint32_t m8 = (uint32_t)(__ballot(any) >> (lane & 56)) & 0xFFu;   // this Gaussian's views with a non-zero sum
+            if (ok && vl == 0 && m8) {
+                const int nv = __popc(m8), c = nv > 4 ? 0 : nv > 2 ? 1 : 2;
+                s_rl[c][atomicAdd(&s_rc[c], 1u)] = (uint32_t)i | (m8 << 24);
+            }
+        }
+        if (ok && (runs ? any : grp_any)) {  // phase 2 reads these back, lane for lane (the lanes of the view mask, with run lists)
             float4* o = iacc + ((size_t)i * G + vl) * 3;
             o[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
             o[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
@@ -561,53 +614,76 @@ __global__ __launch_bounds__(256) void k_inst_gather(
     if (tid == 0 && cnt) s_base = atomicAdd(&hdr->n_active, cnt);  // one global atomic per block
     __syncthreads();
     for (uint32_t k = tid; k < cnt; k += 256) active_list[s_base + k] = s_list[k];
+    if (runs) {
+        if (tid < 3) s_rb[tid] = s_rc[tid] ? atomicAdd(&hdr->n_runs[tid], s_rc[tid]) : 0u;
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            for (uint32_t k = tid; k < s_rc[c]; k += 256) run_list[(size_t)c * N + s_rb[c] + k] = s_rl[c][k];
+    }
 }
 
 // Phase 2: the whole per-view backward chain for the active Gaussians only.
-template <int G, int BMAX, bool MIXED, bool SH_HALF>
-__global__ __launch_bounds__(IB_THREADS) __attribute__((amdgpu_waves_per_eu(MGR_IB_WAVES, MGR_IB_WAVES))) void k_inst_bwd(
+// RUNS: a lane group is a RUN of G lanes for one Gaussian's views that hold records (list entry = Gaussian | view mask << 24,
+// lane r of the run takes the r-th set bit, lanes beyond the popcount idle), not its G views -- at eight views 41 % of the
+// (active Gaussian, view) lanes had a record (tools/instr/lane_stats.py); runs rounded up to 8 / 4 / 2 lanes take 0.53 of the
+// lanes (k_inst_bwd_runs): k_inst_bwd 0.124 -> 0.099 ms -- not 0.53 of it: per Gaussian the rows loaded and stored stay the same.
+template <int G, int BMAX, bool MIXED, bool SH_HALF, bool RUNS>
+__device__ __forceinline__ void inst_bwd_body(
+    int blk, int n_active, const uint32_t* __restrict__ active_list,
     int v_first, int v_count, int N, int B, int n_art, int W, int H, const float* __restrict__ cams,
     const float* __restrict__ xyz, const float* __restrict__ log_scale, const float* __restrict__ rot,
     const float* __restrict__ op_logit, const float* __restrict__ f_dc, const float* __restrict__ f_rest,
     const float* __restrict__ skin_w, const float* __restrict__ transforms, const float4* __restrict__ iacc,
-    const uint32_t* __restrict__ active_list, const MgrHeader* __restrict__ hdr, float grad2d_scale, int accumulate,
+    float grad2d_scale, int accumulate,
     float* __restrict__ d_xyz, float* __restrict__ d_ls, float* __restrict__ d_rot, float* __restrict__ d_op,
     float* __restrict__ d_fdc, float* __restrict__ d_frest, float* __restrict__ d_w, float* __restrict__ st_grad2d) {
     constexpr int IPB = IB_THREADS / G;
-    extern __shared__ __align__(16) float s_view[];  // G x (camera 40 | transforms IB_TSTRIDE(B))
-    const int n_active = (int)hdr->n_active;
-    if ((int)blockIdx.x * IPB >= n_active) return;
+    constexpr int NV = RUNS ? 8 : G;            // view slabs in LDS, lanes per Gaussian of iacc
+    extern __shared__ __align__(16) float s_view[];  // NV x (camera 40 | transforms IB_TSTRIDE(B))
+    if (blk * IPB >= n_active) return;
     const int tid = threadIdx.x, vl = tid & (G - 1), il = tid / G;
-    const int q = blockIdx.x * IPB + il;
+    const int q = blk * IPB + il;
     const bool ok = q < n_active;             // lane's Gaussian exists (all lanes stay for the DPP sums)
-    const int i = (int)active_list[min(q, n_active - 1)];
+    const uint32_t ent = active_list[min(q, n_active - 1)];
+    const int i = RUNS ? (int)(ent & 0xFFFFFFu) : (int)ent;
+    int view = vl;                            // this lane's view within the group
+    bool lane_on = true;
+    if (RUNS) {
+        uint32_t m = ent >> 24;
+        lane_on = vl < __popc(m);
+#pragma unroll
+        for (int k = 0; k < G - 1; ++k)
+            if (k < vl) m &= m - 1u;            // drop the vl lowest set bits
+        view = lane_on ? __builtin_ctz(m | 0x100u) : 0;
+    }
     const bool any_tf = skin_w != nullptr;          // workgroup-uniform: the pose slabs are staged in LDS
     // this lane's Gaussian is articulated (uniform over its lane group; over the launch unless MIXED = composite)
     const bool has_tf = any_tf && (!MIXED || i < n_art);
     const int tstride = IB_TSTRIDE(B), vstride = MGR_CAM_FLOATS + (any_tf ? tstride : 0);
-    for (int k = tid; k < G * MGR_CAM_FLOATS; k += IB_THREADS) {
+    for (int k = tid; k < NV * MGR_CAM_FLOATS; k += IB_THREADS) {
         const int g = k / MGR_CAM_FLOATS, e = k % MGR_CAM_FLOATS;
         s_view[g * vstride + e] = g < v_count ? cams[(size_t)(v_first + g) * MGR_CAM_FLOATS + e] : 0.f;
     }
     if (any_tf)
-        for (int k = tid; k < G * B * 16; k += IB_THREADS) {
+        for (int k = tid; k < NV * B * 16; k += IB_THREADS) {
             const int g = k / (B * 16), e = k % (B * 16);
             s_view[g * vstride + MGR_CAM_FLOATS + e] = g < v_count ? transforms[(size_t)(v_first + g) * B * 16 + e] : 0.f;
         }
     __syncthreads();
-    const float* const Tp = s_view + vl * vstride + MGR_CAM_FLOATS;
+    const float* const Tp = s_view + view * vstride + MGR_CAM_FLOATS;
 
     float acc[9];
     bool any = false;
     {
-        const float4* o = iacc + ((size_t)i * G + vl) * 3;
+        const float4* o = iacc + ((size_t)i * NV + view) * 3;
         const float4 a = o[0], b = o[1], c = o[2];
         acc[0] = a.x; acc[1] = a.y; acc[2] = a.z; acc[3] = a.w;
         acc[4] = b.x; acc[5] = b.y; acc[6] = b.z; acc[7] = b.w;
         acc[8] = c.x;
 #pragma unroll
         for (int k = 0; k < 9; ++k) any = any || (acc[k] != 0.f);
-        any = any && ok && vl < v_count;
+        any = any && ok && lane_on && view < v_count;
     }
     GaussCano g;
     cano_load(xyz, log_scale, rot, i, g);
@@ -622,7 +698,7 @@ __global__ __launch_bounds__(IB_THREADS) __attribute__((amdgpu_waves_per_eu(MGR_
         if (any) {  // culled, or hidden behind saturated pixels everywhere, otherwise
             MgrCam cam;
             {
-                const float* p = s_view + vl * vstride;
+                const float* p = s_view + view * vstride;
                 cam.tanfovx = p[0];
                 cam.tanfovy = p[1];
 #pragma unroll
@@ -658,7 +734,7 @@ __global__ __launch_bounds__(IB_THREADS) __attribute__((amdgpu_waves_per_eu(MGR_
                 const int e = 8 * m + vl;
                 float* dst = e < 3 ? d_fdc + (size_t)i * 3 + e : d_frest + (size_t)i * 45 + (e - 3);
                 if (ok) *dst = acc_out ? *dst + t : t;
-            } else {
+            } else if (m == 0) {   // the block that straddles f_dc | f_rest: element by element
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     const int e = 8 * m + k;
@@ -666,6 +742,11 @@ __global__ __launch_bounds__(IB_THREADS) __attribute__((amdgpu_waves_per_eu(MGR_
                     float* dst = e < 3 ? d_fdc + (size_t)i * 3 + e : d_frest + (size_t)i * 45 + (e - 3);
                     if (ok && vl == 0) *dst = acc_out ? *dst + t : t;
                 }
+            } else {
+                float t[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) t[k] = grp_sum<G>(dsh[8 * m + k]);
+                grp_store_span<G>(t, vl, ok, d_frest + (size_t)i * 45 + (8 * m - 3), 8, acc_out);
             }
         }
     }
@@ -724,6 +805,40 @@ __global__ __launch_bounds__(IB_THREADS) __attribute__((amdgpu_waves_per_eu(MGR_
         }
     }
 }
+
+#define MGR_IB_PARAMS                                                                                                 \
+    int v_first, int v_count, int N, int B, int n_art, int W, int H, const float *__restrict__ cams,                    \
+        const float *__restrict__ xyz, const float *__restrict__ log_scale, const float *__restrict__ rot,             \
+        const float *__restrict__ op_logit, const float *__restrict__ f_dc, const float *__restrict__ f_rest,          \
+        const float *__restrict__ skin_w, const float *__restrict__ transforms, const float4 *__restrict__ iacc,       \
+        const uint32_t *__restrict__ active_list, const MgrHeader *__restrict__ hdr, float grad2d_scale, int accumulate, \
+        float *__restrict__ d_xyz, float *__restrict__ d_ls, float *__restrict__ d_rot, float *__restrict__ d_op,      \
+        float *__restrict__ d_fdc, float *__restrict__ d_frest, float *__restrict__ d_w, float *__restrict__ st_grad2d
+#define MGR_IB_ARGS                                                                                                   \
+    v_first, v_count, N, B, n_art, W, H, cams, xyz, log_scale, rot, op_logit, f_dc, f_rest, skin_w, transforms, iacc,  \
+        grad2d_scale, accumulate, d_xyz, d_ls, d_rot, d_op, d_fdc, d_frest, d_w, st_grad2d
+// lane group = the G views of an active Gaussian (active_list: Gaussian indices)
+template <int G, int BMAX, bool MIXED, bool SH_HALF>
+__global__ __launch_bounds__(IB_THREADS) __attribute__((amdgpu_waves_per_eu(MGR_IB_WAVES, MGR_IB_WAVES))) void k_inst_bwd(MGR_IB_PARAMS) {
+    inst_bwd_body<G, BMAX, MIXED, SH_HALF, false>((int)blockIdx.x, (int)hdr->n_active, active_list, MGR_IB_ARGS);
+}
+// lane group = a run of 8 / 4 / 2 lanes (active_list: the three run lists of k_inst_gather, N entries apart): the
+// workgroups of the three classes follow each other in one launch, so that the classes share the rounds of the launch
+template <int BMAX, bool MIXED, bool SH_HALF>
+__global__ __launch_bounds__(IB_THREADS) __attribute__((amdgpu_waves_per_eu(MGR_IB_WAVES, MGR_IB_WAVES))) void k_inst_bwd_runs(MGR_IB_PARAMS) {
+    const int n8 = (int)hdr->n_runs[0], n4 = (int)hdr->n_runs[1], n2 = (int)hdr->n_runs[2];
+    int blk = (int)blockIdx.x;
+    const int b8 = (n8 + IB_THREADS / 8 - 1) / (IB_THREADS / 8), b4 = (n4 + IB_THREADS / 4 - 1) / (IB_THREADS / 4);
+    if (blk < b8) { inst_bwd_body<8, BMAX, MIXED, SH_HALF, true>(blk, n8, active_list, MGR_IB_ARGS); return; }
+    blk -= b8;
+    if (blk < b4) { inst_bwd_body<4, BMAX, MIXED, SH_HALF, true>(blk, n4, active_list + (size_t)N, MGR_IB_ARGS); return; }
+    blk -= b4;
+    inst_bwd_body<2, BMAX, MIXED, SH_HALF, true>(blk, n2, active_list + 2 * (size_t)N, MGR_IB_ARGS);
+}
+
+// process-wide switch of the run lists (default on; MANUS_INST_RUNS=0 in the environment starts with them off)
+static std::atomic<int> g_inst_runs{[] { const char* e = getenv("MANUS_INST_RUNS"); return e ? atoi(e) : 1; }()};
+extern "C" int mgr_views_backward_run_lists(int on) { return g_inst_runs.exchange(on ? 1 : 0); }
 
 struct CanonGrads {  // fused articulated backward: canonical inputs and leaf-gradient outputs
     int B, n_art, sh_half;
@@ -788,13 +903,19 @@ static int raster_backward_impl(int V, int N, int W, int H, const float* cams, c
         for (int v0 = 0; v0 < V; v0 += Gv) {
             const int vc = V - v0 < Gv ? V - v0 : Gv;
             const int accm = v0 > 0 ? 1 : 0;
-            if (v0 > 0) MGR_HIP(hipMemsetAsync(&hdr->n_active, 0, 4, stream));  // the first group's zero comes from k_blend_bwd
+            if (v0 > 0) {   // the first group's zeros come from k_blend_bwd
+                MGR_HIP(hipMemsetAsync(&hdr->n_active, 0, 4, stream));
+                MGR_HIP(hipMemsetAsync(&hdr->n_runs[0], 0, 12, stream));
+            }
+            // run lists (see k_inst_bwd_runs): eight-lane groups, up to 24 transforms, Gaussian indices of 24 bits
+            const bool runs = g_inst_runs.load(std::memory_order_relaxed) != 0 && Gv == 8 && canon->B <= 24 && N < (1 << 24);
+            uint32_t* rlist = alist + (size_t)N;   // three lists of N entries behind the active list
 #define MGR_IG_LAUNCH(GG)                                                                                             \
     hipLaunchKernelGGL((k_inst_gather<GG>), grid_g, dim3(256), 0, stream, v0, vc, N, canon->B, canon->n_art, canon->radii, \
                        (const ushort4*)(ws + L.rect), (const uint32_t*)(ws + L.pair_off),                             \
                        (const uint32_t*)(ws + L.pair_tag), (const float4*)(ws + L.pair_grad),                        \
                        (const uint32_t*)(ws + L.inst_tag), (uint32_t)cap, epoch, accm, rounds, iacc, alist, hdr, canon->d_xyz, canon->d_ls, canon->d_rot, canon->d_op, canon->d_fdc,    \
-                       canon->d_frest, canon->d_w, canon->st_grad2d, canon->st_vis, canon->st_radii)
+                       canon->d_frest, canon->d_w, canon->st_grad2d, canon->st_vis, canon->st_radii, runs ? rlist : (uint32_t*)nullptr)
 #define MGR_IB_LAUNCH(GG, BB)                                                                                         \
     if (mixed && canon->sh_half) MGR_IB_LAUNCH2(GG, BB, true, true);                                                  \
     else if (mixed) MGR_IB_LAUNCH2(GG, BB, true, false);                                                              \
@@ -814,6 +935,19 @@ static int raster_backward_impl(int V, int N, int W, int H, const float* cams, c
                 else MGR_IG_LAUNCH(1);
             }
             MGR_PROF("k_inst_bwd", stream);
+#define MGR_IBR_LAUNCH(MX, HF)                                                                                        \
+    hipLaunchKernelGGL((k_inst_bwd_runs<24, MX, HF>), dim3(grid.x + 3), dim3(IB_THREADS), lds, stream, v0, vc, N, canon->B, canon->n_art, W, H, cams, canon->xyz, \
+                       canon->log_scale, canon->rot, canon->op_logit, canon->f_dc, canon->f_rest, canon->skin_w,      \
+                       canon->transforms, (const float4*)iacc, (const uint32_t*)rlist, (const MgrHeader*)hdr,         \
+                       canon->grad2d_scale, accm, canon->d_xyz, canon->d_ls, canon->d_rot, canon->d_op, canon->d_fdc, \
+                       canon->d_frest, canon->d_w, canon->st_grad2d)
+            if (runs) {
+                if (mixed && canon->sh_half) MGR_IBR_LAUNCH(true, true);
+                else if (mixed) MGR_IBR_LAUNCH(true, false);
+                else if (canon->sh_half) MGR_IBR_LAUNCH(false, true);
+                else MGR_IBR_LAUNCH(false, false);
+            } else
+#undef MGR_IBR_LAUNCH
             if (canon->B <= 24) {
                 if (Gv == 8) MGR_IB_LAUNCH(8, 24);
                 else if (Gv == 4) MGR_IB_LAUNCH(4, 24);

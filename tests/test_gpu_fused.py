@@ -79,6 +79,37 @@ def test_fused_equals_modular_view_counts(views):
     assert max_rel_err(of["grad2d"].cpu().numpy(), om["grad2d"].cpu().numpy()) < 5e-3
 
 
+@pytest.mark.parametrize("kind,views", [("hand", 8), ("hand", 5), ("composite", 7), ("hand", 11)])
+def test_run_lists_equal_one_lane_per_view(kind, views):
+    """mgr_views_backward_run_lists: an active Gaussian on 8 / 4 / 2 lanes by the number of its views with records against
+    one lane per view.  Same per-view values, summed over a tree of fewer terms: leaf gradients agree to rounding (1e-5 of
+    the largest entry: the views' terms of a Gaussian can be larger than their sum), rows no view contributes to stay exactly zero, statistics and the active list are the same set;
+    each setting is bit-reproducible.  (11 views: the second view group accumulates.)"""
+    from manus_amd._lib import lib
+    from manus_amd.engine import HipViewCompute
+    sc, ct = _scene(kind, n=6000, views=views)
+    tg = torch.rand((views, 3, 64, 96), device=DEV, generator=torch.Generator(device=DEV).manual_seed(views))
+    ids = list(range(views))
+    hc = HipViewCompute(sc, tg, ct, fused=True)
+    clone = lambda o: {k: ({q: t.clone() for q, t in v.items()} if isinstance(v, dict) else v.clone()) for k, v in o.items()}
+    prev = lib().mgr_views_backward_run_lists(1)
+    try:
+        on1 = clone(hc(ids, 1.0 / views))
+        on2 = clone(hc(ids, 1.0 / views))
+        assert lib().mgr_views_backward_run_lists(0) == 1
+        off = clone(hc(ids, 1.0 / views))
+    finally:
+        lib().mgr_views_backward_run_lists(prev)
+    for k in on1["grads"]:
+        assert torch.equal(on1["grads"][k], on2["grads"][k]), k
+        a, b = on1["grads"][k].double(), off["grads"][k].double()
+        assert float((a - b).abs().max()) <= 1e-5 * max(float(b.abs().max()), 1e-30), (k, float((a - b).abs().max()), float(b.abs().max()))
+        assert torch.equal(a.reshape(a.shape[0], -1).abs().sum(1) == 0, b.reshape(b.shape[0], -1).abs().sum(1) == 0), k
+    assert torch.equal(on1["vis"], off["vis"]) and torch.equal(on1["radii"], off["radii"])
+    assert float((on1["grad2d"].double() - off["grad2d"].double()).abs().max()) <= 1e-5 * float(off["grad2d"].abs().max())
+    assert abs(float(on1["loss"]) - float(off["loss"])) < 1e-6   # (the loss scalar is summed with float atomics)
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # The fused path against the ORACLE on identical blend inputs (north_star bars: PSNR delta < 0.01 dB, grad
 # max-rel-err < 1e-4), alpha-threshold flips accounted for instead of avoided by the choice of seed: see
