@@ -623,6 +623,128 @@ __global__ __launch_bounds__(256) void k_inst_gather(
     }
 }
 
+// Phase 1 with run lists (eight-lane groups, k_inst_bwd_runs behind it).  k_inst_gather<8> gives every (Gaussian, view) of
+// its range a lane that walks the instance's pair slots -- 18 % of those lanes have records on the bench step, and a wave
+// lasts as long as its lane with the most records.  Here the workgroup first compacts the instances that hold records
+// (radius > 0 and the epoch tag) of its <= 256 Gaussians into an LDS work list (A), then walks the list with all lanes
+// busy (B: the record sums of an instance by one lane, in slot order as before: the same values bit for bit), and last
+// turns the per-Gaussian view masks the walk left in LDS into the active list and the run lists (C).
+__global__ __launch_bounds__(256) void k_inst_gather_runs(
+    int v_first, int v_count, int N, int B, int n_art, const int32_t* __restrict__ radii, const ushort4* __restrict__ rect,
+    const uint32_t* __restrict__ pair_off, const uint32_t* __restrict__ pair_tag,
+    const float4* __restrict__ pair_grad, const uint32_t* __restrict__ inst_tag, uint32_t cap, uint32_t epoch,
+    int accumulate, int rounds, float4* __restrict__ iacc,
+    uint32_t* __restrict__ active_list, MgrHeader* hdr, float* __restrict__ d_xyz, float* __restrict__ d_ls,
+    float* __restrict__ d_rot, float* __restrict__ d_op, float* __restrict__ d_fdc, float* __restrict__ d_frest,
+    float* __restrict__ d_w, float* __restrict__ st_grad2d, float* __restrict__ st_vis,
+    int32_t* __restrict__ st_radii, uint32_t* __restrict__ run_list) {
+    constexpr int G = 8, IPB = 256 / G, NG = IPB * IG_ROUNDS;
+    __shared__ uint32_t s_wi[NG * G], s_wo[NG * G], s_wc[NG * G];   // work list: (local Gaussian << 3 | view), first slot, slots
+    __shared__ uint32_t s_mask[NG];                                 // per Gaussian: views with a non-zero sum
+    __shared__ uint32_t s_list[NG], s_rl[3][NG];
+    __shared__ uint32_t s_nw, s_cnt, s_base, s_rc[3], s_rb[3];
+    const int tid = threadIdx.x, vl = tid & (G - 1), il = tid / G, lane = tid & 63;
+    if (blockIdx.x == 0 && tid < MGR_NCTR && v_first == 0) hdr->qctr[tid * 64] = 0u;   // the blend's queue is drained: ready for the next backward
+    if (tid == 0) { s_nw = 0; s_cnt = 0; }
+    if (tid < 3) s_rc[tid] = 0;
+    s_mask[tid] = 0u;    // (NG == 256 threads)
+    __syncthreads();
+    const bool acc_out = accumulate != 0;
+    const int i_base = blockIdx.x * rounds * IPB;
+    // ---- A: the instances with records -> work list; visibility statistics
+#pragma unroll 1
+    for (int rnd = 0; rnd < rounds; ++rnd) {
+        const int i_raw = i_base + rnd * IPB + il;
+        const int i = min(i_raw, N - 1);
+        const bool ok = i_raw < N, mine = ok && vl < v_count;
+        const size_t vi = (size_t)min(v_first + vl, v_first + v_count - 1) * N + i;
+        const int rd = radii[vi];
+        const uint32_t tg = inst_tag[vi];
+        const ushort4 rc = rect[vi];
+        const uint32_t po = pair_off[vi];
+        const int rad = mine ? rd : 0;
+        const bool act = rad > 0 && tg == epoch;
+        const float vis = grp_sum<G>(rad > 0 ? 1.0f : 0.0f);
+        int maxrad = rad;
+        maxrad = max(maxrad, __builtin_amdgcn_update_dpp(0, maxrad, 0xb1, 0xf, 0xf, false));
+        maxrad = max(maxrad, __builtin_amdgcn_update_dpp(0, maxrad, 0x4e, 0xf, 0xf, false));
+        maxrad = max(maxrad, __builtin_amdgcn_update_dpp(0, maxrad, 0x141, 0xf, 0xf, false));
+        const unsigned long long m = __ballot(act);
+        if (m) {
+            const int first = __builtin_ctzll(m);
+            uint32_t base = 0;
+            if (lane == first) base = atomicAdd(&s_nw, (uint32_t)__popcll(m));
+            base = (uint32_t)__shfl((int)base, first, 64);
+            if (act) {
+                const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                s_wi[pos] = ((uint32_t)(rnd * IPB + il) << 3) | (uint32_t)vl;
+                s_wo[pos] = po;
+                s_wc[pos] = (uint32_t)((rc.z - rc.x) * (rc.w - rc.y));
+            }
+        }
+        if (ok && vl == 0) {
+            if (st_vis) st_vis[i] = acc_out ? st_vis[i] + vis : vis;
+            if (st_radii) st_radii[i] = acc_out ? max(st_radii[i], maxrad) : maxrad;
+        }
+    }
+    __syncthreads();
+    // ---- B: record sums, one instance per lane
+    const uint32_t n_work = s_nw;
+    for (uint32_t k = (uint32_t)tid; k < n_work; k += 256u) {
+        const uint32_t w = s_wi[k];
+        float acc[9];
+        gather_pair_grads(s_wo[k], s_wc[k], pair_tag, pair_grad, cap, epoch, acc);
+        bool any = false;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) any = any || (acc[q] != 0.f);
+        if (any) {
+            float4* o = iacc + ((size_t)(i_base + (int)(w >> 3)) * G + (w & 7u)) * 3;
+            o[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            o[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+            o[2] = make_float4(acc[8], 0.f, 0.f, 0.f);
+            atomicOr(&s_mask[w >> 3], 1u << (w & 7u));
+        }
+    }
+    if (!acc_out) {   // zero gradients for the Gaussians of this workgroup (see k_inst_gather)
+        const size_t i_lo = (size_t)i_base;
+        const size_t i_hi = min((size_t)N, i_lo + (size_t)rounds * IPB);
+        if (i_hi > i_lo) {
+            const size_t n = i_hi - i_lo;
+            for (size_t k = tid; k < n * 3; k += 256) { d_xyz[i_lo * 3 + k] = 0.f; d_ls[i_lo * 3 + k] = 0.f; d_fdc[i_lo * 3 + k] = 0.f; }
+            for (size_t k = tid; k < n * 4; k += 256) d_rot[i_lo * 4 + k] = 0.f;
+            for (size_t k = tid; k < n * 45; k += 256) d_frest[i_lo * 45 + k] = 0.f;
+            if (d_w && i_lo < (size_t)n_art) {
+                const size_t na = min(i_hi, (size_t)n_art) - i_lo;
+                for (size_t k = tid; k < na * (size_t)B; k += 256) d_w[i_lo * B + k] = 0.f;
+            }
+            for (size_t k = tid; k < n; k += 256) {
+                d_op[i_lo + k] = 0.f;
+                if (st_grad2d) st_grad2d[i_lo + k] = 0.f;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- C: active list and run lists from the view masks
+    {
+        const uint32_t m8 = tid < rounds * IPB ? s_mask[tid] : 0u;
+        if (m8) {
+            const uint32_t i = (uint32_t)(i_base + tid);
+            s_list[atomicAdd(&s_cnt, 1u)] = i;
+            const int nv = __popc(m8), c = nv > 4 ? 0 : nv > 2 ? 1 : 2;
+            s_rl[c][atomicAdd(&s_rc[c], 1u)] = i | (m8 << 24);
+        }
+    }
+    __syncthreads();
+    const uint32_t cnt = s_cnt;
+    if (tid == 0 && cnt) s_base = atomicAdd(&hdr->n_active, cnt);
+    if (tid < 3) s_rb[tid] = s_rc[tid] ? atomicAdd(&hdr->n_runs[tid], s_rc[tid]) : 0u;
+    __syncthreads();
+    for (uint32_t k = tid; k < cnt; k += 256) active_list[s_base + k] = s_list[k];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        for (uint32_t k = tid; k < s_rc[c]; k += 256) run_list[(size_t)c * N + s_rb[c] + k] = s_rl[c][k];
+}
+
 // Phase 2: the whole per-view backward chain for the active Gaussians only.
 // RUNS: a lane group is a RUN of G lanes for one Gaussian's views that hold records (list entry = Gaussian | view mask << 24,
 // lane r of the run takes the r-th set bit, lanes beyond the popcount idle), not its G views -- at eight views 41 % of the
@@ -838,7 +960,7 @@ __global__ __launch_bounds__(IB_THREADS) __attribute__((amdgpu_waves_per_eu(MGR_
 
 // process-wide switch of the run lists (default on; MANUS_INST_RUNS=0 in the environment starts with them off)
 static std::atomic<int> g_inst_runs{[] { const char* e = getenv("MANUS_INST_RUNS"); return e ? atoi(e) : 1; }()};
-extern "C" int mgr_views_backward_run_lists(int on) { return g_inst_runs.exchange(on ? 1 : 0); }
+extern "C" int mgr_views_backward_run_lists(int on) { return g_inst_runs.exchange(on); }   // (2: run lists from k_inst_gather<8>, for A/B)
 
 struct CanonGrads {  // fused articulated backward: canonical inputs and leaf-gradient outputs
     int B, n_art, sh_half;
@@ -929,7 +1051,13 @@ static int raster_backward_impl(int V, int N, int W, int H, const float* cams, c
                        canon->d_frest, canon->d_w, canon->st_grad2d)
             {
                 MGR_PROF("k_inst_gather", stream);
-                if (Gv == 8) MGR_IG_LAUNCH(8);
+                if (runs && g_inst_runs.load(std::memory_order_relaxed) != 2)
+                    hipLaunchKernelGGL(k_inst_gather_runs, grid_g, dim3(256), 0, stream, v0, vc, N, canon->B, canon->n_art, canon->radii,
+                                       (const ushort4*)(ws + L.rect), (const uint32_t*)(ws + L.pair_off),
+                                       (const uint32_t*)(ws + L.pair_tag), (const float4*)(ws + L.pair_grad),
+                                       (const uint32_t*)(ws + L.inst_tag), (uint32_t)cap, epoch, accm, rounds, iacc, alist, hdr, canon->d_xyz, canon->d_ls, canon->d_rot, canon->d_op, canon->d_fdc,
+                                       canon->d_frest, canon->d_w, canon->st_grad2d, canon->st_vis, canon->st_radii, rlist);
+                else if (Gv == 8) MGR_IG_LAUNCH(8);
                 else if (Gv == 4) MGR_IG_LAUNCH(4);
                 else if (Gv == 2) MGR_IG_LAUNCH(2);
                 else MGR_IG_LAUNCH(1);
