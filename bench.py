@@ -285,6 +285,8 @@ def main():
     ap.add_argument("--dense-loss-scan", action="store_true",
                     help="image loss without the rasterizer's tile occupancy: compares rendered and target image everywhere "
                          "to find the spans that need work (the default settles spans under empty tiles from the target alone)")
+    ap.add_argument("--gaussian-order", default="given", choices=["given", "morton"],
+                    help="morton: the model's rows sorted along a Z-order curve first (a what-if for spatially coherent rows; not the headline)")
     ap.add_argument("--no-depth-cut", action="store_true",
                     help="bin every pair every step (no use of the previous forward's per-tile saturation depth)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (cpu_baseline and parity)")
@@ -310,6 +312,18 @@ def main():
 
     V, N, W, H = args.views, args.gaussians, args.width, args.height
     scene = make_scene(n_gaussians=N, kind=args.kind, seed=0, n_cameras=V, width=W, height=H, device=dev)
+    if args.gaussian_order == "morton":   # (an experiment, not the headline workload: the rows of a spatially sorted model)
+        xyz = scene["params"]["_xyz"]
+        q = ((xyz - xyz.min(0).values) / (xyz.max(0).values - xyz.min(0).values + 1e-12) * 1023.0).long().clamp_(0, 1023)
+        code = torch.zeros(xyz.shape[0], dtype=torch.long, device=xyz.device)
+        for bit in range(10):
+            for ax in range(3):
+                code |= ((q[:, ax] >> bit) & 1) << (3 * bit + ax)
+        nh = scene["n_hand"] if scene["kind"] == "composite" else 0
+        if nh:   # the articulated rows stay in front of the static ones
+            code = code + (torch.arange(xyz.shape[0], device=xyz.device) >= nh).long() * (1 << 31)
+        perm = torch.argsort(code)
+        scene["params"] = {k: v[perm].contiguous() for k, v in scene["params"].items()}
     ct = camera_table(scene["cameras"], dev)
 
     # target images: the same scene with parameters perturbed by 1 % (non-trivial dL/dimage)
@@ -592,7 +606,7 @@ def main():
                     "composite": "COMPOSITE: %d Gaussians (hand, 21-transform LBS + static object)" % N}.get(args.kind, args.kind)
         ms = [1e3 * d_ / args.steps for d_ in dts]
         line = {
-            "metric": metric, "headline": bool(headline),
+            "metric": metric, "headline": bool(headline and args.gaussian_order == "given"),
             "value": round(args.steps / dt, 4), "unit": "iters/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4), "repeats": REPEATS,
             "ms_per_step_min": round(min(ms), 4), "ms_per_step_max": round(max(ms), 4), "higher_is_better": True,
@@ -607,6 +621,7 @@ def main():
                                       "detail": "dense 61N floats" if mode == "dense" else
                                                 "rows with a gradient (%s of %d) x 60 floats + 2N bytes" % (step.last_rows, N)}),
                        "optimizer_in_step": bool(args.optimizer), "sh_storage": args.sh_storage,
+                       "gaussian_order": args.gaussian_order,
                        "remeasured_without_hints": remeasured,
                        "depth_cut": ("off" if not compute.depth_cut else
                                      "per-tile saturation depth of the previous forward of the same views bounds the binning; exact "
