@@ -785,10 +785,14 @@ class Trainer:
     over the ranks; max_radii2D is MAX-reduced before it is consumed."""
 
     def __init__(self, compute, n_views, extent, opts=None, spatial_lr_scale=1.0, rank=0, world_size=1, group=None,
-                 bg_white=True, kind=None, compact_allreduce=False, sharded_adam=False, view_weights=None, depth_cut=False):
+                 bg_white=True, kind=None, compact_allreduce=False, sharded_adam=False, view_weights=None, depth_cut=False,
+                 sort_rows=False):
         # sharded_adam (world_size > 1): reduce-scatter of the gradients -> every rank takes the Adam step on the 1/world
         # of the parameter elements it owns -> all-gather of the parameters.  The same bytes on the wire as the
         # all-reduce (which is a reduce-scatter followed by an all-gather), 1/world of the optimizer work per rank.
+        # sort_rows: after a densification / pruning has rebuilt the tensors, put the rows in Z-order of their positions
+        # (GaussianOptimizer.sort_rows: the same model up to the permutation; every rank computes the same one)
+        self.sort_rows = bool(sort_rows)
         self.compact_allreduce = compact_allreduce and not sharded_adam
         self.sharded_adam = bool(sharded_adam) and world_size > 1
         from . import rasterizer
@@ -916,6 +920,8 @@ class Trainer:
         if changed:
             self.density.on_train_epoch_start()
         resized = changed and (self.opt.N != n_before or self.opt.replaced == ALL_GROUPS)   # new leaf tensors
+        if resized and self.sort_rows and self.opt.replaced == ALL_GROUPS:
+            out["row_perm"] = self.opt.sort_rows()
         # ---- on_before_optimizer_step + optimizer.step() ----
         self.opt.update_learning_rate(gs)
         if self.sharded_adam:

@@ -54,6 +54,51 @@ def test_training_loop_learns_and_densifies():
     assert tr.opt.m["_xyz"].shape[0] == tr.opt.N and torch.isfinite(tr.opt.v["_features_rest"]).all()
 
 
+def test_trainer_sort_rows_is_the_same_model_up_to_the_row_order():
+    """Trainer(sort_rows=True): after a densification the rows follow a Z-order curve of the positions; leaves, Adam moments
+    and statistics are those of a Trainer without it, row for row under the returned permutation (bit-equal at the step of
+    the densification); the steps after it see the same model (losses agree to rounding: sums over Gaussians in another order)."""
+    from manus_amd import rasterizer
+    from manus_amd.engine import HipViewCompute, Trainer
+    from manus_amd.synthetic import camera_table, make_scene
+    V, W, H = 3, 128, 96
+    opts = dict(densify_from_step=5, densification_interval=5, densify_until_step=1000, opacity_reset_interval=100000,
+                percent_dense=0.01, densify_grad_threshold=5e-5)
+    rasterizer.set_sync_policy(True)
+
+    def make(sort):
+        torch.manual_seed(0)
+        sc = make_scene(n_gaussians=5000, kind="hand", seed=4, grid_res=32, n_cameras=V, width=W, height=H, cam_radius=0.5,
+                        sigma_range=(2e-3, 6e-3), device=DEV)
+        ct = camera_table(sc["cameras"], DEV)
+        tg = torch.rand((V, 3, H, W), device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))
+        return Trainer(HipViewCompute(sc, tg, ct, loss="l1+ssim"), V, extent=0.3, opts=opts, spatial_lr_scale=0.05,
+                       bg_white=False, sort_rows=sort)
+
+    a, b = make(False), make(True)
+    perm = None
+    for it in range(14):
+        torch.manual_seed(100 + it)          # the split noise of both trainers
+        oa = a.train_step()
+        torch.manual_seed(100 + it)
+        ob = b.train_step()
+        if perm is None and "row_perm" in ob:
+            perm = ob["row_perm"]
+            assert a.opt.N == b.opt.N == perm.numel() and a.opt.N != 5000
+            for k in a.opt.p:
+                assert torch.equal(a.opt.p[k][perm], b.opt.p[k]), k
+                assert torch.equal(a.opt.m[k][perm], b.opt.m[k]) and torch.equal(a.opt.v[k][perm], b.opt.v[k]), k
+            assert torch.equal(a.opt.max_radii2D[perm], b.opt.max_radii2D) and torch.equal(a.opt.denom[perm], b.opt.denom)
+            x = b.opt.p["_xyz"]
+            # Z-order: consecutive rows are close (median step well under the model's extent; shuffled rows are not)
+            step_sorted = (x[1:] - x[:-1]).norm(dim=1).median()
+            step_given = (a.opt.p["_xyz"][1:] - a.opt.p["_xyz"][:-1]).norm(dim=1).median()
+            assert float(step_sorted) < 0.25 * float(step_given)
+        assert abs(float(oa["loss"]) - float(ob["loss"])) <= 2e-5 * abs(float(oa["loss"])), (it, float(oa["loss"]), float(ob["loss"]))
+    assert perm is not None
+    assert "row_perm" not in oa
+
+
 def test_trainer_follows_reference_step_order_and_prunes_by_mask():
     """on_after_backward before optimizer.step(): at step 0 (< remove_seg_end) Gaussians that project outside the
     segmentation mask are pruned and that step's Adam update is skipped for every (replaced) leaf; the following steps
