@@ -79,15 +79,16 @@ def test_fused_equals_modular_view_counts(views):
     assert max_rel_err(of["grad2d"].cpu().numpy(), om["grad2d"].cpu().numpy()) < 5e-3
 
 
-@pytest.mark.parametrize("kind,views", [("hand", 8), ("hand", 5), ("composite", 7), ("hand", 11)])
-def test_run_lists_equal_one_lane_per_view(kind, views):
+@pytest.mark.parametrize("kind,views,n", [("hand", 8, 6000), ("hand", 5, 6000), ("composite", 7, 6000), ("hand", 11, 6000),
+                                            ("hand", 8, 37), ("hand", 6, 1), ("composite", 8, 263)])
+def test_run_lists_equal_one_lane_per_view(kind, views, n):
     """mgr_views_backward_run_lists: an active Gaussian on 8 / 4 / 2 lanes by the number of its views with records against
     one lane per view.  Same per-view values, summed over a tree of fewer terms: leaf gradients agree to rounding (1e-5 of
     the largest entry: the views' terms of a Gaussian can be larger than their sum), rows no view contributes to stay exactly zero, statistics and the active list are the same set;
     each setting is bit-reproducible.  (11 views: the second view group accumulates.)"""
     from manus_amd._lib import lib
     from manus_amd.engine import HipViewCompute
-    sc, ct = _scene(kind, n=6000, views=views)
+    sc, ct = _scene(kind, n=n, views=views)      # (37 / 1 / 263 Gaussians: partial lane groups, partial workgroups, a composite boundary inside one)
     tg = torch.rand((views, 3, 64, 96), device=DEV, generator=torch.Generator(device=DEV).manual_seed(views))
     ids = list(range(views))
     hc = HipViewCompute(sc, tg, ct, fused=True)
