@@ -194,9 +194,11 @@ int mgr_views_backward(int V, int N, int B, int n_articulated, int sh_half, int 
 int mgr_views_active_list(void* workspace, int V, int N, int W, int H, int64_t pair_capacity, const uint32_t** list,
                           const uint32_t** count);
 
-/* Lane layout of the fused per-instance backward at 5..8 views per group (process-wide; returns the previous setting).
+/* Lane layout of the fused per-instance backward at 3..8 views per group (lane groups of four or eight; process-wide; returns
+ * the previous setting).
  * on (default; MANUS_INST_RUNS=0 in the environment starts with it off): an active Gaussian takes 8 / 4 / 2 lanes by the
- * number of its views that hold pair-gradient records (41 % of the (active Gaussian, view) lanes did on the bench step);
+ * number of its views that hold pair-gradient records (41 % of the (active Gaussian, view) lanes did on the bench step), and
+ * the gather walks a compacted list of the instances with records;
  * off: always one lane per view.  The per-view contributions are summed in ascending view order either way, over a tree of
  * the views with records (on) or of all views (off): the results agree to rounding (tests/test_gpu_fused.py), each is
  * bit-reproducible.  No reference counterpart (there, autograd accumulates the views' contributions into .grad). */

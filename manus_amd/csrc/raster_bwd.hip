@@ -623,12 +623,13 @@ __global__ __launch_bounds__(256) void k_inst_gather(
     }
 }
 
-// Phase 1 with run lists (eight-lane groups, k_inst_bwd_runs behind it).  k_inst_gather<8> gives every (Gaussian, view) of
+// Phase 1 with run lists (k_inst_bwd_runs behind it; G = 1: the active list alone, k_inst_bwd<1> behind it).  k_inst_gather<G> gives every (Gaussian, view) of
 // its range a lane that walks the instance's pair slots -- 18 % of those lanes have records on the bench step, and a wave
 // lasts as long as its lane with the most records.  Here the workgroup first compacts the instances that hold records
 // (radius > 0 and the epoch tag) of its <= 256 Gaussians into an LDS work list (A), then walks the list with all lanes
 // busy (B: the record sums of an instance by one lane, in slot order as before: the same values bit for bit), and last
 // turns the per-Gaussian view masks the walk left in LDS into the active list and the run lists (C).
+template <int G>
 __global__ __launch_bounds__(256) void k_inst_gather_runs(
     int v_first, int v_count, int N, int B, int n_art, const int32_t* __restrict__ radii, const ushort4* __restrict__ rect,
     const uint32_t* __restrict__ pair_off, const uint32_t* __restrict__ pair_tag,
@@ -638,7 +639,7 @@ __global__ __launch_bounds__(256) void k_inst_gather_runs(
     float* __restrict__ d_rot, float* __restrict__ d_op, float* __restrict__ d_fdc, float* __restrict__ d_frest,
     float* __restrict__ d_w, float* __restrict__ st_grad2d, float* __restrict__ st_vis,
     int32_t* __restrict__ st_radii, uint32_t* __restrict__ run_list) {
-    constexpr int G = 8, IPB = 256 / G, NG = IPB * IG_ROUNDS;
+    constexpr int IPB = 256 / G, NG = 256;   // at most 256 Gaussians per workgroup (the caller keeps rounds <= G)
     __shared__ uint32_t s_wi[NG * G], s_wo[NG * G], s_wc[NG * G];   // work list: (local Gaussian << 3 | view), first slot, slots
     __shared__ uint32_t s_mask[NG];                                 // per Gaussian: views with a non-zero sum
     __shared__ uint32_t s_list[NG], s_rl[3][NG];
@@ -666,9 +667,9 @@ __global__ __launch_bounds__(256) void k_inst_gather_runs(
         const bool act = rad > 0 && tg == epoch;
         const float vis = grp_sum<G>(rad > 0 ? 1.0f : 0.0f);
         int maxrad = rad;
-        maxrad = max(maxrad, __builtin_amdgcn_update_dpp(0, maxrad, 0xb1, 0xf, 0xf, false));
-        maxrad = max(maxrad, __builtin_amdgcn_update_dpp(0, maxrad, 0x4e, 0xf, 0xf, false));
-        maxrad = max(maxrad, __builtin_amdgcn_update_dpp(0, maxrad, 0x141, 0xf, 0xf, false));
+        if (G >= 2) maxrad = max(maxrad, __builtin_amdgcn_update_dpp(0, maxrad, 0xb1, 0xf, 0xf, false));
+        if (G >= 4) maxrad = max(maxrad, __builtin_amdgcn_update_dpp(0, maxrad, 0x4e, 0xf, 0xf, false));
+        if (G >= 8) maxrad = max(maxrad, __builtin_amdgcn_update_dpp(0, maxrad, 0x141, 0xf, 0xf, false));
         const unsigned long long m = __ballot(act);
         if (m) {
             const int first = __builtin_ctzll(m);
@@ -697,13 +698,13 @@ __global__ __launch_bounds__(256) void k_inst_gather_runs(
         bool any = false;
 #pragma unroll
         for (int q = 0; q < 9; ++q) any = any || (acc[q] != 0.f);
-        if (any) {
+        {   // (written for every instance with records, zero sums included: the sums of an instance whose tag is this call's are valid)
             float4* o = iacc + ((size_t)(i_base + (int)(w >> 3)) * G + (w & 7u)) * 3;
             o[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
             o[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
             o[2] = make_float4(acc[8], 0.f, 0.f, 0.f);
-            atomicOr(&s_mask[w >> 3], 1u << (w & 7u));
         }
+        if (any) atomicOr(&s_mask[w >> 3], 1u << (w & 7u));
     }
     if (!acc_out) {   // zero gradients for the Gaussians of this workgroup (see k_inst_gather)
         const size_t i_lo = (size_t)i_base;
@@ -730,19 +731,23 @@ __global__ __launch_bounds__(256) void k_inst_gather_runs(
         if (m8) {
             const uint32_t i = (uint32_t)(i_base + tid);
             s_list[atomicAdd(&s_cnt, 1u)] = i;
-            const int nv = __popc(m8), c = nv > 4 ? 0 : nv > 2 ? 1 : 2;
-            s_rl[c][atomicAdd(&s_rc[c], 1u)] = i | (m8 << 24);
+            if (G >= 2) {
+                const int nv = __popc(m8), c = nv > 4 ? 0 : nv > 2 ? 1 : 2;
+                s_rl[c][atomicAdd(&s_rc[c], 1u)] = i | (m8 << 24);
+            }
         }
     }
     __syncthreads();
     const uint32_t cnt = s_cnt;
     if (tid == 0 && cnt) s_base = atomicAdd(&hdr->n_active, cnt);
-    if (tid < 3) s_rb[tid] = s_rc[tid] ? atomicAdd(&hdr->n_runs[tid], s_rc[tid]) : 0u;
+    if (G >= 2 && tid < 3) s_rb[tid] = s_rc[tid] ? atomicAdd(&hdr->n_runs[tid], s_rc[tid]) : 0u;
     __syncthreads();
     for (uint32_t k = tid; k < cnt; k += 256) active_list[s_base + k] = s_list[k];
+    if (G >= 2) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
-        for (uint32_t k = tid; k < s_rc[c]; k += 256) run_list[(size_t)c * N + s_rb[c] + k] = s_rl[c][k];
+        for (int c = 0; c < 3; ++c)
+            for (uint32_t k = tid; k < s_rc[c]; k += 256) run_list[(size_t)c * N + s_rb[c] + k] = s_rl[c][k];
+    }
 }
 
 // Phase 2: the whole per-view backward chain for the active Gaussians only.
@@ -750,7 +755,7 @@ __global__ __launch_bounds__(256) void k_inst_gather_runs(
 // lane r of the run takes the r-th set bit, lanes beyond the popcount idle), not its G views -- at eight views 41 % of the
 // (active Gaussian, view) lanes had a record (tools/instr/lane_stats.py); runs rounded up to 8 / 4 / 2 lanes take 0.53 of the
 // lanes (k_inst_bwd_runs): k_inst_bwd 0.124 -> 0.099 ms -- not 0.53 of it: per Gaussian the rows loaded and stored stay the same.
-template <int G, int BMAX, bool MIXED, bool SH_HALF, bool RUNS>
+template <int G, int BMAX, bool MIXED, bool SH_HALF, bool RUNS, int NVV = 8>
 __device__ __forceinline__ void inst_bwd_body(
     int blk, int n_active, const uint32_t* __restrict__ active_list,
     int v_first, int v_count, int N, int B, int n_art, int W, int H, const float* __restrict__ cams,
@@ -761,7 +766,7 @@ __device__ __forceinline__ void inst_bwd_body(
     float* __restrict__ d_xyz, float* __restrict__ d_ls, float* __restrict__ d_rot, float* __restrict__ d_op,
     float* __restrict__ d_fdc, float* __restrict__ d_frest, float* __restrict__ d_w, float* __restrict__ st_grad2d) {
     constexpr int IPB = IB_THREADS / G;
-    constexpr int NV = RUNS ? 8 : G;            // view slabs in LDS, lanes per Gaussian of iacc
+    constexpr int NV = RUNS ? NVV : G;          // view slabs in LDS, lanes per Gaussian of iacc (NVV: the views per group of a launch with run lists)
     extern __shared__ __align__(16) float s_view[];  // NV x (camera 40 | transforms IB_TSTRIDE(B))
     if (blk * IPB >= n_active) return;
     const int tid = threadIdx.x, vl = tid & (G - 1), il = tid / G;
@@ -946,16 +951,21 @@ __global__ __launch_bounds__(IB_THREADS) __attribute__((amdgpu_waves_per_eu(MGR_
 }
 // lane group = a run of 8 / 4 / 2 lanes (active_list: the three run lists of k_inst_gather, N entries apart): the
 // workgroups of the three classes follow each other in one launch, so that the classes share the rounds of the launch
-template <int BMAX, bool MIXED, bool SH_HALF>
+// (NVV = views per group of the launch: 8, 4 or 2 -- with 4 there are the classes of 4 and 2 lanes, with 2 the one of 2)
+template <int NVV, int BMAX, bool MIXED, bool SH_HALF>
 __global__ __launch_bounds__(IB_THREADS) __attribute__((amdgpu_waves_per_eu(MGR_IB_WAVES, MGR_IB_WAVES))) void k_inst_bwd_runs(MGR_IB_PARAMS) {
-    const int n8 = (int)hdr->n_runs[0], n4 = (int)hdr->n_runs[1], n2 = (int)hdr->n_runs[2];
+    const int n8 = NVV >= 8 ? (int)hdr->n_runs[0] : 0, n4 = NVV >= 4 ? (int)hdr->n_runs[1] : 0, n2 = (int)hdr->n_runs[2];
     int blk = (int)blockIdx.x;
     const int b8 = (n8 + IB_THREADS / 8 - 1) / (IB_THREADS / 8), b4 = (n4 + IB_THREADS / 4 - 1) / (IB_THREADS / 4);
-    if (blk < b8) { inst_bwd_body<8, BMAX, MIXED, SH_HALF, true>(blk, n8, active_list, MGR_IB_ARGS); return; }
+    if constexpr (NVV >= 8) {
+        if (blk < b8) { inst_bwd_body<8, BMAX, MIXED, SH_HALF, true, NVV>(blk, n8, active_list, MGR_IB_ARGS); return; }
+    }
     blk -= b8;
-    if (blk < b4) { inst_bwd_body<4, BMAX, MIXED, SH_HALF, true>(blk, n4, active_list + (size_t)N, MGR_IB_ARGS); return; }
+    if constexpr (NVV >= 4) {
+        if (blk < b4) { inst_bwd_body<4, BMAX, MIXED, SH_HALF, true, NVV>(blk, n4, active_list + (size_t)N, MGR_IB_ARGS); return; }
+    }
     blk -= b4;
-    inst_bwd_body<2, BMAX, MIXED, SH_HALF, true>(blk, n2, active_list + 2 * (size_t)N, MGR_IB_ARGS);
+    inst_bwd_body<2, BMAX, MIXED, SH_HALF, true, NVV>(blk, n2, active_list + 2 * (size_t)N, MGR_IB_ARGS);
 }
 
 // process-wide switch of the run lists (default on; MANUS_INST_RUNS=0 in the environment starts with them off)
@@ -1029,15 +1039,19 @@ static int raster_backward_impl(int V, int N, int W, int H, const float* cams, c
                 MGR_HIP(hipMemsetAsync(&hdr->n_active, 0, 4, stream));
                 MGR_HIP(hipMemsetAsync(&hdr->n_runs[0], 0, 12, stream));
             }
-            // run lists (see k_inst_bwd_runs): eight-lane groups, up to 24 transforms, Gaussian indices of 24 bits
-            const bool runs = g_inst_runs.load(std::memory_order_relaxed) != 0 && Gv == 8 && canon->B <= 24 && N < (1 << 24);
+            // run lists (see k_inst_gather_runs, k_inst_bwd_runs): up to 24 transforms, Gaussian indices of 24 bits
+            // (at one and two views per group the plain kernels are as fast or faster -- 0.537 against 0.544 ms per step at one view:
+            // there every instance with records is a lane group of its own -- so the run lists start at groups of four)
+            const bool runs = g_inst_runs.load(std::memory_order_relaxed) != 0 && Gv >= 4 && canon->B <= 24 && N < (1 << 24);
+            const int rounds_r = rounds < Gv ? rounds : Gv;   // (at most 256 Gaussians per workgroup of k_inst_gather_runs)
+            const dim3 grid_gr((N + ipb * rounds_r - 1) / (ipb * rounds_r));
             uint32_t* rlist = alist + (size_t)N;   // three lists of N entries behind the active list
 #define MGR_IG_LAUNCH(GG)                                                                                             \
     hipLaunchKernelGGL((k_inst_gather<GG>), grid_g, dim3(256), 0, stream, v0, vc, N, canon->B, canon->n_art, canon->radii, \
                        (const ushort4*)(ws + L.rect), (const uint32_t*)(ws + L.pair_off),                             \
                        (const uint32_t*)(ws + L.pair_tag), (const float4*)(ws + L.pair_grad),                        \
                        (const uint32_t*)(ws + L.inst_tag), (uint32_t)cap, epoch, accm, rounds, iacc, alist, hdr, canon->d_xyz, canon->d_ls, canon->d_rot, canon->d_op, canon->d_fdc,    \
-                       canon->d_frest, canon->d_w, canon->st_grad2d, canon->st_vis, canon->st_radii, runs ? rlist : (uint32_t*)nullptr)
+                       canon->d_frest, canon->d_w, canon->st_grad2d, canon->st_vis, canon->st_radii, runs && GG == 8 ? rlist : (uint32_t*)nullptr)
 #define MGR_IB_LAUNCH(GG, BB)                                                                                         \
     if (mixed && canon->sh_half) MGR_IB_LAUNCH2(GG, BB, true, true);                                                  \
     else if (mixed) MGR_IB_LAUNCH2(GG, BB, true, false);                                                              \
@@ -1051,12 +1065,20 @@ static int raster_backward_impl(int V, int N, int W, int H, const float* cams, c
                        canon->d_frest, canon->d_w, canon->st_grad2d)
             {
                 MGR_PROF("k_inst_gather", stream);
-                if (runs && g_inst_runs.load(std::memory_order_relaxed) != 2)
-                    hipLaunchKernelGGL(k_inst_gather_runs, grid_g, dim3(256), 0, stream, v0, vc, N, canon->B, canon->n_art, canon->radii,
-                                       (const ushort4*)(ws + L.rect), (const uint32_t*)(ws + L.pair_off),
-                                       (const uint32_t*)(ws + L.pair_tag), (const float4*)(ws + L.pair_grad),
-                                       (const uint32_t*)(ws + L.inst_tag), (uint32_t)cap, epoch, accm, rounds, iacc, alist, hdr, canon->d_xyz, canon->d_ls, canon->d_rot, canon->d_op, canon->d_fdc,
-                                       canon->d_frest, canon->d_w, canon->st_grad2d, canon->st_vis, canon->st_radii, rlist);
+#define MGR_IGR_LAUNCH(GG)                                                                                            \
+    hipLaunchKernelGGL((k_inst_gather_runs<GG>), grid_gr, dim3(256), 0, stream, v0, vc, N, canon->B, canon->n_art, canon->radii, \
+                       (const ushort4*)(ws + L.rect), (const uint32_t*)(ws + L.pair_off),                             \
+                       (const uint32_t*)(ws + L.pair_tag), (const float4*)(ws + L.pair_grad),                        \
+                       (const uint32_t*)(ws + L.inst_tag), (uint32_t)cap, epoch, accm, rounds_r, iacc, alist, hdr, canon->d_xyz, canon->d_ls, canon->d_rot, canon->d_op, canon->d_fdc, \
+                       canon->d_frest, canon->d_w, canon->st_grad2d, canon->st_vis, canon->st_radii, rlist)
+                const bool old_gather = g_inst_runs.load(std::memory_order_relaxed) == 2 && Gv == 8;   // (A/B: run lists from k_inst_gather<8>)
+                if (runs && !old_gather) {
+                    if (Gv == 8) MGR_IGR_LAUNCH(8);
+                    else if (Gv == 4) MGR_IGR_LAUNCH(4);
+                    else if (Gv == 2) MGR_IGR_LAUNCH(2);
+                    else MGR_IGR_LAUNCH(1);
+                }
+#undef MGR_IGR_LAUNCH
                 else if (Gv == 8) MGR_IG_LAUNCH(8);
                 else if (Gv == 4) MGR_IG_LAUNCH(4);
                 else if (Gv == 2) MGR_IG_LAUNCH(2);
@@ -1064,18 +1086,21 @@ static int raster_backward_impl(int V, int N, int W, int H, const float* cams, c
             }
             MGR_PROF("k_inst_bwd", stream);
 #define MGR_IBR_LAUNCH(MX, HF)                                                                                        \
-    hipLaunchKernelGGL((k_inst_bwd_runs<24, MX, HF>), dim3(grid.x + 3), dim3(IB_THREADS), lds, stream, v0, vc, N, canon->B, canon->n_art, W, H, cams, canon->xyz, \
+    if (Gv == 8) MGR_IBR_LAUNCH2(8, MX, HF); else if (Gv == 4) MGR_IBR_LAUNCH2(4, MX, HF); else MGR_IBR_LAUNCH2(2, MX, HF)
+#define MGR_IBR_LAUNCH2(NN, MX, HF)                                                                                   \
+    hipLaunchKernelGGL((k_inst_bwd_runs<NN, 24, MX, HF>), dim3(grid.x + 3), dim3(IB_THREADS), lds, stream, v0, vc, N, canon->B, canon->n_art, W, H, cams, canon->xyz, \
                        canon->log_scale, canon->rot, canon->op_logit, canon->f_dc, canon->f_rest, canon->skin_w,      \
                        canon->transforms, (const float4*)iacc, (const uint32_t*)rlist, (const MgrHeader*)hdr,         \
                        canon->grad2d_scale, accm, canon->d_xyz, canon->d_ls, canon->d_rot, canon->d_op, canon->d_fdc, \
                        canon->d_frest, canon->d_w, canon->st_grad2d)
-            if (runs) {
+            if (runs && Gv >= 2) {
                 if (mixed && canon->sh_half) MGR_IBR_LAUNCH(true, true);
                 else if (mixed) MGR_IBR_LAUNCH(true, false);
                 else if (canon->sh_half) MGR_IBR_LAUNCH(false, true);
                 else MGR_IBR_LAUNCH(false, false);
             } else
 #undef MGR_IBR_LAUNCH
+#undef MGR_IBR_LAUNCH2
             if (canon->B <= 24) {
                 if (Gv == 8) MGR_IB_LAUNCH(8, 24);
                 else if (Gv == 4) MGR_IB_LAUNCH(4, 24);

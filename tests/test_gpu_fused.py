@@ -80,10 +80,12 @@ def test_fused_equals_modular_view_counts(views):
 
 
 @pytest.mark.parametrize("kind,views,n", [("hand", 8, 6000), ("hand", 5, 6000), ("composite", 7, 6000), ("hand", 11, 6000),
-                                            ("hand", 8, 37), ("hand", 6, 1), ("composite", 8, 263)])
+                                            ("hand", 8, 37), ("hand", 6, 1), ("composite", 8, 263),
+                                            ("hand", 4, 6000), ("hand", 3, 6000), ("hand", 2, 6000), ("hand", 1, 6000), ("composite", 4, 263),
+                                            ("object", 1, 6000), ("hand", 2, 1)])
 def test_run_lists_equal_one_lane_per_view(kind, views, n):
-    """mgr_views_backward_run_lists: an active Gaussian on 8 / 4 / 2 lanes by the number of its views with records against
-    one lane per view.  Same per-view values, summed over a tree of fewer terms: leaf gradients agree to rounding (1e-5 of
+    """mgr_views_backward_run_lists: an active Gaussian on 8 / 4 / 2 lanes by the number of its views with records (and the
+    gather over a compacted list of the instances with records; one view: the gather alone) against one lane per view.  Same per-view values, summed over a tree of fewer terms: leaf gradients agree to rounding (1e-5 of
     the largest entry: the views' terms of a Gaussian can be larger than their sum), rows no view contributes to stay exactly zero, statistics and the active list are the same set;
     each setting is bit-reproducible.  (11 views: the second view group accumulates.)"""
     from manus_amd._lib import lib

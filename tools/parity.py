@@ -30,7 +30,15 @@ def fused_records(ws, V, N, W, H):
     grec = ws.buf[L["grec"]: L["grec"] + V * N * 48].view(torch.float32).reshape(V, N, 12).cpu().numpy()
     depth = ws.buf[L["depth"]: L["depth"] + V * N * 4].view(torch.float32).reshape(V, N).cpu().numpy()
     G = 1 if V <= 1 else 2 if V <= 2 else 4 if V <= 4 else 8
-    iacc = ws.buf[L["inst_grad"]: L["inst_grad"] + N * G * 48].view(torch.float32).reshape(N, G, 12).cpu().numpy()
+    iacc = ws.buf[L["inst_grad"]: L["inst_grad"] + N * G * 48].view(torch.float32).reshape(N, G, 12).cpu().numpy().copy()
+    # the sums of a (Gaussian, view) are those of the last backward where its tag is that call's epoch (the largest tag in
+    # the workspace); elsewhere the instance had no record and the lane may hold an earlier call's sums (with run lists
+    # the gather only writes the instances with records)
+    tag = ws.buf[L["inst_tag"]: L["inst_tag"] + V * N * 4].view(torch.int32).reshape(V, N).cpu().numpy()
+    if V <= 8 and tag.size:
+        valid = np.zeros((N, G), bool)
+        valid[:, :V] = (tag == tag.max()).T
+        iacc[~valid] = 0.0
     return grec, depth, iacc, ncontrib
 
 
