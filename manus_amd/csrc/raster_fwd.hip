@@ -147,10 +147,13 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t val, uint32_t* s_wa
 // ---------------------------------------------------------------------------
 // Workgroup sizes of the per-instance kernels (measured on the bench workload: k_inst_fwd 0.245 / 0.173 / 0.189 ms
 // at 1024 / 512 / 256 threads, k_emit 0.100 / 0.105 / 0.175 ms: the LDS tile histogram is flushed once per workgroup).
+// (late in round 4, same kernel with the depth-cut lookups: 0.198 / 0.192 / 0.172 / 0.215 / 0.179 ms at 384 / 448 / 512 / 640 / 768.)
 #ifndef MGR_FWD_GRID
 #define MGR_FWD_GRID (256 * 8)   // persistent workgroups of k_blend_fwd
 #endif
+#ifndef PRE_THREADS
 #define PRE_THREADS 512
+#endif
 #define EMIT_THREADS 1024
 
 __device__ __forceinline__ uint32_t db_bucket(float z) {
