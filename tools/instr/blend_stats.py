@@ -16,7 +16,9 @@ fn(z); base=list(z)
 hc(ids, 1.0/V); torch.cuda.synchronize()
 fn(z); d=[a-b for a,b in zip(z,base)]
 print("box tests", d[0], "survivors", d[1], "pair iters", d[2], "valid lane evals", d[3], "entries w/ any", d[4], "full pair iters", d[5])
-print("survivor rate %.3f; lane utilisation over executed pair iters: %.3f; 4x4 blocks w/ any %d (util %.3f), 8x2 strips w/ any %d (util %.3f); valid per entry-with-any %.1f" % (d[1]/d[0], d[3]/(d[2]*128), d[6], d[3]/(d[6]*16), d[7], d[3]/(d[7]*16), d[3]/d[4]))
+print("survivor rate %.3f; lane utilisation over executed pair iters: %.3f; entries with a valid pixel %.3f of the evaluated; valid pixels per such entry %.1f" % (d[1]/d[0], d[3]/(d[2]*128), d[4]/(2*d[2]), d[3]/d[4]))
+if d[6] and d[7]:   # (only builds that still count 4x4 blocks / 8x2 strips)
+    print("4x4 blocks w/ any %d (util %.3f), 8x2 strips w/ any %d (util %.3f)" % (d[6], d[3]/(d[6]*16), d[7], d[3]/(d[7]*16)))
 # tile statistics
 ws = rz.context().last_ws
 arr=(ctypes.c_size_t*32)(); L.mgr_raster_layout(V,N,W,H,ws.cap,arr,32)
