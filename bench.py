@@ -285,6 +285,9 @@ def main():
     ap.add_argument("--dense-loss-scan", action="store_true",
                     help="image loss without the rasterizer's tile occupancy: compares rendered and target image everywhere "
                          "to find the spans that need work (the default settles spans under empty tiles from the target alone)")
+    ap.add_argument("--fresh-grads", action="store_true",
+                    help="a new, fully zeroed set of gradient tensors every step instead of buffers the compute object keeps "
+                         "(like .grad tensors) and the backward zeroing only the rows that need it")
     ap.add_argument("--gaussian-order", default="given", choices=["given", "morton"],
                     help="morton: the model's rows sorted along a Z-order curve first (a what-if for spatially coherent rows; not the headline)")
     ap.add_argument("--no-depth-cut", action="store_true",
@@ -337,7 +340,7 @@ def main():
         del hp
     rasterizer.context(dev).clear()
     compute = HipViewCompute(scene, targets, ct, loss=args.loss, sh_storage=args.sh_storage, sparse_loss=not args.dense_loss_scan,
-                             depth_cut=not args.no_depth_cut)
+                             depth_cut=not args.no_depth_cut, persistent_grads=not args.fresh_grads)
     shapes = {k: v.shape for k, v in compute.params.items()}
     sharded = args.sharded_adam and args.optimizer and world > 1
     # N > 1: the views go to the ranks by measured cost (pairs per view from one forward of every view -- deterministic,
@@ -622,6 +625,8 @@ def main():
                                                 "rows with a gradient (%s of %d) x 60 floats + 2N bytes" % (step.last_rows, N)}),
                        "optimizer_in_step": bool(args.optimizer), "sh_storage": args.sh_storage,
                        "gaussian_order": args.gaussian_order,
+                       "gradient_buffers": ("fresh tensors, every row zeroed every step" if (args.fresh_grads or world > 1) else
+                                            "kept by the compute object (like .grad); rows without a gradient are zeroed only when the previous step wrote them"),
                        "remeasured_without_hints": remeasured,
                        "depth_cut": ("off" if not compute.depth_cut else
                                      "per-tile saturation depth of the previous forward of the same views bounds the binning; exact "

@@ -189,6 +189,13 @@ int mgr_views_backward(int V, int N, int B, int n_articulated, int sh_half, int 
                        int32_t* stat_radii, void* workspace, size_t workspace_bytes,
                        int64_t pair_capacity, int debug, void* stream);
 
+/* debug of mgr_views_backward: bit 1 as above.  Bit 512 = "outputs kept": the caller vouches that the leaf-gradient buffers
+ * (d_xyz ... d_skin_w, stat_grad2d) are the ones the previous mgr_views_backward on this workspace wrote, untouched since
+ * (persistent .grad-like tensors).  The backward then zeroes only the rows that call wrote and this one does not, instead
+ * of every row of every buffer (97 MB of stores on the bench step); the results are identical.  Honoured only when the
+ * workspace's row state is that previous call's and describes these very buffers (the library checks a call counter and
+ * d_xyz; V <= 8, 3..8 views, run lists on) -- otherwise every row is zeroed as without the bit. */
+
 /* Device pointers (into the workspace) to the compacted list of Gaussians that received a gradient in the last
  * mgr_views_backward and to its length; V <= 8. */
 int mgr_views_active_list(void* workspace, int V, int N, int W, int H, int64_t pair_capacity, const uint32_t** list,

@@ -83,7 +83,12 @@ struct MgrHeader {            // first 256 bytes of the workspace
     // fused backward, 5..8 views per group: the active Gaussians by the number of their views that hold pair records, rounded up
     // to 8 / 4 / 2 lanes -- k_inst_bwd_runs gives a Gaussian that many lanes instead of eight (k_inst_gather counts and lists them)
     uint32_t n_runs[4];       // (three classes; the fourth word is spare)
-    uint32_t spare[64];       // (the size-class counters of the tile scan lived here: it now derives them from per-block histograms)
+    // "outputs kept" (mgr_views_backward, debug bit 512): backward calls on this workspace (k_blend_bwd counts), the call whose
+    // gather left the per-Gaussian row state (which gradient rows of the caller's buffers may be non-zero), the gather's note
+    // for the kernel behind it
+    uint32_t bwd_seq, rows_seq, rows_pending;
+    uint32_t rows_owner[2];   // d_xyz of the call that left the row state: the state describes THOSE buffers
+    uint32_t spare[59];       // (the size-class counters of the tile scan lived here: it now derives them from per-block histograms)
     uint32_t queue_giant;     // queue index of the first tile with fewer than 16384 pairs
     uint32_t n_groups;        // depth groups produced by k_tile_split for the giant tiles
     uint32_t split_head, group_head;

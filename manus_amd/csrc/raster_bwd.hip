@@ -113,6 +113,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BWD_WAVES, 
     const int T = gx * gy;
     const uint32_t n_items = hdr->n_items;
     if (blockIdx.x == 0 && tid < 4) (tid == 3 ? hdr->n_active : hdr->n_runs[tid]) = 0;  // for the gather that follows (first view group)
+    if (blockIdx.x == 0 && tid == 4) hdr->bwd_seq += 1u;
     const size_t P = (size_t)W * H;
     const unsigned long long lt = (1ull << lane) - 1ull;
     float* const slab = &s_pair[wave][0][0];
@@ -638,7 +639,12 @@ __global__ __launch_bounds__(256) void k_inst_gather_runs(
     uint32_t* __restrict__ active_list, MgrHeader* hdr, float* __restrict__ d_xyz, float* __restrict__ d_ls,
     float* __restrict__ d_rot, float* __restrict__ d_op, float* __restrict__ d_fdc, float* __restrict__ d_frest,
     float* __restrict__ d_w, float* __restrict__ st_grad2d, float* __restrict__ st_vis,
-    int32_t* __restrict__ st_radii, uint32_t* __restrict__ run_list) {
+    int32_t* __restrict__ st_radii, uint32_t* __restrict__ run_list, unsigned char* __restrict__ row_state, int kept) {
+    // row_state (one byte per Gaussian; single view group only, else nullptr): 1 = the gradient rows of this Gaussian in the
+    // caller's buffers were written by the previous backward on this workspace.  kept: the caller vouches that the buffers are
+    // those of that call, untouched -- then only the rows that were written then and get nothing now are zeroed (in place of
+    // 324 + 4 B bytes for every Gaussian of the range: 97 MB of the bench step's 151 MB of gather writes), provided the row
+    // state is the previous call's (hdr->rows_seq + 1 == hdr->bwd_seq; any backward through another path breaks the chain).
     constexpr int IPB = 256 / G, NG = 256;   // at most 256 Gaussians per workgroup (the caller keeps rounds <= G)
     __shared__ uint32_t s_wi[NG * G], s_wo[NG * G], s_wc[NG * G];   // work list: (local Gaussian << 3 | view), first slot, slots
     __shared__ uint32_t s_mask[NG];                                 // per Gaussian: views with a non-zero sum
@@ -652,6 +658,9 @@ __global__ __launch_bounds__(256) void k_inst_gather_runs(
     __syncthreads();
     const bool acc_out = accumulate != 0;
     const int i_base = blockIdx.x * rounds * IPB;
+    const unsigned long long owner = (unsigned long long)(uintptr_t)d_xyz;
+    const bool kept_ok = kept && row_state && hdr->rows_seq != 0u && hdr->rows_seq + 1u == hdr->bwd_seq &&
+                         hdr->rows_owner[0] == (uint32_t)owner && hdr->rows_owner[1] == (uint32_t)(owner >> 32);
     // ---- A: the instances with records -> work list; visibility statistics
 #pragma unroll 1
     for (int rnd = 0; rnd < rounds; ++rnd) {
@@ -706,7 +715,7 @@ __global__ __launch_bounds__(256) void k_inst_gather_runs(
         }
         if (any) atomicOr(&s_mask[w >> 3], 1u << (w & 7u));
     }
-    if (!acc_out) {   // zero gradients for the Gaussians of this workgroup (see k_inst_gather)
+    if (!acc_out && !kept_ok) {   // zero gradients for the Gaussians of this workgroup (see k_inst_gather)
         const size_t i_lo = (size_t)i_base;
         const size_t i_hi = min((size_t)N, i_lo + (size_t)rounds * IPB);
         if (i_hi > i_lo) {
@@ -726,6 +735,21 @@ __global__ __launch_bounds__(256) void k_inst_gather_runs(
     }
     __syncthreads();
     // ---- C: active list and run lists from the view masks
+    if (row_state && tid < rounds * IPB && i_base + tid < N) {
+        const int i = i_base + tid;
+        if (kept_ok && row_state[i] && s_mask[tid] == 0u) {   // written by the previous call, nothing now: this row alone is zeroed
+            for (int k = 0; k < 3; ++k) { d_xyz[3 * i + k] = 0.f; d_ls[3 * i + k] = 0.f; d_fdc[3 * i + k] = 0.f; }
+            for (int k = 0; k < 4; ++k) d_rot[4 * i + k] = 0.f;
+            for (int k = 0; k < 45; ++k) d_frest[(size_t)i * 45 + k] = 0.f;
+            if (d_w && i < n_art)
+                for (int k = 0; k < B; ++k) d_w[(size_t)i * B + k] = 0.f;
+            d_op[i] = 0.f;
+            if (st_grad2d) st_grad2d[i] = 0.f;
+        }
+        row_state[i] = s_mask[tid] != 0u ? 1 : 0;
+    }
+    if (blockIdx.x == 0 && tid == 0) hdr->rows_pending = row_state ? hdr->bwd_seq : 0u;   // (rows_owner is written by the kernel behind this one:
+                                                                                           //  every workgroup here still reads it)
     {
         const uint32_t m8 = tid < rounds * IPB ? s_mask[tid] : 0u;
         if (m8) {
@@ -956,6 +980,13 @@ template <int NVV, int BMAX, bool MIXED, bool SH_HALF>
 __global__ __launch_bounds__(IB_THREADS) __attribute__((amdgpu_waves_per_eu(MGR_IB_WAVES, MGR_IB_WAVES))) void k_inst_bwd_runs(MGR_IB_PARAMS) {
     const int n8 = NVV >= 8 ? (int)hdr->n_runs[0] : 0, n4 = NVV >= 4 ? (int)hdr->n_runs[1] : 0, n2 = (int)hdr->n_runs[2];
     int blk = (int)blockIdx.x;
+    if (blk == 0 && threadIdx.x == 0 && hdr->rows_pending == hdr->bwd_seq) {   // the gather left the row state of this call: from
+        MgrHeader* h = const_cast<MgrHeader*>(hdr);                              // here on the outputs hold exactly those rows
+        const unsigned long long owner = (unsigned long long)(uintptr_t)d_xyz;
+        h->rows_seq = hdr->bwd_seq;
+        h->rows_owner[0] = (uint32_t)owner;
+        h->rows_owner[1] = (uint32_t)(owner >> 32);
+    }
     const int b8 = (n8 + IB_THREADS / 8 - 1) / (IB_THREADS / 8), b4 = (n4 + IB_THREADS / 4 - 1) / (IB_THREADS / 4);
     if constexpr (NVV >= 8) {
         if (blk < b8) { inst_bwd_body<8, BMAX, MIXED, SH_HALF, true, NVV>(blk, n8, active_list, MGR_IB_ARGS); return; }
@@ -1017,7 +1048,7 @@ static int raster_backward_impl(int V, int N, int W, int H, const float* cams, c
                        (const float4*)(ws + L.ckpt), (const uint4*)(ws + L.items), hdr, out_color,
                        dL_dcolor, (uint32_t*)(ws + L.pair_tag), (float4*)(ws + L.pair_grad),
                        (uint32_t*)(ws + L.inst_tag), (uint32_t)cap, epoch); }
-    MGR_LAUNCH_CHECK("k_blend_bwd", stream, debug);
+    MGR_LAUNCH_CHECK("k_blend_bwd", stream, debug & 1);
     if (canon) {
         // views of a Gaussian share a lane group; more than 8 views go in groups of 8, the later
         // groups adding to the outputs of the first
@@ -1046,6 +1077,9 @@ static int raster_backward_impl(int V, int N, int W, int H, const float* cams, c
             const int rounds_r = rounds < Gv ? rounds : Gv;   // (at most 256 Gaussians per workgroup of k_inst_gather_runs)
             const dim3 grid_gr((N + ipb * rounds_r - 1) / (ipb * rounds_r));
             uint32_t* rlist = alist + (size_t)N;   // three lists of N entries behind the active list
+            // row state of the "outputs kept" mode (debug bit 512): one byte per Gaussian behind the run lists, single view group only
+            unsigned char* row_state = V <= Gv ? (unsigned char*)(rlist + 3 * (size_t)N) : nullptr;
+            const int kept = (debug & 512) && V <= Gv ? 1 : 0;
 #define MGR_IG_LAUNCH(GG)                                                                                             \
     hipLaunchKernelGGL((k_inst_gather<GG>), grid_g, dim3(256), 0, stream, v0, vc, N, canon->B, canon->n_art, canon->radii, \
                        (const ushort4*)(ws + L.rect), (const uint32_t*)(ws + L.pair_off),                             \
@@ -1070,7 +1104,7 @@ static int raster_backward_impl(int V, int N, int W, int H, const float* cams, c
                        (const ushort4*)(ws + L.rect), (const uint32_t*)(ws + L.pair_off),                             \
                        (const uint32_t*)(ws + L.pair_tag), (const float4*)(ws + L.pair_grad),                        \
                        (const uint32_t*)(ws + L.inst_tag), (uint32_t)cap, epoch, accm, rounds_r, iacc, alist, hdr, canon->d_xyz, canon->d_ls, canon->d_rot, canon->d_op, canon->d_fdc, \
-                       canon->d_frest, canon->d_w, canon->st_grad2d, canon->st_vis, canon->st_radii, rlist)
+                       canon->d_frest, canon->d_w, canon->st_grad2d, canon->st_vis, canon->st_radii, rlist, row_state, kept)
                 const bool old_gather = g_inst_runs.load(std::memory_order_relaxed) == 2 && Gv == 8;   // (A/B: run lists from k_inst_gather<8>)
                 if (runs && !old_gather) {
                     if (Gv == 8) MGR_IGR_LAUNCH(8);
@@ -1123,7 +1157,7 @@ static int raster_backward_impl(int V, int N, int W, int H, const float* cams, c
                        (const uint32_t*)(ws + L.pair_tag), (const float4*)(ws + L.pair_grad),
                        dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dcov3D,
                        (const uint32_t*)(ws + L.inst_tag), (uint32_t)cap, epoch, hdr); }
-    MGR_LAUNCH_CHECK("k_preprocess_bwd", stream, debug);
+    MGR_LAUNCH_CHECK("k_preprocess_bwd", stream, debug & 1);
     return MGR_OK;
 }
 

@@ -317,8 +317,16 @@ class HipViewCompute:
     the modular operators under autograd (the reference-shaped path)."""
 
     def __init__(self, scene, targets, cam_table, loss_weight=1.0, fused=True, loss="l1", w_rgb=0.8, w_ssim=0.2,
-                 sh_storage="fp32", sparse_loss=True, overlap_loss=True, depth_cut=True, max_cut_hints=1024):
+                 sh_storage="fp32", sparse_loss=True, overlap_loss=True, depth_cut=True, max_cut_hints=1024,
+                 persistent_grads=False):
         from . import fused as fused_mod, ops, rasterizer
+        # persistent_grads (fused step, no grad_arena): the leaf gradients, the skin-weight gradient and the statistics are
+        # written into buffers this object keeps -- like `.grad` tensors, the returned tensors are the same storage every
+        # step and hold the LATEST step's values (clone what must outlive the next call; do not write to them).  The
+        # backward then zeroes only the rows that were written by the previous step and get nothing now, instead of every
+        # row of every gradient every step (mgr_views_backward, debug bit 512: 97 MB of stores per bench step).  Off by
+        # default: a fresh tensor per call is what a caller of a function expects.
+        self.persistent_grads, self._pg, self._pg_ws = bool(persistent_grads), None, None
         # depth_cut (fused step only): every forward leaves, per tile whose pixels all saturated, the depth in front of
         # which they had stopped (+ a margin); the next forward of the SAME views leaves the instances behind it out of
         # that tile's list -- the binning kernels then handle a fraction of the pairs, the image and the gradients stay
@@ -576,8 +584,19 @@ class HipViewCompute:
         N, na, V = p["_xyz"].shape[0], self.n_art, len(view_ids)
         W, H = int(s["width"]), int(s["height"])
         arena = self.grad_arena or {}
+        own = None
+        if self.persistent_grads and not arena and self.fused:
+            key = (N, na, str(dev))
+            if self._pg is None or self._pg[0] != key:
+                self._pg, self._pg_ws = (key, {}), None
+            own = self._pg[1]
 
         def e(shape, name):
+            if own is not None:
+                t = own.get(name)
+                if t is None:
+                    t = own[name] = torch.zeros(shape, dtype=torch.float32, device=dev)
+                return t
             t = arena.get(name)
             n = 1
             for d in shape:
@@ -670,13 +689,19 @@ class HipViewCompute:
             d_op, d_fdc, d_frest = e((N, 1), "_opacity"), e((N, 1, 3), "_features_dc"), e((N, 15, 3), "_features_rest")
             st_g, st_v = e((N,), "grad2d"), e((N,), "vis")
             st_r = torch.empty(N, dtype=torch.int32, device=dev)
-            d_w = torch.empty((na, B), dtype=torch.float32, device=dev) if na else None
+            d_w = (e((na, B), "_skin_w") if own is not None else torch.empty((na, B), dtype=torch.float32, device=dev)) if na else None
+            # the buffers are those of the previous backward on this very workspace, untouched since: the library may skip the
+            # zero fill of the rows it knows to be zero (it checks that its row state is that call's; bit 512)
+            kept = 512 if (own is not None and self._pg_ws is ws and V <= 8) else 0
+            self._pg_ws = None
             check(lib().mgr_views_backward(V, N, B, na, sh_half, W, H, ptr(cams), ptr(bg), ptr(p["_xyz"]), ptr(p["_scaling"]),
                                            ptr(p["_rotation"]), ptr(op), ptr(p["_features_dc"]), ptr(f_rest),
                                            ptr(w), ptr(T), ptr(radii), ptr(out), ptr(g_img), 1.0 / scale, ptr(d_xyz),
                                            ptr(d_ls), ptr(d_rot), ptr(d_op), ptr(d_fdc), ptr(d_frest), ptr(d_w), ptr(st_g),
-                                           ptr(st_v), ptr(st_r), ptr(ws.buf), ws.nbytes, ws.cap, 0, stream()),
+                                           ptr(st_v), ptr(st_r), ptr(ws.buf), ws.nbytes, ws.cap, kept, stream()),
                   "mgr_views_backward")
+            if own is not None:
+                self._pg_ws = ws
             active = None
             if V <= 8 and N > 0:
                 # the backward's list of the Gaussians that received a gradient (device pointers: list, length)
@@ -786,13 +811,17 @@ class Trainer:
 
     def __init__(self, compute, n_views, extent, opts=None, spatial_lr_scale=1.0, rank=0, world_size=1, group=None,
                  bg_white=True, kind=None, compact_allreduce=False, sharded_adam=False, view_weights=None, depth_cut=False,
-                 sort_rows=False):
+                 sort_rows=False, persistent_grads=True):
         # sharded_adam (world_size > 1): reduce-scatter of the gradients -> every rank takes the Adam step on the 1/world
         # of the parameter elements it owns -> all-gather of the parameters.  The same bytes on the wire as the
         # all-reduce (which is a reduce-scatter followed by an all-gather), 1/world of the optimizer work per rank.
         # sort_rows: after a densification / pruning has rebuilt the tensors, put the rows in Z-order of their positions
         # (GaussianOptimizer.sort_rows: the same model up to the permutation; every rank computes the same one)
         self.sort_rows = bool(sort_rows)
+        # persistent_grads (one rank): the compute object keeps the gradient buffers (HipViewCompute.persistent_grads): the
+        # tensors in a step's `out["grads"]` are overwritten by the next step -- the optimizer has consumed them by then
+        if world_size == 1 and persistent_grads and hasattr(compute, "persistent_grads"):
+            compute.persistent_grads = True
         self.compact_allreduce = compact_allreduce and not sharded_adam
         self.sharded_adam = bool(sharded_adam) and world_size > 1
         from . import rasterizer

@@ -113,6 +113,47 @@ def test_run_lists_equal_one_lane_per_view(kind, views, n):
     assert abs(float(on1["loss"]) - float(off["loss"])) < 1e-6   # (the loss scalar is summed with float atomics)
 
 
+@pytest.mark.parametrize("kind,views", [("hand", 8), ("hand", 4), ("composite", 7), ("hand", 2)])
+def test_persistent_gradient_buffers_equal_fresh_ones(kind, views):
+    """HipViewCompute(persistent_grads=True): gradients land in buffers the object keeps, and the backward zeroes only the
+    rows the previous step wrote and this one does not (mgr_views_backward, debug bit 512).  Over steps between which the
+    model moves (Gaussians come into view and leave it) every step's gradients, statistics and loss are bit for bit those
+    of a compute object that gets fresh, fully zeroed buffers; the same after the rows were disturbed by another
+    compute object's backward on the same workspace, and with the run lists switched off in between."""
+    from manus_amd._lib import lib
+    from manus_amd.engine import HipViewCompute
+    sc, ct = _scene(kind, n=5000, views=views)
+    tg = torch.rand((views, 3, 64, 96), device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))
+    ids = list(range(views))
+    a = HipViewCompute(sc, tg, ct, fused=True, depth_cut=False)
+    b = HipViewCompute(sc, tg, ct, fused=True, depth_cut=False, persistent_grads=True)
+    c = HipViewCompute(sc, tg, ct, fused=True, depth_cut=False, persistent_grads=True)   # shares the pooled workspace with b
+    gen = torch.Generator(device=DEV).manual_seed(7)
+    n_rows = []
+    for it in range(7):
+        with torch.no_grad():   # move the model: positions jitter, a tenth of the Gaussians turn transparent / opaque
+            noise = 0.004 * torch.randn(a.params["_xyz"].shape, device=DEV, generator=gen)
+            flip = torch.rand(a.params["_opacity"].shape, device=DEV, generator=gen) < 0.1
+            for comp in (a, b, c):
+                comp.params["_xyz"].add_(noise)
+                comp.params["_opacity"][flip] = -comp.params["_opacity"][flip]
+                comp.mark_params_changed()
+        if it == 3:
+            c(ids, 1.0 / views)                                  # another object's backward on the same workspace
+        if it == 5:
+            prev = lib().mgr_views_backward_run_lists(0)         # a backward through the other lane layout in between
+            try:
+                b(ids, 1.0 / views)
+            finally:
+                lib().mgr_views_backward_run_lists(prev)
+        oa, ob = a(ids, 1.0 / views), b(ids, 1.0 / views)
+        for k in oa["grads"]:
+            assert torch.equal(oa["grads"][k], ob["grads"][k]), (it, k)
+        assert torch.equal(oa["grad2d"], ob["grad2d"]) and torch.equal(oa["vis"], ob["vis"]) and torch.equal(oa["radii"], ob["radii"])
+        n_rows.append(int((oa["grads"]["_xyz"].abs().sum(1) != 0).sum()))
+    assert len(set(n_rows)) > 1          # the set of rows with a gradient did change from step to step
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # The fused path against the ORACLE on identical blend inputs (north_star bars: PSNR delta < 0.01 dB, grad
 # max-rel-err < 1e-4), alpha-threshold flips accounted for instead of avoided by the choice of seed: see
