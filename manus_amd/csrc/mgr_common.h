@@ -88,7 +88,11 @@ struct MgrHeader {            // first 256 bytes of the workspace
     // for the kernel behind it
     uint32_t bwd_seq, rows_seq, rows_pending;
     uint32_t rows_owner[2];   // d_xyz of the call that left the row state: the state describes THOSE buffers
-    uint32_t spare[59];       // (the size-class counters of the tile scan lived here: it now derives them from per-block histograms)
+    // "image kept" (forward, debug bit 1024): forwards binned on this workspace (k_tile_scan_a counts), the forward that last
+    // completed an image (k_fwd_items), the image it wrote and its background colour -- tile_bgok says which tiles of THAT image
+    // hold the background
+    uint32_t fwd_seq, img_seq, img_owner[2], img_bg[3];
+    uint32_t spare[52];       // (the size-class counters of the tile scan lived here: it now derives them from per-block histograms)
     uint32_t queue_giant;     // queue index of the first tile with fewer than 16384 pairs
     uint32_t n_groups;        // depth groups produced by k_tile_split for the giant tiles
     uint32_t split_head, group_head;
@@ -121,7 +125,7 @@ struct __attribute__((aligned(16))) MgrGRec {
 
 struct MgrLayout {
     size_t header, scan_part, scan_cls, scan_box, grec, depth, rect, alive, pair_off, tile_count, tile_start, tile_cursor, tile_done, tile_qdone,
-        tile_zcut, tile_zused, tile_qend, tile_queue, tile_qrec, chunk_start, items, ckpt, keys, keys2, groups, sorted_gid, final_T, n_contrib, pair_tag, pair_grad, inst_grad, inst_tag,
+        tile_zcut, tile_zused, tile_qend, tile_bgok, tile_queue, tile_qrec, chunk_start, items, ckpt, keys, keys2, groups, sorted_gid, final_T, n_contrib, pair_tag, pair_grad, inst_grad, inst_tag,
         db_count, db_cursor, db_start, db_nvis, db_bbox, db_keys, db_order, db_rec, bin_mat, total;
 };
 
@@ -193,6 +197,7 @@ static inline MgrLayout mgr_layout(int V, int N, int W, int H, int64_t cap) {
         L.db_rec = o;    o += mgr_align(VN * 16);     // their tile rectangles and alive masks, in that order
         L.bin_mat = o;   o += mgr_align((size_t)V * nblk * gx * gy * 4);   // pairs per (block of the order, tile) -> list offsets
     }
+    L.tile_bgok = o; o += mgr_align((size_t)V * gx * gy);   // one byte per tile: the caller's image holds the background colour there ("image kept")
     L.total = o;
     return L;
 }

@@ -565,7 +565,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan_a(int T, int nbT, const uint
     __shared__ uint32_t s_bb[4];
     const int tid = threadIdx.x, v = blockIdx.x / nbT, t = (blockIdx.x % nbT) * 1024 + tid;
     if (tid == 0) { s_bb[0] = 0xFFFFu; s_bb[1] = 0xFFFFu; s_bb[2] = 0u; s_bb[3] = 0u; }
-    if (blockIdx.x == 0 && tid == 0) { hdr->tiers = 0u; hdr->sort_big = 0u; }   // (phase B's depth-bucket workgroups / the sort set them)
+    if (blockIdx.x == 0 && tid == 0) { hdr->tiers = 0u; hdr->sort_big = 0u; hdr->fwd_seq += 1u; }   // (phase B's depth-bucket workgroups / the sort set them)
     const bool valid = t < T;
     const size_t k = (size_t)v * T + t;
     if (tid < MGR_NCLS) s_cls[tid] = 0;
@@ -605,7 +605,8 @@ __global__ __launch_bounds__(1024) void k_tile_scan_b(int V, int T, int nbT, uin
                                                       uint32_t* __restrict__ chunk_start, MgrHeader* hdr,
                                                       uint32_t cap, uint32_t* __restrict__ tile_zcut,
                                                       uint32_t* __restrict__ tile_zused, uint32_t* __restrict__ tile_qend,
-                                                      int use_cut, const uint4* __restrict__ blk_box, DbinArgs db) {
+                                                      int use_cut, const uint4* __restrict__ blk_box, DbinArgs db,
+                                                      unsigned char* __restrict__ tile_bgok) {
     __shared__ uint32_t s_scan[32];
     if ((int)blockIdx.x >= V * nbT) {   // the workgroups behind the scan's: one per view, depth-bucket offsets + tile box
         __shared__ uint32_t s_box[4];
@@ -679,6 +680,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan_b(int V, int T, int nbT, uin
         // have taken everything the tile should show and no walk will ever notice: flag it here
         if (zu != 0u && c == 0u) atomicOr(&hdr->acc_flags, MGR_OVF_CUT);
         tile_qend[k] = 0u;
+        if (c != 0u) tile_bgok[k] = 0;      // the blend will write this tile's pixels ("image kept": see BgFill)
         const uint32_t rank = atomicAdd(&s_lc[cls], 1u);
         tile_queue[s_gbase[cls] + s_gpre[cls] + rank] = (uint32_t)k;
         if (cls > 0) {
@@ -1247,11 +1249,92 @@ extern "C" int mgr_debug_dbsprof(unsigned long long* dst) {
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_dbsprof), sizeof(unsigned long long) * 16);
 }
 #endif
+// Background of the EMPTY tiles (85 % of the tiles of a capture-like frame: 170 MB of stores at eight 1080p views).  The forward
+// blend used to write it behind its own work -- 0.04 of its 0.30 ms, measured by leaving the stores out -- while the instance
+// sort, which runs when the tile counts are final, keeps 240 workgroups busy for 39 us on a GPU whose memory system idles:
+// extra workgroups of that launch write it there.
+struct BgFill {
+    float* out;                    // (V, 3, H, W); nullptr: no fill blocks in this launch
+    const uint32_t* tile_queue;    // non-empty tiles first (hdr->queue_len of them), the empty ones behind
+    const float* bg;
+    int VT, T, gx, W, H;
+    // "image kept" (debug bit 1024): the caller vouches that `out` is the image of the previous complete forward on this
+    // workspace, untouched -- a tile that was background then (tile_bgok, kept by k_tile_scan_b / k_fwd_items) and is empty now
+    // is left alone.  Honoured when the header says that forward was the last one binned here, wrote THIS buffer, with THIS colour.
+    const unsigned char* tile_bgok;
+    int kept;
+};
+__device__ __forceinline__ void bg_fill_block(const BgFill& f, const MgrHeader* hdr, int fb, int nfb) {
+    const int tid = threadIdx.x;
+    const size_t P = (size_t)f.W * f.H;
+    const float b0 = f.bg[0], b1 = f.bg[1], b2 = f.bg[2];
+    const uint32_t q0 = hdr->queue_len;
+    const unsigned long long owner = (unsigned long long)(uintptr_t)f.out;
+    const bool kept_ok = f.kept && hdr->img_seq != 0u && hdr->img_seq + 1u == hdr->fwd_seq && hdr->img_owner[0] == (uint32_t)owner &&
+                         hdr->img_owner[1] == (uint32_t)(owner >> 32) && hdr->img_bg[0] == __float_as_uint(b0) &&
+                         hdr->img_bg[1] == __float_as_uint(b1) && hdr->img_bg[2] == __float_as_uint(b2);
+    if ((f.W & 3) == 0 && (((uintptr_t)f.out) & 15) == 0) {
+        // 16-byte stores: a tile is 3 planes x 16 rows x 4 quads = 192 stores; a workgroup of 512 threads takes 8 tiles per step
+        // (1536 stores, three per thread); lanes run over (quad, tile) first: the eight tiles of a batch are neighbours in the
+        // queue and mostly in the image, so 32 lanes write 512 contiguous bytes of one image row
+        auto fill8 = [&](uint32_t qb, uint32_t need8) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int e = tid + k * RS_THREADS;            // 0 .. 1535
+                const int quad = e & 3, ti = (e >> 2) & 7, row = (e >> 5) & 15, plane = e >> 9;
+                const uint32_t q = qb + (uint32_t)ti;
+                if (q >= (uint32_t)f.VT || !((need8 >> ti) & 1u)) continue;
+                const uint32_t vt = f.tile_queue[q];
+                const int v = (int)(vt / (uint32_t)f.T), t = (int)(vt % (uint32_t)f.T);
+                const int px = (t % f.gx) * 16 + quad * 4, py = (t / f.gx) * 16 + row;
+                if (px < f.W && py < f.H) {
+                    const float c = plane == 0 ? b0 : plane == 1 ? b1 : b2;
+                    *(float4*)(f.out + ((size_t)v * 3 + plane) * P + (size_t)py * f.W + px) = make_float4(c, c, c, c);
+                }
+            }
+        };
+        if (!kept_ok) {
+            for (uint32_t qb = q0 + 8u * (uint32_t)fb; qb < (uint32_t)f.VT; qb += 8u * (uint32_t)nfb) fill8(qb, 0xFFu);
+            return;
+        }
+        // image kept: 64 tiles are looked at together, one per lane (every wave of the workgroup on its own: the same answer),
+        // and only the batches that hold a tile which was not background before are written
+        const int lane = tid & 63;
+        for (uint32_t qs = q0 + 64u * (uint32_t)fb; qs < (uint32_t)f.VT; qs += 64u * (uint32_t)nfb) {
+            const uint32_t q = qs + (uint32_t)lane;
+            const bool need = q < (uint32_t)f.VT && f.tile_bgok[f.tile_queue[min(q, (uint32_t)f.VT - 1u)]] == 0;
+            const unsigned long long m = __ballot(need);
+            if (m == 0ull) continue;
+            for (int b8 = 0; b8 < 8; ++b8) {
+                const uint32_t need8 = (uint32_t)(m >> (8 * b8)) & 0xFFu;
+                if (need8) fill8(qs + 8u * (uint32_t)b8, need8);
+            }
+        }
+        return;
+    }
+    const int sub = tid >> 8, t8 = tid & 255;      // RS_THREADS = 512: two tiles per step
+    for (uint32_t q = q0 + (uint32_t)(2 * fb + sub); q < (uint32_t)f.VT; q += (uint32_t)(2 * nfb)) {
+        const uint32_t vt = f.tile_queue[q];
+        if (kept_ok && f.tile_bgok[vt]) continue;
+        const int v = (int)(vt / (uint32_t)f.T), t = (int)(vt % (uint32_t)f.T);
+        const int px = (t % f.gx) * 16 + (t8 & 15), py = (t / f.gx) * 16 + (t8 >> 4);
+        if (px < f.W && py < f.H) {
+            float* o = f.out + (size_t)v * 3 * P + (size_t)py * f.W + px;
+            o[0] = b0;
+            o[P] = b1;
+            o[2 * P] = b2;
+        }
+    }
+}
 template <int LDS_KEYS>   // (a template so that the light instantiation sheds the 16-keys-per-thread case and its spills)
 __global__ __launch_bounds__(RS_THREADS) __attribute__((amdgpu_waves_per_eu(DBS_WAVES_EU, DBS_WAVES_EU))) void k_dbin_sort(
     int N, int chunk, int chunks_per_view, int n_items, const uint32_t* __restrict__ db_start, const uint32_t* __restrict__ db_nvis,
     unsigned long long* __restrict__ db_keys, uint32_t* __restrict__ db_order, uint32_t min_keys, MgrHeader* hdr,
-    int full_runs) {
+    int full_runs, BgFill fill, int n_sort_blocks) {
+    if ((int)blockIdx.x >= n_sort_blocks) {   // (the launch's extra workgroups: see BgFill)
+        bg_fill_block(fill, hdr, (int)blockIdx.x - n_sort_blocks, (int)gridDim.x - n_sort_blocks);
+        return;
+    }
     constexpr uint32_t lds_keys = (uint32_t)LDS_KEYS;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     unsigned long long* s_keys = (unsigned long long*)s_raw;
@@ -1261,7 +1344,7 @@ __global__ __launch_bounds__(RS_THREADS) __attribute__((amdgpu_waves_per_eu(DBS_
 #ifdef DBS_PROF
     const long long t_start = wall_clock64();
 #endif
-    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    for (int item = blockIdx.x; item < n_items; item += n_sort_blocks) {
 #ifdef DBS_PROF
         const long long t0 = wall_clock64();
 #endif
@@ -1831,7 +1914,7 @@ __global__ __launch_bounds__(256) FWD_OCC void k_blend_fwd(int N, int W, int H, 
                                                      uint32_t* __restrict__ tile_done,
                                                      uint32_t* __restrict__ tile_qdone,
                                                      float4* __restrict__ ckpt, MgrHeader* hdr,
-                                                     const uint32_t* __restrict__ tile_zused, uint32_t* __restrict__ tile_qend) {
+                                                     const uint32_t* __restrict__ tile_zused, uint32_t* __restrict__ tile_qend, int skip_fill) {
     __shared__ __align__(16) float s_pair[4][32][MGR_PAIR_FLOATS];
     __shared__ __align__(16) uint4 s_qrec[FWD_SLOTS];     // queue record of a published step
     __shared__ uint32_t s_step[FWD_SLOTS];                // which step the slot holds (published last: the flag the readers poll)
@@ -2170,7 +2253,7 @@ __global__ __launch_bounds__(256) FWD_OCC void k_blend_fwd(int N, int W, int H, 
         const uint32_t vt = tile_queue[q];
         const int v = (int)(vt / (uint32_t)T), t = (int)(vt % (uint32_t)T);
         const int px = (t % gx) * 16 + (tid & 15), py = (t / gx) * 16 + (tid >> 4);
-        if (px < W && py < H) {
+        if (!skip_fill && px < W && py < H) {   // (skip_fill: the extra workgroups of k_dbin_sort have written the background)
             const size_t pix = (size_t)py * W + px;
             float* o = out_color + (size_t)v * 3 * P + pix;
             o[0] = bg0;
@@ -2213,7 +2296,9 @@ __global__ __launch_bounds__(256) void k_fwd_items(const uint4* __restrict__ til
                                                    int N, int T, const uint32_t* __restrict__ sorted_gid, const float* __restrict__ depth,
                                                    const uint32_t* __restrict__ tile_zused, const uint32_t* __restrict__ tile_qend,
                                                    uint32_t* __restrict__ tile_zcut, uint32_t* mirror, float cut_frac, uint32_t cut_min,
-                                                   float cut_range, float cut_rel, int gx, int interior_only) {
+                                                   float cut_range, float cut_rel, int gx, int interior_only,
+                                                   const uint32_t* __restrict__ tile_queue, int VT, unsigned char* __restrict__ tile_bgok,
+                                                   const float* out_color, const float* __restrict__ bg) {
     __shared__ uint32_t s_scan[8];
     __shared__ uint32_t s_base;
     __shared__ uint32_t s_run[257];
@@ -2230,6 +2315,15 @@ __global__ __launch_bounds__(256) void k_fwd_items(const uint4* __restrict__ til
             __threadfence_system();
             mirror[3] = 1u;
         }
+    }
+    // "image kept": the image of this forward is complete behind this kernel -- its empty tiles hold the background (written
+    // by the fill or left from the image before), the header names the image and the colour
+    for (uint32_t q = hdr->queue_len + blockIdx.x * 256u + (uint32_t)tid; q < (uint32_t)VT; q += gridDim.x * 256u) tile_bgok[tile_queue[q]] = 1;
+    if (blockIdx.x == 0 && tid == 0) {
+        const unsigned long long owner = (unsigned long long)(uintptr_t)out_color;
+        hdr->img_seq = hdr->fwd_seq;
+        hdr->img_owner[0] = (uint32_t)owner; hdr->img_owner[1] = (uint32_t)(owner >> 32);
+        hdr->img_bg[0] = __float_as_uint(bg[0]); hdr->img_bg[1] = __float_as_uint(bg[1]); hdr->img_bg[2] = __float_as_uint(bg[2]);
     }
     if (blockIdx.x >= nb) return;
     // strided over the queue (which is ordered by depth): every block gets its share of the deep tiles
@@ -2367,7 +2461,10 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
     // bits 4 / 5 (16 / 32): skip the binning launches for tile boxes of more than 2048 / of 1537..2048 tiles (the caller saw
     // in the previous forward's header that no view needed them; a view that does now raises MGR_OVF_TIER)
     const bool do_bin = !(debug & 4), do_blend = !(debug & 2), use_cut = (debug & 8) && canon != nullptr;
+    static const bool bg_fill_on = [] { const char* e = getenv("MANUS_BG_FILL"); return !(e && e[0] == 'b'); }();   // MANUS_BG_FILL=blend: by the blend, as before (A/B)
+    bool bg_filled = false;   // the background of the empty tiles has been written by the instance sort's launch
     const int skip_tiers = ((debug & 16) ? 1 : 0) | ((debug & 32) ? 2 : 0) | ((debug & 128) ? 4 : 0) | ((debug & 256) ? 8 : 0);
+    const int img_kept = (debug & 1024) ? 1 : 0;   // bit 10: "image kept" (see BgFill)
     debug &= 1;
     if (V <= 0 || N < 0 || W <= 0 || H <= 0 || cap < 0 || cap > 0xFFFFFFF0ll)
         return mgr_fail(MGR_EINVAL, "mgr_raster_forward: bad sizes");
@@ -2463,7 +2560,7 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
         { MGR_PROF("k_tile_scan_b", stream); hipLaunchKernelGGL(k_tile_scan_b, dim3(nblk + (dbin ? V : 0)), dim3(1024), 0, stream, V, T, nbT, tile_count, part, (const uint32_t*)blk_cls,
                            tile_start, (uint32_t*)(ws + L.tile_cursor), (uint32_t*)(ws + L.tile_queue), (uint4*)(ws + L.tile_qrec),
                            (const uint32_t*)(ws + L.tile_done), use_hint, (uint32_t*)(ws + L.chunk_start), hdr, (uint32_t)cap,
-                           (uint32_t*)(ws + L.tile_zcut), (uint32_t*)(ws + L.tile_zused), (uint32_t*)(ws + L.tile_qend), use_cut ? 1 : 0, (const uint4*)blk_box, dba); }
+                           (uint32_t*)(ws + L.tile_zcut), (uint32_t*)(ws + L.tile_zused), (uint32_t*)(ws + L.tile_qend), use_cut ? 1 : 0, (const uint4*)blk_box, dba, (unsigned char*)(ws + L.tile_bgok)); }
     }
     MGR_LAUNCH_CHECK("k_tile_scan", stream, debug);
     if (N > 0 && ordered) {
@@ -2484,14 +2581,20 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
                            (const uint32_t*)db_start, (uint32_t*)(ws + L.db_cursor), db_keys); }
         { MGR_PROF("k_dbin_sort", stream);
           const bool run_light = !(skip_tiers & 8) || (skip_tiers & 4), run_full = !(skip_tiers & 4);   // (never neither)
+          // the background of the empty tiles rides on the first of the two launches (when the blend follows in this call)
+          BgFill fill = {do_blend && bg_fill_on ? out_color : nullptr, (const uint32_t*)(ws + L.tile_queue), bg, VT, T, gx, W, H,
+                         (const unsigned char*)(ws + L.tile_bgok), img_kept};
+          const BgFill none = {nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, nullptr, 0};
+          const int n_fill = fill.out ? 1024 : 0;
+          bg_filled = fill.out != nullptr;
           if (run_light)
-              hipLaunchKernelGGL((k_dbin_sort<DBS_LIGHT_KEYS>), dim3(1024), dim3(RS_THREADS), DBS_LIGHT_KEYS * 8 + RS_WAVES * 256 * 4 + 256, stream,
+              hipLaunchKernelGGL((k_dbin_sort<DBS_LIGHT_KEYS>), dim3(1024 + n_fill), dim3(RS_THREADS), DBS_LIGHT_KEYS * 8 + RS_WAVES * 256 * 4 + 256, stream,
                                  N, chunk, chunks, V * chunks, (const uint32_t*)db_start, (const uint32_t*)db_nvis, db_keys, db_order,
-                                 0u, hdr, run_full ? 1 : 0);
+                                 0u, hdr, run_full ? 1 : 0, fill, 1024);
           if (run_full)
-              hipLaunchKernelGGL((k_dbin_sort<SORT_LDS_KEYS>), dim3(1024), dim3(RS_THREADS), SORT_LDS_KEYS * 8 + RS_WAVES * 256 * 4 + 256, stream,
+              hipLaunchKernelGGL((k_dbin_sort<SORT_LDS_KEYS>), dim3(1024 + (run_light ? 0 : n_fill)), dim3(RS_THREADS), SORT_LDS_KEYS * 8 + RS_WAVES * 256 * 4 + 256, stream,
                                  N, chunk, chunks, V * chunks, (const uint32_t*)db_start, (const uint32_t*)db_nvis, db_keys, db_order,
-                                 run_light ? (uint32_t)DBS_LIGHT_KEYS : 0u, hdr, 0); }
+                                 run_light ? (uint32_t)DBS_LIGHT_KEYS : 0u, hdr, 0, run_light ? none : fill, 1024); }
         MGR_LAUNCH_CHECK("k_dbin_sort", stream, debug);
         const bool big_possible = T > BIN_SMALL_TILES;   // a box of more than BIN_SMALL_TILES tiles can only exist then
         { MGR_PROF("k_bin_count", stream);
@@ -2554,12 +2657,13 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
     { MGR_PROF("k_blend_fwd", stream); hipLaunchKernelGGL(k_blend_fwd, dim3(MGR_FWD_GRID), dim3(256), 0, stream, N, W, H, gx, gy, VT, bg,
                        (const uint32_t*)(ws + L.tile_queue), (const uint4*)(ws + L.tile_qrec), (const uint32_t*)(ws + L.sorted_gid), (const MgrGRec*)(ws + L.grec), out_color,
                        (uint32_t*)(ws + L.n_contrib), (uint32_t*)(ws + L.tile_done), (uint32_t*)(ws + L.tile_qdone),
-                       (float4*)(ws + L.ckpt), hdr, (const uint32_t*)(ws + L.tile_zused), (uint32_t*)(ws + L.tile_qend)); }
+                       (float4*)(ws + L.ckpt), hdr, (const uint32_t*)(ws + L.tile_zused), (uint32_t*)(ws + L.tile_qend), bg_filled ? 1 : 0); }
     { MGR_PROF("k_fwd_items", stream); hipLaunchKernelGGL(k_fwd_items, dim3((VT + 255) / 256), dim3(256), 0, stream, (const uint4*)(ws + L.tile_qrec),
                        (const uint32_t*)(ws + L.tile_qdone), (uint32_t*)(ws + L.tile_done), (uint4*)(ws + L.items), hdr,
                        N, T, (const uint32_t*)(ws + L.sorted_gid), (const float*)(ws + L.depth), (const uint32_t*)(ws + L.tile_zused),
                        (const uint32_t*)(ws + L.tile_qend), (uint32_t*)(ws + L.tile_zcut), mgr_take_status_mirror(workspace),
-                       g_cut_frac, (uint32_t)g_cut_min, g_cut_range, g_cut_rel, gx, g_cut_interior); }
+                       g_cut_frac, (uint32_t)g_cut_min, g_cut_range, g_cut_rel, gx, g_cut_interior,
+                       (const uint32_t*)(ws + L.tile_queue), VT, (unsigned char*)(ws + L.tile_bgok), (const float*)out_color, bg); }
     MGR_LAUNCH_CHECK("k_blend_fwd", stream, debug);
     return MGR_OK;
 }

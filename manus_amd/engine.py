@@ -326,7 +326,7 @@ class HipViewCompute:
         # backward then zeroes only the rows that were written by the previous step and get nothing now, instead of every
         # row of every gradient every step (mgr_views_backward, debug bit 512: 97 MB of stores per bench step).  Off by
         # default: a fresh tensor per call is what a caller of a function expects.
-        self.persistent_grads, self._pg, self._pg_ws = bool(persistent_grads), None, None
+        self.persistent_grads, self._pg, self._pg_ws, self._pimg_ws = bool(persistent_grads), None, None, None
         # depth_cut (fused step only): every forward leaves, per tile whose pixels all saturated, the depth in front of
         # which they had stopped (+ a margin); the next forward of the SAME views leaves the instances behind it out of
         # that tile's list -- the binning kernels then handle a fraction of the pairs, the image and the gradients stay
@@ -588,7 +588,7 @@ class HipViewCompute:
         if self.persistent_grads and not arena and self.fused:
             key = (N, na, str(dev))
             if self._pg is None or self._pg[0] != key:
-                self._pg, self._pg_ws = (key, {}), None
+                self._pg, self._pg_ws, self._pimg_ws = (key, {}), None, None
             own = self._pg[1]
 
         def e(shape, name):
@@ -612,7 +612,12 @@ class HipViewCompute:
             check(lib().mgr_skin_weights_fwd(na, ptr(p["_xyz"]), ptr(sg.data), sg.D, sg.H, sg.W, sg.B, sg.stride,
                                              ptr(s["grid_center"]), ptr(s["grid_scale"]), ptr(w), stream()),
                   "mgr_skin_weights_fwd")
-        out = torch.empty((V, 3, H, W), dtype=torch.float32, device=dev)
+        if own is not None:   # persistent_grads: the image too is a buffer this object keeps -- a tile that held the background
+            out = own.get(("image", V, H, W))          # after the previous forward on the same workspace and is empty again is not
+            if out is None:                            # written again (mgr_views_forward, debug bit 1024)
+                out = own[("image", V, H, W)] = torch.empty((V, 3, H, W), dtype=torch.float32, device=dev)
+        else:
+            out = torch.empty((V, 3, H, W), dtype=torch.float32, device=dev)
         radii = torch.empty((V, N), dtype=torch.int32, device=dev)
         op = p["_opacity"].reshape(-1)
         bg = s["bg"]
@@ -627,7 +632,10 @@ class HipViewCompute:
             check(lib().mgr_views_forward(V, N, B, na, sh_half, W, H, ptr(cams), ptr(bg), ptr(p["_xyz"]), ptr(p["_scaling"]),
                                           ptr(p["_rotation"]), ptr(op), ptr(p["_features_dc"]), ptr(f_rest),
                                           ptr(w), ptr(T), ptr(out), ptr(radii), ptr(ws.buf), ws.nbytes, ws.cap,
-                                          phase | self._cut_bit | ws.skip_bits(), stream()), "mgr_views_forward")
+                                          phase | self._cut_bit | ws.skip_bits() | (1024 if (own is not None and self._pimg_ws is ws) else 0),
+                                          stream()), "mgr_views_forward")
+            if own is not None:
+                self._pimg_ws = ws
 
         def launch(ws):
             self._cut_bit = self._cut_flag(ws, view_ids, V, N, W, H)

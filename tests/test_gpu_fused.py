@@ -116,7 +116,8 @@ def test_run_lists_equal_one_lane_per_view(kind, views, n):
 @pytest.mark.parametrize("kind,views", [("hand", 8), ("hand", 4), ("composite", 7), ("hand", 2)])
 def test_persistent_gradient_buffers_equal_fresh_ones(kind, views):
     """HipViewCompute(persistent_grads=True): gradients land in buffers the object keeps, and the backward zeroes only the
-    rows the previous step wrote and this one does not (mgr_views_backward, debug bit 512).  Over steps between which the
+    rows the previous step wrote and this one does not (mgr_views_backward, debug bit 512), and the image into a buffer whose
+    empty tiles are written once (mgr_views_forward, debug bit 1024).  Over steps between which the
     model moves (Gaussians come into view and leave it) every step's gradients, statistics and loss are bit for bit those
     of a compute object that gets fresh, fully zeroed buffers; the same after the rows were disturbed by another
     compute object's backward on the same workspace, and with the run lists switched off in between."""
@@ -150,6 +151,7 @@ def test_persistent_gradient_buffers_equal_fresh_ones(kind, views):
         for k in oa["grads"]:
             assert torch.equal(oa["grads"][k], ob["grads"][k]), (it, k)
         assert torch.equal(oa["grad2d"], ob["grad2d"]) and torch.equal(oa["vis"], ob["vis"]) and torch.equal(oa["radii"], ob["radii"])
+        assert torch.equal(a.last_image, b.last_image), it     # (the image is kept too: tiles that stay empty are not written again)
         n_rows.append(int((oa["grads"]["_xyz"].abs().sum(1) != 0).sum()))
     assert len(set(n_rows)) > 1          # the set of rows with a gradient did change from step to step
 
