@@ -626,7 +626,7 @@ def main():
                        "optimizer_in_step": bool(args.optimizer), "sh_storage": args.sh_storage,
                        "gaussian_order": args.gaussian_order,
                        "gradient_buffers": ("fresh tensors, every row zeroed every step" if (args.fresh_grads or world > 1) else
-                                            "kept by the compute object (like .grad); rows without a gradient are zeroed only when the previous step wrote them"),
+                                            "gradients and image kept by the compute object (like .grad); rows without a gradient are zeroed, and empty tiles written with the background, only where the previous step left something else"),
                        "remeasured_without_hints": remeasured,
                        "depth_cut": ("off" if not compute.depth_cut else
                                      "per-tile saturation depth of the previous forward of the same views bounds the binning; exact "

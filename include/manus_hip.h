@@ -189,6 +189,14 @@ int mgr_views_backward(int V, int N, int B, int n_articulated, int sh_half, int 
                        int32_t* stat_radii, void* workspace, size_t workspace_bytes,
                        int64_t pair_capacity, int debug, void* stream);
 
+/* debug bit 1024 of mgr_views_forward / mgr_raster_forward = "image kept": the caller vouches that out_color is the image the
+ * previous complete forward on this workspace wrote, untouched since.  A tile that held the background colour then and is
+ * empty again is not written again (85 % of the tiles of a capture-like frame are empty: 170 MB of stores at eight 1080p
+ * views); the image is identical.  Honoured only when the header says so: that forward was the last one binned on this
+ * workspace, wrote this very buffer, with this background colour -- otherwise every empty tile is written as without the bit.
+ * (Without the bit the background of the empty tiles is written by extra workgroups of the instance sort's launch when the
+ * depth-ordered binning runs, by the blend otherwise; MANUS_BG_FILL=blend in the environment: always by the blend.) */
+
 /* debug of mgr_views_backward: bit 1 as above.  Bit 512 = "outputs kept": the caller vouches that the leaf-gradient buffers
  * (d_xyz ... d_skin_w, stat_grad2d) are the ones the previous mgr_views_backward on this workspace wrote, untouched since
  * (persistent .grad-like tensors).  The backward then zeroes only the rows that call wrote and this one does not, instead
