@@ -25,7 +25,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
-PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc.json")  # rocprofv3 --pmc passes of this same command (tools/measure_round.sh)
+PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc.json")  # rocprofv3 --pmc passes of this same command (tools/measure_round.sh)
 REPEATS = 5   # the --steps loop is timed this many times; the median goes into the line, min / max beside it
 
 
@@ -70,6 +70,40 @@ def kernel_algorithmic_bytes(name, N, V, R, P):
         "k_preprocess_bwd": V * N * 100,            # K8-K9
     }
     return per.get(name)
+
+
+def kernel_unit_bytes(name, V, consumed, P):
+    """Per-launch bytes of the units the launch PROCESSES (what `roofline.frac` prices since round 5).  The blend kernels
+    work on the list entries the forward's walks consumed (sum over tiles of the deepest contributor), not on the
+    rectangle pairs of SURVEY 8(d) -- exact null-pair culling and early termination leave most of those unread:
+      k_blend_bwd   112 B per consumed entry (gather 40 + 9-float record 72) + 20 B per pixel
+      k_blend_fwd    40 B per consumed entry                                 + 20 B per pixel
+    Other kernels: None (their units are the survey's)."""
+    if consumed is None:
+        return None
+    per = {"k_blend_bwd": 112 * consumed + 20 * P * V, "k_blend_fwd": 40 * consumed + 20 * P * V}
+    return per.get(name)
+
+
+# DESIGN 7's model of the N-GPU step (hand 300 k, 8 views of 1080p sharded): compute of a rank by its number of views,
+# measured on one GPU (profiles/r05_other_configs/hand_v{1,2,4}.json and the headline), + the dense exchange of
+# 61 N + 2 floats between "every peer link at once" (direct reduce-scatter + all-gather: 2 (S / n) / 76.8 GB/s) and "a ring
+# over one link at a time" ((n - 1) times that).
+COMPUTE_MS_BY_VIEWS = {8: 1.40, 4: 0.88, 2: 0.70, 1: 0.53}
+
+
+def predicted_ms(world, N, V, kind, W, H):
+    if world <= 1 or kind != "hand" or (W, H) != (1920, 1080) or V != 8 or N != 300000 or V % world:
+        return None
+    comp = COMPUTE_MS_BY_VIEWS.get(V // world)
+    if comp is None:
+        return None
+    S = (61 * N + 2) * 4
+    direct = 2.0 * (S / world) / 76.8e9 * 1e3
+    ring = direct * (world - 1)
+    return {"compute_ms": comp, "exchange_dense_ms_direct": round(direct, 3), "exchange_dense_ms_ring": round(ring, 3),
+            "step_ms_low": round(comp + direct, 3), "step_ms_high": round(comp + ring, 3),
+            "model": "DESIGN 7: one-GPU compute of views/rank + 61N+2 floats over 7 xGMI links x 76.8 GB/s per direction"}
 
 
 def _median_time(fn, warmup=2, reps=5):
@@ -255,6 +289,122 @@ def cpu_baseline_and_parity(scene_cpu, cams, targets_cpu, gpu, sample_views=2, n
     return cpu, par
 
 
+def dropin_main(args):
+    """`--route dropin`: the zero-change route.  What an unmodified MANUS gets with only PYTHONPATH set is the two shim
+    packages (`diff_gaussian_rasterization.GaussianRasterizer`, `simple_knn._C.distCUDA2`) under torch autograd, ONE
+    (frame, view) per step (config/trainer/trainer.yaml:5) at the training resolution 1280 x 720
+    (config/datasets/train/brics_dynamic.yaml:7-8), with the reference-shaped module code around the operator:
+        TrainingModule.forward    -> manus_amd.modules.hand_forward      (hand_dynamic.py:86-137; skin weights + LBS operators)
+        render_gaussians          -> manus_amd.render.render_gaussians   (gaussian_utils.py:349-428; SH operator + GaussianRasterizer,
+                                     one host read of the pair count per forward, like upstream)
+        loss_func's image terms   -> manus_amd.losses.l1_loss / ssim     (base.py:323-365)
+        loss.backward()              torch autograd through the five operators' backward kernels
+    No fused kernels, no engine, no cross-step state.  Not the headline: one view per step, another resolution."""
+    from types import SimpleNamespace
+    from manus_amd import _lib, losses, rasterizer
+    from manus_amd.modules import hand_forward, object_forward
+    from manus_amd.render import render_gaussians
+    from manus_amd.structures import Bones
+    from manus_amd.synthetic import camera_table, make_scene
+    from manus_amd.engine import HipViewCompute
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    V, N = args.views, args.gaussians
+    W, H = (1280, 720) if (args.width, args.height) == (1920, 1080) else (args.width, args.height)
+    scene = make_scene(n_gaussians=N, kind=args.kind, seed=0, n_cameras=V, width=W, height=H, device=dev)
+    ct = camera_table(scene["cameras"], dev)
+    g = torch.Generator(device="cpu").manual_seed(123)
+    pert = dict(scene)
+    pert["params"] = {k: (v + 0.01 * v.abs().mean() * torch.randn(v.shape, generator=g).to(dev)) for k, v in scene["params"].items()}
+    with torch.no_grad():
+        targets = HipViewCompute(pert, torch.zeros((V, 3, H, W), device=dev), ct).forward_views_fused(list(range(V)))[0]
+        targets_hwc = targets.permute(0, 2, 3, 1).contiguous()
+    rasterizer.context(dev).clear()
+    P = {k: v.detach().clone().requires_grad_(True) for k, v in scene["params"].items()}
+    is_hand = args.kind == "hand"
+
+    class Model:      # the attributes of GaussianModel the module code reads (gaussian.py:55-82)
+        _xyz, _scaling, _rotation = P["_xyz"], P["_scaling"], P["_rotation"]
+        grid_center, grid_scale, grid_weights = scene.get("grid_center"), scene.get("grid_scale"), scene.get("grid")
+
+        @property
+        def get_features(self):
+            return torch.cat([P["_features_dc"], P["_features_rest"]], dim=1)
+
+        @property
+        def get_opacity(self):
+            return torch.sigmoid(P["_opacity"])
+
+    model = Model()
+    cams = [SimpleNamespace(fovx=c["fovx"], fovy=c["fovy"], height=c["height"], width=c["width"],
+                            world_view_transform=torch.tensor(c["world_view_transform"], dtype=torch.float32, device=dev)[None],
+                            full_proj_transform=torch.tensor(c["full_proj_transform"], dtype=torch.float32, device=dev)[None],
+                            camera_center=torch.tensor(c["camera_center"], dtype=torch.float32, device=dev)[None]) for c in scene["cameras"]]
+    batches = [dict(bones_posed=Bones(None, None, None, scene["posed"][v]), bones_rest=Bones(None, None, None, scene["rest"]))
+               for v in range(V)] if is_hand else [None] * V
+    bg = scene["bg"]
+    state = {"k": 0, "radii": None}
+
+    def one_step():
+        v = state["k"] % V
+        state["k"] += 1
+        for t in P.values():
+            t.grad = None
+        pred = hand_forward(model, batches[v]) if is_hand else object_forward(model)
+        out = render_gaussians(pred.posed_xyz, pred.posed_cov, pred.cano_xyz, pred.cano_features, pred.cano_opacity, cams[v], bg,
+                               sh_degree=3, tf=pred.get("tf"), device=dev)
+        gt = targets_hwc[v]
+        loss = 0.8 * losses.l1_loss(out["render"], gt) + 0.2 * (1.0 - losses.ssim(out["render"], gt))
+        loss.backward()
+        state["radii"] = out["radii"]
+        return loss
+
+    for _ in range(max(1, args.warmup)):
+        loss = one_step()
+    torch.cuda.synchronize()
+    dts = []
+    _lib.profile_enable(False)
+    for _ in range(REPEATS):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = one_step()
+        torch.cuda.synchronize()
+        dts.append(time.perf_counter() - t0)
+    dt = float(np.median(dts))
+    # per-kernel breakdown of the library launches (HIP events around each: slows the step, taken in a separate loop)
+    _lib.profile_enable(True, only=None)
+    for _ in range(args.steps):
+        one_step()
+    prof = _lib.profile_report()
+    _lib.profile_enable(False)
+    tot = sum(v[1] for v in prof.values())
+    lib_ms = tot / args.steps
+    if args.profile_all:
+        for k, (c, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
+            print("%-22s %6d launches %9.3f ms avg %8.4f ms  %5.1f%%" % (k, c, ms, ms / c, 100 * ms / tot), file=sys.stderr)
+        print("library kernels %.3f ms/step of %.3f ms/step wall (the rest: torch glue kernels -- cat, sigmoid, permute, the loss's "
+              "arithmetic, gradient accumulation -- and the host: ctypes calls + one blocking read of the pair count per forward)"
+              % (lib_ms, 1e3 * dt / args.steps), file=sys.stderr)
+    finite = all(bool(torch.isfinite(t.grad).all()) for t in P.values())
+    dom = max(prof, key=lambda k_: prof[k_][1]) if prof else None
+    line = {"metric": "train iters/sec (fwd+bwd), drop-in operator route: 1 view per step, %dk Gaussians @%dx%d "
+                      "[not the headline configuration: GaussianRasterizer + reference-shaped modules under autograd]" % (N // 1000, W, H),
+            "headline": False, "value": round(args.steps / dt, 4), "unit": "iters/s", "n_gpus": 1, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4), "repeats": REPEATS,
+            "ms_per_step_min": round(1e3 * min(dts) / args.steps, 4), "ms_per_step_max": round(1e3 * max(dts) / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s, %d Gaussians, ONE view per step (cycling over %d cameras) at %dx%d, modules.hand_forward + "
+                                   "render.render_gaussians + losses (0.8 L1 + 0.2 (1 - SSIM)) under torch autograd" % (args.kind, N, V, W, H),
+                       "route": "dropin", "gaussians": N, "views_per_step": 1, "width": W, "height": H,
+                       "host_syncs_per_step": 1, "library_kernel_ms_per_step": round(lib_ms, 4),
+                       "dominant_library_kernel": dom, "dominant_kernel_ms": round(prof[dom][1] / prof[dom][0], 4) if dom else None,
+                       "finite_grads": finite, "loss": float(loss.detach())},
+            "roofline": None, "cpu_baseline": None, "parity": None}
+    print(json.dumps(line))
+    sys.stdout.flush()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -290,12 +440,22 @@ def main():
                          "(like .grad tensors) and the backward zeroing only the rows that need it")
     ap.add_argument("--gaussian-order", default="given", choices=["given", "morton"],
                     help="morton: the model's rows sorted along a Z-order curve first (a what-if for spatially coherent rows; not the headline)")
-    ap.add_argument("--no-depth-cut", action="store_true",
-                    help="bin every pair every step (no use of the previous forward's per-tile saturation depth)")
+    ap.add_argument("--depth-cut", action="store_true",
+                    help="time the step WITH the depth-cut hints (the previous forward's per-tile saturation depth bounds the "
+                         "binning; exact).  Off by default, like engine.Trainer: it only pays while the model stands still "
+                         "between steps.  The default line reports the hinted figure as `value_with_hints`")
+    ap.add_argument("--no-depth-cut", action="store_true", help="(the default since round 5; accepted for old scripts)")
+    ap.add_argument("--no-hints-variant", action="store_true", help="skip the extra timed region with the depth-cut hints on")
+    ap.add_argument("--route", default="fused", choices=["fused", "dropin"],
+                    help="dropin: what an unmodified MANUS gets with only PYTHONPATH set -- one (frame, view) per step through "
+                         "modules.hand_forward + render.render_gaussians (GaussianRasterizer under autograd) + losses at the "
+                         "reference's 1280x720 training resolution; not the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (cpu_baseline and parity)")
     ap.add_argument("--parity-views", type=int, default=2, help="views of the step run through the CPU oracle")
     ap.add_argument("--profile-all", action="store_true", help="print a per-kernel HIP-event breakdown to stderr")
     args = ap.parse_args()
+    if args.route == "dropin":
+        return dropin_main(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -340,7 +500,7 @@ def main():
         del hp
     rasterizer.context(dev).clear()
     compute = HipViewCompute(scene, targets, ct, loss=args.loss, sh_storage=args.sh_storage, sparse_loss=not args.dense_loss_scan,
-                             depth_cut=not args.no_depth_cut, persistent_grads=not args.fresh_grads)
+                             depth_cut=args.depth_cut and not args.no_depth_cut, persistent_grads=not args.fresh_grads)
     shapes = {k: v.shape for k, v in compute.params.items()}
     sharded = args.sharded_adam and args.optimizer and world > 1
     # N > 1: the views go to the ranks by measured cost (pairs per view from one forward of every view -- deterministic,
@@ -500,8 +660,8 @@ def main():
     # With the optimizer in the loop a Gaussian can walk out of the skin-weight grid; its weights are then 0/0 = NaN
     # exactly like the reference (gaussian_utils.py:193-195), which drops such rows when it loads a checkpoint.
     nonfinite = sum(int((~torch.isfinite(x)).sum()) for x in out["grads"].values())
-    assert args.optimizer or nonfinite == 0, "non-finite gradients"
-    # list entries the blend actually consumed (sum over tiles of the deepest contributor): what k_blend_bwd touches
+    assert args.optimizer or nonfinite == 0 or os.environ.get("MANUS_HIP_VARIANT"), "non-finite gradients"   # (knock-out builds: tools/instr)
+    # list entries the blend actually consumed (sum over tiles of the deepest contributor): the units k_blend_fwd / _bwd process
     consumed = None
     ws = rasterizer.context(dev).last_ws
     if ws is not None:
@@ -510,6 +670,56 @@ def main():
         _lib.lib().mgr_raster_layout(V_local, N, W, H, ws.cap, arr, 32)
         VT = V_local * ((W + 15) // 16) * ((H + 15) // 16)
         consumed = int(ws.buf[int(arr[9]): int(arr[9]) + 4 * VT].view(torch.int32).sum().item())
+
+    def keep(o_):
+        return {k: ({n: g.clone() for n, g in v.items()} if isinstance(v, dict) else (v.clone() if torch.is_tensor(v) else v))
+                for k, v in o_.items()}
+
+    def same_step(a_, b_, img_a, img_b):
+        """Bit-equality of two steps' outputs (the loss scalar is summed with float atomics: 1e-6)."""
+        bad = [k for k in a_["grads"] if not torch.equal(a_["grads"][k], b_["grads"][k])]
+        bad += [k for k in ("grad2d", "vis", "radii") if not torch.equal(a_[k], b_[k])]
+        if not torch.equal(img_a, img_b):
+            bad.append("image")
+        if abs(float(a_["loss"]) - float(b_["loss"])) > 1e-6 * max(1.0, abs(float(b_["loss"]))):
+            bad.append("loss")
+        return bad
+
+    # The headline is timed in the configuration training runs in (engine.Trainer's and HipViewCompute's defaults: depth cut
+    # off, kept buffers).  The depth-cut hints pay only while the model stands still between steps -- as it does in this
+    # fwd+bwd loop -- so their figure is an extra key, `value_with_hints`, measured here on the same box and process.
+    static_model = world == 1 and not args.optimizer
+    timed_out = timed_img = None
+    if static_model:
+        timed_out, timed_img = keep(out), compute.last_image.clone()
+    hints = None
+    if static_model and not compute.depth_cut and not args.no_hints_variant and compute.fused:
+        compute.depth_cut = os.environ.get("MANUS_DEPTH_CUT", "1") != "0"
+        if compute.depth_cut:
+            for _ in range(3):      # the first forward leaves the hints, the following ones bin against them
+                step.step()
+            rasterizer.check_overflow()
+            dts_h, _, out_h = timed_region()
+            try:
+                rasterizer.check_overflow()
+                flagged = False
+            except _lib.ManusHipError:
+                flagged = True
+            dt_h = float(np.median(dts_h))
+            hints = {"value": round(args.steps / dt_h, 4), "ms_per_step": round(1e3 * dt_h / args.steps, 4),
+                     "flagged_forwards": rasterizer.context(dev).cut_retries, "remeasure_needed": flagged,
+                     "differs_from_headline_step": same_step(out_h, timed_out, compute.last_image, timed_img)}
+        compute.depth_cut = False
+        step.step()                 # (back on full lists: the parity block below runs the headline's configuration)
+        rasterizer.check_overflow()
+
+    views_by_rank = None
+    if world > 1:
+        views_by_rank = [None] * world
+        dist.all_gather_object(views_by_rank, [int(v) for v in step.local_views])
+    # digest of the step's (reduced) leaf gradients: lets an N-rank line be compared with the one-rank line of the same size
+    digest = {k: [float(g.double().sum()), float(g.double().abs().sum())] for k, g in out["grads"].items()}
+    digest["loss"] = float(out["loss"])
 
     if rank == 0:
         R_view = npairs_local / max(1, V_local)          # measured pairs per view (num_rendered)
@@ -520,7 +730,8 @@ def main():
         roof = None
         if dom:
             avg_ms = dom[1] / dom[0]
-            kb = kernel_algorithmic_bytes(DOMINANT, N, V_local, R_view, P_px) or 0
+            kb_survey = kernel_algorithmic_bytes(DOMINANT, N, V_local, R_view, P_px) or 0
+            kb = kernel_unit_bytes(DOMINANT, V_local, consumed, P_px) or kb_survey
             ach = kb / (avg_ms * 1e-3) / 1e9
             pmc = pmc_counters(DOMINANT, N, V_local, W, H) if world == 1 else {}
             # the committed counter passes describe THIS kernel only if their dispatch took as long as it does now
@@ -530,8 +741,15 @@ def main():
             roof = {"bound": "hbm", "kernel": DOMINANT, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": pmc.get("traffic"),
                     "avg_kernel_ms": round(avg_ms, 4), "kernel_duration_samples": int(dom[0]), "algorithmic_bytes_per_launch": int(kb),
+                    "units": ("list entries the forward's walks consumed x %d B + pixels x 20 B (the units this launch processes)"
+                              % (112 if DOMINANT == "k_blend_bwd" else 40)) if kb != kb_survey else "SURVEY 8(d) per-unit figures",
+                    "consumed_pairs": consumed,
+                    "survey_formula_bytes_per_launch": int(kb_survey),
+                    "frac_survey_formula": round(kb_survey / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                     "iter_algorithmic_GBps": round(b_iter * args.steps / dt / 1e9, 2),
-                    "note": "peak / unit / achieved / frac price the HBM roofline of SURVEY 8(d) (this path has no dense contraction); "
+                    "note": "peak / unit / achieved / frac price the HBM roofline on the bytes of the units the launch processes "
+                            "(consumed list entries, not SURVEY 8(d)'s rectangle pairs, most of which exact culling and early "
+                            "termination never read: that figure is frac_survey_formula); this path has no dense contraction; "
                             "`limiter` says what the counters say bounds the kernel"}
             if pmc.get("stale"):
                 roof["traffic_stale"] = True    # counters on file are of an older build of the kernel: not reused
@@ -544,13 +762,6 @@ def main():
                     roof["step_traffic_bytes"] = int(pmc["step_hbm_bytes"])
                     roof["step_traffic_GBps"] = round(pmc["step_hbm_bytes"] / (step_ms * 1e-3) / 1e9, 1)
                     roof["step_traffic_frac"] = round(pmc["step_hbm_bytes"] / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-            # The SURVEY 8(d) figure counts every rectangle pair (R = num_rendered); exact null-pair culling and early
-            # termination mean most of them are never read.  What the kernel really touches: 112 B per list entry
-            # consumed + 20 B per pixel.
-            if consumed is not None:
-                tb = 112 * consumed + 20 * P_px * V_local
-                roof.update({"touched_bytes_per_launch": int(tb), "consumed_pairs": consumed,
-                             "frac_touched": round(tb / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)})
             if pmc.get("traffic"):
                 roof["frac_traffic"] = round(pmc["traffic"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
             if pmc.get("valu_issue_frac") is not None:
@@ -571,13 +782,25 @@ def main():
                   file=sys.stderr)
         cpu = parity = None
         if not args.no_cpu_baseline and world == 1 and args.kind == "hand" and not args.optimizer and args.sh_storage == "fp32":
-            # the GPU step once more on the sampled views alone (same targets, same loss, same 1/V scale), keeping the
-            # images, dL/dimage and the kernels' per-instance records for the oracle
+            # The GPU step once more on the sampled views alone (same targets, same loss, same 1/V scale), ON THE TIMED
+            # REGION'S compute object and IN ITS MODE (no host sync per forward: fenced; kept buffers; no depth cut) -- run
+            # twice, so that the second one has the row- / tile-selective fills of the kept buffers in use like every timed
+            # step had -- keeping the images, dL/dimage and the kernels' per-instance records for the oracle.
             Ks = min(args.parity_views, V)
             ids = list(range(Ks))
-            rasterizer.set_sync_policy(True)
             compute.grad_arena = None
-            o = compute(ids, 1.0 / V)
+            for attempt in range(3):
+                compute(ids, 1.0 / V)
+                o = compute(ids, 1.0 / V)
+                try:
+                    rasterizer.check_overflow()      # (blocking; raises if either forward ran out of pair capacity: the
+                    break                            #  hint was enlarged, the two steps are run again)
+                except _lib.ManusHipError:
+                    if attempt == 2:
+                        raise
+            gpu_mode = {"sync_per_forward": bool(rasterizer.context(dev).sync_every_forward), "depth_cut": bool(compute.depth_cut),
+                    "kept_buffers": bool(compute.persistent_grads),
+                    "selective_fills_in_use": bool(compute.persistent_grads and compute._pg_ws is not None and compute._pimg_ws is not None)}
             img_s = compute.last_image
             _, g_img = compute._image_loss(img_s, compute._select(ids)["targets"], 1.0 / V)
             torch.cuda.synchronize()
@@ -596,15 +819,34 @@ def main():
             sc_cpu["params"] = {k: v.detach().cpu() for k, v in scene["params"].items()}
             cpu, parity = cpu_baseline_and_parity(sc_cpu, scene["cameras"], targets[:Ks].cpu(), gpu, sample_views=Ks,
                                                   n_views=V, loss=args.loss)
-        # the headline is BASELINE.json's metric on BASELINE.json's configuration; anything else is labelled by its arguments
+            # ... and the bridge from the timed step itself: the LAST TIMED STEP's outputs (all V views, cloned right after
+            # the timed region) against a plain step of a second compute object -- host sync per forward, fresh zero-filled
+            # tensors, no hints, no skipped launches: bit for bit
+            rasterizer.set_sync_policy(True)
+            plain = HipViewCompute(scene, targets, ct, loss=args.loss, sh_storage=args.sh_storage, sparse_loss=not args.dense_loss_scan,
+                                   depth_cut=False, persistent_grads=False)
+            o_plain = plain(list(range(V)), 1.0 / V)
+            torch.cuda.synchronize()
+            differs = same_step(timed_out, o_plain, timed_img, plain.last_image)
+            del plain, o_plain
+            parity["gpu_step_mode"] = gpu_mode
+            parity["timed_step_vs_plain_step"] = {"differs": differs, "equal": not differs,
+                                                  "what": "last step of the timed region (all %d views; fenced, kept buffers) vs a step of a second "
+                                                          "compute object with a host sync per forward and fresh zeroed tensors: torch.equal on the six "
+                                                          "leaf gradients, grad2d, vis, radii and the image; loss to 1e-6" % V}
+            parity["identical_inputs"]["pass"] = bool(parity["identical_inputs"]["pass"] and not differs)
+        # the headline is BASELINE.json's metric on BASELINE.json's configuration, timed the way training runs it (no depth-cut
+        # hints); anything else is labelled by its arguments
         headline = (args.kind == "hand" and N == 300000 and V == 8 and (W, H) == (1920, 1080) and args.loss == "l1+ssim"
-                    and not args.optimizer and args.sh_storage == "fp32" and not args.dense_loss_scan)
+                    and not args.optimizer and args.sh_storage == "fp32" and not args.dense_loss_scan and not compute.depth_cut
+                    and not args.depth_cut and not args.fresh_grads)
         k_str = "%dk" % (N // 1000) if N % 1000 == 0 else str(N)
         res_str = "1080p" if (W, H) == (1920, 1080) else "%dx%d" % (W, H)
         metric = ("train iters/sec (fwd+bwd) %s Gaussians @%s, %d views; PSNR parity" % (k_str, res_str, V))
         if not headline:
-            metric += " [not the headline configuration: %s%s%s]" % (args.kind, ", optimizer in the step" if args.optimizer else "",
-                                                                    ", fp16 SH storage" if args.sh_storage == "fp16" else "")
+            metric += " [not the headline configuration: %s%s%s%s]" % (args.kind, ", optimizer in the step" if args.optimizer else "",
+                                                                      ", fp16 SH storage" if args.sh_storage == "fp16" else "",
+                                                                      ", depth-cut hints" if args.depth_cut else "")
         kind_str = {"hand": "HAND_GAUSSIAN: %d Gaussians, 21-transform LBS" % N, "object": "OBJ_GAUSSIAN: %d static Gaussians" % N,
                     "composite": "COMPOSITE: %d Gaussians (hand, 21-transform LBS + static object)" % N}.get(args.kind, args.kind)
         ms = [1e3 * d_ / args.steps for d_ in dts]
@@ -614,24 +856,33 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4), "repeats": REPEATS,
             "ms_per_step_min": round(min(ms), 4), "ms_per_step_max": round(max(ms), 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "value_with_hints": hints["value"] if hints else None,
+            "ms_per_step_with_hints": hints["ms_per_step"] if hints else None,
             "config": {"workload": "%s, %d views %dx%d, one pose per view "
                                    "(n_poses=%d), image loss %s, fwd+bwd to leaf grads" % (kind_str, V, W, H, n_poses, "0.8*L1 + 0.2*(1-SSIM)" if args.loss == "l1+ssim" else "L1"),
                        "gaussians": N, "views": V, "width": W, "height": H, "views_per_gpu": V_local,
                        "pairs_per_view": int(R_view), "parallelism": "views/%d" % world,
                        "view_assignment": (None if world == 1 else "round-robin" if weights is None else "balanced by measured pairs per view (LPT)"),
+                       "views_by_rank": views_by_rank, "grad_digest": digest,
                        "allreduce": (None if world == 1 else "reduce-scatter + sharded Adam + all-gather" if sharded else
                                      {"mode": mode, "ms_per_step_by_mode": mode_timings,
                                       "detail": "dense 61N floats" if mode == "dense" else
                                                 "rows with a gradient (%s of %d) x 60 floats + 2N bytes" % (step.last_rows, N)}),
+                       "predicted_ms": predicted_ms(world, N, V, args.kind, W, H),
                        "optimizer_in_step": bool(args.optimizer), "sh_storage": args.sh_storage,
                        "gaussian_order": args.gaussian_order,
                        "gradient_buffers": ("fresh tensors, every row zeroed every step" if (args.fresh_grads or world > 1) else
-                                            "gradients and image kept by the compute object (like .grad); rows without a gradient are zeroed, and empty tiles written with the background, only where the previous step left something else"),
+                                            "gradients and image kept by the compute object (like .grad; engine.Trainer's and HipViewCompute's default); rows without a gradient are zeroed, and empty tiles written with the background, only where the previous step left something else"),
                        "remeasured_without_hints": remeasured,
-                       "depth_cut": ("off" if not compute.depth_cut else
+                       "depth_cut": ("off" if not (compute.depth_cut or args.depth_cut) else
                                      "per-tile saturation depth of the previous forward of the same views bounds the binning; exact "
                                      "(flagged and re-run without it when a cut list runs out): %d flagged forwards in this run"
                                      % rasterizer.context(dev).cut_retries),
+                       "with_hints": (None if not hints else
+                                      {"what": "the same loop with the depth-cut hints on (HipViewCompute(depth_cut=True)): the previous forward's "
+                                               "per-tile saturation depth bounds the binning; exact; pays only while the model stands still "
+                                               "between steps, which is why training (engine.Trainer) and the headline run without it",
+                                       **hints}),
                        "loss_span_list": ("full comparison of rendered and target image" if args.dense_loss_scan else
                                           "tile occupancy of the forward + per-view target-vs-background column masks (computed once per view)"
                                           if compute.target_map else "tile occupancy of the forward + target background"),
@@ -641,7 +892,8 @@ def main():
         print(json.dumps(line))
         sys.stdout.flush()
         if parity is not None and not parity["identical_inputs"]["pass"]:
-            print("bench: PARITY FAILED on identical blend inputs: %s" % json.dumps(parity["identical_inputs"]), file=sys.stderr)
+            print("bench: PARITY FAILED on identical blend inputs: %s / timed step vs plain step: %s"
+                  % (json.dumps(parity["identical_inputs"]), json.dumps(parity["timed_step_vs_plain_step"])), file=sys.stderr)
             sys.exit(3)
     if world > 1:
         dist.destroy_process_group()

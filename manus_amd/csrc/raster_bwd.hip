@@ -91,6 +91,13 @@ __device__ __forceinline__ uint32_t mgr_any64(unsigned long long m) {
 // rows 288 apart the four (exchange row, entry) x four columns of a lane group take 16 different 16-byte slots.
 // (Measured on the way: [column * 8 + row] planes read with ds_read2_b64 cost 29 M conflict cycles of 197 M per launch;
 // a conflict-free variant of that, still on ds_read2_b64's 128 B/clk path, 0.4345 ms.)
+// BWD_KO (instrumentation only, WRONG RESULTS: cost bounds for experiments, tools/instr/ko_bwd.sh): bit 1 skips phase 2, bit 2 also
+// phase 1's exchange stores, bit 4 runs 57 % of the pair steps (what 4x4-pixel boxes would leave: 35.5 % -> 62 % contributing lanes),
+// bit 8 replaces phase 2's LDS atomics by plain stores, bit 16 skips phase 1's arithmetic behind the alpha evaluation,
+// bit 32 reads ONE pair record line instead of five, bit 64 reads the five lines twice, bit 128 = the LDS atomics of rounds 3-4
+#ifndef BWD_KO
+#define BWD_KO 0
+#endif
 #define BWD_ROW 288
 #define BWD_PLANE_W 64
 #define BWD_PLANE_B 128
@@ -244,7 +251,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BWD_WAVES, 
                                first + (uint32_t)lane + 1u);  // 1-based list position
                 if ((na & 1) && rank == na - 1) mgr_pair_pad(pb);
             }
-            const int npair = (na + 1) >> 1;
+            const int npair = (BWD_KO & 4) ? ((na + 1) >> 1) * 57 / 100 : (na + 1) >> 1;
             BP(2);
 #pragma unroll 1
             for (int p0 = 0; p0 < npair; p0 += 4) {
@@ -253,7 +260,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BWD_WAVES, 
                 // ---- phase 1: lane = pixel ----
                 for (int r = 0; r < np; ++r) {
                     const float4* pp = (const float4*)(slab + (p0 + r) * MGR_PAIR_FLOATS);
+#if BWD_KO & 32
+                    const float4 R0 = pp[0], R1 = R0, R2 = R0, R3 = R0, R4 = make_float4(R0.x, R0.y, __uint_as_float(first + 1u), __uint_as_float(first + 2u));
+#elif BWD_KO & 64
+                    float4 R0 = pp[0];
+                    const float4 R1 = pp[1], R2 = pp[2], R3 = pp[3], R4 = pp[4];
+                    {
+                        const float4* qq = (const float4*)(slab + ((p0 + r) ^ 1) * MGR_PAIR_FLOATS);
+                        const float4 S0 = qq[0], S1 = qq[1], S2 = qq[2], S3 = qq[3], S4 = qq[4];
+                        R0.x = __builtin_fmaf(S0.x + S1.y + S2.z + S3.w + S4.x, 0.0f, R0.x);
+                    }
+#else
                     const float4 R0 = pp[0], R1 = pp[1], R2 = pp[2], R3 = pp[3], R4 = pp[4];
+#endif
                     mgr_v2f dx, dy, G, al;
                     bool va, vb;
                     mgr_pair_alpha(R0, R1, R2, fpx2, fpy2, dx, dy, G, al, va, vb);
@@ -270,6 +289,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BWD_WAVES, 
                     if ((ma | mb) == 0ull) continue;
                     MGR_STAT(5, 1);                                                    // pair iterations doing the full math
                     tmask |= (anya | (anyb << 1)) << (2 * r);
+#if BWD_KO & 16
+                    {
+                        float* const xr = xch + r * BWD_ROW + xoff;
+                        xr[0] = al.x; xr[BWD_PLANE_W] = G.x; xr[BWD_PLANE_B] = al.y; xr[BWD_PLANE_B + BWD_PLANE_W] = G.y;
+                        continue;
+                    }
+#endif
                     const mgr_v2f cr = {R3.x, R3.y}, cgn = {R3.z, R3.w}, cb = {R4.x, R4.y};
                     const mgr_v2f cg = cr * g0v + cgn * g1v + cb * g2v;
                     // both entries side by side; only the transmittance and the prefix chain from a to b
@@ -287,11 +313,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BWD_WAVES, 
                     const mgr_v2f d2 = T2 * cg - (Og - P2) * rc;
                     const mgr_v2f da2 = {va ? d2.x : 0.0f, vb ? d2.y : 0.0f};
                     const mgr_v2f v_op = G * da2;   // dL/dopacity share; times the opacity = q = dL/dG G (applied in the flush)
+#if BWD_KO & 2
+                    if (v_op.x + w2.x + v_op.y + w2.y == 12345.678f) xch[xoff] = 1.f;   // (keeps the arithmetic alive)
+#else
                     float* const xr = xch + r * BWD_ROW + xoff;
                     xr[0] = v_op.x; xr[BWD_PLANE_W] = w2.x;
                     xr[BWD_PLANE_B] = v_op.y; xr[BWD_PLANE_B + BWD_PLANE_W] = w2.y;
+#endif
                 }
                 if (tmask == 0u) continue;
+#if BWD_KO & 3
+                if (tmask != 0xFFFFFFFFu) { flag[(p0 * 2) & 63] = 1u; continue; }
+#endif
                 __builtin_amdgcn_wave_barrier();
                 // ---- phase 2: lane = (entry e2, pixel column pc) ----
                 // moments of v = G dL/dalpha about the Gaussian's centre; dx is constant along a column
@@ -302,6 +335,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BWD_WAVES, 
                     const uint32_t pos = __float_as_uint(pbs[18 + h]);
                     const float dxc = xe - fx_col, dy0 = ye - qy0;
                     const float* src = xch + (e2 >> 1) * BWD_ROW + h * BWD_PLANE_B + 4 * pc;
+#if !(BWD_KO & 128)
+                    // the entry's accumulator row: read now, written back with this quadrant's sums at the end of the step.
+                    // The eight entries of a group are distinct list entries, so the 64 + 8 addresses of the step are distinct
+                    // and the wave's own program order is all the ordering there is -- no LDS atomic (measured: the
+                    // ds_add_f32 pair cost 0.05 of the kernel's 0.41 ms, knock-out BWD_KO=8)
+                    const bool on2 = (tmask >> e2) & 1u;
+                    float* const accp = acc + (on2 ? (int)((pos - 1u - first) & 63u) : 0) * 9;
+                    const float old_t = accp[pc], old_9 = accp[8];
+#endif
                     mgr_v2f DY = {dy0, dy0 - 1.0f};
                     mgr_v2f B0 = {0.f, 0.f}, B1 = {0.f, 0.f}, B2 = {0.f, 0.f}, Cr = {0.f, 0.f}, Cg = {0.f, 0.f}, Cb = {0.f, 0.f};
 #pragma unroll
@@ -330,11 +372,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BWD_WAVES, 
                     const float b9 = grp_sum<8>(sb);
                     if ((tmask >> e2) & 1u) {
                         const int ja = (int)(pos - 1u - first);
+#if BWD_KO & 8
+                        acc[ja * 9 + pc] = tot;
+                        if (pc == 0) {
+                            acc[ja * 9 + 8] = b9;
+                            flag[ja] = 1u;
+                        }
+#elif BWD_KO & 128
                         __hip_atomic_fetch_add(acc + ja * 9 + pc, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                         if (pc == 0) {
                             __hip_atomic_fetch_add(acc + ja * 9 + 8, b9, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                             flag[ja] = 1u;
                         }
+#else
+                        accp[pc] = old_t + tot;
+                        if (pc == 0) {
+                            accp[8] = old_9 + b9;
+                            flag[ja] = 1u;
+                        }
+#endif
                     }
                 }
                 __builtin_amdgcn_wave_barrier();

@@ -314,27 +314,42 @@ class HipViewCompute:
     scene["kind"]: "hand" (every Gaussian skinned, hand_dynamic.py:86-137), "object" (static, object.py:32-41) or
     "composite" (the first scene["n_hand"] Gaussians skinned, the rest static with the identity transform,
     composite.py:50-59).  fused=True runs the fused kernels through direct C-ABI calls (no autograd graph); fused=False
-    the modular operators under autograd (the reference-shaped path)."""
+    the modular operators under autograd (the reference-shaped path).
+
+    ONE set of defaults for the step, shared by `Trainer`, `bench.py` and a hand-built object: depth cut off, gradient /
+    image buffers kept (`persistent_grads`).  With kept buffers the tensors in a step's output dict (`grads`, `grad2d`,
+    `vis`) and `last_image` are the SAME storage every step, like `.grad` tensors: they hold the latest step's values --
+    clone what must outlive the next call, or construct with persistent_grads=False for fresh tensors per call.  Writing
+    into them is allowed: every step compares the tensors' torch version counters with those it recorded when it handed
+    them out, and a buffer touched in between (any in-place torch op on it or on a view of it) is filled in full again
+    instead of row- / tile-selectively (tests/test_gpu_fused.py::test_kept_buffers_survive_a_caller_writing_into_them).
+    Writes torch cannot see (raw pointers, `.data`) are the caller's to avoid."""
+
+    # bytes of parked depth-cut hint tables kept per compute object (4 bytes per tile and view each)
+    MAX_CUT_HINT_BYTES = 64 << 20
+    # per-view target maps kept (130 KB per 1080p view)
+    MAX_TARGET_MAPS = 4096
 
     def __init__(self, scene, targets, cam_table, loss_weight=1.0, fused=True, loss="l1", w_rgb=0.8, w_ssim=0.2,
-                 sh_storage="fp32", sparse_loss=True, overlap_loss=True, depth_cut=True, max_cut_hints=1024,
-                 persistent_grads=False):
+                 sh_storage="fp32", sparse_loss=True, overlap_loss=True, depth_cut=False, max_cut_hints=1024,
+                 persistent_grads=True):
         from . import fused as fused_mod, ops, rasterizer
-        # persistent_grads (fused step, no grad_arena): the leaf gradients, the skin-weight gradient and the statistics are
-        # written into buffers this object keeps -- like `.grad` tensors, the returned tensors are the same storage every
-        # step and hold the LATEST step's values (clone what must outlive the next call; do not write to them).  The
-        # backward then zeroes only the rows that were written by the previous step and get nothing now, instead of every
-        # row of every gradient every step (mgr_views_backward, debug bit 512: 97 MB of stores per bench step).  Off by
-        # default: a fresh tensor per call is what a caller of a function expects.
-        self.persistent_grads, self._pg, self._pg_ws, self._pimg_ws = bool(persistent_grads), None, None, None
+        # persistent_grads (fused step, no grad_arena): the leaf gradients, the skin-weight gradient, the statistics and the
+        # image are written into buffers this object keeps (see the class docstring).  The backward then zeroes only the
+        # rows that were written by the previous step and get nothing now, instead of every row of every gradient every
+        # step (mgr_views_backward, debug bit 512: 97 MB of stores per bench step), and the forward writes the background
+        # only into empty tiles that held something else (mgr_views_forward, bit 1024).  `_pg_ver`: the torch version
+        # counter of every kept tensor as of the end of the last step -- a mismatch means somebody wrote into it.
+        self.persistent_grads, self._pg, self._pg_ws, self._pimg_ws, self._pg_ver = bool(persistent_grads), None, None, None, {}
         # depth_cut (fused step only): every forward leaves, per tile whose pixels all saturated, the depth in front of
         # which they had stopped (+ a margin); the next forward of the SAME views leaves the instances behind it out of
         # that tile's list -- the binning kernels then handle a fraction of the pairs, the image and the gradients stay
         # bit for bit those of the full lists (a cut list that runs out under an unsaturated pixel is flagged like a
         # pair-capacity overflow and the step is run again without the cut).  The hints live in the workspace; when the
         # view set changes they are parked per view set (max_cut_hints sets of 4 bytes per tile and view) and brought
-        # back when it returns -- a training run revisits its (frame, camera) pairs every epoch.  MANUS_DEPTH_CUT=0 in
-        # the environment switches it off for A/B runs.
+        # back when it returns -- a training run revisits its (frame, camera) pairs every epoch.  OFF by default: it pays only
+        # while the model stands still between two forwards of its views (fwd+bwd loops without an optimizer, evaluation
+        # sweeps); under a moving model it is a wash (DESIGN 5).  MANUS_DEPTH_CUT=0 in the environment forces it off.
         self.depth_cut = bool(depth_cut) and os.environ.get("MANUS_DEPTH_CUT", "1") != "0"
         self._cut_store, self._cut_max, self._cut_gen, self._cut_bit = {}, int(max_cut_hints), 0, 0
         # A flagged forward costs a whole step, and with the optimizer in the loop no margin prevents them all: a pixel whose
@@ -371,7 +386,8 @@ class HipViewCompute:
         self.sh_half, self._sh_copy, self._sh_dirty = sh_storage == "fp16", None, True
         self.ops, self.rz, self.fz, self.fused = ops, rasterizer, fused_mod, fused
         self.s = scene
-        self.targets = targets          # (V_all,3,H,W) on the GPU
+        self._cache, self._const_stamp = {}, None
+        self.targets = targets          # (V_all,3,H,W) on the GPU (a property: replacing it drops what was derived from it)
         self.cams = cam_table           # (V_all,40)
         self.loss_weight = loss_weight
         # "l1": mean|render - gt| (rgb_loss alone); "l1+ssim": w_rgb * rgb_loss + w_ssim * ssim_loss, the
@@ -391,8 +407,34 @@ class HipViewCompute:
         # operator).  A Trainer sets it False on ITS compute object: no host sync, the forward leaves an overflow fence
         # that Trainer._run_step polls.  (The device-wide policy of rasterizer.set_sync_policy is left alone.)
         self.sync_check = True
-        self._cache = {}
         self.grid = ops.SkinGrid(scene["grid"], scene["grid"].device) if self.is_hand else None
+
+    @property
+    def targets(self):
+        return self._targets
+
+    @targets.setter
+    def targets(self, t):
+        self._targets = t
+        self._drop_view_constants()
+
+    def _drop_view_constants(self):
+        """Forget everything derived from the per-view constants (targets, background, cameras, poses)."""
+        self._cache = {}
+        if hasattr(self, "_tmaps"):
+            self._tmaps.clear()
+        self._const_stamp = None
+
+    def _check_view_constants(self):
+        """The target maps and the per-view-set gathers are functions of `targets`, `s["bg"]`, `cams` and the transforms:
+        when one of those tensors was replaced or written in place (torch version counter) they are rebuilt."""
+        s = self.s
+        tfm = s.get("transforms") if self.is_hand else None
+        stamp = tuple((id(t), t._version) if t is not None else None for t in (self._targets, s.get("bg"), self.cams, tfm))
+        if stamp != self._const_stamp:
+            if self._const_stamp is not None:
+                self._drop_view_constants()
+            self._const_stamp = stamp
 
     def set_params(self, params, n_art=None):
         """Re-point at new leaf tensors (after densification / pruning changed N)."""
@@ -427,6 +469,7 @@ class HipViewCompute:
 
     def _select(self, view_ids):
         """Per-view constants for a set of views (cached: no per-step gather copies)."""
+        self._check_view_constants()
         key = tuple(view_ids)
         c = self._cache.get(key)
         if c is None:
@@ -517,6 +560,8 @@ class HipViewCompute:
                     t = torch.empty(per, dtype=torch.int32, device=self.device)
                     check(lib().mgr_image_loss_target_map(1, H, W, ptr(sel["targets"][k]), ptr(bg), ptr(t), stream()),
                           "mgr_image_loss_target_map")
+                    while len(self._tmaps) >= self.MAX_TARGET_MAPS:
+                        self._tmaps.pop(next(iter(self._tmaps)))
                     self._tmaps[v] = t
                 rows.append(t)
             m = sel["tmap"] = torch.stack(rows).contiguous()
@@ -544,13 +589,16 @@ class HipViewCompute:
         k = self._cut_scale
         lib().mgr_raster_set_cut_margin(min(4.0, 0.125 * k), int(64 * k), min(4.0, 0.0625 * k), 2.0e-4 * k, 1 if k > 1.0 else 0)
         born, self._cut_born[key] = self._cut_born.get(key), self._cut_clock
+        if len(self._cut_born) > 4 * self._cut_max:     # view sets not seen for cut_max_age updates have no usable hints
+            self._cut_born = {k_: b_ for k_, b_ in self._cut_born.items() if self._cut_clock - b_ <= self.cut_max_age}
         too_old = born is None or self._cut_clock - born > self.cut_max_age
         if prev != key:
             T = ((W + 15) // 16) * ((H + 15) // 16)
             off = self._layout(ws, V, N, W, H)[26]
             region = ws.buf[off: off + 4 * V * T]
             if prev is not None and prev[:2] == key[:2]:      # park the hints of the views rendered last
-                while len(self._cut_store) >= self._cut_max:
+                max_sets = max(1, min(self._cut_max, self.MAX_CUT_HINT_BYTES // max(1, region.numel())))
+                while len(self._cut_store) >= max_sets:
                     self._cut_store.pop(next(iter(self._cut_store)))
                 self._cut_store[prev] = region.clone()
             saved = self._cut_store.pop(key, None)
@@ -588,8 +636,12 @@ class HipViewCompute:
         if self.persistent_grads and not arena and self.fused:
             key = (N, na, str(dev))
             if self._pg is None or self._pg[0] != key:
-                self._pg, self._pg_ws, self._pimg_ws = (key, {}), None, None
+                self._pg, self._pg_ws, self._pimg_ws, self._pg_ver = (key, {}), None, None, {}
             own = self._pg[1]
+            # a kept buffer somebody wrote into since it was handed out (torch bumps a tensor's version counter on every
+            # in-place op, also through views) no longer holds what the row / tile bookkeeping says: fill everything again
+            if any(own[n]._version != ver for n, ver in self._pg_ver.items() if n in own):
+                self._pg_ws = self._pimg_ws = None
 
         def e(shape, name):
             if own is not None:
@@ -710,6 +762,7 @@ class HipViewCompute:
                   "mgr_views_backward")
             if own is not None:
                 self._pg_ws = ws
+                self._pg_ver = {n: t._version for n, t in own.items()}
             active = None
             if V <= 8 and N > 0:
                 # the backward's list of the Gaussians that received a gradient (device pointers: list, length)
@@ -729,6 +782,12 @@ class HipViewCompute:
                                                  ptr(s["grid_center"]), ptr(s["grid_scale"]), ptr(d_w), ptr(d_xyz), 1,
                                                  stream()), "mgr_skin_weights_bwd")
             overflow = ws.buf[4:8].view(torch.int32)
+        except BaseException:
+            # a call that failed between the loss's list and finish passes leaves the kept loss workspace with a non-zero
+            # span count (the finish pass is what resets it) and the kept buffers in an unknown state: start over
+            self._lws.pop((V, H, W), None)
+            self._pg_ws = self._pimg_ws = None
+            raise
         finally:
             ws.busy = False
         self.last_image, self.last_radii = out, radii
@@ -826,10 +885,11 @@ class Trainer:
         # sort_rows: after a densification / pruning has rebuilt the tensors, put the rows in Z-order of their positions
         # (GaussianOptimizer.sort_rows: the same model up to the permutation; every rank computes the same one)
         self.sort_rows = bool(sort_rows)
-        # persistent_grads (one rank): the compute object keeps the gradient buffers (HipViewCompute.persistent_grads): the
+        # persistent_grads (one rank): the compute object keeps the gradient buffers (HipViewCompute's own default): the
         # tensors in a step's `out["grads"]` are overwritten by the next step -- the optimizer has consumed them by then
-        if world_size == 1 and persistent_grads and hasattr(compute, "persistent_grads"):
-            compute.persistent_grads = True
+        # (see train_step).  False: fresh tensors every step.
+        if hasattr(compute, "persistent_grads"):
+            compute.persistent_grads = bool(persistent_grads) and world_size == 1
         self.compact_allreduce = compact_allreduce and not sharded_adam
         self.sharded_adam = bool(sharded_adam) and world_size > 1
         from . import rasterizer
@@ -855,9 +915,9 @@ class Trainer:
             compute.sync_check = False      # this trainer's forwards are fenced and polled in _run_step (no global policy flip)
         # depth_cut: a Trainer moves the model every step, and under a moving model the depth cut of the fused forward is a
         # wash at best (flagged forwards are run twice; measured 567 against 578 iters/s with its back-off): off
-        # unless asked for.  A compute object used without an optimizer (fwd+bwd loops, evaluation sweeps) keeps its own.
-        if hasattr(compute, "depth_cut") and not depth_cut:
-            compute.depth_cut = False
+        # -- HipViewCompute's own default -- unless asked for here.
+        if hasattr(compute, "depth_cut"):
+            compute.depth_cut = bool(depth_cut) and os.environ.get("MANUS_DEPTH_CUT", "1") != "0"
         self._rebuild_step()
 
     def _rebuild_step(self):
@@ -907,7 +967,12 @@ class Trainer:
 
     def train_step(self, views=None):
         """One optimisation step; returns the step's output dict (loss, statistics) plus "changed".
-        views: optional list of per-view dicts for the pruning tests (default: `compute.prune_views`)."""
+        views: optional list of per-view dicts for the pruning tests (default: `compute.prune_views`).
+
+        ALIASING: with kept buffers (the default at one rank) `out["grads"]`, `out["grad2d"]`, `out["vis"]` and
+        `compute.last_image` are the same storage every step, like `.grad` tensors -- they hold THIS step's values until the
+        next call; clone what is logged or compared across steps (or construct the Trainer with persistent_grads=False).
+        Writing into them is safe (HipViewCompute notices by the tensors' version counters and refills them in full)."""
         o, gs = self.opt.opts, self.global_step
         out = self._run_step()
         if not self.density_enabled:     # composite: render + reduce + Adam only (see __init__)
@@ -958,7 +1023,8 @@ class Trainer:
             self.density.on_train_epoch_start()
         resized = changed and (self.opt.N != n_before or self.opt.replaced == ALL_GROUPS)   # new leaf tensors
         if resized and self.sort_rows and self.opt.replaced == ALL_GROUPS:
-            out["row_perm"] = self.opt.sort_rows()
+            na = getattr(self.compute, "n_art", 0)
+            out["row_perm"] = self.opt.sort_rows(n_art=na if 0 < na < n_before and getattr(self.compute, "kind", "") == "composite" else None)
         # ---- on_before_optimizer_step + optimizer.step() ----
         self.opt.update_learning_rate(gs)
         if self.sharded_adam:

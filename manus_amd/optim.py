@@ -324,30 +324,49 @@ class GaussianOptimizer:
         return M
 
     # -- row order (no reference counterpart) --------------------------------------------------------------------------
-    def sort_rows(self):
+    def sort_rows(self, n_art=None):
         """Reorder the Gaussians along a Z-order curve of their canonical positions: leaves, both Adam moments, skin
         weights and the three statistics move together, so the model and its optimisation are the same up to the row
         permutation (returned, (N,) int64: new row r is old row perm[r]).  Meant for the moment densification has just
         rebuilt every tensor anyway: the rasterizer gathers 48-byte records of the Gaussians of a tile, and rows that
         are neighbours in space being neighbours in memory is worth ~3 % of the fused step on a shuffled 300 k model
-        ("Row order"; `bench.py --gaussian-order morton`).  The reference keeps whatever order initialisation,
-        cat() of clones / splits and boolean-mask pruning leave (gaussian.py:167-321)."""
+        (LAB.md, "Row order"; `bench.py --gaussian-order morton`).  The reference keeps whatever order initialisation,
+        cat() of clones / splits and boolean-mask pruning leave (gaussian.py:167-321).
+        n_art: a composite model keeps its articulated rows in front of the static ones (the fused kernels skin the
+        first n_art rows, and `skin_weights` has rows for those only): the two segments are sorted separately.  Default:
+        the rows `skin_weights` covers when it covers a prefix only, else one segment."""
+        N = self.N
+        if N == 0:
+            return torch.zeros(0, dtype=torch.long, device=self.device)
+        if n_art is None and self.skin_weights is not None and self.skin_weights.shape[0] < N:
+            n_art = int(self.skin_weights.shape[0])
+        n_art = N if n_art is None else int(n_art)
+        if not 0 <= n_art <= N:
+            raise ManusHipError("sort_rows: n_art must lie in [0, N]")
+        if self.skin_weights is not None and self.skin_weights.shape[0] not in (N, n_art):
+            raise ManusHipError("sort_rows: skin_weights covers %d rows, neither N nor n_art" % self.skin_weights.shape[0])
         xyz = self.p["_xyz"]
         lo, hi = xyz.min(0).values, xyz.max(0).values
         q = ((xyz - lo) / (hi - lo).clamp_min(1e-12) * 1023.0).long().clamp_(0, 1023)
-        code = torch.zeros(xyz.shape[0], dtype=torch.long, device=xyz.device)
+        code = torch.zeros(N, dtype=torch.long, device=xyz.device)
         for bit in range(10):
             for ax in range(3):
                 code |= ((q[:, ax] >> bit) & 1) << (3 * bit + ax)
+        if n_art < N:     # the static segment stays behind the articulated one
+            code += (torch.arange(N, device=xyz.device) >= n_art).long() << 31
         perm = torch.argsort(code, stable=True)
         take = lambda t: t.index_select(0, perm).contiguous()
         self.p = {a: take(t) for a, t in self.p.items()}
         self.m = {a: take(t) for a, t in self.m.items()}
         self.v = {a: take(t) for a, t in self.v.items()}
         if self.skin_weights is not None:
-            self.skin_weights = take(self.skin_weights)
+            self.skin_weights = take(self.skin_weights) if self.skin_weights.shape[0] == N else \
+                self.skin_weights.index_select(0, perm[:n_art]).contiguous()
         self.xyz_gradient_accum, self.denom, self.max_radii2D = take(self.xyz_gradient_accum), take(self.denom), take(self.max_radii2D)
         self.replaced = ALL_GROUPS
+        extra = getattr(self, "last_prune_extra", None)       # side arrays of the last prune follow their rows
+        if extra:
+            self.last_prune_extra = {k: (take(t) if t.shape[0] == N else t) for k, t in extra.items()}
         return perm
 
     # -- reset_opacity, gaussian.py:148-165 -----------------------------------------------------

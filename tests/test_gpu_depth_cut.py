@@ -144,7 +144,8 @@ def test_alternating_view_sets_keep_their_hints(fenced):
     a, b = [0, 1], [2, 3]
     ref = _compute(sc, targets, ct, cut=False)
     _warm(ref, a)
-    want_a, want_b = ref(a), ref(b)
+    from util import keep
+    want_a, want_b = keep(ref(a)), keep(ref(b))     # (one compute object: its outputs are kept buffers)
     full_b = _surviving_pairs(ref, 2, N, W, H)
     rasterizer.check_overflow(DEV)
     rasterizer.set_sync_policy(True, DEV)

@@ -126,7 +126,7 @@ def test_persistent_gradient_buffers_equal_fresh_ones(kind, views):
     sc, ct = _scene(kind, n=5000, views=views)
     tg = torch.rand((views, 3, 64, 96), device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))
     ids = list(range(views))
-    a = HipViewCompute(sc, tg, ct, fused=True, depth_cut=False)
+    a = HipViewCompute(sc, tg, ct, fused=True, depth_cut=False, persistent_grads=False)
     b = HipViewCompute(sc, tg, ct, fused=True, depth_cut=False, persistent_grads=True)
     c = HipViewCompute(sc, tg, ct, fused=True, depth_cut=False, persistent_grads=True)   # shares the pooled workspace with b
     gen = torch.Generator(device=DEV).manual_seed(7)
@@ -154,6 +154,53 @@ def test_persistent_gradient_buffers_equal_fresh_ones(kind, views):
         assert torch.equal(a.last_image, b.last_image), it     # (the image is kept too: tiles that stay empty are not written again)
         n_rows.append(int((oa["grads"]["_xyz"].abs().sum(1) != 0).sum()))
     assert len(set(n_rows)) > 1          # the set of rows with a gradient did change from step to step
+
+
+@pytest.mark.parametrize("kind,views", [("hand", 8), ("composite", 3)])
+def test_kept_buffers_survive_a_caller_writing_into_them(kind, views):
+    """The kept gradient / image buffers are handed out every step; the row- and tile-selective fills rest on their content
+    being what the previous step left.  A caller that writes into them (in place, through torch: also via views) is noticed
+    by the tensors' version counters and answered with a full fill: the next step is bit for bit the step of an object
+    with fresh buffers -- rows that get no gradient are zero again, empty tiles hold the background again."""
+    from manus_amd import rasterizer
+    from manus_amd.engine import HipViewCompute
+    from util import keep
+    sc, ct = _scene(kind, n=5000, views=views)
+    tg = torch.rand((views, 3, 64, 96), device=DEV, generator=torch.Generator(device=DEV).manual_seed(2))
+    ids = list(range(views))
+    fresh = HipViewCompute(sc, tg, ct, fused=True, loss="l1+ssim", persistent_grads=False)
+    want = keep(fresh(ids, 1.0 / views))
+    want_img = fresh.last_image.clone()
+    kept = HipViewCompute(sc, tg, ct, fused=True, loss="l1+ssim")        # the default: kept buffers
+    assert kept.persistent_grads and not kept.depth_cut
+    for mode in ("sync", "fenced"):
+        rasterizer.set_sync_policy(mode == "sync")
+        o = kept(ids, 1.0 / views)
+        o = kept(ids, 1.0 / views)                 # second step: the selective fills are in use
+        rasterizer.check_overflow()
+        assert kept._pg_ws is not None and kept._pimg_ws is not None
+        for k in want["grads"]:
+            assert torch.equal(o["grads"][k], want["grads"][k]), (mode, k)
+        assert torch.equal(kept.last_image, want_img)
+        # the caller scribbles over what it was handed: whole tensors, a view of one, the image
+        o["grads"]["_xyz"].add_(1.0)
+        o["grads"]["_features_rest"][:, 3].fill_(7.0)
+        o["grad2d"].fill_(5.0)
+        o["vis"].zero_()
+        kept.last_image.mul_(0.25)
+        o2 = kept(ids, 1.0 / views)
+        rasterizer.check_overflow()
+        for k in want["grads"]:
+            assert torch.equal(o2["grads"][k], want["grads"][k]), (mode, k)
+        assert torch.equal(o2["grad2d"], want["grad2d"]) and torch.equal(o2["vis"], want["vis"]) and torch.equal(o2["radii"], want["radii"])
+        assert torch.equal(kept.last_image, want_img), mode
+        o3 = kept(ids, 1.0 / views)                # and the selective fills resume on the refilled buffers
+        rasterizer.check_overflow()
+        assert kept._pg_ws is not None
+        for k in want["grads"]:
+            assert torch.equal(o3["grads"][k], want["grads"][k]), (mode, k)
+        assert torch.equal(kept.last_image, want_img), mode
+    rasterizer.set_sync_policy(True)
 
 
 # ---------------------------------------------------------------------------------------------------------------

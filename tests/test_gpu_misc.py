@@ -164,7 +164,8 @@ def test_engine_step_matches_sequential_reference_steps(loss):
     tg = torch.rand((4, 3, 64, 96), device=DEV)
     hc = HipViewCompute(sc, tg, ct, loss=loss)
     shapes = {k: v.shape for k, v in hc.params.items()}
-    full = ViewShardedStep(sc["N"], shapes, hc, 4).step()
+    from util import keep
+    full = keep(ViewShardedStep(sc["N"], shapes, hc, 4).step())     # (hc keeps its output buffers: the steps below reuse them)
     if loss == "l1+ssim":  # loss value = mean over views of 0.8 L1 + 0.2 (1 - ssim) of the oracle restatement
         with torch.no_grad():
             img = torch.cat([hc.forward_views([v])[0] for v in range(4)]).cpu()

@@ -199,6 +199,54 @@ def test_bench_runs_under_torch_distributed_run_with_two_ranks():
     assert set(d["config"]["allreduce"]["ms_per_step_by_mode"]) == {"dense", "compact"}
 
 
+def _run_bench(nproc, extra, timeout=1500):
+    import json
+    import subprocess
+    env = dict(os.environ, MANUS_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    if nproc > 1:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port())]
+    else:
+        cmd = [sys.executable]
+    cmd += [os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "3", "--warmup", "2", "--no-cpu-baseline"] + extra
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("name,extra,views", [
+    ("cfg3", ["--gaussians", "30000", "--views", "8", "--width", "480", "--height", "270"], 8),
+    ("cfg4", ["--kind", "composite", "--gaussians", "30000", "--views", "53", "--width", "480", "--height", "270"], 53)])
+def test_bench_eight_rank_dry_run(name, extra, views):
+    """The 8-rank shape of bench.py -- what the driver's SCALE run launches -- at a reduced size, eight gloo ranks sharing this
+    GPU: BASELINE config 3 (8 views -> one per rank, LPT over 8 ranks, the `auto` dense-vs-compact timing) and config 4
+    (53 cameras -> 7 / 6 per rank, composite).  One JSON line, n_gpus 8, the view assignment a partition of the views,
+    and the all-reduced gradients equal to the one-rank step's (same scene, same views: the sums differ by their order only)."""
+    d8 = _run_bench(8, extra)
+    assert d8["n_gpus"] == 8 and d8["steps"] == 3 and d8["value"] > 0 and d8["headline"] is False
+    c = d8["config"]
+    assert c["view_assignment"].startswith("balanced")
+    by_rank = c["views_by_rank"]
+    assert len(by_rank) == 8 and sorted(v for r in by_rank for v in r) == list(range(views))
+    sizes = sorted(len(r) for r in by_rank)
+    assert sizes[0] >= 1 and (views != 8 or sizes == [1] * 8), sizes      # (LPT balances cost, not counts: 53 views -> ~5..8 per rank)
+    assert c["allreduce"]["mode"] in ("dense", "compact") and set(c["allreduce"]["ms_per_step_by_mode"]) == {"dense", "compact"}
+    assert "predicted_ms" in c      # (None away from the 300 k / 1080p configuration)
+    d1 = _run_bench(1, extra + ["--no-hints-variant"])
+    assert d1["n_gpus"] == 1
+    g8, g1 = c["grad_digest"], d1["config"]["grad_digest"]
+    assert abs(g8["loss"] - g1["loss"]) < 1e-5 * max(1.0, abs(g1["loss"])), (g8["loss"], g1["loss"])
+    for k in g1:
+        if k == "loss":
+            continue
+        s8, a8 = g8[k]
+        s1, a1 = g1[k]
+        assert abs(a8 - a1) <= 2e-5 * a1 + 1e-12, (name, k, a8, a1)
+        assert abs(s8 - s1) <= 2e-5 * a1 + 1e-12, (name, k, s8, s1)
+
+
 _RCCL_ONE_RANK = r"""
 import os, sys
 sys.path.insert(0, sys.argv[1])

@@ -121,3 +121,42 @@ def test_adam_and_densify_match_oracle(n):
         np.testing.assert_array_equal(go.m[ATTR[k]].cpu().numpy(), want[k + "_m"].numpy())
     if info["total"]:
         np.testing.assert_array_equal(go.skin_weights.cpu().numpy(), want["skin"].numpy())
+
+
+def test_sort_rows_keeps_the_articulated_rows_in_front():
+    """GaussianOptimizer.sort_rows on a composite model (the first n_art rows are skinned, skin_weights has rows for those
+    only): each segment is sorted along the Z-order curve on its own, every array moves with its rows, and an empty
+    model returns an empty permutation."""
+    from manus_amd.optim import GaussianOptimizer
+    g = torch.Generator().manual_seed(4)
+    N, na = 3000, 1800
+    p = {"_xyz": torch.rand(N, 3, generator=g), "_features_dc": torch.rand(N, 1, 3, generator=g), "_features_rest": torch.rand(N, 15, 3, generator=g),
+         "_opacity": torch.rand(N, 1, generator=g), "_scaling": torch.rand(N, 3, generator=g), "_rotation": torch.rand(N, 4, generator=g)}
+    skin = torch.rand(na, 21, generator=g)
+    go = GaussianOptimizer({k: v.to(DEV) for k, v in p.items()}, skin_weights=skin.to(DEV))
+    go.m["_xyz"].copy_(p["_xyz"].to(DEV) * 2)
+    go.max_radii2D.copy_(torch.arange(N, dtype=torch.float32))
+    perm = go.sort_rows().cpu()                       # n_art from the rows skin_weights covers
+    assert sorted(perm.tolist()) == list(range(N))
+    assert bool((perm[:na] < na).all()) and bool((perm[na:] >= na).all())
+    for k in p:
+        assert torch.equal(go.p[k].cpu(), p[k][perm]), k
+    assert torch.equal(go.m["_xyz"].cpu(), p["_xyz"][perm] * 2)
+    assert torch.equal(go.skin_weights.cpu(), skin[perm[:na]])
+    assert torch.equal(go.max_radii2D.cpu(), perm.float())
+    assert go.replaced == frozenset(ATTR)
+    # along the curve: the codes of each segment ascend
+    def code(x):
+        lo, hi = p["_xyz"].min(0).values, p["_xyz"].max(0).values
+        q = ((x - lo) / (hi - lo).clamp_min(1e-12) * 1023.0).long().clamp_(0, 1023)
+        c = torch.zeros(x.shape[0], dtype=torch.long)
+        for bit in range(10):
+            for ax in range(3):
+                c |= ((q[:, ax] >> bit) & 1) << (3 * bit + ax)
+        return c
+    c = code(go.p["_xyz"].cpu())
+    assert bool((c[1:na] >= c[:na - 1]).all()) and bool((c[na + 1:] >= c[na:-1]).all())
+    with pytest.raises(Exception):
+        go.sort_rows(n_art=N + 1)
+    empty = GaussianOptimizer({k: v[:0].to(DEV) for k, v in p.items()})
+    assert empty.sort_rows().numel() == 0

@@ -404,3 +404,13 @@ def test_sequence_container_is_read_lazily_and_opened_once(golden_dir, tmp_path)
     assert D.open_sequence(p) is not a
     D.close_sequences()
     assert not D._STORES
+
+
+def test_predicted_ms_rides_in_the_multi_gpu_line():
+    """bench.predicted_ms (DESIGN 7's model) at the headline size: compute of views / rank + the dense exchange bounds."""
+    import bench
+    for n in (2, 4, 8):
+        p = bench.predicted_ms(n, 300000, 8, "hand", 1920, 1080)
+        assert (p["step_ms_low"] < p["step_ms_high"] or n == 2) and p["compute_ms"] == bench.COMPUTE_MS_BY_VIEWS[8 // n]
+    assert bench.predicted_ms(1, 300000, 8, "hand", 1920, 1080) is None
+    assert bench.predicted_ms(8, 30000, 8, "hand", 480, 270) is None

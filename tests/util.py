@@ -73,3 +73,12 @@ def t(a, device="cpu", grad=False):
     if grad:
         x = x.clone().requires_grad_(True)
     return x
+
+
+def keep(out):
+    """Deep copy of a step's output dict.  HipViewCompute keeps its gradient / statistics buffers by default (the tensors
+    of an output dict are the same storage every step, like .grad): what is compared across calls of ONE compute object
+    must be cloned first."""
+    import torch
+    return {k: ({n: g.clone() for n, g in v.items()} if isinstance(v, dict) else (v.clone() if torch.is_tensor(v) else v))
+            for k, v in out.items()}
