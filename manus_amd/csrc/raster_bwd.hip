@@ -98,6 +98,8 @@ __device__ __forceinline__ uint32_t mgr_any64(unsigned long long m) {
 #ifndef BWD_KO
 #define BWD_KO 0
 #endif
+// a volatile load that stays a ds_read (a volatile access through a generic pointer becomes a flat load)
+#define MGR_LDS_VOLATILE_F32 volatile const __attribute__((address_space(3))) float*
 #define BWD_ROW 288
 #define BWD_PLANE_W 64
 #define BWD_PLANE_B 128
@@ -213,9 +215,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BWD_WAVES, 
                     }
                 }
             }
-            uint32_t wlast = last;  // deepest contributor of this quadrant
+            // deepest contributor of this quadrant: the forward recorded exactly this maximum (tile_qdone -> the item record),
+            // so it is a scalar here -- not six cross-lane steps (ds_bpermute round trips) per quadrant visit
+#ifdef BWD_WLAST_REDUCE
+            uint32_t wlast = last;
 #pragma unroll
             for (int d = 32; d > 0; d >>= 1) wlast = max(wlast, (uint32_t)__shfl_xor((int)wlast, d, 64));
+#else
+            const uint32_t wlast = quad == 0 ? mxq[0] : quad == 1 ? mxq[1] : quad == 2 ? mxq[2] : mxq[3];
+#endif
             int bx0, by0, bx1, by1;
             if (!mgr_quad_bbox(__ballot(last > first), bx0, by0, bx1, by1)) continue;
             // dL/dpixel of this lane's phase-2 column (pixels (pc, 0..7) of the quadrant), through the exchange buffer
@@ -257,6 +265,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BWD_WAVES, 
             for (int p0 = 0; p0 < npair; p0 += 4) {
                 const int np = min(4, npair - p0);
                 uint32_t tmask = 0;   // bit 2r + h: entry h of exchange row r is valid at some pixel
+
                 // ---- phase 1: lane = pixel ----
                 for (int r = 0; r < np; ++r) {
                     const float4* pp = (const float4*)(slab + (p0 + r) * MGR_PAIR_FLOATS);
@@ -332,7 +341,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BWD_WAVES, 
                     const int prow = min(p0 + (e2 >> 1), npair - 1), h = e2 & 1;
                     const float* pbs = slab + prow * MGR_PAIR_FLOATS;
                     const float xe = pbs[0 + h], ye = pbs[2 + h];
-                    const uint32_t pos = __float_as_uint(pbs[18 + h]);
+                    // (the position picked up in phase 1 instead -- two selects per pair step there -- measured 0.361 against 0.356 ms)
+                    const uint32_t pos = __float_as_uint(*(MGR_LDS_VOLATILE_F32)(pbs + 18 + h));
                     const float dxc = xe - fx_col, dy0 = ye - qy0;
                     const float* src = xch + (e2 >> 1) * BWD_ROW + h * BWD_PLANE_B + 4 * pc;
 #if !(BWD_KO & 128)
@@ -340,9 +350,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BWD_WAVES, 
                     // The eight entries of a group are distinct list entries, so the 64 + 8 addresses of the step are distinct
                     // and the wave's own program order is all the ordering there is -- no LDS atomic (measured: the
                     // ds_add_f32 pair cost 0.05 of the kernel's 0.41 ms, knock-out BWD_KO=8)
+                    // (volatile: issued here, unconditionally, behind the slab reads -- as plain loads the compiler sinks them
+                    // into the conditional block at the end of the step, three dependent LDS round trips in a row)
                     const bool on2 = (tmask >> e2) & 1u;
                     float* const accp = acc + (on2 ? (int)((pos - 1u - first) & 63u) : 0) * 9;
-                    const float old_t = accp[pc], old_9 = accp[8];
+                    const float old_t = *(MGR_LDS_VOLATILE_F32)(accp + pc), old_9 = *(MGR_LDS_VOLATILE_F32)(accp + 8);
 #endif
                     mgr_v2f DY = {dy0, dy0 - 1.0f};
                     mgr_v2f B0 = {0.f, 0.f}, B1 = {0.f, 0.f}, B2 = {0.f, 0.f}, Cr = {0.f, 0.f}, Cg = {0.f, 0.f}, Cb = {0.f, 0.f};
