@@ -1,11 +1,11 @@
 #!/bin/bash
 # The other workloads of BASELINE.json through the same bench.py (not headline lines): 1 / 2 / 4 views per GPU of the hand
 # scene, the 500 k composite with 7 views, the 100 k object with one view.  Usage: tools/other_configs.sh [ROUND]
-RND=${1:-r04}
+RND=${1:-r05}
 OUT=profiles/${RND}_other_configs
 mkdir -p $OUT
-run() { name=$1; shift; python bench.py --steps 50 --warmup 5 --no-cpu-baseline "$@" > $OUT/$name.json 2>/dev/null
-        python bench.py --steps 30 --warmup 5 --no-cpu-baseline --profile-all "$@" 2>&1 >/dev/null | grep -v amdgpu.ids > $OUT/${name}_breakdown.txt
+run() { name=$1; shift; python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-hints-variant "$@" > $OUT/$name.json 2>/dev/null
+        python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-hints-variant --profile-all "$@" 2>&1 >/dev/null | grep -v amdgpu.ids > $OUT/${name}_breakdown.txt
         python -c "import json;d=json.load(open('$OUT/$name.json'));print('$name',d['value'],d['ms_per_step'])"; }
 run hand_v1 --views 1
 run hand_v2 --views 2
