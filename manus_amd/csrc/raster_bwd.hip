@@ -260,6 +260,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BWD_WAVES, 
                 if ((na & 1) && rank == na - 1) mgr_pair_pad(pb);
             }
             const int npair = (BWD_KO & 4) ? ((na + 1) >> 1) * 57 / 100 : (na + 1) >> 1;
+#ifdef MGR_STATS
+            // what finer pixel blocks could save (tools/instr/blend_stats.py): the quadrant's active pixels, and per 4x4 block the
+            // entries with a valid pixel in it -- a wave with one entry list per block would run max_b ceil(n_b / 2) pair steps
+            MGR_STAT(8, (unsigned long long)npair * __popcll(__ballot(last > first)));
+            MGR_STAT(9, npair);
+            uint32_t nblk_[4] = {0u, 0u, 0u, 0u};
+#endif
             BP(2);
 #pragma unroll 1
             for (int p0 = 0; p0 < npair; p0 += 4) {
@@ -295,6 +302,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BWD_WAVES, 
                     MGR_STAT(2, 1);                                                    // pair iterations
                     MGR_STAT(3, __popcll(__ballot(va)) + __popcll(__ballot(vb)));      // valid (entry, pixel) evaluations
                     MGR_STAT(4, anya + anyb);                      // entries with any valid pixel
+#ifdef MGR_STATS
+                    {
+                        const unsigned long long bm_[4] = {0x0F0F0F0Full, 0xF0F0F0F0ull, 0x0F0F0F0Full << 32, 0xF0F0F0F0ull << 32};
+                        uint32_t nb_ = 0;
+                        for (int b_ = 0; b_ < 4; ++b_) {
+                            const uint32_t ha_ = (ma & bm_[b_]) != 0ull, hb_ = (mb & bm_[b_]) != 0ull;
+                            nblk_[b_] += ha_ + hb_;
+                            nb_ += ha_ + hb_;
+                        }
+                        MGR_STAT(6, nb_);                          // (entry, 4x4 block) combinations with a valid pixel
+                    }
+#endif
                     if ((ma | mb) == 0ull) continue;
                     MGR_STAT(5, 1);                                                    // pair iterations doing the full math
                     tmask |= (anya | (anyb << 1)) << (2 * r);
@@ -407,6 +426,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BWD_WAVES, 
                 }
                 __builtin_amdgcn_wave_barrier();
             }
+#ifdef MGR_STATS
+            MGR_STAT(10, (max(max(nblk_[0], nblk_[1]), max(nblk_[2], nblk_[3])) + 1u) >> 1);
+            MGR_STAT(11, (nblk_[0] + nblk_[1] + nblk_[2] + nblk_[3] + 7u) >> 3);     // perfectly balanced over the four blocks
+#endif
             BP(3);
         }
         // ---- flush: lane j = entry j ----

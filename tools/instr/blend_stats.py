@@ -17,8 +17,12 @@ hc(ids, 1.0/V); torch.cuda.synchronize()
 fn(z); d=[a-b for a,b in zip(z,base)]
 print("box tests", d[0], "survivors", d[1], "pair iters", d[2], "valid lane evals", d[3], "entries w/ any", d[4], "full pair iters", d[5])
 print("survivor rate %.3f; lane utilisation over executed pair iters: %.3f; entries with a valid pixel %.3f of the evaluated; valid pixels per such entry %.1f" % (d[1]/d[0], d[3]/(d[2]*128), d[4]/(2*d[2]), d[3]/d[4]))
-if d[6] and d[7]:   # (only builds that still count 4x4 blocks / 8x2 strips)
-    print("4x4 blocks w/ any %d (util %.3f), 8x2 strips w/ any %d (util %.3f)" % (d[6], d[3]/(d[6]*16), d[7], d[3]/(d[7]*16)))
+if d[6]:
+    print("(entry, 4x4 block) combinations with a valid pixel %d: lane utilisation at block granularity %.3f" % (d[6], d[3] / (d[6] * 16)))
+if d[9]:
+    print("active pixels (last > first) of the visited quadrants, weighted by their pair steps: %.3f of the lanes; valid / active %.3f" % (d[8] / (d[9] * 64), d[3] / (2 * d[8])))
+    print("pair steps now %d; with one entry list per 4x4 block (validity-exact lists): max over the blocks %d (%.3f), perfectly balanced %d (%.3f)"
+          % (d[9], d[10], d[10] / d[9], d[11], d[11] / d[9]))
 # tile statistics
 ws = rz.context().last_ws
 arr=(ctypes.c_size_t*32)(); L.mgr_raster_layout(V,N,W,H,ws.cap,arr,32)
