@@ -362,6 +362,9 @@ def dropin_main(args):
     for _ in range(max(1, args.warmup)):
         loss = one_step()
     torch.cuda.synchronize()
+    if args.dropin_fenced:
+        rasterizer.check_overflow()
+        rasterizer.set_sync_policy(False)
     dts = []
     _lib.profile_enable(False)
     for _ in range(REPEATS):
@@ -372,6 +375,8 @@ def dropin_main(args):
         torch.cuda.synchronize()
         dts.append(time.perf_counter() - t0)
     dt = float(np.median(dts))
+    if args.dropin_fenced:
+        rasterizer.check_overflow()      # (raises if a forward of the timed loops ran out of pair capacity)
     # per-kernel breakdown of the library launches (HIP events around each: slows the step, taken in a separate loop)
     _lib.profile_enable(True, only=None)
     for _ in range(args.steps):
@@ -397,7 +402,7 @@ def dropin_main(args):
             "config": {"workload": "%s, %d Gaussians, ONE view per step (cycling over %d cameras) at %dx%d, modules.hand_forward + "
                                    "render.render_gaussians + losses (0.8 L1 + 0.2 (1 - SSIM)) under torch autograd" % (args.kind, N, V, W, H),
                        "route": "dropin", "gaussians": N, "views_per_step": 1, "width": W, "height": H,
-                       "host_syncs_per_step": 1, "library_kernel_ms_per_step": round(lib_ms, 4),
+                       "host_syncs_per_step": 0 if args.dropin_fenced else 1, "library_kernel_ms_per_step": round(lib_ms, 4),
                        "dominant_library_kernel": dom, "dominant_kernel_ms": round(prof[dom][1] / prof[dom][0], 4) if dom else None,
                        "finite_grads": finite, "loss": float(loss.detach())},
             "roofline": None, "cpu_baseline": None, "parity": None}
@@ -445,6 +450,9 @@ def main():
                          "binning; exact).  Off by default, like engine.Trainer: it only pays while the model stands still "
                          "between steps.  The default line reports the hinted figure as `value_with_hints`")
     ap.add_argument("--no-depth-cut", action="store_true", help="(the default since round 5; accepted for old scripts)")
+    ap.add_argument("--dropin-fenced", action="store_true",
+                    help="--route dropin with rasterizer.set_sync_policy(False): the one line a MANUS user can add -- no blocking read of the "
+                         "pair count per forward (the capacity learnt during warm-up is used; overflows are reported by rasterizer.poll())")
     ap.add_argument("--no-hints-variant", action="store_true", help="skip the extra timed region with the depth-cut hints on")
     ap.add_argument("--route", default="fused", choices=["fused", "dropin"],
                     help="dropin: what an unmodified MANUS gets with only PYTHONPATH set -- one (frame, view) per step through "

@@ -467,6 +467,12 @@ int mgr_adam_step_groups(int n_groups, const int64_t* counts, float* const* para
                          float* const* exp_avg, float* const* exp_avg_sq, const double* lrs, const int64_t* steps,
                          double beta1, double beta2, double eps, void* stream);
 int mgr_reset_opacity(int N, float* opacity_logit, float* exp_avg, float* exp_avg_sq, void* stream);
+/* add_densification_stats, gaussian.py:335-338 (xyz_gradient_accum += the step's sum over views of ||dL/dmeans2D[:, :2]||,
+ * denom += the number of views that saw the Gaussian) and the max_radii2D update of density_update,
+ * gaussian_utils.py:470-473 (max_radii2D = max(max_radii2D, radii)), in one launch.  grad2d_sum / vis_count: (N,) fp32,
+ * radii_max: (N,) int32 -- the statistics outputs of mgr_views_backward; the three accumulators (N,) fp32, in place. */
+int mgr_add_densification_stats(int N, const float* grad2d_sum, const float* vis_count, const int32_t* radii_max,
+                                float* xyz_gradient_accum, float* denom, float* max_radii2D, void* stream);
 size_t mgr_densify_workspace_bytes(int N);
 int mgr_densify_plan(int N, const float* grad_accum, const float* denom, const float* log_scale,
                      const float* opacity_logit, float max_grad, float min_opacity, float extent, float percent_dense,

@@ -82,6 +82,7 @@ SIGNATURES = {
     "mgr_adam_step": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, ctypes.c_double, ctypes.c_double,
                                ctypes.c_double, c_vp]),
     "mgr_reset_opacity": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp]),
+    "mgr_add_densification_stats": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "mgr_densify_workspace_bytes": (c_sz, [c_int]),
     "mgr_densify_plan": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_f32, c_f32, c_vp, c_sz, c_vp, c_vp]),
     "mgr_adam_step_groups": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_double, ctypes.c_double,

@@ -462,10 +462,22 @@ __global__ __launch_bounds__(1024) void k_image_loss_fold(int64_t n, const float
                                                           uint32_t* __restrict__ work_count) {
     __shared__ double s_a[16], s_b[16];
     double a = 0.0, b = 0.0;
-    for (int64_t k = threadIdx.x; k < n; k += 1024) {
-        const float2 p = partial[k];
-        a += (double)p.x;
-        b += (double)p.y;
+    // eight loads in flight per thread, added in index order (the same sums bit for bit as one load per turn, whose 34
+    // dependent round trips were the kernel's 14 us)
+    for (int64_t k0 = threadIdx.x; k0 < n; k0 += 8 * 1024) {
+        float2 p[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t k = k0 + (int64_t)j * 1024;
+            p[j] = k < n ? partial[k] : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (k0 + (int64_t)j * 1024 < n) {
+                a += (double)p[j].x;
+                b += (double)p[j].y;
+            }
+        }
     }
 #pragma unroll
     for (int dlt = 32; dlt > 0; dlt >>= 1) {

@@ -151,6 +151,32 @@ extern "C" int mgr_adam_step(int n_groups, const int64_t* counts, float* const* 
 }
 
 // ---------------------------------------------------------------------------
+// add_densification_stats (+ the max_radii2D update of density_update): one launch for the three read-modify-writes
+// the reference does with four torch ops per step (gaussian.py:335-338, gaussian_utils.py:470-473)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_dens_stats(int N, const float* __restrict__ g2, const float* __restrict__ vis,
+                                                    const int32_t* __restrict__ radii, float* __restrict__ accum,
+                                                    float* __restrict__ denom, float* __restrict__ maxr) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    accum[i] += g2[i];
+    denom[i] += vis[i];
+    maxr[i] = fmaxf(maxr[i], (float)radii[i]);    // (torch.maximum propagates NaN; neither side is ever NaN here)
+}
+
+extern "C" int mgr_add_densification_stats(int N, const float* grad2d_sum, const float* vis_count, const int32_t* radii_max,
+                                           float* xyz_gradient_accum, float* denom, float* max_radii2D, void* stream_) {
+    if (N < 0) return mgr_fail(MGR_EINVAL, "mgr_add_densification_stats: bad size");
+    if (N == 0) return MGR_OK;
+    if (!grad2d_sum || !vis_count || !radii_max || !xyz_gradient_accum || !denom || !max_radii2D)
+        return mgr_fail(MGR_EINVAL, "mgr_add_densification_stats: null pointer");
+    hipStream_t stream = (hipStream_t)stream_;
+    { MGR_PROF("k_dens_stats", stream); hipLaunchKernelGGL(k_dens_stats, dim3((N + 255) / 256), dim3(256), 0, stream, N, grad2d_sum, vis_count, radii_max, xyz_gradient_accum, denom, max_radii2D); }
+    MGR_LAUNCH_CHECK("k_dens_stats", stream, 0);
+    return MGR_OK;
+}
+
+// ---------------------------------------------------------------------------
 // reset_opacity: opacity <- inverse_sigmoid(min(sigmoid(opacity), 0.01)); moments zeroed
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_reset_opacity(int N, float* __restrict__ op, float* __restrict__ m,

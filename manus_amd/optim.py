@@ -223,9 +223,20 @@ class GaussianOptimizer:
     def add_densification_stats(self, grad2d_sum, vis_count, radii_max):
         """Accumulate the statistics of one multi-view step (`fused.ViewStats` / `ViewShardedStep` outputs):
         sum over views of ||dL/dmeans2D[:, :2]||, number of views that saw the Gaussian, max screen radius."""
-        self.xyz_gradient_accum += grad2d_sum.reshape(-1, 1)
-        self.denom += vis_count.reshape(-1, 1).to(torch.float32)
-        self.max_radii2D = torch.maximum(self.max_radii2D, radii_max.to(torch.float32))
+        N = self.N
+        if N == 0:
+            return
+        g2, vis = f32c(grad2d_sum).reshape(-1), f32c(vis_count).reshape(-1)
+        rad = radii_max.reshape(-1)
+        rad = (rad if rad.dtype == torch.int32 else rad.to(torch.int32)).contiguous()
+        for name in ("xyz_gradient_accum", "denom", "max_radii2D"):      # (a caller may have assigned its own tensors)
+            t = getattr(self, name)
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                setattr(self, name, f32c(t))
+        if g2.numel() != N or vis.numel() != N or rad.numel() != N:
+            raise ManusHipError("add_densification_stats: statistics must have %d entries" % N)
+        check(lib().mgr_add_densification_stats(N, ptr(g2), ptr(vis), ptr(rad), ptr(self.xyz_gradient_accum), ptr(self.denom),
+                                                ptr(self.max_radii2D), stream()), "mgr_add_densification_stats")
 
     # -- densify_and_prune, gaussian.py:310-333 ------------------------------------------------
     def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size=None, remove_outliers=False, noise=None,

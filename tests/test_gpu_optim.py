@@ -160,3 +160,26 @@ def test_sort_rows_keeps_the_articulated_rows_in_front():
         go.sort_rows(n_art=N + 1)
     empty = GaussianOptimizer({k: v[:0].to(DEV) for k, v in p.items()})
     assert empty.sort_rows().numel() == 0
+
+
+def test_add_densification_stats_kernel():
+    """mgr_add_densification_stats = the reference's three updates (gaussian.py:335-338, gaussian_utils.py:470-473) in one
+    launch: exactly the torch expressions, for the dtypes the step hands over and for others."""
+    from manus_amd.optim import GaussianOptimizer
+    g = torch.Generator().manual_seed(9)
+    N = 5003
+    p = {"_xyz": torch.rand(N, 3, generator=g), "_features_dc": torch.rand(N, 1, 3, generator=g), "_features_rest": torch.rand(N, 15, 3, generator=g),
+         "_opacity": torch.rand(N, 1, generator=g), "_scaling": torch.rand(N, 3, generator=g), "_rotation": torch.rand(N, 4, generator=g)}
+    go = GaussianOptimizer({k: v.to(DEV) for k, v in p.items()})
+    acc, den, mx = torch.zeros(N, 1), torch.zeros(N, 1), torch.zeros(N)
+    for it in range(3):
+        g2 = torch.rand(N, generator=g) * (torch.rand(N, generator=g) < 0.4)
+        vis = torch.randint(0, 9, (N,), generator=g).float()
+        rad = torch.randint(0, 60, (N,), generator=g).to(torch.int32)
+        acc += g2.reshape(-1, 1); den += vis.reshape(-1, 1); mx = torch.maximum(mx, rad.float())
+        if it == 1:      # other dtypes / shapes are converted, not misread
+            go.add_densification_stats(g2.double().to(DEV).reshape(-1, 1), vis.to(torch.int64).to(DEV), rad.float().to(DEV))
+        else:
+            go.add_densification_stats(g2.to(DEV), vis.to(DEV), rad.to(DEV))
+    assert torch.equal(go.xyz_gradient_accum.cpu(), acc) and torch.equal(go.denom.cpu(), den) and torch.equal(go.max_radii2D.cpu(), mx)
+    assert go.xyz_gradient_accum.shape == (N, 1) and go.max_radii2D.shape == (N,)
