@@ -5,6 +5,10 @@
 reference obtains from OpenCV, `cv2.getOptimalNewCameraMatrix(intr, dist, (w, h), alpha=0, centerPrincipalPoint=True)`
 (params.py:95-99): the published algorithm of OpenCV 4.x `calib3d` (getOptimalNewCameraMatrix -> icvGetRectangles ->
 undistortPoints with its five fixed-point iterations) for the 4-coefficient model (k1, k2, p1, p2) params.py passes.
+Which OpenCV: the reference installs an unpinned `opencv-python` (setup_env.sh:20), i.e. a current 4.x, whose
+icvGetRectangles samples the border grid at x (w - 1) / (n - 1), y (h - 1) / (n - 1) (pixel centres 0 .. w - 1); releases
+before the 3.4.14 / 4.5.2 fix sampled x w / (n - 1).  The current form is the default here, `legacy_grid=True` gives
+the older one (the two differ by a fraction of a pixel in the rectangles, ~1e-3 relative in the focal lengths).
 
 PARITY UNPINNED: OpenCV is not in this image, params.py cannot be imported without it, and the reference ships no
 calibration file or expected values for this leg; tests/test_host_logic.py checks the restatement against closed forms
@@ -61,12 +65,13 @@ def undistort_points(pts, intr, dist, new_intr, iters=5):
     return np.stack([x * new_intr[0, 0] + new_intr[0, 2], y * new_intr[1, 1] + new_intr[1, 2]], -1)
 
 
-def _rectangles(intr, dist, size, n=9):
+def _rectangles(intr, dist, size, n=9, legacy_grid=False):
     """icvGetRectangles: the border grid of n x n points undistorted with the same matrix; the largest inscribed and
     the bounding rectangle (x, y, w, h) of the result.  Grid and results in float32 like OpenCV's CV_32FC2 buffer."""
     w, h = size
-    gx = (np.arange(n, dtype=np.float32) * np.float32(w) / np.float32(n - 1))
-    gy = (np.arange(n, dtype=np.float32) * np.float32(h) / np.float32(n - 1))
+    ex, ey = (w, h) if legacy_grid else (w - 1, h - 1)
+    gx = (np.arange(n, dtype=np.float32) * np.float32(ex) / np.float32(n - 1))
+    gy = (np.arange(n, dtype=np.float32) * np.float32(ey) / np.float32(n - 1))
     grid = np.stack(np.meshgrid(gx, gy, indexing="xy"), -1).reshape(-1, 2)       # row-major: y outer, x inner
     p = undistort_points(grid, intr, dist, intr).astype(np.float32).reshape(n, n, 2)
     ix0, ix1 = p[:, 0, 0].max(), p[:, n - 1, 0].min()
@@ -75,7 +80,7 @@ def _rectangles(intr, dist, size, n=9):
     return (ix0, iy0, ix1 - ix0, iy1 - iy0), (ox0, oy0, ox1 - ox0, oy1 - oy0)
 
 
-def optimal_new_camera_matrix(intr, dist, size, alpha=0.0):
+def optimal_new_camera_matrix(intr, dist, size, alpha=0.0, legacy_grid=False):
     """cv2.getOptimalNewCameraMatrix(intr, dist, size, alpha, centerPrincipalPoint=True) -> (new_intr, roi): the
     principal point moves to the image centre ((w - 1) / 2, (h - 1) / 2) and both focal lengths are scaled by
     s = s0 (1 - alpha) + s1 alpha, s0 / s1 the scales at which the inscribed / the bounding rectangle of the undistorted
@@ -84,7 +89,7 @@ def optimal_new_camera_matrix(intr, dist, size, alpha=0.0):
     m = np.array(intr, dtype=np.float64)
     cx0, cy0 = m[0, 2], m[1, 2]
     cx, cy = (w - 1) * 0.5, (h - 1) * 0.5
-    (ix, iy, iw, ih), (ox, oy, ow, oh) = [tuple(float(v) for v in r) for r in _rectangles(m, dist, size)]
+    (ix, iy, iw, ih), (ox, oy, ow, oh) = [tuple(float(v) for v in r) for r in _rectangles(m, dist, size, legacy_grid=legacy_grid)]
     s0 = max(cx / (cx0 - ix), cy / (cy0 - iy), cx / (ix + iw - cx0), cy / (iy + ih - cy0))
     s1 = min(cx / (cx0 - ox), cy / (cy0 - oy), cx / (ox + ow - cx0), cy / (oy + oh - cy0))
     s = s0 * (1.0 - alpha) + s1 * alpha

@@ -94,7 +94,9 @@ __device__ __forceinline__ uint32_t mgr_any64(unsigned long long m) {
 // BWD_KO (instrumentation only, WRONG RESULTS: cost bounds for experiments, tools/instr/ko_bwd.sh): bit 1 skips phase 2, bit 2 also
 // phase 1's exchange stores, bit 4 runs 57 % of the pair steps (what 4x4-pixel boxes would leave: 35.5 % -> 62 % contributing lanes),
 // bit 8 replaces phase 2's LDS atomics by plain stores, bit 16 skips phase 1's arithmetic behind the alpha evaluation,
-// bit 32 reads ONE pair record line instead of five, bit 64 reads the five lines twice, bit 128 = the LDS atomics of rounds 3-4
+// bit 32 reads ONE pair record line instead of five, bit 64 reads the five lines twice, bit 128 = the LDS atomics of rounds 3-4,
+// bit 256 leaves the flush's stores out, bit 512 the per-quadrant pixel-state loads (constants instead), bit 1024 the entry gathers of
+// the item prologue (one record for all lanes)
 #ifndef BWD_KO
 #define BWD_KO 0
 #endif
@@ -153,7 +155,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BWD_WAVES, 
 #endif
         BP(0);
         // lane j: entry j of the chunk (clamped index: the loads are unconditional, the results masked)
+#if BWD_KO & 1024
+        const uint32_t gid = sorted_gid[recA.z] + 0u * (uint32_t)lane;
+#else
         const uint32_t gid = sorted_gid[recA.z + (uint32_t)min(lane, cnt - 1)];
+#endif
         float4 ra, rb, rcz;   // (x, y, conic A, B | conic C, opacity, colour r, g | colour b, slot base, rect width, -)
         {
             const MgrGRec* r = gv + gid;
@@ -181,12 +187,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BWD_WAVES, 
             const int px = bx * 16 + (quad & 1) * 8 + (lane & 7);
             const int py = by * 16 + (quad >> 1) * 8 + (lane >> 3);
             const size_t pixc = (size_t)min(py, H - 1) * W + min(px, W - 1);
+#if BWD_KO & 512
+            q.nc = tmax; q.t0 = 0.001f * (float)pixc; q.t1 = 0.5f; q.t2 = 0.25f; q.o0 = 0.3f; q.o1 = 0.2f; q.o2 = 0.1f;
+            q.ck = make_float4(0.1f, 0.1f, 0.1f, 0.5f);
+#else
             q.nc = n_contrib[(size_t)v * P + pixc];
             const float* gp = dL_dpix + (size_t)v * 3 * P + pixc;
             const float* op = out_color + (size_t)v * 3 * P + pixc;
             q.t0 = gp[0]; q.t1 = gp[P]; q.t2 = gp[2 * P];
             q.o0 = op[0]; q.o1 = op[P]; q.o2 = op[2 * P];
             q.ck = ckpt[(size_t)recA.w * 256 + ((quad << 6) | lane)];
+#endif
         };
         PxState pxn;
         load_px(qmask ? __builtin_ctz(qmask) : 0, pxn);
@@ -445,12 +456,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BWD_WAVES, 
             const float cA = ra.z, cB = ra.w, cC = rb.x;
             const float mx = (-0.5f * (float)W) * (cA * r[0] + cB * r[1]);
             const float my = (-0.5f * (float)H) * (cC * r[1] + cB * r[0]);
+#if BWD_KO & 256
+            if (mx + my + r[2] + r[3] + r[4] + r[5] + r[6] + r[7] + r[8] == 12345.678f) pair_tag[slot] = epoch;
+#else
             float4* o = pair_grad + (size_t)slot * 3;
             o[0] = make_float4(mx, my, -0.5f * r[2], -0.5f * r[3]);
             o[1] = make_float4(-0.5f * r[4], r[5], r[6], r[7]);
             o[2] = make_float4(r[8], 0.f, 0.f, 0.f);
             pair_tag[slot] = epoch;
             inst_tag[(size_t)v * N + gid] = epoch;  // "this (view, Gaussian) has records": lets the gather skip the rest
+#endif
         }
         __builtin_amdgcn_wave_barrier();
         BP(5);

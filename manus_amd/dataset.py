@@ -525,7 +525,7 @@ def convert_armature_space_to_world_space(md):
 def _load_table(path, size=None):
     """A camera-path / skeleton table: the reference's joblib pickle, the same dict as one `.npz`, or -- cameras only,
     `size` = (width, height) -- a calibration `.txt` (brics_dynamic.py:513-531; manus_amd/calib.py, parity unpinned)."""
-    if path.endswith(".txt") and size is not None:
+    if ".txt" in path and size is not None:      # (the reference's own test, brics_dynamic.py:512)
         from .calib import camera_table_from_calibration
         return camera_table_from_calibration(path, size[0], size[1])
     if path.endswith(".npz"):

@@ -195,8 +195,11 @@ def test_calibration_file_cameras(golden_dir, tmp_path):
     np.testing.assert_allclose(calib.undistort_points(pts, K, np.zeros(4), K), pts, atol=1e-9)
     new, roi = calib.optimal_new_camera_matrix(K, np.zeros(4), (w, h), alpha=0.0)
     cx, cy = (w - 1) / 2, (h - 1) / 2
-    s = max(cx / 600.0, cy / 380.0, cx / (w - 600.0), cy / (h - 380.0))
+    s = max(cx / 600.0, cy / 380.0, cx / (w - 1 - 600.0), cy / (h - 1 - 380.0))     # grid over the pixel centres 0 .. w - 1 (current OpenCV)
     np.testing.assert_allclose([new[0, 0], new[1, 1], new[0, 2], new[1, 2]], [900.0 * s, 910.0 * s, cx, cy], rtol=1e-6)
+    old, _ = calib.optimal_new_camera_matrix(K, np.zeros(4), (w, h), alpha=0.0, legacy_grid=True)    # releases before 4.5.2: 0 .. w
+    s_old = max(cx / 600.0, cy / 380.0, cx / (w - 600.0), cy / (h - 380.0))
+    np.testing.assert_allclose([old[0, 0], old[1, 1]], [900.0 * s_old, 910.0 * s_old], rtol=1e-6)
     assert roi[0] >= 0 and roi[1] >= 0 and roi[0] + roi[2] <= w and roi[1] + roi[3] <= h
     # radial + tangential distortion: the fixed-point iteration inverts the forward model
     d = np.array([-0.12, 0.04, 1.5e-3, -8e-4])
