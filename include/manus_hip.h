@@ -326,6 +326,19 @@ int mgr_sh_color_bwd(int V, int N, const float* sh, const float* xyz, int64_t st
                      const float* dL_dcolors, float* dL_dsh, float* dL_dxyz, float* dL_dtf,
                      void* stream);
 
+/* Host glue of the reference-shaped route, one launch each (no reference kernel counterpart: the reference does both with
+ * a dozen small torch ops per step).
+ * mgr_pack_camera: the (MGR_CAM_FLOATS = 40)-float camera row every kernel here reads, from the fields of
+ *   GaussianRasterizationSettings (src/utils/gaussian_utils.py:378-391): [tanfovx, tanfovy, viewmatrix 16, projmatrix 16,
+ *   campos 3, 0 0 0]; the matrices as the reference stores them (row-major of the transposed = column-major float[16],
+ *   SURVEY App. A).  view16 / proj16 / campos3 are DEVICE pointers and may be NULL (zeros); the scalars travel as kernel
+ *   arguments, so no host-to-device copy is made.
+ * mgr_bone_transforms: T_b = posed_b @ inv(rest_b) for B bones (4x4 row-major each), + one identity row when
+ *   `background` (src/modules/hand_dynamic.py:93-102); out (B + background, 4, 4). */
+int mgr_pack_camera(float tanfovx, float tanfovy, const float* view16, const float* proj16, const float* campos3,
+                    float* out40, void* stream);
+int mgr_bone_transforms(int B, int background, const float* posed, const float* rest, float* out, void* stream);
+
 /* uv = (K*E*[x;1])[:2]/z for N points; K (3,3), E (3,4) row-major. */
 int mgr_project_points(int N, const float* xyz, const float* K9, const float* E12, float* uv,
                        void* stream);

@@ -56,6 +56,8 @@ SIGNATURES = {
     "mgr_sh_color_fwd": (c_int, [c_int, c_int, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "mgr_sh_color_bwd": (c_int, [c_int, c_int, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp,
                                  c_vp]),
+    "mgr_pack_camera": (c_int, [c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "mgr_bone_transforms": (c_int, [c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "mgr_project_points": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "mgr_dilate_mask": (c_int, [c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "mgr_points_outside_mask": (c_int, [c_int, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_vp]),
@@ -178,6 +180,19 @@ def pack_cameras(tanfovx, tanfovy, viewmatrix, projmatrix, campos, device):
     Lists give V > 1.  No host synchronisation."""
     if not isinstance(viewmatrix, (list, tuple)):
         tanfovx, tanfovy, viewmatrix, projmatrix, campos = [tanfovx], [tanfovy], [viewmatrix], [projmatrix], [campos]
+    dev = torch.device(device)
+
+    def on_dev(t, n):
+        return torch.is_tensor(t) and t.is_cuda and (dev.index is None or t.device.index == dev.index) and t.dtype == torch.float32 \
+            and t.is_contiguous() and t.numel() >= n
+
+    if dev.type == "cuda" and all(on_dev(v, 16) and on_dev(p, 16) and on_dev(c, 3) for v, p, c in zip(viewmatrix, projmatrix, campos)):
+        # tensors already on the device (the reference's batch is): one launch per camera, the two tangents as kernel
+        # arguments -- no host-to-device copy, no cat
+        out = torch.empty((len(viewmatrix), MGR_CAM_FLOATS), dtype=torch.float32, device=viewmatrix[0].device)
+        for k, (tx, ty, vm, pm, cp) in enumerate(zip(tanfovx, tanfovy, viewmatrix, projmatrix, campos)):
+            check(lib().mgr_pack_camera(float(tx), float(ty), ptr(vm), ptr(pm), ptr(cp), out[k].data_ptr(), stream()), "mgr_pack_camera")
+        return out
     rows = []
     for tx, ty, vm, pm, cp in zip(tanfovx, tanfovy, viewmatrix, projmatrix, campos):
         head = torch.tensor([float(tx), float(ty)], dtype=torch.float32, device=device)

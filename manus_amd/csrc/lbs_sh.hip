@@ -720,6 +720,101 @@ extern "C" int mgr_sh_color_bwd(int V, int N, const float* sh, const float* xyz,
     return MGR_OK;
 }
 
+// ---------------------------------------------------------------------------
+// Host-glue kernels of the reference-shaped route: what render_gaussians / TrainingModule.forward do with a dozen tiny
+// torch launches each per step (camera table from the settings tuple; posed @ inv(rest) of the bone transforms).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_pack_camera(float tfx, float tfy, const float* __restrict__ view,
+                                                    const float* __restrict__ proj, const float* __restrict__ campos,
+                                                    float* __restrict__ out) {
+    const int t = threadIdx.x;
+    if (t >= MGR_CAM_FLOATS) return;
+    float v = 0.f;
+    if (t == 0) v = tfx;
+    else if (t == 1) v = tfy;
+    else if (t < 18) v = view ? view[t - 2] : 0.f;
+    else if (t < 34) v = proj ? proj[t - 18] : 0.f;
+    else if (t < 37) v = campos ? campos[t - 34] : 0.f;
+    out[t] = v;
+}
+
+extern "C" int mgr_pack_camera(float tanfovx, float tanfovy, const float* view16, const float* proj16, const float* campos3,
+                               float* out40, void* stream_) {
+    if (!out40) return mgr_fail(MGR_EINVAL, "mgr_pack_camera: null pointer");
+    hipStream_t stream = (hipStream_t)stream_;
+    hipLaunchKernelGGL(k_pack_camera, dim3(1), dim3(64), 0, stream, tanfovx, tanfovy, view16, proj16, campos3, out40);
+    MGR_LAUNCH_CHECK("k_pack_camera", stream, 0);
+    return MGR_OK;
+}
+
+// One thread per bone: T_b = posed_b @ inv(rest_b), the inverse by Gauss-Jordan elimination with partial pivoting in fp32
+// (the operation count and pivoting of the LU route torch.linalg.inv takes; results agree with it to fp32 roundoff).
+// A singular rest matrix gives non-finite entries, like the reference's inverse raising would stop the step.
+__global__ __launch_bounds__(64) void k_bone_transforms(int B, int background, const float* __restrict__ posed,
+                                                        const float* __restrict__ rest, float* __restrict__ out) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B + (background ? 1 : 0)) return;
+    float* o = out + (size_t)b * 16;
+    if (b >= B) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) o[k] = (k % 5 == 0) ? 1.f : 0.f;
+        return;
+    }
+    float a[4][8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            a[r][c] = rest[(size_t)b * 16 + r * 4 + c];
+            a[r][4 + c] = r == c ? 1.f : 0.f;
+        }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        int piv = c;
+        float best = fabsf(a[c][c]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (r > c && fabsf(a[r][c]) > best) { best = fabsf(a[r][c]); piv = r; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (r == piv && r != c) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { const float t = a[c][k]; a[c][k] = a[r][k]; a[r][k] = t; }
+            }
+        const float inv = 1.0f / a[c][c];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[c][k] *= inv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (r != c) {
+                const float f = a[r][c];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) a[r][k] -= f * a[c][k];
+            }
+    }
+    const float* p = posed + (size_t)b * 16;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc += p[r * 4 + k] * a[k][4 + c];
+            o[r * 4 + c] = acc;
+        }
+}
+
+extern "C" int mgr_bone_transforms(int B, int background, const float* posed, const float* rest, float* out, void* stream_) {
+    if (B < 0) return mgr_fail(MGR_EINVAL, "mgr_bone_transforms: bad size");
+    const int n = B + (background ? 1 : 0);
+    if (n == 0) return MGR_OK;
+    if (!out || (B > 0 && (!posed || !rest))) return mgr_fail(MGR_EINVAL, "mgr_bone_transforms: null pointer");
+    hipStream_t stream = (hipStream_t)stream_;
+    hipLaunchKernelGGL(k_bone_transforms, dim3((n + 63) / 64), dim3(64), 0, stream, B, background, posed, rest, out);
+    MGR_LAUNCH_CHECK("k_bone_transforms", stream, 0);
+    return MGR_OK;
+}
+
 extern "C" int mgr_project_points(int N, const float* xyz, const float* K9, const float* E12, float* uv,
                                   void* stream_) {
     if (N < 0) return mgr_fail(MGR_EINVAL, "mgr_project_points: bad sizes");

@@ -80,6 +80,16 @@ def euler_angles_to_armature_space(pose, kintree, rest_matrixs, global_T):
 
 def bone_transforms(posed_transforms, rest_transforms, background=True):
     """T_b = posed_b @ inv(rest_b) (+ identity background), hand_dynamic.py:93-102."""
+    pt, rt = posed_transforms, rest_transforms
+    if pt.is_cuda and rt.is_cuda and pt.dtype == rt.dtype == torch.float32 and pt.dim() == 3 and pt.shape == rt.shape \
+            and pt.shape[1:] == (4, 4) and not (pt.requires_grad or rt.requires_grad):
+        # on the device (where the reference's batch lives): one launch instead of the ~12 of linalg.inv + einsum + cat
+        from ._lib import check, lib, ptr, stream
+        B = pt.shape[0]
+        out = torch.empty((B + (1 if background else 0), 4, 4), dtype=torch.float32, device=pt.device)
+        check(lib().mgr_bone_transforms(B, int(bool(background)), ptr(pt.contiguous()), ptr(rt.contiguous()), ptr(out), stream()),
+              "mgr_bone_transforms")
+        return out
     T = torch.einsum("nij,njk->nik", posed_transforms, torch.linalg.inv(rest_transforms))
     if background:
         T = torch.cat([T, torch.eye(4, dtype=T.dtype, device=T.device)[None]], dim=0)

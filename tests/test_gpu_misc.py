@@ -263,3 +263,35 @@ def test_forward_from_another_host_thread_and_after_device_churn():
     t.join()
     for k in ("sorted", "ordered"):
         assert torch.equal(out[k][0], ref[0]) and torch.equal(out[k][1], ref[1]), k
+
+
+def test_glue_kernels_equal_the_torch_expressions():
+    """mgr_pack_camera / mgr_bone_transforms (one launch each on the reference-shaped route) against the torch expressions
+    they replace: the camera row exactly, posed @ inv(rest) (hand_dynamic.py:93-102) to fp32 roundoff; tensors that carry a
+    gradient, or live on the host, still take the torch route."""
+    from manus_amd import _lib
+    from manus_amd.synthetic import make_scene
+    from manus_amd.transforms import bone_transforms
+    sc = make_scene(n_gaussians=100, kind="hand", seed=3, grid_res=16, n_cameras=3, width=96, height=64, device="cpu")
+    cams = sc["cameras"]
+    g = lambda c, k: torch.tensor(c[k], dtype=torch.float32)
+    tfx = [math.tan(c["fovx"] / 2) for c in cams]
+    tfy = [math.tan(c["fovy"] / 2) for c in cams]
+    host = _lib.pack_cameras(tfx, tfy, [g(c, "world_view_transform")[None] for c in cams], [g(c, "full_proj_transform")[None] for c in cams],
+                             [g(c, "camera_center")[None] for c in cams], DEV)       # host tensors: cat + copies
+    dev = _lib.pack_cameras(tfx, tfy, [g(c, "world_view_transform")[None].to(DEV) for c in cams],
+                            [g(c, "full_proj_transform")[None].to(DEV) for c in cams], [g(c, "camera_center")[None].to(DEV) for c in cams], DEV)
+    assert dev.shape == (3, _lib.MGR_CAM_FLOATS) and torch.equal(host, dev)
+    one = _lib.pack_cameras(tfx[1], tfy[1], g(cams[1], "world_view_transform").to(DEV), g(cams[1], "full_proj_transform").to(DEV),
+                            g(cams[1], "camera_center").to(DEV), torch.device("cuda"))
+    assert torch.equal(one[0], host[1])
+    posed, rest = sc["posed"][0].float(), sc["rest"].float()
+    for bgd in (True, False):
+        want = bone_transforms(posed, rest, background=bgd)                       # host tensors: torch.linalg.inv + einsum
+        got = bone_transforms(posed.to(DEV), rest.to(DEV), background=bgd)
+        assert got.shape == want.shape and got.is_cuda
+        assert float((got.cpu() - want).abs().max()) < 2e-6 * float(want.abs().max())
+    pg = posed.to(DEV).requires_grad_(True)
+    t = bone_transforms(pg, rest.to(DEV))
+    t.sum().backward()
+    assert pg.grad is not None and torch.isfinite(pg.grad).all()
