@@ -1981,6 +1981,9 @@ __global__ __launch_bounds__(256) FWD_OCC void k_blend_fwd(int N, int W, int H, 
         uint4 qrec;
         if (step == 0) {   // the first tile of a workgroup is its own index (k_tile_scan_b starts the counters behind the grid)
             qrec = blockIdx.x < n_queue ? tile_qrec[blockIdx.x] : make_uint4(END, 0u, 0u, 0u);
+#ifdef FWD_KO_DEEP   // (instrumentation, WRONG RESULTS: the first FWD_KO_DEEP queue positions -- the deepest tiles -- are not walked)
+            if (blockIdx.x < FWD_KO_DEEP && qrec.x != END) qrec.x = MGR_HOLE;
+#endif
         } else {
             while (__hip_atomic_load(&s_step[step % FWD_SLOTS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != step) __builtin_amdgcn_s_sleep(1);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -2118,6 +2121,9 @@ __global__ __launch_bounds__(256) FWD_OCC void k_blend_fwd(int N, int W, int H, 
                 const uint32_t nxt = queue.resolve(raw, lane);
                 uint4 nrec = make_uint4(END, 0u, 0u, 0u);
                 if (nxt != END) nrec = tile_qrec[nxt];
+#ifdef FWD_KO_DEEP
+                if (nxt != END && nxt < FWD_KO_DEEP) nrec.x = MGR_HOLE;
+#endif
                 if (lane == 0) {
                     s_qrec[(step + 1u) % FWD_SLOTS] = nrec;
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -2212,6 +2218,9 @@ __global__ __launch_bounds__(256) FWD_OCC void k_blend_fwd(int N, int W, int H, 
             const uint32_t nxt = queue.resolve(raw, lane);
             uint4 nrec = make_uint4(END, 0u, 0u, 0u);
             if (nxt != END) nrec = tile_qrec[nxt];
+#ifdef FWD_KO_DEEP
+            if (nxt != END && nxt < FWD_KO_DEEP) nrec.x = MGR_HOLE;
+#endif
             if (lane == 0) {
                 s_qrec[(step + 1u) % FWD_SLOTS] = nrec;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
