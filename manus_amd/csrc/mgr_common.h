@@ -235,6 +235,23 @@ __device__ __forceinline__ float mgr_dpp(float v) {
         float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, BANK_MASK, false));
 }
 
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ uint32_t mgr_dpp_u(uint32_t v) {   // lanes without a source / masked rows receive 0
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+// Inclusive wave64 scan of one uint per lane on the DPP network (row_shr 1 / 2 / 4 / 8 inside the rows of 16, then the
+// rows' totals across: row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3) -- no LDS round trips, where six
+// __shfl_up steps are six ds_bpermute round trips.
+__device__ __forceinline__ uint32_t mgr_wave_incl_scan_u32(uint32_t v) {
+    v += mgr_dpp_u<0x111>(v);         // row_shr:1
+    v += mgr_dpp_u<0x112>(v);         // row_shr:2
+    v += mgr_dpp_u<0x114>(v);         // row_shr:4
+    v += mgr_dpp_u<0x118>(v);         // row_shr:8
+    v += mgr_dpp_u<0x142, 0xa>(v);    // row_bcast:15 -> rows 1, 3
+    v += mgr_dpp_u<0x143, 0xc>(v);    // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
 // Full wave64 sum; the total is valid in lane 63 only.
 __device__ __forceinline__ float mgr_wave_sum63(float v) {
     v += mgr_dpp<0xb1>(v);          // quad_perm [1,0,3,2]

@@ -117,12 +117,7 @@ extern "C" size_t mgr_raster_workspace_bytes(int V, int N, int W, int H, int64_t
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t val, uint32_t* s_wave /*>=17*/,
                                                     uint32_t& block_total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    uint32_t incl = val;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t o = __shfl_up(incl, d, 64);
-        if (lane >= d) incl += o;
-    }
+    const uint32_t incl = mgr_wave_incl_scan_u32(val);   // (DPP: no ds_bpermute round trips)
     if (lane == 63) s_wave[wave] = incl;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1635,8 +1630,15 @@ __device__ unsigned long long g_binprof[8 * 4096];
 // batch i + 1 while wave 1 (consumer) hands out the slots of batch i -- the cursors and masks are only ever touched by
 // the consumer, so the order argument is unchanged; the two batches live in the two halves of a double buffer and the
 // waves meet at one workgroup barrier per batch.
-#define BIN_SC_THREADS 128
-#define BIN_SC_FIXED_BYTES (2 * 64 * sizeof(BinRec) + 2 * BIN_PAIR_CAP * 4 + 2 * 64 * 4 + 16)
+// Round 5: TWO consumer waves.  The loop was consumer-bound (ranked steps 34 us per block of 1024 instances against 29 us of
+// scan + expansion, -DBIN_PROF): the producer now writes the batch's pairs as two lists -- tiles in even rows of the box from the
+// front of the buffer, tiles in odd rows from its back, each in instance order -- and wave 1 takes the even rows, wave 2 the odd
+// ones: a tile's list is only ever touched by one wave, so the order argument is unchanged.  The pair counts of both lists
+// travel through one packed (16 | 16 bit) scan on the DPP network.
+#define BIN_SC_THREADS 192
+// c_row_comb[w] = sum over j of 2^(2 w j) below 2^64: times a row's w bits = the even rows of a rectangle of width w
+__constant__ unsigned long long c_row_comb[65] = {0x0000000000000000ull, 0x5555555555555555ull, 0x1111111111111111ull, 0x1041041041041041ull, 0x0101010101010101ull, 0x1004010040100401ull, 0x1001001001001001ull, 0x0100040010004001ull, 0x0001000100010001ull, 0x0040001000040001ull, 0x1000010000100001ull, 0x0000100000400001ull, 0x0001000001000001ull, 0x0010000004000001ull, 0x0100000010000001ull, 0x1000000040000001ull, 0x0000000100000001ull, 0x0000000400000001ull, 0x0000001000000001ull, 0x0000004000000001ull, 0x0000010000000001ull, 0x0000040000000001ull, 0x0000100000000001ull, 0x0000400000000001ull, 0x0001000000000001ull, 0x0004000000000001ull, 0x0010000000000001ull, 0x0040000000000001ull, 0x0100000000000001ull, 0x0400000000000001ull, 0x1000000000000001ull, 0x4000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull};
+#define BIN_SC_FIXED_BYTES (2 * 64 * sizeof(BinRec) + 2 * BIN_PAIR_CAP * 4 + 2 * 64 * 4 + 16 + 66 * 8)
 // MASKS = tiles the per-tile lane masks cover: BIN_MID_TILES (30 KB of LDS, five workgroups per CU -- the boxes of the
 // hand scene hold 960-1470 tiles, tools/instr/tile_bbox.py), BIN_SMALL_TILES (36 KB, four per CU) or 0 (no masks: any box).
 #define BIN_MID_TILES 1536
@@ -1661,7 +1663,8 @@ __global__ __launch_bounds__(BIN_SC_THREADS) void k_bin_scatter(int N, int T, in
     uint32_t* s_pairs = (uint32_t*)(s_mask + MASKS);                      // [2][CAP] pairs: tile | lane << 16
     uint32_t* s_gid = s_pairs + 2 * BIN_PAIR_CAP;                       // [2][64] Gaussians of the batch
     uint32_t* s_info = s_gid + 2 * 64;                                  // [2] pairs of the batch, or ~0: by-instance route
-    uint32_t* s_cur = s_info + 4;                                       // cursors of the box's tiles (absolute list slots)
+    unsigned long long* s_comb = (unsigned long long*)(s_info + 4);     // [66] copy of c_row_comb (a divergent constant load is a vector-memory round trip)
+    uint32_t* s_cur = (uint32_t*)(s_comb + 66);                         // cursors of the box's tiles (absolute list slots)
     const int v = blockIdx.y, b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const ushort4 box = db_bbox[v];
     if (!bin_sc_mine(box, MASKS)) {
@@ -1691,6 +1694,7 @@ __global__ __launch_bounds__(BIN_SC_THREADS) void k_bin_scatter(int N, int T, in
         }
         for (; k < TB; k += BIN_SC_THREADS) s_cur[k] = row[k];
         if (SMALL) for (k = tid; k < TB; k += BIN_SC_THREADS) s_mask[k] = 0ull;
+        if (tid < 65) s_comb[tid] = c_row_comb[tid];
     }
     const unsigned long long lt = (1ull << lane) - 1ull;
 #ifdef BIN_PROF
@@ -1710,28 +1714,38 @@ __global__ __launch_bounds__(BIN_SC_THREADS) void k_bin_scatter(int N, int T, in
                 if (it + 1 < nbatch) nxt = bin_load(N, v, p0 + 64u * (uint32_t)(it + 1) + lane, nvis, box, db_order, db_rec);
                 const unsigned long long am = ((unsigned long long)r.ahi << 32) | r.alo;
                 const bool big = r.tiles > 64u;
-                const uint32_t cnt = (r.tiles == 0u || big) ? 0u : (uint32_t)__popcll(am);
-                uint32_t incl = cnt;   // inclusive wave scan
-#pragma unroll
-                for (int dd = 1; dd < 64; dd <<= 1) {
-                    const uint32_t o = (uint32_t)__shfl_up((int)incl, dd, 64);
-                    if (lane >= dd) incl += o;
+                const bool use = !(r.tiles == 0u || big);
+                const uint32_t w = r.wh & 0xFFFFu;
+                // the alive tiles in even rows of the box: rows of the rectangle are runs of w bits
+                unsigned long long amE = 0ull;
+                if (use) {   // (no loop over the rows: the lanes' rectangles differ and the wave would run to the tallest)
+                    const unsigned long long rb = w >= 64u ? ~0ull : ((1ull << w) - 1ull);
+                    const unsigned long long rowm = (rb * s_comb[min(w, 64u)]) << ((uint32_t)(bin_y0(r.xy) & 1) * (w & 63u));
+                    amE = am & rowm;
                 }
-                const uint32_t P = (uint32_t)__shfl((int)incl, 63, 64);
+                const unsigned long long amU = use ? am : 0ull;
+                const uint32_t cntE = (uint32_t)__popcll(amE), cntO = (uint32_t)__popcll(amU & ~amE);
+                const uint32_t incl = mgr_wave_incl_scan_u32(cntE | (cntO << 16));   // (both sums stay below 2^16: 64 lanes x 64 tiles)
+                const uint32_t P = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                const uint32_t PE = P & 0xFFFFu, PO = P >> 16;
                 BP(1)
-                if (__ballot(big) == 0ull && P <= (uint32_t)BIN_PAIR_CAP) {
-                    // expand: pairs of lane's instance at [incl - cnt, incl), tiles in row-major order of the rectangle
+                if (__ballot(big) == 0ull && PE + PO <= (uint32_t)BIN_PAIR_CAP) {
+                    // expand: the lane's pairs in row-major order of the rectangle, even box rows at [oE, oE + cntE) from the front,
+                    // odd ones at CAP - 1 - [oO, oO + cntO) from the back
                     uint32_t* pl = s_pairs + d * BIN_PAIR_CAP;
-                    uint32_t o = incl - cnt;
-                    const uint32_t w = r.wh & 0xFFFFu;
+                    uint32_t oE = (incl & 0xFFFFu) - cntE, oO = (incl >> 16) - cntO;
                     const float rw = __frcp_rn((float)max(w, 1u));
                     const int org = bin_y0(r.xy) * bw + bin_x0(r.xy);
-                    unsigned long long m = cnt ? am : 0ull;
+                    unsigned long long m = amU;
                     while (m) {
                         const uint32_t k = (uint32_t)__builtin_ctzll(m);
                         m &= m - 1ull;
                         const uint32_t ty = (uint32_t)(((float)k + 0.5f) * rw), tx = k - ty * w;   // k / w, exact for k < 64
-                        pl[o++] = (uint32_t)(org + (int)ty * bw + (int)tx) | ((uint32_t)lane << 16);
+                        const uint32_t isE = (uint32_t)((amE >> k) & 1ull);
+                        const uint32_t at = isE ? oE : (uint32_t)BIN_PAIR_CAP - 1u - oO;
+                        oE += isE;
+                        oO += 1u - isE;
+                        pl[at] = (uint32_t)(org + (int)ty * bw + (int)tx) | ((uint32_t)lane << 16);
                     }
                     s_gid[d * 64 + lane] = r.gid;
                     if (lane == 0) s_info[d] = P;
@@ -1741,13 +1755,16 @@ __global__ __launch_bounds__(BIN_SC_THREADS) void k_bin_scatter(int N, int T, in
                 }
                 BP(2)
             }
-        } else if (it >= 1) {   // ---- consumer: batch it - 1 from buffer (it - 1) & 1
+        } else if (it >= 1) {   // ---- consumers: batch it - 1 from buffer (it - 1) & 1; wave 1 the even box rows, wave 2 the odd ones
             const int d = (it - 1) & 1;
-            const uint32_t P = s_info[d];
-            if (P != 0xFFFFFFFFu) {
-                const uint32_t* pl = s_pairs + d * BIN_PAIR_CAP;
+            const uint32_t Pboth = s_info[d];
+            if (Pboth != 0xFFFFFFFFu) {
+                const bool odd = wave == 2;
+                const uint32_t P = odd ? Pboth >> 16 : Pboth & 0xFFFFu;
+                const uint32_t* const plist = s_pairs + d * BIN_PAIR_CAP;
+                auto pl = [&](uint32_t i) -> uint32_t { return plist[odd ? (uint32_t)BIN_PAIR_CAP - 1u - i : i]; };
                 const uint32_t* gl = s_gid + d * 64;
-                uint32_t pr_n = lane < P ? pl[lane] : 0u;
+                uint32_t pr_n = lane < P ? pl((uint32_t)lane) : 0u;
                 if (SMALL) {
                     // Lanes of a step on the same tile find each other through the tile's 64-bit lane mask (LDS OR, read back):
                     // the lowest lane adds the group's size to the cursor, the others take its result + their rank in the mask.
@@ -1758,7 +1775,7 @@ __global__ __launch_bounds__(BIN_SC_THREADS) void k_bin_scatter(int N, int T, in
                     for (uint32_t c = 0; c < P + 64; c += 64) {
                         const bool valid = c + lane < P;
                         const uint32_t pr = pr_n;
-                        if (c + 64 < P) pr_n = (c + 64 + lane < P) ? pl[c + 64 + lane] : 0u;   // next step's pairs
+                        if (c + 64 < P) pr_n = (c + 64 + lane < P) ? pl(c + 64u + (uint32_t)lane) : 0u;   // next step's pairs
                         const uint32_t t = pr & 0xFFFFu;
                         if (valid) atomicOr(&s_mask[t], 1ull << lane);
                         __builtin_amdgcn_wave_barrier();
@@ -1785,7 +1802,7 @@ __global__ __launch_bounds__(BIN_SC_THREADS) void k_bin_scatter(int N, int T, in
                     for (uint32_t c = 0; c < P; c += 64) {
                         const bool valid = c + lane < P;
                         const uint32_t pr = pr_n;
-                        if (c + 64 < P) pr_n = (c + 64 + lane < P) ? pl[c + 64 + lane] : 0u;   // next step's pairs
+                        if (c + 64 < P) pr_n = (c + 64 + lane < P) ? pl(c + 64u + (uint32_t)lane) : 0u;   // next step's pairs
                         const uint32_t t = pr & 0xFFFFu;
                         uint32_t pos = 0u, cend = 1u;
                         if (valid) {
@@ -1806,7 +1823,7 @@ __global__ __launch_bounds__(BIN_SC_THREADS) void k_bin_scatter(int N, int T, in
                     }
                 }
                 BP(3)
-            } else {
+            } else if (wave == 1) {
                 const BinRec r = s_rec[d * 64 + lane];
                 bin_batch_by_instance(r, s_rec + d * 64, s_cur, bw, lane, sorted_gid, cap);
                 BP(4)
