@@ -252,6 +252,17 @@ __device__ __forceinline__ uint32_t mgr_wave_incl_scan_u32(uint32_t v) {
     return v;
 }
 
+// Wave64 maximum of one uint per lane, wave-uniform result (DPP inside the rows of 16, the four row results through readlane).
+__device__ __forceinline__ uint32_t mgr_wave_max_u32(uint32_t v) {
+    v = max(v, mgr_dpp_u<0xb1>(v));    // quad_perm [1,0,3,2]
+    v = max(v, mgr_dpp_u<0x4e>(v));    // quad_perm [2,3,0,1]
+    v = max(v, mgr_dpp_u<0x141>(v));   // row_half_mirror
+    v = max(v, mgr_dpp_u<0x140>(v));   // row_mirror
+    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16),
+                   c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+    return max(max(a, b), max(c, d));
+}
+
 // Full wave64 sum; the total is valid in lane 63 only.
 __device__ __forceinline__ float mgr_wave_sum63(float v) {
     v += mgr_dpp<0xb1>(v);          // quad_perm [1,0,3,2]

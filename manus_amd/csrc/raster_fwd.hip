@@ -2254,9 +2254,7 @@ __global__ __launch_bounds__(256) FWD_OCC void k_blend_fwd(int N, int W, int H, 
             o[2 * P] = C2 + Tr * bg2;
         }
         // list depth this quadrant consumed; the tile's maximum drives the backward pass (k_fwd_items)
-        uint32_t mx = last;
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
+        const uint32_t mx = mgr_wave_max_u32(last);   // (DPP + readlane: the six __shfl_xor steps were ds_bpermute round trips at the end of every unit)
         if (lane == 0 && !hole) {
             tile_qdone[(size_t)vt * 4 + quad] = mx;
             // depth cut: the list position in front of which every pixel of the quadrant had stopped (a whole number of
