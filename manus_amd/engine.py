@@ -407,6 +407,7 @@ class HipViewCompute:
         # operator).  A Trainer sets it False on ITS compute object: no host sync, the forward leaves an overflow fence
         # that Trainer._run_step polls.  (The device-wide policy of rasterizer.set_sync_policy is left alone.)
         self.sync_check = True
+        self._w_cache = None     # forward-only skin weights of the current model state (forward_views_fused under no_grad)
         self.grid = ops.SkinGrid(scene["grid"], scene["grid"].device) if self.is_hand else None
 
     @property
@@ -517,7 +518,18 @@ class HipViewCompute:
         s, p, ops = self.s, self.params, self.ops
         sel = self._select(view_ids)
         na = self.n_art
-        w = ops.skin_weights(p["_xyz"][:na], self.grid, s["grid_center"], s["grid_scale"]) if na else None
+        w = None
+        if na and not torch.is_grad_enabled():
+            # forward only (evaluation sweeps, target rendering): the skin weights depend on `_xyz` alone, so they are kept per
+            # model state -- (generation, parameter-update clock, the leaf's storage and version) -- instead of gathered from
+            # the grid again for every batch of views (0.04 ms for 300 k Gaussians: 13 % of a one-view forward).  Training
+            # steps always recompute them (their gradient flows back into `_xyz`).
+            key = (self._cut_gen, self._cut_clock, p["_xyz"].data_ptr(), p["_xyz"]._version, na, id(self.grid))
+            if self._w_cache is None or self._w_cache[0] != key:
+                self._w_cache = (key, ops.skin_weights(p["_xyz"][:na], self.grid, s["grid_center"], s["grid_scale"]))
+            w = self._w_cache[1]
+        elif na:
+            w = ops.skin_weights(p["_xyz"][:na], self.grid, s["grid_center"], s["grid_scale"])
         return self.fz.render_views(p["_xyz"], p["_scaling"], p["_rotation"], p["_opacity"], p["_features_dc"],
                                     p["_features_rest"], w, sel["T"], sel["cams"], s["bg"], s["width"], s["height"],
                                     stats=stats, grad2d_scale=grad2d_scale, grad_arena=self.grad_arena)

@@ -255,3 +255,38 @@ def test_fp16_sh_storage_is_exact_on_representable_coefficients(kind):
     f16.mark_params_changed()
     f16([0, 1, 2], 1.0 / 3)
     assert torch.equal(f16._sh_copy[:, :45].float(), f16.params["_features_rest"].detach().reshape(5000, 45).half().float())
+
+
+def test_forward_only_skin_weights_follow_the_model():
+    """forward_views_fused under no_grad keeps the skin weights per model state: the image must follow every way the
+    positions can change -- an in-place torch update (version counter), an optimizer-style update announced by
+    mark_params_changed, new leaves through set_params -- and equal a fresh object's render each time."""
+    from manus_amd.engine import HipViewCompute
+    sc, ct = _scene("hand", n=4000, views=2)
+    tg = torch.zeros((2, 3, 64, 96), device=DEV)
+    hc = HipViewCompute(sc, tg, ct)
+
+    def fresh_image(params):
+        s2 = dict(sc)
+        s2["params"] = {k: v.detach().clone() for k, v in params.items()}
+        with torch.no_grad():
+            return HipViewCompute(s2, tg, ct).forward_views_fused([0, 1])[0].clone()
+
+    with torch.no_grad():
+        a = hc.forward_views_fused([0, 1])[0].clone()
+        b = hc.forward_views_fused([0, 1])[0].clone()          # second call: cached weights
+        assert hc._w_cache is not None and torch.equal(a, b) and torch.equal(a, fresh_image(hc.params))
+        hc.params["_xyz"].add_(0.004 * torch.randn(hc.params["_xyz"].shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1)))
+        c = hc.forward_views_fused([0, 1])[0].clone()
+        assert not torch.equal(c, a) and torch.equal(c, fresh_image(hc.params))
+        # an update torch does not see (what the fused Adam kernel does through raw pointers), announced like the Trainer does
+        hc.params["_xyz"].data.mul_(1.01)
+        hc.mark_params_changed()
+        d = hc.forward_views_fused([0, 1])[0].clone()
+        assert not torch.equal(d, c) and torch.equal(d, fresh_image(hc.params))
+    hc.set_params({k: (v.detach() * (0.99 if k == "_xyz" else 1.0)).clone() for k, v in hc.params.items()})
+    with torch.no_grad():
+        e = hc.forward_views_fused([0, 1])[0].clone()
+    assert torch.equal(e, fresh_image(hc.params))
+    out = hc([0, 1], 0.5)                                   # a training step never uses the cache: d xyz includes the grid path
+    assert float(out["grads"]["_xyz"].abs().sum()) > 0
