@@ -144,7 +144,12 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t val, uint32_t* s_wa
 // at 1024 / 512 / 256 threads, k_emit 0.100 / 0.105 / 0.175 ms: the LDS tile histogram is flushed once per workgroup).
 // (late in round 4, same kernel with the depth-cut lookups: 0.198 / 0.192 / 0.172 / 0.215 / 0.179 ms at 384 / 448 / 512 / 640 / 768.)
 #ifndef MGR_FWD_GRID
-#define MGR_FWD_GRID (256 * 8)   // persistent workgroups of k_blend_fwd
+// Workgroups of k_blend_fwd.  Workgroup w starts with queue position w (deepest tiles first) and draws tickets behind the grid;
+// ~1280 of them are resident at a time (five per CU), the others are handed to the CUs by the hardware dispatcher as slots
+// free up -- in blockIdx order, i.e. down the depth-ordered queue, with no ticket round trip.  Round 5 sweep on the no-hints
+// step (k_blend_fwd, ms): 1536 0.2615 | 2048 0.2592 | 3072 0.2517 | 4096 0.2480 | 6144 0.2445 | 8192 0.2447; the 500 k composite
+// with 7 views 0.333 -> 0.280; one and four views unchanged.  (Round 4 had looked at 1024 .. 2048 only.)
+#define MGR_FWD_GRID (256 * 24)
 #endif
 #ifndef PRE_THREADS
 #define PRE_THREADS 512
