@@ -1882,11 +1882,12 @@ extern "C" int mgr_debug_fprof(unsigned long long* dst) {
 #endif
 // (occupancy of the forward blend: 78 VGPRs = six waves per SIMD as compiled; forced to five or four the kernel and the step
 // time stay within the run-to-run noise, 0.369-0.377 ms / 598-607 iters/s on one box)
-#ifdef FWD_WAVES_EU
-#define FWD_OCC __attribute__((amdgpu_waves_per_eu(FWD_WAVES_EU, FWD_WAVES_EU)))
-#else
-#define FWD_OCC
+// (round 5, on 6144 workgroups: 95 VGPRs = five waves per SIMD as compiled 0.2495 ms; forced to four 0.2415, to three 0.2750, to
+// six 0.2762 -- four it is; composite and one view unchanged)
+#ifndef FWD_WAVES_EU
+#define FWD_WAVES_EU 4
 #endif
+#define FWD_OCC __attribute__((amdgpu_waves_per_eu(FWD_WAVES_EU, FWD_WAVES_EU)))
 // ---------------------------------------------------------------------------
 // K5, wave-granular: the same walk, but nothing in the kernel waits at a workgroup barrier.  -DFWD_PROF on the workgroup
 // version above showed why: per tile of fewer than 1024 list entries (63 % of the tiles of the bench scene) a wave spent
