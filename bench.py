@@ -89,7 +89,7 @@ def kernel_unit_bytes(name, V, consumed, P):
 # measured on one GPU (profiles/r05_other_configs/hand_v{1,2,4}.json and the headline), + the dense exchange of
 # 61 N + 2 floats between "every peer link at once" (direct reduce-scatter + all-gather: 2 (S / n) / 76.8 GB/s) and "a ring
 # over one link at a time" ((n - 1) times that).
-COMPUTE_MS_BY_VIEWS = {8: 1.37, 4: 0.88, 2: 0.70, 1: 0.54}
+COMPUTE_MS_BY_VIEWS = {8: 1.34, 4: 0.87, 2: 0.70, 1: 0.54}
 
 
 def predicted_ms(world, N, V, kind, W, H):
