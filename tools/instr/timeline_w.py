@@ -10,7 +10,7 @@ ct = camera_table(sc["cameras"], DEV)
 hc = HipViewCompute(sc, torch.zeros((V, 3, H, W), device=DEV) + 0.5, ct, loss="l1+ssim")
 ids = list(range(V))
 L = ctypes.CDLL(_lib.LIB_PATH)
-NREC = 2048 * 4 * 24
+NREC = 6144 * 4 * 24   # MGR_FWD_GRID workgroups x 4 waves x TLW_PER_WAVE
 buf = (ctypes.c_ulonglong * (NREC * 4))(); n = ctypes.c_uint(0)
 for _ in range(3): hc(ids, 1.0 / V)
 torch.cuda.synchronize(); L.mgr_debug_timeline_w(buf, ctypes.byref(n))
