@@ -553,7 +553,10 @@ static int image_loss_impl(int V, int H, int W, const float* pred, const float* 
     if (phase == 1) return MGR_OK;
     {
         MGR_PROF("k_image_loss", stream);
-        const int64_t pb = nb < 256 * 5 ? nb : 256 * 5;   // persistent: 5 workgroups of 32 KB LDS per CU
+#ifndef IL_GRID
+#define IL_GRID (256 * 5)
+#endif
+        const int64_t pb = nb < IL_GRID ? nb : IL_GRID;   // persistent: 5 workgroups of 32 KB LDS per CU are resident
         hipLaunchKernelGGL(k_image_loss, dim3((unsigned)pb), dim3(IL_T), 0, stream, H, W, pred, target, win, w_l1, w_ssim,
                            grad_scale, dL_dpred, partial, (const uint32_t*)work_list, (const uint32_t*)work_count,
                            (int)grid.x, (int)grid.y);
