@@ -295,3 +295,23 @@ def test_glue_kernels_equal_the_torch_expressions():
     t = bone_transforms(pg, rest.to(DEV))
     t.sum().backward()
     assert pg.grad is not None and torch.isfinite(pg.grad).all()
+
+
+@pytest.mark.parametrize("extra", [[], ["--dropin-fenced"], ["--kind", "object"]])
+def test_bench_dropin_route_runs(extra):
+    """`bench.py --route dropin` (the zero-change operator route: modules.hand_forward / object_forward + render_gaussians +
+    losses under autograd, one view per step) at a tiny size: one JSON line, labelled as not the headline, finite gradients."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--route", "dropin", "--gaussians", "4000", "--views", "2", "--width", "160",
+           "--height", "96", "--steps", "2", "--warmup", "1"] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["headline"] is False and d["value"] > 0 and d["config"]["route"] == "dropin" and d["config"]["finite_grads"] is True
+    assert d["config"]["host_syncs_per_step"] == (0 if "--dropin-fenced" in extra else 1)
+    assert (d["config"]["width"], d["config"]["height"]) == (160, 96)
