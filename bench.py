@@ -106,6 +106,18 @@ def predicted_ms(world, N, V, kind, W, H):
             "model": "DESIGN 7: one-GPU compute of views/rank + 61N+2 floats over 7 xGMI links x 76.8 GB/s per direction"}
 
 
+def cpu_model_string():
+    """The host CPU's model name (BASELINE.md 3 asks for it next to os.cpu_count())."""
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
 def _median_time(fn, warmup=2, reps=5):
     for _ in range(warmup):
         fn()
@@ -278,7 +290,7 @@ def cpu_baseline_and_parity(scene_cpu, cams, targets_cpu, gpu, sample_views=2, n
     t_view = float(tt.sum())
     chain = torch_chain_timing(scene_cpu, cams[0])
     cpu = {"value": round(1.0 / (t_view * n_views), 5), "unit": "iters/s", "cores": threads, "kind": "port",
-           "cpu_count": os.cpu_count(),
+           "cpu_count": os.cpu_count(), "cpu_model": cpu_model_string(),
            "sample": "oracle port, %d of %d views (%.1f s of CPU work), N=%d, %dx%d; per view: torch LBS+cov+SH fwd %.2fs + "
                      "bwd %.2fs (%d threads), scalar C rasterizer fwd %.2fs + bwd %.2fs (1 thread), image loss %s %.2fs; "
                      "value = 1/(%d x %.2fs).  Not comparable with the reference's CUDA path; the torch chain alone "
@@ -459,6 +471,12 @@ def main():
                          "modules.hand_forward + render.render_gaussians (GaussianRasterizer under autograd) + losses at the "
                          "reference's 1280x720 training resolution; not the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (cpu_baseline and parity)")
+    ap.add_argument("--cam-radius", type=float, default=1.2,
+                    help="radius of the camera sphere in metres: 1.2 = the capture-like set of SURVEY 8(d) (the headline), 0.45 = its "
+                         "'close-up' set (the hand fills the frame, deep tile lists); anything but 1.2 is labelled, not the headline")
+    ap.add_argument("--trained-steps", type=int, default=300,
+                    help="Adam steps taken before the `value_trained_state` figure is timed (the same fwd+bwd loop on the model those "
+                         "steps leave; 0 = skip it)")
     ap.add_argument("--parity-views", type=int, default=2, help="views of the step run through the CPU oracle")
     ap.add_argument("--profile-all", action="store_true", help="print a per-kernel HIP-event breakdown to stderr")
     args = ap.parse_args()
@@ -481,8 +499,12 @@ def main():
     from manus_amd.engine import HipViewCompute, ViewShardedStep
     from manus_amd.synthetic import camera_table, make_scene
 
+    # an instrumented / knock-out build of the library (tools/instr; MANUS_HIP_VARIANT names the .so) labels its line and is
+    # never the headline; one whose knock-outs change results (bit 0) also skips the parity block
+    variant_bits = int(_lib.lib().mgr_build_variant())
+    variant_name = os.environ.get("MANUS_HIP_VARIANT", "")
     V, N, W, H = args.views, args.gaussians, args.width, args.height
-    scene = make_scene(n_gaussians=N, kind=args.kind, seed=0, n_cameras=V, width=W, height=H, device=dev)
+    scene = make_scene(n_gaussians=N, kind=args.kind, seed=0, n_cameras=V, width=W, height=H, device=dev, cam_radius=args.cam_radius)
     if args.gaussian_order == "morton":   # (an experiment, not the headline workload: the rows of a spatially sorted model)
         xyz = scene["params"]["_xyz"]
         q = ((xyz - xyz.min(0).values) / (xyz.max(0).values - xyz.min(0).values + 1e-12) * 1023.0).long().clamp_(0, 1023)
@@ -668,12 +690,12 @@ def main():
     # With the optimizer in the loop a Gaussian can walk out of the skin-weight grid; its weights are then 0/0 = NaN
     # exactly like the reference (gaussian_utils.py:193-195), which drops such rows when it loads a checkpoint.
     nonfinite = sum(int((~torch.isfinite(x)).sum()) for x in out["grads"].values())
-    assert args.optimizer or nonfinite == 0 or os.environ.get("MANUS_HIP_VARIANT"), "non-finite gradients"   # (knock-out builds: tools/instr)
+    assert args.optimizer or nonfinite == 0 or (variant_bits & 1), "non-finite gradients"   # (only a knock-out build may produce them: tools/instr)
     # list entries the blend actually consumed (sum over tiles of the deepest contributor): the units k_blend_fwd / _bwd process
     consumed = None
+    import ctypes
     ws = rasterizer.context(dev).last_ws
     if ws is not None:
-        import ctypes
         arr = (ctypes.c_size_t * 32)()
         _lib.lib().mgr_raster_layout(V_local, N, W, H, ws.cap, arr, 32)
         VT = V_local * ((W + 15) // 16) * ((H + 15) // 16)
@@ -721,6 +743,58 @@ def main():
         step.step()                 # (back on full lists: the parity block below runs the headline's configuration)
         rasterizer.check_overflow()
 
+    # What the same loop costs on the state TRAINING leaves: a few hundred Adam steps at the reference's learning rates lengthen
+    # the walks (2.9 M -> ~4 M consumed list entries on this scene); the headline above is timed on the initial state.  Same
+    # process, same compute object and mode; the parameters are put back bit for bit afterwards (the parity block follows).
+    trained = None
+    if static_model and args.trained_steps > 0 and compute.fused:
+        from manus_amd.optim import GaussianOptimizer
+        saved = {k: v.detach().clone() for k, v in compute.params.items()}
+        try:
+            opt_t = GaussianOptimizer(compute.params, adopt=True)
+            for it_ in range(args.trained_steps):
+                o_t = step.step()
+                if it_ % 50 == 49:
+                    try:
+                        rasterizer.poll(dev)
+                    except RuntimeError:       # the pair capacity was outgrown: the hint is enlarged, the step repeated
+                        o_t = step.step()
+                opt_t.update_learning_rate(opt_t.state_step + 1)
+                opt_t.step(o_t["grads"])
+                compute.mark_params_changed()
+            rasterizer.set_sync_policy(True)
+            step.step()
+            rasterizer.check_overflow()
+            rasterizer.set_sync_policy(False)
+            step.step()
+            dts_t, prof_t, out_t = timed_region()
+            rasterizer.check_overflow()
+            dt_t = float(np.median(dts_t))
+            ws_t = rasterizer.context(dev).last_ws
+            arr_t = (ctypes.c_size_t * 32)()
+            _lib.lib().mgr_raster_layout(V_local, N, W, H, ws_t.cap, arr_t, 32)
+            consumed_t = int(ws_t.buf[int(arr_t[9]): int(arr_t[9]) + 4 * V_local * ((W + 15) // 16) * ((H + 15) // 16)].view(torch.int32).sum().item())
+            dom_t = prof_t.get(DOMINANT)
+            trained = {"value": round(args.steps / dt_t, 4), "ms_per_step": round(1e3 * dt_t / args.steps, 4),
+                       "adam_steps_before": args.trained_steps, "consumed_pairs": consumed_t,
+                       "dominant_kernel_ms": round(dom_t[1] / dom_t[0], 4) if dom_t else None,
+                       "nonfinite_grad_values": sum(int((~torch.isfinite(x)).sum()) for x in out_t["grads"].values()),
+                       "what": "the headline's fwd+bwd loop (no optimizer inside the timed steps) on the parameters %d fused Adam steps "
+                               "at the reference's learning rates leave: the state a training run is in" % args.trained_steps}
+        except _lib.ManusHipError as exc:
+            trained = {"error": str(exc)[:200]}
+        with torch.no_grad():
+            for k, v in compute.params.items():
+                v.copy_(saved[k])
+        compute.mark_params_changed()
+        del saved
+        rasterizer.set_sync_policy(True)
+        step.step()
+        rasterizer.check_overflow()
+        rasterizer.set_sync_policy(False)
+        step.step()
+        rasterizer.check_overflow()
+
     views_by_rank = None
     if world > 1:
         views_by_rank = [None] * world
@@ -747,7 +821,7 @@ def main():
             if stale or not pmc.get("duration_ns"):
                 pmc = {"stale": bool(stale)}
             roof = {"bound": "hbm", "kernel": DOMINANT, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": pmc.get("traffic"),
+                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "frac_units": round(ach / HBM_PEAK_GBS, 5), "traffic": pmc.get("traffic"),
                     "avg_kernel_ms": round(avg_ms, 4), "kernel_duration_samples": int(dom[0]), "algorithmic_bytes_per_launch": int(kb),
                     "units": ("list entries the forward's walks consumed x %d B + pixels x 20 B (the units this launch processes)"
                               % (112 if DOMINANT == "k_blend_bwd" else 40)) if kb != kb_survey else "SURVEY 8(d) per-unit figures",
@@ -789,7 +863,7 @@ def main():
             print("library kernels %.3f ms/iter of %.3f ms/iter wall" % (tot / (args.steps * REPEATS), 1e3 * dt / args.steps),
                   file=sys.stderr)
         cpu = parity = None
-        if not args.no_cpu_baseline and world == 1 and args.kind == "hand" and not args.optimizer and args.sh_storage == "fp32":
+        if not args.no_cpu_baseline and world == 1 and args.kind == "hand" and not args.optimizer and args.sh_storage == "fp32" and not (variant_bits & 1):
             # The GPU step once more on the sampled views alone (same targets, same loss, same 1/V scale), ON THE TIMED
             # REGION'S compute object and IN ITS MODE (no host sync per forward: fenced; kept buffers; no depth cut) -- run
             # twice, so that the second one has the row- / tile-selective fills of the kept buffers in use like every timed
@@ -847,14 +921,16 @@ def main():
         # hints); anything else is labelled by its arguments
         headline = (args.kind == "hand" and N == 300000 and V == 8 and (W, H) == (1920, 1080) and args.loss == "l1+ssim"
                     and not args.optimizer and args.sh_storage == "fp32" and not args.dense_loss_scan and not compute.depth_cut
-                    and not args.depth_cut and not args.fresh_grads)
+                    and not args.depth_cut and not args.fresh_grads and args.cam_radius == 1.2 and not variant_bits and not variant_name)
         k_str = "%dk" % (N // 1000) if N % 1000 == 0 else str(N)
         res_str = "1080p" if (W, H) == (1920, 1080) else "%dx%d" % (W, H)
         metric = ("train iters/sec (fwd+bwd) %s Gaussians @%s, %d views; PSNR parity" % (k_str, res_str, V))
         if not headline:
-            metric += " [not the headline configuration: %s%s%s%s]" % (args.kind, ", optimizer in the step" if args.optimizer else "",
-                                                                      ", fp16 SH storage" if args.sh_storage == "fp16" else "",
-                                                                      ", depth-cut hints" if args.depth_cut else "")
+            metric += " [not the headline configuration: %s%s%s%s%s%s]" % (args.kind, ", optimizer in the step" if args.optimizer else "",
+                                                                          ", fp16 SH storage" if args.sh_storage == "fp16" else "",
+                                                                          ", depth-cut hints" if args.depth_cut else "",
+                                                                          ", cameras at %.2f m" % args.cam_radius if args.cam_radius != 1.2 else "",
+                                                                          ", library variant '%s' (bits %d)" % (variant_name, variant_bits) if (variant_bits or variant_name) else "")
         kind_str = {"hand": "HAND_GAUSSIAN: %d Gaussians, 21-transform LBS" % N, "object": "OBJ_GAUSSIAN: %d static Gaussians" % N,
                     "composite": "COMPOSITE: %d Gaussians (hand, 21-transform LBS + static object)" % N}.get(args.kind, args.kind)
         ms = [1e3 * d_ / args.steps for d_ in dts]
@@ -866,9 +942,15 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "value_with_hints": hints["value"] if hints else None,
             "ms_per_step_with_hints": hints["ms_per_step"] if hints else None,
+            "value_trained_state": trained.get("value") if trained else None,
+            "ms_per_step_trained_state": trained.get("ms_per_step") if trained else None,
+            "variant": ({"name": variant_name, "bits": variant_bits} if (variant_bits or variant_name) else None),
             "config": {"workload": "%s, %d views %dx%d, one pose per view "
                                    "(n_poses=%d), image loss %s, fwd+bwd to leaf grads" % (kind_str, V, W, H, n_poses, "0.8*L1 + 0.2*(1-SSIM)" if args.loss == "l1+ssim" else "L1"),
                        "gaussians": N, "views": V, "width": W, "height": H, "views_per_gpu": V_local,
+                       "cameras": ("capture-like: %d cameras on a %.2f m sphere (SURVEY 8d)" % (V, args.cam_radius) if args.cam_radius == 1.2 else
+                                   "close-up: %d cameras on a %.2f m sphere (SURVEY 8d's deep-list set at 0.45 m)" % (V, args.cam_radius)),
+                       "trained_state": trained,
                        "pairs_per_view": int(R_view), "parallelism": "views/%d" % world,
                        "view_assignment": (None if world == 1 else "round-robin" if weights is None else "balanced by measured pairs per view (LPT)"),
                        "views_by_rank": views_by_rank, "grad_digest": digest,

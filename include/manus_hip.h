@@ -87,6 +87,13 @@ enum {
 };
 
 int mgr_version(void);
+/* 0 for the product build.  Non-zero when the library was compiled with one of the instrumentation macros of tools/instr
+ * (never by manus_amd.build's defaults): bit 0 = a knock-out that CHANGES RESULTS (BWD_KO, FWD_KO_DEEP: cost bounds
+ * only), bit 1 = counters / clocks inside the kernels (MGR_STATS, MGR_TIMELINE, *_PROF: results unchanged, timings
+ * perturbed), bit 2 = an alternative code path selected at compile time (FWD_PF1, FWD_LDS_PIPE1, BWD_WLAST_REDUCE, a
+ * non-default MGR_BIN_BLOCK: results unchanged).  bench.py labels such a run and refuses to call it the headline; the parity
+ * block does not run on a library that reports bit 0. */
+int mgr_build_variant(void);
 /* Thread-local text of the last error returned on this host thread. */
 const char* mgr_last_error(void);
 

@@ -23,6 +23,7 @@ c_int, c_i64, c_f32, c_vp, c_sz = ctypes.c_int, ctypes.c_int64, ctypes.c_float, 
 # name -> (restype, argtypes); must list every symbol of include/manus_hip.h
 SIGNATURES = {
     "mgr_version": (c_int, []),
+    "mgr_build_variant": (c_int, []),
     "mgr_last_error": (ctypes.c_char_p, []),
     "mgr_raster_workspace_bytes": (c_sz, [c_int, c_int, c_int, c_int, c_i64]),
     "mgr_raster_forward": (c_int, [c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp,

@@ -100,6 +100,17 @@ __device__ __forceinline__ uint32_t mgr_any64(unsigned long long m) {
 #ifndef BWD_KO
 #define BWD_KO 0
 #endif
+int mgr_bwd_variant_bits(void) {   // (mgr_build_variant, raster_fwd.hip)
+    int bits = 0;
+    if (BWD_KO != 0) bits |= 1;
+#if defined(MGR_STATS) || defined(BWD_PROF)
+    bits |= 2;
+#endif
+#ifdef BWD_WLAST_REDUCE
+    bits |= 4;
+#endif
+    return bits;
+}
 // a volatile load that stays a ds_read (a volatile access through a generic pointer becomes a flat load)
 #define MGR_LDS_VOLATILE_F32 volatile const __attribute__((address_space(3))) float*
 #define BWD_ROW 288

@@ -105,6 +105,23 @@ extern "C" int mgr_profile_report(char* buf, size_t len, void* stream_) {
 }
 
 extern "C" int mgr_version(void) { return MGR_VERSION; }
+// instrumentation compiled into the library (include/manus_hip.h: 0 for the product build); the backward's half lives in
+// its translation unit, the macros being per-source -D flags of tools/instr/build_variant.sh
+int mgr_bwd_variant_bits(void);
+extern "C" int mgr_build_variant(void) {
+    int bits = mgr_bwd_variant_bits();
+#ifdef FWD_KO_DEEP
+    bits |= 1;
+#endif
+#if defined(MGR_STATS) || defined(MGR_TIMELINE) || defined(FWD_PROF) || defined(BIN_PROF) || defined(DBS_PROF)
+    bits |= 2;
+#endif
+#if defined(FWD_PF1) || defined(FWD_LDS_PIPE1)
+    bits |= 4;
+#endif
+    if (MGR_BIN_BLOCK != 1024) bits |= 4;
+    return bits;
+}
 extern "C" const char* mgr_last_error(void) { return g_mgr_err; }
 
 extern "C" size_t mgr_raster_workspace_bytes(int V, int N, int W, int H, int64_t cap) {
@@ -1492,9 +1509,10 @@ __global__ __launch_bounds__(BCNT_THREADS) void k_bin_count(int N, int T, int nb
     for (int k = tid; k < TB; k += BCNT_THREADS) row[k] = s_hist[k];
 }
 
-// column-wise exclusive scan over the blocks of a view, starting at the tile's list start.  A workgroup takes 32 columns;
-// its 8 waves each sum an eighth of the rows (loads of a wave: 32 columns x 2 rows, coalesced), the partial sums meet in
-// LDS, and every wave then rewrites its rows as running offsets.
+// column-wise exclusive scan over the blocks of a view, starting at the tile's list start.  A workgroup of 1024 threads
+// takes BSCAN_COLS = 32 columns; its BSCAN_SEGS = 32 row segments (32 lanes each: two segments per wave, the loads of a
+// wave = 32 columns x 2 rows, coalesced) each sum a 32nd of the rows with eight loads in flight, the partial sums meet in
+// LDS, and every segment then rewrites its rows as running offsets.
 #define BSCAN_COLS 32
 #define BSCAN_SEGS 32   // (16 segments with four loads in flight: 11.5 us at eight views, 21 us at one view's 1172 rows of 256 instances)
 __global__ __launch_bounds__(BSCAN_COLS * BSCAN_SEGS) void k_bin_scan(int gx, int T, int nblk, int bb, const uint32_t* __restrict__ db_nvis,
@@ -1725,7 +1743,11 @@ __global__ __launch_bounds__(BIN_SC_THREADS) void k_bin_scatter(int N, int T, in
                 unsigned long long amE = 0ull;
                 if (use) {   // (no loop over the rows: the lanes' rectangles differ and the wave would run to the tallest)
                     const unsigned long long rb = w >= 64u ? ~0ull : ((1ull << w) - 1ull);
-                    const unsigned long long rowm = (rb * s_comb[min(w, 64u)]) << ((uint32_t)(bin_y0(r.xy) & 1) * (w & 63u));
+                    const unsigned long long evens = rb * s_comb[min(w, 64u)];   // rows 0, 2, ... of the rectangle
+                    // a rectangle that starts on an odd box row has its rows 1, 3, ... on even box rows: the comb moves up one
+                    // row.  A row of 64 tiles (w == 64, one row: tiles <= 64) has no second row -- and a shift by 64 is none
+                    // at all: on an odd box row such a rectangle belongs to the odd list entirely
+                    const unsigned long long rowm = (bin_y0(r.xy) & 1) ? (w >= 64u ? 0ull : evens << w) : evens;
                     amE = am & rowm;
                 }
                 const unsigned long long amU = use ? am : 0ull;

@@ -900,8 +900,9 @@ class Trainer:
         # persistent_grads (one rank): the compute object keeps the gradient buffers (HipViewCompute's own default): the
         # tensors in a step's `out["grads"]` are overwritten by the next step -- the optimizer has consumed them by then
         # (see train_step).  False: fresh tensors every step.
+        # (only ever narrowed: a compute object built with persistent_grads=False keeps handing out fresh tensors)
         if hasattr(compute, "persistent_grads"):
-            compute.persistent_grads = bool(persistent_grads) and world_size == 1
+            compute.persistent_grads = bool(compute.persistent_grads) and bool(persistent_grads) and world_size == 1
         self.compact_allreduce = compact_allreduce and not sharded_adam
         self.sharded_adam = bool(sharded_adam) and world_size > 1
         from . import rasterizer

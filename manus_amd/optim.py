@@ -229,12 +229,16 @@ class GaussianOptimizer:
         g2, vis = f32c(grad2d_sum).reshape(-1), f32c(vis_count).reshape(-1)
         rad = radii_max.reshape(-1)
         rad = (rad if rad.dtype == torch.int32 else rad.to(torch.int32)).contiguous()
-        for name in ("xyz_gradient_accum", "denom", "max_radii2D"):      # (a caller may have assigned its own tensors)
-            t = getattr(self, name)
-            if t.dtype != torch.float32 or not t.is_contiguous():
-                setattr(self, name, f32c(t))
         if g2.numel() != N or vis.numel() != N or rad.numel() != N:
             raise ManusHipError("add_densification_stats: statistics must have %d entries" % N)
+        for name in ("xyz_gradient_accum", "denom", "max_radii2D"):
+            # the kernel writes N floats through a raw pointer into each accumulator: a tensor of another size (assigned by
+            # a caller, or left behind by a resize) would be written out of bounds where the torch ops raised a shape error
+            t = getattr(self, name)
+            if not t.is_cuda or t.numel() != N:
+                raise ManusHipError("add_densification_stats: %s has %d entries, the model %d" % (name, t.numel(), N))
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                raise ManusHipError("add_densification_stats: %s must be a contiguous float32 tensor (it is updated in place)" % name)
         check(lib().mgr_add_densification_stats(N, ptr(g2), ptr(vis), ptr(rad), ptr(self.xyz_gradient_accum), ptr(self.denom),
                                                 ptr(self.max_radii2D), stream()), "mgr_add_densification_stats")
 

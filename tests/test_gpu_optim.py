@@ -183,3 +183,8 @@ def test_add_densification_stats_kernel():
             go.add_densification_stats(g2.to(DEV), vis.to(DEV), rad.to(DEV))
     assert torch.equal(go.xyz_gradient_accum.cpu(), acc) and torch.equal(go.denom.cpu(), den) and torch.equal(go.max_radii2D.cpu(), mx)
     assert go.xyz_gradient_accum.shape == (N, 1) and go.max_radii2D.shape == (N,)
+    # an accumulator of another size (a caller's tensor, a missed resize) is refused, not written out of bounds
+    from manus_amd._lib import ManusHipError
+    go.denom = go.denom[: N - 7].clone()
+    with pytest.raises(ManusHipError):
+        go.add_densification_stats(g2.to(DEV), vis.to(DEV), rad.to(DEV))

@@ -491,6 +491,57 @@ def test_ordered_binning_equals_sorted_route(kind, n, views, size, sigma, monkey
     assert torch.equal(got["sorted"][0], got["ordered"][0])
 
 
+def test_row_of_64_tiles_on_an_odd_box_row(monkeypatch):
+    """k_bin_scatter splits a batch's pairs into the tiles on even and on odd rows of the view's tile box (one consumer wave
+    each).  A rectangle exactly 64 tiles wide and one tile high -- a 1000-px Gaussian clipped to the image's last tile row --
+    on an ODD box row is the case where the even-row comb must not be shifted by 64 (= not at all): its tiles belong to
+    the odd list, next to those of the small Gaussians that share the row in the same batch of 64 depth-consecutive
+    instances (round-5 advisor finding: they went to the even list, two waves then raced on the same cursors)."""
+    W, H = 1920, 1080
+    cam = make_camera(W, H, pos=(0, 0, -1.5))
+    f = 1.2 * W
+    rng = np.random.default_rng(3)
+    n = 600
+    px, py, Z = rng.uniform(560, 1360, n), rng.uniform(1067.5, 1078, n), rng.uniform(-0.05, 0.05, n)
+    d = 1.5 + Z
+    m = np.stack([(959.5 - px) * d / f, (539.5 - py) * d / f, Z], 1).astype(np.float32)
+    s, sw = 0.0019, 0.103
+    c = np.tile(np.array([s * s, 0, 0, s * s, 0, s * s], np.float32), (n, 1))
+    op = rng.uniform(0.3, 0.95, n).astype(np.float32)
+    # the wide one: isotropic, 497 px of radius, centred 490 px below the image, in the middle of the depth range
+    m = np.concatenate([m, np.array([[-0.0005, -0.671, 0.0]], np.float32)])
+    c = np.concatenate([c, np.array([[sw * sw, 0, 0, sw * sw, 0, sw * sw]], np.float32)])
+    op = np.concatenate([op, np.array([0.99], np.float32)])
+    col = rng.uniform(0, 1, size=(n + 1, 3)).astype(np.float32)
+    o = _oracle(cam, m, c, col, op)
+    r = o.geom()["rect"]
+    assert r[n, 2] - r[n, 0] == 64 and r[n, 3] - r[n, 1] == 1 and r[n, 1] == 67        # 64 x 1 tiles on the last tile row
+    assert r[:n, 1].min() == 66                                                          # ... which is row 1 of the box
+    opl, org = o.binning()
+    shared = [t for t in range(67 * 120, 68 * 120) if n in opl[org[t, 0]:org[t, 1]] and org[t, 1] - org[t, 0] > 8]
+    assert len(shared) > 30                                                              # tiles it shares with many others
+    from manus_amd import rasterizer as rz
+    from test_gpu_fused import _layout
+    lists = {}
+    for route in ("ordered", "ordered", "ordered", "sorted"):      # (the race of the two waves was not deterministic: three runs)
+        monkeypatch.setenv("MGR_BINNING", route)
+        h = _hip([cam], m, c, col, op)
+        assert (h["radii"][0] == o.radii).all()
+        npairs, ranges, pl = _binning(0, 1, n + 1, W, H)
+        assert npairs == o.num_rendered
+        _check_lists_vs_oracle(o, ranges, pl, W, H)
+        assert np.abs(h["img"][0] - o.color).max() < 5e-3
+        if route == "ordered":
+            ws = rz.context().last_ws
+            L = _layout(1, n + 1, W, H, ws.cap)
+            bb = ws.buf[L["db_bbox"]: L["db_bbox"] + 8].view(torch.int16).int().tolist()
+            assert (67 - bb[1]) % 2 == 1 and bb[2] * bb[3] <= 1536, bb                  # odd box row, the lane-mask route
+        prev = lists.setdefault(route, (ranges.copy(), pl.copy(), h["img"].copy()))
+        assert (prev[0] == ranges).all() and (prev[1] == pl).all() and (prev[2] == h["img"]).all()
+    assert (lists["ordered"][0] == lists["sorted"][0]).all() and (lists["ordered"][1] == lists["sorted"][1]).all()
+    assert (lists["ordered"][2] == lists["sorted"][2]).all()
+
+
 @pytest.mark.parametrize("size", [(3840, 2160), (6016, 4000)])
 def test_large_tile_grids_against_oracle(size):
     """Tile grids beyond the usual: 4K (32 400 tiles: LDS histograms and the ordered binning's whole-grid cursors, one

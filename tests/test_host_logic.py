@@ -109,6 +109,8 @@ def test_library_exports_every_declared_symbol():
         assert n in _lib.SIGNATURES, "python binding missing for " + n
     assert set(_lib.SIGNATURES) == set(names)
     assert _lib.lib().mgr_version() == 100
+    # the product build carries no knock-out / instrumentation switch (tools/instr variants report their bits here)
+    assert _lib.lib().mgr_build_variant() == 0
 
 
 def test_argument_validation_without_gpu():
