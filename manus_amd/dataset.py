@@ -294,6 +294,46 @@ def _area_resize(img, factor):
     return cv2.resize(img, (0, 0), fx=factor, fy=factor, interpolation=cv2.INTER_AREA)
 
 
+@dataclass
+class _Take:
+    """One recorded action of the subject: its container file, frame keys and cameras."""
+    name: str                 # file name up to the first '.', the key of metadata_dict and of the items
+    file: str                 # file name inside the dataset directory
+    path: str
+    frames_as_stored: list    # frame keys in the container's order
+    frames: list              # ... in natural order (the order items are generated in)
+    cams: list
+
+
+def _scan_takes(root_dir, wanted="all"):
+    """The takes of a subject directory in natural file order, or those named by `wanted` in the order given."""
+    files = natsorted([f for f in os.listdir(root_dir) if f.endswith((".hdf5", ".npz"))])
+    if wanted != "all":
+        files = [f for w in wanted for f in files if f.rsplit(".", 1)[0] == w]
+    takes = []
+    for f in files:
+        path = os.path.join(root_dir, f)
+        with open_sequence(path) as file:
+            stored, cams = list(file["frames"].keys()), list(file.get("K").keys())
+        takes.append(_Take(f.split(".")[0], f, path, stored, natsorted(stored), cams))
+    return takes
+
+
+def _strided(frames, n_steps):
+    """Every (len // n_steps)-th frame -- all of them when n_steps is negative or exceeds their number."""
+    if n_steps < 0 or n_steps > len(frames):
+        return list(frames)
+    return list(frames[::len(frames) // n_steps])
+
+
+def _split_part(seq, ratio, split):
+    """The train (front) or test (back) part of a sequence cut at int(ratio * len); the whole of it for ratio <= 0."""
+    if ratio <= 0:
+        return list(seq)
+    cut = int(ratio * len(seq))
+    return list(seq[:cut] if split == "train" else seq[cut:])
+
+
 class SequenceDataset(torch.utils.data.Dataset):
     """brics_dynamic.py::Dataset: one subject, several actions, every (action, frame, camera) one item (or one item per
     (action, frame) with `rand_views_per_timestep` random cameras)."""
@@ -306,11 +346,25 @@ class SequenceDataset(torch.utils.data.Dataset):
         self.resize_factor, self.bg_color = o["resize_factor"], o["bg_color"]
         self.width, self.height, self.subject_id = o["width"], o["height"], o["subject"]
         self.split_file_dir = split_file_dir
-        self.actions, self.index_list, self.metadata_dict, to_choose = self.dataset_index_list(
-            root_dir, split, o["num_time_steps"], o["split_ratio"], o["rand_views_per_timestep"])
-        self.get_all_cameras(to_choose)
+        takes = self._takes_of_split(_scan_takes(root_dir, o["sequences"]), split, o["split_ratio"], o["split_by_action"])
+        self.actions = [t.file for t in takes]
+        self.metadata_dict = {t.name: self._pose_records(t) for t in takes}
+        # the item table: (take, frame) rows in take order, every `stride`-th frame of a take; one item per row and camera,
+        # or one per row when the cameras are drawn at random per item (rand_views_per_timestep >= 0)
+        rows = [(t, f) for t in takes for f in _strided(t.frames, o["num_time_steps"])]
+        per_camera = o["rand_views_per_timestep"] < 0
+        items = [(t.name, f, c) for t, f in rows for c in (t.cams if per_camera else (None,))]
+        if not o["split_by_action"]:
+            # (a single take with split_by_action is the one case where the ratio is ignored altogether: _takes_of_split)
+            items = _split_part(items, o["split_ratio"], split)
+            if split_file_dir is not None:           # the reference always drops ./<split>_split.json in the cwd
+                with open(os.path.join(split_file_dir, "%s_split.json" % split), "w") as f:
+                    json.dump(items, f)
+        self.index_list = items
+        # the camera table holds the rig once per kept frame of the LAST take (brics_dynamic.py:215-263 repeats it like
+        # that; items only ever index its first copy through cam2idx)
+        self._load_rig(copies=len(_strided(takes[-1].frames, o["num_time_steps"])) if takes else 0)
 
-    # -- brics_dynamic.py:145-213 ---------------------------------------------------------------------------
     def _path(self, action):
         for ext in (".hdf5", ".npz"):
             p = os.path.join(self.root_dir, action + ext)
@@ -318,63 +372,40 @@ class SequenceDataset(torch.utils.data.Dataset):
                 return p
         raise FileNotFoundError(os.path.join(self.root_dir, action + ".hdf5"))
 
-    def dataset_index_list(self, root_dir, split, num_time_steps, split_ratio, rand_views_per_timestep):
-        o = self.opts
-        actions = natsorted([fp for fp in os.listdir(root_dir) if fp.endswith((".hdf5", ".npz"))])
-        if o["sequences"] != "all":
-            wanted = [a for a in o["sequences"]]
-            actions = [f for a in wanted for f in actions if f.rsplit(".", 1)[0] == a]
-        if len(actions) == 1 and o["split_by_action"]:
-            split_ratio = -1
-        if split_ratio > 0 and o["split_by_action"]:
-            cut = int(split_ratio * len(actions))
-            actions = actions[:cut] if split == "train" else actions[cut:]
-        index_list, metadata_dict, to_choose = [], {}, []
-        for action_path in actions:
-            action = action_path.split(".")[0]
-            metadata_dict[action] = {}
-            with open_sequence(os.path.join(root_dir, action_path)) as file:
-                frame_nos = list(file["frames"].keys())
-                cam_names = list(file.get("K").keys())
-                for fno in frame_nos:
-                    md = self.fetch_metadata(file["frames"][fno]["metadata"])
-                    md["frame_id"], md["action"] = fno, action
-                    metadata_dict[action][fno] = md
-            frame_nos = natsorted(frame_nos)
-            if num_time_steps < 0 or num_time_steps > len(frame_nos):
-                to_choose = frame_nos
-            else:
-                to_choose = frame_nos[::(len(frame_nos) // num_time_steps)]
-            for fno in to_choose:
-                if rand_views_per_timestep < 0:
-                    index_list.extend((action, fno, view) for view in cam_names)
-                else:
-                    index_list.append((action, fno, None))
-        if not o["split_by_action"]:
-            if split_ratio > 0:
-                cut = int(split_ratio * len(index_list))
-                index_list = index_list[:cut] if split == "train" else index_list[cut:]
-            if self.split_file_dir is not None:      # the reference always drops ./<split>_split.json in the cwd
-                with open(os.path.join(self.split_file_dir, "%s_split.json" % split), "w") as f:
-                    json.dump(index_list, f)
-        return actions, index_list, metadata_dict, to_choose
+    @staticmethod
+    def _takes_of_split(takes, split, ratio, by_action):
+        """Train / test by whole takes (brics_dynamic.py:156-165): the first int(ratio * n) takes train, the rest test;
+        one take alone is never split this way."""
+        if by_action and len(takes) > 1:
+            return _split_part(takes, ratio, split)
+        return takes
 
-    # -- brics_dynamic.py:215-263 ---------------------------------------------------------------------------
-    def get_all_cameras(self, to_choose):
-        action = self.index_list[0][0]               # the rig is the same for every action
-        cols = {}
-        with open_sequence(self._path(action)) as file:
-            self.mano_data = {k: v[:] for k, v in file.get("mano_rest").items()} if file.get("mano_rest") is not None else {}
+    def _pose_records(self, take):
+        """{frame: pose record} of EVERY frame of a take (brics_dynamic.py:173-188 reads them all, kept or not)."""
+        out = {}
+        with open_sequence(take.path) as file:
+            for f in take.frames_as_stored:
+                rec = self._pose_record(file["frames"][f]["metadata"])
+                rec["frame_id"], rec["action"] = f, take.name
+                out[f] = rec
+        return out
+
+    def _load_rig(self, copies):
+        """all_cameras / cam_names / cam2idx / mano_data / extent from the first item's take (one rig per subject)."""
+        cols = collections.defaultdict(list)
+        with open_sequence(self._path(self.index_list[0][0])) as file:
+            mano = file.get("mano_rest")
+            self.mano_data = {k: v[:] for k, v in mano.items()} if mano is not None else {}
             Ks, extrs = file.get("K"), file.get("extr")
             self.cam_names = list(Ks.keys())
             self.cam2idx = {c: i for i, c in enumerate(self.cam_names)}
-            for _ in to_choose:                      # (the reference repeats the rig once per chosen time step)
-                for cam in self.cam_names:
-                    attrs = get_opengl_camera_attributes(Ks[cam][:], extrs[cam][:], self.width, self.height,
-                                                         resize_factor=self.resize_factor)
-                    for k, v in attrs.items():
-                        cols.setdefault(k, []).append(v)
-                    cols.setdefault("cam_name", []).append(cam)
+            rig = [(c, get_opengl_camera_attributes(Ks[c][:], extrs[c][:], self.width, self.height, resize_factor=self.resize_factor))
+                   for c in self.cam_names]
+        for _ in range(copies):
+            for cam, attrs in rig:
+                for k, v in attrs.items():
+                    cols[k].append(v)
+                cols["cam_name"].append(cam)
         self.all_cameras = Cameras(**{k: np.stack(v, 0) for k, v in cols.items()})
         self.extent = get_scene_extent(self.all_cameras.camera_center)
 
@@ -390,22 +421,21 @@ class SequenceDataset(torch.utils.data.Dataset):
         except (ValueError, KeyError):
             return None
 
-    # -- brics_dynamic.py:279-327 ---------------------------------------------------------------------------
-    def fetch_metadata(self, metadata):
-        def names(key):
-            return [n[0].decode("UTF-8") if isinstance(n[0], bytes) else str(n[0]) for n in metadata[key][:].tolist()]
-        bnames, parents = np.array(names("bnames")), names("bnames_parent")
-        ids = np.arange(self.opts["n_bones"]).tolist()
-        rest = Bones(bnames=bnames, heads=metadata["rest_heads"][ids], tails=metadata["rest_tails"][ids],
-                     transforms=metadata["rest_matrixs"][ids])
-        eulers = metadata["eulers"][:]
-        r_T, r_R = metadata["root_translation"][:], metadata["root_rotation"][:]
-        posed = Bones(bnames=bnames, heads=metadata["pose_heads"][ids], tails=metadata["pose_tails"][ids],
-                      transforms=metadata["pose_matrixs"][ids], eulers=eulers,
-                      eulers_c=apply_constraints_to_poses(eulers[None], bnames), root_translation=r_T, root_rotation=r_R,
-                      kintree=T.build_kintree(bnames, parents))
-        quats = euler_angles_to_quats(torch.tensor(np.concatenate([eulers, r_R[None]], 0), dtype=torch.float32))
-        return {"bones_rest": rest, "bones_posed": posed, "pose_latent": quats.flatten()}
+    def _pose_record(self, g):
+        """One frame's metadata group -> {"bones_rest", "bones_posed", "pose_latent"} (the dict brics_dynamic.py:279-327
+        builds: the first n_bones rows of the rest / posed armature, constrained Euler angles, the kinematic tree, and the
+        latent = quaternions of the joint angles followed by the root rotation)."""
+        def strings(key):
+            return [n[0].decode("UTF-8") if isinstance(n[0], bytes) else str(n[0]) for n in g[key][:].tolist()]
+        rows = list(range(self.opts["n_bones"]))
+        names = np.array(strings("bnames"))
+        armature = {kind: dict(bnames=names, heads=g[kind + "_heads"][rows], tails=g[kind + "_tails"][rows], transforms=g[kind + "_matrixs"][rows])
+                    for kind in ("rest", "pose")}
+        angles, root_R = g["eulers"][:], g["root_rotation"][:]
+        posed = Bones(**armature["pose"], eulers=angles, eulers_c=apply_constraints_to_poses(angles[None], names),
+                      root_translation=g["root_translation"][:], root_rotation=root_R, kintree=T.build_kintree(names, strings("bnames_parent")))
+        latent = euler_angles_to_quats(torch.tensor(np.concatenate([angles, root_R[None]], 0), dtype=torch.float32)).flatten()
+        return {"bones_rest": Bones(**armature["rest"]), "bones_posed": posed, "pose_latent": latent}
 
     # -- brics_dynamic.py:334-373 ---------------------------------------------------------------------------
     def get_bg_color(self):
