@@ -130,6 +130,17 @@ size_t mgr_raster_workspace_bytes(int V, int N, int W, int H, int64_t pair_capac
  * a pixel that has not saturated the forward raises the overflow word's bit 1 (mgr_raster_status_sync: MGR_ECUT) and
  * the caller runs it again without bit 8.  Pass the bit to both calls of a forward split with bits 2 / 4.  No
  * counterpart upstream (the reference renders one view per step and re-bins everything).
+ * 2048 (with bit 8) = repair on the device.  A tile whose cut list runs out under an unsaturated pixel is completed by
+ * two kernels behind the blend instead of flagging the forward: the instances the cut dropped from that tile are found
+ * (one pass over the view's rectangles), sorted by (depth, index) -- the tail of the tile's full list --, appended
+ * behind the regular lists, and the walks of the tile's unsaturated quadrants continue from their saved state; the
+ * backward's work items of such a tile point at the appended entries / checkpoints.  Image, n_contrib and gradients
+ * stay bit for bit those of the full lists and NO re-run is needed; MGR_ECUT is only raised when a capacity of the repair
+ * is exceeded (repaired quadrants, 256 tiles per view, 8192 entries behind the cut of one tile, the appended entries: all
+ * sized from pair_capacity), or when a hinted tile ends up with no list at all.  A tile that ran out gets no hint for the
+ * next mgr_raster_set_cut_penalty forwards (the same few tiles at the rim of the saturating region otherwise run out
+ * step after step under a moving model).  The status mirror's overflow word carries the number of repaired quadrants
+ * of the forward in its bits 16..31.
  * 16 / 32 = skip the binning launches that only serve views whose box of non-empty tiles has more than 2048 / has
  * 1537..2048 tiles (they hold more LDS per workgroup; three launches of ~6 us each that do nothing for smaller boxes).
  * mgr_raster_status_tiers_sync reports which of them a forward needed (bit 0 / bit 1); pass the bits for the tiers the
@@ -234,8 +245,10 @@ int mgr_sh_to_half(int N, const float* f_rest, void* out_half, void* stream);
  * ckpt, keys, sorted_gid, final_T (reserved, not written), n_contrib, pair_tag, pair_grad, total, inst_grad
  * (fused backward: per (Gaussian, view-lane) the 9 gathered blend sums, 12 floats each, then the active list),
  * inst_tag, db_nvis (per view: instances with at least one non-null tile), db_bbox (per view: ushort4 x0, y0, w, h of the
- * non-empty tiles), db_order (per view: those instances in (depth, index) order) -- the last three belong to the
- * depth-ordered binning.  Returns the count. */
+ * non-empty tiles), db_order (per view: those instances in (depth, index) order) -- these three belong to the
+ * depth-ordered binning --, tile_zcut, tile_zused, tile_qend (depth cut: hint of the next forward / applied / end of the
+ * tile's walks), tile_rep, rep_unit, rep_cnt (repair of depth-cut tiles: owner unit + 1 per tile, the 64-byte unit records,
+ * entries found behind the cut per owner unit).  Returns the count. */
 int mgr_raster_layout(int V, int N, int W, int H, int64_t pair_capacity, size_t* out, int n_out);
 
 /* Blocking read-back of the workspace header after a forward: total number of
@@ -247,6 +260,8 @@ int mgr_raster_layout(int V, int N, int W, int H, int64_t pair_capacity, size_t*
  * too (a silhouette tile stops saturating when an edge moves by a fraction of a pixel).  Defaults 0.125, 64, 0.0625, 2e-4, 0.
  * Wider margins: more pairs binned, fewer forwards flagged MGR_ECUT when the model moves between two forwards of a view. */
 int mgr_raster_set_cut_margin(float frac_entries, int min_entries, float depth_range_frac, float depth_rel, int interior_only);
+/* Forwards (of this host thread) for which a tile whose cut list ran out receives no hint; default 16, 0 = none. */
+int mgr_raster_set_cut_penalty(int forwards);
 /* Status without a copy: `host_words` points to 4 uint32 of host memory the device can write (hipHostMalloc / pinned
  * memory); the next forward that runs the blend on `workspace` writes (pair total, overflow word, binning tiers, 1) there
  * from its last kernel.  An event recorded behind that forward then tells the host when the words are valid -- no

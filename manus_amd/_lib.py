@@ -38,6 +38,7 @@ SIGNATURES = {
     "mgr_raster_status_sync": (c_int, [c_vp, ctypes.POINTER(c_i64), ctypes.POINTER(ctypes.c_int32), c_vp]),
     "mgr_raster_set_status_mirror": (c_int, [c_vp, c_vp]),
     "mgr_raster_set_cut_margin": (c_int, [c_f32, c_int, c_f32, c_f32, c_int]),
+    "mgr_raster_set_cut_penalty": (c_int, [c_int]),
     "mgr_raster_status_tiers_sync": (c_int, [c_vp, ctypes.POINTER(c_i64), ctypes.POINTER(ctypes.c_int32),
                                              ctypes.POINTER(ctypes.c_int32), c_vp]),
     "mgr_debug_pair_alpha": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),

@@ -59,6 +59,40 @@ struct MgrProfScope {
 // ---------------------------------------------------------------------------
 // workspace layout of the rasterizer (shared by forward and backward)
 // ---------------------------------------------------------------------------
+// repair of depth-cut tiles on the device (described below, next to MGR_CHUNK)
+#define MGR_WHY_UNITS 1u        // more quadrants ran out than the repair has units for (or the repair is off)
+#define MGR_WHY_VIEW_TILES 2u   // more repaired tiles in one view than MGR_REP_VIEW_TILES
+#define MGR_WHY_CAND 4u         // more instances behind a tile's cut (inside the depth window) than MGR_REP_CAND
+#define MGR_WHY_LIST 8u         // the appended entries / checkpoints are used up
+#define MGR_WHY_EMPTY 16u       // a hinted tile ended up with no list at all
+#define MGR_WHY_WINDOW 32u      // a repaired walk reached the end of its depth window unsaturated with instances left behind it
+#define MGR_REP_CAND 8192          // instances behind the cut one repaired tile may hold (one LDS sort)
+#define MGR_REP_TARGET 3072        // ... of which the scan aims for this many: the depth window behind the cut (tile_zwin, k_fwd_items)
+#define MGR_REP_VIEW_TILES 256     // repaired tiles per view and forward
+struct __attribute__((aligned(16))) MgrRepUnit {      // 64 bytes
+    uint32_t vt, quad, nlist, start;      // tile (view * T + tile), quadrant, length and offset of the CUT list
+    uint32_t ck0, done_lo, done_hi, ntail;   // first checkpoint of the tile; lanes whose walk had ended; entries appended (owner unit; 0: none)
+    uint32_t ov_start, ov_ck0, p0, ck_first;   // owner unit: list offset of entry p0 = 64 * (nlist / 64), checkpoint in front of chunk c > p0 / 64 at ov_ck0 + c - p0 / 64, of chunk p0 / 64 at ck_first
+    uint32_t beyond;                      // owner unit: instances behind the cut AND behind the depth window (not collected)
+    uint32_t pad[3];
+};
+struct __attribute__((aligned(16))) MgrRepTile {      // one repaired tile of a view (k_repair_prep -> k_repair_scan)
+    uint32_t tile, unit, zc, zw;          // tile of the view, owner unit, float bits of the depth of the cut / of the end of the depth window
+};
+struct MgrRepView {       // per view: its repaired tiles of the forward in flight
+    uint32_t n, x0, y0, x1, y1, pad[3];   // count; bounding box of the repaired tiles (tile units, x1 / y1 exclusive)
+    MgrRepTile t[MGR_REP_VIEW_TILES];
+};
+struct MgrRep {           // device pointers of the repair state (max_units == 0: repair off)
+    MgrRepUnit* unit;
+    float4* state;        // [unit][64] prefix colour + transmittance of the quadrant's pixels at the end of the cut list
+    uint32_t* last;       // [unit][64] last contributor
+    uint32_t* cnt;        // [unit] candidates found (owner units)
+    uint32_t* tile_rep;   // [V * T] owner unit + 1 of a repaired tile (0: none)
+    unsigned long long* cand;   // [unit][MGR_REP_CAND] (depth bits << 32 | Gaussian)
+    MgrRepView* view;     // [V]
+    uint32_t max_units, list_cap, ck_cap, list_base, ck_base;   // capacities; first appended entry / checkpoint index
+};
 struct MgrHeader {            // first 256 bytes of the workspace
     uint32_t total_pairs;     // sum of tiles_touched over all views (may exceed capacity); published by k_tile_scan_b
     uint32_t overflow;        // MGR_OVF_* bits of the most recent forward (k_tile_scan_b: pairs; k_fwd_items adds the depth-cut flag)
@@ -92,7 +126,13 @@ struct MgrHeader {            // first 256 bytes of the workspace
     // completed an image (k_fwd_items), the image it wrote and its background colour -- tile_bgok says which tiles of THAT image
     // hold the background
     uint32_t fwd_seq, img_seq, img_owner[2], img_bg[3];
-    uint32_t spare[52];       // (the size-class counters of the tile scan lived here: it now derives them from per-block histograms)
+    // depth cut, repaired on the device (forward debug bit 2048; see MgrRepUnit): (tile, quadrant) units registered by the blend
+    // of the forward in flight, entries / checkpoints handed out behind the regular lists; reset by k_tile_scan_b
+    uint32_t n_rep_units, rep_list_used, rep_ck_used;
+    uint32_t rep_why;         // why the forward in flight raised MGR_OVF_CUT (bits MGR_WHY_*; k_tile_scan_a clears it)
+    MgrRep rep;               // the repair's pointers / capacities of the forward in flight (k_tile_scan_b copies its argument here: the
+                              // forward blend reads them in its rare "list ran out" branch instead of carrying 17 more scalars)
+    uint32_t spare[48 - sizeof(MgrRep) / 4];
     uint32_t queue_giant;     // queue index of the first tile with fewer than 16384 pairs
     uint32_t n_groups;        // depth groups produced by k_tile_split for the giant tiles
     uint32_t split_head, group_head;
@@ -123,10 +163,33 @@ struct __attribute__((aligned(16))) MgrGRec {
 
 #define MGR_CHUNK 64         // list entries per backward work item / forward checkpoint interval (one batch of the blend waves)
 
+// ---------------------------------------------------------------------------
+// Depth cut, repaired on the device (round 6; mgr_views_forward debug bits 8 + 2048).
+//
+// A forward with the depth cut drops, per tile, the instances behind the depth at which the tile's pixels had all saturated
+// in the previous forward (+ a margin).  When the model moves, a few tiles per step run out of list under a pixel that has
+// not saturated (measured with Adam at the reference's learning rates on the bench scene: 6 tiles per step at the default
+// margins, 36 at half of them -- tools/instr/cut_flag_stats.py).  Up to round 5 such a forward was flagged and the WHOLE
+// step run again on full lists, which made the cut useless under an optimizer.  Now the blend wave that runs out registers
+// a repair unit = (tile, quadrant, the 64 pixels' state); behind the blend
+//   k_repair_scan   finds, per repaired tile, the instances the cut dropped from it (one pass over the view's rectangles:
+//                   rectangle covers the tile, depth behind the cut, not null by the exact cull test of the binning),
+//   k_repair_blend  sorts them by (depth, index) = the tail of the tile's full list, appends it behind the regular lists
+//                   (the last partial 64-entry chunk of the cut list is copied in front of it, so that the backward's
+//                   chunks stay contiguous), and walks it from the saved state: image, n_contrib, checkpoints, consumed
+//                   depth -- bit for bit what the walk of the full list leaves,
+// and k_fwd_items points the backward's work items of the repaired tiles at the appended lists / checkpoints.  The forward
+// is only flagged (MGR_OVF_CUT: re-run without the cut) when a capacity below is exceeded.
+// ---------------------------------------------------------------------------
+// repair capacities as a function of the pair capacity (small scenes: small workspaces)
+static inline uint32_t mgr_rep_units(int64_t cap) { int64_t u = cap / 16384; return (uint32_t)(u < 64 ? 64 : (u > 1024 ? 1024 : u)); }
+static inline uint32_t mgr_rep_list(int64_t cap) { int64_t n = cap / 8; return (uint32_t)(n < (1 << 16) ? (1 << 16) : (n > (2 << 20) ? (2 << 20) : n)); }
+static inline uint32_t mgr_rep_ck(int64_t cap) { return mgr_rep_list(cap) / MGR_CHUNK + mgr_rep_units(cap); }
+
 struct MgrLayout {
     size_t header, scan_part, scan_cls, scan_box, grec, depth, rect, alive, pair_off, tile_count, tile_start, tile_cursor, tile_done, tile_qdone,
         tile_zcut, tile_zused, tile_qend, tile_bgok, tile_queue, tile_qrec, chunk_start, items, ckpt, keys, keys2, groups, sorted_gid, final_T, n_contrib, pair_tag, pair_grad, inst_grad, inst_tag,
-        db_count, db_cursor, db_start, db_nvis, db_bbox, db_keys, db_order, db_rec, bin_mat, total;
+        db_count, db_cursor, db_start, db_nvis, db_bbox, db_keys, db_order, db_rec, bin_mat, tile_rep, rep_unit, rep_state, rep_last, rep_cnt, rep_cand, rep_view, tile_zwin, total;
 };
 
 // Depth-ordered binning (raster_fwd.hip, "ordered" route): the instances of a view are sorted by depth once, then
@@ -173,12 +236,13 @@ static inline MgrLayout mgr_layout(int V, int N, int W, int H, int64_t cap) {
     L.tile_queue = o;  o += mgr_align(VT * 4);
     L.tile_qrec = o;   o += mgr_align(VT * 16);       // queue of the forward blend, interleaved by view: position p = (tile, list offset, list length, first checkpoint) of a tile of view p % V, or a hole
     L.chunk_start = o; o += mgr_align((VT + 1) * 4);
-    L.items = o;       o += mgr_align((c / MGR_CHUNK + VT + 1) * 32);   // 32-byte record per (tile, chunk) work item of the backward blend
-    L.ckpt = o;        o += mgr_align((c / MGR_CHUNK + 1) * 256 * 16);  // float4 per pixel per checkpoint
+    const size_t rep_u = mgr_rep_units(cap), rep_l = mgr_rep_list(cap), rep_c = mgr_rep_ck(cap);   // (repaired depth-cut tiles append behind the regular entries)
+    L.items = o;       o += mgr_align((c / MGR_CHUNK + VT + 1 + rep_c) * 32);   // 32-byte record per (tile, chunk) work item of the backward blend
+    L.ckpt = o;        o += mgr_align((c / MGR_CHUNK + 1 + rep_c) * 256 * 16);  // float4 per pixel per checkpoint
     L.keys = o;        o += mgr_align(c * 8);
     L.keys2 = o;       o += mgr_align(c * 8);       // giant tiles: keys regrouped by depth range
     L.groups = o;      o += mgr_align((c / 4096 + 64) * 16);  // (src offset, count) of every depth group
-    L.sorted_gid = o;  o += mgr_align(c * 4);
+    L.sorted_gid = o;  o += mgr_align((c + rep_l) * 4);
     L.final_T = o;     o += mgr_align(VP * 4);
     L.n_contrib = o;   o += mgr_align(VP * 4);
     L.pair_tag = o;    o += mgr_align(c * 4 + 64);
@@ -198,6 +262,16 @@ static inline MgrLayout mgr_layout(int V, int N, int W, int H, int64_t cap) {
         L.bin_mat = o;   o += mgr_align((size_t)V * nblk * gx * gy * 4);   // pairs per (block of the order, tile) -> list offsets
     }
     L.tile_bgok = o; o += mgr_align((size_t)V * gx * gy);   // one byte per tile: the caller's image holds the background colour there ("image kept")
+    L.tile_rep = o;  o += mgr_align(VT * 4);
+    L.rep_unit = o;  o += mgr_align(rep_u * sizeof(MgrRepUnit));
+    L.rep_state = o; o += mgr_align(rep_u * 64 * 16);
+    L.rep_last = o;  o += mgr_align(rep_u * 64 * 4);
+    L.rep_cnt = o;   o += mgr_align(rep_u * 4);
+    L.rep_cand = o;  o += mgr_align(rep_u * (size_t)MGR_REP_CAND * 8);
+    L.rep_view = o;  o += mgr_align((size_t)V * sizeof(MgrRepView));
+    // depth cut: per tile the float bits of the depth behind which the repair of a tile that ran out stops collecting (about
+    // MGR_REP_TARGET entries behind the cut; written with the hint by a forward that saw the tile's full list, kept otherwise)
+    L.tile_zwin = o; o += mgr_align(VT * 4);
     L.total = o;
     return L;
 }

@@ -582,7 +582,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan_a(int T, int nbT, const uint
     __shared__ uint32_t s_bb[4];
     const int tid = threadIdx.x, v = blockIdx.x / nbT, t = (blockIdx.x % nbT) * 1024 + tid;
     if (tid == 0) { s_bb[0] = 0xFFFFu; s_bb[1] = 0xFFFFu; s_bb[2] = 0u; s_bb[3] = 0u; }
-    if (blockIdx.x == 0 && tid == 0) { hdr->tiers = 0u; hdr->sort_big = 0u; hdr->fwd_seq += 1u; }   // (phase B's depth-bucket workgroups / the sort set them)
+    if (blockIdx.x == 0 && tid == 0) { hdr->tiers = 0u; hdr->sort_big = 0u; hdr->fwd_seq += 1u; hdr->rep_why = 0u; }   // (phase B's depth-bucket workgroups / the sort set them)
     const bool valid = t < T;
     const size_t k = (size_t)v * T + t;
     if (tid < MGR_NCLS) s_cls[tid] = 0;
@@ -623,7 +623,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan_b(int V, int T, int nbT, uin
                                                       uint32_t cap, uint32_t* __restrict__ tile_zcut,
                                                       uint32_t* __restrict__ tile_zused, uint32_t* __restrict__ tile_qend,
                                                       int use_cut, const uint4* __restrict__ blk_box, DbinArgs db,
-                                                      unsigned char* __restrict__ tile_bgok) {
+                                                      unsigned char* __restrict__ tile_bgok, uint32_t* __restrict__ tile_rep, const MgrRep rep) {
     __shared__ uint32_t s_scan[32];
     if ((int)blockIdx.x >= V * nbT) {   // the workgroups behind the scan's: one per view, depth-bucket offsets + tile box
         __shared__ uint32_t s_box[4];
@@ -690,12 +690,18 @@ __global__ __launch_bounds__(1024) void k_tile_scan_b(int V, int T, int nbT, uin
         tile_cursor[k] = 0;
         // depth cut: what this forward applied to the tile moves to tile_zused (the blend's check, k_fwd_items), the hint
         // itself is consumed -- k_fwd_items writes the next one for the tiles that have a list
-        const uint32_t zu = use_cut ? tile_zcut[k] : 0u;
+        // (tile_zcut holds either a hint -- the complement of a positive float's bits: top bit set -- or, round 6, a small
+        // countdown: the tile ran out of list under a cut a few forwards ago and gets no hint until it has counted down;
+        // the countdown stays in place here, k_fwd_items decrements it)
+        const uint32_t zraw = tile_zcut[k];
+        const bool is_hint = (zraw & 0x80000000u) != 0u;
+        const uint32_t zu = (use_cut && is_hint) ? zraw : 0u;
         tile_zused[k] = zu;
-        tile_zcut[k] = 0u;
+        tile_zcut[k] = is_hint ? 0u : zraw;
+        tile_rep[k] = 0u;
         // a tile that had a hint saturated in the forward that left it; if nothing at all is listed for it now, the cut may
         // have taken everything the tile should show and no walk will ever notice: flag it here
-        if (zu != 0u && c == 0u) atomicOr(&hdr->acc_flags, MGR_OVF_CUT);
+        if (zu != 0u && c == 0u) { atomicOr(&hdr->acc_flags, MGR_OVF_CUT); atomicOr(&hdr->rep_why, MGR_WHY_EMPTY); }
         tile_qend[k] = 0u;
         if (c != 0u) tile_bgok[k] = 0;      // the blend will write this tile's pixels ("image kept": see BgFill)
         const uint32_t rank = atomicAdd(&s_lc[cls], 1u);
@@ -717,6 +723,8 @@ __global__ __launch_bounds__(1024) void k_tile_scan_b(int V, int T, int nbT, uin
         hdr->overflow = (s_tot[0] > cap || rect_pairs > cap) ? MGR_OVF_PAIRS : 0u;
         hdr->n_items = 0;
         hdr->item_head = 0;
+        hdr->n_rep_units = 0; hdr->rep_list_used = 0; hdr->rep_ck_used = 0;
+        hdr->rep = rep;
         hdr->queue_len = s_gbase[0];     // class 0 (empty tiles) starts after all non-empty ones
         hdr->queue_len_i = s_maxnb * (uint32_t)V;
         hdr->queue_small = s_gbase[11];  // classes <= 11: fewer than 2048 pairs
@@ -1953,6 +1961,46 @@ __device__ __forceinline__ uint32_t mgr_selu(unsigned long long m, uint32_t a, u
     asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
     return r;
 }
+// One pair step of the front-to-back walk (two list entries at one pixel per lane); true when every pixel of the quadrant has
+// stopped.  ONE definition for the forward blend and for the repair of depth-cut tiles (k_repair_blend), which must continue a
+// walk bit for bit as the forward blend would have.
+// Per entry: a = alpha if kept and the pixel still accumulates, else 0; the walk of a pixel ends where T (1 - a) < 1e-4 (that
+// entry contributes nothing).  The lane masks of the decisions live in scalar registers: "contributes" = kept & not ended &
+// not ending here is formed there, one select per use.
+__device__ __forceinline__ bool mgr_fwd_pair_step(const float4& R0, const float4& R1, const float4& R2, const float4& R3, const float4& R4,
+                                                  const mgr_v2f fpx2, const mgr_v2f fpy2, float& Tr, mgr_v2f& C01, float& C2, uint32_t& last,
+                                                  unsigned long long& done_m, const unsigned long long exec_m) {
+    mgr_v2f al;
+    unsigned long long ma, mb;
+    mgr_pair_alpha_masks(R0, R1, R2, fpx2, fpy2, al, ma, mb);
+    {   // entry a
+        const unsigned long long keep = ma & ~done_m;
+        const float a = mgr_sel(keep, al.x, 0.0f);
+        const float testT = Tr * (1.0f - a);
+        const unsigned long long stop = __builtin_amdgcn_ballot_w64(testT < 0.0001f);  // a == 0 leaves testT = Tr >= 1e-4
+        const unsigned long long contrib = keep & ~stop;
+        const float w = mgr_sel(contrib, a * Tr, 0.0f);
+        C01 += mgr_v2f{R3.x, R3.y} * w;
+        C2 += R4.x * w;
+        Tr = mgr_sel(stop, Tr, testT);
+        last = mgr_selu(contrib, __float_as_uint(R4.z), last);
+        done_m |= stop;
+    }
+    {   // entry b
+        const unsigned long long keep = mb & ~done_m;
+        const float a = mgr_sel(keep, al.y, 0.0f);
+        const float testT = Tr * (1.0f - a);
+        const unsigned long long stop = __builtin_amdgcn_ballot_w64(testT < 0.0001f);
+        const unsigned long long contrib = keep & ~stop;
+        const float w = mgr_sel(contrib, a * Tr, 0.0f);
+        C01 += mgr_v2f{R3.z, R3.w} * w;
+        C2 += R4.y * w;
+        Tr = mgr_sel(stop, Tr, testT);
+        last = mgr_selu(contrib, __float_as_uint(R4.w), last);
+        done_m |= stop;
+    }
+    return (~done_m & exec_m) == 0ull;
+}
 #define FWD_SLOTS 64   // LDS ring of published steps; a reader spins on its slot from the moment it claims, so it cannot be lapped
 __global__ __launch_bounds__(256) FWD_OCC void k_blend_fwd(int N, int W, int H, int gx, int gy, int VT,
                                                      const float* __restrict__ bg,
@@ -2180,39 +2228,7 @@ __global__ __launch_bounds__(256) FWD_OCC void k_blend_fwd(int N, int W, int H, 
             FP(1);
             // one pair step; true when every pixel of the quadrant has stopped
             auto pair_step = [&](const float4& R0, const float4& R1, const float4& R2, const float4& R3, const float4& R4) -> bool {
-                    mgr_v2f al;
-                    unsigned long long ma, mb;
-                    mgr_pair_alpha_masks(R0, R1, R2, fpx2, fpy2, al, ma, mb);
-                    // Per entry: a = alpha if kept and the pixel still accumulates, else 0; the walk of a pixel ends where
-                    // T (1 - a) < 1e-4 (that entry contributes nothing).  The lane masks of the decisions live in scalar registers:
-                    // "contributes" = kept & not ended & not ending here is formed there, one select per use.
-                    {   // entry a
-                        const unsigned long long keep = ma & ~done_m;
-                        const float a = mgr_sel(keep, al.x, 0.0f);
-                        const float testT = Tr * (1.0f - a);
-                        const unsigned long long stop = __builtin_amdgcn_ballot_w64(testT < 0.0001f);  // a == 0 leaves testT = Tr >= 1e-4
-                        const unsigned long long contrib = keep & ~stop;
-                        const float w = mgr_sel(contrib, a * Tr, 0.0f);
-                        C01 += mgr_v2f{R3.x, R3.y} * w;
-                        C2 += R4.x * w;
-                        Tr = mgr_sel(stop, Tr, testT);
-                        last = mgr_selu(contrib, __float_as_uint(R4.z), last);
-                        done_m |= stop;
-                    }
-                    {   // entry b
-                        const unsigned long long keep = mb & ~done_m;
-                        const float a = mgr_sel(keep, al.y, 0.0f);
-                        const float testT = Tr * (1.0f - a);
-                        const unsigned long long stop = __builtin_amdgcn_ballot_w64(testT < 0.0001f);
-                        const unsigned long long contrib = keep & ~stop;
-                        const float w = mgr_sel(contrib, a * Tr, 0.0f);
-                        C01 += mgr_v2f{R3.z, R3.w} * w;
-                        C2 += R4.y * w;
-                        Tr = mgr_sel(stop, Tr, testT);
-                        last = mgr_selu(contrib, __float_as_uint(R4.w), last);
-                        done_m |= stop;
-                    }
-                return (~done_m & exec_m) == 0ull;
+                return mgr_fwd_pair_step(R0, R1, R2, R3, R4, fpx2, fpy2, Tr, C01, C2, last, done_m, exec_m);
             };
 #ifdef FWD_LDS_PIPE1
             for (int p = 0; p < npair; ++p) {
@@ -2283,14 +2299,39 @@ __global__ __launch_bounds__(256) FWD_OCC void k_blend_fwd(int N, int W, int H, 
         }
         // list depth this quadrant consumed; the tile's maximum drives the backward pass (k_fwd_items)
         const uint32_t mx = mgr_wave_max_u32(last);   // (DPP + readlane: the six __shfl_xor steps were ds_bpermute round trips at the end of every unit)
+        // depth cut: the list position in front of which every pixel of the quadrant had stopped (a whole number of
+        // batches; the tile's maximum becomes the next forward's hint), or "never" -- and if the list ran out under an
+        // unsaturated pixel while this forward had cut it short, the image may lack contributions: the quadrant is handed
+        // to the repair kernels with its pixels' state (MgrRepUnit), or, without them, the forward is flagged
+        const bool unsat = (~done_m & exec_m) != 0ull;
         if (lane == 0 && !hole) {
             tile_qdone[(size_t)vt * 4 + quad] = mx;
-            // depth cut: the list position in front of which every pixel of the quadrant had stopped (a whole number of
-            // batches; the tile's maximum becomes the next forward's hint), or "never" -- and if the list ran out under an
-            // unsaturated pixel while this forward had cut it short, the image may lack contributions: raise the flag
-            const bool unsat = (~done_m & exec_m) != 0ull;
             atomicMax(&tile_qend[vt], unsat ? 0xFFFFFFFFu : min(off, nlist));
-            if (unsat && tile_zused[vt] != 0u) atomicOr(&hdr->acc_flags, MGR_OVF_CUT);
+        }
+        if (unsat && !hole && tile_zused[vt] != 0u) {      // (wave-uniform: rare)
+            const MgrRep rep = hdr->rep;                    // (k_tile_scan_b left it there)
+            uint32_t u = 0xFFFFFFFFu;
+            if (rep.max_units) {
+                if (lane == 0) u = atomicAdd(&hdr->n_rep_units, 1u);
+                u = (uint32_t)__builtin_amdgcn_readfirstlane((int)u);
+            }
+            if (u < rep.max_units) {
+                rep.state[(size_t)u * 64 + lane] = make_float4(C01.x, C01.y, C2, Tr);
+                rep.last[(size_t)u * 64 + lane] = last;
+                if (lane == 0) {
+                    MgrRepUnit r;
+                    r.vt = vt; r.quad = quad; r.nlist = nlist; r.start = start;
+                    r.ck0 = ck0; r.done_lo = (uint32_t)done_m; r.done_hi = (uint32_t)(done_m >> 32); r.ntail = 0u;
+                    r.ov_start = 0u; r.ov_ck0 = 0u; r.p0 = 0u; r.ck_first = 0u;
+                    r.beyond = 0u; r.pad[0] = r.pad[1] = r.pad[2] = 0u;
+                    rep.unit[u] = r;
+                    rep.cnt[u] = 0u;
+                    atomicMax(&rep.tile_rep[vt], u + 1u);      // the tile's owner unit: the highest of its (up to four) units
+                }
+            } else if (lane == 0) {
+                atomicOr(&hdr->acc_flags, MGR_OVF_CUT);
+                atomicOr(&hdr->rep_why, MGR_WHY_UNITS);
+            }
         }
 #ifdef MGR_TIMELINE
         if (lane == 0 && tlw_n < TLW_PER_WAVE) {
@@ -2325,6 +2366,283 @@ __global__ __launch_bounds__(256) FWD_OCC void k_blend_fwd(int N, int W, int H, 
     }
 }
 
+// ---------------------------------------------------------------------------
+// Depth cut, repaired on the device (mgr_common.h, MgrRepUnit).
+// ---------------------------------------------------------------------------
+// k_repair_prep: one workgroup per view collects the view's repaired tiles (the owner units of the view) into MgrRepView: tile,
+// owner unit, depth of the cut, end of the depth window (tile_zwin) and the bounding box of the tiles -- so that the hundreds of
+// workgroups of k_repair_scan start from one coalesced read instead of each walking the unit list and its dependent loads
+// (unit -> tile -> hint: measured 0.045 ms per launch that way, most of it that latency).
+__global__ __launch_bounds__(256) void k_repair_prep(int T, int gx, MgrHeader* hdr, const MgrRep rep, const uint32_t* __restrict__ tile_zused,
+                                                     const uint32_t* __restrict__ tile_zwin) {
+    const uint32_t nu = min(hdr->n_rep_units, rep.max_units);
+    const int tid = threadIdx.x, v = blockIdx.x;
+    MgrRepView* rv = rep.view + v;
+    __shared__ uint32_t s_n, s_bb[4];
+    if (tid == 0) { s_n = 0u; s_bb[0] = 0xFFFFu; s_bb[1] = 0xFFFFu; s_bb[2] = 0u; s_bb[3] = 0u; }
+    __syncthreads();
+    for (uint32_t u = (uint32_t)tid; u < nu; u += 256u) {
+        const uint32_t vt = rep.unit[u].vt;
+        if ((int)(vt / (uint32_t)T) == v && rep.tile_rep[vt] == u + 1u) {
+            const uint32_t k = atomicAdd(&s_n, 1u);
+            if (k < (uint32_t)MGR_REP_VIEW_TILES) {
+                const uint32_t t = vt % (uint32_t)T, zcb = ~tile_zused[vt];      // float bits of the depth of the cut
+                uint32_t zwb = tile_zwin[vt];
+                if (zwb <= zcb) zwb = 0x7F7FFFFFu;                                // no usable window on file: everything behind the cut
+                MgrRepTile e;
+                e.tile = t; e.unit = u; e.zc = zcb; e.zw = zwb;
+                rv->t[k] = e;
+                const uint32_t ty = t / (uint32_t)gx, tx = t - ty * (uint32_t)gx;
+                atomicMin(&s_bb[0], tx); atomicMin(&s_bb[1], ty); atomicMax(&s_bb[2], tx + 1u); atomicMax(&s_bb[3], ty + 1u);
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        rv->n = s_n; rv->x0 = s_bb[0]; rv->y0 = s_bb[1]; rv->x1 = s_bb[2]; rv->y1 = s_bb[3];
+        if (s_n > (uint32_t)MGR_REP_VIEW_TILES) { atomicOr(&hdr->acc_flags, MGR_OVF_CUT); atomicOr(&hdr->rep_why, MGR_WHY_VIEW_TILES); }
+    }
+}
+
+// k_repair_scan: grid (segments of the instance range, views).  An instance the cut dropped from a repaired tile (rectangle of
+// at most 64 tiles covering the tile, depth bits behind the cut, alive by the very cull test pre_tail applied: same inputs from
+// the 48-byte record, same contraction-free functions) is a candidate = (depth bits << 32 | Gaussian) key of the tile's buffer,
+// in whatever order -- k_repair_blend sorts.
+//  * Depth window.  A repaired walk needs tens to hundreds of entries; everything behind a deep tile's cut is thousands (up to
+//    21 000 on the bench scene).  Candidates behind the tile's window (tile_zwin: the depth of the entry MGR_REP_TARGET behind
+//    the kept ones when the hint was made) are only counted (`beyond`); a walk that reaches the end of its window unsaturated
+//    with instances behind it flags the forward (MGR_WHY_WINDOW: the legacy answer).
+//  * The candidates of a workgroup are staged in LDS and handed to the tile's buffer with ONE global atomic per (workgroup,
+//    tile): thousands of returning atomics on one address are served one after the other at ~11 ns each (measured: 0.157 ms
+//    per launch with an atomic per candidate).
+#define REP_SCAN_THREADS 256
+#define REP_SCAN_SEGS 64
+#define REP_STASH 1024
+__global__ __launch_bounds__(REP_SCAN_THREADS) void k_repair_scan(int N, int T, int gx, MgrHeader* hdr, const MgrRep rep,
+                                                                  const int32_t* __restrict__ radii, const ushort4* __restrict__ rect,
+                                                                  const float* __restrict__ depth, const MgrGRec* __restrict__ grec) {
+    if (min(hdr->n_rep_units, rep.max_units) == 0u) return;
+    const int tid = threadIdx.x, v = blockIdx.y;
+    const MgrRepView* rv = rep.view + v;
+    const uint32_t nt = rv->n;
+    if (nt == 0u || nt > (uint32_t)MGR_REP_VIEW_TILES) return;
+    __shared__ uint32_t s_stash_n;
+    __shared__ uint32_t s_tile[MGR_REP_VIEW_TILES], s_unit[MGR_REP_VIEW_TILES], s_zc[MGR_REP_VIEW_TILES], s_zw[MGR_REP_VIEW_TILES];
+    __shared__ uint32_t s_hits[MGR_REP_VIEW_TILES], s_beyond[MGR_REP_VIEW_TILES];
+    __shared__ uint4 s_stash[REP_STASH];   // (tile slot, rank among the workgroup's hits of that tile, depth bits, Gaussian)
+    __shared__ uint32_t s_bits[2048];      // one bit per tile of the view (the ordered binning serves grids of up to 65535 tiles)
+    if (tid == 0) s_stash_n = 0u;
+    for (int k = tid; k < 2048; k += REP_SCAN_THREADS) s_bits[k] = 0u;
+    __syncthreads();
+    for (uint32_t k = (uint32_t)tid; k < nt; k += REP_SCAN_THREADS) {
+        const MgrRepTile e = rv->t[k];
+        s_tile[k] = e.tile; s_unit[k] = e.unit; s_zc[k] = e.zc; s_zw[k] = e.zw; s_hits[k] = 0u; s_beyond[k] = 0u;
+        atomicOr(&s_bits[e.tile >> 5], 1u << (e.tile & 31u));
+    }
+    const int bx0 = (int)rv->x0, by0 = (int)rv->y0, bx1 = (int)rv->x1, by1 = (int)rv->y1;
+    __syncthreads();
+    const int per = (N + REP_SCAN_SEGS - 1) / REP_SCAN_SEGS, i_lo = (int)blockIdx.x * per, i_hi = min(N, i_lo + per);
+    for (int ib = i_lo; ib < i_hi; ib += 4 * REP_SCAN_THREADS) {
+        ushort4 rc[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rc[r] = rect[(size_t)v * N + min(ib + r * REP_SCAN_THREADS + tid, N - 1)];      // four loads in flight
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = ib + r * REP_SCAN_THREADS + tid;
+            const int x0 = rc[r].x, y0 = rc[r].y, x1 = rc[r].z, y1 = rc[r].w;
+            const int tiles = (x1 - x0) * (y1 - y0);
+            if (i >= i_hi || tiles <= 0 || tiles > 64) continue;            // (larger rectangles are never cut: pre_tail)
+            if (x1 <= bx0 || x0 >= bx1 || y1 <= by0 || y0 >= by1) continue;
+            bool have = false;
+            uint32_t zbits = 0u;
+            MgrCull cull;
+            for (int y = max(y0, by0); y < min(y1, by1); ++y)
+                for (int x = max(x0, bx0); x < min(x1, bx1); ++x) {
+                    const uint32_t t = (uint32_t)(y * gx + x);
+                    if (!((s_bits[t >> 5] >> (t & 31u)) & 1u)) continue;
+                    uint32_t k = 0;
+                    while (k < nt && s_tile[k] != t) ++k;
+                    if (k == nt) continue;
+                    const size_t vi = (size_t)v * N + i;
+                    if (!have) {
+                        have = true;
+                        if (radii[vi] > 0) {
+                            zbits = __float_as_uint(depth[vi]);
+                            const MgrGRec g = grec[vi];
+                            cull = mgr_cull_init(g.x, g.y, g.ca, g.cb, g.cc, mgr_qmax(g.op));
+                        }
+                    }
+                    if (zbits == 0u || zbits <= s_zc[k]) continue;       // not visible, or in front of the cut: listed already
+                    float dy_lo, dy_hi, dxo;
+                    mgr_cull_row(cull, 16.0f * y, 16.0f * y + 15.0f, dy_lo, dy_hi, dxo);
+                    if (mgr_cull_dead(cull, dy_lo, dy_hi, dxo, 16.0f * x, 16.0f * x + 15.0f)) continue;
+                    if (zbits > s_zw[k]) { atomicAdd(&s_beyond[k], 1u); continue; }      // behind the depth window: counted only
+                    const uint32_t slot = atomicAdd(&s_stash_n, 1u);
+                    if (slot < (uint32_t)REP_STASH) {
+                        s_stash[slot] = make_uint4(k, atomicAdd(&s_hits[k], 1u), zbits, (uint32_t)i);
+                    } else {      // (more hits in one workgroup than the stage holds: straight to the buffer)
+                        const uint32_t u = s_unit[k], g = atomicAdd(&rep.cnt[u], 1u);
+                        if (g < (uint32_t)MGR_REP_CAND) rep.cand[(size_t)u * MGR_REP_CAND + g] = ((unsigned long long)zbits << 32) | (unsigned)i;
+                    }
+                }
+        }
+    }
+    __syncthreads();
+    for (uint32_t k = (uint32_t)tid; k < nt; k += REP_SCAN_THREADS) {
+        const uint32_t c = s_hits[k], by = s_beyond[k], u = s_unit[k];
+        s_hits[k] = c ? atomicAdd(&rep.cnt[u], c) : 0u;          // the workgroup's first slot in the tile's buffer
+        if (by) atomicAdd(&rep.unit[u].beyond, by);
+    }
+    __syncthreads();
+    const uint32_t ns = min(s_stash_n, (uint32_t)REP_STASH);
+    for (uint32_t q = (uint32_t)tid; q < ns; q += REP_SCAN_THREADS) {
+        const uint4 e = s_stash[q];
+        const uint32_t u = s_unit[e.x], g = s_hits[e.x] + e.y;
+        if (g < (uint32_t)MGR_REP_CAND) rep.cand[(size_t)u * MGR_REP_CAND + g] = ((unsigned long long)e.z << 32) | e.w;
+    }
+}
+
+// k_repair_blend: workgroups of RS_THREADS threads take the owner units.  Per repaired tile: the candidates are sorted in LDS
+// (lds_sort_emit: (depth, index) order = the tail of the tile's full list) and written behind the regular lists, after a copy
+// of the cut list's last partial chunk; then waves 0..3 continue the walks of the tile's registered quadrants from their
+// saved state through the sorted tail, with the forward blend's own pair step (mgr_fwd_pair_step), its box test and its
+// checkpoint rule -- batches end on the chunk boundaries of the FULL list's positions, so the checkpoints are those the walk of
+// the full list writes.  An empty tail needs nothing: the cut list was the full list.
+#define REP_BLEND_LDS ((size_t)MGR_REP_CAND * 8 + RS_WAVES * 256 * 4 + 32 * 4 + 8 * 4 + 4 * 32 * MGR_PAIR_FLOATS * 4)
+__global__ __launch_bounds__(RS_THREADS) void k_repair_blend(int N, int W, int H, int gx, int T, MgrHeader* hdr, const MgrRep rep,
+                                                             const float* __restrict__ bg, uint32_t* __restrict__ sorted_gid,
+                                                             const MgrGRec* __restrict__ grec, float* __restrict__ out_color,
+                                                             uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_qdone,
+                                                             float4* __restrict__ ckpt) {
+    const uint32_t nu = min(hdr->n_rep_units, rep.max_units);
+    if (nu == 0u) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    unsigned long long* s_keys = (unsigned long long*)s_raw;                       // MGR_REP_CAND keys
+    uint32_t* s_cnt = (uint32_t*)(s_raw + (size_t)MGR_REP_CAND * 8);               // RS_WAVES x 256 counters
+    uint32_t* s_scan = s_cnt + RS_WAVES * 256;                                     // 32 words
+    uint32_t* s_q = s_scan + 32;                                                   // [4] unit + 1 of the tile's quadrants; [4..7] allocation
+    float* s_slab = (float*)(s_q + 8);                                             // [4][32][MGR_PAIR_FLOATS]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const size_t P = (size_t)W * H;
+    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (uint32_t u = blockIdx.x; u < nu; u += gridDim.x) {
+        __syncthreads();
+        const MgrRepUnit ru = rep.unit[u];
+        if (rep.tile_rep[ru.vt] != u + 1u) continue;                               // not the tile's owner (workgroup-uniform)
+        const uint32_t nraw = rep.cnt[u];
+        if (nraw == 0u) {                                                          // nothing behind the cut: the cut list was the full list
+            if (ru.beyond != 0u && tid == 0) {                                     // ... unless what there is lies behind the depth window
+                atomicOr(&hdr->acc_flags, MGR_OVF_CUT);
+                atomicOr(&hdr->rep_why, MGR_WHY_WINDOW);
+            }
+            continue;
+        }
+        if (tid < 4) s_q[tid] = 0u;
+        __syncthreads();
+        for (uint32_t k = (uint32_t)tid; k < nu; k += RS_THREADS) {
+            const MgrRepUnit o = rep.unit[k];
+            if (o.vt == ru.vt) s_q[o.quad & 3u] = k + 1u;
+        }
+        const uint32_t n = min(nraw, (uint32_t)MGR_REP_CAND);
+        const uint32_t nl = ru.nlist, p0 = (nl / MGR_CHUNK) * MGR_CHUNK, pre = nl - p0, total = nl + n;
+        const uint32_t c0 = p0 / MGR_CHUNK, c_last = (total - 1u) / MGR_CHUNK, nck = c_last - c0 + 1u;
+        if (tid == 0) {
+            const uint32_t ov = atomicAdd(&hdr->rep_list_used, pre + n), ck = atomicAdd(&hdr->rep_ck_used, nck);
+            const bool fits = ov + pre + n <= rep.list_cap && ck + nck <= rep.ck_cap, ok = nraw <= (uint32_t)MGR_REP_CAND && fits;
+            s_q[4] = ok ? 1u : 0u; s_q[5] = rep.list_base + ov; s_q[6] = rep.ck_base + ck;
+            if (!ok) {                                                              // a capacity of the repair is exceeded: the legacy answer
+                atomicOr(&hdr->acc_flags, MGR_OVF_CUT);
+                atomicOr(&hdr->rep_why, fits ? MGR_WHY_CAND : MGR_WHY_LIST);
+            }
+        }
+        __syncthreads();
+        if (s_q[4] == 0u) continue;
+        const uint32_t ov_start = s_q[5], ov_ck0 = s_q[6];
+        // the tail in (depth, index) order: ids to the appended list, keys stay in LDS for the walks
+        lds_sort_emit(rep.cand + (size_t)u * MGR_REP_CAND, n, s_keys, s_cnt, s_scan, tid, sorted_gid + ov_start + pre);
+        if ((uint32_t)tid < pre) sorted_gid[ov_start + tid] = sorted_gid[ru.start + p0 + tid];
+        if (tid == 0) {
+            MgrRepUnit w = ru;
+            w.ntail = n; w.ov_start = ov_start; w.ov_ck0 = ov_ck0; w.p0 = p0;
+            w.ck_first = pre == 0u ? ov_ck0 : (p0 ? ru.ck0 + c0 - 1u : 0u);
+            rep.unit[u] = w;
+        }
+        __syncthreads();
+        if (wave >= 4 || s_q[wave] == 0u) continue;
+        // ---- one wave per registered quadrant: the walk goes on ----
+        const uint32_t uq = s_q[wave] - 1u;
+        const MgrRepUnit rq = rep.unit[uq];
+        const uint32_t vt = ru.vt, quad = rq.quad;
+        const int v = (int)(vt / (uint32_t)T), t = (int)(vt % (uint32_t)T);
+        const int bx = t % gx, by = t / gx;
+        const int px = bx * 16 + (int)(quad & 1u) * 8 + (lane & 7), py = by * 16 + (int)(quad >> 1) * 8 + (lane >> 3);
+        const bool inside = px < W && py < H;
+        const mgr_v2f fpx2 = {(float)px, (float)px}, fpy2 = {(float)py, (float)py};
+        const float qx0 = (float)(bx * 16 + (int)(quad & 1u) * 8), qy0 = (float)(by * 16 + (int)(quad >> 1) * 8);
+        const int pslot = (int)(quad << 6) | lane;
+        const float4 st = rep.state[(size_t)uq * 64 + lane];
+        float Tr = st.w, C2 = st.z;
+        mgr_v2f C01 = {st.x, st.y};
+        uint32_t last = rep.last[(size_t)uq * 64 + lane];
+        const unsigned long long exec_m = __builtin_amdgcn_ballot_w64(true);
+        unsigned long long done_m = ((unsigned long long)rq.done_hi << 32) | rq.done_lo;
+        const MgrGRec* const gv = grec + (size_t)v * N;
+        float* const slab = s_slab + wave * 32 * MGR_PAIR_FLOATS;
+        // the checkpoint in front of chunk c0 when the cut list ended exactly there (the forward blend writes a checkpoint only
+        // in front of a chunk that exists in ITS list): the saved state is that checkpoint
+        if (pre == 0u && p0 != 0u && (((~done_m & exec_m) >> lane) & 1ull)) ckpt[(size_t)ov_ck0 * 256 + pslot] = make_float4(C01.x, C01.y, C2, Tr);
+        uint32_t j = 0;
+        while (j < n) {
+            const uint32_t blen = min(n - j, (uint32_t)MGR_CHUNK - ((nl + j) % MGR_CHUNK));   // up to the next chunk boundary of the full list
+            int bx0, by0, bx1, by1;
+            if (!mgr_quad_bbox(~done_m & exec_m, bx0, by0, bx1, by1)) break;
+            bool alive = false;
+            MgrGRec r;
+            if ((uint32_t)lane < blen) {
+                r = gv[(uint32_t)s_keys[j + lane]];
+                alive = !mgr_box_dead(r.x, r.y, r.ca, r.cb, r.cc, mgr_qmax(r.op), qx0 + (float)bx0, qy0 + (float)by0, qx0 + (float)bx1,
+                                      qy0 + (float)by1);
+            }
+            const unsigned long long m = __ballot(alive);
+            const int cnt = __popcll(m);
+            if (alive) {
+                const int rank = __popcll(m & lt);
+                float* pb = slab + (rank >> 1) * MGR_PAIR_FLOATS;
+                mgr_pair_store<true>(pb, rank & 1, r.x, r.y, r.ca, r.cb, r.cc, r.op, r.r, r.g, r.b, nl + j + (uint32_t)lane + 1u);   // 1-based position in the FULL list
+                if ((cnt & 1) && rank == cnt - 1) mgr_pair_pad<true>(pb);
+            }
+            __builtin_amdgcn_wave_barrier();
+            const int npair = (cnt + 1) >> 1;
+            for (int p = 0; p < npair; ++p) {
+                const float4* pp = (const float4*)(slab + p * MGR_PAIR_FLOATS);
+                const float4 R0 = pp[0], R1 = pp[1], R2 = pp[2], R3 = pp[3], R4 = pp[4];
+                if (mgr_fwd_pair_step(R0, R1, R2, R3, R4, fpx2, fpy2, Tr, C01, C2, last, done_m, exec_m)) break;
+            }
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t nextpos = nl + j + blen;
+            if ((nextpos % MGR_CHUNK) == 0u && nextpos < total && (((~done_m & exec_m) >> lane) & 1ull))
+                ckpt[(size_t)(ov_ck0 + nextpos / MGR_CHUNK - c0) * 256 + pslot] = make_float4(C01.x, C01.y, C2, Tr);
+            j += blen;
+        }
+        if (inside) {
+            const size_t pix = (size_t)py * W + px;
+            n_contrib[(size_t)v * P + pix] = last;
+            float* o = out_color + (size_t)v * 3 * P + pix;
+            o[0] = C01.x + Tr * bg0;
+            o[P] = C01.y + Tr * bg1;
+            o[2 * P] = C2 + Tr * bg2;
+        }
+        const uint32_t mx = mgr_wave_max_u32(last);
+        if (lane == 0) {
+            tile_qdone[(size_t)vt * 4 + quad] = mx;      // (tile_qend keeps "never": no hint from a repaired walk)
+            // the walk used up its depth window with a pixel unsaturated and instances behind the window: what lies there is needed
+            if ((~done_m & exec_m) != 0ull && ru.beyond != 0u) { atomicOr(&hdr->acc_flags, MGR_OVF_CUT); atomicOr(&hdr->rep_why, MGR_WHY_WINDOW); }
+        }
+    }
+}
+
 // The backward blend's work items, built after the wave-granular forward blend: one 32-byte record per (tile, 64-entry
 // chunk the tile consumed) = (tile, chunk, list offset of the chunk's first entry, checkpoint in front of the chunk | list
 // depth consumed by each quadrant).  One thread per queue entry; a block reserves its range with one atomic and writes it
@@ -2343,7 +2661,12 @@ __global__ __launch_bounds__(256) FWD_OCC void k_blend_fwd(int N, int W, int H, 
 // cut; an uncut one that does is needed whole.  Unsaturated tiles (silhouette, thin parts) get no hint.
 // margins of the depth-cut hints (per host thread; see k_fwd_items)
 static thread_local float g_cut_frac = 0.125f, g_cut_range = 0.0625f, g_cut_rel = 2.0e-4f;
-static thread_local int g_cut_min = 64, g_cut_interior = 0;
+static thread_local int g_cut_min = 64, g_cut_interior = 0, g_cut_penalty = 16;
+extern "C" int mgr_raster_set_cut_penalty(int forwards) {
+    if (forwards < 0 || forwards > 0x7FFFFFF) return mgr_fail(MGR_EINVAL, "mgr_raster_set_cut_penalty: 0 .. 2^27 forwards");
+    g_cut_penalty = forwards;
+    return MGR_OK;
+}
 extern "C" int mgr_raster_set_cut_margin(float frac_entries, int min_entries, float depth_range_frac, float depth_rel,
                                          int interior_only) {
     if (!(frac_entries >= 0.f) || min_entries < 0 || !(depth_range_frac >= 0.f) || !(depth_rel >= 0.f))
@@ -2359,11 +2682,12 @@ __global__ __launch_bounds__(256) void k_fwd_items(const uint4* __restrict__ til
                                                    uint32_t* __restrict__ tile_zcut, uint32_t* mirror, float cut_frac, uint32_t cut_min,
                                                    float cut_range, float cut_rel, int gx, int interior_only,
                                                    const uint32_t* __restrict__ tile_queue, int VT, unsigned char* __restrict__ tile_bgok,
-                                                   const float* out_color, const float* __restrict__ bg) {
+                                                   const float* out_color, const float* __restrict__ bg, const MgrRep rep, uint32_t cut_penalty,
+                                                   uint32_t* __restrict__ tile_zwin) {
     __shared__ uint32_t s_scan[8];
     __shared__ uint32_t s_base;
     __shared__ uint32_t s_run[257];
-    __shared__ uint4 s_qr[256], s_qd[256];
+    __shared__ uint4 s_qr[256], s_qd[256], s_rp[256];
     const int tid = threadIdx.x;
     const uint32_t n_busy = hdr->queue_len_i;
     const uint32_t nb = (n_busy + 255u) / 256u;
@@ -2372,7 +2696,8 @@ __global__ __launch_bounds__(256) void k_fwd_items(const uint4* __restrict__ til
         uint32_t ovf = hdr->overflow;
         if (f) { ovf |= f; hdr->overflow = ovf; hdr->acc_flags = 0u; }
         if (mirror) {   // the caller's host-mapped status words (mgr_raster_set_status_mirror): no copy, no launch
-            mirror[0] = hdr->total_pairs; mirror[1] = ovf; mirror[2] = hdr->tiers | (min(hdr->sort_big, 0xFFFFu) << 8);
+            // (bits 16.. of the overflow word: quadrants of depth-cut tiles repaired on the device in this forward)
+            mirror[0] = hdr->total_pairs; mirror[1] = ovf | (min(hdr->n_rep_units, 0xFFFFu) << 16); mirror[2] = hdr->tiers | (min(hdr->sort_big, 0xFFFFu) << 8);
             __threadfence_system();
             mirror[3] = 1u;
         }
@@ -2389,11 +2714,19 @@ __global__ __launch_bounds__(256) void k_fwd_items(const uint4* __restrict__ til
     if (blockIdx.x >= nb) return;
     // strided over the queue (which is ordered by depth): every block gets its share of the deep tiles
     const uint32_t q = (uint32_t)tid * nb + blockIdx.x;
-    uint4 qr = make_uint4(0, 0, 0, 0), qd = make_uint4(0, 0, 0, 0);
+    uint4 qr = make_uint4(0, 0, 0, 0), qd = make_uint4(0, 0, 0, 0), rp = make_uint4(0, 0, 0, 0);
     uint32_t nch = 0;
     if (q < n_busy && tile_qrec[q].x != MGR_HOLE) {
         qr = tile_qrec[q];
         qd = *(const uint4*)(tile_qdone + (size_t)qr.x * 4);
+        // a tile the repair kernels extended: its entries from p0 on live behind the regular lists (MgrRepUnit)
+        if (rep.max_units) {
+            const uint32_t ro = rep.tile_rep[qr.x];
+            if (ro != 0u) {
+                const MgrRepUnit ru = rep.unit[ro - 1u];
+                if (ru.ntail != 0u) rp = make_uint4(ru.p0 | 0x80000000u, ru.ov_start, ru.ov_ck0, ru.ck_first);
+            }
+        }
         const uint32_t tmax = max(max(qd.x, qd.y), max(qd.z, qd.w));
         tile_done[qr.x] = tmax;
         nch = (tmax + MGR_CHUNK - 1) / MGR_CHUNK;
@@ -2416,7 +2749,14 @@ __global__ __launch_bounds__(256) void k_fwd_items(const uint4* __restrict__ til
                     interior = interior && q2 != 0xFFFFFFFFu && q2 != 0u;
                 }
         }
-        if (interior && e <= nl && (em <= nl || used != 0u)) {
+        // a countdown left by an earlier forward (k_tile_scan_b kept it): no hint while it runs; a tile whose cut list ran out
+        // in THIS forward (repaired on the device, or flagged) starts one -- the same few tiles at the silhouette of the
+        // saturating region otherwise run out step after step under a moving model
+        const uint32_t pen = tile_zcut[qr.x];
+        const bool ran_out = used != 0u && e == 0xFFFFFFFFu;
+        if (ran_out) hint = cut_penalty;
+        else if (pen > 1u) hint = pen - 1u;
+        else if (interior && e <= nl && (em <= nl || used != 0u)) {
             const uint32_t* sg = sorted_gid + qr.y;
             const float* dv = depth + (size_t)(qr.x / (uint32_t)T) * N;
             const uint32_t g0 = sg[0], ge = sg[e - 1u], gm = sg[min(em, nl) - 1u];
@@ -2427,6 +2767,13 @@ __global__ __launch_bounds__(256) void k_fwd_items(const uint4* __restrict__ til
             const float zx = fmaxf(__uint_as_float(~used), ze + 1.5f * (float)(em - e) * (ze - z0) / (float)e);
             zc = fmaxf(zc, em <= nl ? zm : zx);
             hint = ~__float_as_uint(zc);
+            // the repair's depth window (k_repair_scan): a forward that walked the tile's FULL list knows the depth of the entry
+            // MGR_REP_TARGET behind the kept ones (or that the list ends before: no window); a cut list does not reach that far:
+            // the window on file stays (the cut creeps by a margin's fraction per step, the window is thousands of entries deep)
+            if (used == 0u) {
+                const uint32_t iw = max(em, e) + (uint32_t)MGR_REP_TARGET;
+                tile_zwin[qr.x] = iw >= nl ? 0x7F7FFFFFu : __float_as_uint(fmaxf(dv[sg[iw - 1u]], zc));
+            }
         }
         tile_zcut[qr.x] = hint;
     }
@@ -2435,6 +2782,7 @@ __global__ __launch_bounds__(256) void k_fwd_items(const uint4* __restrict__ til
     s_run[tid] = run;
     s_qr[tid] = qr;
     s_qd[tid] = qd;
+    s_rp[tid] = rp;
     if (tid == 0) {
         s_run[256] = total;
         s_base = total ? atomicAdd(&hdr->n_items, total) : 0u;
@@ -2448,8 +2796,14 @@ __global__ __launch_bounds__(256) void k_fwd_items(const uint4* __restrict__ til
             if (s_run[mid] <= i) lo = mid; else hi = mid;
         }
         const uint32_t c = i - s_run[lo];
-        const uint4 r = s_qr[lo];
-        items[2 * (size_t)(base + i)] = make_uint4(r.x, c, r.y + c * MGR_CHUNK, r.w + (c > 0 ? c - 1 : 0));
+        const uint4 r = s_qr[lo], x = s_rp[lo];
+        uint32_t off = r.y + c * MGR_CHUNK, ck = r.w + (c > 0 ? c - 1 : 0);
+        const uint32_t p0 = x.x & 0x7FFFFFFFu;
+        if (x.x != 0u && c * MGR_CHUNK >= p0) {      // chunk of a repaired tile at or behind the end of its cut list
+            off = x.y + (c * MGR_CHUNK - p0);
+            ck = c * MGR_CHUNK == p0 ? x.w : x.z + (c - p0 / MGR_CHUNK);
+        }
+        items[2 * (size_t)(base + i)] = make_uint4(r.x, c, off, ck);
         items[2 * (size_t)(base + i) + 1] = s_qd[lo];
     }
 }
@@ -2526,6 +2880,9 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
     bool bg_filled = false;   // the background of the empty tiles has been written by the instance sort's launch
     const int skip_tiers = ((debug & 16) ? 1 : 0) | ((debug & 32) ? 2 : 0) | ((debug & 128) ? 4 : 0) | ((debug & 256) ? 8 : 0);
     const int img_kept = (debug & 1024) ? 1 : 0;   // bit 10: "image kept" (see BgFill)
+    // bit 11 (2048, with bit 3): tiles whose cut list runs out under an unsaturated pixel are repaired on the device
+    // (k_repair_scan / k_repair_blend) instead of flagging the forward
+    const bool repair = use_cut && (debug & 2048);
     debug &= 1;
     if (V <= 0 || N < 0 || W <= 0 || H <= 0 || cap < 0 || cap > 0xFFFFFFF0ll)
         return mgr_fail(MGR_EINVAL, "mgr_raster_forward: bad sizes");
@@ -2541,6 +2898,13 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
     uint32_t* tile_count = (uint32_t*)(ws + L.tile_count);
     uint32_t* tile_start = (uint32_t*)(ws + L.tile_start);
     const int VT = V * T;
+    MgrRep rep_all;
+    rep_all.unit = (MgrRepUnit*)(ws + L.rep_unit); rep_all.state = (float4*)(ws + L.rep_state); rep_all.last = (uint32_t*)(ws + L.rep_last);
+    rep_all.cnt = (uint32_t*)(ws + L.rep_cnt); rep_all.tile_rep = (uint32_t*)(ws + L.tile_rep); rep_all.cand = (unsigned long long*)(ws + L.rep_cand);
+    rep_all.view = (MgrRepView*)(ws + L.rep_view);
+    rep_all.max_units = repair ? mgr_rep_units(cap) : 0u;
+    rep_all.list_cap = mgr_rep_list(cap); rep_all.ck_cap = mgr_rep_ck(cap);
+    rep_all.list_base = (uint32_t)cap; rep_all.ck_base = (uint32_t)(cap / MGR_CHUNK + 1);
 
     // function attributes are per device: set once for each device a forward runs on (first call on that device)
     static std::atomic<bool> attr_set[MGR_MAX_DEVICES];
@@ -2562,6 +2926,7 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
                                     SORT_LDS_KEYS * 8 + RS_WAVES * 256 * 4 + 256));
         MGR_HIP(hipFuncSetAttribute((const void*)k_bin_count<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
         MGR_HIP(hipFuncSetAttribute((const void*)k_bin_scatter<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+        MGR_HIP(hipFuncSetAttribute((const void*)k_repair_blend, hipFuncAttributeMaxDynamicSharedMemorySize, REP_BLEND_LDS));
         attr_set[device].store(true, std::memory_order_release);
     }
 
@@ -2621,7 +2986,7 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
         { MGR_PROF("k_tile_scan_b", stream); hipLaunchKernelGGL(k_tile_scan_b, dim3(nblk + (dbin ? V : 0)), dim3(1024), 0, stream, V, T, nbT, tile_count, part, (const uint32_t*)blk_cls,
                            tile_start, (uint32_t*)(ws + L.tile_cursor), (uint32_t*)(ws + L.tile_queue), (uint4*)(ws + L.tile_qrec),
                            (const uint32_t*)(ws + L.tile_done), use_hint, (uint32_t*)(ws + L.chunk_start), hdr, (uint32_t)cap,
-                           (uint32_t*)(ws + L.tile_zcut), (uint32_t*)(ws + L.tile_zused), (uint32_t*)(ws + L.tile_qend), use_cut ? 1 : 0, (const uint4*)blk_box, dba, (unsigned char*)(ws + L.tile_bgok)); }
+                           (uint32_t*)(ws + L.tile_zcut), (uint32_t*)(ws + L.tile_zused), (uint32_t*)(ws + L.tile_qend), use_cut ? 1 : 0, (const uint4*)blk_box, dba, (unsigned char*)(ws + L.tile_bgok), (uint32_t*)(ws + L.tile_rep), rep_all); }
     }
     MGR_LAUNCH_CHECK("k_tile_scan", stream, debug);
     if (N > 0 && ordered) {
@@ -2719,12 +3084,25 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
                        (const uint32_t*)(ws + L.tile_queue), (const uint4*)(ws + L.tile_qrec), (const uint32_t*)(ws + L.sorted_gid), (const MgrGRec*)(ws + L.grec), out_color,
                        (uint32_t*)(ws + L.n_contrib), (uint32_t*)(ws + L.tile_done), (uint32_t*)(ws + L.tile_qdone),
                        (float4*)(ws + L.ckpt), hdr, (const uint32_t*)(ws + L.tile_zused), (uint32_t*)(ws + L.tile_qend), bg_filled ? 1 : 0); }
+    if (repair && N > 0) {   // (both return at once when the blend registered no unit)
+        { MGR_PROF("k_repair_scan", stream);
+          hipLaunchKernelGGL(k_repair_prep, dim3(V), dim3(256), 0, stream, T, gx, hdr, rep_all, (const uint32_t*)(ws + L.tile_zused),
+                             (const uint32_t*)(ws + L.tile_zwin));
+          hipLaunchKernelGGL(k_repair_scan, dim3(REP_SCAN_SEGS, V), dim3(REP_SCAN_THREADS), 0, stream, N, T, gx, hdr, rep_all, (const int32_t*)radii,
+                             (const ushort4*)(ws + L.rect), (const float*)(ws + L.depth), (const MgrGRec*)(ws + L.grec)); }
+        { MGR_PROF("k_repair_blend", stream);
+          hipLaunchKernelGGL(k_repair_blend, dim3(128), dim3(RS_THREADS), REP_BLEND_LDS, stream, N, W, H, gx, T, hdr, rep_all, bg,
+                             (uint32_t*)(ws + L.sorted_gid), (const MgrGRec*)(ws + L.grec), out_color, (uint32_t*)(ws + L.n_contrib),
+                             (uint32_t*)(ws + L.tile_qdone), (float4*)(ws + L.ckpt)); }
+        MGR_LAUNCH_CHECK("k_repair_blend", stream, debug);
+    }
     { MGR_PROF("k_fwd_items", stream); hipLaunchKernelGGL(k_fwd_items, dim3((VT + 255) / 256), dim3(256), 0, stream, (const uint4*)(ws + L.tile_qrec),
                        (const uint32_t*)(ws + L.tile_qdone), (uint32_t*)(ws + L.tile_done), (uint4*)(ws + L.items), hdr,
                        N, T, (const uint32_t*)(ws + L.sorted_gid), (const float*)(ws + L.depth), (const uint32_t*)(ws + L.tile_zused),
                        (const uint32_t*)(ws + L.tile_qend), (uint32_t*)(ws + L.tile_zcut), mgr_take_status_mirror(workspace),
                        g_cut_frac, (uint32_t)g_cut_min, g_cut_range, g_cut_rel, gx, g_cut_interior,
-                       (const uint32_t*)(ws + L.tile_queue), VT, (unsigned char*)(ws + L.tile_bgok), (const float*)out_color, bg); }
+                       (const uint32_t*)(ws + L.tile_queue), VT, (unsigned char*)(ws + L.tile_bgok), (const float*)out_color, bg, rep_all,
+                       (uint32_t)g_cut_penalty, (uint32_t*)(ws + L.tile_zwin)); }
     MGR_LAUNCH_CHECK("k_blend_fwd", stream, debug);
     return MGR_OK;
 }
@@ -2766,7 +3144,7 @@ extern "C" int mgr_raster_layout(int V, int N, int W, int H, int64_t cap, size_t
     const size_t v[] = {L.header, L.grec, L.depth, L.rect, L.alive, L.pair_off, L.tile_count, L.tile_start,
                         L.tile_cursor, L.tile_done, L.tile_queue, L.chunk_start, L.items, L.ckpt, L.keys,
                         L.sorted_gid, L.final_T, L.n_contrib, L.pair_tag, L.pair_grad, L.total, L.inst_grad, L.inst_tag,
-                        L.db_nvis, L.db_bbox, L.db_order, L.tile_zcut, L.tile_zused, L.tile_qend};
+                        L.db_nvis, L.db_bbox, L.db_order, L.tile_zcut, L.tile_zused, L.tile_qend, L.tile_rep, L.rep_unit, L.rep_cnt, L.tile_zwin};
     const int n = (int)(sizeof(v) / sizeof(v[0]));
     for (int i = 0; i < n && i < n_out; ++i) out[i] = v[i];
     return n;

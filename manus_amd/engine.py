@@ -364,6 +364,11 @@ class HipViewCompute:
         # epoch: the forward then simply runs uncut and leaves fresh hints).
         self._cut_scale, self._cut_seen, self.cut_max_age, self._cut_clock, self._cut_born = 1.0, 0, 16, 0, {}
         self._cut_pause, self._cut_backoff, self._cut_clean = 0, 4, 0
+        # cut_repair (round 6): tiles whose cut list runs out are repaired on the device (mgr_views_forward, debug bit 2048) --
+        # no flagged forward, no re-run, no back-off; cut_margin scales the library's default margins, cut_penalty = forwards
+        # a tile that ran out goes without a hint.  MANUS_CUT_REPAIR=0 in the environment: the round-5 behaviour (A/B).
+        self.cut_repair = os.environ.get("MANUS_CUT_REPAIR", "1") != "0"
+        self.cut_margin, self.cut_penalty = float(os.environ.get("MANUS_CUT_MARGIN", "1.0")), int(os.environ.get("MANUS_CUT_PENALTY", "16"))
         # sparse_loss: the fused step hands the forward's tile-list offsets to the image loss, which then settles the
         # spans under empty tiles from the target alone (exact: the rasterizer writes the background colour there) and
         # leaves their gradient unwritten (the backward never reads it).  False: the loss reads both images everywhere.
@@ -553,8 +558,8 @@ class HipViewCompute:
         if off is None:
             import ctypes
             from ._lib import lib
-            arr = (ctypes.c_size_t * 32)()
-            lib().mgr_raster_layout(V, N, W, H, ws.cap, arr, 32)
+            arr = (ctypes.c_size_t * 40)()
+            lib().mgr_raster_layout(V, N, W, H, ws.cap, arr, 40)
             off = self._ts_off[key] = [int(x) for x in arr]
         return off
 
@@ -599,30 +604,49 @@ class HipViewCompute:
         else:
             self._cut_scale = max(1.0, self._cut_scale * 0.98)
         k = self._cut_scale
-        lib().mgr_raster_set_cut_margin(min(4.0, 0.125 * k), int(64 * k), min(4.0, 0.0625 * k), 2.0e-4 * k, 1 if k > 1.0 else 0)
+        if self.cut_repair:
+            # tiles that run out are completed on the device (bit 2048): a flagged forward is then a capacity matter, rare, and
+            # the margins need neither widening nor the interior-only rule -- the library's per-tile countdown keeps the
+            # repeat offenders out
+            lib().mgr_raster_set_cut_margin(0.125 * self.cut_margin, int(64 * self.cut_margin), 0.0625 * self.cut_margin,
+                                            2.0e-4 * self.cut_margin, 0)
+            lib().mgr_raster_set_cut_penalty(int(self.cut_penalty))
+        else:
+            lib().mgr_raster_set_cut_margin(min(4.0, 0.125 * k), int(64 * k), min(4.0, 0.0625 * k), 2.0e-4 * k, 1 if k > 1.0 else 0)
         born, self._cut_born[key] = self._cut_born.get(key), self._cut_clock
         if len(self._cut_born) > 4 * self._cut_max:     # view sets not seen for cut_max_age updates have no usable hints
             self._cut_born = {k_: b_ for k_, b_ in self._cut_born.items() if self._cut_clock - b_ <= self.cut_max_age}
         too_old = born is None or self._cut_clock - born > self.cut_max_age
         if prev != key:
             T = ((W + 15) // 16) * ((H + 15) // 16)
-            off = self._layout(ws, V, N, W, H)[26]
-            region = ws.buf[off: off + 4 * V * T]
+            lay = self._layout(ws, V, N, W, H)
+            # the hints (tile_zcut) and the depth windows of the repair that belong to them (tile_zwin): 2 x 4 bytes per tile and view
+            regions = [ws.buf[o_: o_ + 4 * V * T] for o_ in (lay[26], lay[32])]
+            nbytes = sum(r.numel() for r in regions)
             if prev is not None and prev[:2] == key[:2]:      # park the hints of the views rendered last
-                max_sets = max(1, min(self._cut_max, self.MAX_CUT_HINT_BYTES // max(1, region.numel())))
+                max_sets = max(1, min(self._cut_max, self.MAX_CUT_HINT_BYTES // max(1, nbytes)))
                 while len(self._cut_store) >= max_sets:
                     self._cut_store.pop(next(iter(self._cut_store)))
-                self._cut_store[prev] = region.clone()
+                self._cut_store[prev] = torch.cat(regions)
             saved = self._cut_store.pop(key, None)
-            if saved is not None and saved.numel() == region.numel():
-                region.copy_(saved)
+            if saved is not None and saved.numel() == nbytes:
+                o_ = 0
+                for r in regions:
+                    r.copy_(saved[o_: o_ + r.numel()])
+                    o_ += r.numel()
             else:
-                region.zero_()                                              # no hints for these views yet
+                for r in regions:
+                    r.zero_()                                               # no hints for these views yet
         if ws.cut_block:                  # the previous forward was flagged: this one rebuilds the hints from full lists
             ws.cut_block = False
             return 0
         if too_old:
             return 0
+        if self.cut_repair:
+            if self._cut_pause > 0:       # (a capacity of the repair was exceeded: a few forwards on full lists, no escalation)
+                self._cut_pause = min(self._cut_pause, 4) - 1
+                return 0
+            return 8 | 2048
         if self._cut_pause > 0:           # backing off after a flagged forward
             self._cut_pause -= 1
             return 0

@@ -64,6 +64,9 @@ class RasterWorkspace:
         # binning tiers (debug bits 16 / 32 of the forward): which LDS tiers beyond the smallest the most recent forward
         # whose header was read needed (None: unknown -- launch them all)
         self.tiers = None
+        # set by a forward that runs without a host read but promises the caller a complete result (the operator route's
+        # automatic fences): launches whose absence would have to be answered by a re-run are then never skipped
+        self.no_flagging_skips = False
 
     def skip_bits(self):
         """debug bits that spare the forward the binning launches its views did not need last time (they are verified on
@@ -71,7 +74,8 @@ class RasterWorkspace:
         if self.tiers is None:
             return 0
         # (128 / 256: the instance sort's light launch alone, or its full-size launch alone)
-        return (0 if self.tiers & 1 else 16) | (0 if self.tiers & 2 else 32) | (128 if (self.tiers >> 8) <= RasterWorkspace.SORT_BIG_MAX else 256)
+        bits = (0 if self.tiers & 1 else 16) | (0 if self.tiers & 2 else 32) | (128 if (self.tiers >> 8) <= RasterWorkspace.SORT_BIG_MAX else 256)
+        return bits & ~48 if self.no_flagging_skips else bits      # (bits 128 / 256 choose between two complete sorts: never flagged)
 
 
 def default_pair_capacity(V, N):
@@ -84,6 +88,13 @@ class RasterContext:
     fences of forwards that ran without a host synchronisation."""
 
     MAX_FENCES = 64
+    # Operator route (`GaussianRasterizer` under autograd, sync policy left at its default): after this many consecutive
+    # forwards of one (V, N, W, H) whose pair count fitted the learnt capacity, the blocking read of the pair count per forward
+    # (upstream's cudaMemcpy; 0.23 ms of a 1.47 ms step at 1280x720, profiles/r05_other_configs/dropin_c*) is replaced by a
+    # fence that the NEXT forward of the context resolves -- by then it has long been written.  The capacity keeps its 25 %
+    # headroom; should a forward outgrow it all the same, the next forward raises ManusHipError (the step before it used an
+    # incomplete image) and the context returns to the blocking mode.  0 = never switch; a densification (new N) starts over.
+    AUTO_FENCE_AFTER = int(os.environ.get("MANUS_AUTO_FENCE_AFTER", "8"))
 
     def __init__(self, device):
         self.device = torch.device(device)
@@ -95,6 +106,9 @@ class RasterContext:
         self._free_pinned = []
         self._evicted_overflow = False   # an overflow seen while retiring old fences: raised by the next poll()
         self.cut_retries = 0             # forwards flagged MGR_OVF_CUT (each is answered by a forward without the depth cut)
+        self.cut_repairs = 0             # (tile, quadrant) units repaired on the device by forwards with the depth cut (bit 2048)
+        self._clean = {}                 # (V, N, W, H) -> consecutive synchronised forwards that fitted their capacity
+        self.auto_fenced = 0             # forwards that ran on an automatic fence instead of the blocking read
         self.tier_retries = 0            # forwards flagged MGR_OVF_TIER (answered by a forward with every binning launch)
 
     # -- pool ---------------------------------------------------------------------------------
@@ -128,12 +142,13 @@ class RasterContext:
         self._fences.clear()
         self._evicted_overflow = False
         self.last_ws = None
+        self._clean.clear()
 
     def _learn(self, key, npairs):
         self.cap_hint[key] = max(self.cap_hint.get(key, 0), int(npairs * 1.25) + 4096)
 
     # -- forward driver -------------------------------------------------------------------------
-    def forward(self, V, N, W, H, launch, sync_check=True, defer_fence=False):
+    def forward(self, V, N, W, H, launch, sync_check=True, defer_fence=False, auto_fence=False):
         """Run `launch(ws)` (which enqueues one forward on the current stream) with a workspace large enough for
         the pairs it produces.  sync policy True: read the pair count back (one host sync, like upstream) and
         retry with a larger workspace on overflow; False: no host sync, an overflow fence is recorded instead
@@ -142,17 +157,30 @@ class RasterContext:
         the depth-cut flag in its second half."""
         key = (V, N, W, H)
         cap = max(self.cap_hint.get(key, 0), default_pair_capacity(V, N))
+        # auto_fence (the operator route): see AUTO_FENCE_AFTER
+        auto = bool(auto_fence) and sync_check and self.sync_every_forward and 0 < self.AUTO_FENCE_AFTER <= self._clean.get(key, 0)
+        if auto:
+            try:
+                self.poll()              # the automatic fences of the forwards before (complete by now)
+            except _lib.ManusHipError:
+                self._clean[key] = 0
+                raise _lib.ManusHipError("an unsynchronised forward of the previous step outgrew its pair capacity: its image and "
+                                         "gradients were incomplete.  The capacity was enlarged and this context reads the pair count "
+                                         "back again; set MANUS_AUTO_FENCE_AFTER=0 to keep every forward synchronous.")
         while True:
             ws = self.acquire(V, N, W, H, cap)
             # whoever launches may claim the depth-cut hints of the forward before (prev_hint_key) and name the views of
             # this one; a launch that does neither leaves hints nobody may use
             ws.prev_hint_key, ws.hint_key = ws.hint_key, None
-            fenced = not (sync_check and self.sync_every_forward)
+            fenced = auto or not (sync_check and self.sync_every_forward)
+            ws.no_flagging_skips = auto
             if fenced:
                 self._arm_mirror(ws)
             launch(ws)
             self.last_ws = ws
             if fenced:
+                if auto:
+                    self.auto_fenced += 1
                 if not defer_fence:
                     self._fence(ws)
                 return ws, None
@@ -162,7 +190,9 @@ class RasterContext:
             ws.tiers = None if (ovf.value & 4) else int(tiers.value)
             if rc == 0:
                 self._learn(key, npairs.value)
+                self._clean[key] = self._clean.get(key, 0) + 1
                 return ws, int(npairs.value)
+            self._clean[key] = 0
             if rc == -7 and not (ovf.value & 3):   # MGR_ETIER: a skipped binning launch was needed; same workspace, all launches
                 self.tier_retries += 1
                 ws.busy = False
@@ -231,7 +261,9 @@ class RasterContext:
         elif pinned is not None and not self._wait_flag(pinned):
             torch.cuda.synchronize(self.device)      # (a forward whose blend never ran: nothing will write the flag)
         if pinned is not None and int(pinned[3].item()) == 1:
-            npairs, ovf, tiers_seen = int(pinned[0].item()) & 0xFFFFFFFF, int(pinned[1].item()), int(pinned[2].item())
+            npairs, word, tiers_seen = int(pinned[0].item()) & 0xFFFFFFFF, int(pinned[1].item()) & 0xFFFFFFFF, int(pinned[2].item())
+            ovf = word & 0xFFFF
+            self.cut_repairs += word >> 16       # quadrants of depth-cut tiles the forward repaired on the device (no re-run)
         else:   # (a forward that did not run its blend, or no mirror: read the header -- valid if nothing ran on ws since)
             import ctypes
             n_, o_, t_ = ctypes.c_int64(0), ctypes.c_int32(0), ctypes.c_int32(0)
@@ -341,7 +373,7 @@ def _run_forward(cams, V, N, W, H, bg, means3D, cov3D, colors, opacity, debug, s
                                        ptr(ws.buf), ws.nbytes, ws.cap, int(bool(debug)) | ws.skip_bits(), stream()),
               "mgr_raster_forward")
 
-    ws, npairs = context(dev).forward(V, N, W, H, launch, sync_check)
+    ws, npairs = context(dev).forward(V, N, W, H, launch, sync_check, auto_fence=True)
     return out, radii, ws, npairs
 
 

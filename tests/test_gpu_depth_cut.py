@@ -117,6 +117,7 @@ def test_outdated_hints_are_flagged_and_the_rerun_is_exact(fenced):
     rasterizer.check_overflow(DEV)
     rasterizer.set_sync_policy(True, DEV)
     cmp_ = _compute(sc, targets, ct, cut=True)
+    cmp_.cut_repair = False                    # (the path without the on-device repair: flag, re-run)
     _warm(cmp_, views)
     cmp_(views)
     cmp_(views)
@@ -134,6 +135,67 @@ def test_outdated_hints_are_flagged_and_the_rerun_is_exact(fenced):
     rasterizer.poll(DEV)
     _same(nxt, want)
     assert fenced.cut_retries == 1
+
+
+def _moving_model_run(fenced, V, W, H, n, steps, d_opacity, margin, seed=5, penalty=16):
+    """A model whose opacities fall by d_opacity per step (the walks lengthen under the hints of the step before), rendered
+    by a compute object without the cut -- all states first: two objects taking turns on one workspace would wipe the hints --
+    and then by one with the cut and tight margins.  Returns (repaired quadrants, flagged forwards)."""
+    from manus_amd import rasterizer
+    from manus_amd._lib import ManusHipError
+    from util import keep
+    sc, targets, ct = _scene(V=V, n=n, W=W, H=H, seed=seed)
+    views = list(range(V))
+    ref = _compute(sc, targets, ct, cut=False)
+    _warm(ref, views)
+    wants = []
+    for _ in range(steps):
+        with torch.no_grad():
+            ref.params["_opacity"].sub_(d_opacity)
+        ref.mark_params_changed()
+        wants.append((keep(ref(views)), ref.last_image.clone()))
+    rasterizer.check_overflow(DEV)
+    rasterizer.set_sync_policy(True, DEV)
+    cmp_ = _compute(sc, targets, ct, cut=True)
+    cmp_.cut_margin, cmp_.cut_penalty = margin, penalty
+    _warm(cmp_, views)
+    cmp_(views)
+    cmp_(views)
+    rasterizer.poll(DEV)
+    flagged = 0
+    for want, img_want in wants:
+        with torch.no_grad():
+            cmp_.params["_opacity"].sub_(d_opacity)
+        cmp_.mark_params_changed()
+        got = cmp_(views)
+        try:
+            rasterizer.poll(DEV)
+        except ManusHipError:             # a capacity of the repair exceeded: the legacy answer, still exact
+            flagged += 1
+            got = cmp_(views)
+            rasterizer.poll(DEV)
+        _same(got, want)
+        assert torch.equal(cmp_.last_image, img_want)
+    return fenced.cut_repairs, flagged
+
+
+def test_tiles_that_run_out_are_repaired_on_the_device(fenced):
+    """Forward debug bit 2048: quadrants whose cut list runs out under an unsaturated pixel are completed by k_repair_scan /
+    k_repair_blend -- image, loss and every gradient stay bit for bit those of the full lists, step after step, without a
+    flagged forward; the per-tile countdown then keeps the tiles that ran out off the hints for a while."""
+    fenced.cut_repairs = 0
+    repairs, flagged = _moving_model_run(fenced, V=2, W=256, H=192, n=40000, steps=8, d_opacity=0.15, margin=0.25)
+    print("repaired quadrants over 8 steps: %d, flagged forwards: %d" % (repairs, flagged))
+    assert repairs > 0
+    assert flagged == 0, flagged
+
+
+def test_repair_capacity_exceeded_falls_back_to_the_flag(fenced):
+    """Every opacity far lower at once: more quadrants run out than the repair has units for (64 at this workspace size) -- the
+    forward is flagged like before round 6 and the re-run on full lists is exact."""
+    fenced.cut_repairs = 0
+    _, flagged = _moving_model_run(fenced, V=2, W=256, H=192, n=40000, steps=2, d_opacity=3.0, margin=0.25)
+    assert flagged >= 1
 
 
 def test_alternating_view_sets_keep_their_hints(fenced):
@@ -214,3 +276,50 @@ def test_depth_cut_at_the_bench_size(fenced):
     rasterizer.check_overflow(DEV)
     print("pairs in the lists at the bench size: %d full, %d with the cut (%.3f)" % (full, cut, cut / full))
     assert fenced.cut_retries == 0 and cut < 0.4 * full
+
+
+def test_repair_at_the_bench_size_under_adam(fenced):
+    """BASELINE config 3 at full size with the fused Adam step in the loop (the reference's learning rates): the model moves
+    under the hints every step, a handful of tiles run out per step and are repaired on the device -- gradients, statistics
+    and images of every step equal those of the same trajectory rendered from full lists, and no forward is flagged."""
+    from manus_amd import rasterizer
+    from manus_amd.optim import GaussianOptimizer
+    from manus_amd.synthetic import camera_table, make_scene
+    from util import keep
+    V, N, W, H = 8, 300000, 1920, 1080
+    sc = make_scene(n_gaussians=N, kind="hand", seed=0, n_cameras=V, width=W, height=H, device=DEV)
+    ct = camera_table(sc["cameras"], DEV)
+    targets = torch.rand((V, 3, H, W), generator=torch.Generator().manual_seed(9)).to(DEV)
+    views = list(range(V))
+    steps = 6
+    fenced.cut_repairs = 0
+
+    def run(cut):
+        rasterizer.set_sync_policy(True, DEV)
+        c = _compute(sc, targets, ct, cut=cut)
+        opt = GaussianOptimizer(c.params, adopt=True)
+        _warm(c, views)
+        c(views)
+        c(views)
+        outs = []
+        for _ in range(steps):
+            o = c(views, 1.0 / V)
+            rasterizer.poll(DEV)
+            outs.append((keep(o) if cut is False else o, c.last_image.clone() if cut is False else c.last_image))
+            if cut:
+                want, img_want = ref_outs[len(outs) - 1]
+                _same(o, want)
+                assert torch.equal(c.last_image, img_want)
+            opt.update_learning_rate(opt.state_step + 1)
+            opt.step(o["grads"])
+            c.mark_params_changed()
+        pairs = _surviving_pairs(c, V, N, W, H)
+        rasterizer.check_overflow(DEV)
+        return outs, pairs
+
+    ref_outs, full = run(False)
+    fenced.clear()
+    _, cut = run(True)
+    print("bench size under Adam: %d pairs in full lists, %d with the cut; %d quadrants repaired over %d steps, %d flagged forwards"
+          % (full, cut, fenced.cut_repairs, steps, fenced.cut_retries))
+    assert fenced.cut_retries == 0 and cut < 0.6 * full

@@ -13,11 +13,12 @@ DEV = "cuda:0"
 
 def layout(V, N, W, H, cap):
     from manus_amd._lib import lib
-    arr = (ctypes.c_size_t * 32)()
-    n = lib().mgr_raster_layout(V, N, W, H, cap, arr, 32)
+    arr = (ctypes.c_size_t * 40)()
+    n = lib().mgr_raster_layout(V, N, W, H, cap, arr, 40)
     names = ["header", "grec", "depth", "rect", "alive", "pair_off", "tile_count", "tile_start", "tile_cursor", "tile_done",
              "tile_queue", "chunk_start", "items", "ckpt", "keys", "sorted_gid", "final_T", "n_contrib", "pair_tag",
-             "pair_grad", "total", "inst_grad", "inst_tag", "db_nvis", "db_bbox", "db_order", "tile_zcut", "tile_zused", "tile_qend"]
+             "pair_grad", "total", "inst_grad", "inst_tag", "db_nvis", "db_bbox", "db_order", "tile_zcut", "tile_zused", "tile_qend",
+             "tile_rep", "rep_unit", "rep_cnt", "tile_zwin"]
     assert n == len(names)
     return dict(zip(names, [int(x) for x in arr[:n]]))
 
