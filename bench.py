@@ -90,20 +90,33 @@ def kernel_unit_bytes(name, V, consumed, P):
 # 61 N + 2 floats between "every peer link at once" (direct reduce-scatter + all-gather: 2 (S / n) / 76.8 GB/s) and "a ring
 # over one link at a time" ((n - 1) times that).
 COMPUTE_MS_BY_VIEWS = {8: 1.34, 4: 0.87, 2: 0.70, 1: 0.54}
+# ... and of BASELINE config 4 (COMPOSITE, 500 k Gaussians, 53 cameras over 8 ranks: seven views on the fullest rank),
+# profiles/r05_other_configs/composite_500k_v7.json; six views interpolated between that and the hand's per-view slope
+COMPOSITE_MS_BY_VIEWS = {7: 1.81, 6: 1.62}
 
 
 def predicted_ms(world, N, V, kind, W, H):
-    if world <= 1 or kind != "hand" or (W, H) != (1920, 1080) or V != 8 or N != 300000 or V % world:
+    """One-GPU compute of the fullest rank + the dense exchange between "every peer link at once" and "a ring over one link"
+    (DESIGN 8).  Only for the two multi-GPU configurations of BASELINE.json measured on one GPU: cfg3 (hand, 300 k, 8 views) and
+    cfg4 (composite, 500 k, 53 cameras)."""
+    if world <= 1 or (W, H) != (1920, 1080):
         return None
-    comp = COMPUTE_MS_BY_VIEWS.get(V // world)
+    per_rank = -(-V // world)          # views on the fullest rank
+    if kind == "hand" and V == 8 and N == 300000 and V % world == 0:
+        comp = COMPUTE_MS_BY_VIEWS.get(per_rank)
+    elif kind == "composite" and V == 53 and N == 500000 and world == 8:
+        comp = COMPOSITE_MS_BY_VIEWS.get(per_rank)
+    else:
+        comp = None
     if comp is None:
         return None
     S = (61 * N + 2) * 4
     direct = 2.0 * (S / world) / 76.8e9 * 1e3
     ring = direct * (world - 1)
-    return {"compute_ms": comp, "exchange_dense_ms_direct": round(direct, 3), "exchange_dense_ms_ring": round(ring, 3),
+    return {"compute_ms": comp, "views_on_the_fullest_rank": per_rank, "exchange_bytes_dense": S,
+            "exchange_dense_ms_direct": round(direct, 3), "exchange_dense_ms_ring": round(ring, 3),
             "step_ms_low": round(comp + direct, 3), "step_ms_high": round(comp + ring, 3),
-            "model": "DESIGN 7: one-GPU compute of views/rank + 61N+2 floats over 7 xGMI links x 76.8 GB/s per direction"}
+            "model": "DESIGN 8: one-GPU compute of the fullest rank's views + 61N+2 floats over 7 xGMI links x 76.8 GB/s per direction"}
 
 
 def cpu_model_string():
@@ -795,6 +808,10 @@ def main():
         step.step()
         rasterizer.check_overflow()
 
+    if world > 1 and out.get("overflow") is not None and float(out["overflow"]) > 0.0:
+        # (summed over the ranks by the step's collective: a rasterizer overflow on some rank, or -- compact mode -- a union of rows
+        # beyond the capacity the exchange was sized for; engine.Trainer runs such a step again, a benchmark must not count it)
+        raise RuntimeError("bench: the last timed step raised the step's overflow word (%g)" % float(out["overflow"]))
     views_by_rank = None
     if world > 1:
         views_by_rank = [None] * world
@@ -891,10 +908,11 @@ def main():
             arr = (ctypes.c_size_t * 32)()
             _lib.lib().mgr_raster_layout(Ks, N, W, H, ws2.cap, arr, 32)
             raw = ws2.buf
+            from tools.parity import read_records      # (test infrastructure: only the parity leg reads the kernels' records back)
             gpu = {"n_contrib": raw[int(arr[17]): int(arr[17]) + Ks * W * H * 4].view(torch.int32).reshape(Ks, H, W).cpu().numpy(),
                    "img": img_s.cpu().numpy(), "g_img": g_img.cpu().numpy(),
                    "grads": {k: v.detach().cpu() for k, v in o["grads"].items()},
-                   "grec": raw[int(arr[1]): int(arr[1]) + Ks * N * 48].view(torch.float32).reshape(Ks, N, 12).cpu().numpy(),
+                   "grec": read_records(raw, int(arr[1]), Ks * N).reshape(Ks, N, 12),
                    "depth": raw[int(arr[2]): int(arr[2]) + Ks * N * 4].view(torch.float32).reshape(Ks, N).cpu().numpy(),
                    "radii": compute.last_radii.cpu().numpy()}
             sc_cpu = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in scene.items() if k != "params"}

@@ -250,6 +250,9 @@ int mgr_sh_to_half(int N, const float* f_rest, void* out_half, void* stream);
  * tile's walks), tile_rep, rep_unit, rep_cnt (repair of depth-cut tiles: owner unit + 1 per tile, the 64-byte unit records,
  * entries found behind the cut per owner unit).  Returns the count. */
 int mgr_raster_layout(int V, int N, int W, int H, int64_t pair_capacity, size_t* out, int n_out);
+/* Debug/test: stride in bytes of the per-(view, Gaussian) records of the workspace's `grec` region (x, y, conic A B C, opacity,
+ * r g b, pair-slot base, rectangle width: twelve 4-byte words, then padding to the stride). */
+int mgr_raster_record_bytes(void);
 
 /* Blocking read-back of the workspace header after a forward: total number of
  * (Gaussian, tile) pairs (`num_rendered`, summed over views) and the overflow
@@ -583,6 +586,15 @@ int mgr_exchange_pack(int N, int n, const uint32_t* idx, const float* flat, int 
                       int64_t tail_off, float* buf, void* stream);
 int mgr_exchange_unpack(int N, int n, const uint32_t* idx, float* flat, int nseg, const int64_t* offs, const int* widths,
                         int64_t tail_off, const float* buf, const uint8_t* small_vis, int64_t vis_off, void* stream);
+/* The same two with the row count read FROM THE DEVICE (`count`: the word mgr_exchange_index wrote) and a row capacity
+ * `cap_rows` <= N chosen by the host beforehand -- the second collective (cap_rows x columns + 2 floats, segment k at
+ * cap_rows x its first column) is sized without a host read in the middle of the step.  Rows [min(*count, cap_rows), cap_rows)
+ * are packed as zeros and ignored by the unpack; *count > cap_rows adds 1 to the packed overflow word (buf's last float), which
+ * the all-reduce sums and the unpack writes back: the caller runs the step again with a larger capacity. */
+int mgr_exchange_pack_rows(int N, int cap_rows, const uint32_t* count, const uint32_t* idx, const float* flat, int nseg, const int64_t* offs,
+                           const int* widths, int64_t tail_off, float* buf, void* stream);
+int mgr_exchange_unpack_rows(int N, int cap_rows, const uint32_t* count, const uint32_t* idx, float* flat, int nseg, const int64_t* offs,
+                             const int* widths, int64_t tail_off, const float* buf, const uint8_t* small_vis, int64_t vis_off, void* stream);
 
 /* ------------------------------------------------------------------------
  * Measurement aid: when enabled, every kernel launched by this library is

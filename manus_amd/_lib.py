@@ -34,6 +34,7 @@ SIGNATURES = {
     "mgr_sh_to_half": (c_int, [c_int, c_vp, c_vp, c_vp]),
     "mgr_views_forward": (c_int, [c_int] * 7 + [c_vp] * 12 + [c_vp, c_sz, c_i64, c_int, c_vp]),
     "mgr_views_backward": (c_int, [c_int] * 7 + [c_vp] * 13 + [c_f32] + [c_vp] * 10 + [c_vp, c_sz, c_i64, c_int, c_vp]),
+    "mgr_raster_record_bytes": (c_int, []),
     "mgr_raster_layout": (c_int, [c_int, c_int, c_int, c_int, c_i64, ctypes.POINTER(c_sz), c_int]),
     "mgr_raster_status_sync": (c_int, [c_vp, ctypes.POINTER(c_i64), ctypes.POINTER(ctypes.c_int32), c_vp]),
     "mgr_raster_set_status_mirror": (c_int, [c_vp, c_vp]),
@@ -72,6 +73,9 @@ SIGNATURES = {
     "mgr_exchange_pack": (c_int, [c_int, c_int, c_vp, c_vp, c_int, ctypes.POINTER(c_i64), ctypes.POINTER(c_int), c_i64, c_vp, c_vp]),
     "mgr_exchange_unpack": (c_int, [c_int, c_int, c_vp, c_vp, c_int, ctypes.POINTER(c_i64), ctypes.POINTER(c_int), c_i64, c_vp, c_vp,
                                     c_i64, c_vp]),
+    "mgr_exchange_pack_rows": (c_int, [c_int, c_int, c_vp, c_vp, c_vp, c_int, ctypes.POINTER(c_i64), ctypes.POINTER(c_int), c_i64, c_vp, c_vp]),
+    "mgr_exchange_unpack_rows": (c_int, [c_int, c_int, c_vp, c_vp, c_vp, c_int, ctypes.POINTER(c_i64), ctypes.POINTER(c_int), c_i64, c_vp, c_vp,
+                                         c_i64, c_vp]),
     "mgr_l1_loss_grad": (c_int, [c_i64, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp]),
     "mgr_image_loss_workspace_bytes": (c_sz, [c_int, c_int, c_int]),
     "mgr_image_loss": (c_int, [c_int, c_int, c_int, c_vp, c_vp, c_f32, c_f32, c_f32, c_f32, c_vp, c_vp, c_vp, c_sz, c_vp]),

@@ -11,6 +11,10 @@
 //   mgr_exchange_pack     the union's rows, segment by segment, + (loss, overflow) into the buffer that is all-reduced
 //   mgr_exchange_unpack   the reduced rows back into the step buffer (rows outside the union are zero on every rank and
 //                         stay untouched), the reduced visibility counts back as floats
+// Round 6: mgr_exchange_pack_rows / _unpack_rows take the row count FROM THE DEVICE (the word mgr_exchange_index wrote) and a
+// row capacity the host chose beforehand (last step's count + headroom): the second collective is sized without the host
+// reading anything in the middle of the step.  Rows between the count and the capacity travel as zeros; a count beyond the
+// capacity raises the buffer's overflow word (summed over the ranks like the rasterizer's: the step is run again).
 #include "mgr_common.h"
 
 #define XCH_MAX_SEG 8
@@ -127,6 +131,66 @@ __global__ __launch_bounds__(256) void k_xch_move(int N, int n, int cols, const 
         else flat[tail_off + t] = buf[(size_t)n * cols + t];
     }
     if (!PACK && small_vis && t < N) flat[vis_off + t] = (float)small_vis[t];
+}
+
+template <bool PACK>
+__global__ __launch_bounds__(256) void k_xch_move_rows(int N, int cap_rows, const uint32_t* __restrict__ count, int cols,
+                                                       const uint32_t* __restrict__ idx, float* __restrict__ flat, XchSegs s, long long tail_off,
+                                                       float* __restrict__ buf, const uint8_t* __restrict__ small_vis, long long vis_off) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t cnt = *count;
+    const int n = (int)min(cnt, (uint32_t)cap_rows);
+    if (t < (long long)cap_rows * cols) {
+        const int r = (int)(t / cols), c = (int)(t % cols);
+        int k = 0;
+        while (k + 1 < s.n && c >= s.col0[k + 1]) ++k;
+        float* dst = buf + (size_t)cap_rows * s.col0[k] + (size_t)r * s.width[k] + (c - s.col0[k]);
+        if (r < n) {
+            float* src = flat + s.off[k] + (size_t)idx[r] * s.width[k] + (c - s.col0[k]);
+            if (PACK) *dst = *src; else *src = *dst;
+        } else if (PACK) {
+            *dst = 0.0f;                               // padding rows: zeros on every rank
+        }
+    }
+    if (t < 2) {   // (loss, overflow): a union larger than the capacity adds to the overflow word
+        if (PACK) buf[(size_t)cap_rows * cols + t] = flat[tail_off + t] + ((t == 1 && cnt > (uint32_t)cap_rows) ? 1.0f : 0.0f);
+        else flat[tail_off + t] = buf[(size_t)cap_rows * cols + t];
+    }
+    if (!PACK && small_vis && t < N) flat[vis_off + t] = (float)small_vis[t];
+}
+
+static int xch_move_rows(bool pack, int N, int cap_rows, const uint32_t* count, const uint32_t* idx, float* flat, int nseg, const int64_t* offs,
+                         const int* widths, int64_t tail_off, float* buf, const uint8_t* small_vis, int64_t vis_off, hipStream_t stream) {
+    const char* who = pack ? "mgr_exchange_pack_rows" : "mgr_exchange_unpack_rows";
+    if (N < 0 || cap_rows < 0 || cap_rows > N || !count || !flat || !buf || (cap_rows > 0 && !idx) || tail_off < 0)
+        return mgr_fail(MGR_EINVAL, "%s: bad arguments", who);
+    XchSegs s;
+    const int rc = xch_segs(nseg, offs, widths, s, who);
+    if (rc != MGR_OK) return rc;
+    const int cols = s.col0[nseg - 1] + s.width[nseg - 1];
+    long long threads = (long long)cap_rows * cols;
+    if (threads < 2) threads = 2;
+    if (!pack && small_vis && threads < N) threads = N;
+    MGR_PROF(pack ? "k_xch_pack" : "k_xch_unpack", stream);
+    if (pack)
+        hipLaunchKernelGGL((k_xch_move_rows<true>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, N, cap_rows, count, cols, idx, flat, s,
+                           (long long)tail_off, buf, (const uint8_t*)nullptr, 0ll);
+    else
+        hipLaunchKernelGGL((k_xch_move_rows<false>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, N, cap_rows, count, cols, idx, flat, s,
+                           (long long)tail_off, buf, small_vis, (long long)vis_off);
+    MGR_LAUNCH_CHECK(who, stream, 0);
+    return MGR_OK;
+}
+
+extern "C" int mgr_exchange_pack_rows(int N, int cap_rows, const uint32_t* count, const uint32_t* idx, const float* flat, int nseg, const int64_t* offs,
+                                      const int* widths, int64_t tail_off, float* buf, void* stream) {
+    return xch_move_rows(true, N, cap_rows, count, idx, const_cast<float*>(flat), nseg, offs, widths, tail_off, buf, nullptr, 0, (hipStream_t)stream);
+}
+
+extern "C" int mgr_exchange_unpack_rows(int N, int cap_rows, const uint32_t* count, const uint32_t* idx, float* flat, int nseg, const int64_t* offs,
+                                        const int* widths, int64_t tail_off, const float* buf, const uint8_t* small_vis, int64_t vis_off, void* stream) {
+    return xch_move_rows(false, N, cap_rows, count, idx, flat, nseg, offs, widths, tail_off, const_cast<float*>(buf), small_vis, vis_off,
+                         (hipStream_t)stream);
 }
 
 extern "C" int mgr_exchange_mask(int N, const float* flat, int nseg, const int64_t* offs, const int* widths, int64_t vis_off,

@@ -151,14 +151,23 @@ struct MgrHeader {            // first 256 bytes of the workspace
 #define MGR_OVF_CUT 2u     // a tile whose list was cut short by the depth cut ran out of entries with a pixel still unsaturated
 #define MGR_OVF_TIER 4u    // a view's tile box needed a binning launch the caller had asked to skip (debug bits 16 / 32)
 
-// 48-byte per-(view,Gaussian) record gathered by the blend kernels
-struct __attribute__((aligned(16))) MgrGRec {
+// Per-(view, Gaussian) record gathered by the blend kernels: 48 bytes of content in a 64-byte slot on a 64-byte boundary.
+// The memory side serves gathers in 128-byte requests (profiles/r06_counter_calibration.txt): a quarter of 48-byte records at
+// 16-byte alignment straddle two of them, a 64-byte slot never does -- k_blend_bwd 0.350 -> 0.344 ms, k_blend_fwd 0.239 -> 0.238,
+// step 1.332 -> 1.318 ms (round 6 A/B, one box; -DMGR_GREC_BYTES=48 builds the packed layout again).
+#ifndef MGR_GREC_BYTES
+#define MGR_GREC_BYTES 64
+#endif
+struct __attribute__((aligned(MGR_GREC_BYTES == 64 ? 64 : 16))) MgrGRec {
     float x, y, ca, cb;       // pixel centre, conic A, B
     float cc, op, r, g;       // conic C, opacity, colour r, g
     float b;                  // colour b
     int32_t slot_base;        // pair slot = slot_base + ty*rect_w + tx
     int32_t rect_w;
     int32_t pad;
+#if MGR_GREC_BYTES == 64
+    int32_t pad64[4];
+#endif
 };
 
 #define MGR_CHUNK 64         // list entries per backward work item / forward checkpoint interval (one batch of the blend waves)

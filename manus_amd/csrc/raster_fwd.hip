@@ -119,11 +119,12 @@ extern "C" int mgr_build_variant(void) {
 #if defined(FWD_PF1) || defined(FWD_LDS_PIPE1)
     bits |= 4;
 #endif
-    if (MGR_BIN_BLOCK != 1024) bits |= 4;
+    if (MGR_BIN_BLOCK != 1024 || MGR_GREC_BYTES != 64) bits |= 4;
     return bits;
 }
 extern "C" const char* mgr_last_error(void) { return g_mgr_err; }
 
+extern "C" int mgr_raster_record_bytes(void) { return (int)sizeof(MgrGRec); }
 extern "C" size_t mgr_raster_workspace_bytes(int V, int N, int W, int H, int64_t cap) {
     return mgr_layout(V, N, W, H, cap).total;
 }
@@ -2416,8 +2417,9 @@ __global__ __launch_bounds__(256) void k_repair_prep(int T, int gx, MgrHeader* h
 //    tile): thousands of returning atomics on one address are served one after the other at ~11 ns each (measured: 0.157 ms
 //    per launch with an atomic per candidate).
 #define REP_SCAN_THREADS 256
-#define REP_SCAN_SEGS 64
+#define REP_SCAN_SEGS 128
 #define REP_STASH 1024
+#define REP_HITS 3072
 __global__ __launch_bounds__(REP_SCAN_THREADS) void k_repair_scan(int N, int T, int gx, MgrHeader* hdr, const MgrRep rep,
                                                                   const int32_t* __restrict__ radii, const ushort4* __restrict__ rect,
                                                                   const float* __restrict__ depth, const MgrGRec* __restrict__ grec) {
@@ -2426,10 +2428,11 @@ __global__ __launch_bounds__(REP_SCAN_THREADS) void k_repair_scan(int N, int T, 
     const MgrRepView* rv = rep.view + v;
     const uint32_t nt = rv->n;
     if (nt == 0u || nt > (uint32_t)MGR_REP_VIEW_TILES) return;
-    __shared__ uint32_t s_stash_n;
+    __shared__ uint32_t s_stash_n, s_nhit;
     __shared__ uint32_t s_tile[MGR_REP_VIEW_TILES], s_unit[MGR_REP_VIEW_TILES], s_zc[MGR_REP_VIEW_TILES], s_zw[MGR_REP_VIEW_TILES];
     __shared__ uint32_t s_hits[MGR_REP_VIEW_TILES], s_beyond[MGR_REP_VIEW_TILES];
     __shared__ uint4 s_stash[REP_STASH];   // (tile slot, rank among the workgroup's hits of that tile, depth bits, Gaussian)
+    __shared__ uint2 s_hit[REP_HITS];      // (instance, tile slot | tile x << 8 | tile y << 20) of a batch
     __shared__ uint32_t s_bits[2048];      // one bit per tile of the view (the ordered binning serves grids of up to 65535 tiles)
     if (tid == 0) s_stash_n = 0u;
     for (int k = tid; k < 2048; k += REP_SCAN_THREADS) s_bits[k] = 0u;
@@ -2441,21 +2444,45 @@ __global__ __launch_bounds__(REP_SCAN_THREADS) void k_repair_scan(int N, int T, 
     }
     const int bx0 = (int)rv->x0, by0 = (int)rv->y0, bx1 = (int)rv->x1, by1 = (int)rv->y1;
     __syncthreads();
+    // Two phases per batch of instances.  (1) rectangle against the bitmap, LDS only: (instance, repaired tile) hits go to an LDS
+    // list.  (2) the hits, one per thread: visibility, depth, the exact cull test -- the three global loads of a hit (radius,
+    // depth, 48-byte record) are then in flight for 256 hits at once.  (With the loads inside the rectangle loop a wave paid
+    // their round trip once per hit, lane by lane as the loop diverged: 0.079 ms per launch for six repaired tiles.)
+    auto settle = [&](uint32_t i, uint32_t k, int x, int y) {
+        const size_t vi = (size_t)v * N + i;
+        if (radii[vi] <= 0) return;
+        const uint32_t zbits = __float_as_uint(depth[vi]);
+        if (zbits <= s_zc[k]) return;                            // in front of the cut: listed already
+        const MgrGRec g = grec[vi];
+        const MgrCull cull = mgr_cull_init(g.x, g.y, g.ca, g.cb, g.cc, mgr_qmax(g.op));
+        float dy_lo, dy_hi, dxo;
+        mgr_cull_row(cull, 16.0f * y, 16.0f * y + 15.0f, dy_lo, dy_hi, dxo);
+        if (mgr_cull_dead(cull, dy_lo, dy_hi, dxo, 16.0f * x, 16.0f * x + 15.0f)) return;
+        if (zbits > s_zw[k]) { atomicAdd(&s_beyond[k], 1u); return; }      // behind the depth window: counted only
+        const uint32_t slot = atomicAdd(&s_stash_n, 1u);
+        if (slot < (uint32_t)REP_STASH) {
+            s_stash[slot] = make_uint4(k, atomicAdd(&s_hits[k], 1u), zbits, i);
+        } else {      // (more candidates in one workgroup than the stage holds: straight to the buffer)
+            const uint32_t u = s_unit[k], gslot = atomicAdd(&rep.cnt[u], 1u);
+            if (gslot < (uint32_t)MGR_REP_CAND) rep.cand[(size_t)u * MGR_REP_CAND + gslot] = ((unsigned long long)zbits << 32) | i;
+        }
+    };
     const int per = (N + REP_SCAN_SEGS - 1) / REP_SCAN_SEGS, i_lo = (int)blockIdx.x * per, i_hi = min(N, i_lo + per);
-    for (int ib = i_lo; ib < i_hi; ib += 4 * REP_SCAN_THREADS) {
-        ushort4 rc[4];
+    if (tid == 0) s_nhit = 0u;
+    __syncthreads();
+    // (one pass over the workgroup's whole segment, no barrier inside: with a barrier per batch of 1024 instances the five
+    // batches of a segment each paid the rectangle loads' and the hits' round trips one after the other: 0.055 ms per launch)
+    for (int ib = i_lo; ib < i_hi; ib += 6 * REP_SCAN_THREADS) {
+        ushort4 rc[6];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) rc[r] = rect[(size_t)v * N + min(ib + r * REP_SCAN_THREADS + tid, N - 1)];      // four loads in flight
+        for (int r = 0; r < 6; ++r) rc[r] = rect[(size_t)v * N + min(ib + r * REP_SCAN_THREADS + tid, N - 1)];      // six loads in flight
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < 6; ++r) {
             const int i = ib + r * REP_SCAN_THREADS + tid;
             const int x0 = rc[r].x, y0 = rc[r].y, x1 = rc[r].z, y1 = rc[r].w;
             const int tiles = (x1 - x0) * (y1 - y0);
             if (i >= i_hi || tiles <= 0 || tiles > 64) continue;            // (larger rectangles are never cut: pre_tail)
             if (x1 <= bx0 || x0 >= bx1 || y1 <= by0 || y0 >= by1) continue;
-            bool have = false;
-            uint32_t zbits = 0u;
-            MgrCull cull;
             for (int y = max(y0, by0); y < min(y1, by1); ++y)
                 for (int x = max(x0, bx0); x < min(x1, bx1); ++x) {
                     const uint32_t t = (uint32_t)(y * gx + x);
@@ -2463,28 +2490,18 @@ __global__ __launch_bounds__(REP_SCAN_THREADS) void k_repair_scan(int N, int T, 
                     uint32_t k = 0;
                     while (k < nt && s_tile[k] != t) ++k;
                     if (k == nt) continue;
-                    const size_t vi = (size_t)v * N + i;
-                    if (!have) {
-                        have = true;
-                        if (radii[vi] > 0) {
-                            zbits = __float_as_uint(depth[vi]);
-                            const MgrGRec g = grec[vi];
-                            cull = mgr_cull_init(g.x, g.y, g.ca, g.cb, g.cc, mgr_qmax(g.op));
-                        }
-                    }
-                    if (zbits == 0u || zbits <= s_zc[k]) continue;       // not visible, or in front of the cut: listed already
-                    float dy_lo, dy_hi, dxo;
-                    mgr_cull_row(cull, 16.0f * y, 16.0f * y + 15.0f, dy_lo, dy_hi, dxo);
-                    if (mgr_cull_dead(cull, dy_lo, dy_hi, dxo, 16.0f * x, 16.0f * x + 15.0f)) continue;
-                    if (zbits > s_zw[k]) { atomicAdd(&s_beyond[k], 1u); continue; }      // behind the depth window: counted only
-                    const uint32_t slot = atomicAdd(&s_stash_n, 1u);
-                    if (slot < (uint32_t)REP_STASH) {
-                        s_stash[slot] = make_uint4(k, atomicAdd(&s_hits[k], 1u), zbits, (uint32_t)i);
-                    } else {      // (more hits in one workgroup than the stage holds: straight to the buffer)
-                        const uint32_t u = s_unit[k], g = atomicAdd(&rep.cnt[u], 1u);
-                        if (g < (uint32_t)MGR_REP_CAND) rep.cand[(size_t)u * MGR_REP_CAND + g] = ((unsigned long long)zbits << 32) | (unsigned)i;
-                    }
+                    const uint32_t h = atomicAdd(&s_nhit, 1u);
+                    if (h < (uint32_t)REP_HITS) s_hit[h] = make_uint2((uint32_t)i, k | ((uint32_t)x << 8) | ((uint32_t)y << 20));
+                    else settle((uint32_t)i, k, x, y);                      // (list full: settled on the spot)
                 }
+        }
+    }
+    __syncthreads();
+    {
+        const uint32_t nh = min(s_nhit, (uint32_t)REP_HITS);
+        for (uint32_t h = (uint32_t)tid; h < nh; h += REP_SCAN_THREADS) {
+            const uint2 e = s_hit[h];
+            settle(e.x, e.y & 0xFFu, (int)((e.y >> 8) & 0xFFFu), (int)(e.y >> 20));
         }
     }
     __syncthreads();
@@ -2882,7 +2899,7 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
     const int img_kept = (debug & 1024) ? 1 : 0;   // bit 10: "image kept" (see BgFill)
     // bit 11 (2048, with bit 3): tiles whose cut list runs out under an unsaturated pixel are repaired on the device
     // (k_repair_scan / k_repair_blend) instead of flagging the forward
-    const bool repair = use_cut && (debug & 2048);
+    const bool repair = use_cut && (debug & 2048) && W < 65536 && H < 65536;   // (k_repair_scan packs tile coordinates in 12 bits)
     debug &= 1;
     if (V <= 0 || N < 0 || W <= 0 || H <= 0 || cap < 0 || cap > 0xFFFFFFF0ll)
         return mgr_fail(MGR_EINVAL, "mgr_raster_forward: bad sizes");

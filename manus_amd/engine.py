@@ -237,9 +237,14 @@ def _compact_all_reduce(self, flat, fv, active=None):
 
     On the GPU everything around the two collectives is five launches of the library (csrc/exchange.hip): the mask -- from
     the fused backward's own list of the Gaussians that received a gradient when the compute function hands it over
-    (`active`), otherwise from the rows --, the ordered row list (two launches), one pack, one unpack; the host reads one
-    number, the list's length, which sizes the second collective.  Tensors on the CPU (the gloo tests of the rank logic,
-    where a CPU stand-in computes the gradients) take the same steps in torch."""
+    (`active`), otherwise from the rows --, the ordered row list (two launches), one pack, one unpack.  The host reads
+    NOTHING in the middle of the step (round 6): the second collective is sized by a row capacity chosen beforehand -- the
+    union's size of the step before + 25 % (+ 1024; all N rows the first time) --, the pack / unpack kernels take the actual
+    count from the device, rows between count and capacity travel as zeros, and a union that outgrows the capacity adds to
+    the step's overflow word (summed over the ranks: `Trainer._run_step` runs the step again, by which time the count has
+    arrived on the host through an asynchronous copy and the capacity has grown).  `self.last_rows`: the count of the most
+    recent step whose copy has arrived.  Tensors on the CPU (the gloo tests of the rank logic, where a CPU stand-in
+    computes the gradients) take the same steps in torch."""
     N = self.N
     if self.n_views > 255:
         raise ValueError("compact all-reduce carries the visibility count in one byte: at most 255 views per step (use the dense mode)")
@@ -259,26 +264,33 @@ def _compact_all_reduce(self, flat, fv, active=None):
             sc = self._xch = dict(small=torch.empty(2 * N, dtype=torch.uint8, device=dev), idx=torch.empty(N, dtype=torch.int32, device=dev),
                                   count=torch.zeros(1, dtype=torch.int32, device=dev),
                                   ws=torch.empty(L.mgr_exchange_index_workspace_bytes(N), dtype=torch.uint8, device=dev),
-                                  host=torch.zeros(1, dtype=torch.int32).pin_memory(), buf=None)
+                                  host=torch.zeros(1, dtype=torch.int32).pin_memory(), buf=None, ev=None, cap_rows=N)
         small, idx, count = sc["small"], sc["idx"], sc["count"]
+        if sc["ev"] is not None and sc["ev"].query():          # the count of an earlier step has arrived: the capacity follows it
+            n_seen = int(sc["host"][0])
+            self.last_rows, sc["ev"] = n_seen, None
+            sc["cap_rows"] = min(N, int(n_seen * 1.25) + 1024)
+        cap_rows = int(getattr(self, "row_capacity", None) or sc["cap_rows"])      # (row_capacity: a test's fixed capacity)
         lst, cnt = active if active is not None else (None, None)
         check(L.mgr_exchange_mask(N, ptr(flat), nseg, offs, widths, vis_off, lst, cnt, ptr(small), stream()), "mgr_exchange_mask")
         if live:
             dist.all_reduce(small, op=dist.ReduceOp.SUM, group=self.group)
         check(L.mgr_exchange_index(N, ptr(small), ptr(idx), ptr(count), ptr(sc["ws"]), sc["ws"].numel(), stream()), "mgr_exchange_index")
-        sc["host"].copy_(count, non_blocking=True)
-        torch.cuda.current_stream().synchronize()                            # (host sync: the collective's size)
-        n = int(sc["host"][0])
-        self.last_rows = n
-        need = n * (GRAD_WIDTH + 1) + FLAT_TAIL
+        need = cap_rows * (GRAD_WIDTH + 1) + FLAT_TAIL
         if sc["buf"] is None or sc["buf"].numel() < need:
-            sc["buf"] = torch.empty(int(need * 1.25) + 64, dtype=torch.float32, device=dev)
+            sc["buf"] = torch.empty(need + 64, dtype=torch.float32, device=dev)
         buf = sc["buf"][:need]
-        check(L.mgr_exchange_pack(N, n, ptr(idx), ptr(flat), nseg, offs, widths, tail_off, ptr(buf), stream()), "mgr_exchange_pack")
+        check(L.mgr_exchange_pack_rows(N, cap_rows, ptr(count), ptr(idx), ptr(flat), nseg, offs, widths, tail_off, ptr(buf), stream()),
+              "mgr_exchange_pack_rows")
         if live:
             dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
-        check(L.mgr_exchange_unpack(N, n, ptr(idx), ptr(flat), nseg, offs, widths, tail_off, ptr(buf), small[N:].data_ptr(), vis_off,
-                                    stream()), "mgr_exchange_unpack")
+        check(L.mgr_exchange_unpack_rows(N, cap_rows, ptr(count), ptr(idx), ptr(flat), nseg, offs, widths, tail_off, ptr(buf),
+                                         small[N:].data_ptr(), vis_off, stream()), "mgr_exchange_unpack_rows")
+        if sc["ev"] is None:                                   # the count travels to the host behind the step (read by a later one)
+            sc["host"].copy_(count, non_blocking=True)
+            sc["ev"] = torch.cuda.Event()
+            sc["ev"].record()
+        self.last_cap_rows = cap_rows
         return
     small = torch.cat([_row_mask(fv, N), fv["vis"].to(torch.uint8)])
     if live:

@@ -24,7 +24,7 @@ import torch
 from util import max_rel_err, psnr
 
 from tools.parity import (DEV, FLIP_EPS, align_threshold_decisions, device_alpha_decisions, fused_records,  # noqa: F401
-                          kernel_last_gaussian, layout)
+                          kernel_last_gaussian, layout, read_records)
 
 
 def _contributors_at(bo, rec, pix, W):

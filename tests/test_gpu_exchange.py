@@ -55,7 +55,12 @@ def test_compact_exchange_kernels_equal_the_torch_steps(N, density, use_list):
         st._compact_all_reduce(st._store, fv, active=active)
         if dev != "cpu":
             torch.cuda.synchronize()
+            # (the union's size reaches the host through an asynchronous copy behind the step; the first step travels with all N rows)
+            assert int(st._xch["host"][0]) == (n_expect if use_list else len(rows)) and st.last_cap_rows == N
+            st._compact_all_reduce(st._store, fv, active=active)      # ... and sizes the next step's collective
+            torch.cuda.synchronize()
             assert st.last_rows == (n_expect if use_list else len(rows))
+            assert st.last_cap_rows == min(N, int(st.last_rows * 1.25) + 1024)
         outs.append(st._store.cpu())
     # one rank: the exchange is the identity on the rows and rewrites the visibility counts from their byte form
     assert torch.equal(outs[0], flat_cpu) and torch.equal(outs[1], flat_cpu)
@@ -103,3 +108,32 @@ def test_exchange_index_is_ordered_and_pack_layout_matches_the_torch_buffer():
     assert torch.equal(flat.cpu(), exp)
     with pytest.raises(Exception):
         check(L.mgr_exchange_pack(N, N + 1, ptr(idx), ptr(flat), 7, offs_c, widths_c, 0, ptr(buf), stream()), "pack")
+
+
+def test_compact_exchange_row_capacity_is_enforced_on_the_device():
+    """mgr_exchange_pack_rows / _unpack_rows: the collective is sized by a row capacity the host chose beforehand, the count
+    stays on the device.  A capacity that holds the union: the exchange is the identity on one rank, padding rows travel as
+    zeros.  A capacity below the union: the overflow word of the step buffer is raised (Trainer._run_step runs the step again)."""
+    from manus_amd.engine import GRAD_LAYOUT, GRAD_WIDTH, ViewShardedStep
+    N = 6000
+    flat_cpu, rows, padded = _flat(N, 0.3, seed=21)
+    shapes = {name: (N, w) for name, w in GRAD_LAYOUT}
+    n = len(rows)
+    for cap, ok in ((n, True), (n + 57, True), (n - 1, False), (N, True)):
+        st = ViewShardedStep(N, shapes, _Fn(), 8)
+        st._store = flat_cpu.clone().to(DEV)
+        st.row_capacity = cap
+        st._compact_all_reduce(st._store, st._views())
+        torch.cuda.synchronize()
+        out = st._store.cpu()
+        buf = st._xch["buf"][: cap * (GRAD_WIDTH + 1) + 2].cpu()
+        assert st.last_cap_rows == cap and int(st._xch["host"][0]) == n
+        if ok:
+            assert torch.equal(out, flat_cpu)
+            # rows [n, cap) of every segment are zeros
+            o = 0
+            for _, w in list(GRAD_LAYOUT) + [("grad2d", 1)]:
+                assert not buf[o + n * w: o + cap * w].any()
+                o += cap * w
+        else:
+            assert float(out[-1]) == 1.0 and float(out[-2]) == float(flat_cpu[-2])     # the overflow word; the loss still travels

@@ -15,7 +15,7 @@ import numpy as np
 import pytest
 import torch
 
-from fused_oracle import align_threshold_decisions, assert_north_star, kernel_last_gaussian, layout, run_fused_vs_oracle
+from fused_oracle import align_threshold_decisions, assert_north_star, kernel_last_gaussian, layout, read_records, run_fused_vs_oracle
 from util import cam_args, cam_table_np, max_rel_err, psnr
 
 pytestmark = pytest.mark.gpu
@@ -54,7 +54,7 @@ def test_config2_object_100k_operator_path_vs_full_oracle():
     # ---- threshold flips: the oracle's ambiguous pairs, decided by the device on the KERNEL's records
     ws = rz.context().last_ws
     L = layout(1, n, W, H, ws.cap)
-    grec = ws.buf[L["grec"]: L["grec"] + n * 48].view(torch.float32).reshape(n, 12).cpu().numpy()
+    grec = read_records(ws.buf, L["grec"], n)
     geo = ro.geom()
     vis = ro.radii > 0
     assert np.abs(grec[vis, 0:2] - geo["xy"][vis]).max() < 1e-3 and max_rel_err(grec[vis, 2:5], geo["conic_opacity"][vis, :3]) < 1e-5

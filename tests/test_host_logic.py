@@ -416,3 +416,7 @@ def test_predicted_ms_rides_in_the_multi_gpu_line():
         assert (p["step_ms_low"] < p["step_ms_high"] or n == 2) and p["compute_ms"] == bench.COMPUTE_MS_BY_VIEWS[8 // n]
     assert bench.predicted_ms(1, 300000, 8, "hand", 1920, 1080) is None
     assert bench.predicted_ms(8, 30000, 8, "hand", 480, 270) is None
+    # BASELINE config 4: composite, 500 k Gaussians, 53 cameras over 8 ranks (seven views on the fullest rank, 122 MB dense)
+    p = bench.predicted_ms(8, 500000, 53, "composite", 1920, 1080)
+    assert p["views_on_the_fullest_rank"] == 7 and p["compute_ms"] == bench.COMPOSITE_MS_BY_VIEWS[7] and p["exchange_bytes_dense"] == (61 * 500000 + 2) * 4
+    assert p["step_ms_low"] < p["step_ms_high"]

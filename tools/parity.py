@@ -23,12 +23,20 @@ def layout(V, N, W, H, cap):
     return dict(zip(names, [int(x) for x in arr[:n]]))
 
 
+def read_records(buf, offset, n):
+    """(n, 12) float32: the content words of n per-(view, Gaussian) records starting at byte `offset` of a workspace tensor (the
+    records sit in slots of mgr_raster_record_bytes() bytes)."""
+    from manus_amd._lib import lib
+    stride = int(lib().mgr_raster_record_bytes())
+    return buf[offset: offset + n * stride].view(torch.float32).reshape(n, stride // 4)[:, :12].cpu().numpy().copy()
+
+
 def fused_records(ws, V, N, W, H):
     """(grec (V,N,12), depth (V,N), gathered blend sums (N,G,12)) of the last forward / backward on workspace `ws`."""
     L = layout(V, N, W, H, ws.cap)
     P = W * H
     ncontrib = ws.buf[L["n_contrib"]: L["n_contrib"] + V * P * 4].view(torch.int32).reshape(V, H, W).cpu().numpy()
-    grec = ws.buf[L["grec"]: L["grec"] + V * N * 48].view(torch.float32).reshape(V, N, 12).cpu().numpy()
+    grec = read_records(ws.buf, L["grec"], V * N).reshape(V, N, 12)
     depth = ws.buf[L["depth"]: L["depth"] + V * N * 4].view(torch.float32).reshape(V, N).cpu().numpy()
     G = 1 if V <= 1 else 2 if V <= 2 else 4 if V <= 4 else 8
     iacc = ws.buf[L["inst_grad"]: L["inst_grad"] + N * G * 48].view(torch.float32).reshape(N, G, 12).cpu().numpy().copy()
