@@ -975,7 +975,8 @@ def main():
                        "allreduce": (None if world == 1 else "reduce-scatter + sharded Adam + all-gather" if sharded else
                                      {"mode": mode, "ms_per_step_by_mode": mode_timings,
                                       "detail": "dense 61N floats" if mode == "dense" else
-                                                "rows with a gradient (%s of %d) x 60 floats + 2N bytes" % (step.last_rows, N)}),
+                                                "rows with a gradient (%s of %d; the collective is sized for %s) x 60 floats + 2N bytes"
+                                                % (step.exchanged_rows(), N, getattr(step, "last_cap_rows", None))}),
                        "predicted_ms": predicted_ms(world, N, V, args.kind, W, H),
                        "optimizer_in_step": bool(args.optimizer), "sh_storage": args.sh_storage,
                        "gaussian_order": args.gaussian_order,

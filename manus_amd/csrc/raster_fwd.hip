@@ -1670,7 +1670,8 @@ __device__ unsigned long long g_binprof[8 * 4096];
 #define BIN_SC_THREADS 192
 // c_row_comb[w] = sum over j of 2^(2 w j) below 2^64: times a row's w bits = the even rows of a rectangle of width w
 __constant__ unsigned long long c_row_comb[65] = {0x0000000000000000ull, 0x5555555555555555ull, 0x1111111111111111ull, 0x1041041041041041ull, 0x0101010101010101ull, 0x1004010040100401ull, 0x1001001001001001ull, 0x0100040010004001ull, 0x0001000100010001ull, 0x0040001000040001ull, 0x1000010000100001ull, 0x0000100000400001ull, 0x0001000001000001ull, 0x0010000004000001ull, 0x0100000010000001ull, 0x1000000040000001ull, 0x0000000100000001ull, 0x0000000400000001ull, 0x0000001000000001ull, 0x0000004000000001ull, 0x0000010000000001ull, 0x0000040000000001ull, 0x0000100000000001ull, 0x0000400000000001ull, 0x0001000000000001ull, 0x0004000000000001ull, 0x0010000000000001ull, 0x0040000000000001ull, 0x0100000000000001ull, 0x0400000000000001ull, 0x1000000000000001ull, 0x4000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull};
-#define BIN_SC_FIXED_BYTES (2 * 64 * sizeof(BinRec) + 2 * BIN_PAIR_CAP * 4 + 2 * 64 * 4 + 16 + 66 * 8)
+#define BIN_SC_FIXED_BYTES (2 * 64 * sizeof(BinRec) + 2 * BIN_PAIR_CAP * 4 + 3 * 64 * 4 + 16 + 66 * 8)
+#define BIN_END 0xFFFFFFFEu   // s_info: the producer has nothing more (the loop's exit, read by every wave behind the barrier)
 // MASKS = tiles the per-tile lane masks cover: BIN_MID_TILES (30 KB of LDS, five workgroups per CU -- the boxes of the
 // hand scene hold 960-1470 tiles, tools/instr/tile_bbox.py), BIN_SMALL_TILES (36 KB, four per CU) or 0 (no masks: any box).
 #define BIN_MID_TILES 1536
@@ -1694,9 +1695,10 @@ __global__ __launch_bounds__(BIN_SC_THREADS) void k_bin_scatter(int N, int T, in
     unsigned long long* s_mask = (unsigned long long*)(s_mem + 2 * 64 * (sizeof(BinRec) / 4));   // SMALL: lane mask per tile
     uint32_t* s_pairs = (uint32_t*)(s_mask + MASKS);                      // [2][CAP] pairs: tile | lane << 16
     uint32_t* s_gid = s_pairs + 2 * BIN_PAIR_CAP;                       // [2][64] Gaussians of the batch
-    uint32_t* s_info = s_gid + 2 * 64;                                  // [2] pairs of the batch, or ~0: by-instance route
+    uint32_t* s_info = s_gid + 2 * 64;                                  // [2] pairs of the batch, or ~0: by-instance route, or BIN_END
     unsigned long long* s_comb = (unsigned long long*)(s_info + 4);     // [66] copy of c_row_comb (a divergent constant load is a vector-memory round trip)
-    uint32_t* s_cur = (uint32_t*)(s_comb + 66);                         // cursors of the box's tiles (absolute list slots)
+    uint32_t* s_vend = (uint32_t*)(s_comb + 66);                        // [64] producer: running count of the lanes a batch with a rectangle of more than 64 tiles is spread over
+    uint32_t* s_cur = s_vend + 64;                                      // cursors of the box's tiles (absolute list slots)
     const int v = blockIdx.y, b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const ushort4 box = db_bbox[v];
     if (!bin_sc_mine(box, MASKS)) {
@@ -1734,19 +1736,78 @@ __global__ __launch_bounds__(BIN_SC_THREADS) void k_bin_scatter(int N, int T, in
     const long long t00_ = wall_clock64();
     long long tp_ = t00_;
 #endif
+    // Round 6: rectangles of more than 64 tiles (a third of the Gaussians when the cameras are close to the hand) no longer send
+    // their whole batch through the instance-by-instance route (measured on the close-up camera set: k_bin_scatter 1.2 ms of a
+    // 4.1 ms step).  A batch that holds one is spread over LANES: every row of such a rectangle -- pieces of at most 64 tiles --
+    // becomes a lane of its own with an all-ones mask (nothing of these rectangles is culled), the others keep their lane, in
+    // instance order; the lanes go through the expansion below 64 at a time, so the producer emits a data-dependent number of
+    // batches and ends the loop with BIN_END.  Pieces of one rectangle cover different tiles: their order among themselves
+    // does not matter, and a tile still sees its entries in instance order.
+    int src_it = 0;                 // producer: source batches taken
+    uint32_t v_total = 0, v_off = 0;   // lanes the current source batch is spread over / already emitted
+    bool v_mapped = false;
+    BinRec cur = {0u, 0u, 0u, 0u, 0u, 0u};
 #pragma unroll 1
-    for (int it = 0; it <= nbatch; ++it) {
+    for (int it = 0;; ++it) {
         __syncthreads();   // batch it - 1 is expanded (and, the first time, the cursors are loaded); batch it - 2 is consumed
+        if (it >= 1 && s_info[(it - 1) & 1] == BIN_END) break;
         BP(5)
         if (wave == 0) {
-            if (it < nbatch) {   // ---- producer: batch `it` into buffer it & 1
-                const int d = it & 1;
-                const BinRec r = nxt;
-                BP(0)
-                if (it + 1 < nbatch) nxt = bin_load(N, v, p0 + 64u * (uint32_t)(it + 1) + lane, nvis, box, db_order, db_rec);
+            const int d = it & 1;
+            if (v_off >= v_total && src_it >= nbatch) {
+                if (lane == 0) s_info[d] = BIN_END;
+            } else {   // ---- producer: the next 64 lanes into buffer it & 1
+                if (v_off >= v_total) {      // the next source batch
+                    cur = nxt;
+                    BP(0)
+                    ++src_it;
+                    if (src_it < nbatch) nxt = bin_load(N, v, p0 + 64u * (uint32_t)src_it + lane, nvis, box, db_order, db_rec);
+                    const uint32_t cw = cur.wh & 0xFFFFu, ch = cur.wh >> 16;
+                    v_mapped = __ballot(cur.tiles > 64u) != 0ull;
+                    v_off = 0u;
+                    v_total = 64u;
+                    if (v_mapped) {
+                        const uint32_t nl = cur.tiles == 0u ? 0u : (cur.tiles <= 64u ? 1u : ch * ((cw + 63u) / 64u));
+                        const uint32_t ve = mgr_wave_incl_scan_u32(nl);
+                        v_total = (uint32_t)__builtin_amdgcn_readlane((int)ve, 63);
+                        s_vend[lane] = ve;
+                        __builtin_amdgcn_wave_barrier();      // (same wave: LDS operations complete in program order)
+                        if (v_total == 0u) v_total = 1u;         // (an empty batch still passes through once)
+                    }
+                }
+                BinRec r = cur;
+                if (v_mapped) {
+                    const uint32_t j = v_off + (uint32_t)lane;
+                    r = BinRec{0u, 0u, 0u, 0u, 0u, 0u};
+                    const bool on = j < s_vend[63];
+                    int lo = 0, hi = 63;      // the first source lane whose running count exceeds j
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        if (s_vend[mid] > j) hi = mid; else lo = mid + 1;
+                    }
+                    // that lane's record, out of its registers (every lane takes part in the exchange)
+                    BinRec q;
+                    q.xy = (uint32_t)__shfl((int)cur.xy, lo, 64); q.wh = (uint32_t)__shfl((int)cur.wh, lo, 64);
+                    q.alo = (uint32_t)__shfl((int)cur.alo, lo, 64); q.ahi = (uint32_t)__shfl((int)cur.ahi, lo, 64);
+                    q.gid = (uint32_t)__shfl((int)cur.gid, lo, 64); q.tiles = (uint32_t)__shfl((int)cur.tiles, lo, 64);
+                    if (on) {
+                        if (q.tiles <= 64u) {
+                            r = q;
+                        } else {
+                            const uint32_t piece = j - (lo ? s_vend[lo - 1] : 0u), qw = q.wh & 0xFFFFu, per_row = (qw + 63u) / 64u;
+                            const uint32_t row = piece / per_row, px = piece - row * per_row, ww = min(64u, qw - 64u * px);
+                            r.xy = ((uint32_t)(bin_x0(q.xy) + (int)(64u * px)) & 0xFFFFu) | ((uint32_t)(bin_y0(q.xy) + (int)row) << 16);
+                            r.wh = ww | (1u << 16);
+                            const unsigned long long ones = ww >= 64u ? ~0ull : ((1ull << ww) - 1ull);
+                            r.alo = (uint32_t)ones; r.ahi = (uint32_t)(ones >> 32);
+                            r.gid = q.gid;
+                            r.tiles = ww;
+                        }
+                    }
+                }
+                v_off += 64u;
                 const unsigned long long am = ((unsigned long long)r.ahi << 32) | r.alo;
-                const bool big = r.tiles > 64u;
-                const bool use = !(r.tiles == 0u || big);
+                const bool use = r.tiles != 0u;
                 const uint32_t w = r.wh & 0xFFFFu;
                 // the alive tiles in even rows of the box: rows of the rectangle are runs of w bits
                 unsigned long long amE = 0ull;
@@ -1765,7 +1826,7 @@ __global__ __launch_bounds__(BIN_SC_THREADS) void k_bin_scatter(int N, int T, in
                 const uint32_t P = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
                 const uint32_t PE = P & 0xFFFFu, PO = P >> 16;
                 BP(1)
-                if (__ballot(big) == 0ull && PE + PO <= (uint32_t)BIN_PAIR_CAP) {
+                if (PE + PO <= (uint32_t)BIN_PAIR_CAP) {
                     // expand: the lane's pairs in row-major order of the rectangle, even box rows at [oE, oE + cntE) from the front,
                     // odd ones at CAP - 1 - [oO, oO + cntO) from the back
                     uint32_t* pl = s_pairs + d * BIN_PAIR_CAP;
@@ -1785,7 +1846,7 @@ __global__ __launch_bounds__(BIN_SC_THREADS) void k_bin_scatter(int N, int T, in
                     }
                     s_gid[d * 64 + lane] = r.gid;
                     if (lane == 0) s_info[d] = P;
-                } else {
+                } else {      // (more pairs than the stage holds: the lanes one after the other -- every one of at most 64 tiles now)
                     s_rec[d * 64 + lane] = r;
                     if (lane == 0) s_info[d] = 0xFFFFFFFFu;
                 }

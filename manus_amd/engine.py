@@ -154,6 +154,16 @@ class ViewShardedStep:
         out["loss"], out["overflow"] = st[o + 2 * N:o + 2 * N + 1], st[o + 2 * N + 1:o + 2 * N + 2]
         return out
 
+    def exchanged_rows(self):
+        """Rows in the union of a recent compact exchange (the count reaches the host through an asynchronous copy behind the
+        step: this waits for the one in flight, if any).  None before the first compact step."""
+        sc = getattr(self, "_xch", None)
+        if sc is not None and sc.get("ev") is not None:
+            sc["ev"].synchronize()
+            self.last_rows, sc["ev"] = int(sc["host"][0]), None
+            sc["cap_rows"] = min(self.N, int(self.last_rows * 1.25) + 1024)
+        return self.last_rows
+
     def reduce_max_radii(self, radii):
         """MAX over ranks of a per-Gaussian radius statistic (in place; any integer or float dtype)."""
         if self.world > 1 or self.force:

@@ -78,7 +78,7 @@ def _worker(rank, world, port, q, compact, sharded=False):
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         assert torch.equal(lo, hi)
     if rank == 0:
-        q.put((hist, {k: v.detach().cpu().numpy() for k, v in tr.opt.p.items()}, tr.stepper.last_rows))   # by value
+        q.put((hist, {k: v.detach().cpu().numpy() for k, v in tr.opt.p.items()}, tr.stepper.exchanged_rows()))   # by value
     dist.barrier()
     dist.destroy_process_group()
 
