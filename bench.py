@@ -25,7 +25,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
-PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc.json")  # rocprofv3 --pmc passes of this same command (tools/measure_round.sh)
+PMC_FILE = os.path.join(ROOT, "profiles", "r06_pmc.json")  # rocprofv3 --pmc passes of this same command (tools/measure_round.sh)
 REPEATS = 5   # the --steps loop is timed this many times; the median goes into the line, min / max beside it
 
 

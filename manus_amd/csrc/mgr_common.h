@@ -198,12 +198,14 @@ static inline uint32_t mgr_rep_ck(int64_t cap) { return mgr_rep_list(cap) / MGR_
 struct MgrLayout {
     size_t header, scan_part, scan_cls, scan_box, grec, depth, rect, alive, pair_off, tile_count, tile_start, tile_cursor, tile_done, tile_qdone,
         tile_zcut, tile_zused, tile_qend, tile_bgok, tile_queue, tile_qrec, chunk_start, items, ckpt, keys, keys2, groups, sorted_gid, final_T, n_contrib, pair_tag, pair_grad, inst_grad, inst_tag,
-        db_count, db_cursor, db_start, db_nvis, db_bbox, db_keys, db_order, db_rec, bin_mat, tile_rep, rep_unit, rep_state, rep_last, rep_cnt, rep_cand, rep_view, tile_zwin, total;
+        db_count, db_cursor, db_start, db_nvis, db_bbox, db_keys, db_order, db_rec, bin_mat, tile_rep, rep_unit, rep_state, rep_last, rep_cnt, rep_cand, rep_view, tile_zwin, db_zrange, db_item, total;
 };
 
 // Depth-ordered binning (raster_fwd.hip, "ordered" route): the instances of a view are sorted by depth once, then
 // scattered to the tile lists in that order, instead of sorting every tile list.
-#define MGR_DB_BUCKETS 8192   // depth buckets per view of the instance sort (1024 per octave of z above the 0.2 cull plane)
+#define MGR_DB_BUCKETS 1024   // depth buckets per view of the instance sort (uniform over the depth range of the view's visible instances)
+#define MGR_DB_ITEM 768       // keys per item of the instance sort (whole buckets: an item ends with the bucket it is in)
+#define MGR_DB_RANK_MAX 2048  // items of at most this many keys are sorted by k_dbin_rank (16 KB of LDS: four workgroups per CU), larger ones by the launch behind it
 #ifndef MGR_BIN_BLOCK
 #define MGR_BIN_BLOCK 1024
 #endif
@@ -281,6 +283,12 @@ static inline MgrLayout mgr_layout(int V, int N, int W, int H, int64_t cap) {
     // depth cut: per tile the float bits of the depth behind which the repair of a tile that ran out stops collecting (about
     // MGR_REP_TARGET entries behind the cut; written with the hint by a forward that saw the tile's full list, kept otherwise)
     L.tile_zwin = o; o += mgr_align(VT * 4);
+    // instance sort (round 6): per view the depth range of its visible instances (two words, both kept by atomicMax: the
+    // complement of the smallest depth's bits and the largest depth's bits; zero = none yet) -> uniform depth buckets over
+    // THAT range; per sort item (MGR_DB_ITEM keys of the bucketed order, whole buckets) its first bucket (complement, atomicMax)
+    // and the end of its last one -- written by the bucket scan, consumed (left zero) by k_dbin_rank
+    L.db_zrange = o; o += mgr_align((size_t)V * 2 * 4);
+    L.db_item = o;   o += mgr_align((size_t)V * (((size_t)(N > 0 ? N : 1) + MGR_DB_ITEM - 1) / MGR_DB_ITEM + 1) * 2 * 4);
     L.total = o;
     return L;
 }

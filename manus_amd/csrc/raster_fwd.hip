@@ -174,9 +174,22 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t val, uint32_t* s_wa
 #endif
 #define EMIT_THREADS 1024
 
-__device__ __forceinline__ uint32_t db_bucket(float z) {
-    const uint32_t b = __float_as_uint(z) >> 13, b0 = 0x3E4CCCCDu >> 13;   // 0.2f
-    return b > b0 ? min(b - b0, (uint32_t)MGR_DB_BUCKETS - 1u) : 0u;
+// Depth bucket of an instance: uniform over the depth range [zmin, zmax] of the view's visible instances (round 6; up to
+// round 5: 1024 buckets per octave of z above the cull plane -- a hand at 1.2 m then fills ~200 of the 8192 buckets with ~1000
+// keys each, and a sort item could not be smaller than a bucket).  Monotone in z (a float subtraction and a multiplication by a
+// positive constant are), evaluated by the same function wherever a bucket is needed.
+struct DbRange { float zmin, scale; };
+__device__ __forceinline__ DbRange db_range(const uint32_t* __restrict__ zr /* this view's two words */) {
+    const uint32_t lo_c = zr[0], hi = zr[1];
+    DbRange r;
+    r.zmin = __uint_as_float(~lo_c);
+    const float zmax = __uint_as_float(hi), ext = zmax - r.zmin;
+    r.scale = (lo_c != 0u && ext > 0.0f) ? (float)(MGR_DB_BUCKETS - 1) / ext : 0.0f;
+    return r;
+}
+__device__ __forceinline__ uint32_t db_bucket(float z, const DbRange r) {
+    const float f = (z - r.zmin) * r.scale;
+    return f > 0.0f ? min((uint32_t)f, (uint32_t)MGR_DB_BUCKETS - 1u) : 0u;
 }
 // an instance takes part when it has at least one non-null tile
 __device__ __forceinline__ bool db_takes_part(int radius, ushort4 rc, unsigned long long am) {
@@ -193,10 +206,18 @@ __device__ __forceinline__ void pre_tail(int N, int gx, int gy, int v, int i, co
                                          MgrGRec* __restrict__ grec, float* __restrict__ depth,
                                          ushort4* __restrict__ rect, unsigned long long* __restrict__ alive,
                                          uint32_t* __restrict__ pair_off, uint32_t* __restrict__ tile_count,
-                                         int32_t* __restrict__ radii, MgrHeader* hdr, const uint32_t* __restrict__ zcut_v = nullptr) {
+                                         int32_t* __restrict__ radii, MgrHeader* hdr, uint32_t* __restrict__ db_zrange_v,
+                                         const uint32_t* __restrict__ zcut_v = nullptr) {
     const int tid = threadIdx.x, T = gx * gy;
     const int radius = po.radius, x0 = po.x0, y0 = po.y0, x1 = po.x1, y1 = po.y1;
     const uint32_t tiles = (uint32_t)((x1 - x0) * (y1 - y0));
+    {   // depth range of the view's visible instances (the instance sort's buckets are uniform over it): wave maxima of the depth
+        // bits and of their complement -> s_scan[22 / 23] (zeroed by the kernel before its first barrier) -> one pair of global
+        // atomics per workgroup behind the scan's barrier below
+        const uint32_t zb = (radius > 0 && tiles > 0u) ? __float_as_uint(po.zv) : 0u;
+        const uint32_t wmax = mgr_wave_max_u32(zb), wminc = mgr_wave_max_u32(zb ? ~zb : 0u);
+        if ((tid & 63) == 0 && wmax) { atomicMax(&s_scan[22], wmax); atomicMax(&s_scan[23], wminc); }
+    }
     unsigned long long amask = ~0ull;
     if (radius > 0 && !(zcut_v && tiles <= 64)) {
         const bool small = tiles <= 64;
@@ -249,6 +270,7 @@ __device__ __forceinline__ void pre_tail(int N, int gx, int gy, int v, int i, co
     uint32_t block_total;
     const uint32_t local = block_excl_scan(tiles, s_scan, block_total);
     if (tid == 0) s_scan[20] = block_total ? atomicAdd(&hdr->acc_pairs, block_total) : 0u;
+    if (tid == 64 && s_scan[22] != 0u) { atomicMax(&db_zrange_v[1], s_scan[22]); atomicMax(&db_zrange_v[0], s_scan[23]); }
     __syncthreads();
     const uint32_t off = s_scan[20] + local;
     if (i < N) {
@@ -283,7 +305,7 @@ __global__ __launch_bounds__(PRE_THREADS) void k_preprocess(
     const float* __restrict__ opacity, int64_t s_op, MgrGRec* __restrict__ grec,
     float* __restrict__ depth, ushort4* __restrict__ rect, unsigned long long* __restrict__ alive,
     uint32_t* __restrict__ pair_off, uint32_t* __restrict__ tile_count, int32_t* __restrict__ radii,
-    MgrHeader* hdr, int lds_hist) {
+    MgrHeader* hdr, int lds_hist, uint32_t* __restrict__ db_zrange) {
     extern __shared__ uint32_t s_mem[];
     uint32_t* s_scan = s_mem;       // 32 words
     uint32_t* s_hist = s_mem + 32;  // gx*gy words when lds_hist
@@ -293,6 +315,7 @@ __global__ __launch_bounds__(PRE_THREADS) void k_preprocess(
     if (lds_hist) {
         for (int k = tid; k < T; k += PRE_THREADS) s_hist[k] = 0;
     }
+    if (tid < 2) s_scan[22 + tid] = 0u;
     __syncthreads();
 
     MgrCam cam;
@@ -315,7 +338,7 @@ __global__ __launch_bounds__(PRE_THREADS) void k_preprocess(
         col[0] = cp[0]; col[1] = cp[1]; col[2] = cp[2];
     }
     pre_tail(N, gx, gy, v, i, po, op_i, col, s_scan, s_hist, lds_hist, grec, depth, rect, alive, pair_off, tile_count,
-             radii, hdr);
+             radii, hdr, db_zrange + 2 * v);
 }
 
 // ---------------------------------------------------------------------------
@@ -336,7 +359,7 @@ __global__ __launch_bounds__(PRE_THREADS) void k_inst_fwd(
     const float* __restrict__ skin_w, const float* __restrict__ transforms, MgrGRec* __restrict__ grec,
     float* __restrict__ depth, ushort4* __restrict__ rect, unsigned long long* __restrict__ alive,
     uint32_t* __restrict__ pair_off, uint32_t* __restrict__ tile_count, int32_t* __restrict__ radii,
-    MgrHeader* hdr, int lds_hist, int V, const uint32_t* __restrict__ tile_zcut) {
+    MgrHeader* hdr, int lds_hist, int V, const uint32_t* __restrict__ tile_zcut, uint32_t* __restrict__ db_zrange) {
     extern __shared__ uint32_t s_mem[];
     uint32_t* s_scan = s_mem;
     uint32_t* s_hist = s_mem + 32;
@@ -356,6 +379,7 @@ __global__ __launch_bounds__(PRE_THREADS) void k_inst_fwd(
     if (lds_hist) {
         for (int k2 = tid; k2 < T; k2 += PRE_THREADS) s_hist[k2] = 0;
     }
+    if (tid < 2) s_scan[22 + tid] = 0u;
     __syncthreads();
     MgrCam cam;
     mgr_load_cam(cams, v, cam);
@@ -410,7 +434,7 @@ __global__ __launch_bounds__(PRE_THREADS) void k_inst_fwd(
         }
     }
     pre_tail(N, gx, gy, v, i, po, op_i, col, s_scan, s_hist, lds_hist, grec, depth, rect, alive, pair_off, tile_count,
-             radii, hdr, tile_zcut ? tile_zcut + (size_t)v * T : nullptr);
+             radii, hdr, db_zrange + 2 * v, tile_zcut ? tile_zcut + (size_t)v * T : nullptr);
 }
 
 // ---------------------------------------------------------------------------
@@ -438,8 +462,9 @@ __device__ __forceinline__ uint32_t mgr_queue_key(uint32_t count, uint32_t prev_
 __device__ __forceinline__ void dbin_count_block(int bx, int v, int N, const int32_t* __restrict__ radii,
                                                  const float* __restrict__ depth, const ushort4* __restrict__ rect,
                                                  const unsigned long long* __restrict__ alive, uint32_t* __restrict__ db_count,
-                                                 uint32_t* s_hist /*MGR_DB_BUCKETS*/) {
+                                                 uint32_t* s_hist /*MGR_DB_BUCKETS*/, const uint32_t* __restrict__ db_zrange) {
     const int tid = threadIdx.x;
+    const DbRange zr = db_range(db_zrange + 2 * v);
     for (int k = tid; k < MGR_DB_BUCKETS; k += 1024) s_hist[k] = 0;
     __syncthreads();
 #pragma unroll
@@ -447,7 +472,7 @@ __device__ __forceinline__ void dbin_count_block(int bx, int v, int N, const int
         const int i = (bx * DB_PER + r) * 1024 + tid;
         if (i < N) {
             const size_t vi = (size_t)v * N + i;
-            if (db_takes_part(radii[vi], rect[vi], alive[vi])) atomicAdd(&s_hist[db_bucket(depth[vi])], 1u);
+            if (db_takes_part(radii[vi], rect[vi], alive[vi])) atomicAdd(&s_hist[db_bucket(depth[vi], zr)], 1u);
         }
     }
     __syncthreads();
@@ -464,9 +489,11 @@ __device__ __forceinline__ void dbin_scan_block(int v, int nbT, const uint4* __r
                                                 uint32_t* __restrict__ db_count, uint32_t* __restrict__ db_cursor,
                                                 uint32_t* __restrict__ db_start, uint32_t* __restrict__ db_nvis,
                                                 ushort4* __restrict__ db_bbox, uint32_t* s_scan /*32*/, uint32_t* s_box /*4*/,
-                                                MgrHeader* hdr) {
+                                                MgrHeader* hdr, uint32_t* __restrict__ db_item, int items_per_view, uint32_t* s_items /* LDS, 2 x items_per_view words, or nullptr */) {
     const int tid = threadIdx.x;
     if (tid == 0) { s_box[0] = 0xFFFFu; s_box[1] = 0xFFFFu; s_box[2] = 0u; s_box[3] = 0u; }
+    if (s_items)
+        for (int k = tid; k < 2 * items_per_view; k += 1024) s_items[k] = 0u;      // (published by the scan's barrier below)
     constexpr int PER = MGR_DB_BUCKETS / 1024;
     uint32_t c[PER], sum = 0;
     uint32_t* cnt = db_count + (size_t)v * MGR_DB_BUCKETS + tid * PER;
@@ -474,10 +501,18 @@ __device__ __forceinline__ void dbin_scan_block(int v, int nbT, const uint4* __r
     for (int k = 0; k < PER; ++k) { c[k] = cnt[k]; sum += c[k]; cnt[k] = 0; }
     uint32_t total;
     uint32_t run = block_excl_scan(sum, s_scan, total);   // (contains the barrier that publishes s_box)
+    // sort items: item i of the view = the buckets whose first key lies in [i, i + 1) * MGR_DB_ITEM of the bucketed order; every
+    // non-empty bucket reports itself to its item -- in LDS (s_items: first bucket as a complement, end of the last: both kept by
+    // atomicMax on zeros); the table is then written out whole, empty items as zeros (global atomics from here measured 40 us)
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
         db_start[(size_t)v * (MGR_DB_BUCKETS + 1) + tid * PER + k] = run;
         db_cursor[(size_t)v * MGR_DB_BUCKETS + tid * PER + k] = 0;
+        if (c[k] && s_items) {
+            const uint32_t it = min(run / (uint32_t)MGR_DB_ITEM, (uint32_t)items_per_view - 1u), b = (uint32_t)(tid * PER + k);
+            atomicMax(&s_items[2 * it], ~b);
+            atomicMax(&s_items[2 * it + 1], b + 1u);
+        }
         run += c[k];
     }
     uint32_t x0 = 0xFFFFu, y0 = 0xFFFFu, x1 = 0u, y1 = 0u;
@@ -487,6 +522,8 @@ __device__ __forceinline__ void dbin_scan_block(int v, int nbT, const uint4* __r
     }
     if (x1 > 0u) { atomicMin(&s_box[0], x0); atomicMin(&s_box[1], y0); atomicMax(&s_box[2], x1); atomicMax(&s_box[3], y1); }
     __syncthreads();
+    if (s_items)
+        for (int k = tid; k < 2 * items_per_view; k += 1024) db_item[(size_t)v * items_per_view * 2 + k] = s_items[k];
     if (tid == 0) {
         db_start[(size_t)v * (MGR_DB_BUCKETS + 1) + MGR_DB_BUCKETS] = total;
         db_nvis[v] = total;
@@ -505,8 +542,10 @@ __device__ __forceinline__ void dbin_scatter_block(int bx, int v, int N, const i
                                                    const float* __restrict__ depth, const ushort4* __restrict__ rect,
                                                    const unsigned long long* __restrict__ alive,
                                                    const uint32_t* __restrict__ db_start, uint32_t* __restrict__ db_cursor,
-                                                   unsigned long long* __restrict__ db_keys, uint32_t* s_hist /*MGR_DB_BUCKETS*/) {
+                                                   unsigned long long* __restrict__ db_keys, uint32_t* s_hist /*MGR_DB_BUCKETS*/,
+                                                   const uint32_t* __restrict__ db_zrange) {
     const int tid = threadIdx.x;
+    const DbRange zr = db_range(db_zrange + 2 * v);
     for (int k = tid; k < MGR_DB_BUCKETS; k += 1024) s_hist[k] = 0;
     __syncthreads();
     float z[DB_PER];
@@ -520,7 +559,7 @@ __device__ __forceinline__ void dbin_scatter_block(int bx, int v, int N, const i
             z[r] = depth[vi];
             if (db_takes_part(radii[vi], rect[vi], alive[vi])) {
                 on |= 1u << r;
-                atomicAdd(&s_hist[db_bucket(z[r])], 1u);
+                atomicAdd(&s_hist[db_bucket(z[r], zr)], 1u);
             }
         }
     }
@@ -534,7 +573,7 @@ __device__ __forceinline__ void dbin_scatter_block(int bx, int v, int N, const i
     for (int r = 0; r < DB_PER; ++r) {
         if ((on >> r) & 1u) {
             const int i = (bx * DB_PER + r) * 1024 + tid;
-            const uint32_t pos = atomicAdd(&s_hist[db_bucket(z[r])], 1u);
+            const uint32_t pos = atomicAdd(&s_hist[db_bucket(z[r], zr)], 1u);
             db_keys[(size_t)v * N + pos] = ((unsigned long long)__float_as_uint(z[r]) << 32) | (unsigned)i;
         }
     }
@@ -544,9 +583,9 @@ __global__ __launch_bounds__(1024) void k_dbin_scatter(int N, const int32_t* __r
                                                        const float* __restrict__ depth, const ushort4* __restrict__ rect,
                                                        const unsigned long long* __restrict__ alive,
                                                        const uint32_t* __restrict__ db_start, uint32_t* __restrict__ db_cursor,
-                                                       unsigned long long* __restrict__ db_keys) {
+                                                       unsigned long long* __restrict__ db_keys, const uint32_t* __restrict__ db_zrange) {
     __shared__ uint32_t s_hist[MGR_DB_BUCKETS];
-    dbin_scatter_block((int)blockIdx.x, (int)blockIdx.y, N, radii, depth, rect, alive, db_start, db_cursor, db_keys, s_hist);
+    dbin_scatter_block((int)blockIdx.x, (int)blockIdx.y, N, radii, depth, rect, alive, db_start, db_cursor, db_keys, s_hist, db_zrange);
 }
 
 struct DbinArgs {   // depth-bucket side of the two tile-scan launches (ordered binning); db_count == nullptr: none
@@ -558,9 +597,12 @@ struct DbinArgs {   // depth-bucket side of the two tile-scan launches (ordered 
     uint32_t *db_count, *db_cursor, *db_start, *db_nvis;
     ushort4* db_bbox;
     unsigned long long* db_keys;
+    uint32_t *db_zrange, *db_item;
+    int items_per_view;
 };
 
 #define MGR_HOLE 0xFFFFFFFEu   // a position of the view-interleaved queue its view has no tile for
+#define DBR_MAX_ITEMS 4096    // sort items per view the bucket scan can table in LDS (1 M instances per view; beyond: the radix launch sorts everything)
 #define MGR_NCLS 34
 
 // Phase A: one block = up to 1024 tiles of ONE view (grid = V x ceil(T / 1024), view-major like the tile index, so the
@@ -575,7 +617,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan_a(int T, int nbT, const uint
     __shared__ uint32_t s_dbh[MGR_DB_BUCKETS];
     if ((int)blockIdx.x >= n_scan_blocks) {   // the workgroups behind the scan's: depth buckets of 8192 instances of one view
         const int b2 = (int)blockIdx.x - n_scan_blocks;
-        dbin_count_block(b2 % db.n_bx, b2 / db.n_bx, db.N, db.radii, db.depth, db.rect, db.alive, db.db_count, s_dbh);
+        dbin_count_block(b2 % db.n_bx, b2 / db.n_bx, db.N, db.radii, db.depth, db.rect, db.alive, db.db_count, s_dbh, db.db_zrange);
         return;
     }
     __shared__ uint32_t s_scan[32];
@@ -590,7 +632,13 @@ __global__ __launch_bounds__(1024) void k_tile_scan_a(int T, int nbT, const uint
     __syncthreads();
     const uint32_t c = valid ? tile_count[k] : 0u;
     const uint32_t key = mgr_queue_key(c, valid ? tile_done[k] : 0u, use_hint);
-    if (valid) atomicAdd(&s_cls[key ? 32 - __clz(key) : 0], 1u);
+    {   // (class 0 = empty tiles, 85 % of a capture-like frame: counted per wave by a ballot -- a thousand LDS atomics on one
+        // address are served one after the other)
+        const int cls = key ? 32 - __clz(key) : 0;
+        const unsigned long long m0 = __ballot(valid && cls == 0);
+        if (valid && cls != 0) atomicAdd(&s_cls[cls], 1u);
+        if ((tid & 63) == 0 && m0) atomicAdd(&s_cls[0], (uint32_t)__popcll(m0));
+    }
     if (c) {   // bounding box of the block's non-empty tiles (one wave-level step, then four LDS atomics per wave)
         const uint32_t y = (uint32_t)t / (uint32_t)gx, x = (uint32_t)t - y * (uint32_t)gx;
         atomicMin(&s_bb[0], x); atomicMin(&s_bb[1], y); atomicMax(&s_bb[2], x + 1u); atomicMax(&s_bb[3], y + 1u);
@@ -628,8 +676,9 @@ __global__ __launch_bounds__(1024) void k_tile_scan_b(int V, int T, int nbT, uin
     __shared__ uint32_t s_scan[32];
     if ((int)blockIdx.x >= V * nbT) {   // the workgroups behind the scan's: one per view, depth-bucket offsets + tile box
         __shared__ uint32_t s_box[4];
+        __shared__ uint32_t s_items[2 * DBR_MAX_ITEMS];
         dbin_scan_block((int)blockIdx.x - V * nbT, nbT, blk_box, db.db_count, db.db_cursor, db.db_start, db.db_nvis, db.db_bbox,
-                        s_scan, s_box, hdr);
+                        s_scan, s_box, hdr, db.db_item, db.items_per_view, db.items_per_view <= DBR_MAX_ITEMS ? s_items : (uint32_t*)nullptr);
         return;
     }
     __shared__ uint32_t s_gtot[MGR_NCLS], s_gpre[MGR_NCLS], s_vtot[MGR_NCLS], s_vpre[MGR_NCLS];   // tiles per class: all / in front of this block, of all views / of this view
@@ -705,7 +754,20 @@ __global__ __launch_bounds__(1024) void k_tile_scan_b(int V, int T, int nbT, uin
         if (zu != 0u && c == 0u) { atomicOr(&hdr->acc_flags, MGR_OVF_CUT); atomicOr(&hdr->rep_why, MGR_WHY_EMPTY); }
         tile_qend[k] = 0u;
         if (c != 0u) tile_bgok[k] = 0;      // the blend will write this tile's pixels ("image kept": see BgFill)
-        const uint32_t rank = atomicAdd(&s_lc[cls], 1u);
+    }
+    uint32_t rank = 0;
+    {   // rank inside the block's tiles of the class: the empty tiles (class 0, most of them) by one atomic per wave + ballot
+        const unsigned long long m0 = __ballot(valid && cls == 0);
+        if (valid && cls != 0) rank = atomicAdd(&s_lc[cls], 1u);
+        if (m0) {
+            const int leader = __builtin_ctzll(m0), ln = tid & 63;
+            uint32_t base = 0;
+            if (ln == leader) base = atomicAdd(&s_lc[0], (uint32_t)__popcll(m0));
+            base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+            if (valid && cls == 0) rank = base + (uint32_t)__popcll(m0 & ((1ull << ln) - 1ull));
+        }
+    }
+    if (valid) {
         tile_queue[s_gbase[cls] + s_gpre[cls] + rank] = (uint32_t)k;
         if (cls > 0) {
             const uint32_t st = min(s_base[0] + run, cap), en = min(s_base[0] + run + c, cap);
@@ -1361,6 +1423,9 @@ __global__ __launch_bounds__(RS_THREADS) __attribute__((amdgpu_waves_per_eu(DBS_
         bg_fill_block(fill, hdr, (int)blockIdx.x - n_sort_blocks, (int)gridDim.x - n_sort_blocks);
         return;
     }
+    // full_runs == 2 (round 6): the launch behind k_dbin_rank -- it takes the items of more than min_keys keys, all of them, and
+    // returns at once when the ranking kernel met none (MgrHeader::sort_big: the usual case)
+    if (full_runs == 2 && hdr->sort_big == 0u) return;
     constexpr uint32_t lds_keys = (uint32_t)LDS_KEYS;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     unsigned long long* s_keys = (unsigned long long*)s_raw;
@@ -1384,7 +1449,7 @@ __global__ __launch_bounds__(RS_THREADS) __attribute__((amdgpu_waves_per_eu(DBS_
         const uint32_t lo = st[b0], hi = st[b1];
         if (hi == lo) continue;
         if (hi - lo <= min_keys) continue;                          // the light launch's
-        if (hi - lo > (uint32_t)DBS_LIGHT_KEYS) {
+        if (full_runs != 2 && hi - lo > (uint32_t)DBS_LIGHT_KEYS) {
             // an item beyond the light launch's LDS: the light launch still takes it, bucket by bucket, unless one of its
             // buckets alone is beyond it (that one would go through the bitonic network in global memory: ~90 us) -- such
             // items are the full launch's, and they are what the header counts for the caller's next choice
@@ -1434,6 +1499,38 @@ __global__ __launch_bounds__(RS_THREADS) __attribute__((amdgpu_waves_per_eu(DBS_
         }
 #endif
     }
+}
+
+// Instance sort, round 6.  Up to round 5 an item was ~2048 keys of whole depth buckets in an LDS radix sort: 66 us per step at
+// eight views for a million keys -- one item's latency (four passes of counters, scans and barriers), the chip idle around it --
+// and 45 us of a 0.53 ms step at one view.  With uniform depth buckets (db_bucket) a bucket holds ~130 keys of a narrow depth
+// slice, so items can be small -- MGR_DB_ITEM keys (+ the rest of the last bucket): two keys per thread -- and their keys share
+// their high bits: the radix sort skips those passes (lds_radix_sort).  One workgroup per item; its first / last bucket come from
+// the table the bucket scan left (dbin_scan_block).  Items beyond MGR_DB_RANK_MAX keys (a dense depth slice: every Gaussian in
+// one plane) are counted in MgrHeader::sort_big and left to the launch behind.
+// (Measured on the way, eight views: items of 512 keys ordered by counting -- a key's position = the number of smaller keys of
+// its item -- 0.15 ms, the 64-bit compares run at a quarter of the rate; items of 256 keys through a bitonic network in LDS
+// 0.063 ms, throughput-bound at n log^2 n; one view: 0.029 against the radix items' 0.045.)
+#define DBR_THREADS RS_THREADS
+__global__ __launch_bounds__(DBR_THREADS) void k_dbin_rank(int N, int V, int items_per_view, const uint32_t* __restrict__ db_start,
+                                                           const uint32_t* __restrict__ db_item, const unsigned long long* __restrict__ db_keys,
+                                                           uint32_t* __restrict__ db_order, MgrHeader* hdr, uint32_t* __restrict__ db_zrange) {
+    __shared__ __attribute__((aligned(16))) unsigned long long s_keys[MGR_DB_RANK_MAX];
+    __shared__ uint32_t s_cnt[RS_WAVES * 256];
+    __shared__ uint32_t s_scan[32];
+    const int tid = threadIdx.x;
+    const int v = (int)blockIdx.x % V, it = (int)blockIdx.x / V;      // view-minor: neighbours differ in view
+    if (blockIdx.x == 0 && tid < 2 * V) db_zrange[tid] = 0u;          // (the bucket kernels of this forward are done with the ranges)
+    const uint32_t* const ent = db_item + ((size_t)v * items_per_view + it) * 2;
+    const uint32_t e0 = ent[0], e1 = ent[1];                          // (uniform: scalar loads)
+    if (e0 == 0u) return;                                             // no bucket starts in this item
+    const uint32_t* st = db_start + (size_t)v * (MGR_DB_BUCKETS + 1);
+    const uint32_t lo = st[~e0], hi = st[e1], n = hi - lo;
+    if (n > (uint32_t)MGR_DB_RANK_MAX) {
+        if (tid == 0) atomicAdd(&hdr->sort_big, 1u);
+        return;
+    }
+    lds_sort_emit(db_keys + (size_t)v * N + lo, n, s_keys, s_cnt, s_scan, tid, db_order + (size_t)v * N + lo);
 }
 
 // The (block, tile) matrix only spans the bounding box of a view's non-empty tiles; a view whose box has at most
@@ -3031,7 +3128,7 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
                        canon->f_rest, canon->skin_w, canon->transforms, (MgrGRec*)(ws + L.grec),                        \
                        (float*)(ws + L.depth), (ushort4*)(ws + L.rect), (unsigned long long*)(ws + L.alive),            \
                        (uint32_t*)(ws + L.pair_off), tile_count, radii, hdr, lds_hist, V,                                  \
-                       use_cut ? (const uint32_t*)(ws + L.tile_zcut) : (const uint32_t*)nullptr)
+                       use_cut ? (const uint32_t*)(ws + L.tile_zcut) : (const uint32_t*)nullptr, (uint32_t*)(ws + L.db_zrange))
             if (mixed && canon->sh_half) MGR_IF_LAUNCH(true, true);
             else if (mixed) MGR_IF_LAUNCH(true, false);
             else if (canon->sh_half) MGR_IF_LAUNCH(false, true);
@@ -3042,7 +3139,7 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
                            gy, cams, means3D, s_means, cov3D, s_cov, colors, s_col, opacity, s_op,
                            (MgrGRec*)(ws + L.grec), (float*)(ws + L.depth), (ushort4*)(ws + L.rect),
                            (unsigned long long*)(ws + L.alive), (uint32_t*)(ws + L.pair_off), tile_count, radii,
-                           hdr, lds_hist); }
+                           hdr, lds_hist, (uint32_t*)(ws + L.db_zrange)); }
         MGR_LAUNCH_CHECK("k_preprocess", stream, debug);
     }
     {
@@ -3058,7 +3155,8 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
         const DbinArgs dba = {N, n_bx, (const int32_t*)radii, (const float*)(ws + L.depth), (const ushort4*)(ws + L.rect),
                               (const unsigned long long*)(ws + L.alive), dbin ? (uint32_t*)(ws + L.db_count) : nullptr,
                               (uint32_t*)(ws + L.db_cursor), (uint32_t*)(ws + L.db_start), (uint32_t*)(ws + L.db_nvis),
-                              (ushort4*)(ws + L.db_bbox), (unsigned long long*)(ws + L.db_keys)};
+                              (ushort4*)(ws + L.db_bbox), (unsigned long long*)(ws + L.db_keys), (uint32_t*)(ws + L.db_zrange),
+                              (uint32_t*)(ws + L.db_item), (N + MGR_DB_ITEM - 1) / MGR_DB_ITEM + 1};
         { MGR_PROF("k_tile_scan_a", stream); hipLaunchKernelGGL(k_tile_scan_a, dim3(nblk + (dbin ? n_bx * V : 0)), dim3(1024), 0, stream, T, nbT, tile_count,
                            (const uint32_t*)(ws + L.tile_done), use_hint, part, blk_cls, blk_box, gx, nblk, dba, hdr); }
         { MGR_PROF("k_tile_scan_b", stream); hipLaunchKernelGGL(k_tile_scan_b, dim3(nblk + (dbin ? V : 0)), dim3(1024), 0, stream, V, T, nbT, tile_count, part, (const uint32_t*)blk_cls,
@@ -3082,23 +3180,24 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
         const int chunk = bb == MGR_BIN_BLOCK ? DB_CHUNK : 1024, chunks = (N + chunk - 1) / chunk;
         const size_t rec_bytes = BIN_SC_FIXED_BYTES;
         { MGR_PROF("k_dbin_scatter", stream); hipLaunchKernelGGL(k_dbin_scatter, grid_n, dim3(1024), 0, stream, N, (const int32_t*)radii, (const float*)(ws + L.depth), rect, alive,
-                           (const uint32_t*)db_start, (uint32_t*)(ws + L.db_cursor), db_keys); }
+                           (const uint32_t*)db_start, (uint32_t*)(ws + L.db_cursor), db_keys, (const uint32_t*)(ws + L.db_zrange)); }
         { MGR_PROF("k_dbin_sort", stream);
-          const bool run_light = !(skip_tiers & 8) || (skip_tiers & 4), run_full = !(skip_tiers & 4);   // (never neither)
-          // the background of the empty tiles rides on the first of the two launches (when the blend follows in this call)
+          // items of at most MGR_DB_RANK_MAX keys by counting, one workgroup each (k_dbin_rank); behind it the radix launch for
+          // larger ones (returns at once when there are none) -- it also carries the background of the empty tiles (BgFill)
+          const int ipv = (N + MGR_DB_ITEM - 1) / MGR_DB_ITEM + 1;
+          const bool ranked = ipv <= DBR_MAX_ITEMS;      // (more instances per view than the scan can table: everything through the radix launch)
+          if (ranked)
+              hipLaunchKernelGGL(k_dbin_rank, dim3((unsigned)(ipv * V)), dim3(DBR_THREADS), 0, stream, N, V, ipv, (const uint32_t*)db_start, (const uint32_t*)(ws + L.db_item),
+                                 (const unsigned long long*)db_keys, db_order, hdr, (uint32_t*)(ws + L.db_zrange));
           BgFill fill = {do_blend && bg_fill_on ? out_color : nullptr, (const uint32_t*)(ws + L.tile_queue), bg, VT, T, gx, W, H,
                          (const unsigned char*)(ws + L.tile_bgok), img_kept};
-          const BgFill none = {nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, nullptr, 0};
           const int n_fill = fill.out ? 1024 : 0;
           bg_filled = fill.out != nullptr;
-          if (run_light)
-              hipLaunchKernelGGL((k_dbin_sort<DBS_LIGHT_KEYS>), dim3(1024 + n_fill), dim3(RS_THREADS), DBS_LIGHT_KEYS * 8 + RS_WAVES * 256 * 4 + 256, stream,
-                                 N, chunk, chunks, V * chunks, (const uint32_t*)db_start, (const uint32_t*)db_nvis, db_keys, db_order,
-                                 0u, hdr, run_full ? 1 : 0, fill, 1024);
-          if (run_full)
-              hipLaunchKernelGGL((k_dbin_sort<SORT_LDS_KEYS>), dim3(1024 + (run_light ? 0 : n_fill)), dim3(RS_THREADS), SORT_LDS_KEYS * 8 + RS_WAVES * 256 * 4 + 256, stream,
-                                 N, chunk, chunks, V * chunks, (const uint32_t*)db_start, (const uint32_t*)db_nvis, db_keys, db_order,
-                                 run_light ? (uint32_t)DBS_LIGHT_KEYS : 0u, hdr, 0, run_light ? none : fill, 1024); }
+          const int fchunk = ranked ? (int)MGR_DB_ITEM : chunk, fchunks = (N + fchunk - 1) / fchunk;
+          (void)chunks;
+          hipLaunchKernelGGL((k_dbin_sort<SORT_LDS_KEYS>), dim3(1024 + n_fill), dim3(RS_THREADS), SORT_LDS_KEYS * 8 + RS_WAVES * 256 * 4 + 256, stream,
+                             N, fchunk, fchunks, V * fchunks, (const uint32_t*)db_start, (const uint32_t*)db_nvis, db_keys, db_order,
+                             ranked ? (uint32_t)MGR_DB_RANK_MAX : 0u, hdr, ranked ? 2 : 0, fill, 1024); }
         MGR_LAUNCH_CHECK("k_dbin_sort", stream, debug);
         const bool big_possible = T > BIN_SMALL_TILES;   // a box of more than BIN_SMALL_TILES tiles can only exist then
         { MGR_PROF("k_bin_count", stream);

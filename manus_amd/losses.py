@@ -12,6 +12,8 @@ differentiable w.r.t. the first argument.  `ssim` reproduces the reference's beh
 input exactly: `channel = img1.size(-3)` is the image height, so the window runs over the (W,3)
 plane of each row.  GPU tensors only; there is no CPU fallback.
 """
+import weakref
+
 import torch
 
 from . import ops
@@ -28,14 +30,35 @@ def _chw(img):
     return img.permute(2, 0, 1).contiguous()
 
 
+# CHW copy of a ground-truth image: the reference hands the same HWC tensor to both loss terms of a step (loss_func calls
+# l1_loss and ssim on one `gt`, base.py:329-347).  Keyed by the tensor OBJECT (weakly: the entry dies with it -- a storage address
+# is reused by the allocator for the next step's image) and its version counter.
+_GT_CHW = {}      # id(tensor) -> (weak reference to it, version, CHW copy)
+
+
+def _gt_chw(gt_hwc):
+    key = id(gt_hwc)
+    ent = _GT_CHW.get(key)
+    if ent is None or ent[0]() is not gt_hwc or ent[1] != gt_hwc._version:
+        ref = weakref.ref(gt_hwc, lambda _r, k=key: _GT_CHW.pop(k, None))
+        ent = _GT_CHW[key] = (ref, gt_hwc._version, _chw(gt_hwc))
+    return ent[2]
+
+
 class _ImageLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pred_hwc, gt_hwc, w_l1, w_ssim):
-        pred, gt = _chw(pred_hwc), _chw(gt_hwc)
+        pred, gt = _chw(pred_hwc), _gt_chw(gt_hwc)
         n = pred.numel()
+        ctx.batched = pred_hwc.dim() == 4
+        if w_ssim == 0.0:
+            # the L1 term alone needs no windows: one streaming pass (mgr_l1_loss_grad) instead of the fused kernel's three
+            # launches -- the route is bound by the host's launches (profiles/r05_other_configs/dropin_c_step_timeline.txt)
+            s, g = ops.l1_loss_grad(pred, gt, w_l1 / n)
+            ctx.save_for_backward(g[None])
+            return (s[0] * (w_l1 / n)).clone()
         sums, g = ops.image_loss_grad(pred, gt, w_l1, w_ssim, 1.0 / n)
         ctx.save_for_backward(g)
-        ctx.batched = pred_hwc.dim() == 4
         # value of w_l1 * mean|d| + w_ssim * (-mean ssim_map); callers add the constant w_ssim
         return sums[2].clone()
 

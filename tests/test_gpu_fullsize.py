@@ -114,6 +114,19 @@ def test_config3_hand_300k_fused_vs_oracle_identical_blend_inputs():
     assert raw["dev_rows_unexplained"] == [], raw["dev_rows_unexplained"]
 
 
+def test_closeup_hand_300k_fused_vs_oracle_identical_blend_inputs():
+    """SURVEY 8(d)'s "close-up" camera set at full size (cameras on a 0.45 m sphere: the hand fills the 1080p frame, 11 M
+    rectangle pairs per view, a third of the Gaussians with rectangles of more than 64 tiles -- the lane-spreading route of
+    k_bin_scatter --, tile lists thousands of entries deep): the same bars as config 3."""
+    res = run_fused_vs_oracle("hand", 1, 300000, W, H, seed=0, grid_res=128, cam_radius=0.45, sigma_range=(5e-4, 4e-3), n_cameras=8,
+                              own_projection=True)
+    print("close-up full size:", {k: (v if not isinstance(v, dict) else {q: "%.1e" % e for q, e in v.items()}) for k, v in res.items() if k != "own"})
+    assert_north_star(res, "closeup")
+    assert_own_projection(res, 300000, "closeup")
+    assert min(res["num_rendered"]) > 8000000
+    assert max(res["rows_over_2e5"].values()) == 0.0, res["rows_over_2e5"]
+
+
 def test_config4_composite_500k_fused_vs_oracle_identical_blend_inputs():
     res = run_fused_vs_oracle("composite", 1, 500000, W, H, seed=0, grid_res=128, cam_radius=1.2, sigma_range=(5e-4, 4e-3), n_cameras=7,
                               own_projection=True)

@@ -2,7 +2,7 @@
 # The zero-change drop-in route under the profiler: bench line + per-kernel breakdown + rocprofv3 kernel stats + one step's timeline
 # (kernel trace between two k_skin_fwd24x8 launches: library kernels, torch glue kernels and the gaps the host leaves).
 # Usage: tools/measure_dropin.sh TAG [ROUND]
-TAG=${1:-a}; RND=${2:-r05}
+TAG=${1:-a}; RND=${2:-r06}
 ROOT=$(pwd); export TMPDIR=/tmp
 OUT=profiles/${RND}_other_configs; mkdir -p $OUT gpurun_out
 python bench.py --route dropin --steps 40 --warmup 5 --profile-all > $OUT/dropin_$TAG.json 2> gpurun_out/dropin_$TAG.err

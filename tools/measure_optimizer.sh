@@ -3,7 +3,7 @@
 # timeline of `bench.py --optimizer`, the per-kernel HIP-event breakdown, and the same box's plain lines beside it.
 # Usage: tools/measure_optimizer.sh TAG [ROUND] [extra bench flags]   (outputs under gpurun_out/ and profiles/)
 TAG=${1:-x}
-RND=${2:-r05}
+RND=${2:-r06}
 shift; shift
 EXTRA="$@"
 ROOT=$(pwd)

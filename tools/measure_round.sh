@@ -3,7 +3,7 @@
 # (separate passes, never combined with API traces), the bench itself (with the CPU oracle leg).
 # Usage: tools/measure_round.sh TAG [ROUND]      (outputs under gpurun_out/, summaries copied to profiles/)
 TAG=${1:-x}
-RND=${2:-r05}
+RND=${2:-r06}
 ROOT=$(pwd)
 export TMPDIR=/tmp
 mkdir -p profiles gpurun_out
@@ -14,7 +14,7 @@ python tools/pmc_summary.py gpurun_out/pmc_${TAG}_0 gpurun_out/pmc_${TAG}_1 gpur
 cp gpurun_out/pmc_${TAG}.json profiles/${RND}_pmc.json       # (on the box: so that the bench run below reads THIS pass; tools/pull_profiles.sh copies the summaries home)
 cp gpurun_out/pmc_${TAG}.txt profiles/${RND}_${TAG}_pmc.txt
 rm -rf gpurun_out/prof_$TAG
-(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof_$TAG -o run -- python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-hints-variant > $ROOT/gpurun_out/prof_$TAG.log 2>&1)
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof_$TAG -o run -- python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-hints-variant --trained-steps 0 > $ROOT/gpurun_out/prof_$TAG.log 2>&1)
 cp $(find gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1) profiles/${RND}_${TAG}_rocprofv3_kernel_stats.csv
 python tools/instr/step_timeline.py $(find gpurun_out/prof_$TAG -name "*kernel_trace.csv" | head -1) > profiles/${RND}_${TAG}_step_timeline.txt
 rm -f $(find gpurun_out/prof_$TAG -name "*kernel_trace.csv")

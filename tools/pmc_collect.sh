@@ -11,7 +11,7 @@ for grp in "$@"; do
   out=$ROOT/gpurun_out/pmc_${TAG}_$k
   rm -rf $out; mkdir -p $out
   (cd /tmp && timeout 600 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $out -o runc -- \
-      python $ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-hints-variant ${PMC_BENCH_FLAGS:-} > $out.log 2>&1)
+      python $ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-hints-variant --trained-steps 0 ${PMC_BENCH_FLAGS:-} > $out.log 2>&1)
   echo "group $k [$grp] rc=$?"
   k=$((k+1))
 done
