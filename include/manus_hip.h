@@ -145,10 +145,13 @@ size_t mgr_raster_workspace_bytes(int V, int N, int W, int H, int64_t pair_capac
  * 1537..2048 tiles (they hold more LDS per workgroup; three launches of ~6 us each that do nothing for smaller boxes).
  * mgr_raster_status_tiers_sync reports which of them a forward needed (bit 0 / bit 1); pass the bits for the tiers the
  * previous forward did not need.  A view that needs a skipped launch raises the overflow word's bit 2 (MGR_ETIER).
- * 128 = skip the instance sort's full-size launch: its light launch (LDS for 4096 keys, more workgroups per CU) sorts every
- * item, the ones of more than 4096 keys bucket by bucket -- the better choice unless an item holds a single bucket of more
- * than 4096 keys (bits 8.. of `tiers` count those; not a correctness matter, nothing to verify).  256 = skip the light
- * launch instead: the full one sorts every item.  Neither bit: both launches, each item sorted by exactly one of them. */
+ * 128 = skip the launch behind the instance sort.  Since round 6 the (depth, index) keys of a view are sorted in items of
+ * ~768 keys, one workgroup each (k_dbin_rank: depth buckets uniform over the depth range the view's visible instances had in
+ * the previous forward on this workspace); an item of more than 2048 keys -- a dense depth slice, or a first forward that has
+ * no range yet -- is left to a radix launch behind, which returns at once when there is none.  Bit 128 omits that launch
+ * (mgr_raster_status_tiers_sync reported no such item for the previous forward); an item that needs it then raises the
+ * overflow word's bit 2 (MGR_ETIER: run the forward again without the bit), like a skipped tile-box tier.  256 is accepted
+ * and ignored (up to round 5: the full-size sort launch alone). */
 int mgr_raster_forward(int V, int N, int W, int H, const float* cams, const float* bg,
                        const float* means3D, int64_t stride_means3D, const float* cov3D,
                        int64_t stride_cov3D, const float* colors, int64_t stride_colors,
@@ -273,7 +276,8 @@ int mgr_raster_set_cut_penalty(int forwards);
  * num_rendered through a blocking read-back, SURVEY App. A.) */
 int mgr_raster_set_status_mirror(const void* workspace, void* host_words);
 /* mgr_raster_status_sync plus `tiers` (see debug bits 16 / 32 / 128 of the forward): bit 0 = a view's tile box had more than
- * 2048 tiles, bit 1 = one had 1537..2048, bits 8.. = items of the instance sort that hold a single depth bucket of more than 4096 keys. */
+ * 2048 tiles, bit 1 = one had 1537..2048, bits 8.. = items of the instance sort beyond k_dbin_rank's 2048 keys
+ * (capped at 65535): zero lets the next forward pass debug bit 128. */
 int mgr_raster_status_tiers_sync(const void* workspace, int64_t* num_pairs, int32_t* overflow, int32_t* tiers,
                                  void* stream);
 int mgr_raster_status_sync(const void* workspace, int64_t* num_pairs, int32_t* overflow,

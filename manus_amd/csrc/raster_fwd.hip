@@ -174,16 +174,22 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t val, uint32_t* s_wa
 #endif
 #define EMIT_THREADS 1024
 
-// Depth bucket of an instance: uniform over the depth range [zmin, zmax] of the view's visible instances (round 6; up to
-// round 5: 1024 buckets per octave of z above the cull plane -- a hand at 1.2 m then fills ~200 of the 8192 buckets with ~1000
-// keys each, and a sort item could not be smaller than a bucket).  Monotone in z (a float subtraction and a multiplication by a
-// positive constant are), evaluated by the same function wherever a bucket is needed.
+// Depth bucket of an instance: uniform over the depth range [zmin, zmax] the view's visible instances had IN THE PREVIOUS FORWARD
+// on this workspace, widened by 1 % (round 6; up to round 5: 1024 buckets per octave of z above the cull plane -- a hand at 1.2 m
+// then fills ~200 of the 8192 buckets with ~1000 keys each, and a sort item could not be smaller than a bucket).  Any monotone
+// map of z serves (a float subtraction and a multiplication by a positive constant are monotone; depths outside the range fall
+// into the end buckets); a range that fits gives small items.  Four words per view: [0 / 1] the range the bucket kernels of a
+// forward read (complement of the smallest depth's bits, largest depth's bits; zero = none: one bucket, the radix launch sorts
+// it), [2 / 3] the range THIS forward accumulates (dbin_count_block: one pair of atomicMax per 8192 instances) -- published to
+// [0 / 1] by k_dbin_rank, behind the bucket kernels.  (Accumulating it in the per-instance kernel for the SAME forward was
+// measured: +9 .. +21 us on k_inst_fwd for the atomics in front of its barrier.)
 struct DbRange { float zmin, scale; };
 __device__ __forceinline__ DbRange db_range(const uint32_t* __restrict__ zr /* this view's two words */) {
     const uint32_t lo_c = zr[0], hi = zr[1];
     DbRange r;
     r.zmin = __uint_as_float(~lo_c);
-    const float zmax = __uint_as_float(hi), ext = zmax - r.zmin;
+    const float zmax = __uint_as_float(hi), ext = 1.02f * (zmax - r.zmin);
+    r.zmin -= 0.01f * (zmax - r.zmin);
     r.scale = (lo_c != 0u && ext > 0.0f) ? (float)(MGR_DB_BUCKETS - 1) / ext : 0.0f;
     return r;
 }
@@ -206,18 +212,10 @@ __device__ __forceinline__ void pre_tail(int N, int gx, int gy, int v, int i, co
                                          MgrGRec* __restrict__ grec, float* __restrict__ depth,
                                          ushort4* __restrict__ rect, unsigned long long* __restrict__ alive,
                                          uint32_t* __restrict__ pair_off, uint32_t* __restrict__ tile_count,
-                                         int32_t* __restrict__ radii, MgrHeader* hdr, uint32_t* __restrict__ db_zrange_v,
-                                         const uint32_t* __restrict__ zcut_v = nullptr) {
+                                         int32_t* __restrict__ radii, MgrHeader* hdr, const uint32_t* __restrict__ zcut_v = nullptr) {
     const int tid = threadIdx.x, T = gx * gy;
     const int radius = po.radius, x0 = po.x0, y0 = po.y0, x1 = po.x1, y1 = po.y1;
     const uint32_t tiles = (uint32_t)((x1 - x0) * (y1 - y0));
-    {   // depth range of the view's visible instances (the instance sort's buckets are uniform over it): wave maxima of the depth
-        // bits and of their complement -> s_scan[22 / 23] (zeroed by the kernel before its first barrier) -> one pair of global
-        // atomics per workgroup behind the scan's barrier below
-        const uint32_t zb = (radius > 0 && tiles > 0u) ? __float_as_uint(po.zv) : 0u;
-        const uint32_t wmax = mgr_wave_max_u32(zb), wminc = mgr_wave_max_u32(zb ? ~zb : 0u);
-        if ((tid & 63) == 0 && wmax) { atomicMax(&s_scan[22], wmax); atomicMax(&s_scan[23], wminc); }
-    }
     unsigned long long amask = ~0ull;
     if (radius > 0 && !(zcut_v && tiles <= 64)) {
         const bool small = tiles <= 64;
@@ -270,7 +268,6 @@ __device__ __forceinline__ void pre_tail(int N, int gx, int gy, int v, int i, co
     uint32_t block_total;
     const uint32_t local = block_excl_scan(tiles, s_scan, block_total);
     if (tid == 0) s_scan[20] = block_total ? atomicAdd(&hdr->acc_pairs, block_total) : 0u;
-    if (tid == 64 && s_scan[22] != 0u) { atomicMax(&db_zrange_v[1], s_scan[22]); atomicMax(&db_zrange_v[0], s_scan[23]); }
     __syncthreads();
     const uint32_t off = s_scan[20] + local;
     if (i < N) {
@@ -305,7 +302,7 @@ __global__ __launch_bounds__(PRE_THREADS) void k_preprocess(
     const float* __restrict__ opacity, int64_t s_op, MgrGRec* __restrict__ grec,
     float* __restrict__ depth, ushort4* __restrict__ rect, unsigned long long* __restrict__ alive,
     uint32_t* __restrict__ pair_off, uint32_t* __restrict__ tile_count, int32_t* __restrict__ radii,
-    MgrHeader* hdr, int lds_hist, uint32_t* __restrict__ db_zrange) {
+    MgrHeader* hdr, int lds_hist) {
     extern __shared__ uint32_t s_mem[];
     uint32_t* s_scan = s_mem;       // 32 words
     uint32_t* s_hist = s_mem + 32;  // gx*gy words when lds_hist
@@ -315,7 +312,6 @@ __global__ __launch_bounds__(PRE_THREADS) void k_preprocess(
     if (lds_hist) {
         for (int k = tid; k < T; k += PRE_THREADS) s_hist[k] = 0;
     }
-    if (tid < 2) s_scan[22 + tid] = 0u;
     __syncthreads();
 
     MgrCam cam;
@@ -338,7 +334,7 @@ __global__ __launch_bounds__(PRE_THREADS) void k_preprocess(
         col[0] = cp[0]; col[1] = cp[1]; col[2] = cp[2];
     }
     pre_tail(N, gx, gy, v, i, po, op_i, col, s_scan, s_hist, lds_hist, grec, depth, rect, alive, pair_off, tile_count,
-             radii, hdr, db_zrange + 2 * v);
+             radii, hdr);
 }
 
 // ---------------------------------------------------------------------------
@@ -359,7 +355,7 @@ __global__ __launch_bounds__(PRE_THREADS) void k_inst_fwd(
     const float* __restrict__ skin_w, const float* __restrict__ transforms, MgrGRec* __restrict__ grec,
     float* __restrict__ depth, ushort4* __restrict__ rect, unsigned long long* __restrict__ alive,
     uint32_t* __restrict__ pair_off, uint32_t* __restrict__ tile_count, int32_t* __restrict__ radii,
-    MgrHeader* hdr, int lds_hist, int V, const uint32_t* __restrict__ tile_zcut, uint32_t* __restrict__ db_zrange) {
+    MgrHeader* hdr, int lds_hist, int V, const uint32_t* __restrict__ tile_zcut) {
     extern __shared__ uint32_t s_mem[];
     uint32_t* s_scan = s_mem;
     uint32_t* s_hist = s_mem + 32;
@@ -379,7 +375,6 @@ __global__ __launch_bounds__(PRE_THREADS) void k_inst_fwd(
     if (lds_hist) {
         for (int k2 = tid; k2 < T; k2 += PRE_THREADS) s_hist[k2] = 0;
     }
-    if (tid < 2) s_scan[22 + tid] = 0u;
     __syncthreads();
     MgrCam cam;
     mgr_load_cam(cams, v, cam);
@@ -434,7 +429,7 @@ __global__ __launch_bounds__(PRE_THREADS) void k_inst_fwd(
         }
     }
     pre_tail(N, gx, gy, v, i, po, op_i, col, s_scan, s_hist, lds_hist, grec, depth, rect, alive, pair_off, tile_count,
-             radii, hdr, db_zrange + 2 * v, tile_zcut ? tile_zcut + (size_t)v * T : nullptr);
+             radii, hdr, tile_zcut ? tile_zcut + (size_t)v * T : nullptr);
 }
 
 // ---------------------------------------------------------------------------
@@ -462,20 +457,33 @@ __device__ __forceinline__ uint32_t mgr_queue_key(uint32_t count, uint32_t prev_
 __device__ __forceinline__ void dbin_count_block(int bx, int v, int N, const int32_t* __restrict__ radii,
                                                  const float* __restrict__ depth, const ushort4* __restrict__ rect,
                                                  const unsigned long long* __restrict__ alive, uint32_t* __restrict__ db_count,
-                                                 uint32_t* s_hist /*MGR_DB_BUCKETS*/, const uint32_t* __restrict__ db_zrange) {
+                                                 uint32_t* s_hist /*MGR_DB_BUCKETS*/, uint32_t* __restrict__ db_zrange) {
     const int tid = threadIdx.x;
-    const DbRange zr = db_range(db_zrange + 2 * v);
+    const DbRange zr = db_range(db_zrange + 4 * v);
     for (int k = tid; k < MGR_DB_BUCKETS; k += 1024) s_hist[k] = 0;
+    __shared__ uint32_t s_zr[2];
+    if (tid < 2) s_zr[tid] = 0u;
     __syncthreads();
+    uint32_t zmax_b = 0u, zmin_c = 0u;      // this thread's participating depths: largest bits, largest complement
 #pragma unroll
     for (int r = 0; r < DB_PER; ++r) {
         const int i = (bx * DB_PER + r) * 1024 + tid;
         if (i < N) {
             const size_t vi = (size_t)v * N + i;
-            if (db_takes_part(radii[vi], rect[vi], alive[vi])) atomicAdd(&s_hist[db_bucket(depth[vi], zr)], 1u);
+            if (db_takes_part(radii[vi], rect[vi], alive[vi])) {
+                const float z = depth[vi];
+                atomicAdd(&s_hist[db_bucket(z, zr)], 1u);
+                zmax_b = max(zmax_b, __float_as_uint(z));
+                zmin_c = max(zmin_c, ~__float_as_uint(z));
+            }
         }
     }
+    {   // the range of this forward's participating instances, for the next forward's buckets
+        const uint32_t wmax = mgr_wave_max_u32(zmax_b), wminc = mgr_wave_max_u32(zmin_c);
+        if ((tid & 63) == 0 && wmax) { atomicMax(&s_zr[1], wmax); atomicMax(&s_zr[0], wminc); }
+    }
     __syncthreads();
+    if (tid == 0 && s_zr[1]) { atomicMax(&db_zrange[4 * v + 3], s_zr[1]); atomicMax(&db_zrange[4 * v + 2], s_zr[0]); }
     for (int k = tid; k < MGR_DB_BUCKETS; k += 1024) {
         const uint32_t c = s_hist[k];
         if (c) atomicAdd(&db_count[(size_t)v * MGR_DB_BUCKETS + k], c);
@@ -545,7 +553,7 @@ __device__ __forceinline__ void dbin_scatter_block(int bx, int v, int N, const i
                                                    unsigned long long* __restrict__ db_keys, uint32_t* s_hist /*MGR_DB_BUCKETS*/,
                                                    const uint32_t* __restrict__ db_zrange) {
     const int tid = threadIdx.x;
-    const DbRange zr = db_range(db_zrange + 2 * v);
+    const DbRange zr = db_range(db_zrange + 4 * v);
     for (int k = tid; k < MGR_DB_BUCKETS; k += 1024) s_hist[k] = 0;
     __syncthreads();
     float z[DB_PER];
@@ -1514,20 +1522,35 @@ __global__ __launch_bounds__(RS_THREADS) __attribute__((amdgpu_waves_per_eu(DBS_
 #define DBR_THREADS RS_THREADS
 __global__ __launch_bounds__(DBR_THREADS) void k_dbin_rank(int N, int V, int items_per_view, const uint32_t* __restrict__ db_start,
                                                            const uint32_t* __restrict__ db_item, const unsigned long long* __restrict__ db_keys,
-                                                           uint32_t* __restrict__ db_order, MgrHeader* hdr, uint32_t* __restrict__ db_zrange) {
+                                                           uint32_t* __restrict__ db_order, MgrHeader* hdr, uint32_t* __restrict__ db_zrange,
+                                                           int no_launch_behind, BgFill fill, int n_sort_blocks) {
+    if ((int)blockIdx.x >= n_sort_blocks) {   // (the launch's extra workgroups: see BgFill)
+        bg_fill_block(fill, hdr, (int)blockIdx.x - n_sort_blocks, (int)gridDim.x - n_sort_blocks);
+        return;
+    }
     __shared__ __attribute__((aligned(16))) unsigned long long s_keys[MGR_DB_RANK_MAX];
     __shared__ uint32_t s_cnt[RS_WAVES * 256];
     __shared__ uint32_t s_scan[32];
     const int tid = threadIdx.x;
     const int v = (int)blockIdx.x % V, it = (int)blockIdx.x / V;      // view-minor: neighbours differ in view
-    if (blockIdx.x == 0 && tid < 2 * V) db_zrange[tid] = 0u;          // (the bucket kernels of this forward are done with the ranges)
+    if (blockIdx.x == 0 && tid < 2 * V) {      // the bucket kernels of this forward are done with the ranges: this forward's becomes the next one's
+        const int vv = tid >> 1, w = tid & 1;
+        const uint32_t acc = db_zrange[4 * vv + 2 + w];
+        if (acc) db_zrange[4 * vv + w] = acc;
+        db_zrange[4 * vv + 2 + w] = 0u;
+    }
     const uint32_t* const ent = db_item + ((size_t)v * items_per_view + it) * 2;
     const uint32_t e0 = ent[0], e1 = ent[1];                          // (uniform: scalar loads)
     if (e0 == 0u) return;                                             // no bucket starts in this item
     const uint32_t* st = db_start + (size_t)v * (MGR_DB_BUCKETS + 1);
     const uint32_t lo = st[~e0], hi = st[e1], n = hi - lo;
     if (n > (uint32_t)MGR_DB_RANK_MAX) {
-        if (tid == 0) atomicAdd(&hdr->sort_big, 1u);
+        if (tid == 0) {
+            atomicAdd(&hdr->sort_big, 1u);
+            // the caller skipped the launch behind (debug bit 128: the previous forward met no such item): flagged like a skipped
+            // binning tier -- the forward is run again with every launch
+            if (no_launch_behind) atomicOr(&hdr->overflow, MGR_OVF_TIER);
+        }
         return;
     }
     lds_sort_emit(db_keys + (size_t)v * N + lo, n, s_keys, s_cnt, s_scan, tid, db_order + (size_t)v * N + lo);
@@ -1693,6 +1716,34 @@ __device__ __forceinline__ BinRec bin_load(int N, int v, uint32_t p, uint32_t nv
     }
     return r;
 }
+// The lane-th lane of a batch that is spread over lanes (k_bin_scatter, round 6): the instance (or the row piece of a rectangle of
+// more than 64 tiles) that virtual lane j of the batch stands for.  s_vend: running count of the lanes the 64 instances of the
+// batch take; every lane of the wave must call it (the source records travel by lane exchange).
+__device__ __noinline__ BinRec bin_spread_lane(uint32_t j, const BinRec cur, const uint32_t* s_vend) {
+    BinRec r = {0u, 0u, 0u, 0u, 0u, 0u};
+    const bool on = j < s_vend[63];
+    int lo = 0, hi = 63;      // the first source lane whose running count exceeds j
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (s_vend[mid] > j) hi = mid; else lo = mid + 1;
+    }
+    BinRec q;
+    q.xy = (uint32_t)__shfl((int)cur.xy, lo, 64); q.wh = (uint32_t)__shfl((int)cur.wh, lo, 64);
+    q.alo = (uint32_t)__shfl((int)cur.alo, lo, 64); q.ahi = (uint32_t)__shfl((int)cur.ahi, lo, 64);
+    q.gid = (uint32_t)__shfl((int)cur.gid, lo, 64); q.tiles = (uint32_t)__shfl((int)cur.tiles, lo, 64);
+    if (!on) return r;
+    if (q.tiles <= 64u) return q;
+    const uint32_t piece = j - (lo ? s_vend[lo - 1] : 0u), qw = q.wh & 0xFFFFu, per_row = (qw + 63u) / 64u;
+    const uint32_t row = piece / per_row, px = piece - row * per_row, ww = min(64u, qw - 64u * px);
+    r.xy = ((uint32_t)(bin_x0(q.xy) + (int)(64u * px)) & 0xFFFFu) | ((uint32_t)(bin_y0(q.xy) + (int)row) << 16);
+    r.wh = ww | (1u << 16);
+    const unsigned long long ones = ww >= 64u ? ~0ull : ((1ull << ww) - 1ull);
+    r.alo = (uint32_t)ones; r.ahi = (uint32_t)(ones >> 32);
+    r.gid = q.gid;
+    r.tiles = ww;
+    return r;
+}
+
 // Slots for one batch of 64 instances, instance by instance (the general route: any rectangle size, any grid).
 // Four instances of at most 16 tiles share a step (16 lanes each, their LDS adds issued one instance after the other).
 __device__ __forceinline__ void bin_batch_by_instance(const BinRec& r, const BinRec* s_rec, uint32_t* s_cur, int bw, int lane,
@@ -1768,7 +1819,7 @@ __device__ unsigned long long g_binprof[8 * 4096];
 // c_row_comb[w] = sum over j of 2^(2 w j) below 2^64: times a row's w bits = the even rows of a rectangle of width w
 __constant__ unsigned long long c_row_comb[65] = {0x0000000000000000ull, 0x5555555555555555ull, 0x1111111111111111ull, 0x1041041041041041ull, 0x0101010101010101ull, 0x1004010040100401ull, 0x1001001001001001ull, 0x0100040010004001ull, 0x0001000100010001ull, 0x0040001000040001ull, 0x1000010000100001ull, 0x0000100000400001ull, 0x0001000001000001ull, 0x0010000004000001ull, 0x0100000010000001ull, 0x1000000040000001ull, 0x0000000100000001ull, 0x0000000400000001ull, 0x0000001000000001ull, 0x0000004000000001ull, 0x0000010000000001ull, 0x0000040000000001ull, 0x0000100000000001ull, 0x0000400000000001ull, 0x0001000000000001ull, 0x0004000000000001ull, 0x0010000000000001ull, 0x0040000000000001ull, 0x0100000000000001ull, 0x0400000000000001ull, 0x1000000000000001ull, 0x4000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull, 0x0000000000000001ull};
 #define BIN_SC_FIXED_BYTES (2 * 64 * sizeof(BinRec) + 2 * BIN_PAIR_CAP * 4 + 3 * 64 * 4 + 16 + 66 * 8)
-#define BIN_END 0xFFFFFFFEu   // s_info: the producer has nothing more (the loop's exit, read by every wave behind the barrier)
+// (bit 31 of s_info[d]: the batch in buffer d is the producer's last one -- the consumers leave the loop behind it)
 // MASKS = tiles the per-tile lane masks cover: BIN_MID_TILES (30 KB of LDS, five workgroups per CU -- the boxes of the
 // hand scene hold 960-1470 tiles, tools/instr/tile_bbox.py), BIN_SMALL_TILES (36 KB, four per CU) or 0 (no masks: any box).
 #define BIN_MID_TILES 1536
@@ -1844,16 +1895,15 @@ __global__ __launch_bounds__(BIN_SC_THREADS) void k_bin_scatter(int N, int T, in
     uint32_t v_total = 0, v_off = 0;   // lanes the current source batch is spread over / already emitted
     bool v_mapped = false;
     BinRec cur = {0u, 0u, 0u, 0u, 0u, 0u};
+    bool last_emitted = false;      // producer: the batch emitted in the previous iteration was the last one
 #pragma unroll 1
     for (int it = 0;; ++it) {
         __syncthreads();   // batch it - 1 is expanded (and, the first time, the cursors are loaded); batch it - 2 is consumed
-        if (it >= 1 && s_info[(it - 1) & 1] == BIN_END) break;
         BP(5)
         if (wave == 0) {
             const int d = it & 1;
-            if (v_off >= v_total && src_it >= nbatch) {
-                if (lane == 0) s_info[d] = BIN_END;
-            } else {   // ---- producer: the next 64 lanes into buffer it & 1
+            if (last_emitted) break;      // (the consumers take the last batch in this iteration and leave by its bit 31: same barrier count)
+            {   // ---- producer: the next 64 lanes into buffer it & 1
                 if (v_off >= v_total) {      // the next source batch
                     cur = nxt;
                     BP(0)
@@ -1873,36 +1923,9 @@ __global__ __launch_bounds__(BIN_SC_THREADS) void k_bin_scatter(int N, int T, in
                     }
                 }
                 BinRec r = cur;
-                if (v_mapped) {
-                    const uint32_t j = v_off + (uint32_t)lane;
-                    r = BinRec{0u, 0u, 0u, 0u, 0u, 0u};
-                    const bool on = j < s_vend[63];
-                    int lo = 0, hi = 63;      // the first source lane whose running count exceeds j
-                    while (lo < hi) {
-                        const int mid = (lo + hi) >> 1;
-                        if (s_vend[mid] > j) hi = mid; else lo = mid + 1;
-                    }
-                    // that lane's record, out of its registers (every lane takes part in the exchange)
-                    BinRec q;
-                    q.xy = (uint32_t)__shfl((int)cur.xy, lo, 64); q.wh = (uint32_t)__shfl((int)cur.wh, lo, 64);
-                    q.alo = (uint32_t)__shfl((int)cur.alo, lo, 64); q.ahi = (uint32_t)__shfl((int)cur.ahi, lo, 64);
-                    q.gid = (uint32_t)__shfl((int)cur.gid, lo, 64); q.tiles = (uint32_t)__shfl((int)cur.tiles, lo, 64);
-                    if (on) {
-                        if (q.tiles <= 64u) {
-                            r = q;
-                        } else {
-                            const uint32_t piece = j - (lo ? s_vend[lo - 1] : 0u), qw = q.wh & 0xFFFFu, per_row = (qw + 63u) / 64u;
-                            const uint32_t row = piece / per_row, px = piece - row * per_row, ww = min(64u, qw - 64u * px);
-                            r.xy = ((uint32_t)(bin_x0(q.xy) + (int)(64u * px)) & 0xFFFFu) | ((uint32_t)(bin_y0(q.xy) + (int)row) << 16);
-                            r.wh = ww | (1u << 16);
-                            const unsigned long long ones = ww >= 64u ? ~0ull : ((1ull << ww) - 1ull);
-                            r.alo = (uint32_t)ones; r.ahi = (uint32_t)(ones >> 32);
-                            r.gid = q.gid;
-                            r.tiles = ww;
-                        }
-                    }
-                }
+                if (v_mapped) r = bin_spread_lane(v_off + (uint32_t)lane, cur, s_vend);      // (out of line: the usual path keeps its schedule)
                 v_off += 64u;
+                last_emitted = v_off >= v_total && src_it >= nbatch;      // (travels in bit 31 of s_info[d])
                 const unsigned long long am = ((unsigned long long)r.ahi << 32) | r.alo;
                 const bool use = r.tiles != 0u;
                 const uint32_t w = r.wh & 0xFFFFu;
@@ -1942,17 +1965,17 @@ __global__ __launch_bounds__(BIN_SC_THREADS) void k_bin_scatter(int N, int T, in
                         pl[at] = (uint32_t)(org + (int)ty * bw + (int)tx) | ((uint32_t)lane << 16);
                     }
                     s_gid[d * 64 + lane] = r.gid;
-                    if (lane == 0) s_info[d] = P;
+                    if (lane == 0) s_info[d] = P | (last_emitted ? 0x80000000u : 0u);
                 } else {      // (more pairs than the stage holds: the lanes one after the other -- every one of at most 64 tiles now)
                     s_rec[d * 64 + lane] = r;
-                    if (lane == 0) s_info[d] = 0xFFFFFFFFu;
+                    if (lane == 0) s_info[d] = 0x7FFFFFFFu | (last_emitted ? 0x80000000u : 0u);
                 }
                 BP(2)
             }
         } else if (it >= 1) {   // ---- consumers: batch it - 1 from buffer (it - 1) & 1; wave 1 the even box rows, wave 2 the odd ones
             const int d = (it - 1) & 1;
-            const uint32_t Pboth = s_info[d];
-            if (Pboth != 0xFFFFFFFFu) {
+            const uint32_t Praw = s_info[d], Pboth = Praw & 0x7FFFFFFFu;      // (bit 31: the producer's last batch)
+            if (Pboth != 0x7FFFFFFFu) {
                 const bool odd = wave == 2;
                 const uint32_t P = odd ? Pboth >> 16 : Pboth & 0xFFFFu;
                 const uint32_t* const plist = s_pairs + d * BIN_PAIR_CAP;
@@ -2022,6 +2045,7 @@ __global__ __launch_bounds__(BIN_SC_THREADS) void k_bin_scatter(int N, int T, in
                 bin_batch_by_instance(r, s_rec + d * 64, s_cur, bw, lane, sorted_gid, cap);
                 BP(4)
             }
+            if (Praw & 0x80000000u) break;      // that was the producer's last batch
         }
     }
 #ifdef BIN_PROF
@@ -3128,7 +3152,7 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
                        canon->f_rest, canon->skin_w, canon->transforms, (MgrGRec*)(ws + L.grec),                        \
                        (float*)(ws + L.depth), (ushort4*)(ws + L.rect), (unsigned long long*)(ws + L.alive),            \
                        (uint32_t*)(ws + L.pair_off), tile_count, radii, hdr, lds_hist, V,                                  \
-                       use_cut ? (const uint32_t*)(ws + L.tile_zcut) : (const uint32_t*)nullptr, (uint32_t*)(ws + L.db_zrange))
+                       use_cut ? (const uint32_t*)(ws + L.tile_zcut) : (const uint32_t*)nullptr)
             if (mixed && canon->sh_half) MGR_IF_LAUNCH(true, true);
             else if (mixed) MGR_IF_LAUNCH(true, false);
             else if (canon->sh_half) MGR_IF_LAUNCH(false, true);
@@ -3139,7 +3163,7 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
                            gy, cams, means3D, s_means, cov3D, s_cov, colors, s_col, opacity, s_op,
                            (MgrGRec*)(ws + L.grec), (float*)(ws + L.depth), (ushort4*)(ws + L.rect),
                            (unsigned long long*)(ws + L.alive), (uint32_t*)(ws + L.pair_off), tile_count, radii,
-                           hdr, lds_hist, (uint32_t*)(ws + L.db_zrange)); }
+                           hdr, lds_hist); }
         MGR_LAUNCH_CHECK("k_preprocess", stream, debug);
     }
     {
@@ -3186,18 +3210,23 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
           // larger ones (returns at once when there are none) -- it also carries the background of the empty tiles (BgFill)
           const int ipv = (N + MGR_DB_ITEM - 1) / MGR_DB_ITEM + 1;
           const bool ranked = ipv <= DBR_MAX_ITEMS;      // (more instances per view than the scan can table: everything through the radix launch)
-          if (ranked)
-              hipLaunchKernelGGL(k_dbin_rank, dim3((unsigned)(ipv * V)), dim3(DBR_THREADS), 0, stream, N, V, ipv, (const uint32_t*)db_start, (const uint32_t*)(ws + L.db_item),
-                                 (const unsigned long long*)db_keys, db_order, hdr, (uint32_t*)(ws + L.db_zrange));
+          // debug bit 128 (skip_tiers & 4): the previous forward met no item beyond k_dbin_rank -- the launch behind it is skipped
+          // (7 us of workgroups that return at once); an item that needs it after all raises MGR_OVF_TIER
+          const bool behind = !ranked || !(skip_tiers & 4);
           BgFill fill = {do_blend && bg_fill_on ? out_color : nullptr, (const uint32_t*)(ws + L.tile_queue), bg, VT, T, gx, W, H,
                          (const unsigned char*)(ws + L.tile_bgok), img_kept};
+          const BgFill none = {nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, nullptr, 0};
           const int n_fill = fill.out ? 1024 : 0;
           bg_filled = fill.out != nullptr;
+          if (ranked)
+              hipLaunchKernelGGL(k_dbin_rank, dim3((unsigned)(ipv * V + n_fill)), dim3(DBR_THREADS), 0, stream, N, V, ipv, (const uint32_t*)db_start, (const uint32_t*)(ws + L.db_item),
+                                 (const unsigned long long*)db_keys, db_order, hdr, (uint32_t*)(ws + L.db_zrange), behind ? 0 : 1, fill, ipv * V);
           const int fchunk = ranked ? (int)MGR_DB_ITEM : chunk, fchunks = (N + fchunk - 1) / fchunk;
           (void)chunks;
-          hipLaunchKernelGGL((k_dbin_sort<SORT_LDS_KEYS>), dim3(1024 + n_fill), dim3(RS_THREADS), SORT_LDS_KEYS * 8 + RS_WAVES * 256 * 4 + 256, stream,
-                             N, fchunk, fchunks, V * fchunks, (const uint32_t*)db_start, (const uint32_t*)db_nvis, db_keys, db_order,
-                             ranked ? (uint32_t)MGR_DB_RANK_MAX : 0u, hdr, ranked ? 2 : 0, fill, 1024); }
+          if (behind)
+              hipLaunchKernelGGL((k_dbin_sort<SORT_LDS_KEYS>), dim3(1024 + (ranked ? 0 : n_fill)), dim3(RS_THREADS), SORT_LDS_KEYS * 8 + RS_WAVES * 256 * 4 + 256, stream,
+                                 N, fchunk, fchunks, V * fchunks, (const uint32_t*)db_start, (const uint32_t*)db_nvis, db_keys, db_order,
+                                 ranked ? (uint32_t)MGR_DB_RANK_MAX : 0u, hdr, ranked ? 2 : 0, ranked ? none : fill, 1024); }
         MGR_LAUNCH_CHECK("k_dbin_sort", stream, debug);
         const bool big_possible = T > BIN_SMALL_TILES;   // a box of more than BIN_SMALL_TILES tiles can only exist then
         { MGR_PROF("k_bin_count", stream);

@@ -75,7 +75,9 @@ class RasterWorkspace:
             return 0
         # (128 / 256: the instance sort's light launch alone, or its full-size launch alone)
         bits = (0 if self.tiers & 1 else 16) | (0 if self.tiers & 2 else 32) | (128 if (self.tiers >> 8) <= RasterWorkspace.SORT_BIG_MAX else 256)
-        return bits & ~48 if self.no_flagging_skips else bits      # (bits 128 / 256 choose between two complete sorts: never flagged)
+        # (bit 128 = "the previous forward met no sort item beyond k_dbin_rank: skip the launch behind it" -- verified on the device like
+        # the tile-box tiers, MGR_OVF_TIER; bit 256 is accepted and ignored since round 6)
+        return bits & ~(48 | 128) if self.no_flagging_skips else bits
 
 
 def default_pair_capacity(V, N):

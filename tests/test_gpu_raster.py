@@ -212,21 +212,25 @@ def test_skipped_binning_tiers_are_verified_and_retried():
     want_big = _hip([cam], 6.0 * m, c, col, op, grad_img=g)
     ctx.clear()
     ctx.tier_retries = 0
-    got_small = _hip([cam], m, c, col, op, grad_img=g)
+    first = _hip([cam], m, c, col, op, grad_img=g)
     ws = ctx.last_ws
-    assert ws.tiers == 0 and ws.skip_bits() == 48 + 128      # box of at most 1536 tiles, sort items of at most 4096 keys
+    # a fresh workspace has no depth range for the instance sort's buckets yet: one bucket per view, left to the launch behind
+    # k_dbin_rank -- which therefore is not skipped next time (bit 128 stays clear)
+    assert (ws.tiers & 0xFF) == 0 and (ws.tiers >> 8) >= 1 and ws.skip_bits() == 48 + 256
+    got_small = _hip([cam], m, c, col, op, grad_img=g)      # buckets over the range the first forward left: small items only
+    assert ws is ctx.last_ws and ws.tiers == 0 and ws.skip_bits() == 48 + 128      # box of at most 1536 tiles, no sort item beyond k_dbin_rank
     got_big = _hip([cam], 6.0 * m, c, col, op, grad_img=g)  # skips them, is flagged, runs again
-    assert ctx.tier_retries == 1 and (ctx.last_ws.tiers & 0xFF) == 1 and ctx.last_ws.skip_bits() == 32 + 128
+    assert ctx.tier_retries == 1 and (ctx.last_ws.tiers & 0xFF) == 1 and (ctx.last_ws.skip_bits() & 48) == 32
     again = _hip([cam], 6.0 * m, c, col, op, grad_img=g)
-    assert ctx.tier_retries == 1
+    assert ctx.tier_retries == 1 and ctx.last_ws.skip_bits() == 32 + 128
+    for k in want_small:
+        assert np.array_equal(first[k], want_small[k]), k
     for k in want_small:
         assert np.array_equal(got_small[k], want_small[k]), k
         assert np.array_equal(got_big[k], want_big[k]), k
         assert np.array_equal(again[k], want_big[k]), k
-    # the instance sort (bits 128 / 256): every Gaussian in one depth plane of the camera -> one depth bucket of 20 000 keys,
-    # beyond the light launch's LDS: both launches the first time (no record yet), the full launch alone from then on; the
-    # scene before had no such bucket: the light launch alone (the bench-size test of tests/test_gpu_depth_cut.py runs its
-    # larger items bucket by bucket)
+    # the instance sort (bit 128): every Gaussian in one depth plane of the camera -> one depth bucket of 20 000 keys whatever the
+    # range, beyond k_dbin_rank's items: the launch behind it sorts it, every time (bit 128 never set for this scene)
     E = look_at_extrinsics((0.3, -0.2, -1.5), (0, 0, 0), up=(0, 1, 0))
     R, tvec = np.asarray(E)[:3, :3], np.asarray(E)[:3, 3]
     pc = (m.astype(np.float64) @ R.T + tvec)
@@ -236,8 +240,22 @@ def test_skipped_binning_tiers_are_verified_and_retried():
     want_plane = _hip([cam], m_plane, c, col, op, grad_img=g)        # (no record of the tiers yet: both launches)
     assert (ctx.last_ws.tiers >> 8) >= 1 and (ctx.last_ws.skip_bits() & 256) and not (ctx.last_ws.skip_bits() & 128)
     got_plane = _hip([cam], m_plane, c, col, op, grad_img=g)
+    assert (ctx.last_ws.tiers >> 8) >= 1 and not (ctx.last_ws.skip_bits() & 128)
     for k in want_plane:
         assert np.array_equal(got_plane[k], want_plane[k]), k
+    # ... and a scene whose depths leave the range on file while the launch behind is being skipped: flagged, run again, exact
+    ctx.clear()
+    ctx.tier_retries = 0
+    _hip([cam], m, c, col, op, grad_img=g)
+    _hip([cam], m, c, col, op, grad_img=g)
+    assert ctx.last_ws.skip_bits() & 128
+    far = m.copy()
+    far[:, 2] += 0.6 * np.sign(far[:, 2])                      # the cloud pulled apart in depth: most of it outside the old range
+    got_far = _hip([cam], far, c, col, op, grad_img=g)
+    ctx.clear()
+    want_far = _hip([cam], far, c, col, op, grad_img=g)
+    for k in want_far:
+        assert np.array_equal(got_far[k], want_far[k]), k
 
 
 def test_multi_view_batch_equals_single_views_bitwise():
