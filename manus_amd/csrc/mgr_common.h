@@ -283,10 +283,10 @@ static inline MgrLayout mgr_layout(int V, int N, int W, int H, int64_t cap) {
     // depth cut: per tile the float bits of the depth behind which the repair of a tile that ran out stops collecting (about
     // MGR_REP_TARGET entries behind the cut; written with the hint by a forward that saw the tile's full list, kept otherwise)
     L.tile_zwin = o; o += mgr_align(VT * 4);
-    // instance sort (round 6): per view the depth range of its visible instances (db_range, raster_fwd.hip: four words) -> uniform
-    // depth buckets over that range; per sort item (MGR_DB_ITEM keys of the bucketed order, whole buckets) its first bucket (complement, atomicMax)
+    // instance sort (round 6): the depth range of every per-instance workgroup's visible instances (db_range_reduce, raster_fwd.hip)
+    // -> uniform depth buckets over the view's range; per sort item (MGR_DB_ITEM keys of the bucketed order, whole buckets) its first bucket (complement, atomicMax)
     // and the end of its last one -- written by the bucket scan, consumed (left zero) by k_dbin_rank
-    L.db_zrange = o; o += mgr_align((size_t)V * 4 * 4);
+    L.db_zrange = o; o += mgr_align((size_t)V * (((size_t)(N > 0 ? N : 1) + 511) / 512) * 2 * 4);   // one slot per workgroup of the per-instance kernel (PRE_THREADS = 512)
     L.db_item = o;   o += mgr_align((size_t)V * (((size_t)(N > 0 ? N : 1) + MGR_DB_ITEM - 1) / MGR_DB_ITEM + 1) * 2 * 4);
     L.total = o;
     return L;

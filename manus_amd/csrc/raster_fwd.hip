@@ -174,23 +174,26 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t val, uint32_t* s_wa
 #endif
 #define EMIT_THREADS 1024
 
-// Depth bucket of an instance: uniform over the depth range [zmin, zmax] the view's visible instances had IN THE PREVIOUS FORWARD
-// on this workspace, widened by 1 % (round 6; up to round 5: 1024 buckets per octave of z above the cull plane -- a hand at 1.2 m
-// then fills ~200 of the 8192 buckets with ~1000 keys each, and a sort item could not be smaller than a bucket).  Any monotone
-// map of z serves (a float subtraction and a multiplication by a positive constant are monotone; depths outside the range fall
-// into the end buckets); a range that fits gives small items.  Four words per view: [0 / 1] the range the bucket kernels of a
-// forward read (complement of the smallest depth's bits, largest depth's bits; zero = none: one bucket, the radix launch sorts
-// it), [2 / 3] the range THIS forward accumulates (dbin_count_block: one pair of atomicMax per 8192 instances) -- published to
-// [0 / 1] by k_dbin_rank, behind the bucket kernels.  (Accumulating it in the per-instance kernel for the SAME forward was
-// measured: +9 .. +21 us on k_inst_fwd for the atomics in front of its barrier.)
+// Depth bucket of an instance: uniform over the depth range [zmin, zmax] of the view's visible instances (round 6; up to round 5:
+// 1024 buckets per octave of z above the cull plane -- a hand at 1.2 m then fills ~200 of the 8192 buckets with ~1000 keys each,
+// and a sort item could not be smaller than a bucket).  Monotone in z (a float subtraction and a multiplication by a positive
+// constant are), evaluated by the same function wherever a bucket is needed.
+// The range: every workgroup of the per-instance kernel leaves (largest complement of its visible depths' bits, largest bits) in
+// its own slot of db_zrange -- a plain store behind its last barrier: no atomics, nothing to wait for (sending them to sixteen
+// shared words by atomicMax in front of a barrier cost that kernel 9 - 21 us; the previous forward's range, tried next, misfits
+// whenever the views change: end buckets of thousands of keys) -- and the bucket kernels reduce the view's slots (a few KB).
 struct DbRange { float zmin, scale; };
-__device__ __forceinline__ DbRange db_range(const uint32_t* __restrict__ zr /* this view's two words */) {
-    const uint32_t lo_c = zr[0], hi = zr[1];
+__device__ __forceinline__ DbRange db_range_reduce(const uint32_t* __restrict__ slots /* this view's */, int nslots, uint32_t* s_zr /* LDS, 2 words, zeroed */) {
+    uint32_t lo_c = 0u, hi = 0u;
+    for (int k = threadIdx.x; k < nslots; k += blockDim.x) { lo_c = max(lo_c, slots[2 * k]); hi = max(hi, slots[2 * k + 1]); }
+    lo_c = mgr_wave_max_u32(lo_c); hi = mgr_wave_max_u32(hi);
+    if ((threadIdx.x & 63) == 0 && hi) { atomicMax(&s_zr[0], lo_c); atomicMax(&s_zr[1], hi); }
+    __syncthreads();
+    lo_c = s_zr[0]; hi = s_zr[1];
     DbRange r;
     r.zmin = __uint_as_float(~lo_c);
-    const float zmax = __uint_as_float(hi), ext = 1.02f * (zmax - r.zmin);
-    r.zmin -= 0.01f * (zmax - r.zmin);
-    r.scale = (lo_c != 0u && ext > 0.0f) ? (float)(MGR_DB_BUCKETS - 1) / ext : 0.0f;
+    const float ext = __uint_as_float(hi) - r.zmin;
+    r.scale = (hi != 0u && ext > 0.0f) ? (float)(MGR_DB_BUCKETS - 1) / ext : 0.0f;
     return r;
 }
 __device__ __forceinline__ uint32_t db_bucket(float z, const DbRange r) {
@@ -212,10 +215,17 @@ __device__ __forceinline__ void pre_tail(int N, int gx, int gy, int v, int i, co
                                          MgrGRec* __restrict__ grec, float* __restrict__ depth,
                                          ushort4* __restrict__ rect, unsigned long long* __restrict__ alive,
                                          uint32_t* __restrict__ pair_off, uint32_t* __restrict__ tile_count,
-                                         int32_t* __restrict__ radii, MgrHeader* hdr, const uint32_t* __restrict__ zcut_v = nullptr) {
+                                         int32_t* __restrict__ radii, MgrHeader* hdr, uint32_t* __restrict__ zr_slot,
+                                         const uint32_t* __restrict__ zcut_v = nullptr) {
     const int tid = threadIdx.x, T = gx * gy;
     const int radius = po.radius, x0 = po.x0, y0 = po.y0, x1 = po.x1, y1 = po.y1;
     const uint32_t tiles = (uint32_t)((x1 - x0) * (y1 - y0));
+    {   // depth range of this workgroup's visible instances (db_range_reduce): wave maxima -> s_scan[22 / 23] (zeroed by the kernel
+        // before its first barrier); stored to the workgroup's slot at the very end
+        const uint32_t zb = (radius > 0 && tiles > 0u) ? __float_as_uint(po.zv) : 0u;
+        const uint32_t wmax = mgr_wave_max_u32(zb), wminc = mgr_wave_max_u32(zb ? ~zb : 0u);
+        if ((tid & 63) == 0 && wmax) { atomicMax(&s_scan[23], wmax); atomicMax(&s_scan[22], wminc); }
+    }
     unsigned long long amask = ~0ull;
     if (radius > 0 && !(zcut_v && tiles <= 64)) {
         const bool small = tiles <= 64;
@@ -293,6 +303,7 @@ __device__ __forceinline__ void pre_tail(int N, int gx, int gy, int v, int i, co
             if (c) atomicAdd(&tile_count[(size_t)v * T + k], c);
         }
     }
+    if (tid == 0) { zr_slot[0] = s_scan[22]; zr_slot[1] = s_scan[23]; }      // (behind the scan's barriers: every wave's maxima are in)
 }
 
 __global__ __launch_bounds__(PRE_THREADS) void k_preprocess(
@@ -302,7 +313,7 @@ __global__ __launch_bounds__(PRE_THREADS) void k_preprocess(
     const float* __restrict__ opacity, int64_t s_op, MgrGRec* __restrict__ grec,
     float* __restrict__ depth, ushort4* __restrict__ rect, unsigned long long* __restrict__ alive,
     uint32_t* __restrict__ pair_off, uint32_t* __restrict__ tile_count, int32_t* __restrict__ radii,
-    MgrHeader* hdr, int lds_hist) {
+    MgrHeader* hdr, int lds_hist, uint32_t* __restrict__ db_zrange) {
     extern __shared__ uint32_t s_mem[];
     uint32_t* s_scan = s_mem;       // 32 words
     uint32_t* s_hist = s_mem + 32;  // gx*gy words when lds_hist
@@ -312,6 +323,7 @@ __global__ __launch_bounds__(PRE_THREADS) void k_preprocess(
     if (lds_hist) {
         for (int k = tid; k < T; k += PRE_THREADS) s_hist[k] = 0;
     }
+    if (tid < 2) s_scan[22 + tid] = 0u;
     __syncthreads();
 
     MgrCam cam;
@@ -334,7 +346,7 @@ __global__ __launch_bounds__(PRE_THREADS) void k_preprocess(
         col[0] = cp[0]; col[1] = cp[1]; col[2] = cp[2];
     }
     pre_tail(N, gx, gy, v, i, po, op_i, col, s_scan, s_hist, lds_hist, grec, depth, rect, alive, pair_off, tile_count,
-             radii, hdr);
+             radii, hdr, db_zrange + 2 * ((size_t)v * gridDim.x + blockIdx.x));
 }
 
 // ---------------------------------------------------------------------------
@@ -355,7 +367,7 @@ __global__ __launch_bounds__(PRE_THREADS) void k_inst_fwd(
     const float* __restrict__ skin_w, const float* __restrict__ transforms, MgrGRec* __restrict__ grec,
     float* __restrict__ depth, ushort4* __restrict__ rect, unsigned long long* __restrict__ alive,
     uint32_t* __restrict__ pair_off, uint32_t* __restrict__ tile_count, int32_t* __restrict__ radii,
-    MgrHeader* hdr, int lds_hist, int V, const uint32_t* __restrict__ tile_zcut) {
+    MgrHeader* hdr, int lds_hist, int V, const uint32_t* __restrict__ tile_zcut, uint32_t* __restrict__ db_zrange) {
     extern __shared__ uint32_t s_mem[];
     uint32_t* s_scan = s_mem;
     uint32_t* s_hist = s_mem + 32;
@@ -375,6 +387,7 @@ __global__ __launch_bounds__(PRE_THREADS) void k_inst_fwd(
     if (lds_hist) {
         for (int k2 = tid; k2 < T; k2 += PRE_THREADS) s_hist[k2] = 0;
     }
+    if (tid < 2) s_scan[22 + tid] = 0u;
     __syncthreads();
     MgrCam cam;
     mgr_load_cam(cams, v, cam);
@@ -429,7 +442,7 @@ __global__ __launch_bounds__(PRE_THREADS) void k_inst_fwd(
         }
     }
     pre_tail(N, gx, gy, v, i, po, op_i, col, s_scan, s_hist, lds_hist, grec, depth, rect, alive, pair_off, tile_count,
-             radii, hdr, tile_zcut ? tile_zcut + (size_t)v * T : nullptr);
+             radii, hdr, db_zrange + 2 * ((size_t)v * nrange + range), tile_zcut ? tile_zcut + (size_t)v * T : nullptr);
 }
 
 // ---------------------------------------------------------------------------
@@ -457,33 +470,22 @@ __device__ __forceinline__ uint32_t mgr_queue_key(uint32_t count, uint32_t prev_
 __device__ __forceinline__ void dbin_count_block(int bx, int v, int N, const int32_t* __restrict__ radii,
                                                  const float* __restrict__ depth, const ushort4* __restrict__ rect,
                                                  const unsigned long long* __restrict__ alive, uint32_t* __restrict__ db_count,
-                                                 uint32_t* s_hist /*MGR_DB_BUCKETS*/, uint32_t* __restrict__ db_zrange) {
+                                                 uint32_t* s_hist /*MGR_DB_BUCKETS*/, const uint32_t* __restrict__ db_zrange, int nslots) {
     const int tid = threadIdx.x;
-    const DbRange zr = db_range(db_zrange + 4 * v);
-    for (int k = tid; k < MGR_DB_BUCKETS; k += 1024) s_hist[k] = 0;
     __shared__ uint32_t s_zr[2];
     if (tid < 2) s_zr[tid] = 0u;
+    for (int k = tid; k < MGR_DB_BUCKETS; k += 1024) s_hist[k] = 0;
     __syncthreads();
-    uint32_t zmax_b = 0u, zmin_c = 0u;      // this thread's participating depths: largest bits, largest complement
+    const DbRange zr = db_range_reduce(db_zrange + 2 * (size_t)v * nslots, nslots, s_zr);
 #pragma unroll
     for (int r = 0; r < DB_PER; ++r) {
         const int i = (bx * DB_PER + r) * 1024 + tid;
         if (i < N) {
             const size_t vi = (size_t)v * N + i;
-            if (db_takes_part(radii[vi], rect[vi], alive[vi])) {
-                const float z = depth[vi];
-                atomicAdd(&s_hist[db_bucket(z, zr)], 1u);
-                zmax_b = max(zmax_b, __float_as_uint(z));
-                zmin_c = max(zmin_c, ~__float_as_uint(z));
-            }
+            if (db_takes_part(radii[vi], rect[vi], alive[vi])) atomicAdd(&s_hist[db_bucket(depth[vi], zr)], 1u);
         }
     }
-    {   // the range of this forward's participating instances, for the next forward's buckets
-        const uint32_t wmax = mgr_wave_max_u32(zmax_b), wminc = mgr_wave_max_u32(zmin_c);
-        if ((tid & 63) == 0 && wmax) { atomicMax(&s_zr[1], wmax); atomicMax(&s_zr[0], wminc); }
-    }
     __syncthreads();
-    if (tid == 0 && s_zr[1]) { atomicMax(&db_zrange[4 * v + 3], s_zr[1]); atomicMax(&db_zrange[4 * v + 2], s_zr[0]); }
     for (int k = tid; k < MGR_DB_BUCKETS; k += 1024) {
         const uint32_t c = s_hist[k];
         if (c) atomicAdd(&db_count[(size_t)v * MGR_DB_BUCKETS + k], c);
@@ -551,11 +553,13 @@ __device__ __forceinline__ void dbin_scatter_block(int bx, int v, int N, const i
                                                    const unsigned long long* __restrict__ alive,
                                                    const uint32_t* __restrict__ db_start, uint32_t* __restrict__ db_cursor,
                                                    unsigned long long* __restrict__ db_keys, uint32_t* s_hist /*MGR_DB_BUCKETS*/,
-                                                   const uint32_t* __restrict__ db_zrange) {
+                                                   const uint32_t* __restrict__ db_zrange, int nslots) {
     const int tid = threadIdx.x;
-    const DbRange zr = db_range(db_zrange + 4 * v);
+    __shared__ uint32_t s_zr[2];
+    if (tid < 2) s_zr[tid] = 0u;
     for (int k = tid; k < MGR_DB_BUCKETS; k += 1024) s_hist[k] = 0;
     __syncthreads();
+    const DbRange zr = db_range_reduce(db_zrange + 2 * (size_t)v * nslots, nslots, s_zr);
     float z[DB_PER];
     uint32_t on = 0;
 #pragma unroll
@@ -591,9 +595,9 @@ __global__ __launch_bounds__(1024) void k_dbin_scatter(int N, const int32_t* __r
                                                        const float* __restrict__ depth, const ushort4* __restrict__ rect,
                                                        const unsigned long long* __restrict__ alive,
                                                        const uint32_t* __restrict__ db_start, uint32_t* __restrict__ db_cursor,
-                                                       unsigned long long* __restrict__ db_keys, const uint32_t* __restrict__ db_zrange) {
+                                                       unsigned long long* __restrict__ db_keys, const uint32_t* __restrict__ db_zrange, int nslots) {
     __shared__ uint32_t s_hist[MGR_DB_BUCKETS];
-    dbin_scatter_block((int)blockIdx.x, (int)blockIdx.y, N, radii, depth, rect, alive, db_start, db_cursor, db_keys, s_hist, db_zrange);
+    dbin_scatter_block((int)blockIdx.x, (int)blockIdx.y, N, radii, depth, rect, alive, db_start, db_cursor, db_keys, s_hist, db_zrange, nslots);
 }
 
 struct DbinArgs {   // depth-bucket side of the two tile-scan launches (ordered binning); db_count == nullptr: none
@@ -606,7 +610,7 @@ struct DbinArgs {   // depth-bucket side of the two tile-scan launches (ordered 
     ushort4* db_bbox;
     unsigned long long* db_keys;
     uint32_t *db_zrange, *db_item;
-    int items_per_view;
+    int items_per_view, zr_slots;      // (zr_slots: workgroups of the per-instance kernel per view = slots of db_zrange per view)
 };
 
 #define MGR_HOLE 0xFFFFFFFEu   // a position of the view-interleaved queue its view has no tile for
@@ -625,7 +629,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan_a(int T, int nbT, const uint
     __shared__ uint32_t s_dbh[MGR_DB_BUCKETS];
     if ((int)blockIdx.x >= n_scan_blocks) {   // the workgroups behind the scan's: depth buckets of 8192 instances of one view
         const int b2 = (int)blockIdx.x - n_scan_blocks;
-        dbin_count_block(b2 % db.n_bx, b2 / db.n_bx, db.N, db.radii, db.depth, db.rect, db.alive, db.db_count, s_dbh, db.db_zrange);
+        dbin_count_block(b2 % db.n_bx, b2 / db.n_bx, db.N, db.radii, db.depth, db.rect, db.alive, db.db_count, s_dbh, db.db_zrange, db.zr_slots);
         return;
     }
     __shared__ uint32_t s_scan[32];
@@ -1533,20 +1537,15 @@ __global__ __launch_bounds__(DBR_THREADS) void k_dbin_rank(int N, int V, int ite
     __shared__ uint32_t s_scan[32];
     const int tid = threadIdx.x;
     const int v = (int)blockIdx.x % V, it = (int)blockIdx.x / V;      // view-minor: neighbours differ in view
-    if (blockIdx.x == 0 && tid < 2 * V) {      // the bucket kernels of this forward are done with the ranges: this forward's becomes the next one's
-        const int vv = tid >> 1, w = tid & 1;
-        const uint32_t acc = db_zrange[4 * vv + 2 + w];
-        if (acc) db_zrange[4 * vv + w] = acc;
-        db_zrange[4 * vv + 2 + w] = 0u;
-    }
     const uint32_t* const ent = db_item + ((size_t)v * items_per_view + it) * 2;
     const uint32_t e0 = ent[0], e1 = ent[1];                          // (uniform: scalar loads)
     if (e0 == 0u) return;                                             // no bucket starts in this item
     const uint32_t* st = db_start + (size_t)v * (MGR_DB_BUCKETS + 1);
     const uint32_t lo = st[~e0], hi = st[e1], n = hi - lo;
+    if (n > (uint32_t)MGR_DB_RANK_MAX * 3u / 4u && tid == 0) atomicAdd(&hdr->sort_big, 1u);      // (counted from three quarters of the limit on:
+                                                                                                   //  the launch behind is only skipped well clear of it)
     if (n > (uint32_t)MGR_DB_RANK_MAX) {
         if (tid == 0) {
-            atomicAdd(&hdr->sort_big, 1u);
             // the caller skipped the launch behind (debug bit 128: the previous forward met no such item): flagged like a skipped
             // binning tier -- the forward is run again with every launch
             if (no_launch_behind) atomicOr(&hdr->overflow, MGR_OVF_TIER);
@@ -3152,7 +3151,7 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
                        canon->f_rest, canon->skin_w, canon->transforms, (MgrGRec*)(ws + L.grec),                        \
                        (float*)(ws + L.depth), (ushort4*)(ws + L.rect), (unsigned long long*)(ws + L.alive),            \
                        (uint32_t*)(ws + L.pair_off), tile_count, radii, hdr, lds_hist, V,                                  \
-                       use_cut ? (const uint32_t*)(ws + L.tile_zcut) : (const uint32_t*)nullptr)
+                       use_cut ? (const uint32_t*)(ws + L.tile_zcut) : (const uint32_t*)nullptr, (uint32_t*)(ws + L.db_zrange))
             if (mixed && canon->sh_half) MGR_IF_LAUNCH(true, true);
             else if (mixed) MGR_IF_LAUNCH(true, false);
             else if (canon->sh_half) MGR_IF_LAUNCH(false, true);
@@ -3163,7 +3162,7 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
                            gy, cams, means3D, s_means, cov3D, s_cov, colors, s_col, opacity, s_op,
                            (MgrGRec*)(ws + L.grec), (float*)(ws + L.depth), (ushort4*)(ws + L.rect),
                            (unsigned long long*)(ws + L.alive), (uint32_t*)(ws + L.pair_off), tile_count, radii,
-                           hdr, lds_hist); }
+                           hdr, lds_hist, (uint32_t*)(ws + L.db_zrange)); }
         MGR_LAUNCH_CHECK("k_preprocess", stream, debug);
     }
     {
@@ -3180,7 +3179,7 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
                               (const unsigned long long*)(ws + L.alive), dbin ? (uint32_t*)(ws + L.db_count) : nullptr,
                               (uint32_t*)(ws + L.db_cursor), (uint32_t*)(ws + L.db_start), (uint32_t*)(ws + L.db_nvis),
                               (ushort4*)(ws + L.db_bbox), (unsigned long long*)(ws + L.db_keys), (uint32_t*)(ws + L.db_zrange),
-                              (uint32_t*)(ws + L.db_item), (N + MGR_DB_ITEM - 1) / MGR_DB_ITEM + 1};
+                              (uint32_t*)(ws + L.db_item), (N + MGR_DB_ITEM - 1) / MGR_DB_ITEM + 1, (N + PRE_THREADS - 1) / PRE_THREADS};
         { MGR_PROF("k_tile_scan_a", stream); hipLaunchKernelGGL(k_tile_scan_a, dim3(nblk + (dbin ? n_bx * V : 0)), dim3(1024), 0, stream, T, nbT, tile_count,
                            (const uint32_t*)(ws + L.tile_done), use_hint, part, blk_cls, blk_box, gx, nblk, dba, hdr); }
         { MGR_PROF("k_tile_scan_b", stream); hipLaunchKernelGGL(k_tile_scan_b, dim3(nblk + (dbin ? V : 0)), dim3(1024), 0, stream, V, T, nbT, tile_count, part, (const uint32_t*)blk_cls,
@@ -3204,7 +3203,7 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
         const int chunk = bb == MGR_BIN_BLOCK ? DB_CHUNK : 1024, chunks = (N + chunk - 1) / chunk;
         const size_t rec_bytes = BIN_SC_FIXED_BYTES;
         { MGR_PROF("k_dbin_scatter", stream); hipLaunchKernelGGL(k_dbin_scatter, grid_n, dim3(1024), 0, stream, N, (const int32_t*)radii, (const float*)(ws + L.depth), rect, alive,
-                           (const uint32_t*)db_start, (uint32_t*)(ws + L.db_cursor), db_keys, (const uint32_t*)(ws + L.db_zrange)); }
+                           (const uint32_t*)db_start, (uint32_t*)(ws + L.db_cursor), db_keys, (const uint32_t*)(ws + L.db_zrange), (N + PRE_THREADS - 1) / PRE_THREADS); }
         { MGR_PROF("k_dbin_sort", stream);
           // items of at most MGR_DB_RANK_MAX keys by counting, one workgroup each (k_dbin_rank); behind it the radix launch for
           // larger ones (returns at once when there are none) -- it also carries the background of the empty tiles (BgFill)

@@ -214,10 +214,9 @@ def test_skipped_binning_tiers_are_verified_and_retried():
     ctx.tier_retries = 0
     first = _hip([cam], m, c, col, op, grad_img=g)
     ws = ctx.last_ws
-    # a fresh workspace has no depth range for the instance sort's buckets yet: one bucket per view, left to the launch behind
-    # k_dbin_rank -- which therefore is not skipped next time (bit 128 stays clear)
-    assert (ws.tiers & 0xFF) == 0 and (ws.tiers >> 8) >= 1 and ws.skip_bits() == 48 + 256
-    got_small = _hip([cam], m, c, col, op, grad_img=g)      # buckets over the range the first forward left: small items only
+    # (the instance sort's buckets span the depth range of THIS forward's visible instances: small items from the first forward on)
+    assert ws.tiers == 0 and ws.skip_bits() == 48 + 128
+    got_small = _hip([cam], m, c, col, op, grad_img=g)
     assert ws is ctx.last_ws and ws.tiers == 0 and ws.skip_bits() == 48 + 128      # box of at most 1536 tiles, no sort item beyond k_dbin_rank
     got_big = _hip([cam], 6.0 * m, c, col, op, grad_img=g)  # skips them, is flagged, runs again
     assert ctx.tier_retries == 1 and (ctx.last_ws.tiers & 0xFF) == 1 and (ctx.last_ws.skip_bits() & 48) == 32
@@ -243,17 +242,25 @@ def test_skipped_binning_tiers_are_verified_and_retried():
     assert (ctx.last_ws.tiers >> 8) >= 1 and not (ctx.last_ws.skip_bits() & 128)
     for k in want_plane:
         assert np.array_equal(got_plane[k], want_plane[k]), k
-    # ... and a scene whose depths leave the range on file while the launch behind is being skipped: flagged, run again, exact
+    # ... and the same plane met while the launch behind is being skipped: flagged, run again, exact
     ctx.clear()
     ctx.tier_retries = 0
     _hip([cam], m, c, col, op, grad_img=g)
-    _hip([cam], m, c, col, op, grad_img=g)
     assert ctx.last_ws.skip_bits() & 128
+    got_plane2 = _hip([cam], m_plane, c, col, op, grad_img=g)
+    assert ctx.tier_retries == 1 and not (ctx.last_ws.skip_bits() & 128)
+    for k in want_plane:
+        assert np.array_equal(got_plane2[k], want_plane[k]), k
+    # a cloud pulled apart in depth between two forwards: the buckets follow the forward's own range, nothing to re-run
     far = m.copy()
-    far[:, 2] += 0.6 * np.sign(far[:, 2])                      # the cloud pulled apart in depth: most of it outside the old range
-    got_far = _hip([cam], far, c, col, op, grad_img=g)
+    far[:, 2] += 0.6 * np.sign(far[:, 2])
     ctx.clear()
     want_far = _hip([cam], far, c, col, op, grad_img=g)
+    ctx.clear()
+    ctx.tier_retries = 0
+    _hip([cam], m, c, col, op, grad_img=g)
+    got_far = _hip([cam], far, c, col, op, grad_img=g)
+    assert (ctx.last_ws.tiers >> 8) == 0          # (no sort item near k_dbin_rank's limit; the nearer half's larger tile box may ask for its tier)
     for k in want_far:
         assert np.array_equal(got_far[k], want_far[k]), k
 
