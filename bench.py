@@ -390,16 +390,18 @@ def dropin_main(args):
     if args.dropin_fenced:
         rasterizer.check_overflow()
         rasterizer.set_sync_policy(False)
-    dts = []
+    dts, issue = [], []
     _lib.profile_enable(False)
     for _ in range(REPEATS):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             loss = one_step()
+        issue.append(time.perf_counter() - t0)      # (the host is done issuing; what is left is the device's backlog)
         torch.cuda.synchronize()
         dts.append(time.perf_counter() - t0)
     dt = float(np.median(dts))
+    host_issue_ms = 1e3 * float(np.median(issue)) / args.steps
     if args.dropin_fenced:
         rasterizer.check_overflow()      # (raises if a forward of the timed loops ran out of pair capacity)
     # per-kernel breakdown of the library launches (HIP events around each: slows the step, taken in a separate loop)
@@ -427,7 +429,9 @@ def dropin_main(args):
             "config": {"workload": "%s, %d Gaussians, ONE view per step (cycling over %d cameras) at %dx%d, modules.hand_forward + "
                                    "render.render_gaussians + losses (0.8 L1 + 0.2 (1 - SSIM)) under torch autograd" % (args.kind, N, V, W, H),
                        "route": "dropin", "gaussians": N, "views_per_step": 1, "width": W, "height": H,
-                       "host_syncs_per_step": 0 if args.dropin_fenced else 1, "library_kernel_ms_per_step": round(lib_ms, 4),
+                       "host_syncs_per_step": 0 if (args.dropin_fenced or rasterizer.context(dev).auto_fenced > 0) else 1,
+                       "library_kernel_ms_per_step": round(lib_ms, 4),
+                       "host_issue_ms_per_step": round(host_issue_ms, 4),
                        "dominant_library_kernel": dom, "dominant_kernel_ms": round(prof[dom][1] / prof[dom][0], 4) if dom else None,
                        "finite_grads": finite, "loss": float(loss.detach())},
             "roofline": None, "cpu_baseline": None, "parity": None}

@@ -8,6 +8,8 @@ GPU.
 import ctypes
 import os
 
+import weakref
+
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -169,7 +171,16 @@ def ptr(t):
     return t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream():
+    """The current HIP stream of the current device, as the integer handle the C ABI takes.  Through torch's raw accessors (two C
+    calls): `torch.cuda.current_stream().cuda_stream` walks ~15 Python frames per call (device-index helpers, an os.getenv), and
+    the operator route asks eight times per step (tools/instr/dropin_host_profile.py)."""
+    if _raw_stream is not None and _raw_device is not None:
+        return _raw_stream(_raw_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -180,7 +191,38 @@ def f32c(t):
     return t.contiguous()
 
 
+_PACKED = {}      # (ids of the source tensors, scalars) -> (weak references, versions, packed table)
+
+
+def cached_pack(tensors, scalars, build):
+    """`build()` once per set of unmodified source TENSOR OBJECTS: a training loop passes the same camera tensors step after
+    step (the reference keeps them on its Camera objects), and packing them again is a handful of launches per forward on a
+    route that is bound by launches.  Valid while every source is the same object (weak reference) at the same version
+    (in-place writes bump it); anything else -- new tensors, non-tensors -- builds afresh."""
+    if not all(torch.is_tensor(t) for t in tensors):
+        return build()
+    key = tuple(id(t) for t in tensors) + tuple(scalars)
+    ent = _PACKED.get(key)
+    if ent is not None and all(r() is t and t._version == ver for r, t, ver in zip(ent[0], tensors, ent[1])):
+        return ent[2]
+    out = build()
+    if len(_PACKED) >= 1024:
+        _PACKED.clear()
+    _PACKED[key] = (tuple(weakref.ref(t) for t in tensors), tuple(t._version for t in tensors), out)
+    return out
+
+
 def pack_cameras(tanfovx, tanfovy, viewmatrix, projmatrix, campos, device):
+    """See _pack_cameras; the table of one set of camera tensors is built once (cached_pack)."""
+    if isinstance(viewmatrix, (list, tuple)):
+        srcs = list(viewmatrix) + list(projmatrix) + list(campos)
+        scal = [float(x) for x in tanfovx] + [float(x) for x in tanfovy]
+    else:
+        srcs, scal = [viewmatrix, projmatrix, campos], [float(tanfovx), float(tanfovy)]
+    return cached_pack(srcs, scal + [str(device)], lambda: _pack_cameras(tanfovx, tanfovy, viewmatrix, projmatrix, campos, device))
+
+
+def _pack_cameras(tanfovx, tanfovy, viewmatrix, projmatrix, campos, device):
     """Build the (V, MGR_CAM_FLOATS) device camera table from reference-style
     camera tensors (each may carry a leading batch dim of 1).
     Lists give V > 1.  No host synchronisation."""
@@ -190,14 +232,16 @@ def pack_cameras(tanfovx, tanfovy, viewmatrix, projmatrix, campos, device):
 
     def on_dev(t, n):
         return torch.is_tensor(t) and t.is_cuda and (dev.index is None or t.device.index == dev.index) and t.dtype == torch.float32 \
-            and t.is_contiguous() and t.numel() >= n
+            and t.numel() >= n
 
     if dev.type == "cuda" and all(on_dev(v, 16) and on_dev(p, 16) and on_dev(c, 3) for v, p, c in zip(viewmatrix, projmatrix, campos)):
         # tensors already on the device (the reference's batch is): one launch per camera, the two tangents as kernel
         # arguments -- no host-to-device copy, no cat
         out = torch.empty((len(viewmatrix), MGR_CAM_FLOATS), dtype=torch.float32, device=viewmatrix[0].device)
         for k, (tx, ty, vm, pm, cp) in enumerate(zip(tanfovx, tanfovy, viewmatrix, projmatrix, campos)):
-            check(lib().mgr_pack_camera(float(tx), float(ty), ptr(vm), ptr(pm), ptr(cp), out[k].data_ptr(), stream()), "mgr_pack_camera")
+            # (.contiguous(): the reference's world_view_transform is a transposed view -- a copy on the device, still no host-to-device one)
+            check(lib().mgr_pack_camera(float(tx), float(ty), ptr(vm.contiguous()), ptr(pm.contiguous()), ptr(cp.contiguous()), out[k].data_ptr(), stream()),
+                  "mgr_pack_camera")
         return out
     rows = []
     for tx, ty, vm, pm, cp in zip(tanfovx, tanfovy, viewmatrix, projmatrix, campos):

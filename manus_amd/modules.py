@@ -20,11 +20,19 @@ class Pred(dict):
     __setattr__ = dict.__setitem__
 
 
+_LAST_ROW = {}
+
+
 def _tf44(tf12):
     """(N,12) rows 0..2 -> the reference's (N,4,4) layout."""
     N = tf12.shape[0]
-    last = torch.tensor([0.0, 0.0, 0.0, 1.0], dtype=tf12.dtype, device=tf12.device).expand(N, 1, 4)
-    return torch.cat([tf12.reshape(N, 3, 4), last], dim=1)
+    key = (tf12.device, tf12.dtype)
+    last = _LAST_ROW.get(key)
+    if last is None:
+        # built once per device: a host-to-device copy from pageable memory is ordered behind everything queued on the stream and
+        # the host waits for it -- one per step was a host synchronisation per step (bench.py --route dropin: 1.25 -> ... ms)
+        last = _LAST_ROW[key] = torch.tensor([0.0, 0.0, 0.0, 1.0], dtype=tf12.dtype, device=tf12.device)
+    return torch.cat([tf12.reshape(N, 3, 4), last.expand(N, 1, 4)], dim=1)
 
 
 def device_grid(model):

@@ -23,13 +23,17 @@ def calculate_colors_from_sh(posed_means, cano_features, cano_means, camera, sh_
     if sh_degree != 3:
         raise ValueError("only sh_degree 3 is supported (MANUS fixes it, src/models/gaussian.py:29)")
     dev = posed_means.device
-    cc = torch.as_tensor(camera.camera_center, dtype=torch.float32, device=dev).reshape(-1)
-    if cc.is_cuda and cc.is_contiguous():     # (the SH kernel reads the camera centre only: one launch, no fill + slice copy)
-        cams = torch.empty((1, _lib.MGR_CAM_FLOATS), dtype=torch.float32, device=dev)
-        _lib.check(_lib.lib().mgr_pack_camera(0.0, 0.0, None, None, _lib.ptr(cc), _lib.ptr(cams), _lib.stream()), "mgr_pack_camera")
-    else:
-        cams = torch.zeros((1, _lib.MGR_CAM_FLOATS), dtype=torch.float32, device=dev)
-        cams[0, 34:37] = cc[:3]
+    def pack():
+        cc = torch.as_tensor(camera.camera_center, dtype=torch.float32, device=dev).reshape(-1)
+        if cc.is_cuda:     # (the SH kernel reads the camera centre only: one launch, no fill + slice copy)
+            cams = torch.empty((1, _lib.MGR_CAM_FLOATS), dtype=torch.float32, device=dev)
+            _lib.check(_lib.lib().mgr_pack_camera(0.0, 0.0, None, None, _lib.ptr(cc.contiguous()), _lib.ptr(cams), _lib.stream()), "mgr_pack_camera")
+        else:
+            cams = torch.zeros((1, _lib.MGR_CAM_FLOATS), dtype=torch.float32, device=dev)
+            cams[0, 34:37] = cc[:3]
+        return cams
+
+    cams = _lib.cached_pack([camera.camera_center], ["sh", str(dev)], pack)
     if tf is not None:
         return sh_colors(cano_features, cano_means, _tf12(tf), cams)[0]
     return sh_colors(cano_features, posed_means, None, cams)[0]

@@ -420,3 +420,25 @@ def test_predicted_ms_rides_in_the_multi_gpu_line():
     p = bench.predicted_ms(8, 500000, 53, "composite", 1920, 1080)
     assert p["views_on_the_fullest_rank"] == 7 and p["compute_ms"] == bench.COMPOSITE_MS_BY_VIEWS[7] and p["exchange_bytes_dense"] == (61 * 500000 + 2) * 4
     assert p["step_ms_low"] < p["step_ms_high"]
+
+
+def test_packed_camera_tables_are_cached_per_unmodified_tensor_object():
+    """_lib.cached_pack: one build per set of source tensor OBJECTS at unchanged versions; an in-place write, another tensor of
+    equal content, or a non-tensor source builds again."""
+    from manus_amd import _lib
+    calls = []
+
+    def build():
+        calls.append(1)
+        return len(calls)
+
+    a, b = torch.zeros(4), torch.ones(3)
+    assert _lib.cached_pack([a, b], [0.5, "cpu"], build) == 1
+    assert _lib.cached_pack([a, b], [0.5, "cpu"], build) == 1 and len(calls) == 1
+    assert _lib.cached_pack([a, b], [0.25, "cpu"], build) == 2            # another scalar
+    a.add_(1.0)                                                            # in-place write: the version moves
+    assert _lib.cached_pack([a, b], [0.5, "cpu"], build) == 3
+    assert _lib.cached_pack([a, b], [0.5, "cpu"], build) == 3
+    assert _lib.cached_pack([a.clone(), b], [0.5, "cpu"], build) == 4     # equal content, another object
+    assert _lib.cached_pack([a.numpy(), b], [0.5, "cpu"], build) == 5     # not a tensor: never cached
+    assert _lib.cached_pack([a.numpy(), b], [0.5, "cpu"], build) == 6

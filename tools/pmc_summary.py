@@ -24,7 +24,9 @@ def main():
                 key = (r["Dispatch_Id"], r["Counter_Name"])
                 per_dispatch[key] += float(r["Counter_Value"])
                 per_dispatch[(r["Dispatch_Id"], "duration_ns")] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
-                names[r["Dispatch_Id"]] = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
+                # (template arguments kept: the instantiations of one kernel are different launches of a step -- the three
+                #  tiers of k_bin_scatter, of which a view set uses one and the others return at once)
+                names[r["Dispatch_Id"]] = r["Kernel_Name"].split("(")[0].replace("void ", "").strip()
             for (disp, cname), val in per_dispatch.items():
                 acc[names[disp]][cname].append(val)
     res = {}
@@ -56,7 +58,7 @@ def main():
         json.dump({"workload": wl, "step_hbm_bytes": step_bytes, "step_kernel_ns": step_ns, "source": "rocprofv3 --pmc passes of `python bench.py --steps 4 --warmup 2 --no-cpu-baseline` "
                    "(tools/pmc_collect.sh: one pass per counter group, never combined with API traces), median per launch, "
                    "summed over XCDs / SEs; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) KB (gfx950 FETCH_SIZE correction, "
-                   "MI355X_MICROARCH.md HBM section; gather widths uncalibrated)",
+                   "MI355X_MICROARCH.md HBM section; checked on this path's gathers and scatters: profiles/r06_counter_calibration.txt)",
                    "kernels": res}, open(out_json, "w"), indent=1)
 
 if __name__ == "__main__":
