@@ -132,7 +132,8 @@ struct MgrHeader {            // first 256 bytes of the workspace
     uint32_t rep_why;         // why the forward in flight raised MGR_OVF_CUT (bits MGR_WHY_*; k_tile_scan_a clears it)
     MgrRep rep;               // the repair's pointers / capacities of the forward in flight (k_tile_scan_b copies its argument here: the
                               // forward blend reads them in its rare "list ran out" branch instead of carrying 17 more scalars)
-    uint32_t spare[48 - sizeof(MgrRep) / 4];
+    uint32_t sort_huge;       // items of the instance sort beyond MGR_DB_RANK_MAX keys (k_dbin_rank counts; the launch behind it returns at once on 0)
+    uint32_t spare[47 - sizeof(MgrRep) / 4];
     uint32_t queue_giant;     // queue index of the first tile with fewer than 16384 pairs
     uint32_t n_groups;        // depth groups produced by k_tile_split for the giant tiles
     uint32_t split_head, group_head;
@@ -203,9 +204,17 @@ struct MgrLayout {
 
 // Depth-ordered binning (raster_fwd.hip, "ordered" route): the instances of a view are sorted by depth once, then
 // scattered to the tile lists in that order, instead of sorting every tile list.
-#define MGR_DB_BUCKETS 1024   // depth buckets per view of the instance sort (uniform over the depth range of the view's visible instances)
+#ifndef MGR_DB_BUCKETS
+#define MGR_DB_BUCKETS 1024   // depth buckets per view of the instance sort (uniform over the depth range of the view's visible instances).
+                              // The densest depth slice of the bench hand (the palm seen face on) is a bucket of 1569 keys, 2196 after 600 Adam
+                              // steps (tools/instr/depth_bucket_stats.py): that item goes to the launch behind k_dbin_rank.  More buckets keep
+                              // every item within k_dbin_rank but cost the bucket scatter one global add per non-empty bucket and block: same
+                              // box, eight views, 2048 buckets 1.312-1.322 ms against 1.308-1.311 (with the optimizer 1.507 against 1.488), 4096
+                              // buckets 1.324 against 1.315 -- not adopted.
+#endif
 #define MGR_DB_ITEM 768       // keys per item of the instance sort (whole buckets: an item ends with the bucket it is in)
-#define MGR_DB_RANK_MAX 2048  // items of at most this many keys are sorted by k_dbin_rank (16 KB of LDS: four workgroups per CU), larger ones by the launch behind it
+#define MGR_DB_RANK_MAX 2048  // items of at most this many keys are sorted by k_dbin_rank (16 + 8 KB of LDS: six workgroups per CU), larger ones by the
+                              // launch behind it.  (3584 keys -- four workgroups per CU -- cost k_dbin_rank 15 us at eight views, measured.)
 #ifndef MGR_BIN_BLOCK
 #define MGR_BIN_BLOCK 1024
 #endif

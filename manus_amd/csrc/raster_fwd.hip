@@ -637,7 +637,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan_a(int T, int nbT, const uint
     __shared__ uint32_t s_bb[4];
     const int tid = threadIdx.x, v = blockIdx.x / nbT, t = (blockIdx.x % nbT) * 1024 + tid;
     if (tid == 0) { s_bb[0] = 0xFFFFu; s_bb[1] = 0xFFFFu; s_bb[2] = 0u; s_bb[3] = 0u; }
-    if (blockIdx.x == 0 && tid == 0) { hdr->tiers = 0u; hdr->sort_big = 0u; hdr->fwd_seq += 1u; hdr->rep_why = 0u; }   // (phase B's depth-bucket workgroups / the sort set them)
+    if (blockIdx.x == 0 && tid == 0) { hdr->tiers = 0u; hdr->sort_big = 0u; hdr->sort_huge = 0u; hdr->fwd_seq += 1u; hdr->rep_why = 0u; }   // (phase B's depth-bucket workgroups / the sort set them)
     const bool valid = t < T;
     const size_t k = (size_t)v * T + t;
     if (tid < MGR_NCLS) s_cls[tid] = 0;
@@ -1436,8 +1436,9 @@ __global__ __launch_bounds__(RS_THREADS) __attribute__((amdgpu_waves_per_eu(DBS_
         return;
     }
     // full_runs == 2 (round 6): the launch behind k_dbin_rank -- it takes the items of more than min_keys keys, all of them, and
-    // returns at once when the ranking kernel met none (MgrHeader::sort_big: the usual case)
-    if (full_runs == 2 && hdr->sort_big == 0u) return;
+    // returns at once when the ranking kernel met none (MgrHeader::sort_huge: the usual case; sort_big also counts the items from
+    // three quarters of the limit on, which decide whether the caller may skip this launch next time)
+    if (full_runs == 2 && hdr->sort_huge == 0u) return;
     constexpr uint32_t lds_keys = (uint32_t)LDS_KEYS;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     unsigned long long* s_keys = (unsigned long long*)s_raw;
@@ -1546,6 +1547,7 @@ __global__ __launch_bounds__(DBR_THREADS) void k_dbin_rank(int N, int V, int ite
                                                                                                    //  the launch behind is only skipped well clear of it)
     if (n > (uint32_t)MGR_DB_RANK_MAX) {
         if (tid == 0) {
+            atomicAdd(&hdr->sort_huge, 1u);
             // the caller skipped the launch behind (debug bit 128: the previous forward met no such item): flagged like a skipped
             // binning tier -- the forward is run again with every launch
             if (no_launch_behind) atomicOr(&hdr->overflow, MGR_OVF_TIER);

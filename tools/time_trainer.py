@@ -27,16 +27,18 @@ tr.global_step = 1          # (step 0 and every 100th run the keypoint test of t
 for _ in range(10):
     tr.train_step()
 torch.cuda.synchronize()
-ts = []
+ts, issue = [], []
 for rep in range(3):
     t0 = time.perf_counter()
     for _ in range(steps):
         if tr.global_step % 100 == 0:
             tr.global_step += 1
         out = tr.train_step()
+    issue.append((time.perf_counter() - t0) / steps)      # (the host is done issuing; the rest is the device's backlog)
     torch.cuda.synchronize()
     ts.append((time.perf_counter() - t0) / steps)
 ms = sorted(ts)[1] * 1e3
+print("host issue time %.4f ms / step (median of 3)" % (sorted(issue)[1] * 1e3))
 from manus_amd import rasterizer
 ctx = rasterizer.context(dev)
 print("Trainer.train_step: %.4f ms / step = %.1f steps/s (median of 3 x %d steps; depth cut %s; re-run steps %d, flagged forwards %d, quadrants repaired on the device %d; loss %.6f)"
