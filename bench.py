@@ -416,7 +416,7 @@ def dropin_main(args):
         for k, (c, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
             print("%-22s %6d launches %9.3f ms avg %8.4f ms  %5.1f%%" % (k, c, ms, ms / c, 100 * ms / tot), file=sys.stderr)
         print("library kernels %.3f ms/step of %.3f ms/step wall (the rest: torch glue kernels -- cat, sigmoid, permute, the loss's "
-              "arithmetic, gradient accumulation -- and the host: ctypes calls + one blocking read of the pair count per forward)"
+              "arithmetic, gradient accumulation -- and the host: ctypes calls; the pair count is read back for the first forwards only)"
               % (lib_ms, 1e3 * dt / args.steps), file=sys.stderr)
     finite = all(bool(torch.isfinite(t.grad).all()) for t in P.values())
     dom = max(prof, key=lambda k_: prof[k_][1]) if prof else None
