@@ -779,16 +779,46 @@ __global__ __launch_bounds__(256) void k_inst_gather_runs(
     const bool kept_ok = kept && row_state && hdr->rows_seq != 0u && hdr->rows_seq + 1u == hdr->bwd_seq &&
                          hdr->rows_owner[0] == (uint32_t)owner && hdr->rows_owner[1] == (uint32_t)(owner >> 32);
     // ---- A: the instances with records -> work list; visibility statistics
+    // (the kernel is ONE round of workgroups -- 1172 of them at 300 k Gaussians -- so its time is a workgroup's chain of dependent
+    //  round trips: the four loads of all its rounds are issued together instead of a round trip per round)
+    int rd_r[G];
+    uint32_t tg_r[G], po_r[G];
+    ushort4 rc_r[G];
+#ifndef MGR_GATHER_PRELOAD
+#define MGR_GATHER_PRELOAD 1
+#endif
+#if MGR_GATHER_PRELOAD
+#pragma unroll
+    for (int rnd = 0; rnd < G; ++rnd) {
+        const int i = min(i_base + min(rnd, rounds - 1) * IPB + il, N - 1);
+        const size_t vi = (size_t)min(v_first + vl, v_first + v_count - 1) * N + i;
+        rd_r[rnd] = radii[vi];
+        tg_r[rnd] = inst_tag[vi];
+        rc_r[rnd] = rect[vi];
+        po_r[rnd] = pair_off[vi];
+    }
+#pragma unroll
+#else
 #pragma unroll 1
-    for (int rnd = 0; rnd < rounds; ++rnd) {
+#endif
+    for (int rnd = 0; rnd < G; ++rnd) {
+        if (rnd >= rounds) break;
         const int i_raw = i_base + rnd * IPB + il;
         const int i = min(i_raw, N - 1);
         const bool ok = i_raw < N, mine = ok && vl < v_count;
+#if MGR_GATHER_PRELOAD
+        const int rd = rd_r[rnd];
+        const uint32_t tg = tg_r[rnd];
+        const ushort4 rc = rc_r[rnd];
+        const uint32_t po = po_r[rnd];
+#else
         const size_t vi = (size_t)min(v_first + vl, v_first + v_count - 1) * N + i;
         const int rd = radii[vi];
         const uint32_t tg = inst_tag[vi];
         const ushort4 rc = rect[vi];
         const uint32_t po = pair_off[vi];
+        (void)rd_r; (void)tg_r; (void)rc_r; (void)po_r;
+#endif
         const int rad = mine ? rd : 0;
         const bool act = rad > 0 && tg == epoch;
         const float vis = grp_sum<G>(rad > 0 ? 1.0f : 0.0f);
