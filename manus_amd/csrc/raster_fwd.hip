@@ -475,16 +475,24 @@ __device__ __forceinline__ void dbin_count_block(int bx, int v, int N, const int
     __shared__ uint32_t s_zr[2];
     if (tid < 2) s_zr[tid] = 0u;
     for (int k = tid; k < MGR_DB_BUCKETS; k += 1024) s_hist[k] = 0;
-    __syncthreads();
-    const DbRange zr = db_range_reduce(db_zrange + 2 * (size_t)v * nslots, nslots, s_zr);
+    // (the instances' loads are issued in front of the range's barriers: one dependent round trip less)
+    float z[DB_PER];
+    uint32_t on = 0;
 #pragma unroll
     for (int r = 0; r < DB_PER; ++r) {
         const int i = (bx * DB_PER + r) * 1024 + tid;
+        z[r] = 0.f;
         if (i < N) {
             const size_t vi = (size_t)v * N + i;
-            if (db_takes_part(radii[vi], rect[vi], alive[vi])) atomicAdd(&s_hist[db_bucket(depth[vi], zr)], 1u);
+            z[r] = depth[vi];
+            if (db_takes_part(radii[vi], rect[vi], alive[vi])) on |= 1u << r;
         }
     }
+    __syncthreads();
+    const DbRange zr = db_range_reduce(db_zrange + 2 * (size_t)v * nslots, nslots, s_zr);
+#pragma unroll
+    for (int r = 0; r < DB_PER; ++r)
+        if ((on >> r) & 1u) atomicAdd(&s_hist[db_bucket(z[r], zr)], 1u);
     __syncthreads();
     for (int k = tid; k < MGR_DB_BUCKETS; k += 1024) {
         const uint32_t c = s_hist[k];
@@ -558,23 +566,23 @@ __device__ __forceinline__ void dbin_scatter_block(int bx, int v, int N, const i
     __shared__ uint32_t s_zr[2];
     if (tid < 2) s_zr[tid] = 0u;
     for (int k = tid; k < MGR_DB_BUCKETS; k += 1024) s_hist[k] = 0;
-    __syncthreads();
-    const DbRange zr = db_range_reduce(db_zrange + 2 * (size_t)v * nslots, nslots, s_zr);
     float z[DB_PER];
     uint32_t on = 0;
 #pragma unroll
-    for (int r = 0; r < DB_PER; ++r) {
+    for (int r = 0; r < DB_PER; ++r) {      // (in front of the range's barriers, like dbin_count_block)
         const int i = (bx * DB_PER + r) * 1024 + tid;
         z[r] = 0.f;
         if (i < N) {
             const size_t vi = (size_t)v * N + i;
             z[r] = depth[vi];
-            if (db_takes_part(radii[vi], rect[vi], alive[vi])) {
-                on |= 1u << r;
-                atomicAdd(&s_hist[db_bucket(z[r], zr)], 1u);
-            }
+            if (db_takes_part(radii[vi], rect[vi], alive[vi])) on |= 1u << r;
         }
     }
+    __syncthreads();
+    const DbRange zr = db_range_reduce(db_zrange + 2 * (size_t)v * nslots, nslots, s_zr);
+#pragma unroll
+    for (int r = 0; r < DB_PER; ++r)
+        if ((on >> r) & 1u) atomicAdd(&s_hist[db_bucket(z[r], zr)], 1u);
     __syncthreads();
     for (int k = tid; k < MGR_DB_BUCKETS; k += 1024) {
         const uint32_t c = s_hist[k];
@@ -722,6 +730,8 @@ __global__ __launch_bounds__(1024) void k_tile_scan_b(int V, int T, int nbT, uin
     }
     __syncthreads();
     // non-empty tiles per view (threads 128 ..: one view each, strided) -> the longest view sets the interleaved queue's length
+    // (staging phase A's block sums in LDS first -- every thread two or three words, the sums over LDS -- was measured in round 6:
+    //  0.018 -> 0.021 ms at eight views, 0.009 -> 0.016 at one: these loops are not the kernel's chain)
     for (int w = tid - 128; w >= 0 && w < V; w += 896) {
         uint32_t nb = 0;
         for (int j = w * nbT; j < (w + 1) * nbT; ++j)
