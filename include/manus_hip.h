@@ -355,6 +355,26 @@ int mgr_sh_color_bwd(int V, int N, const float* sh, const float* xyz, int64_t st
                      const float* dL_dcolors, float* dL_dsh, float* dL_dxyz, float* dL_dtf,
                      void* stream);
 
+/* The same four with the rows of tf / dL_dtf `tf_row_floats` apart: 12 (as above) or 16 = the reference's (N,4,4) layout
+ * (TrainingModule.forward returns the blended transforms as 4x4, src/modules/hand_dynamic.py:128-137, and render_gaussians
+ * takes them as such, src/utils/gaussian_utils.py:431-449): mgr_lbs_cov_fwd_rows then writes the constant last row
+ * (0,0,0,1) too, mgr_sh_color_bwd_rows writes zeros into the last row of dL_dtf, the readers skip it -- no torch.cat /
+ * slice copy between the two operators and none in their backward (round 6). */
+int mgr_lbs_cov_fwd_rows(int P, int N, int B, const float* xyz, const float* log_scale,
+                         const float* rot, const float* skin_w, const float* transforms,
+                         float* posed_xyz, float* posed_cov, float* tf, int tf_row_floats, void* stream);
+int mgr_lbs_cov_bwd_rows(int P, int N, int B, const float* xyz, const float* log_scale,
+                         const float* rot, const float* skin_w, const float* transforms,
+                         const float* dL_dposed_xyz, const float* dL_dposed_cov, const float* dL_dtf, int tf_row_floats,
+                         float* dL_dxyz, float* dL_dlog_scale, float* dL_drot, float* dL_dw, void* stream);
+int mgr_sh_color_fwd_rows(int V, int N, const float* sh, const float* xyz, int64_t stride_xyz,
+                          const float* tf, int64_t stride_tf, int tf_row_floats, const float* cams, float* colors,
+                          void* stream);
+int mgr_sh_color_bwd_rows(int V, int N, const float* sh, const float* xyz, int64_t stride_xyz,
+                          const float* tf, int64_t stride_tf, int tf_row_floats, const float* cams,
+                          const float* dL_dcolors, float* dL_dsh, float* dL_dxyz, float* dL_dtf,
+                          void* stream);
+
 /* Host glue of the reference-shaped route, one launch each (no reference kernel counterpart: the reference does both with
  * a dozen small torch ops per step).
  * mgr_pack_camera: the (MGR_CAM_FLOATS = 40)-float camera row every kernel here reads, from the fields of

@@ -58,6 +58,12 @@ SIGNATURES = {
     "mgr_lbs_cov_fwd": (c_int, [c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "mgr_lbs_cov_bwd": (c_int, [c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                 c_vp, c_vp, c_vp, c_vp]),
+    "mgr_lbs_cov_fwd_rows": (c_int, [c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp]),
+    "mgr_lbs_cov_bwd_rows": (c_int, [c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp,
+                                     c_vp, c_vp, c_vp, c_vp]),
+    "mgr_sh_color_fwd_rows": (c_int, [c_int, c_int, c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_vp, c_vp]),
+    "mgr_sh_color_bwd_rows": (c_int, [c_int, c_int, c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                      c_vp]),
     "mgr_sh_color_fwd": (c_int, [c_int, c_int, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "mgr_sh_color_bwd": (c_int, [c_int, c_int, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp,
                                  c_vp]),

@@ -296,7 +296,8 @@ __global__ __launch_bounds__(256) void k_lbs_fwd(int N, int B, const float* __re
                                                  const float* __restrict__ transforms,
                                                  float* __restrict__ posed_xyz,
                                                  float* __restrict__ posed_cov,
-                                                 float* __restrict__ tf_out) {
+                                                 float* __restrict__ tf_out, int tfr) {
+    // tfr: floats per row of tf_out -- 12 (rows 0..2 of the 4x4) or 16 (the reference's (N,4,4) layout: the constant last row is written too)
     const int i = blockIdx.x * 256 + threadIdx.x, p = blockIdx.y;
     if (i >= N) return;
     float tf[12];
@@ -311,8 +312,10 @@ __global__ __launch_bounds__(256) void k_lbs_fwd(int N, int B, const float* __re
 #pragma unroll
     for (int k = 0; k < 6; ++k) posed_cov[pi * 6 + k] = cov6[k];
     if (tf_out) {
+        float* to = tf_out + pi * (size_t)tfr;
 #pragma unroll
-        for (int k = 0; k < 12; ++k) tf_out[pi * 12 + k] = tf[k];
+        for (int k = 0; k < 12; ++k) to[k] = tf[k];
+        if (tfr == 16) { to[12] = 0.f; to[13] = 0.f; to[14] = 0.f; to[15] = 1.f; }
     }
 }
 
@@ -327,7 +330,7 @@ __global__ __launch_bounds__(256) void k_lbs_bwd(int P, int N, int B, const floa
                                                  float* __restrict__ dL_dxyz,
                                                  float* __restrict__ dL_dls,
                                                  float* __restrict__ dL_drot,
-                                                 float* __restrict__ dL_dw) {
+                                                 float* __restrict__ dL_dw, int tfr) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
     GaussCano g;
@@ -348,7 +351,7 @@ __global__ __launch_bounds__(256) void k_lbs_bwd(int P, int N, int B, const floa
                              g_cov[pi * 6 + 3], g_cov[pi * 6 + 4], g_cov[pi * 6 + 5]};
         float gt[12];
 #pragma unroll
-        for (int k = 0; k < 12; ++k) gt[k] = g_tf ? g_tf[pi * 12 + k] : 0.f;
+        for (int k = 0; k < 12; ++k) gt[k] = g_tf ? g_tf[pi * (size_t)tfr + k] : 0.f;
         lbs_backward_view<true>(tf, g, gp, g6, gt, dxyz, ds, dR, dtf);
         if (skin_w) {
 #pragma unroll
@@ -383,7 +386,7 @@ __global__ __launch_bounds__(256) void k_sh_fwd(int N, const float* __restrict__
                                                 const float* __restrict__ xyz, int64_t s_xyz,
                                                 const float* __restrict__ tf, int64_t s_tf,
                                                 const float* __restrict__ cams,
-                                                float* __restrict__ colors) {
+                                                float* __restrict__ colors, int tfr) {
     const int i = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y;
     if (i >= N) return;
     const float* cp = cams + (size_t)v * MGR_CAM_FLOATS + 34;
@@ -393,7 +396,7 @@ __global__ __launch_bounds__(256) void k_sh_fwd(int N, const float* __restrict__
     float t12[12];
     if (tf) {
 #pragma unroll
-        for (int k = 0; k < 12; ++k) t12[k] = tf[(size_t)v * s_tf + (size_t)i * 12 + k];
+        for (int k = 0; k < 12; ++k) t12[k] = tf[(size_t)v * s_tf + (size_t)i * tfr + k];
         sh_dir_xyz<true>(xv[3 * i], xv[3 * i + 1], xv[3 * i + 2], t12, cam, D);
     } else {
         sh_dir_xyz<false>(xv[3 * i], xv[3 * i + 1], xv[3 * i + 2], t12, cam, D);
@@ -416,7 +419,7 @@ __global__ __launch_bounds__(256, 2) void k_sh_bwd(int V, int N, const float* __
                                                 const float* __restrict__ g_col,
                                                 float* __restrict__ dL_dsh,
                                                 float* __restrict__ dL_dxyz,
-                                                float* __restrict__ dL_dtf) {
+                                                float* __restrict__ dL_dtf, int tfr) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
     float c[48], dsh[48];
@@ -434,7 +437,7 @@ __global__ __launch_bounds__(256, 2) void k_sh_bwd(int V, int N, const float* __
         float t12[12];
         if (has_tf) {
 #pragma unroll
-            for (int k = 0; k < 12; ++k) t12[k] = tf[(size_t)v * s_tf + (size_t)i * 12 + k];
+            for (int k = 0; k < 12; ++k) t12[k] = tf[(size_t)v * s_tf + (size_t)i * tfr + k];
             sh_dir_xyz<true>(xv[3 * i], xv[3 * i + 1], xv[3 * i + 2], t12, cam, D);
         } else {
             sh_dir_xyz<false>(xv[3 * i], xv[3 * i + 1], xv[3 * i + 2], t12, cam, D);
@@ -446,9 +449,10 @@ __global__ __launch_bounds__(256, 2) void k_sh_bwd(int V, int N, const float* __
         float* ox = dL_dxyz + ((size_t)v * N + i) * 3;
         ox[0] = gd[0]; ox[1] = gd[1]; ox[2] = gd[2];
         if (has_tf && dL_dtf) {
-            float* ot = dL_dtf + ((size_t)v * N + i) * 12;
+            float* ot = dL_dtf + ((size_t)v * N + i) * (size_t)tfr;
 #pragma unroll
             for (int k = 0; k < 12; ++k) ot[k] = dtf[k];
+            if (tfr == 16) { ot[12] = 0.f; ot[13] = 0.f; ot[14] = 0.f; ot[15] = 0.f; }      // (the constant row has no gradient)
         }
     }
 #pragma unroll
@@ -658,27 +662,34 @@ extern "C" int mgr_skin_weights_bwd_indexed(int N, const float* xyz, const float
                                  max_count, stream_);
 }
 
-extern "C" int mgr_lbs_cov_fwd(int P, int N, int B, const float* xyz, const float* log_scale,
-                               const float* rot, const float* skin_w, const float* transforms,
-                               float* posed_xyz, float* posed_cov, float* tf, void* stream_) {
-    if (P <= 0 || N < 0 || (skin_w && (B <= 0 || B > MGR_MAX_BONES)))
+static bool tf_rows_ok(int tfr) { return tfr == 12 || tfr == 16; }
+
+extern "C" int mgr_lbs_cov_fwd_rows(int P, int N, int B, const float* xyz, const float* log_scale,
+                                    const float* rot, const float* skin_w, const float* transforms,
+                                    float* posed_xyz, float* posed_cov, float* tf, int tf_row_floats, void* stream_) {
+    if (P <= 0 || N < 0 || (skin_w && (B <= 0 || B > MGR_MAX_BONES)) || !tf_rows_ok(tf_row_floats))
         return mgr_fail(MGR_EINVAL, "mgr_lbs_cov_fwd: bad sizes");
     if (N == 0) return MGR_OK;
     if (!xyz || !log_scale || !rot || !posed_xyz || !posed_cov || (skin_w && !transforms))
         return mgr_fail(MGR_EINVAL, "mgr_lbs_cov_fwd: null pointer");
     hipStream_t stream = (hipStream_t)stream_;
     { MGR_PROF("k_lbs_fwd", stream); hipLaunchKernelGGL(k_lbs_fwd, dim3((N + 255) / 256, P), dim3(256), 0, stream, N, B, xyz, log_scale, rot,
-                       skin_w, transforms, posed_xyz, posed_cov, tf); }
+                       skin_w, transforms, posed_xyz, posed_cov, tf, tf_row_floats); }
     MGR_LAUNCH_CHECK("k_lbs_fwd", stream, 0);
     return MGR_OK;
 }
-
-extern "C" int mgr_lbs_cov_bwd(int P, int N, int B, const float* xyz, const float* log_scale,
+extern "C" int mgr_lbs_cov_fwd(int P, int N, int B, const float* xyz, const float* log_scale,
                                const float* rot, const float* skin_w, const float* transforms,
-                               const float* dL_dposed_xyz, const float* dL_dposed_cov,
-                               const float* dL_dtf, float* dL_dxyz, float* dL_dlog_scale,
-                               float* dL_drot, float* dL_dw, void* stream_) {
-    if (P <= 0 || N < 0 || (skin_w && (B <= 0 || B > MGR_MAX_BONES)))
+                               float* posed_xyz, float* posed_cov, float* tf, void* stream_) {
+    return mgr_lbs_cov_fwd_rows(P, N, B, xyz, log_scale, rot, skin_w, transforms, posed_xyz, posed_cov, tf, 12, stream_);
+}
+
+extern "C" int mgr_lbs_cov_bwd_rows(int P, int N, int B, const float* xyz, const float* log_scale,
+                                    const float* rot, const float* skin_w, const float* transforms,
+                                    const float* dL_dposed_xyz, const float* dL_dposed_cov,
+                                    const float* dL_dtf, int tf_row_floats, float* dL_dxyz, float* dL_dlog_scale,
+                                    float* dL_drot, float* dL_dw, void* stream_) {
+    if (P <= 0 || N < 0 || (skin_w && (B <= 0 || B > MGR_MAX_BONES)) || !tf_rows_ok(tf_row_floats))
         return mgr_fail(MGR_EINVAL, "mgr_lbs_cov_bwd: bad sizes");
     if (N == 0) return MGR_OK;
     if (!xyz || !log_scale || !rot || !dL_dposed_xyz || !dL_dposed_cov || !dL_dxyz || !dL_dlog_scale ||
@@ -687,37 +698,56 @@ extern "C" int mgr_lbs_cov_bwd(int P, int N, int B, const float* xyz, const floa
     hipStream_t stream = (hipStream_t)stream_;
     { MGR_PROF("k_lbs_bwd", stream); hipLaunchKernelGGL(k_lbs_bwd, dim3((N + 255) / 256), dim3(256), 0, stream, P, N, B, xyz, log_scale, rot,
                        skin_w, transforms, dL_dposed_xyz, dL_dposed_cov, dL_dtf, dL_dxyz, dL_dlog_scale,
-                       dL_drot, dL_dw); }
+                       dL_drot, dL_dw, tf_row_floats); }
     MGR_LAUNCH_CHECK("k_lbs_bwd", stream, 0);
     return MGR_OK;
 }
+extern "C" int mgr_lbs_cov_bwd(int P, int N, int B, const float* xyz, const float* log_scale,
+                               const float* rot, const float* skin_w, const float* transforms,
+                               const float* dL_dposed_xyz, const float* dL_dposed_cov,
+                               const float* dL_dtf, float* dL_dxyz, float* dL_dlog_scale,
+                               float* dL_drot, float* dL_dw, void* stream_) {
+    return mgr_lbs_cov_bwd_rows(P, N, B, xyz, log_scale, rot, skin_w, transforms, dL_dposed_xyz, dL_dposed_cov, dL_dtf, 12, dL_dxyz,
+                                dL_dlog_scale, dL_drot, dL_dw, stream_);
+}
 
-extern "C" int mgr_sh_color_fwd(int V, int N, const float* sh, const float* xyz, int64_t stride_xyz,
-                                const float* tf, int64_t stride_tf, const float* cams, float* colors,
-                                void* stream_) {
-    if (V <= 0 || N < 0) return mgr_fail(MGR_EINVAL, "mgr_sh_color_fwd: bad sizes");
+extern "C" int mgr_sh_color_fwd_rows(int V, int N, const float* sh, const float* xyz, int64_t stride_xyz,
+                                     const float* tf, int64_t stride_tf, int tf_row_floats, const float* cams, float* colors,
+                                     void* stream_) {
+    if (V <= 0 || N < 0 || !tf_rows_ok(tf_row_floats)) return mgr_fail(MGR_EINVAL, "mgr_sh_color_fwd: bad sizes");
     if (N == 0) return MGR_OK;
     if (!sh || !xyz || !cams || !colors) return mgr_fail(MGR_EINVAL, "mgr_sh_color_fwd: null pointer");
     hipStream_t stream = (hipStream_t)stream_;
     { MGR_PROF("k_sh_fwd", stream); hipLaunchKernelGGL(k_sh_fwd, dim3((N + 255) / 256, V), dim3(256), 0, stream, N, sh, xyz, stride_xyz, tf,
-                       stride_tf, cams, colors); }
+                       stride_tf, cams, colors, tf_row_floats); }
     MGR_LAUNCH_CHECK("k_sh_fwd", stream, 0);
     return MGR_OK;
 }
-
-extern "C" int mgr_sh_color_bwd(int V, int N, const float* sh, const float* xyz, int64_t stride_xyz,
-                                const float* tf, int64_t stride_tf, const float* cams,
-                                const float* dL_dcolors, float* dL_dsh, float* dL_dxyz, float* dL_dtf,
+extern "C" int mgr_sh_color_fwd(int V, int N, const float* sh, const float* xyz, int64_t stride_xyz,
+                                const float* tf, int64_t stride_tf, const float* cams, float* colors,
                                 void* stream_) {
-    if (V <= 0 || N < 0) return mgr_fail(MGR_EINVAL, "mgr_sh_color_bwd: bad sizes");
+    return mgr_sh_color_fwd_rows(V, N, sh, xyz, stride_xyz, tf, stride_tf, 12, cams, colors, stream_);
+}
+
+extern "C" int mgr_sh_color_bwd_rows(int V, int N, const float* sh, const float* xyz, int64_t stride_xyz,
+                                     const float* tf, int64_t stride_tf, int tf_row_floats, const float* cams,
+                                     const float* dL_dcolors, float* dL_dsh, float* dL_dxyz, float* dL_dtf,
+                                     void* stream_) {
+    if (V <= 0 || N < 0 || !tf_rows_ok(tf_row_floats)) return mgr_fail(MGR_EINVAL, "mgr_sh_color_bwd: bad sizes");
     if (N == 0) return MGR_OK;
     if (!sh || !xyz || !cams || !dL_dcolors || !dL_dsh || !dL_dxyz || (tf && !dL_dtf))
         return mgr_fail(MGR_EINVAL, "mgr_sh_color_bwd: null pointer");
     hipStream_t stream = (hipStream_t)stream_;
     { MGR_PROF("k_sh_bwd", stream); hipLaunchKernelGGL(k_sh_bwd, dim3((N + 255) / 256), dim3(256), 0, stream, V, N, sh, xyz, stride_xyz, tf,
-                       stride_tf, cams, dL_dcolors, dL_dsh, dL_dxyz, dL_dtf); }
+                       stride_tf, cams, dL_dcolors, dL_dsh, dL_dxyz, dL_dtf, tf_row_floats); }
     MGR_LAUNCH_CHECK("k_sh_bwd", stream, 0);
     return MGR_OK;
+}
+extern "C" int mgr_sh_color_bwd(int V, int N, const float* sh, const float* xyz, int64_t stride_xyz,
+                                const float* tf, int64_t stride_tf, const float* cams,
+                                const float* dL_dcolors, float* dL_dsh, float* dL_dxyz, float* dL_dtf,
+                                void* stream_) {
+    return mgr_sh_color_bwd_rows(V, N, sh, xyz, stride_xyz, tf, stride_tf, 12, cams, dL_dcolors, dL_dsh, dL_dxyz, dL_dtf, stream_);
 }
 
 // ---------------------------------------------------------------------------

@@ -20,21 +20,6 @@ class Pred(dict):
     __setattr__ = dict.__setitem__
 
 
-_LAST_ROW = {}
-
-
-def _tf44(tf12):
-    """(N,12) rows 0..2 -> the reference's (N,4,4) layout."""
-    N = tf12.shape[0]
-    key = (tf12.device, tf12.dtype)
-    last = _LAST_ROW.get(key)
-    if last is None:
-        # built once per device: a host-to-device copy from pageable memory is ordered behind everything queued on the stream and
-        # the host waits for it -- one per step was a host synchronisation per step (bench.py --route dropin: 1.25 -> ... ms)
-        last = _LAST_ROW[key] = torch.tensor([0.0, 0.0, 0.0, 1.0], dtype=tf12.dtype, device=tf12.device)
-    return torch.cat([tf12.reshape(N, 3, 4), last.expand(N, 1, 4)], dim=1)
-
-
 def device_grid(model):
     """The reference re-uploads the (D,H,W,21) grid on every call
     (gaussian_utils.py:169); here it is uploaded once and cached on the model."""
@@ -56,9 +41,11 @@ def hand_forward(model, batch, background_transform=True, full_tf=True):
     w = skin_weights(cano_xyz, device_grid(model),
                      torch.as_tensor(model.grid_center).to(dev), torch.as_tensor(model.grid_scale).to(dev))
     assert w.shape[-1] == T.shape[0]  # hand_dynamic.py:104
-    pxyz, pcov, tf = lbs_cov(cano_xyz, model._scaling, model._rotation, w, T)
+    # full_tf: the reference's (N,4,4) -- written in that layout by the LBS kernel and read in place by the SH operator
+    # (render.calculate_colors_from_sh): no cat of the constant row, no slice copy, nothing in between in the backward either
+    pxyz, pcov, tf = lbs_cov(cano_xyz, model._scaling, model._rotation, w, T, tf44=full_tf)
     return Pred(posed_xyz=pxyz[0], posed_cov=pcov[0], cano_xyz=cano_xyz, cano_features=model.get_features,
-                cano_opacity=model.get_opacity, tf=_tf44(tf[0]) if full_tf else tf[0], skin_wts=w)
+                cano_opacity=model.get_opacity, tf=tf[0], skin_wts=w)
 
 
 def object_forward(model, batch=None):

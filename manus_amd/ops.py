@@ -77,7 +77,7 @@ def skin_weights(xyz, grid_weights, grid_center, grid_scale):
 
 class _LbsCov(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, xyz, log_scale, rot, skin_w, transforms):
+    def forward(ctx, xyz, log_scale, rot, skin_w, transforms, tf44=False):
         xyz, log_scale, rot = f32c(xyz), f32c(log_scale), f32c(rot)
         N = xyz.shape[0]
         if skin_w is not None:
@@ -94,17 +94,18 @@ class _LbsCov(torch.autograd.Function):
         dev = xyz.device
         pxyz = torch.empty((P, N, 3), dtype=torch.float32, device=dev)
         pcov = torch.empty((P, N, 6), dtype=torch.float32, device=dev)
-        tf = torch.empty((P, N, 12), dtype=torch.float32, device=dev)
-        check(lib().mgr_lbs_cov_fwd(P, N, B, ptr(xyz), ptr(log_scale), ptr(rot), ptr(skin_w), ptr(transforms),
-                                    ptr(pxyz), ptr(pcov), ptr(tf), stream()), "mgr_lbs_cov_fwd")
+        rows = 16 if tf44 else 12     # (4x4 rows: the reference's (N,4,4) layout written by the kernel, no cat of the constant row)
+        tf = torch.empty((P, N, 4, 4) if tf44 else (P, N, 12), dtype=torch.float32, device=dev)
+        check(lib().mgr_lbs_cov_fwd_rows(P, N, B, ptr(xyz), ptr(log_scale), ptr(rot), ptr(skin_w), ptr(transforms),
+                                         ptr(pxyz), ptr(pcov), ptr(tf), rows, stream()), "mgr_lbs_cov_fwd")
         ctx.save_for_backward(xyz, log_scale, rot, skin_w, transforms)
-        ctx.meta = (P, N, B)
+        ctx.meta = (P, N, B, rows)
         return pxyz, pcov, tf
 
     @staticmethod
     def backward(ctx, g_xyz, g_cov, g_tf):
         xyz, log_scale, rot, skin_w, transforms = ctx.saved_tensors
-        P, N, B = ctx.meta
+        P, N, B, rows = ctx.meta
         dev = xyz.device
         g_xyz = f32c(g_xyz) if g_xyz is not None else torch.zeros((P, N, 3), dtype=torch.float32, device=dev)
         g_cov = f32c(g_cov) if g_cov is not None else torch.zeros((P, N, 6), dtype=torch.float32, device=dev)
@@ -113,21 +114,21 @@ class _LbsCov(torch.autograd.Function):
         d_ls = torch.empty((N, 3), dtype=torch.float32, device=dev)
         d_rot = torch.empty((N, 4), dtype=torch.float32, device=dev)
         d_w = torch.empty((N, B), dtype=torch.float32, device=dev) if skin_w is not None else None
-        check(lib().mgr_lbs_cov_bwd(P, N, B, ptr(xyz), ptr(log_scale), ptr(rot), ptr(skin_w), ptr(transforms),
-                                    ptr(g_xyz), ptr(g_cov), ptr(g_tf), ptr(d_xyz), ptr(d_ls), ptr(d_rot),
-                                    ptr(d_w), stream()), "mgr_lbs_cov_bwd")
-        return d_xyz, d_ls, d_rot, d_w, None
+        check(lib().mgr_lbs_cov_bwd_rows(P, N, B, ptr(xyz), ptr(log_scale), ptr(rot), ptr(skin_w), ptr(transforms),
+                                         ptr(g_xyz), ptr(g_cov), ptr(g_tf), rows, ptr(d_xyz), ptr(d_ls), ptr(d_rot),
+                                         ptr(d_w), stream()), "mgr_lbs_cov_bwd")
+        return d_xyz, d_ls, d_rot, d_w, None, None
 
 
-def lbs_cov(xyz, log_scale, rot, skin_w, transforms):
+def lbs_cov(xyz, log_scale, rot, skin_w, transforms, tf44=False):
     """Skin means and covariances for P poses.
 
     xyz (N,3), log_scale (N,3) (`_scaling`), rot (N,4) raw (`_rotation`),
     skin_w (N,B) or None (static object: identity transform),
     transforms (P,B,4,4) / (B,4,4) = posed @ inv(rest) (+ identity background).
     Returns posed_xyz (P,N,3), posed_cov (P,N,6), tf (P,N,12) (rows 0..2 of the
-    blended 4x4)."""
-    return _LbsCov.apply(xyz, log_scale, rot, skin_w, transforms)
+    blended 4x4) -- or, with tf44, (P,N,4,4): the reference's layout, constant last row included, written by the kernel."""
+    return _LbsCov.apply(xyz, log_scale, rot, skin_w, transforms, bool(tf44))
 
 
 class _ShColors(torch.autograd.Function):
@@ -139,32 +140,36 @@ class _ShColors(torch.autograd.Function):
         if sh.shape[1:] != (16, 3):
             raise ManusHipError("sh_colors: features must be (N,16,3) (sh_degree 3)")
         s_xyz = xyz.stride(0) if xyz.dim() == 3 else 0
-        s_tf = 0
+        s_tf, rows, tf_per_view = 0, 12, False
         if tf is not None:
             tf = f32c(tf)
-            s_tf = tf.stride(0) if tf.dim() == 3 else 0
+            if tf.dim() >= 3 and tuple(tf.shape[-2:]) == (4, 4):      # (N,4,4) / (V,N,4,4): the reference's layout, read in place
+                rows, tf_per_view = 16, tf.dim() == 4
+            else:                                                     # (N,12) / (V,N,12)
+                tf_per_view = tf.dim() == 3
+            s_tf = tf.stride(0) if tf_per_view else 0
         col = torch.empty((V, N, 3), dtype=torch.float32, device=sh.device)
-        check(lib().mgr_sh_color_fwd(V, N, ptr(sh), ptr(xyz), s_xyz, ptr(tf), s_tf, ptr(cams), ptr(col),
-                                     stream()), "mgr_sh_color_fwd")
+        check(lib().mgr_sh_color_fwd_rows(V, N, ptr(sh), ptr(xyz), s_xyz, ptr(tf), s_tf, rows, ptr(cams), ptr(col),
+                                          stream()), "mgr_sh_color_fwd")
         ctx.save_for_backward(sh, xyz, tf, cams)
-        ctx.meta = (V, N, s_xyz, s_tf)
+        ctx.meta = (V, N, s_xyz, s_tf, rows, tf_per_view)
         return col
 
     @staticmethod
     def backward(ctx, g_col):
         sh, xyz, tf, cams = ctx.saved_tensors
-        V, N, s_xyz, s_tf = ctx.meta
+        V, N, s_xyz, s_tf, rows, tf_per_view = ctx.meta
         dev = sh.device
         g_col = f32c(g_col)
         d_sh = torch.empty((N, 16, 3), dtype=torch.float32, device=dev)
         d_xyz = torch.empty((V, N, 3), dtype=torch.float32, device=dev)
-        d_tf = torch.empty((V, N, 12), dtype=torch.float32, device=dev) if tf is not None else None
-        check(lib().mgr_sh_color_bwd(V, N, ptr(sh), ptr(xyz), s_xyz, ptr(tf), s_tf, ptr(cams), ptr(g_col),
-                                     ptr(d_sh), ptr(d_xyz), ptr(d_tf), stream()), "mgr_sh_color_bwd")
+        d_tf = torch.empty((V, N, 4, 4) if rows == 16 else (V, N, 12), dtype=torch.float32, device=dev) if tf is not None else None
+        check(lib().mgr_sh_color_bwd_rows(V, N, ptr(sh), ptr(xyz), s_xyz, ptr(tf), s_tf, rows, ptr(cams), ptr(g_col),
+                                          ptr(d_sh), ptr(d_xyz), ptr(d_tf), stream()), "mgr_sh_color_bwd")
         g_xyz = d_xyz if xyz.dim() == 3 else (d_xyz.sum(0) if V > 1 else d_xyz[0])
         g_tf = None
         if tf is not None:
-            g_tf = d_tf if tf.dim() == 3 else (d_tf.sum(0) if V > 1 else d_tf[0])
+            g_tf = d_tf if tf_per_view else (d_tf.sum(0) if V > 1 else d_tf[0])
         return d_sh, g_xyz, g_tf, None
 
 

@@ -10,11 +10,11 @@ from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 
 
 def _tf12(tf):
-    """(N,4,4) reference layout or (N,12) -> contiguous (N,12) rows 0..2."""
+    """(N,4,4) reference layout (passed on as it is: the SH operator reads its rows 0..2 in place) or (N,12)."""
     if tf is None:
         return None
-    if tf.dim() == 3 and tf.shape[-2:] == (4, 4):
-        return tf[:, :3, :].reshape(tf.shape[0], 12)
+    if tf.dim() == 3 and tuple(tf.shape[-2:]) == (4, 4):
+        return tf
     return tf.reshape(tf.shape[0], 12)
 
 

@@ -52,6 +52,42 @@ def test_hand_chain_vs_reference_golden(fn):
         assert e < 1e-4, (k, e)
 
 
+@pytest.mark.parametrize("fn", sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "lbs_sh_hand_*.npz")))[:2])
+def test_hand_chain_with_4x4_transform_rows_equals_the_12_float_rows(fn):
+    """`lbs_cov(..., tf44=True)` returns the reference's (N,4,4) transforms written by the kernel (constant last row included)
+    and `sh_colors` reads them in place: same outputs and the same leaf gradients, bit for bit, as the (N,12) rows -- and the 4x4
+    equals the reference's golden transform, last row included."""
+    from manus_amd import ops
+    from manus_amd.transforms import bone_transforms
+    d = np.load(fn)
+    res = []
+    for tf44 in (False, True):
+        p = {k: torch.tensor(d[v], device=DEV, requires_grad=True) for k, v in NAMES.items()}
+        w = ops.skin_weights(p["_xyz"], torch.tensor(d["grid"], device=DEV), torch.tensor(d["grid_center"], device=DEV),
+                             torch.tensor(d["grid_scale"], device=DEV))
+        T = bone_transforms(torch.tensor(d["posed"], device=DEV), torch.tensor(d["rest"], device=DEV))
+        pxyz, pcov, tf = ops.lbs_cov(p["_xyz"], p["_scaling"], p["_rotation"], w, T, tf44=tf44)
+        cams = torch.zeros((1, 40), device=DEV)
+        cams[0, 34:37] = torch.tensor(d["cam_center"], device=DEV).reshape(-1)
+        col = ops.sh_colors(torch.cat([p["_features_dc"], p["_features_rest"]], 1), p["_xyz"], tf[0], cams)
+        # a loss that also reads the transforms directly (their gradient then has two sources: the SH operator and this term)
+        r4 = torch.linspace(-1.0, 1.0, 12, device=DEV).reshape(3, 4)
+        tf_rows = tf[0][:, :3, :] if tf44 else tf[0].reshape(-1, 3, 4)
+        loss = ((pxyz[0] * torch.tensor(d["r1"], device=DEV)).sum() + (pcov[0] * torch.tensor(d["r2"], device=DEV)).sum()
+                + (col[0] * torch.tensor(d["r3"], device=DEV)).sum() + (tf_rows * r4).sum())
+        loss.backward()
+        res.append((pxyz.detach(), pcov.detach(), tf.detach(), col.detach(), {k: v.grad.clone() for k, v in p.items() if v.grad is not None}))
+    a, b = res
+    assert b[2].shape[-2:] == (4, 4)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[3], b[3])
+    assert torch.equal(a[2][0].reshape(-1, 3, 4), b[2][0][:, :3, :])
+    assert torch.equal(b[2][0][:, 3, :], torch.tensor([0.0, 0.0, 0.0, 1.0], device=DEV).expand(b[2].shape[1], 4))
+    assert max_rel_err(b[2][0].cpu().numpy(), d["tf"]) < 2e-5
+    assert set(a[4]) == set(b[4]) and {"_xyz", "_scaling", "_rotation", "_features_dc", "_features_rest"} <= set(a[4])
+    for k in a[4]:
+        assert torch.equal(a[4][k], b[4][k]), k
+
+
 def test_object_chain_vs_reference_golden(golden_dir):
     from manus_amd import ops
     d = np.load(os.path.join(golden_dir, "lbs_sh_object_s3_n64.npz"))
