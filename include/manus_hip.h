@@ -146,12 +146,13 @@ size_t mgr_raster_workspace_bytes(int V, int N, int W, int H, int64_t pair_capac
  * mgr_raster_status_tiers_sync reports which of them a forward needed (bit 0 / bit 1); pass the bits for the tiers the
  * previous forward did not need.  A view that needs a skipped launch raises the overflow word's bit 2 (MGR_ETIER).
  * 128 = skip the launch behind the instance sort.  Since round 6 the (depth, index) keys of a view are sorted in items of
- * ~768 keys, one workgroup each (k_dbin_rank: depth buckets uniform over the depth range the view's visible instances had in
- * the previous forward on this workspace); an item of more than 2048 keys -- a dense depth slice, or a first forward that has
- * no range yet -- is left to a radix launch behind, which returns at once when there is none.  Bit 128 omits that launch
- * (mgr_raster_status_tiers_sync reported no such item for the previous forward); an item that needs it then raises the
- * overflow word's bit 2 (MGR_ETIER: run the forward again without the bit), like a skipped tile-box tier.  256 is accepted
- * and ignored (up to round 5: the full-size sort launch alone). */
+ * ~768 keys, one workgroup each (k_dbin_rank: depth buckets uniform over the depth range of the view's visible instances in
+ * this forward); an item of more than 2048 keys -- a dense depth slice -- is left to a radix launch behind, which returns at
+ * once when there is none.  Bit 128 omits that launch (mgr_raster_status_tiers_sync reported no item near the limit for the
+ * previous forward: bits 8..23 of its tiers word); an item that needs it then raises the overflow word's bit 2 (MGR_ETIER:
+ * run the forward again without the bit), like a skipped tile-box tier.  256 = k_dbin_rank's instantiation for items of up
+ * to 3072 keys (the previous forward met items of more than 2048: bits 24..30 of the tiers word) -- ~4 us slower for all its
+ * items, but the dense slice no longer waits for the launch behind (33 us). */
 int mgr_raster_forward(int V, int N, int W, int H, const float* cams, const float* bg,
                        const float* means3D, int64_t stride_means3D, const float* cov3D,
                        int64_t stride_cov3D, const float* colors, int64_t stride_colors,

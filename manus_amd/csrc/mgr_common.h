@@ -132,8 +132,10 @@ struct MgrHeader {            // first 256 bytes of the workspace
     uint32_t rep_why;         // why the forward in flight raised MGR_OVF_CUT (bits MGR_WHY_*; k_tile_scan_a clears it)
     MgrRep rep;               // the repair's pointers / capacities of the forward in flight (k_tile_scan_b copies its argument here: the
                               // forward blend reads them in its rare "list ran out" branch instead of carrying 17 more scalars)
-    uint32_t sort_huge;       // items of the instance sort beyond MGR_DB_RANK_MAX keys (k_dbin_rank counts; the launch behind it returns at once on 0)
-    uint32_t spare[47 - sizeof(MgrRep) / 4];
+    uint32_t sort_huge;       // items of the instance sort beyond the LDS of the k_dbin_rank launch (it counts; the launch behind it returns at once on 0)
+    uint32_t sort_large;      // items beyond MGR_DB_RANK_MAX keys, whatever the launch's LDS (bits 24.. of the reported tiers word: the caller asks
+                              // the next forward for the large LDS, debug bit 256)
+    uint32_t spare[46 - sizeof(MgrRep) / 4];
     uint32_t queue_giant;     // queue index of the first tile with fewer than 16384 pairs
     uint32_t n_groups;        // depth groups produced by k_tile_split for the giant tiles
     uint32_t split_head, group_head;
@@ -213,8 +215,11 @@ struct MgrLayout {
                               // buckets 1.324 against 1.315 -- not adopted.
 #endif
 #define MGR_DB_ITEM 768       // keys per item of the instance sort (whole buckets: an item ends with the bucket it is in)
-#define MGR_DB_RANK_MAX 2048  // items of at most this many keys are sorted by k_dbin_rank (16 + 8 KB of LDS: six workgroups per CU), larger ones by the
-                              // launch behind it.  (3584 keys -- four workgroups per CU -- cost k_dbin_rank 15 us at eight views, measured.)
+#define MGR_DB_RANK_MAX 2048  // items of at most this many keys are sorted by k_dbin_rank (16 + 8 KB of LDS), larger ones by the launch behind it --
+                              // 33 us on the critical path -- unless the caller asked for the instantiation for MGR_DB_RANK_LARGE keys (debug bit
+                              // 256: the previous forward met such items), which costs k_dbin_rank ~4 us (six keys per thread compiled in) and
+                              // spares the launch behind.  (3584: eight keys per thread, +15 us.)
+#define MGR_DB_RANK_LARGE 3072
 #ifndef MGR_BIN_BLOCK
 #define MGR_BIN_BLOCK 1024
 #endif

@@ -645,7 +645,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan_a(int T, int nbT, const uint
     __shared__ uint32_t s_bb[4];
     const int tid = threadIdx.x, v = blockIdx.x / nbT, t = (blockIdx.x % nbT) * 1024 + tid;
     if (tid == 0) { s_bb[0] = 0xFFFFu; s_bb[1] = 0xFFFFu; s_bb[2] = 0u; s_bb[3] = 0u; }
-    if (blockIdx.x == 0 && tid == 0) { hdr->tiers = 0u; hdr->sort_big = 0u; hdr->sort_huge = 0u; hdr->fwd_seq += 1u; hdr->rep_why = 0u; }   // (phase B's depth-bucket workgroups / the sort set them)
+    if (blockIdx.x == 0 && tid == 0) { hdr->tiers = 0u; hdr->sort_big = 0u; hdr->sort_huge = 0u; hdr->sort_large = 0u; hdr->fwd_seq += 1u; hdr->rep_why = 0u; }   // (phase B's depth-bucket workgroups / the sort set them)
     const bool valid = t < T;
     const size_t k = (size_t)v * T + t;
     if (tid < MGR_NCLS) s_cls[tid] = 0;
@@ -1535,15 +1535,19 @@ __global__ __launch_bounds__(RS_THREADS) __attribute__((amdgpu_waves_per_eu(DBS_
 // its item -- 0.15 ms, the 64-bit compares run at a quarter of the rate; items of 256 keys through a bitonic network in LDS
 // 0.063 ms, throughput-bound at n log^2 n; one view: 0.029 against the radix items' 0.045.)
 #define DBR_THREADS RS_THREADS
+// CAP (keys of LDS) is a template argument, not a launch parameter: the sort below is compiled for item sizes up to CAP only --
+// with a run-time bound its 8 / 16-keys-per-thread cases stay alive and the kernel takes 0.100 instead of 0.042 ms (registers).
+template <int CAP>
 __global__ __launch_bounds__(DBR_THREADS) void k_dbin_rank(int N, int V, int items_per_view, const uint32_t* __restrict__ db_start,
                                                            const uint32_t* __restrict__ db_item, const unsigned long long* __restrict__ db_keys,
-                                                           uint32_t* __restrict__ db_order, MgrHeader* hdr, uint32_t* __restrict__ db_zrange,
+                                                           uint32_t* __restrict__ db_order, MgrHeader* hdr,
                                                            int no_launch_behind, BgFill fill, int n_sort_blocks) {
+    constexpr uint32_t cap_keys = (uint32_t)CAP;
     if ((int)blockIdx.x >= n_sort_blocks) {   // (the launch's extra workgroups: see BgFill)
         bg_fill_block(fill, hdr, (int)blockIdx.x - n_sort_blocks, (int)gridDim.x - n_sort_blocks);
         return;
     }
-    __shared__ __attribute__((aligned(16))) unsigned long long s_keys[MGR_DB_RANK_MAX];
+    __shared__ __attribute__((aligned(16))) unsigned long long s_keys[CAP];
     __shared__ uint32_t s_cnt[RS_WAVES * 256];
     __shared__ uint32_t s_scan[32];
     const int tid = threadIdx.x;
@@ -1553,9 +1557,10 @@ __global__ __launch_bounds__(DBR_THREADS) void k_dbin_rank(int N, int V, int ite
     if (e0 == 0u) return;                                             // no bucket starts in this item
     const uint32_t* st = db_start + (size_t)v * (MGR_DB_BUCKETS + 1);
     const uint32_t lo = st[~e0], hi = st[e1], n = hi - lo;
-    if (n > (uint32_t)MGR_DB_RANK_MAX * 3u / 4u && tid == 0) atomicAdd(&hdr->sort_big, 1u);      // (counted from three quarters of the limit on:
-                                                                                                   //  the launch behind is only skipped well clear of it)
-    if (n > (uint32_t)MGR_DB_RANK_MAX) {
+    if (n > cap_keys * 3u / 4u && tid == 0) atomicAdd(&hdr->sort_big, 1u);      // (counted from three quarters of the limit on:
+                                                                                  //  the launch behind is only skipped well clear of it)
+    if (n > (uint32_t)MGR_DB_RANK_MAX && tid == 0) atomicAdd(&hdr->sort_large, 1u);
+    if (n > cap_keys) {
         if (tid == 0) {
             atomicAdd(&hdr->sort_huge, 1u);
             // the caller skipped the launch behind (debug bit 128: the previous forward met no such item): flagged like a skipped
@@ -2907,7 +2912,7 @@ __global__ __launch_bounds__(256) void k_fwd_items(const uint4* __restrict__ til
         if (f) { ovf |= f; hdr->overflow = ovf; hdr->acc_flags = 0u; }
         if (mirror) {   // the caller's host-mapped status words (mgr_raster_set_status_mirror): no copy, no launch
             // (bits 16.. of the overflow word: quadrants of depth-cut tiles repaired on the device in this forward)
-            mirror[0] = hdr->total_pairs; mirror[1] = ovf | (min(hdr->n_rep_units, 0xFFFFu) << 16); mirror[2] = hdr->tiers | (min(hdr->sort_big, 0xFFFFu) << 8);
+            mirror[0] = hdr->total_pairs; mirror[1] = ovf | (min(hdr->n_rep_units, 0xFFFFu) << 16); mirror[2] = hdr->tiers | (min(hdr->sort_big, 0xFFFFu) << 8) | (min(hdr->sort_large, 0x7Fu) << 24);
             __threadfence_system();
             mirror[3] = 1u;
         }
@@ -3229,15 +3234,21 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
           const BgFill none = {nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, nullptr, 0};
           const int n_fill = fill.out ? 1024 : 0;
           bg_filled = fill.out != nullptr;
-          if (ranked)
-              hipLaunchKernelGGL(k_dbin_rank, dim3((unsigned)(ipv * V + n_fill)), dim3(DBR_THREADS), 0, stream, N, V, ipv, (const uint32_t*)db_start, (const uint32_t*)(ws + L.db_item),
-                                 (const unsigned long long*)db_keys, db_order, hdr, (uint32_t*)(ws + L.db_zrange), behind ? 0 : 1, fill, ipv * V);
+          // debug bit 256 (skip_tiers & 8): the previous forward met items beyond MGR_DB_RANK_MAX keys (one dense depth bucket: the palm
+          // seen face on, in the trained state of the bench scene) -- this launch gets LDS for MGR_DB_RANK_LARGE keys per workgroup
+          const uint32_t cap_keys = (skip_tiers & 8) ? (uint32_t)MGR_DB_RANK_LARGE : (uint32_t)MGR_DB_RANK_MAX;
+          if (ranked && (skip_tiers & 8))
+              hipLaunchKernelGGL((k_dbin_rank<MGR_DB_RANK_LARGE>), dim3((unsigned)(ipv * V + n_fill)), dim3(DBR_THREADS), 0, stream, N, V, ipv, (const uint32_t*)db_start, (const uint32_t*)(ws + L.db_item),
+                                 (const unsigned long long*)db_keys, db_order, hdr, behind ? 0 : 1, fill, ipv * V);
+          else if (ranked)
+              hipLaunchKernelGGL((k_dbin_rank<MGR_DB_RANK_MAX>), dim3((unsigned)(ipv * V + n_fill)), dim3(DBR_THREADS), 0, stream, N, V, ipv, (const uint32_t*)db_start, (const uint32_t*)(ws + L.db_item),
+                                 (const unsigned long long*)db_keys, db_order, hdr, behind ? 0 : 1, fill, ipv * V);
           const int fchunk = ranked ? (int)MGR_DB_ITEM : chunk, fchunks = (N + fchunk - 1) / fchunk;
           (void)chunks;
           if (behind)
               hipLaunchKernelGGL((k_dbin_sort<SORT_LDS_KEYS>), dim3(1024 + (ranked ? 0 : n_fill)), dim3(RS_THREADS), SORT_LDS_KEYS * 8 + RS_WAVES * 256 * 4 + 256, stream,
                                  N, fchunk, fchunks, V * fchunks, (const uint32_t*)db_start, (const uint32_t*)db_nvis, db_keys, db_order,
-                                 ranked ? (uint32_t)MGR_DB_RANK_MAX : 0u, hdr, ranked ? 2 : 0, ranked ? none : fill, 1024); }
+                                 ranked ? cap_keys : 0u, hdr, ranked ? 2 : 0, ranked ? none : fill, 1024); }
         MGR_LAUNCH_CHECK("k_dbin_sort", stream, debug);
         const bool big_possible = T > BIN_SMALL_TILES;   // a box of more than BIN_SMALL_TILES tiles can only exist then
         { MGR_PROF("k_bin_count", stream);
@@ -3412,14 +3423,16 @@ extern "C" int mgr_raster_status_sync(const void* workspace, int64_t* num_pairs,
 extern "C" int mgr_raster_status_tiers_sync(const void* workspace, int64_t* num_pairs, int32_t* overflow, int32_t* tiers,
                                             void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    uint32_t h[16];
+    uint32_t h[64];      // (the first 256 bytes of the header: everything but the queue counters)
+    static_assert(offsetof(MgrHeader, sort_large) / 4 < 64, "status words beyond the copied part of the header");
     MGR_HIP(hipMemcpyAsync(h, workspace, sizeof(h), hipMemcpyDeviceToHost, stream));
     MGR_HIP(hipStreamSynchronize(stream));
     if (num_pairs) *num_pairs = h[0];
     if (overflow) *overflow = (int32_t)h[1];
-    if (tiers) {   // bits 0-1: binning tiers needed; bits 8..: items of the instance sort beyond its light launch (capped at 65535)
-        const uint32_t sb = h[offsetof(MgrHeader, sort_big) / 4];
-        *tiers = (int32_t)(h[offsetof(MgrHeader, tiers) / 4] | ((sb < 0xFFFFu ? sb : 0xFFFFu) << 8));
+    if (tiers) {   // bits 0-1: binning tiers needed; bits 8..23: items of the instance sort near / beyond the LDS of its launch (capped);
+                   // bits 24..30: items beyond MGR_DB_RANK_MAX keys (the next forward should ask for the large LDS: debug bit 256)
+        const uint32_t sb = h[offsetof(MgrHeader, sort_big) / 4], sl = h[offsetof(MgrHeader, sort_large) / 4];
+        *tiers = (int32_t)(h[offsetof(MgrHeader, tiers) / 4] | ((sb < 0xFFFFu ? sb : 0xFFFFu) << 8) | ((sl < 0x7Fu ? sl : 0x7Fu) << 24));
     }
     if (h[1] & MGR_OVF_PAIRS) return mgr_fail(MGR_EOVERFLOW, "pair capacity exceeded");
     if (h[1] & MGR_OVF_CUT) return mgr_fail(MGR_ECUT, "depth cut violated: run the forward again without debug bit 8");

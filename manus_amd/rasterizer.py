@@ -73,10 +73,11 @@ class RasterWorkspace:
         the device: a view that needs a skipped launch flags the forward, which is then run again with all of them)."""
         if self.tiers is None:
             return 0
-        # (128 / 256: the instance sort's light launch alone, or its full-size launch alone)
-        bits = (0 if self.tiers & 1 else 16) | (0 if self.tiers & 2 else 32) | (128 if (self.tiers >> 8) <= RasterWorkspace.SORT_BIG_MAX else 256)
-        # (bit 128 = "the previous forward met no sort item beyond k_dbin_rank: skip the launch behind it" -- verified on the device like
-        # the tile-box tiers, MGR_OVF_TIER; bit 256 is accepted and ignored since round 6)
+        near, large = (self.tiers >> 8) & 0xFFFF, (self.tiers >> 24) & 0x7F
+        bits = (0 if self.tiers & 1 else 16) | (0 if self.tiers & 2 else 32) | (128 if near <= RasterWorkspace.SORT_BIG_MAX else 0) | (256 if large else 0)
+        # (bit 128 = "the previous forward met no sort item near the LDS of k_dbin_rank: skip the launch behind it" -- verified on the
+        # device like the tile-box tiers, MGR_OVF_TIER; bit 256 = "it met items beyond MGR_DB_RANK_MAX keys: k_dbin_rank's instantiation
+        # for larger items" -- a dense depth slice then costs that kernel ~4 us instead of 33 us in the launch behind)
         return bits & ~(48 | 128) if self.no_flagging_skips else bits
 
 

@@ -41,7 +41,8 @@ def report(tag):
     depth = ws.buf[L["depth"]: L["depth"] + 4 * V * N].view(torch.float32).reshape(V, N).cpu().numpy()
     rect = ws.buf[L["rect"]: L["rect"] + 8 * V * N].view(torch.int16).reshape(V, N, 4).cpu().numpy().astype(np.int64) & 0xFFFF
     vis = ((rect[..., 2] - rect[..., 0]) * (rect[..., 3] - rect[..., 1]) > 0)
-    print("%s: sort items near / beyond k_dbin_rank's limit in the last forward: %d" % (tag, (ws.tiers or 0) >> 8))
+    print("%s: sort items near / beyond the LDS of the last forward's k_dbin_rank launch: %d; beyond MGR_DB_RANK_MAX keys: %d; debug bits of the next forward: %d"
+          % (tag, ((ws.tiers or 0) >> 8) & 0xFFFF, ((ws.tiers or 0) >> 24) & 0x7F, ws.skip_bits()))
     for v in range(V):
         z = depth[v][vis[v]]
         lo, hi = z.min(), z.max()
