@@ -149,7 +149,8 @@ size_t mgr_raster_workspace_bytes(int V, int N, int W, int H, int64_t pair_capac
  * ~768 keys, one workgroup each (k_dbin_rank: depth buckets uniform over the depth range of the view's visible instances in
  * this forward); an item of more than 2048 keys -- a dense depth slice -- is left to a radix launch behind, which returns at
  * once when there is none.  Bit 128 omits that launch (mgr_raster_status_tiers_sync reported no item near the limit for the
- * previous forward: bits 8..23 of its tiers word); an item that needs it then raises the overflow word's bit 2 (MGR_ETIER:
+ * previous forward: bits 8..15 of its tiers word for the usual instantiation, bits 16..23 for the one bit 256 asks for);
+ * an item that needs it then raises the overflow word's bit 2 (MGR_ETIER:
  * run the forward again without the bit), like a skipped tile-box tier.  256 = k_dbin_rank's instantiation for items of up
  * to 3072 keys (the previous forward met items of more than 2048: bits 24..30 of the tiers word) -- ~4 us slower for all its
  * items, but the dense slice no longer waits for the launch behind (33 us). */

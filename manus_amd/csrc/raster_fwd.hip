@@ -645,7 +645,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan_a(int T, int nbT, const uint
     __shared__ uint32_t s_bb[4];
     const int tid = threadIdx.x, v = blockIdx.x / nbT, t = (blockIdx.x % nbT) * 1024 + tid;
     if (tid == 0) { s_bb[0] = 0xFFFFu; s_bb[1] = 0xFFFFu; s_bb[2] = 0u; s_bb[3] = 0u; }
-    if (blockIdx.x == 0 && tid == 0) { hdr->tiers = 0u; hdr->sort_big = 0u; hdr->sort_huge = 0u; hdr->sort_large = 0u; hdr->fwd_seq += 1u; hdr->rep_why = 0u; }   // (phase B's depth-bucket workgroups / the sort set them)
+    if (blockIdx.x == 0 && tid == 0) { hdr->tiers = 0u; hdr->sort_big = 0u; hdr->sort_huge = 0u; hdr->sort_large = 0u; hdr->sort_near_large = 0u; hdr->fwd_seq += 1u; hdr->rep_why = 0u; }   // (phase B's depth-bucket workgroups / the sort set them)
     const bool valid = t < T;
     const size_t k = (size_t)v * T + t;
     if (tid < MGR_NCLS) s_cls[tid] = 0;
@@ -1557,9 +1557,13 @@ __global__ __launch_bounds__(DBR_THREADS) void k_dbin_rank(int N, int V, int ite
     if (e0 == 0u) return;                                             // no bucket starts in this item
     const uint32_t* st = db_start + (size_t)v * (MGR_DB_BUCKETS + 1);
     const uint32_t lo = st[~e0], hi = st[e1], n = hi - lo;
-    if (n > cap_keys * 3u / 4u && tid == 0) atomicAdd(&hdr->sort_big, 1u);      // (counted from three quarters of the limit on:
-                                                                                  //  the launch behind is only skipped well clear of it)
-    if (n > (uint32_t)MGR_DB_RANK_MAX && tid == 0) atomicAdd(&hdr->sort_large, 1u);
+    // counted from three quarters of a limit on (the launch behind is only skipped well clear of it) -- for BOTH instantiations,
+    // whichever this one is: the caller picks the next forward's by sort_large and skips by the count that belongs to it
+    if (n > (uint32_t)MGR_DB_RANK_MAX * 3u / 4u && tid == 0) {
+        atomicAdd(&hdr->sort_big, 1u);
+        if (n > (uint32_t)MGR_DB_RANK_LARGE * 3u / 4u) atomicAdd(&hdr->sort_near_large, 1u);
+        if (n > (uint32_t)MGR_DB_RANK_MAX) atomicAdd(&hdr->sort_large, 1u);
+    }
     if (n > cap_keys) {
         if (tid == 0) {
             atomicAdd(&hdr->sort_huge, 1u);
@@ -2912,7 +2916,7 @@ __global__ __launch_bounds__(256) void k_fwd_items(const uint4* __restrict__ til
         if (f) { ovf |= f; hdr->overflow = ovf; hdr->acc_flags = 0u; }
         if (mirror) {   // the caller's host-mapped status words (mgr_raster_set_status_mirror): no copy, no launch
             // (bits 16.. of the overflow word: quadrants of depth-cut tiles repaired on the device in this forward)
-            mirror[0] = hdr->total_pairs; mirror[1] = ovf | (min(hdr->n_rep_units, 0xFFFFu) << 16); mirror[2] = hdr->tiers | (min(hdr->sort_big, 0xFFFFu) << 8) | (min(hdr->sort_large, 0x7Fu) << 24);
+            mirror[0] = hdr->total_pairs; mirror[1] = ovf | (min(hdr->n_rep_units, 0xFFFFu) << 16); mirror[2] = hdr->tiers | (min(hdr->sort_big, 0xFFu) << 8) | (min(hdr->sort_near_large, 0xFFu) << 16) | (min(hdr->sort_large, 0x7Fu) << 24);
             __threadfence_system();
             mirror[3] = 1u;
         }
@@ -3424,15 +3428,16 @@ extern "C" int mgr_raster_status_tiers_sync(const void* workspace, int64_t* num_
                                             void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     uint32_t h[64];      // (the first 256 bytes of the header: everything but the queue counters)
-    static_assert(offsetof(MgrHeader, sort_large) / 4 < 64, "status words beyond the copied part of the header");
+    static_assert(offsetof(MgrHeader, sort_near_large) / 4 < 64, "status words beyond the copied part of the header");
     MGR_HIP(hipMemcpyAsync(h, workspace, sizeof(h), hipMemcpyDeviceToHost, stream));
     MGR_HIP(hipStreamSynchronize(stream));
     if (num_pairs) *num_pairs = h[0];
     if (overflow) *overflow = (int32_t)h[1];
-    if (tiers) {   // bits 0-1: binning tiers needed; bits 8..23: items of the instance sort near / beyond the LDS of its launch (capped);
-                   // bits 24..30: items beyond MGR_DB_RANK_MAX keys (the next forward should ask for the large LDS: debug bit 256)
-        const uint32_t sb = h[offsetof(MgrHeader, sort_big) / 4], sl = h[offsetof(MgrHeader, sort_large) / 4];
-        *tiers = (int32_t)(h[offsetof(MgrHeader, tiers) / 4] | ((sb < 0xFFFFu ? sb : 0xFFFFu) << 8) | ((sl < 0x7Fu ? sl : 0x7Fu) << 24));
+    if (tiers) {   // bits 0-1: binning tiers needed; bits 8..15 / 16..23: items of the instance sort beyond three quarters of
+                   // MGR_DB_RANK_MAX / MGR_DB_RANK_LARGE keys (capped at 255); bits 24..30: items beyond MGR_DB_RANK_MAX keys (the
+                   // next forward should ask for the large instantiation: debug bit 256)
+        const uint32_t sb = h[offsetof(MgrHeader, sort_big) / 4], sn = h[offsetof(MgrHeader, sort_near_large) / 4], sl = h[offsetof(MgrHeader, sort_large) / 4];
+        *tiers = (int32_t)(h[offsetof(MgrHeader, tiers) / 4] | ((sb < 0xFFu ? sb : 0xFFu) << 8) | ((sn < 0xFFu ? sn : 0xFFu) << 16) | ((sl < 0x7Fu ? sl : 0x7Fu) << 24));
     }
     if (h[1] & MGR_OVF_PAIRS) return mgr_fail(MGR_EOVERFLOW, "pair capacity exceeded");
     if (h[1] & MGR_OVF_CUT) return mgr_fail(MGR_ECUT, "depth cut violated: run the forward again without debug bit 8");

@@ -41,8 +41,9 @@ def report(tag):
     depth = ws.buf[L["depth"]: L["depth"] + 4 * V * N].view(torch.float32).reshape(V, N).cpu().numpy()
     rect = ws.buf[L["rect"]: L["rect"] + 8 * V * N].view(torch.int16).reshape(V, N, 4).cpu().numpy().astype(np.int64) & 0xFFFF
     vis = ((rect[..., 2] - rect[..., 0]) * (rect[..., 3] - rect[..., 1]) > 0)
-    print("%s: sort items near / beyond the LDS of the last forward's k_dbin_rank launch: %d; beyond MGR_DB_RANK_MAX keys: %d; debug bits of the next forward: %d"
-          % (tag, ((ws.tiers or 0) >> 8) & 0xFFFF, ((ws.tiers or 0) >> 24) & 0x7F, ws.skip_bits()))
+    t = ws.tiers or 0
+    print("%s: sort items of the last forward beyond 3/4 of k_dbin_rank's small capacity: %d, of its large one: %d; beyond the small capacity: %d; "
+          "debug bits of the next forward: %d" % (tag, (t >> 8) & 0xFF, (t >> 16) & 0xFF, (t >> 24) & 0x7F, ws.skip_bits()))
     for v in range(V):
         z = depth[v][vis[v]]
         lo, hi = z.min(), z.max()
