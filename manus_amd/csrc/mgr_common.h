@@ -217,7 +217,9 @@ struct MgrLayout {
                               // box, eight views, 2048 buckets 1.312-1.322 ms against 1.308-1.311 (with the optimizer 1.507 against 1.488), 4096
                               // buckets 1.324 against 1.315 -- not adopted.
 #endif
+#ifndef MGR_DB_ITEM
 #define MGR_DB_ITEM 768       // keys per item of the instance sort (whole buckets: an item ends with the bucket it is in)
+#endif
 #define MGR_DB_RANK_MAX 2048  // items of at most this many keys are sorted by k_dbin_rank (16 + 8 KB of LDS), larger ones by the launch behind it --
                               // 33 us on the critical path -- unless the caller asked for the instantiation for MGR_DB_RANK_LARGE keys (debug bit
                               // 256: the previous forward met such items), which costs k_dbin_rank ~4 us (six keys per thread compiled in) and
