@@ -2910,7 +2910,10 @@ __global__ __launch_bounds__(256) void k_fwd_items(const uint4* __restrict__ til
     const int tid = threadIdx.x;
     const uint32_t n_busy = hdr->queue_len_i;
     const uint32_t nb = (n_busy + 255u) / 256u;
-    if (blockIdx.x == 0 && tid == 0) {   // the forward's last kernel publishes the depth-cut flags (tile scan + blend) and consumes them
+    // the forward's last kernel publishes the depth-cut flags (tile scan + blend) and consumes them -- by the LAST workgroup of the
+    // grid, which has no tiles of the queue when the frame has empty tiles (the system-scope fence of the status mirror then waits
+    // beside the others' work instead of in front of workgroup 0's)
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) {
         const uint32_t f = hdr->acc_flags;
         uint32_t ovf = hdr->overflow;
         if (f) { ovf |= f; hdr->overflow = ovf; hdr->acc_flags = 0u; }
