@@ -707,9 +707,23 @@ __global__ __launch_bounds__(1024) void k_tile_scan_b(int V, int T, int nbT, uin
     const int tid = threadIdx.x, nblk = V * nbT, b = blockIdx.x, v = b / nbT, t = (b % nbT) * 1024 + tid;
     const bool valid = t < T;
     const size_t k = (size_t)v * T + t;
-    if (tid < MGR_NCLS) {   // thread c: class c over the blocks
+    if (tid < MGR_NCLS) {   // thread c: class c over the blocks (eight loads in flight: the walk is a chain of round trips otherwise)
         uint32_t gt = 0, gp = 0, vt = 0, vp = 0;
-        for (int j = 0; j < nblk; ++j) {
+        int j0 = 0;
+        for (; j0 + 8 <= nblk; j0 += 8) {
+            uint32_t x8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x8[u] = blk_cls[(size_t)(j0 + u) * MGR_NCLS + tid];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + u;
+                const uint32_t x = x8[u];
+                gt += x;
+                if (j < b) gp += x;
+                if (j / nbT == v) { vt += x; if (j < b) vp += x; }
+            }
+        }
+        for (int j = j0; j < nblk; ++j) {
             const uint32_t x = blk_cls[(size_t)j * MGR_NCLS + tid];
             gt += x;
             if (j < b) gp += x;
@@ -720,7 +734,19 @@ __global__ __launch_bounds__(1024) void k_tile_scan_b(int V, int T, int nbT, uin
     }
     if (tid == 64) {
         uint32_t r = 0, rc = 0, b0 = 0, b1 = 0;
-        for (int j = 0; j < nblk; ++j) {
+        int j0 = 0;
+        for (; j0 + 8 <= nblk; j0 += 8) {
+            uint2 p8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) p8[u] = part[j0 + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (j0 + u == b) { b0 = r; b1 = rc; }
+                r += p8[u].x;
+                rc += p8[u].y;
+            }
+        }
+        for (int j = j0; j < nblk; ++j) {
             if (j == b) { b0 = r; b1 = rc; }
             r += part[j].x;
             rc += part[j].y;
