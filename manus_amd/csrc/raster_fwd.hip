@@ -757,7 +757,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan_b(int V, int T, int nbT, uin
     __syncthreads();
     // non-empty tiles per view (threads 128 ..: one view each, strided) -> the longest view sets the interleaved queue's length
     // (staging phase A's block sums in LDS first -- every thread two or three words, the sums over LDS -- was measured in round 6:
-    //  0.018 -> 0.021 ms at eight views, 0.009 -> 0.016 at one: these loops are not the kernel's chain)
+    //  0.018 -> 0.021 ms at eight views, 0.009 -> 0.016 at one; eight loads in flight in the walks above: 0.018 -> 0.013)
     for (int w = tid - 128; w >= 0 && w < V; w += 896) {
         uint32_t nb = 0;
         for (int j = w * nbT; j < (w + 1) * nbT; ++j)
