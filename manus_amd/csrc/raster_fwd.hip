@@ -1875,7 +1875,11 @@ __device__ __forceinline__ bool bin_sc_mine(ushort4 box, int masks) {
     const int tier = tb <= (uint32_t)BIN_MID_TILES ? BIN_MID_TILES : (tb <= (uint32_t)BIN_SMALL_TILES ? BIN_SMALL_TILES : 0);
     return tier == masks;
 }
-template <int MASKS>
+// SPREAD (round 6, end): the lane-spreading producer is an instantiation of its own, asked for when the previous forward met
+// rectangles of more than 64 tiles (MgrHeader::tiers bit 2 -> debug bit 4096).  Without it a batch that holds such a rectangle
+// goes instance by instance, as up to round 5: correct for any input, and the usual producer keeps round 5's loop and
+// registers (0.094 -> 0.087 ms at eight views of the capture-like set, where no rectangle is that large).
+template <int MASKS, bool SPREAD>
 __global__ __launch_bounds__(BIN_SC_THREADS) void k_bin_scatter(int N, int T, int nblk, int bb, const uint32_t* __restrict__ db_nvis,
                                                                 const ushort4* __restrict__ db_bbox,
                                                                 const uint32_t* __restrict__ db_order,
@@ -1942,14 +1946,21 @@ __global__ __launch_bounds__(BIN_SC_THREADS) void k_bin_scatter(int N, int T, in
     bool v_mapped = false;
     BinRec cur = {0u, 0u, 0u, 0u, 0u, 0u};
     bool last_emitted = false;      // producer: the batch emitted in the previous iteration was the last one
+    bool met_big = false;           // producer: a rectangle of more than 64 tiles among this block's instances (-> MgrHeader::tiers bit 2)
 #pragma unroll 1
-    for (int it = 0;; ++it) {
+    for (int it = 0; SPREAD || it <= nbatch; ++it) {
         __syncthreads();   // batch it - 1 is expanded (and, the first time, the cursors are loaded); batch it - 2 is consumed
         BP(5)
         if (wave == 0) {
             const int d = it & 1;
-            if (last_emitted) break;      // (the consumers take the last batch in this iteration and leave by its bit 31: same barrier count)
-            {   // ---- producer: the next 64 lanes into buffer it & 1
+            if (SPREAD && last_emitted) break;      // (the consumers take the last batch in this iteration and leave by its bit 31: same barrier count)
+            if (SPREAD || it < nbatch) {   // ---- producer: the next 64 lanes into buffer it & 1
+                BinRec r;
+                if constexpr (!SPREAD) {
+                    r = nxt;
+                    BP(0)
+                    if (it + 1 < nbatch) nxt = bin_load(N, v, p0 + 64u * (uint32_t)(it + 1) + lane, nvis, box, db_order, db_rec);
+                } else {
                 if (v_off >= v_total) {      // the next source batch
                     cur = nxt;
                     BP(0)
@@ -1960,6 +1971,7 @@ __global__ __launch_bounds__(BIN_SC_THREADS) void k_bin_scatter(int N, int T, in
                     v_off = 0u;
                     v_total = 64u;
                     if (v_mapped) {
+                        met_big = true;
                         const uint32_t nl = cur.tiles == 0u ? 0u : (cur.tiles <= 64u ? 1u : ch * ((cw + 63u) / 64u));
                         const uint32_t ve = mgr_wave_incl_scan_u32(nl);
                         v_total = (uint32_t)__builtin_amdgcn_readlane((int)ve, 63);
@@ -1968,12 +1980,14 @@ __global__ __launch_bounds__(BIN_SC_THREADS) void k_bin_scatter(int N, int T, in
                         if (v_total == 0u) v_total = 1u;         // (an empty batch still passes through once)
                     }
                 }
-                BinRec r = cur;
+                r = cur;
                 if (v_mapped) r = bin_spread_lane(v_off + (uint32_t)lane, cur, s_vend);      // (out of line: the usual path keeps its schedule)
                 v_off += 64u;
                 last_emitted = v_off >= v_total && src_it >= nbatch;      // (travels in bit 31 of s_info[d])
+                }
                 const unsigned long long am = ((unsigned long long)r.ahi << 32) | r.alo;
-                const bool use = r.tiles != 0u;
+                const bool big = !SPREAD && r.tiles > 64u;      // (SPREAD: no lane holds more than 64 tiles any more)
+                const bool use = r.tiles != 0u && !big;
                 const uint32_t w = r.wh & 0xFFFFu;
                 // the alive tiles in even rows of the box: rows of the rectangle are runs of w bits
                 unsigned long long amE = 0ull;
@@ -1992,7 +2006,9 @@ __global__ __launch_bounds__(BIN_SC_THREADS) void k_bin_scatter(int N, int T, in
                 const uint32_t P = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
                 const uint32_t PE = P & 0xFFFFu, PO = P >> 16;
                 BP(1)
-                if (PE + PO <= (uint32_t)BIN_PAIR_CAP) {
+                const bool any_big = !SPREAD && __ballot(big) != 0ull;
+                met_big = met_big || any_big;
+                if (!any_big && PE + PO <= (uint32_t)BIN_PAIR_CAP) {
                     // expand: the lane's pairs in row-major order of the rectangle, even box rows at [oE, oE + cntE) from the front,
                     // odd ones at CAP - 1 - [oO, oO + cntO) from the back
                     uint32_t* pl = s_pairs + d * BIN_PAIR_CAP;
@@ -2094,6 +2110,9 @@ __global__ __launch_bounds__(BIN_SC_THREADS) void k_bin_scatter(int N, int T, in
             if (Praw & 0x80000000u) break;      // that was the producer's last batch
         }
     }
+    // (the next forward should ask for -- or stay on -- the spreading instantiation.  Read first: with cameras close to the hand
+    //  nearly every block meets one, and nine thousand atomics on one address cost 0.4 ms)
+    if (wave == 0 && lane == 0 && met_big && (*(volatile uint32_t*)&hdr->tiers & 4u) == 0u) atomicOr(&hdr->tiers, 4u);
 #ifdef BIN_PROF
     {
         const int wid = blockIdx.y * gridDim.x + blockIdx.x;
@@ -3128,6 +3147,7 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
     bool bg_filled = false;   // the background of the empty tiles has been written by the instance sort's launch
     const int skip_tiers = ((debug & 16) ? 1 : 0) | ((debug & 32) ? 2 : 0) | ((debug & 128) ? 4 : 0) | ((debug & 256) ? 8 : 0);
     const int img_kept = (debug & 1024) ? 1 : 0;   // bit 10: "image kept" (see BgFill)
+    const bool spread = (debug & 4096) != 0;       // bit 12: k_bin_scatter's lane-spreading instantiation (the previous forward met rectangles of more than 64 tiles)
     // bit 11 (2048, with bit 3): tiles whose cut list runs out under an unsaturated pixel are repaired on the device
     // (k_repair_scan / k_repair_blend) instead of flagging the forward
     const bool repair = use_cut && (debug & 2048) && W < 65536 && H < 65536;   // (k_repair_scan packs tile coordinates in 12 bits)
@@ -3173,7 +3193,8 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
         MGR_HIP(hipFuncSetAttribute((const void*)k_dbin_sort<SORT_LDS_KEYS>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     SORT_LDS_KEYS * 8 + RS_WAVES * 256 * 4 + 256));
         MGR_HIP(hipFuncSetAttribute((const void*)k_bin_count<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
-        MGR_HIP(hipFuncSetAttribute((const void*)k_bin_scatter<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+        MGR_HIP(hipFuncSetAttribute((const void*)k_bin_scatter<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+        MGR_HIP(hipFuncSetAttribute((const void*)k_bin_scatter<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
         MGR_HIP(hipFuncSetAttribute((const void*)k_repair_blend, hipFuncAttributeMaxDynamicSharedMemorySize, REP_BLEND_LDS));
         attr_set[device].store(true, std::memory_order_release);
     }
@@ -3294,17 +3315,24 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
         { MGR_PROF("k_bin_scan", stream); hipLaunchKernelGGL(k_bin_scan, dim3((T + BSCAN_COLS - 1) / BSCAN_COLS, V), dim3(BSCAN_COLS * BSCAN_SEGS), 0, stream, gx, T, nblk, bb, (const uint32_t*)db_nvis,
                            (const ushort4*)db_bbox, (const uint32_t*)tile_start, bin_mat); }
         { MGR_PROF("k_bin_scatter", stream);
-          hipLaunchKernelGGL((k_bin_scatter<BIN_MID_TILES>), grid_b, dim3(BIN_SC_THREADS), (size_t)BIN_MID_TILES * 12 + rec_bytes, stream, N, T, nblk, bb,
+#define MGR_SC_LAUNCH(MK, LDSB, ...)                                                                                                          \
+    do {                                                                                                                                  \
+        if (spread) hipLaunchKernelGGL((k_bin_scatter<MK, true>), grid_b, dim3(BIN_SC_THREADS), LDSB, stream, __VA_ARGS__);             \
+        else hipLaunchKernelGGL((k_bin_scatter<MK, false>), grid_b, dim3(BIN_SC_THREADS), LDSB, stream, __VA_ARGS__);                   \
+    } while (0)
+          MGR_SC_LAUNCH(BIN_MID_TILES, (size_t)BIN_MID_TILES * 12 + rec_bytes, N, T, nblk, bb,
                              (const uint32_t*)db_nvis, (const ushort4*)db_bbox, (const uint32_t*)db_order, (const uint4*)db_rec, (const uint32_t*)bin_mat,
                              (uint32_t*)(ws + L.sorted_gid), (uint32_t)cap, hdr, skip_tiers);
           if (T > BIN_MID_TILES && !(skip_tiers & 2))
-              hipLaunchKernelGGL((k_bin_scatter<BIN_SMALL_TILES>), grid_b, dim3(BIN_SC_THREADS), (size_t)BIN_SMALL_TILES * 12 + rec_bytes, stream, N, T, nblk, bb,
-                                 (const uint32_t*)db_nvis, (const ushort4*)db_bbox, (const uint32_t*)db_order, (const uint4*)db_rec, (const uint32_t*)bin_mat,
-                                 (uint32_t*)(ws + L.sorted_gid), (uint32_t)cap, hdr, 0);
+              MGR_SC_LAUNCH(BIN_SMALL_TILES, (size_t)BIN_SMALL_TILES * 12 + rec_bytes, N, T, nblk, bb,
+                            (const uint32_t*)db_nvis, (const ushort4*)db_bbox, (const uint32_t*)db_order, (const uint4*)db_rec, (const uint32_t*)bin_mat,
+                            (uint32_t*)(ws + L.sorted_gid), (uint32_t)cap, hdr, 0);
           if (big_possible && !(skip_tiers & 1))
-              hipLaunchKernelGGL((k_bin_scatter<0>), grid_b, dim3(BIN_SC_THREADS), (size_t)T * 4 + rec_bytes, stream, N, T, nblk, bb,
-                                 (const uint32_t*)db_nvis, (const ushort4*)db_bbox, (const uint32_t*)db_order, (const uint4*)db_rec, (const uint32_t*)bin_mat,
-                                 (uint32_t*)(ws + L.sorted_gid), (uint32_t)cap, hdr, 0); }
+              MGR_SC_LAUNCH(0, (size_t)T * 4 + rec_bytes, N, T, nblk, bb,
+                            (const uint32_t*)db_nvis, (const ushort4*)db_bbox, (const uint32_t*)db_order, (const uint4*)db_rec, (const uint32_t*)bin_mat,
+                            (uint32_t*)(ws + L.sorted_gid), (uint32_t)cap, hdr, 0);
+#undef MGR_SC_LAUNCH
+        }
         MGR_LAUNCH_CHECK("k_bin_scatter", stream, debug);
     } else if (N > 0) {
         dim3 grid((N + EMIT_THREADS - 1) / EMIT_THREADS, V);

@@ -77,6 +77,7 @@ class RasterWorkspace:
         near_s, near_l, large = (self.tiers >> 8) & 0xFF, (self.tiers >> 16) & 0xFF, (self.tiers >> 24) & 0x7F
         near = near_l if large else near_s          # (the count that belongs to the instantiation this forward asks for)
         bits = (0 if self.tiers & 1 else 16) | (0 if self.tiers & 2 else 32) | (128 if near <= RasterWorkspace.SORT_BIG_MAX else 0) | (256 if large else 0)
+        bits |= 4096 if self.tiers & 4 else 0       # rectangles of more than 64 tiles met: k_bin_scatter's lane-spreading instantiation
         # (bit 128 = "the previous forward met no sort item near the LDS of k_dbin_rank: skip the launch behind it" -- verified on the
         # device like the tile-box tiers, MGR_OVF_TIER; bit 256 = "it met items beyond MGR_DB_RANK_MAX keys: k_dbin_rank's instantiation
         # for larger items" -- a dense depth slice then costs that kernel ~4 us instead of 33 us in the launch behind)

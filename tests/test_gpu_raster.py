@@ -492,11 +492,15 @@ def test_ordered_binning_equals_sorted_route(kind, n, views, size, sigma, monkey
     rz.set_sync_policy(True)
     from test_gpu_fused import _layout
     got = {}
-    for route in ("sorted", "ordered"):
-        monkeypatch.setenv("MGR_BINNING", route)
+    # ("ordered" twice: the second forward runs with what the first one learnt -- skipped tiers, and for the scene with large
+    #  rectangles k_bin_scatter's lane-spreading instantiation instead of the instance-by-instance route)
+    for route in ("sorted", "ordered", "ordered2"):
+        monkeypatch.setenv("MGR_BINNING", "ordered" if route == "ordered2" else route)
         with torch.no_grad():
             img = hc.forward_views_fused(list(range(views)))[0].clone()
         ws = rz.context().last_ws
+        if route == "ordered2" and sigma is not None:
+            assert ws.tiers & 4 and ws.skip_bits() & 4096
         L = _layout(views, n, W, H, ws.cap)
         T = ((W + 15) // 16) * ((H + 15) // 16)
         ts = ws.buf[L["tile_start"]: L["tile_start"] + 4 * (views * T + 1)].view(torch.int32).clone()
@@ -505,15 +509,17 @@ def test_ordered_binning_equals_sorted_route(kind, n, views, size, sigma, monkey
         gid = ws.buf[L["sorted_gid"]: L["sorted_gid"] + 4 * total].view(torch.int32).clone()
         got[route] = (img, ts, gid)
         if sigma is not None and route == "ordered":      # the scene does exercise the general routes
+            assert ws.tiers & 4                           # (k_bin_scatter met rectangles of more than 64 tiles and said so)
             rect = ws.buf[L["rect"]: L["rect"] + 8 * views * n].view(torch.int16).view(-1, 4).int()
             tiles = (rect[:, 2] - rect[:, 0]) * (rect[:, 3] - rect[:, 1])
             assert int((tiles > 64).sum()) > 50 and int(((tiles > 16) & (tiles <= 64)).sum()) > 50
             bb = ws.buf[L["db_bbox"]: L["db_bbox"] + 8 * views].view(torch.int16).view(-1, 4).int()
             assert int((bb[:, 2] * bb[:, 3]).max()) > 2048
-    assert torch.equal(got["sorted"][1], got["ordered"][1])
-    neq = (got["sorted"][2] != got["ordered"][2]).nonzero()
-    assert neq.numel() == 0, (int(neq.numel()), neq[:5].flatten().tolist())
-    assert torch.equal(got["sorted"][0], got["ordered"][0])
+    for route in ("ordered", "ordered2"):
+        assert torch.equal(got["sorted"][1], got[route][1])
+        neq = (got["sorted"][2] != got[route][2]).nonzero()
+        assert neq.numel() == 0, (route, int(neq.numel()), neq[:5].flatten().tolist())
+        assert torch.equal(got["sorted"][0], got[route][0])
 
 
 def test_row_of_64_tiles_on_an_odd_box_row(monkeypatch):
