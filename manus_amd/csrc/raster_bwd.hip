@@ -109,6 +109,9 @@ int mgr_bwd_variant_bits(void) {   // (mgr_build_variant, raster_fwd.hip)
 #ifdef BWD_WLAST_REDUCE
     bits |= 4;
 #endif
+#if defined(MGR_GATHER_PRELOAD)
+    if (MGR_GATHER_PRELOAD != 1) bits |= 4;      // (set on the command line only by an A/B build: the default is defined further down)
+#endif
     return bits;
 }
 // a volatile load that stays a ds_read (a volatile access through a generic pointer becomes a flat load)

@@ -119,7 +119,9 @@ extern "C" int mgr_build_variant(void) {
 #if defined(FWD_PF1) || defined(FWD_LDS_PIPE1)
     bits |= 4;
 #endif
-    if (MGR_BIN_BLOCK != 1024 || MGR_GREC_BYTES != 64) bits |= 4;
+    if (MGR_BIN_BLOCK != 1024 || MGR_GREC_BYTES != 64 || MGR_DB_BUCKETS != 1024 || MGR_DB_ITEM != 768 || MGR_DB_RANK_MAX != 2048 ||
+        MGR_DB_RANK_LARGE != 3072)
+        bits |= 4;      // (round 6's A/B switches of the instance sort)
     return bits;
 }
 extern "C" const char* mgr_last_error(void) { return g_mgr_err; }
