@@ -282,7 +282,7 @@ int mgr_raster_set_cut_penalty(int forwards);
 int mgr_raster_set_status_mirror(const void* workspace, void* host_words);
 /* mgr_raster_status_sync plus `tiers` (see debug bits 16 / 32 / 128 / 256 / 4096 of the forward): bit 0 = a view's tile box
  * had more than 2048 tiles, bit 1 = one had 1537..2048, bit 2 = rectangles of more than 64 tiles were met (pass bit 4096
- * next time); bits 8..15 / 16..23 = items of the instance sort beyond 3/4 of k_dbin_rank's 2048 / 3072 keys (capped at
+ * next time); bits 8..15 / 16..23 = items of the instance sort beyond 13/16 of k_dbin_rank's 2048 / 3072 keys (capped at
  * 255): zero in the field that belongs to the instantiation the next forward asks for lets it pass bit 128; bits 24..30 =
  * items beyond 2048 keys (pass bit 256 next time). */
 int mgr_raster_status_tiers_sync(const void* workspace, int64_t* num_pairs, int32_t* overflow, int32_t* tiers,

@@ -135,8 +135,8 @@ struct MgrHeader {            // first 256 bytes of the workspace
     uint32_t sort_huge;       // items of the instance sort beyond the LDS of the k_dbin_rank launch (it counts; the launch behind it returns at once on 0)
     uint32_t sort_large;      // items beyond MGR_DB_RANK_MAX keys, whatever the launch's LDS (bits 24.. of the reported tiers word: the caller asks
                               // the next forward for the large LDS, debug bit 256)
-    uint32_t sort_near_large; // items beyond three quarters of MGR_DB_RANK_LARGE (bits 16..23 of the reported tiers word; sort_big -- bits 8..15 --
-                              // counts those beyond three quarters of MGR_DB_RANK_MAX: the caller skips the launch behind by the one that
+    uint32_t sort_near_large; // items beyond 13/16 of MGR_DB_RANK_LARGE (bits 16..23 of the reported tiers word; sort_big -- bits 8..15 --
+                              // counts those beyond 13/16 of MGR_DB_RANK_MAX: the caller skips the launch behind by the one that
                               // belongs to the instantiation it is going to ask for)
     uint32_t spare[45 - sizeof(MgrRep) / 4];
     uint32_t queue_giant;     // queue index of the first tile with fewer than 16384 pairs

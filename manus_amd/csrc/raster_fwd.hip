@@ -1475,7 +1475,7 @@ __global__ __launch_bounds__(RS_THREADS) __attribute__((amdgpu_waves_per_eu(DBS_
     }
     // full_runs == 2 (round 6): the launch behind k_dbin_rank -- it takes the items of more than min_keys keys, all of them, and
     // returns at once when the ranking kernel met none (MgrHeader::sort_huge: the usual case; sort_big also counts the items from
-    // three quarters of the limit on, which decide whether the caller may skip this launch next time)
+    // 13/16 of the limit on, which decide whether the caller may skip this launch next time)
     if (full_runs == 2 && hdr->sort_huge == 0u) return;
     constexpr uint32_t lds_keys = (uint32_t)LDS_KEYS;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
@@ -1585,11 +1585,12 @@ __global__ __launch_bounds__(DBR_THREADS) void k_dbin_rank(int N, int V, int ite
     if (e0 == 0u) return;                                             // no bucket starts in this item
     const uint32_t* st = db_start + (size_t)v * (MGR_DB_BUCKETS + 1);
     const uint32_t lo = st[~e0], hi = st[e1], n = hi - lo;
-    // counted from three quarters of a limit on (the launch behind is only skipped well clear of it) -- for BOTH instantiations,
+    // counted from 13/16 of a limit on (the launch behind is only skipped clear of it: a model under Adam moves a few keys per step
+    // between buckets, and the largest items of the bench scene's still model are 1531 .. 1575 keys) -- for BOTH instantiations,
     // whichever this one is: the caller picks the next forward's by sort_large and skips by the count that belongs to it
-    if (n > (uint32_t)MGR_DB_RANK_MAX * 3u / 4u && tid == 0) {
+    if (n > (uint32_t)MGR_DB_RANK_MAX * 13u / 16u && tid == 0) {
         atomicAdd(&hdr->sort_big, 1u);
-        if (n > (uint32_t)MGR_DB_RANK_LARGE * 3u / 4u) atomicAdd(&hdr->sort_near_large, 1u);
+        if (n > (uint32_t)MGR_DB_RANK_LARGE * 13u / 16u) atomicAdd(&hdr->sort_near_large, 1u);
         if (n > (uint32_t)MGR_DB_RANK_MAX) atomicAdd(&hdr->sort_large, 1u);
     }
     if (n > cap_keys) {
@@ -3492,7 +3493,7 @@ extern "C" int mgr_raster_status_tiers_sync(const void* workspace, int64_t* num_
     MGR_HIP(hipStreamSynchronize(stream));
     if (num_pairs) *num_pairs = h[0];
     if (overflow) *overflow = (int32_t)h[1];
-    if (tiers) {   // bits 0-1: binning tiers needed; bits 8..15 / 16..23: items of the instance sort beyond three quarters of
+    if (tiers) {   // bits 0-1: binning tiers needed; bits 8..15 / 16..23: items of the instance sort beyond 13/16 of
                    // MGR_DB_RANK_MAX / MGR_DB_RANK_LARGE keys (capped at 255); bits 24..30: items beyond MGR_DB_RANK_MAX keys (the
                    // next forward should ask for the large instantiation: debug bit 256)
         const uint32_t sb = h[offsetof(MgrHeader, sort_big) / 4], sn = h[offsetof(MgrHeader, sort_near_large) / 4], sl = h[offsetof(MgrHeader, sort_large) / 4];

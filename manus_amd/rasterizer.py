@@ -73,7 +73,7 @@ class RasterWorkspace:
         the device: a view that needs a skipped launch flags the forward, which is then run again with all of them)."""
         if self.tiers is None:
             return 0
-        # sort items of the previous forward beyond 3/4 of k_dbin_rank's small / large capacity, and beyond the small capacity
+        # sort items of the previous forward beyond 13/16 of k_dbin_rank's small / large capacity, and beyond the small capacity
         near_s, near_l, large = (self.tiers >> 8) & 0xFF, (self.tiers >> 16) & 0xFF, (self.tiers >> 24) & 0x7F
         near = near_l if large else near_s          # (the count that belongs to the instantiation this forward asks for)
         bits = (0 if self.tiers & 1 else 16) | (0 if self.tiers & 2 else 32) | (128 if near <= RasterWorkspace.SORT_BIG_MAX else 0) | (256 if large else 0)

@@ -42,7 +42,7 @@ def report(tag):
     rect = ws.buf[L["rect"]: L["rect"] + 8 * V * N].view(torch.int16).reshape(V, N, 4).cpu().numpy().astype(np.int64) & 0xFFFF
     vis = ((rect[..., 2] - rect[..., 0]) * (rect[..., 3] - rect[..., 1]) > 0)
     t = ws.tiers or 0
-    print("%s: sort items of the last forward beyond 3/4 of k_dbin_rank's small capacity: %d, of its large one: %d; beyond the small capacity: %d; "
+    print("%s: sort items of the last forward beyond 13/16 of k_dbin_rank's small capacity: %d, of its large one: %d; beyond the small capacity: %d; "
           "debug bits of the next forward: %d" % (tag, (t >> 8) & 0xFF, (t >> 16) & 0xFF, (t >> 24) & 0x7F, ws.skip_bits()))
     for v in range(V):
         z = depth[v][vis[v]]
@@ -53,8 +53,14 @@ def report(tag):
             row.append(int(np.bincount(np.minimum(((z - lo) * ((B - 1) / (hi - lo))).astype(np.int64), B - 1), minlength=B).max()))
             lz = np.log(z)
             row.append(int(np.bincount(np.minimum(((lz - lz.min()) * ((B - 1) / (lz.max() - lz.min()))).astype(np.int64), B - 1), minlength=B).max()))
-        print("  view %d: %6d visible, z in [%.4f, %.4f], 0.1 / 99.9 %%: [%.4f, %.4f] | largest bucket: 1024 lin %5d log %5d, 4096 lin %5d log %5d"
-              % (v, z.size, lo, hi, p[0], p[1], row[0], row[1], row[2], row[3]))
+        # the sort items of this view (1024 linear buckets, 768 keys per item: an item = the buckets whose first key lies in its range)
+        cnt = np.bincount(np.minimum(((z - lo) * (1023 / (hi - lo))).astype(np.int64), 1023), minlength=1024)
+        start = np.concatenate([[0], np.cumsum(cnt)])
+        first_item = start[:-1] // 768
+        sizes = np.bincount(first_item[cnt > 0], weights=cnt[cnt > 0]).astype(np.int64)
+        top = np.sort(sizes)[::-1][:4]
+        print("  view %d: %6d visible, z in [%.4f, %.4f], 0.1 / 99.9 %%: [%.4f, %.4f] | largest bucket: 1024 lin %5d log %5d, 4096 lin %5d log %5d | largest items %s"
+              % (v, z.size, lo, hi, p[0], p[1], row[0], row[1], row[2], row[3], top.tolist()))
 
 
 for _ in range(3):
