@@ -28,6 +28,7 @@
 #include <cstdlib>
 
 #define IL_T 128                    // threads
+#define IL_ACC_SLOTS 64             // slot triples the workgroups of k_image_loss add their fixed-point sums to
 #define IL_ND (2 * IL_T)            // 256 derivative positions, two per thread
 #define IL_H1 5                     // halo of the derivative maps
 #define IL_W (IL_ND - 2 * IL_H1)    // 246 outputs per workgroup and row
@@ -44,13 +45,22 @@ __global__ __launch_bounds__(IL_T) void k_image_loss(int H, int W, const float* 
                                                      const float* __restrict__ target, IlWindow win, float w_l1,
                                                      float w_ssim, float grad_scale, float* __restrict__ dL_dpred,
                                                      float2* __restrict__ partial, const uint32_t* __restrict__ work_list,
-                                                     const uint32_t* __restrict__ work_count, int gxb, int gyb) {
+                                                     const uint32_t* __restrict__ work_count, int gxb, int gyb,
+                                                     unsigned long long* __restrict__ acc_slots) {
     // channel-mixed statistics (5 x 3 rows of positions) and, later, the channel-mixed derivative
     // maps (3 x 3); .x = image row h0, .y = image row h0 + 1
     __shared__ v2f s_mix[5][3][IL_NX];
     __shared__ float s_red[4];
     const int tid = threadIdx.x;
     const uint32_t n_work = *work_count;
+    // The loss sums (round 6).  Thread 0 keeps the workgroup's sums of its spans as 64-bit FIXED-POINT integers (2^-32: integer
+    // addition is associative, so the total does not depend on which workgroup took which span or on the order the atomics land
+    // in -- the value is reproducible, as the fold over the per-span sums in index order was) and adds them to one of IL_ACC_SLOTS
+    // slot triples at its end (no return value, no fence: the kernel boundary orders them); k_image_loss_fold adds the slots and
+    // the spans the list pass finished (every pixel of those has SSIM 1 and no L1: all pixels minus the listed ones).  The fold
+    // over 34 560 per-span sums took 12 us between this kernel and the backward blend; over 64 slots it is a minimal launch.
+    long long acc_l1 = 0, acc_ss = 0;
+    unsigned long long acc_px = 0;
   for (uint32_t wi = blockIdx.x; wi < n_work; wi += gridDim.x) {   // the workgroups k_image_loss_scan found different
     const uint32_t bid = work_list[wi];
     const int bxi = (int)(bid % (uint32_t)gxb), byi = (int)((bid / (uint32_t)gxb) % (uint32_t)gyb), v = (int)(bid / (uint32_t)(gxb * gyb));
@@ -203,8 +213,20 @@ __global__ __launch_bounds__(IL_T) void k_image_loss(int H, int W, const float* 
         s_red[2 + (tid >> 6)] = ssim_sum;
     }
     __syncthreads();
-    if (tid == 0) partial[bid] = make_float2(s_red[0] + s_red[1], s_red[2] + s_red[3]);
+    if (tid == 0) {
+        const float pa = s_red[0] + s_red[1], pb = s_red[2] + s_red[3];
+        partial[bid] = make_float2(pa, pb);
+        acc_l1 += __double2ll_rn((double)pa * 4294967296.0);
+        acc_ss += __double2ll_rn((double)pb * 4294967296.0);
+        acc_px += (unsigned long long)((min((bxi + 1) * IL_W, W) - bxi * IL_W) * 3 * (row1 ? 2 : 1));
+    }
   }
+    if (tid == 0 && acc_px) {
+        unsigned long long* sl = acc_slots + 3 * (blockIdx.x & (IL_ACC_SLOTS - 1));
+        atomicAdd(sl, (unsigned long long)acc_l1);
+        atomicAdd(sl + 1, (unsigned long long)acc_ss);
+        atomicAdd(sl + 2, acc_px);
+    }
 }
 
 // Pass 1, almost no LDS, full occupancy.  Every (246 px x 2 rows) span whose rendered and target pixels are identical
@@ -456,79 +478,43 @@ __global__ __launch_bounds__(ILS_T) void k_image_loss_list_mapped(int H, int W, 
         if (my_rank[k] != 0xFFFFFFFFu) work_list[s_base + my_rank[k]] = my_bid[k];
 }
 
-// fold the per-workgroup sums: sums[0] = sum |pred - target|, sums[1] = sum of the SSIM map.
-// IL_FOLD_WGS workgroups take a fixed slice of the spans each (double sums in index order: the result does not depend on which
-// workgroup finishes when); the last one to finish -- a ticket in the word behind the work counter, no spinning -- adds the
-// slice sums in slice order and leaves both counters zero.  (One workgroup over all 34 560 spans of eight 1080p views took
-// 13.6 us between the loss kernel and the backward blend: five dependent rounds of loads.)
-#define IL_FOLD_WGS 32
-__global__ __launch_bounds__(1024) void k_image_loss_fold(int64_t n, const float2* __restrict__ partial,
-                                                          float* __restrict__ sums, float ca, float cb, float cc,
-                                                          uint32_t* __restrict__ work_count, double2* __restrict__ slice_sum) {
-    __shared__ double s_a[16], s_b[16];
-    __shared__ uint32_t s_ticket;
-    const int64_t per = (n + IL_FOLD_WGS - 1) / IL_FOLD_WGS;
-    const int64_t k_lo = (int64_t)blockIdx.x * per, k_hi = k_lo + per < n ? k_lo + per : n;
-    double a = 0.0, b = 0.0;
-    // eight loads in flight per thread, added in index order
-    for (int64_t k0 = k_lo + threadIdx.x; k0 < k_hi; k0 += 8 * 1024) {
-        float2 p[8];
+// the loss from the slot sums of k_image_loss: sums[0] = sum |pred - target|, sums[1] = sum of the SSIM map (the spans the list
+// pass finished contribute one per pixel and channel: total_px3 minus the listed ones), sums[2] = the caller's loss value
+__global__ __launch_bounds__(IL_ACC_SLOTS) void k_image_loss_fold(unsigned long long* __restrict__ acc_slots, long long total_px3,
+                                                                  float* __restrict__ sums, float ca, float cb, float cc,
+                                                                  uint32_t* __restrict__ work_count) {
+    __shared__ unsigned long long s_fin[3 * IL_ACC_SLOTS];
+    const int tid = threadIdx.x;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int64_t k = k0 + (int64_t)j * 1024;
-            p[j] = k < k_hi ? partial[k] : make_float2(0.f, 0.f);
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            if (k0 + (int64_t)j * 1024 < k_hi) {
-                a += (double)p[j].x;
-                b += (double)p[j].y;
-            }
-        }
-    }
-#pragma unroll
-    for (int dlt = 32; dlt > 0; dlt >>= 1) {
-        a += __shfl_xor(a, dlt, 64);
-        b += __shfl_xor(b, dlt, 64);
-    }
-    if ((threadIdx.x & 63) == 0) {
-        s_a[threadIdx.x >> 6] = a;
-        s_b[threadIdx.x >> 6] = b;
+    for (int q = 0; q < 3; ++q) {
+        s_fin[q * IL_ACC_SLOTS + tid] = acc_slots[3 * tid + q];
+        acc_slots[3 * tid + q] = 0ull;                          // left zero for the next call (a kept workspace needs no memset)
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double ta = 0.0, tb = 0.0;
-        for (int k = 0; k < 16; ++k) {
-            ta += s_a[k];
-            tb += s_b[k];
+    if (tid == 0) {
+        long long t_l1 = 0, t_ss = 0;
+        unsigned long long t_px = 0;
+        for (int k = 0; k < IL_ACC_SLOTS; ++k) {
+            t_l1 += (long long)s_fin[k];
+            t_ss += (long long)s_fin[IL_ACC_SLOTS + k];
+            t_px += s_fin[2 * IL_ACC_SLOTS + k];
         }
-        slice_sum[blockIdx.x] = make_double2(ta, tb);
-        __threadfence();                                        // the slice sum is out before the ticket is taken
-        s_ticket = atomicAdd(&work_count[1], 1u);
-    }
-    __syncthreads();
-    if (s_ticket != (uint32_t)gridDim.x - 1u) return;
-    if (threadIdx.x == 0) {                                     // the last workgroup: every slice sum is visible
-        __threadfence();
-        double ta = 0.0, tb = 0.0;
-        for (int k = 0; k < (int)gridDim.x; ++k) {
-            const volatile double* q = (const volatile double*)&slice_sum[k];
-            ta += q[0];
-            tb += q[1];
-        }
+        const double ta = (double)t_l1 * (1.0 / 4294967296.0);
+        const double tb = (double)t_ss * (1.0 / 4294967296.0) + (double)((unsigned long long)total_px3 - t_px);
         sums[0] = (float)ta;
         sums[1] = (float)tb;
         sums[2] = (float)((double)ca * ta + (double)cb * tb + (double)cc);  // the caller's loss value, no host-side arithmetic
-        work_count[0] = 0u;   // the list is consumed: a caller that keeps the workspace builds the next one without a memset
-        work_count[1] = 0u;   // (and the ticket counter)
+        *work_count = 0u;   // the list is consumed: a caller that keeps the workspace builds the next one without a memset
     }
 }
 
 static int64_t il_blocks(int V, int H, int W) { return (int64_t)V * ((H + 1) / 2) * ((W + IL_W - 1) / IL_W); }
 
+// byte offset of the sum slots (64-bit atomics: aligned) behind the per-span sums, the work list and the 256 bytes of counters
+static size_t il_slots_offset(int64_t nb) { return (((size_t)nb * (sizeof(float2) + sizeof(uint32_t)) + 256) + 63) & ~(size_t)63; }
 extern "C" size_t mgr_image_loss_workspace_bytes(int V, int H, int W) {
     if (V <= 0 || H <= 0 || W <= 0) return 0;
-    return (size_t)il_blocks(V, H, W) * (sizeof(float2) + sizeof(uint32_t)) + 256 + IL_FOLD_WGS * sizeof(double2);  // per-span sums | work list | counters | slice sums
+    return il_slots_offset(il_blocks(V, H, W)) + 3 * IL_ACC_SLOTS * sizeof(unsigned long long);  // per-span sums | work list | counters | sum slots
 }
 
 static int image_loss_impl(int V, int H, int W, const float* pred, const float* target, const float* bg3,
@@ -557,8 +543,9 @@ static int image_loss_impl(int V, int H, int W, const float* pred, const float* 
     uint32_t* work_list = (uint32_t*)((char*)workspace + (size_t)nb * sizeof(float2));
     uint32_t* work_count = (uint32_t*)((char*)workspace + (size_t)nb * (sizeof(float2) + sizeof(uint32_t)) + 64);
     if (W > ILS_MAXW) return mgr_fail(MGR_EINVAL, "mgr_image_loss: image wider than 16384");
-    double2* slice_sum = (double2*)((char*)workspace + (size_t)nb * (sizeof(float2) + sizeof(uint32_t)) + 256);
-    if (phase != 2 && !clean) MGR_HIP(hipMemsetAsync(work_count, 0, 8, stream));      // (work counter + the fold's ticket)
+    unsigned long long* acc_slots = (unsigned long long*)((char*)workspace + il_slots_offset(nb));
+    if (phase != 2 && !clean)      // (work counter and sum slots: a kept workspace leaves them zero itself)
+        MGR_HIP(hipMemsetAsync(work_count, 0, (size_t)((char*)(acc_slots + 3 * IL_ACC_SLOTS) - (char*)work_count), stream));
     if (phase == 2) {
     } else if (tile_start && tmap) {
         MGR_PROF("k_image_loss_list", stream);
@@ -582,10 +569,10 @@ static int image_loss_impl(int V, int H, int W, const float* pred, const float* 
         const int64_t pb = nb < IL_GRID ? nb : IL_GRID;   // persistent: 5 workgroups of 32 KB LDS per CU are resident
         hipLaunchKernelGGL(k_image_loss, dim3((unsigned)pb), dim3(IL_T), 0, stream, H, W, pred, target, win, w_l1, w_ssim,
                            grad_scale, dL_dpred, partial, (const uint32_t*)work_list, (const uint32_t*)work_count,
-                           (int)grid.x, (int)grid.y);
+                           (int)grid.x, (int)grid.y, acc_slots);
     }
-    hipLaunchKernelGGL(k_image_loss_fold, dim3(IL_FOLD_WGS), dim3(1024), 0, stream, il_blocks(V, H, W), (const float2*)workspace,
-                       sums, grad_scale * w_l1, -grad_scale * w_ssim, loss_offset, work_count, slice_sum);
+    hipLaunchKernelGGL(k_image_loss_fold, dim3(1), dim3(IL_ACC_SLOTS), 0, stream, acc_slots, (long long)V * H * W * 3,
+                       sums, grad_scale * w_l1, -grad_scale * w_ssim, loss_offset, work_count);
     MGR_LAUNCH_CHECK("k_image_loss", stream, 0);
     return MGR_OK;
 }
