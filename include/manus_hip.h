@@ -479,6 +479,14 @@ int mgr_image_loss_tiles_list_mapped(int V, int H, int W, const uint32_t* map, c
                                      void* workspace, size_t workspace_bytes, int workspace_kept, void* stream);
 /* workspace_kept != 0: the workspace was zero-filled when allocated and has only been used by list / finish pairs since (the
  * finish pass leaves its list counter zero): the 4-byte memset per call is skipped. */
+/* The same list built by the forward itself: attached to `raster_workspace`, the next forward (mgr_views_forward /
+ * mgr_raster_forward) that runs its blend on that workspace builds the list in extra workgroups of its last kernel, from
+ * its own tile offsets (one shot, like mgr_raster_set_status_mirror; map == NULL withdraws a pending attachment).
+ * `loss_workspace` must be a kept one (zero-filled once, only ever used by list / finish pairs: nothing is cleared here);
+ * mgr_image_loss_tiles_finish follows as after mgr_image_loss_tiles_list_mapped.  V, H, W must be the forward's.  (Round 6:
+ * as a launch of its own the list was 8 us in the chain of small kernels between the forward blend and the loss.) */
+int mgr_views_forward_attach_loss_list(const void* raster_workspace, int V, int H, int W, const uint32_t* map,
+                                       void* loss_workspace, size_t loss_workspace_bytes);
 int mgr_image_loss_tiles_finish(int V, int H, int W, const float* pred, const float* target, float w_l1, float w_ssim,
                                 float grad_scale, float loss_offset, float* dL_dpred, float* sums, void* workspace,
                                 size_t workspace_bytes, void* stream);

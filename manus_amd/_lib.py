@@ -92,6 +92,7 @@ SIGNATURES = {
     "mgr_image_loss_target_map_words": (c_sz, [c_int, c_int, c_int]),
     "mgr_image_loss_target_map": (c_int, [c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "mgr_image_loss_tiles_list_mapped": (c_int, [c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_sz, c_int, c_vp]),
+    "mgr_views_forward_attach_loss_list": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_sz]),
     "mgr_image_loss_tiles_list": (c_int, [c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "mgr_image_loss_tiles_finish": (c_int, [c_int, c_int, c_int, c_vp, c_vp, c_f32, c_f32, c_f32, c_f32, c_vp, c_vp, c_vp, c_sz,
                                             c_vp]),

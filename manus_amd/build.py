@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["raster_fwd.hip", "raster_bwd.hip", "lbs_sh.hip", "knn.hip", "image_loss.hip", "optim.hip", "contact.hip", "mesh.hip", "exchange.hip"]
-HEADERS = ["mgr_common.h", "instance_math.h", os.path.join("..", "..", "include", "manus_hip.h")]
+HEADERS = ["mgr_common.h", "instance_math.h", "il_list.h", os.path.join("..", "..", "include", "manus_hip.h")]
 # MGR_VARIANT=name builds an instrumented copy (libmanus_hip_<name>.so, objects under build_<name>/) next to the product
 # library; MANUS_HIP_VARIANT=name makes _lib load it (tools/instr only)
 VARIANT = os.environ.get("MGR_VARIANT", "")

@@ -25,13 +25,10 @@
 // statistics 5 beyond that), only the gradient is written.  The two loss sums are written per
 // workgroup and folded by a second tiny kernel: no float atomics, the loss value is reproducible.
 #include "mgr_common.h"
+#include "il_list.h"                // IL_T, IL_ND, IL_H1, IL_W, ILS_T, ILS_MAXW, ILM_R, il_blocks, the mapped list's workgroup
 #include <cstdlib>
 
-#define IL_T 128                    // threads
 #define IL_ACC_SLOTS 64             // slot triples the workgroups of k_image_loss add their fixed-point sums to
-#define IL_ND (2 * IL_T)            // 256 derivative positions, two per thread
-#define IL_H1 5                     // halo of the derivative maps
-#define IL_W (IL_ND - 2 * IL_H1)    // 246 outputs per workgroup and row
 #define IL_NX (IL_ND + 2 * IL_H1)   // 266 staged positions
 
 struct IlWindow {
@@ -236,8 +233,6 @@ __global__ __launch_bounds__(IL_T) void k_image_loss(int H, int W, const float* 
 // spans are appended to the work list of k_image_loss.
 // One workgroup takes a whole pair of image rows: 16-byte loads along w (W % 4 == 0; otherwise dwords) mark the
 // pixels that differ in a bitmap, the spans are classified from the bitmap, zeros are written with 16-byte stores.
-#define ILS_T 256
-#define ILS_MAXW 16384
 __global__ __launch_bounds__(ILS_T) void k_image_loss_scan(int H, int W, int gxb, const float* __restrict__ pred,
                                                            const float* __restrict__ target, float* __restrict__ dL_dpred,
                                                            float2* __restrict__ partial, uint32_t* __restrict__ work_list,
@@ -431,51 +426,9 @@ __global__ __launch_bounds__(ILS_T) void k_image_loss_list(int H, int W, int gxb
 // (row pair, span), ILM_R row pairs per workgroup -- the list kernel above spends its time on one returning atomic per row
 // pair, all on one counter (4320 of them at 8 views of 1080p: 31 us for a few kilobytes of work); here a workgroup
 // collects its listed spans in LDS and takes ONE slot range.
-#define ILM_R 8
-__global__ __launch_bounds__(ILS_T) void k_image_loss_list_mapped(int H, int W, int gxb, int HP, const uint32_t* __restrict__ tmap,
-                                                                  const uint32_t* __restrict__ tile_start,
-                                                                  float2* __restrict__ partial, uint32_t* __restrict__ work_list,
-                                                                  uint32_t* __restrict__ work_count) {
-    __shared__ uint32_t s_n, s_base;
-    const int tid = threadIdx.x, v = blockIdx.y;
-    if (tid == 0) s_n = 0;
-    __syncthreads();
-    const int nwords = (W + 31) / 32;
-    const int gxt = (W + 15) / 16, T = gxt * ((H + 15) / 16);
-    const int n_items = ILM_R * gxb;
-    constexpr int PER = (ILM_R * ((ILS_MAXW + IL_W - 1) / IL_W) + ILS_T - 1) / ILS_T;
-    uint32_t my_rank[PER], my_bid[PER];
-    int nmine = 0;
-    for (int it = tid; it < n_items; it += ILS_T, ++nmine) {
-        const int rp = blockIdx.x * ILM_R + it / gxb, b = it % gxb;
-        my_rank[nmine] = 0xFFFFFFFFu;
-        my_bid[nmine] = 0;
-        if (rp >= HP) continue;
-        const int h0 = rp * 2, rows = h0 + 1 < H ? 2 : 1;
-        const uint32_t* trow = tile_start + (size_t)v * T + (size_t)(h0 >> 4) * gxt;
-        const int lo = max(b * IL_W - 2 * IL_H1, 0), hi = min(b * IL_W + IL_ND, W);  // [lo, hi)
-        uint32_t any = trow[((hi - 1) >> 4) + 1] == trow[lo >> 4] ? 0u : 1u;   // some tile under the span holds Gaussians
-        const uint32_t* mrow = tmap + ((size_t)v * HP + rp) * (size_t)nwords;
-        for (int k = lo >> 5; k <= (hi - 1) >> 5 && !any; ++k) {
-            uint32_t m = mrow[k];
-            const int base = k << 5;
-            if (lo > base) m &= ~0u << (lo - base);
-            if (hi < base + 32) m &= ~0u >> (base + 32 - hi);
-            any |= m;
-        }
-        const uint32_t bid = ((uint32_t)v * (uint32_t)HP + (uint32_t)rp) * (uint32_t)gxb + (uint32_t)b;
-        my_bid[nmine] = bid;
-        if (any) my_rank[nmine] = atomicAdd(&s_n, 1u);
-        else {
-            const int wcnt = min((b + 1) * IL_W, W) - b * IL_W;
-            partial[bid] = make_float2(0.f, (float)(wcnt * 3 * rows));
-        }
-    }
-    __syncthreads();
-    if (tid == 0 && s_n) s_base = atomicAdd(work_count, s_n);
-    __syncthreads();
-    for (int k = 0; k < nmine; ++k)
-        if (my_rank[k] != 0xFFFFFFFFu) work_list[s_base + my_rank[k]] = my_bid[k];
+__global__ __launch_bounds__(ILS_T) void k_image_loss_list_mapped(IlListArgs a) {
+    __shared__ uint32_t s2[2];
+    il_list_mapped_block(a, (int)blockIdx.x, (int)blockIdx.y, s2);
 }
 
 // the loss from the slot sums of k_image_loss: sums[0] = sum |pred - target|, sums[1] = sum of the SSIM map (the spans the list
@@ -508,7 +461,6 @@ __global__ __launch_bounds__(IL_ACC_SLOTS) void k_image_loss_fold(unsigned long 
     }
 }
 
-static int64_t il_blocks(int V, int H, int W) { return (int64_t)V * ((H + 1) / 2) * ((W + IL_W - 1) / IL_W); }
 
 // byte offset of the sum slots (64-bit atomics: aligned) behind the per-span sums, the work list and the 256 bytes of counters
 static size_t il_slots_offset(int64_t nb) { return (((size_t)nb * (sizeof(float2) + sizeof(uint32_t)) + 256) + 63) & ~(size_t)63; }
@@ -549,8 +501,8 @@ static int image_loss_impl(int V, int H, int W, const float* pred, const float* 
     if (phase == 2) {
     } else if (tile_start && tmap) {
         MGR_PROF("k_image_loss_list", stream);
-        hipLaunchKernelGGL(k_image_loss_list_mapped, dim3((grid.y + ILM_R - 1) / ILM_R, V), dim3(ILS_T), 0, stream, H, W, (int)grid.x,
-                           (int)grid.y, tmap, tile_start, partial, work_list, work_count);
+        const IlListArgs la = il_list_args(V, H, W, tmap, tile_start, workspace);
+        hipLaunchKernelGGL(k_image_loss_list_mapped, dim3((unsigned)la.nbx, V), dim3(ILS_T), 0, stream, la);
     } else if (tile_start) {
         MGR_PROF("k_image_loss_list", stream);
         hipLaunchKernelGGL(k_image_loss_list, dim3(grid.y, V), dim3(ILS_T), 0, stream, H, W, (int)grid.x, target, bg3, tile_start,

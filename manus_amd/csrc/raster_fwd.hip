@@ -18,6 +18,7 @@
 #include <mutex>
 
 #include "instance_math.h"
+#include "il_list.h"
 
 #include <cstdlib>
 #include <cstring>
@@ -2950,8 +2951,13 @@ __global__ __launch_bounds__(256) void k_fwd_items(const uint4* __restrict__ til
                                                    float cut_range, float cut_rel, int gx, int interior_only,
                                                    const uint32_t* __restrict__ tile_queue, int VT, unsigned char* __restrict__ tile_bgok,
                                                    const float* out_color, const float* __restrict__ bg, const MgrRep rep, uint32_t cut_penalty,
-                                                   uint32_t* __restrict__ tile_zwin) {
+                                                   uint32_t* __restrict__ tile_zwin, const IlListArgs ll, int n_item_blocks) {
     __shared__ uint32_t s_scan[8];
+    if ((int)blockIdx.x >= n_item_blocks) {      // the workgroups behind the items': the span list of the image loss (il_list.h), when attached
+        const int lb = (int)blockIdx.x - n_item_blocks;
+        il_list_mapped_block(ll, lb % ll.nbx, lb / ll.nbx, s_scan);
+        return;
+    }
     __shared__ uint32_t s_base;
     __shared__ uint32_t s_run[257];
     __shared__ uint4 s_qr[256], s_qd[256], s_rp[256];
@@ -2961,7 +2967,7 @@ __global__ __launch_bounds__(256) void k_fwd_items(const uint4* __restrict__ til
     // the forward's last kernel publishes the depth-cut flags (tile scan + blend) and consumes them -- by the LAST workgroup of the
     // grid, which has no tiles of the queue when the frame has empty tiles (the system-scope fence of the status mirror then waits
     // beside the others' work instead of in front of workgroup 0's)
-    if (blockIdx.x == gridDim.x - 1 && tid == 0) {
+    if ((int)blockIdx.x == n_item_blocks - 1 && tid == 0) {
         const uint32_t f = hdr->acc_flags;
         uint32_t ovf = hdr->overflow;
         if (f) { ovf |= f; hdr->overflow = ovf; hdr->acc_flags = 0u; }
@@ -2974,7 +2980,7 @@ __global__ __launch_bounds__(256) void k_fwd_items(const uint4* __restrict__ til
     }
     // "image kept": the image of this forward is complete behind this kernel -- its empty tiles hold the background (written
     // by the fill or left from the image before), the header names the image and the colour
-    for (uint32_t q = hdr->queue_len + blockIdx.x * 256u + (uint32_t)tid; q < (uint32_t)VT; q += gridDim.x * 256u) tile_bgok[tile_queue[q]] = 1;
+    for (uint32_t q = hdr->queue_len + blockIdx.x * 256u + (uint32_t)tid; q < (uint32_t)VT; q += (uint32_t)n_item_blocks * 256u) tile_bgok[tile_queue[q]] = 1;
     if (blockIdx.x == 0 && tid == 0) {
         const unsigned long long owner = (unsigned long long)(uintptr_t)out_color;
         hdr->img_seq = hdr->fwd_seq;
@@ -3117,6 +3123,39 @@ static uint32_t* mgr_take_status_mirror(const void* workspace) {
         if (m.ws == workspace) { uint32_t* p = m.dev; m.ws = nullptr; m.dev = nullptr; return p; }
     return nullptr;
 }
+// The span list of the image loss, attached to the next forward that runs its last kernel on `workspace` (one shot, like the
+// status mirror): k_fwd_items' launch then carries the list's workgroups (il_list.h) -- the list needs the forward's tile offsets
+// only, and as a launch of its own it was 8 us of the chain of small kernels between the forward blend and the loss.
+static struct { const void* ws; IlListArgs a; } g_loss_list[64];
+static IlListArgs mgr_take_loss_list(const void* workspace) {
+    std::lock_guard<std::mutex> lk(g_mirror_mu);
+    for (auto& m : g_loss_list)
+        if (m.ws == workspace) { IlListArgs a = m.a; m.ws = nullptr; return a; }
+    IlListArgs none;
+    memset(&none, 0, sizeof(none));
+    return none;
+}
+extern "C" int mgr_views_forward_attach_loss_list(const void* workspace, int V, int H, int W, const uint32_t* target_map,
+                                                  void* loss_workspace, size_t loss_workspace_bytes) {
+    if (!workspace) return mgr_fail(MGR_EINVAL, "mgr_views_forward_attach_loss_list: null workspace");
+    std::lock_guard<std::mutex> lk(g_mirror_mu);
+    int free_slot = -1;
+    for (int k = 0; k < 64; ++k) {
+        if (g_loss_list[k].ws == workspace) { free_slot = k; break; }
+        if (!g_loss_list[k].ws && free_slot < 0) free_slot = k;
+    }
+    if (!target_map) {      // withdraw
+        if (free_slot >= 0 && g_loss_list[free_slot].ws == workspace) g_loss_list[free_slot].ws = nullptr;
+        return MGR_OK;
+    }
+    if (V <= 0 || H <= 0 || W <= 0 || W > ILS_MAXW || !loss_workspace) return mgr_fail(MGR_EINVAL, "mgr_views_forward_attach_loss_list: bad arguments");
+    if (loss_workspace_bytes < (size_t)il_blocks(V, H, W) * 12 + 256) return mgr_fail(MGR_ENOMEM, "mgr_views_forward_attach_loss_list: loss workspace too small");
+    if (free_slot < 0) return mgr_fail(MGR_ENOMEM, "mgr_views_forward_attach_loss_list: too many pending lists");
+    g_loss_list[free_slot].ws = workspace;
+    g_loss_list[free_slot].a = il_list_args(V, H, W, target_map, nullptr, loss_workspace);
+    return MGR_OK;
+}
+
 extern "C" int mgr_raster_set_status_mirror(const void* workspace, void* host_words) {
     if (!workspace) return mgr_fail(MGR_EINVAL, "mgr_raster_set_status_mirror: null workspace");
     void* dev = nullptr;
@@ -3388,13 +3427,20 @@ static int raster_forward_impl(int V, int N, int W, int H, const float* cams, co
                              (uint32_t*)(ws + L.tile_qdone), (float4*)(ws + L.ckpt)); }
         MGR_LAUNCH_CHECK("k_repair_blend", stream, debug);
     }
-    { MGR_PROF("k_fwd_items", stream); hipLaunchKernelGGL(k_fwd_items, dim3((VT + 255) / 256), dim3(256), 0, stream, (const uint4*)(ws + L.tile_qrec),
+    // the span list of the image loss rides on this launch when the caller attached one (mgr_views_forward_attach_loss_list)
+    IlListArgs ll = mgr_take_loss_list(workspace);
+    if (ll.nbx) {
+        if (ll.H != H || ll.W != W || ll.list_views != V) return mgr_fail(MGR_EINVAL, "attached loss list: views or image size differ from the forward's");
+        ll.tile_start = tile_start;
+    }
+    const int n_item_blocks = (VT + 255) / 256;
+    { MGR_PROF("k_fwd_items", stream); hipLaunchKernelGGL(k_fwd_items, dim3((unsigned)(n_item_blocks + ll.nbx * V)), dim3(256), 0, stream, (const uint4*)(ws + L.tile_qrec),
                        (const uint32_t*)(ws + L.tile_qdone), (uint32_t*)(ws + L.tile_done), (uint4*)(ws + L.items), hdr,
                        N, T, (const uint32_t*)(ws + L.sorted_gid), (const float*)(ws + L.depth), (const uint32_t*)(ws + L.tile_zused),
                        (const uint32_t*)(ws + L.tile_qend), (uint32_t*)(ws + L.tile_zcut), mgr_take_status_mirror(workspace),
                        g_cut_frac, (uint32_t)g_cut_min, g_cut_range, g_cut_rel, gx, g_cut_interior,
                        (const uint32_t*)(ws + L.tile_queue), VT, (unsigned char*)(ws + L.tile_bgok), (const float*)out_color, bg, rep_all,
-                       (uint32_t)g_cut_penalty, (uint32_t*)(ws + L.tile_zwin)); }
+                       (uint32_t)g_cut_penalty, (uint32_t*)(ws + L.tile_zwin), ll, n_item_blocks); }
     MGR_LAUNCH_CHECK("k_blend_fwd", stream, debug);
     return MGR_OK;
 }

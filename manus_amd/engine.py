@@ -404,6 +404,8 @@ class HipViewCompute:
         # 1080p view) and the list is built from them, in-stream, in a few microseconds -- no second stream, no forward
         # split at the blend.  Same list, same loss and gradients.  MANUS_TARGET_MAP=0 switches it off for A/B runs.
         self.target_map, self._tmaps, self._lws = os.environ.get("MANUS_TARGET_MAP", "1") != "0", {}, {}
+        # the mapped span list built by the forward's last kernel (mgr_views_forward_attach_loss_list) instead of a launch of its own (A/B: 0)
+        self.attach_list = os.environ.get("MANUS_LOSS_LIST_ATTACH", "1") != "0"
         # sh_storage "fp16" (BASELINE config 5): the fused kernels read an fp16 copy of _features_rest (96 B instead of
         # 180 B per Gaussian and view group); arithmetic, gradients and the optimizer's master copy stay fp32.  The copy
         # is refreshed lazily after the leaves changed (`mark_params_changed`).  The reference has no fp16 mode:
@@ -747,8 +749,31 @@ class HipViewCompute:
             if own is not None:
                 self._pimg_ws = ws
 
+        # mapped: the span list of the loss is built by the forward itself (extra workgroups of its last kernel, attached per launch)
+        lws = tmap = None
+        lnbytes = 0
+        if mapped:
+            lnbytes = int(lib().mgr_image_loss_workspace_bytes(V, H, W))
+            lws = self._lws.get((V, H, W))      # kept across steps, zero-filled once: list / finish pairs leave it clean
+            if lws is None:
+                lws = self._lws[(V, H, W)] = torch.zeros(lnbytes, dtype=torch.uint8, device=dev)
+            tmap = self._target_map(view_ids, sel, bg)
+        launches = [0]
+
         def launch(ws):
             self._cut_bit = self._cut_flag(ws, view_ids, V, N, W, H)
+            if mapped and self.attach_list:
+                if launches[0]:          # a forward of this step ran before (capacity / tier retry): its list was never finished
+                    lws.zero_()
+                launches[0] += 1
+                check(lib().mgr_views_forward_attach_loss_list(ptr(ws.buf), V, H, W, ptr(tmap), ptr(lws), lnbytes),
+                      "mgr_views_forward_attach_loss_list")
+                try:
+                    fwd(ws, 0)
+                except Exception:        # (a forward that failed before its last kernel leaves the attachment pending: withdraw it)
+                    lib().mgr_views_forward_attach_loss_list(ptr(ws.buf), V, H, W, None, None, 0)
+                    raise
+                return
             fwd(ws, 2 if overlap else 0)
 
         ctx = self.rz.context(dev)
@@ -757,17 +782,14 @@ class HipViewCompute:
             if not overlap and ctx.fenced(self.sync_check):
                 ctx.fence(ws)
             if mapped:
-                import ctypes
                 tgt = sel["targets"]
-                nbytes = int(lib().mgr_image_loss_workspace_bytes(V, H, W))
-                lws = self._lws.get((V, H, W))      # kept across steps, zero-filled once: list / finish pairs leave it clean
-                if lws is None:
-                    lws = self._lws[(V, H, W)] = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+                nbytes = lnbytes
                 g_img = torch.empty_like(out)
                 sums = torch.empty(3, dtype=torch.float32, device=dev)
-                check(lib().mgr_image_loss_tiles_list_mapped(V, H, W, ptr(self._target_map(view_ids, sel, bg)), ptr(bg),
-                                                             ctypes.c_void_p(self._tile_start_ptr(ws, V, N, W, H)),
-                                                             ptr(lws), nbytes, 1, stream()), "mgr_image_loss_tiles_list_mapped")
+                if not self.attach_list:
+                    import ctypes
+                    check(lib().mgr_image_loss_tiles_list_mapped(V, H, W, ptr(tmap), ptr(bg), ctypes.c_void_p(self._tile_start_ptr(ws, V, N, W, H)),
+                                                                 ptr(lws), nbytes, 1, stream()), "mgr_image_loss_tiles_list_mapped")
                 per_view = out[0].numel()
                 k = self.loss_weight * scale / per_view
                 const = self.w_ssim * self.loss_weight * scale * V
